@@ -1,0 +1,269 @@
+"""ctypes binding of the C ABI in include/amico_amd.h (amico_amd/csrc/libamico_amd.so).
+
+There is NO CPU fallback: if the HIP library is missing or no gfx950 GPU is visible every
+entry point raises.  Device memory for the ``*_device`` calls is plain pointers (e.g.
+``torch.Tensor.data_ptr()``) -- torch is plumbing, never part of the signatures.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libamico_amd.so')
+
+AMX_OK, AMX_E_BADARG, AMX_E_HIP, AMX_E_DIR_OOB, AMX_E_OVERFLOW, AMX_E_NODEVICE = 0, -1, -2, -3, -4, -5
+F_RMSE, F_NRMSE, F_MODULATED, F_CORRECTED = 1, 2, 4, 8
+
+# every symbol include/amico_amd.h declares (tests check that the library exports them all)
+SYMBOLS = ['amx_version', 'amx_ctx_create', 'amx_ctx_destroy', 'amx_last_error',
+           'amx_lut_upload_noddi', 'amx_lut_upload_freewater', 'amx_lut_upload_sandi', 'amx_lut_destroy',
+           'amx_dir_to_lut_idx', 'amx_noddi_fit', 'amx_freewater_fit', 'amx_sandi_fit',
+           'amx_noddi_fit_device', 'amx_freewater_fit_device', 'amx_sandi_fit_device', 'amx_sync_status',
+           'amx_set_profiling', 'amx_last_kernel_ms', 'amx_last_stats', 'amx_selftest', 'amx_debug_trace']
+
+_lib = None
+c_vp, c_dp, c_fp = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float)
+c_i16p, c_i32p, c_i64p = C.POINTER(C.c_int16), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+
+
+class AmxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+def lib():
+    """Load libamico_amd.so (fails loudly when the HIP extension has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f'amico_amd: HIP library {LIB_PATH} not found -- run `python -c "import '
+                           f'__graft_entry__ as g; g.build()"` (or `make -C amico_amd/csrc -j`). '
+                           f'There is no CPU fallback.')
+    L = C.CDLL(LIB_PATH)
+    L.amx_version.restype = C.c_int
+    L.amx_ctx_create.argtypes = [C.c_int, C.POINTER(c_vp)]
+    L.amx_ctx_destroy.argtypes = [c_vp]
+    L.amx_ctx_destroy.restype = None
+    L.amx_last_error.argtypes = [c_vp]
+    L.amx_last_error.restype = C.c_char_p
+    L.amx_lut_upload_noddi.argtypes = [c_vp, c_fp, c_fp, c_dp, c_fp, c_fp, c_i16p, c_i64p, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, C.POINTER(c_vp)]
+    L.amx_lut_upload_freewater.argtypes = [c_vp, c_fp, c_fp, c_i16p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.POINTER(c_vp)]
+    L.amx_lut_upload_sandi.argtypes = [c_vp, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.POINTER(c_vp)]
+    L.amx_lut_destroy.argtypes = [c_vp]
+    L.amx_lut_destroy.restype = None
+    L.amx_dir_to_lut_idx.argtypes = [c_vp, c_vp, c_dp, C.c_int64, c_i32p]
+    L.amx_noddi_fit.argtypes = [c_vp, c_vp, c_dp, c_dp, C.c_int64, C.c_double, C.c_double, C.c_uint,
+                                c_dp, c_dp, c_dp, c_dp]
+    L.amx_freewater_fit.argtypes = [c_vp, c_vp, c_dp, c_dp, C.c_int64, C.c_double, C.c_double, C.c_int,
+                                    C.c_uint, c_dp, c_dp, c_dp, c_dp]
+    L.amx_sandi_fit.argtypes = [c_vp, c_vp, c_dp, C.c_int64, C.c_double, C.c_double, C.c_uint, c_dp, c_dp, c_dp]
+    L.amx_noddi_fit_device.argtypes = [c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_double, C.c_double, C.c_uint,
+                                       c_vp, c_vp, c_vp, c_vp, c_vp]
+    L.amx_freewater_fit_device.argtypes = [c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_double, C.c_double, C.c_int,
+                                           C.c_uint, c_vp, c_vp, c_vp, c_vp, c_vp]
+    L.amx_sandi_fit_device.argtypes = [c_vp, c_vp, c_vp, C.c_int64, C.c_double, C.c_double, C.c_uint,
+                                       c_vp, c_vp, c_vp, c_vp]
+    L.amx_sync_status.argtypes = [c_vp, c_vp]
+    L.amx_set_profiling.argtypes = [c_vp, C.c_int]
+    L.amx_last_kernel_ms.argtypes = [c_vp, C.c_int, C.POINTER(C.c_float)]
+    L.amx_last_stats.argtypes = [c_vp, c_i64p]
+    L.amx_selftest.argtypes = [c_vp, c_dp]
+    L.amx_debug_trace.argtypes = [c_vp, c_i32p]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int and name not in ('amx_version',):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(ct) if a is not None else None
+
+
+class Context:
+    """amx_ctx: one per process and GPU."""
+
+    def __init__(self, device=-1):
+        self._h = c_vp()
+        rc = lib().amx_ctx_create(int(device), C.byref(self._h))
+        if rc != AMX_OK:
+            self._h = None
+            raise AmxError(rc, 'amico_amd: no usable MI355X (gfx950) device -- the fit path has no CPU fallback'
+                           if rc == AMX_E_NODEVICE else f'amx_ctx_create failed ({rc})')
+
+    def close(self):
+        if getattr(self, '_h', None):
+            lib().amx_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc == AMX_OK:
+            return
+        msg = lib().amx_last_error(self._h).decode('utf-8', 'replace')
+        if rc == AMX_E_BADARG:
+            raise ValueError(msg or 'bad argument')
+        raise AmxError(rc, msg or f'amico_amd error {rc}')       # RuntimeError, like lut.pyx:352-354
+
+    def sync(self, stream=None):
+        self.check(lib().amx_sync_status(self._h, c_vp(stream or 0)))
+
+    def set_profiling(self, on=True):
+        self.check(lib().amx_set_profiling(self._h, int(bool(on))))
+
+    def last_kernel_ms(self, which=0):
+        ms = C.c_float()
+        self.check(lib().amx_last_kernel_ms(self._h, int(which), C.byref(ms)))
+        return ms.value
+
+    def last_stats(self):
+        out = (C.c_int64 * 4)()
+        self.check(lib().amx_last_stats(self._h, out))
+        return {'rerun_voxels': out[0], 'itercap_voxels': out[1], 'overflow_voxels': out[2],
+                'guard_trips': out[3] >> 32, 'guard_last': out[3] & 0xffffffff}
+
+    def selftest(self):
+        out = np.zeros((8, 64))
+        self.check(lib().amx_selftest(self._h, _p(out, c_dp)))
+        return out
+
+
+class Lut:
+    """amx_lut: device-resident dictionary."""
+
+    def __init__(self, ctx, handle, model, nS, n_maps=None):
+        self.ctx, self._h, self.model, self.nS = ctx, handle, model, nS
+
+    def close(self):
+        if getattr(self, '_h', None) and getattr(self.ctx, '_h', None):
+            lib().amx_lut_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def upload_noddi(ctx, kernels, htable, dwi_idx, is_exvivo=False):
+    wm = np.ascontiguousarray(kernels['wm'], dtype=np.float32)
+    if wm.ndim != 3:
+        raise ValueError("KERNELS['wm'] must be [n_wm, ndirs, nS]")
+    n_wm, ndirs, nS = wm.shape
+    iso = np.ascontiguousarray(kernels['iso'], dtype=np.float32)
+    norms = np.ascontiguousarray(kernels['norms'], dtype=np.float64)
+    icvf = np.ascontiguousarray(kernels['icvf'], dtype=np.float32)
+    kappa = np.ascontiguousarray(kernels['kappa'], dtype=np.float32)
+    ht = np.ascontiguousarray(htable, dtype=np.int16)
+    dwi = np.ascontiguousarray(dwi_idx, dtype=np.int64)
+    if iso.shape != (nS,) or icvf.shape != (n_wm,) or kappa.shape != (n_wm,) or ht.size != 181 * 181 \
+            or norms.shape != (len(dwi), n_wm):
+        raise ValueError('NODDI KERNELS / htable have inconsistent shapes')
+    h = c_vp()
+    ctx.check(lib().amx_lut_upload_noddi(ctx._h, _p(wm, c_fp), _p(iso, c_fp), _p(norms, c_dp), _p(icvf, c_fp),
+                                         _p(kappa, c_fp), _p(ht, c_i16p), _p(dwi, c_i64p), n_wm, ndirs, nS,
+                                         len(dwi), int(bool(is_exvivo)), C.byref(h)))
+    return Lut(ctx, h, 'NODDI', nS)
+
+
+def upload_freewater(ctx, kernels, htable):
+    D = np.ascontiguousarray(kernels['D'], dtype=np.float32)
+    CSF = np.ascontiguousarray(kernels['CSF'], dtype=np.float32)
+    if D.ndim != 3 or CSF.ndim != 2 or CSF.shape[1] != D.shape[2]:
+        raise ValueError('FreeWater KERNELS have inconsistent shapes')
+    ht = np.ascontiguousarray(htable, dtype=np.int16)
+    if ht.size != 181 * 181:
+        raise ValueError('htable must have 181*181 entries')
+    h = c_vp()
+    ctx.check(lib().amx_lut_upload_freewater(ctx._h, _p(D, c_fp), _p(CSF, c_fp), _p(ht, c_i16p), D.shape[0],
+                                             CSF.shape[0], D.shape[1], D.shape[2], C.byref(h)))
+    return Lut(ctx, h, 'FreeWater', D.shape[2])
+
+
+def upload_sandi(ctx, kernels, Rs, d_in, d_isos):
+    sig = np.asfortranarray(kernels['signal'], dtype=np.float64)
+    norms = np.ascontiguousarray(kernels['norms'], dtype=np.float64)
+    Rs = np.ascontiguousarray(Rs, dtype=np.float64)
+    d_in = np.ascontiguousarray(d_in, dtype=np.float64)
+    d_isos = np.ascontiguousarray(d_isos, dtype=np.float64)
+    nS, n_atoms = sig.shape
+    if n_atoms != len(Rs) + len(d_in) + len(d_isos) or norms.shape != (n_atoms,):
+        raise ValueError('SANDI KERNELS have inconsistent shapes')
+    h = c_vp()
+    ctx.check(lib().amx_lut_upload_sandi(ctx._h, _p(sig, c_dp), _p(norms, c_dp), _p(Rs, c_dp), _p(d_in, c_dp),
+                                         _p(d_isos, c_dp), nS, len(Rs), len(d_in), len(d_isos), C.byref(h)))
+    return Lut(ctx, h, 'SANDI', nS)
+
+
+def _check_y(y, nS):
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    if y.ndim != 2 or y.shape[1] != nS:
+        raise ValueError(f'y must be [n_vox, {nS}] float64')
+    return y
+
+
+def _check_dirs(dirs, n):
+    dirs = np.ascontiguousarray(dirs, dtype=np.float64)      # a copy is never modified (lut.pyx:335-338 quirk)
+    if dirs.shape != (n, 3):
+        raise ValueError('DIRs must be [n_vox, 3]')
+    return dirs
+
+
+def noddi_fit(ctx, lut, y, dirs, lambda1, lambda2, n_maps, rmse=False, nrmse=False, mod=False):
+    y = _check_y(y, lut.nS)
+    n = y.shape[0]
+    dirs = _check_dirs(dirs, n)
+    flags = (F_RMSE if rmse else 0) | (F_NRMSE if nrmse else 0) | (F_MODULATED if mod else 0)
+    est = np.zeros((n, n_maps), dtype=np.float64, order='C')
+    r = np.zeros(n) if rmse else None
+    nr = np.zeros(n) if nrmse else None
+    md = np.zeros((n, 2), dtype=np.float64, order='C') if mod else None
+    ctx.check(lib().amx_noddi_fit(ctx._h, lut._h, _p(y, c_dp), _p(dirs, c_dp), n, float(lambda1), float(lambda2),
+                                  flags, _p(est, c_dp), _p(r, c_dp), _p(nr, c_dp), _p(md, c_dp)))
+    return est, r, nr, md
+
+
+def freewater_fit(ctx, lut, y, dirs, lambda1, lambda2, is_mouse, rmse=False, nrmse=False, corrected=False):
+    y = _check_y(y, lut.nS)
+    n = y.shape[0]
+    dirs = _check_dirs(dirs, n)
+    flags = (F_RMSE if rmse else 0) | (F_NRMSE if nrmse else 0) | (F_CORRECTED if corrected else 0)
+    est = np.zeros((n, 4 if is_mouse else 2), dtype=np.float64, order='C')
+    r = np.zeros(n) if rmse else None
+    nr = np.zeros(n) if nrmse else None
+    yc = np.zeros((n, lut.nS), dtype=np.float64, order='C') if corrected else None
+    ctx.check(lib().amx_freewater_fit(ctx._h, lut._h, _p(y, c_dp), _p(dirs, c_dp), n, float(lambda1),
+                                      float(lambda2), int(bool(is_mouse)), flags, _p(est, c_dp), _p(r, c_dp),
+                                      _p(nr, c_dp), _p(yc, c_dp)))
+    return est, r, nr, yc
+
+
+def sandi_fit(ctx, lut, y, lambda1, lambda2, rmse=False, nrmse=False):
+    y = _check_y(y, lut.nS)
+    n = y.shape[0]
+    flags = (F_RMSE if rmse else 0) | (F_NRMSE if nrmse else 0)
+    est = np.zeros((n, 6), dtype=np.float64, order='C')
+    r = np.zeros(n) if rmse else None
+    nr = np.zeros(n) if nrmse else None
+    ctx.check(lib().amx_sandi_fit(ctx._h, lut._h, _p(y, c_dp), n, float(lambda1), float(lambda2), flags,
+                                  _p(est, c_dp), _p(r, c_dp), _p(nr, c_dp)))
+    return est, r, nr
+
+
+def dir_to_lut_idx(ctx, lut, dirs):
+    dirs = np.ascontiguousarray(np.atleast_2d(dirs), dtype=np.float64)
+    out = np.zeros(dirs.shape[0], dtype=np.int32)
+    ctx.check(lib().amx_dir_to_lut_idx(ctx._h, lut._h, _p(dirs, c_dp), dirs.shape[0], _p(out, c_i32p)))
+    return out

@@ -1,0 +1,564 @@
+// amx_api.hip -- C ABI (include/amico_amd.h) of the MI355X-native AMICO fitter.
+// Host side only drives HIP: workspace, dictionary upload, kernel launches, status.
+#include "amx_host.hpp"
+#include "amx_prep.hpp"
+
+using namespace amx;
+
+namespace {
+
+int ensure(amx_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap && b.p) return AMX_OK;
+    if (b.p) HIPCHK(ctx, hipFree(b.p));
+    b.p = nullptr; b.cap = 0;
+    const size_t want = bytes + bytes / 8 + 256;
+    HIPCHK(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return AMX_OK;
+}
+
+template <typename T>
+int upload(amx_ctx *ctx, T **dst, const T *src, size_t n)
+{
+    HIPCHK(ctx, hipMalloc((void **)dst, n * sizeof(T) + 16));
+    HIPCHK(ctx, hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return AMX_OK;
+}
+
+int reset_status(amx_ctx *ctx, hipStream_t s)
+{
+    HIPCHK(ctx, hipMemsetAsync(ctx->status_d, 0, ST_WORDS * sizeof(int), s));
+    HIPCHK(ctx, hipMemsetAsync(ctx->status_d + ST_ERRVOX, 0x7f, sizeof(int), s));
+    return AMX_OK;
+}
+
+int make_plan(amx_ctx *ctx, int64_t n, int ndirs, Plan &pl)
+{
+    int rc;
+    const int max_chunks = (int)(n / kChunk) + ndirs + 1;
+    if ((rc = ensure(ctx, ctx->lutidx, n * sizeof(int)))) return rc;
+    if ((rc = ensure(ctx, ctx->perm, n * sizeof(int)))) return rc;
+    if ((rc = ensure(ctx, ctx->counts, (size_t)(ndirs + 1) * sizeof(int)))) return rc;
+    if ((rc = ensure(ctx, ctx->dir_start, (size_t)(ndirs + 1) * sizeof(int)))) return rc;
+    if ((rc = ensure(ctx, ctx->cursor, (size_t)(ndirs + 1) * sizeof(int)))) return rc;
+    if ((rc = ensure(ctx, ctx->chunks, (size_t)max_chunks * sizeof(Chunk)))) return rc;
+    if ((rc = ensure(ctx, ctx->misc, 64 * sizeof(int)))) return rc;
+    if ((rc = ensure(ctx, ctx->ovf, (size_t)4 * n * sizeof(int)))) return rc;
+    pl.lutidx = (int *)ctx->lutidx.p; pl.perm = (int *)ctx->perm.p; pl.counts = (int *)ctx->counts.p;
+    pl.dir_start = (int *)ctx->dir_start.p; pl.cursor = (int *)ctx->cursor.p;
+    pl.chunks = (Chunk *)ctx->chunks.p; pl.n_chunks = (int *)ctx->misc.p;
+    pl.ovf_count = (int *)ctx->misc.p + 4; pl.ovf_list = (int *)ctx->ovf.p;
+    pl.max_chunks = max_chunks;
+    pl.n = (size_t)n;
+    return AMX_OK;
+}
+
+int enqueue_bucketing(amx_ctx *ctx, const amx_lut *lut, const double *d_dirs, int64_t n, Plan &pl, hipStream_t s)
+{
+    HIPCHK(ctx, hipMemsetAsync(pl.counts, 0, (size_t)(lut->ndirs + 1) * sizeof(int), s));
+    HIPCHK(ctx, hipMemsetAsync(ctx->misc.p, 0, 64 * sizeof(int), s));
+    const int nb = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(k_dir_to_lut, dim3(nb), dim3(256), 0, s, d_dirs, (int)n, lut->htable, lut->ndirs,
+                       pl.lutidx, pl.counts, ctx->status_d);
+    AMX_TRACE(ctx, s, "k_dir_to_lut");
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, pl.counts, lut->ndirs, kChunk, pl.dir_start,
+                       pl.cursor, pl.chunks, pl.n_chunks);
+    AMX_TRACE(ctx, s, "k_plan");
+    hipLaunchKernelGGL(k_bucket, dim3(nb), dim3(256), 0, s, pl.lutidx, (int)n, pl.dir_start, pl.cursor, pl.perm);
+    AMX_TRACE(ctx, s, "k_bucket");
+    HIPCHK(ctx, hipGetLastError());
+    return AMX_OK;
+}
+
+// wavefront primitives exercised on the device (tests/test_gpu_parity.py::test_wave_primitives)
+__global__ void k_selftest(double *out)
+{
+    const int lane = threadIdx.x & 63;
+    const double v = (double)(lane * lane) - 100.5 * lane + 3.25;     // distinct, sign-changing values
+    out[0 * 64 + lane] = wave_sum(v);
+    out[1 * 64 + lane] = wave_max(v);
+    out[2 * 64 + lane] = wave_min(v);
+    out[3 * 64 + lane] = bcast(v, 37);
+    out[4 * 64 + lane] = from_next_lane(v);
+    out[5 * 64 + lane] = (double)__builtin_popcountll(ballot64(v > 0.0));
+    out[6 * 64 + lane] = (double)bcast_i(lane * 3, 21);
+    out[7 * 64 + lane] = v;
+}
+
+int bad(amx_ctx *ctx, const char *msg)
+{
+    if (ctx) ctx->err = msg;
+    return AMX_E_BADARG;
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+extern "C" {
+
+int amx_version(void) { return 100; }
+
+int amx_ctx_create(int device, amx_ctx **out)
+{
+    if (!out) return AMX_E_BADARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return AMX_E_NODEVICE;
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) return AMX_E_NODEVICE; }
+    if (device >= ndev) return AMX_E_NODEVICE;
+    if (hipSetDevice(device) != hipSuccess) return AMX_E_NODEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return AMX_E_NODEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return AMX_E_NODEVICE;   // code objects are gfx950 only
+    amx_ctx *ctx = new amx_ctx();
+    ctx->device = device;
+    if (hipMalloc((void **)&ctx->status_d, ST_WORDS * sizeof(int)) != hipSuccess ||
+        hipHostMalloc((void **)&ctx->status_h, (ST_WORDS + 16) * sizeof(int)) != hipSuccess) {
+        delete ctx;
+        return AMX_E_HIP;
+    }
+    for (int k = 0; k < kEv; k++) { hipEventCreate(&ctx->ev[k]); ctx->ev_valid[k] = false; }
+    if (amx_debug() && hipHostMalloc((void **)&ctx->trace_h, 256 * sizeof(int)) == hipSuccess) memset(ctx->trace_h, 0, 256 * sizeof(int));
+    reset_status(ctx, nullptr);
+    hipStreamSynchronize(nullptr);
+    *out = ctx;
+    return AMX_OK;
+}
+
+void amx_ctx_destroy(amx_ctx *ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipDeviceSynchronize();
+    DevBuf *bufs[] = {&ctx->lutidx, &ctx->perm, &ctx->counts, &ctx->dir_start, &ctx->cursor, &ctx->chunks,
+                      &ctx->misc, &ctx->xiso, &ctx->supp, &ctx->ovf, &ctx->hy, &ctx->hdirs, &ctx->hest,
+                      &ctx->hrmse, &ctx->hnrmse, &ctx->hextra};
+    for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
+    if (ctx->status_d) hipFree(ctx->status_d);
+    if (ctx->status_h) hipHostFree(ctx->status_h);
+    for (int k = 0; k < kEv; k++) (void)hipEventDestroy(ctx->ev[k]);
+    delete ctx;
+}
+
+const char *amx_last_error(amx_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+void amx_lut_destroy(amx_lut *lut)
+{
+    if (!lut) return;
+    if (lut->ctx) hipSetDevice(lut->ctx->device);
+    void *ps[] = {lut->tiles, lut->htable, lut->rowdwi, lut->colscale, lut->icvf, lut->kappa,
+                  lut->norms, lut->Rs, lut->d_in, lut->d_isos};
+    for (void *p : ps) if (p) hipFree(p);
+    delete lut;
+}
+
+static int build_tiles(amx_ctx *ctx, amx_lut *lut, const float *src, size_t src_n, const float *fix,
+                       size_t fix_n, const std::vector<int> &fix_ones, int n_lut)
+{
+    float *d_src = nullptr, *d_fix = nullptr; int *d_ones = nullptr;
+    int rc;
+    if ((rc = upload(ctx, &d_src, src, src_n))) return rc;
+    if ((rc = upload(ctx, &d_fix, fix, fix_n ? fix_n : 1))) return rc;
+    if ((rc = upload(ctx, &d_ones, fix_ones.data(), fix_ones.size()))) return rc;
+    const size_t bytes = (size_t)lut->ndirs * lut->tile_stride * sizeof(float) + 64;
+    HIPCHK(ctx, hipMalloc(&lut->tiles, bytes));
+    HIPCHK(ctx, hipMemset(lut->tiles, 0, bytes));
+    hipLaunchKernelGGL(k_build_lut, dim3(2048), dim3(256), 0, nullptr, d_src, d_fix, d_ones, n_lut,
+                       (int)fix_ones.size(), lut->ndirs, lut->nS, lut->ldA, lut->tile_stride, (float *)lut->tiles);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipDeviceSynchronize());
+    hipFree(d_src); hipFree(d_fix); hipFree(d_ones);
+    return AMX_OK;
+}
+
+int amx_lut_upload_noddi(amx_ctx *ctx, const float *wm, const float *iso, const double *norms,
+                         const float *icvf, const float *kappa, const int16_t *htable,
+                         const int64_t *dwi_idx, int n_wm, int ndirs, int nS, int dwi_count,
+                         int is_exvivo, amx_lut **out)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!wm || !iso || !norms || !icvf || !kappa || !htable || !dwi_idx || !out || n_wm <= 0 || ndirs <= 0 ||
+        nS <= 0 || dwi_count < 0 || dwi_count > nS)
+        return bad(ctx, "amx_lut_upload_noddi: bad argument");
+    const int n_atoms = n_wm + 1 + (is_exvivo ? 1 : 0);
+    if (n_atoms > 192 || nS > 256) return bad(ctx, "amx_lut_upload_noddi: unsupported size (n_atoms <= 192, nS <= 256)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    amx_lut *lut = new amx_lut();
+    lut->ctx = ctx; lut->model = 1; lut->nS = nS; lut->n_atoms = n_atoms; lut->ndirs = ndirs;
+    lut->n_wm = n_wm; lut->is_exvivo = is_exvivo;
+    lut->ldA = (n_atoms & 1) ? n_atoms : n_atoms + 1;         // odd: conflict-free LDS columns
+    lut->tile_stride = (nS * lut->ldA + 3) & ~3;
+    int rc;
+    std::vector<int> ones;
+    std::vector<float> fix;
+    if (is_exvivo) { ones.push_back(1); fix.insert(fix.end(), nS, 1.0f); }   // models.pyx:843-844
+    ones.push_back(0); fix.insert(fix.end(), iso, iso + nS);
+    if ((rc = build_tiles(ctx, lut, wm, (size_t)n_wm * ndirs * nS, fix.data(), fix.size(), ones, n_wm))) { amx_lut_destroy(lut); return rc; }
+    // rows of stage 2 (models.pyx:820, 917-921): j+1 if nS == 1+dwi_count ("single_b0") else dwi_idx[j]
+    std::vector<unsigned char> rowdwi(nS, 0);
+    const bool single_b0 = (nS == 1 + dwi_count);
+    for (int j = 0; j < dwi_count; j++) {
+        const int64_t row = single_b0 ? j + 1 : dwi_idx[j];
+        if (row < 0 || row >= nS) { amx_lut_destroy(lut); return bad(ctx, "amx_lut_upload_noddi: dwi_idx out of range"); }
+        rowdwi[row] = 1;
+    }
+    std::vector<double> colscale(n_atoms, 1.0);
+    for (int k = 0; k < n_wm; k++) colscale[k] = dwi_count > 0 ? norms[k] : 1.0;   // rows of norms are identical
+    std::vector<short> ht(htable, htable + 181 * 181);
+    if ((rc = upload(ctx, &lut->rowdwi, rowdwi.data(), rowdwi.size())) ||
+        (rc = upload(ctx, &lut->colscale, colscale.data(), colscale.size())) ||
+        (rc = upload(ctx, &lut->icvf, icvf, (size_t)n_wm)) || (rc = upload(ctx, &lut->kappa, kappa, (size_t)n_wm)) ||
+        (rc = upload(ctx, &lut->htable, ht.data(), ht.size()))) { amx_lut_destroy(lut); return rc; }
+    *out = lut;
+    return AMX_OK;
+}
+
+int amx_lut_upload_freewater(amx_ctx *ctx, const float *D, const float *CSF, const int16_t *htable,
+                             int n_perp, int n_iso, int ndirs, int nS, amx_lut **out)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!D || !CSF || !htable || !out || n_perp <= 0 || n_iso <= 0 || ndirs <= 0 || nS <= 0)
+        return bad(ctx, "amx_lut_upload_freewater: bad argument");
+    const int n_atoms = n_perp + n_iso;
+    if (n_atoms > 64 || nS > 256) return bad(ctx, "amx_lut_upload_freewater: unsupported size (n_atoms <= 64, nS <= 256)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    amx_lut *lut = new amx_lut();
+    lut->ctx = ctx; lut->model = 2; lut->nS = nS; lut->n_atoms = n_atoms; lut->ndirs = ndirs;
+    lut->n_perp = n_perp; lut->n_iso = n_iso;
+    lut->ldA = (n_atoms & 1) ? n_atoms : n_atoms + 1;
+    lut->tile_stride = (nS * lut->ldA + 3) & ~3;
+    int rc;
+    std::vector<int> ones(n_iso, 0);
+    if ((rc = build_tiles(ctx, lut, D, (size_t)n_perp * ndirs * nS, CSF, (size_t)n_iso * nS, ones, n_perp))) { amx_lut_destroy(lut); return rc; }
+    std::vector<short> ht(htable, htable + 181 * 181);
+    if ((rc = upload(ctx, &lut->htable, ht.data(), ht.size()))) { amx_lut_destroy(lut); return rc; }
+    *out = lut;
+    return AMX_OK;
+}
+
+int amx_lut_upload_sandi(amx_ctx *ctx, const double *signal, const double *norms, const double *Rs,
+                         const double *d_in, const double *d_isos, int nS, int n_rs, int n_in,
+                         int n_iso, amx_lut **out)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!signal || !norms || !Rs || !d_in || !d_isos || !out || nS <= 0 || n_rs < 0 || n_in < 0 || n_iso < 0)
+        return bad(ctx, "amx_lut_upload_sandi: bad argument");
+    const int n_atoms = n_rs + n_in + n_iso;
+    if (n_atoms <= 0 || n_atoms > 64 || nS > 128) return bad(ctx, "amx_lut_upload_sandi: unsupported size (n_atoms <= 64, nS <= 128)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    amx_lut *lut = new amx_lut();
+    lut->ctx = ctx; lut->model = 3; lut->nS = nS; lut->n_atoms = n_atoms; lut->ndirs = 1;
+    lut->n_rs = n_rs; lut->n_in = n_in; lut->n_isos = n_iso;
+    lut->ldA = (n_atoms & 1) ? n_atoms : n_atoms + 1;
+    lut->tile_stride = (nS * lut->ldA + 3) & ~3;
+    std::vector<double> tile((size_t)lut->tile_stride + 8, 0.0);
+    for (int j = 0; j < n_atoms; j++)
+        for (int i = 0; i < nS; i++) tile[(size_t)i * lut->ldA + j] = signal[(size_t)j * nS + i];   // col-major in
+    int rc;
+    double *dt = nullptr;
+    if ((rc = upload(ctx, &dt, tile.data(), tile.size())) || (rc = upload(ctx, &lut->norms, norms, (size_t)n_atoms)) ||
+        (rc = upload(ctx, &lut->Rs, Rs, (size_t)(n_rs ? n_rs : 1))) || (rc = upload(ctx, &lut->d_in, d_in, (size_t)(n_in ? n_in : 1))) ||
+        (rc = upload(ctx, &lut->d_isos, d_isos, (size_t)(n_iso ? n_iso : 1)))) { lut->tiles = dt; amx_lut_destroy(lut); return rc; }
+    lut->tiles = dt;
+    *out = lut;
+    return AMX_OK;
+}
+
+int amx_sync_status(amx_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return AMX_E_BADARG;
+    hipStream_t s = (hipStream_t)hip_stream;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->status_h, ctx->status_d, ST_WORDS * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (ctx->misc.p)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->status_h + ST_WORDS, ctx->misc.p, 16 * sizeof(int), hipMemcpyDeviceToHost, s));
+    else
+        memset(ctx->status_h + ST_WORDS, 0, 16 * sizeof(int));
+    int rc = reset_status(ctx, s);
+    if (rc) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    const int *st = ctx->status_h;
+    const int *ov = st + ST_WORDS + 4;
+    ctx->stats[0] = (int64_t)ov[0] + ov[1] + ov[2];
+    ctx->stats[1] = st[ST_ITCAP];
+    ctx->stats[2] = ov[8];
+    ctx->stats[3] = ((int64_t)st[ST_GUARD] << 32) | (unsigned)st[ST_GUARDVOX];
+    if (st[ST_ERRVOX] != 0x7f7f7f7f) {
+        char b[256];
+        snprintf(b, sizeof b, "\"amico.lut.dir_to_lut_idx\" index out of bounds (%d, %d) [voxel %d]", st[ST_II1], st[ST_II2], st[ST_ERRVOX]);
+        ctx->err = b;
+        return AMX_E_DIR_OOB;
+    }
+    if (ov[8] > 0) {
+        char b[256];
+        snprintf(b, sizeof b, "%d voxel(s) exceeded the largest supported active set", ov[8]);
+        ctx->err = b;
+        return AMX_E_OVERFLOW;
+    }
+    return AMX_OK;
+}
+
+int amx_selftest(amx_ctx *ctx, double *out512)
+{
+    if (!ctx || !out512) return AMX_E_BADARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, ctx->hest, 512 * sizeof(double)))) return rc;
+    hipLaunchKernelGGL(k_selftest, dim3(1), dim3(64), 0, nullptr, (double *)ctx->hest.p);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpy(out512, ctx->hest.p, 512 * sizeof(double), hipMemcpyDeviceToHost));
+    return AMX_OK;
+}
+
+int amx_debug_trace(amx_ctx *ctx, int *out64)
+{
+    if (!ctx || !out64) return AMX_E_BADARG;
+    if (!ctx->trace_h) return bad(ctx, "amx_debug_trace: run with AMX_DEBUG=1");
+    for (int k = 0; k < 256; k++) out64[k] = ((volatile int *)ctx->trace_h)[k];
+    return AMX_OK;
+}
+
+int amx_set_profiling(amx_ctx *ctx, int enable)
+{
+    if (!ctx) return AMX_E_BADARG;
+    ctx->profiling = enable != 0;
+    for (int k = 0; k < kEv; k++) ctx->ev_valid[k] = false;
+    return AMX_OK;
+}
+
+int amx_last_kernel_ms(amx_ctx *ctx, int which, float *out_ms)
+{
+    if (!ctx || !out_ms || which < 0 || which > 3) return AMX_E_BADARG;
+    const int a = which == 0 ? 0 : 2 * which, b = which == 0 ? 1 : 2 * which + 1;
+    if (!ctx->ev_valid[a] || !ctx->ev_valid[b]) return bad(ctx, "amx_last_kernel_ms: no profiled call");
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev[b]));
+    HIPCHK(ctx, hipEventElapsedTime(out_ms, ctx->ev[a], ctx->ev[b]));
+    return AMX_OK;
+}
+
+int amx_last_stats(amx_ctx *ctx, int64_t out[4])
+{
+    if (!ctx || !out) return AMX_E_BADARG;
+    for (int k = 0; k < 4; k++) out[k] = ctx->stats[k];
+    return AMX_OK;
+}
+
+// ------------------------------------------------------------------ NODDI
+int amx_noddi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, const double *d_dirs,
+                         int64_t n_vox, double lambda1, double lambda2, unsigned flags,
+                         double *d_estimates, double *d_rmse, double *d_nrmse, double *d_mod,
+                         void *hip_stream)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!lut || lut->model != 1 || lut->ctx != ctx) return bad(ctx, "amx_noddi_fit: not a NODDI dictionary of this ctx");
+    if (n_vox < 0 || n_vox > INT_MAX / 4) return bad(ctx, "amx_noddi_fit: bad n_vox");
+    if (n_vox == 0) return AMX_OK;
+    if (!d_y || !d_dirs || !d_estimates) return bad(ctx, "amx_noddi_fit: null buffer");
+    if (((flags & AMX_F_RMSE) && !d_rmse) || ((flags & AMX_F_NRMSE) && !d_nrmse) || ((flags & AMX_F_MODULATED) && !d_mod))
+        return bad(ctx, "amx_noddi_fit: flag set but output buffer is null");
+    if (!(lambda2 > 0.0) || !(lambda1 >= 0.0)) return bad(ctx, "amx_noddi_fit: need lambda1 >= 0 and lambda2 > 0");
+    hipStream_t s = (hipStream_t)hip_stream;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Plan pl; int rc;
+    if ((rc = make_plan(ctx, n_vox, lut->ndirs, pl))) return rc;
+    if ((rc = ensure(ctx, ctx->xiso, (size_t)n_vox * 2 * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->supp, (size_t)n_vox * 4 * sizeof(unsigned long long)))) return rc;
+    rec(ctx, 0, s);
+    if ((rc = enqueue_bucketing(ctx, lut, d_dirs, n_vox, pl, s))) return rc;
+    NoddiArgs a;
+    memset(&a, 0, sizeof a);
+    a.c.tiles = lut->tiles; a.c.y = d_y; a.c.perm = pl.perm; a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks;
+    a.c.lutidx = pl.lutidx; a.c.status = ctx->status_d; a.c.trace = ctx->trace_h; a.c.nS = lut->nS; a.c.ldA = lut->ldA;
+    a.c.n_atoms = lut->n_atoms; a.c.tile_stride = lut->tile_stride; a.c.lam1 = lambda1; a.c.lam2 = lambda2; a.c.flags = flags;
+    a.rowdwi = lut->rowdwi; a.colscale = lut->colscale; a.icvf = lut->icvf; a.kappa = lut->kappa;
+    a.n_wm = lut->n_wm; a.is_exvivo = lut->is_exvivo; a.n_maps = 3 + (lut->is_exvivo ? 1 : 0);
+    a.xiso = (double *)ctx->xiso.p; a.supp = (unsigned long long *)ctx->supp.p;
+    a.est = d_estimates; a.rmse = (flags & AMX_F_RMSE) ? d_rmse : nullptr;
+    a.nrmse = (flags & AMX_F_NRMSE) ? d_nrmse : nullptr; a.mod = (flags & AMX_F_MODULATED) ? d_mod : nullptr;
+    // voxels with an out-of-bounds direction are skipped: give them defined (zero) maps
+    HIPCHK(ctx, hipMemsetAsync(d_estimates, 0, (size_t)n_vox * a.n_maps * sizeof(double), s));
+    if (!(rc = amx_launch_noddi_s1(ctx, a, pl, s)) && !(rc = amx_launch_noddi_s2(ctx, a, pl, s)))
+        rc = amx_launch_noddi_s3(ctx, a, pl, s);
+    rec(ctx, 1, s);
+    return rc;
+}
+
+// ------------------------------------------------------------------ FreeWater
+int amx_freewater_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y,
+                             const double *d_dirs, int64_t n_vox, double lambda1, double lambda2,
+                             int is_mouse, unsigned flags, double *d_estimates, double *d_rmse,
+                             double *d_nrmse, double *d_ycorr, void *hip_stream)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!lut || lut->model != 2 || lut->ctx != ctx) return bad(ctx, "amx_freewater_fit: not a FreeWater dictionary of this ctx");
+    if (n_vox < 0 || n_vox > INT_MAX / 4) return bad(ctx, "amx_freewater_fit: bad n_vox");
+    if (n_vox == 0) return AMX_OK;
+    if (!d_y || !d_dirs || !d_estimates) return bad(ctx, "amx_freewater_fit: null buffer");
+    if (((flags & AMX_F_RMSE) && !d_rmse) || ((flags & AMX_F_NRMSE) && !d_nrmse) || ((flags & AMX_F_CORRECTED) && !d_ycorr))
+        return bad(ctx, "amx_freewater_fit: flag set but output buffer is null");
+    if (!(lambda2 > 0.0) || !(lambda1 >= 0.0)) return bad(ctx, "amx_freewater_fit: need lambda1 >= 0 and lambda2 > 0");
+    if (is_mouse && lut->n_iso < 2) return bad(ctx, "amx_freewater_fit: Mouse needs two isotropic atoms");
+    hipStream_t s = (hipStream_t)hip_stream;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Plan pl; int rc;
+    if ((rc = make_plan(ctx, n_vox, lut->ndirs, pl))) return rc;
+    rec(ctx, 0, s);
+    if ((rc = enqueue_bucketing(ctx, lut, d_dirs, n_vox, pl, s))) return rc;
+    FwArgs a;
+    memset(&a, 0, sizeof a);
+    a.c.tiles = lut->tiles; a.c.y = d_y; a.c.perm = pl.perm; a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks;
+    a.c.lutidx = pl.lutidx; a.c.status = ctx->status_d; a.c.trace = ctx->trace_h; a.c.nS = lut->nS; a.c.ldA = lut->ldA;
+    a.c.n_atoms = lut->n_atoms; a.c.tile_stride = lut->tile_stride; a.c.lam1 = lambda1; a.c.lam2 = lambda2; a.c.flags = flags;
+    a.n_perp = lut->n_perp; a.n_iso = lut->n_iso; a.is_mouse = is_mouse; a.n_maps = is_mouse ? 4 : 2;
+    a.est = d_estimates; a.rmse = (flags & AMX_F_RMSE) ? d_rmse : nullptr;
+    a.nrmse = (flags & AMX_F_NRMSE) ? d_nrmse : nullptr; a.ycorr = (flags & AMX_F_CORRECTED) ? d_ycorr : nullptr;
+    HIPCHK(ctx, hipMemsetAsync(d_estimates, 0, (size_t)n_vox * a.n_maps * sizeof(double), s));
+    rc = amx_launch_fw(ctx, a, pl, s);
+    rec(ctx, 1, s);
+    return rc;
+}
+
+// ------------------------------------------------------------------ SANDI
+int amx_sandi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, int64_t n_vox,
+                         double lambda1, double lambda2, unsigned flags, double *d_estimates,
+                         double *d_rmse, double *d_nrmse, void *hip_stream)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!lut || lut->model != 3 || lut->ctx != ctx) return bad(ctx, "amx_sandi_fit: not a SANDI dictionary of this ctx");
+    if (n_vox < 0 || n_vox > INT_MAX / 4) return bad(ctx, "amx_sandi_fit: bad n_vox");
+    if (n_vox == 0) return AMX_OK;
+    if (!d_y || !d_estimates) return bad(ctx, "amx_sandi_fit: null buffer");
+    if (((flags & AMX_F_RMSE) && !d_rmse) || ((flags & AMX_F_NRMSE) && !d_nrmse))
+        return bad(ctx, "amx_sandi_fit: flag set but output buffer is null");
+    if (!(lambda2 > 0.0) || !(lambda1 >= 0.0)) return bad(ctx, "amx_sandi_fit: need lambda1 >= 0 and lambda2 > 0");
+    hipStream_t s = (hipStream_t)hip_stream;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Plan pl; int rc;
+    if ((rc = make_plan(ctx, n_vox, 1, pl))) return rc;
+    rec(ctx, 0, s);
+    HIPCHK(ctx, hipMemsetAsync(ctx->misc.p, 0, 64 * sizeof(int), s));
+    const int nb = (int)((n_vox + 255) / 256);
+    hipLaunchKernelGGL(k_plan_linear, dim3(nb), dim3(256), 0, s, (int)n_vox, kChunk, pl.chunks, pl.n_chunks, pl.perm);
+    SandiArgs a;
+    memset(&a, 0, sizeof a);
+    a.c.tiles = lut->tiles; a.c.y = d_y; a.c.perm = pl.perm; a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks;
+    a.c.lutidx = pl.lutidx; a.c.status = ctx->status_d; a.c.trace = ctx->trace_h; a.c.nS = lut->nS; a.c.ldA = lut->ldA;
+    a.c.n_atoms = lut->n_atoms; a.c.tile_stride = lut->tile_stride; a.c.lam1 = lambda1; a.c.lam2 = lambda2; a.c.flags = flags;
+    a.norms = lut->norms; a.Rs = lut->Rs; a.d_in = lut->d_in; a.d_isos = lut->d_isos;
+    a.n_rs = lut->n_rs; a.n_in = lut->n_in; a.n_iso = lut->n_isos;
+    a.est = d_estimates; a.rmse = (flags & AMX_F_RMSE) ? d_rmse : nullptr; a.nrmse = (flags & AMX_F_NRMSE) ? d_nrmse : nullptr;
+    rc = amx_launch_sandi(ctx, a, pl, s);
+    rec(ctx, 1, s);
+    return rc;
+}
+
+// ------------------------------------------------------------------ host-pointer entry points
+#define AMX_H2D(buf, src, bytes)                                                     \
+    if ((rc = ensure(ctx, buf, bytes))) return rc;                                   \
+    HIPCHK(ctx, hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, nullptr));
+#define AMX_D2H(dst, buf, bytes) HIPCHK(ctx, hipMemcpyAsync(dst, buf.p, bytes, hipMemcpyDeviceToHost, nullptr));
+
+int amx_noddi_fit(amx_ctx *ctx, const amx_lut *lut, const double *y, const double *dirs,
+                  int64_t n_vox, double lambda1, double lambda2, unsigned flags,
+                  double *out_estimates, double *out_rmse, double *out_nrmse, double *out_mod)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!lut || lut->model != 1) return bad(ctx, "amx_noddi_fit: not a NODDI dictionary");
+    if (n_vox == 0) return AMX_OK;
+    if (n_vox < 0 || !y || !dirs || !out_estimates) return bad(ctx, "amx_noddi_fit: bad argument");
+    if (((flags & AMX_F_RMSE) && !out_rmse) || ((flags & AMX_F_NRMSE) && !out_nrmse) || ((flags & AMX_F_MODULATED) && !out_mod))
+        return bad(ctx, "amx_noddi_fit: flag set but output buffer is null");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    const int n_maps = 3 + (lut->is_exvivo ? 1 : 0);
+    AMX_H2D(ctx->hy, y, (size_t)n_vox * lut->nS * sizeof(double))
+    AMX_H2D(ctx->hdirs, dirs, (size_t)n_vox * 3 * sizeof(double))
+    if ((rc = ensure(ctx, ctx->hest, (size_t)n_vox * n_maps * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->hrmse, (size_t)n_vox * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->hnrmse, (size_t)n_vox * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->hextra, (size_t)n_vox * 2 * sizeof(double)))) return rc;
+    rc = amx_noddi_fit_device(ctx, lut, (const double *)ctx->hy.p, (const double *)ctx->hdirs.p, n_vox, lambda1,
+                              lambda2, flags, (double *)ctx->hest.p, (double *)ctx->hrmse.p,
+                              (double *)ctx->hnrmse.p, (double *)ctx->hextra.p, nullptr);
+    if (rc) return rc;
+    AMX_D2H(out_estimates, ctx->hest, (size_t)n_vox * n_maps * sizeof(double))
+    if (flags & AMX_F_RMSE) AMX_D2H(out_rmse, ctx->hrmse, (size_t)n_vox * sizeof(double))
+    if (flags & AMX_F_NRMSE) AMX_D2H(out_nrmse, ctx->hnrmse, (size_t)n_vox * sizeof(double))
+    if (flags & AMX_F_MODULATED) AMX_D2H(out_mod, ctx->hextra, (size_t)n_vox * 2 * sizeof(double))
+    return amx_sync_status(ctx, nullptr);
+}
+
+int amx_freewater_fit(amx_ctx *ctx, const amx_lut *lut, const double *y, const double *dirs,
+                      int64_t n_vox, double lambda1, double lambda2, int is_mouse, unsigned flags,
+                      double *out_estimates, double *out_rmse, double *out_nrmse, double *out_ycorr)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!lut || lut->model != 2) return bad(ctx, "amx_freewater_fit: not a FreeWater dictionary");
+    if (n_vox == 0) return AMX_OK;
+    if (n_vox < 0 || !y || !dirs || !out_estimates) return bad(ctx, "amx_freewater_fit: bad argument");
+    if (((flags & AMX_F_RMSE) && !out_rmse) || ((flags & AMX_F_NRMSE) && !out_nrmse) || ((flags & AMX_F_CORRECTED) && !out_ycorr))
+        return bad(ctx, "amx_freewater_fit: flag set but output buffer is null");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    const int n_maps = is_mouse ? 4 : 2;
+    AMX_H2D(ctx->hy, y, (size_t)n_vox * lut->nS * sizeof(double))
+    AMX_H2D(ctx->hdirs, dirs, (size_t)n_vox * 3 * sizeof(double))
+    if ((rc = ensure(ctx, ctx->hest, (size_t)n_vox * n_maps * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->hrmse, (size_t)n_vox * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->hnrmse, (size_t)n_vox * sizeof(double)))) return rc;
+    if ((flags & AMX_F_CORRECTED) && (rc = ensure(ctx, ctx->hextra, (size_t)n_vox * lut->nS * sizeof(double)))) return rc;
+    rc = amx_freewater_fit_device(ctx, lut, (const double *)ctx->hy.p, (const double *)ctx->hdirs.p, n_vox, lambda1,
+                                  lambda2, is_mouse, flags, (double *)ctx->hest.p, (double *)ctx->hrmse.p,
+                                  (double *)ctx->hnrmse.p, (double *)ctx->hextra.p, nullptr);
+    if (rc) return rc;
+    AMX_D2H(out_estimates, ctx->hest, (size_t)n_vox * n_maps * sizeof(double))
+    if (flags & AMX_F_RMSE) AMX_D2H(out_rmse, ctx->hrmse, (size_t)n_vox * sizeof(double))
+    if (flags & AMX_F_NRMSE) AMX_D2H(out_nrmse, ctx->hnrmse, (size_t)n_vox * sizeof(double))
+    if (flags & AMX_F_CORRECTED) AMX_D2H(out_ycorr, ctx->hextra, (size_t)n_vox * lut->nS * sizeof(double))
+    return amx_sync_status(ctx, nullptr);
+}
+
+int amx_sandi_fit(amx_ctx *ctx, const amx_lut *lut, const double *y, int64_t n_vox,
+                  double lambda1, double lambda2, unsigned flags,
+                  double *out_estimates, double *out_rmse, double *out_nrmse)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!lut || lut->model != 3) return bad(ctx, "amx_sandi_fit: not a SANDI dictionary");
+    if (n_vox == 0) return AMX_OK;
+    if (n_vox < 0 || !y || !out_estimates) return bad(ctx, "amx_sandi_fit: bad argument");
+    if (((flags & AMX_F_RMSE) && !out_rmse) || ((flags & AMX_F_NRMSE) && !out_nrmse))
+        return bad(ctx, "amx_sandi_fit: flag set but output buffer is null");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    AMX_H2D(ctx->hy, y, (size_t)n_vox * lut->nS * sizeof(double))
+    if ((rc = ensure(ctx, ctx->hest, (size_t)n_vox * 6 * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->hrmse, (size_t)n_vox * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->hnrmse, (size_t)n_vox * sizeof(double)))) return rc;
+    rc = amx_sandi_fit_device(ctx, lut, (const double *)ctx->hy.p, n_vox, lambda1, lambda2, flags,
+                              (double *)ctx->hest.p, (double *)ctx->hrmse.p, (double *)ctx->hnrmse.p, nullptr);
+    if (rc) return rc;
+    AMX_D2H(out_estimates, ctx->hest, (size_t)n_vox * 6 * sizeof(double))
+    if (flags & AMX_F_RMSE) AMX_D2H(out_rmse, ctx->hrmse, (size_t)n_vox * sizeof(double))
+    if (flags & AMX_F_NRMSE) AMX_D2H(out_nrmse, ctx->hnrmse, (size_t)n_vox * sizeof(double))
+    return amx_sync_status(ctx, nullptr);
+}
+
+int amx_dir_to_lut_idx(amx_ctx *ctx, const amx_lut *lut, const double *dirs, int64_t n, int32_t *out_idx)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!lut || !lut->htable) return bad(ctx, "amx_dir_to_lut_idx: dictionary has no hash table");
+    if (n == 0) return AMX_OK;
+    if (n < 0 || n > INT_MAX / 4 || !dirs || !out_idx) return bad(ctx, "amx_dir_to_lut_idx: bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    AMX_H2D(ctx->hdirs, dirs, (size_t)n * 3 * sizeof(double))
+    if ((rc = ensure(ctx, ctx->lutidx, (size_t)n * sizeof(int)))) return rc;
+    hipLaunchKernelGGL(k_dir_to_lut, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (const double *)ctx->hdirs.p,
+                       (int)n, lut->htable, lut->ndirs, (int *)ctx->lutidx.p, (int *)nullptr, ctx->status_d);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(out_idx, ctx->lutidx.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, nullptr));
+    return amx_sync_status(ctx, nullptr);
+}
+
+}  // extern "C"

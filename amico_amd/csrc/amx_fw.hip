@@ -1,0 +1,16 @@
+// amx_fw.hip -- FreeWater solver kernel (models.pyx:1231-1276)
+#include "amx_launch.hpp"
+using namespace amx;
+
+template <int NR>
+static int go(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s)
+{
+    constexpr int NQ = 1, MP = 16, MB = 64;
+    return launch_pair(ctx, a, pl, s, k_freewater<NR, NQ, MP, kNW, false>, k_freewater<NR, NQ, MB, 1, true>,
+                       fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, kNW), fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1), 0, 2);
+}
+
+int amx_launch_fw(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s)
+{
+    return a.c.nS <= 128 ? go<2>(ctx, a, pl, s) : go<4>(ctx, a, pl, s);
+}

@@ -1,0 +1,93 @@
+// amx_host.hpp -- host-side context shared by amx_api.hip and the per-model launch units.
+#pragma once
+#include "../../include/amico_amd.h"
+#include "amx_kernels.hpp"
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+constexpr int kChunk = 256;        // voxels of one orientation per workgroup
+constexpr int kNW = 4;             // wavefronts per workgroup (main pass)
+constexpr int kListGrid = 512;     // workgroups of the large-MAXP re-run pass
+constexpr int kEv = 10;
+
+struct DevBuf {
+    void *p = nullptr; size_t cap = 0;
+};
+
+struct amx_ctx {
+    int device = 0;
+    std::string err;
+    // stream-ordered workspace (grow-only)
+    DevBuf lutidx, perm, counts, dir_start, cursor, chunks, misc, xiso, supp, ovf;
+    DevBuf hy, hdirs, hest, hrmse, hnrmse, hextra;   // staging for the host-pointer entry points
+    int *status_d = nullptr;       // ST_WORDS ints
+    int *status_h = nullptr;       // pinned mirror (+16 words: copy of the misc counters)
+    int *trace_h = nullptr;        // AMX_DEBUG: 64 host-visible progress words written by the kernels
+    bool profiling = false;
+    hipEvent_t ev[kEv];
+    bool ev_valid[kEv];
+    int64_t stats[4] = {0, 0, 0, 0};
+};
+
+struct amx_lut {
+    amx_ctx *ctx = nullptr;
+    int model = 0;                 // 1 NODDI, 2 FreeWater, 3 SANDI
+    int nS = 0, ldA = 0, n_atoms = 0, ndirs = 0, tile_stride = 0;
+    int n_wm = 0, is_exvivo = 0;   // NODDI
+    int n_perp = 0, n_iso = 0;     // FreeWater
+    int n_rs = 0, n_in = 0, n_isos = 0;   // SANDI
+    void *tiles = nullptr;
+    short *htable = nullptr;
+    unsigned char *rowdwi = nullptr;
+    double *colscale = nullptr;
+    float *icvf = nullptr, *kappa = nullptr;
+    double *norms = nullptr, *Rs = nullptr, *d_in = nullptr, *d_isos = nullptr;
+};
+
+#define HIPCHK(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            char b_[512];                                                                         \
+            snprintf(b_, sizeof b_, "HIP error %s at %s:%d (%s)", hipGetErrorString(e_), __FILE__, \
+                     __LINE__, #call);                                                            \
+            (ctx)->err = b_;                                                                      \
+            return AMX_E_HIP;                                                                     \
+        }                                                                                         \
+    } while (0)
+
+// misc buffer layout (ints): [0] n_chunks, [4..6] overflow counters of the 3 stages,
+// [12] voxels that did not fit the large-MAXP variant either
+struct Plan {
+    int *lutidx, *perm, *counts, *dir_start, *cursor, *n_chunks, *ovf_count, *ovf_list;
+    amx::Chunk *chunks;
+    int max_chunks;
+    size_t n;
+};
+
+// AMX_DEBUG=1: synchronise after every launch and trace progress on stderr
+static inline bool amx_debug() { static int d = -1; if (d < 0) { const char *e = getenv("AMX_DEBUG"); d = (e && *e && *e != '0') ? 1 : 0; } return d == 1; }
+#define AMX_TRACE(ctx, s, what)                                                                   \
+    do {                                                                                          \
+        if (amx_debug()) {                                                                        \
+            fprintf(stderr, "[amx] %s ...", what); fflush(stderr);                                \
+            hipError_t e_ = hipStreamSynchronize(s);                                              \
+            fprintf(stderr, " %s\n", hipGetErrorString(e_)); fflush(stderr);                      \
+        }                                                                                         \
+    } while (0)
+
+static inline void rec(amx_ctx *ctx, int k, hipStream_t s)
+{
+    if (ctx->profiling) { (void)hipEventRecord(ctx->ev[k], s); ctx->ev_valid[k] = true; }
+}
+
+// defined in the per-model launch units (amx_noddi.hip, amx_fw.hip, amx_sandi.hip)
+int amx_launch_noddi_s1(amx_ctx *ctx, amx::NoddiArgs &a, const Plan &pl, hipStream_t s);
+int amx_launch_noddi_s2(amx_ctx *ctx, amx::NoddiArgs &a, const Plan &pl, hipStream_t s);
+int amx_launch_noddi_s3(amx_ctx *ctx, amx::NoddiArgs &a, const Plan &pl, hipStream_t s);
+int amx_launch_fw(amx_ctx *ctx, amx::FwArgs &a, const Plan &pl, hipStream_t s);
+int amx_launch_sandi(amx_ctx *ctx, amx::SandiArgs &a, const Plan &pl, hipStream_t s);

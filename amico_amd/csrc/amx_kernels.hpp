@@ -1,0 +1,486 @@
+// amx_kernels.hpp -- gfx950 kernels of the AMICO fit path (included by amx_api.hip only).
+//
+//   k_dir_to_lut      lut.pyx:316-356 per voxel + histogram of LUT indices
+//   k_plan            exclusive scan of the histogram, chunk list (<= CH voxels of ONE
+//                     orientation per workgroup, so the dictionary slice is staged once)
+//   k_bucket          counting-sort scatter -> permutation grouped by orientation
+//   k_build_lut*      one-off re-layout of KERNELS into [ndirs][nS][ldA] tiles
+//   k_noddi<STAGE>    models.pyx:902-981 split at its three solver calls
+//   k_freewater       models.pyx:1231-1276
+//   k_sandi           models.pyx:1567-1619
+#pragma once
+#include "amx_solver.hpp"
+
+namespace amx {
+
+struct Chunk { int dir, start, count, pad; };
+
+enum StatusSlot { ST_ERRVOX = 0, ST_II1 = 1, ST_II2 = 2, ST_OVERFLOW = 3, ST_ITCAP = 4, ST_RERUN = 5, ST_GUARD = 6, ST_GUARDVOX = 7, ST_WORDS = 8 };
+
+// ------------------------------------------------------------------ shared pieces
+struct FitCommon {
+    const void *tiles;            // [ndirs][nS][ldA] (float) or [nS][ldA] (double, SANDI)
+    const double *y;              // [n_vox][nS]
+    const int *perm;              // voxels grouped by orientation
+    const Chunk *chunks;
+    const int *n_chunks;
+    const int *list;              // LIST mode: voxel ids to re-run
+    const int *list_count;
+    const int *lutidx;            // [n_vox]
+    int *ovf_list;                // voxels whose passive set did not fit MAXP
+    int *ovf_count;
+    int *status;
+    int *trace;                   // debug: host-visible progress words of the first voxel (or null)
+    int nS, ldA, n_atoms;
+    int tile_stride;              // elements between consecutive orientation tiles (multiple of 4)
+    double lam1, lam2;
+    unsigned flags;
+};
+
+template <typename AT>
+__device__ __forceinline__ void stage_tile(AT *As, const AT *__restrict__ g, int words, int pad)
+{
+    // straight copy global -> LDS (tile is already in LDS layout), 16 B per lane per step
+    const int nvec = words / (16 / (int)sizeof(AT));
+    const uint4 *gv = reinterpret_cast<const uint4 *>(g);
+    uint4 *sv = reinterpret_cast<uint4 *>(As);
+    for (int k = threadIdx.x; k < nvec; k += blockDim.x) sv[k] = gv[k];
+    for (int k = nvec * (16 / (int)sizeof(AT)) + threadIdx.x; k < words; k += blockDim.x) As[k] = g[k];
+    for (int k = threadIdx.x; k < pad; k += blockDim.x) As[words + k] = (AT)0;
+}
+
+template <int NR>
+__device__ __forceinline__ bool load_rows(const double *__restrict__ yv, int nS, int lane, double (&yr)[NR])
+{
+    bool finite = true;
+#pragma unroll
+    for (int rr = 0; rr < NR; rr++) {
+        const int i = lane + kWave * rr;
+        yr[rr] = (i < nS) ? yv[i] : 0.0;
+        finite = finite && (fabs(yr[rr]) <= 1.79769313486231570e308);
+    }
+    return ballot64(!finite) == 0ull;
+}
+
+// ------------------------------------------------------------------ NODDI
+struct NoddiArgs {
+    FitCommon c;
+    const unsigned char *rowdwi;  // [nS] rows entering stage 2 (scheme.dwi_idx / single_b0 rule)
+    const double *colscale;       // [n_atoms] KERNELS['norms'][0][k] (1.0 for iso/dot)
+    const float *icvf, *kappa;    // [n_wm]
+    int n_wm, is_exvivo, n_maps;
+    double *xiso;                 // [n_vox][2]  x_iso, x_dot after stage 1
+    unsigned long long *supp;     // [n_vox][4]  stage-2 support bit set
+    double *est, *rmse, *nrmse, *mod;
+};
+
+template <int STAGE, int NR, int NQ, int MAXP>
+__device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const float *As, double *rs,
+                                            unsigned long long *wmask, int vox, int lane)
+{
+    const int nS = a.c.nS, ldA = a.c.ldA, n_atoms = a.c.n_atoms, n_wm = a.n_wm;
+    const int iso_atom = n_atoms - 1, dot_atom = a.is_exvivo ? n_atoms - 2 : -1;
+    double yr[NR];
+    const bool ok = load_rows<NR>(a.c.y + (size_t)vox * nS, nS, lane, yr);
+    bool rowok[NR];
+    double scl[NQ];
+    unsigned long long allowed[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const int lo = kWave * q;
+        const int cnt = (STAGE == 2 ? n_wm : n_atoms) - lo;
+        allowed[q] = cnt >= 64 ? ~0ull : (cnt > 0 ? ((1ull << cnt) - 1ull) : 0ull);
+        scl[q] = 1.0;
+    }
+    if (!ok) {   // non-finite signal: propagate NaN maps, never iterate (SURVEY 8(b) error convention)
+        if (STAGE == 1 && lane < 2) a.xiso[(size_t)vox * 2 + lane] = __builtin_nan("");
+        if (STAGE == 3 && lane < a.n_maps) a.est[(size_t)vox * a.n_maps + lane] = __builtin_nan("");
+        if (STAGE == 3 && lane == 0) {
+            if (a.rmse) a.rmse[vox] = __builtin_nan("");
+            if (a.nrmse) a.nrmse[vox] = __builtin_nan("");
+            if (a.mod) { a.mod[(size_t)vox * 2] = __builtin_nan(""); a.mod[(size_t)vox * 2 + 1] = __builtin_nan(""); }
+        }
+        if (STAGE == 2 && lane < 4) a.supp[(size_t)vox * 4 + lane] = 0ull;
+    }
+    if (ok) {
+    if (STAGE == 2) {
+        // models.pyx:914-925: y2 = max(0, y_dwi - x_iso*iso_dwi (- x_dot)), columns scaled by norms
+        const double xiso = a.xiso[(size_t)vox * 2], xdot = a.xiso[(size_t)vox * 2 + 1];
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) {
+            const int i = lane + kWave * rr;
+            rowok[rr] = (i < nS) && a.rowdwi[i];
+            double t = 0.0;
+            if (rowok[rr]) {
+                t = yr[rr] - xiso * (double)As[i * ldA + iso_atom];
+                if (a.is_exvivo) t -= xdot * 1.0;
+                if (t < 0.0) t = 0.0;
+            }
+            yr[rr] = t;
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int j = lane + kWave * q;
+            scl[q] = (j < n_atoms) ? a.colscale[j] : 1.0;
+        }
+    } else {
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) rowok[rr] = (lane + kWave * rr) < nS;
+    }
+    if (STAGE == 3) {
+        // models.pyx:929-936: support of the LASSO solution plus iso (and dot)
+#pragma unroll
+        for (int q = 0; q < NQ; q++) allowed[q] = a.supp[(size_t)vox * 4 + q];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            if ((iso_atom >> 6) == q) allowed[q] |= 1ull << (iso_atom & 63);
+            if (dot_atom >= 0 && (dot_atom >> 6) == q) allowed[q] |= 1ull << (dot_atom & 63);
+        }
+    }
+
+    NNSolver<NR, NQ, MAXP, STAGE == 2, float> S;
+    const int st = __builtin_amdgcn_readfirstlane(S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed,
+                           STAGE == 2 ? a.c.lam1 : 0.0, STAGE == 2 ? a.c.lam2 : 0.0, rs, lane,
+                           (a.c.trace && vox < 7) ? a.c.trace + 64 * STAGE + 8 + 8 * vox : nullptr));
+    volatile int *tr = (a.c.trace && vox < 7) ? a.c.trace + 64 * STAGE + 8 + 8 * vox : nullptr;
+    if (tr && lane == 0) tr[7] = 70 + st;
+    if (st == kOverflow) {
+        if (lane == 0) {
+            const int k = atomicAdd(a.c.ovf_count, 1);
+            a.c.ovf_list[k] = vox;
+        }
+    } else {
+    if (st == kIterCap && lane == 0) atomicAdd(&a.c.status[ST_ITCAP], 1);
+    if (st > kIterCap && lane == 0) { atomicAdd(&a.c.status[ST_GUARD], 1); a.c.status[ST_GUARDVOX] = vox * 8 + st; }
+    const bool act = lane < S.np;
+
+    if (STAGE == 1) {
+        const double xi = wave_sum((act && S.idx == iso_atom) ? S.x : 0.0);
+        if (tr && lane == 0) tr[7] = 81;
+        const double xd = wave_sum((act && S.idx == dot_atom) ? S.x : 0.0);
+        if (tr && lane == 0) tr[7] = 82;
+        if (lane == 0) { a.xiso[(size_t)vox * 2] = xi; a.xiso[(size_t)vox * 2 + 1] = xd; }
+        if (tr && lane == 0) tr[7] = 83;
+    } else if (STAGE == 2) {
+        if (lane < 4) wmask[lane] = 0ull;
+        if (act && S.x > 0.0) atomicOr(&wmask[S.idx >> 6], 1ull << (S.idx & 63));
+        if (lane < 4) a.supp[(size_t)vox * 4 + lane] = wmask[lane];
+    } else {
+        // models.pyx:945-967
+        const double xs = act ? S.x : 0.0;
+        const bool iswm = act && S.idx < n_wm;
+        if (tr && lane == 0) tr[7] = 84;
+        const double sum_atoms = wave_sum(xs) + 1e-16;
+        const double sum_wm = wave_sum(iswm ? xs / sum_atoms : 0.0) + 1e-16;
+        double f1 = 0.0, f2 = 0.0, k1 = 0.0;
+        if (iswm) {
+            const float ic = a.icvf[S.idx];
+            const double t = xs / sum_atoms / sum_wm;
+            f1 = (double)ic * t;
+            f2 = (double)((float)(1.0 - (double)ic)) * t;
+            k1 = (double)a.kappa[S.idx] * t;
+        }
+        if (tr && lane == 0) tr[7] = 85;
+        f1 = wave_sum(f1); f2 = wave_sum(f2); k1 = wave_sum(k1);
+        if (tr && lane == 0) tr[7] = 86;
+        const double ndi = f1 / (f1 + f2 + 1e-16);
+        const double odi = 2.0 / 3.14159265358979323846 * atan2(1.0, k1);
+        const double fwf = wave_sum((act && S.idx == iso_atom) ? xs : 0.0) / sum_atoms;
+        const double dot = wave_sum((act && S.idx == dot_atom) ? xs : 0.0) / sum_atoms;
+        double rsq = 0.0, ysq = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) { rsq += S.r[rr] * S.r[rr]; ysq += yr[rr] * yr[rr]; }
+        if (a.c.flags & 3u) { rsq = wave_sum(rsq); ysq = wave_sum(ysq); }
+        if (tr && lane == 0) tr[7] = 87;
+        if (lane == 0) {
+            double *e = a.est + (size_t)vox * a.n_maps;
+            e[0] = ndi; e[1] = odi; e[2] = fwf;
+            if (a.is_exvivo) e[3] = dot;
+            if (a.rmse) a.rmse[vox] = sqrt(rsq / (double)nS);                       // models.pyx:47-54
+            if (a.nrmse) a.nrmse[vox] = (ysq > 1e-16) ? sqrt(rsq / ysq) : 0.0;      // models.pyx:58-71
+            if (a.mod) { const double tf = 1.0 - fwf; a.mod[(size_t)vox * 2] = ndi * tf; a.mod[(size_t)vox * 2 + 1] = odi * tf; }
+        }
+        if (tr && lane == 0) tr[7] = 88;
+    }
+    }   // st != kOverflow
+    }   // ok
+}
+
+// ------------------------------------------------------------------ FreeWater
+struct FwArgs {
+    FitCommon c;
+    int n_perp, n_iso, is_mouse, n_maps;
+    double *est, *rmse, *nrmse, *ycorr;
+};
+
+template <int NR, int NQ, int MAXP>
+__device__ __forceinline__ void fw_voxel(const FwArgs &a, const float *As, double *rs, int vox, int lane)
+{
+    const int nS = a.c.nS, ldA = a.c.ldA, n_atoms = a.c.n_atoms, n_perp = a.n_perp;
+    double yr[NR];
+    const bool ok = load_rows<NR>(a.c.y + (size_t)vox * nS, nS, lane, yr);
+    bool rowok[NR];
+    double scl[NQ];
+    unsigned long long allowed[NQ];
+#pragma unroll
+    for (int rr = 0; rr < NR; rr++) rowok[rr] = (lane + kWave * rr) < nS;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const int cnt = n_atoms - kWave * q;
+        allowed[q] = cnt >= 64 ? ~0ull : (cnt > 0 ? ((1ull << cnt) - 1ull) : 0ull);
+        scl[q] = 1.0;
+    }
+    if (!ok) {
+        if (lane < a.n_maps) a.est[(size_t)vox * a.n_maps + lane] = __builtin_nan("");
+        if (lane == 0 && a.rmse) a.rmse[vox] = __builtin_nan("");
+        if (lane == 0 && a.nrmse) a.nrmse[vox] = __builtin_nan("");
+        if (a.ycorr)
+            for (int i = lane; i < nS; i += kWave) a.ycorr[(size_t)vox * nS + i] = __builtin_nan("");
+    }
+    if (ok) {
+    NNSolver<NR, NQ, MAXP, true, float> S;
+    const int st = __builtin_amdgcn_readfirstlane(S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed, a.c.lam1, a.c.lam2, rs, lane));
+    if (st == kOverflow) {
+        if (lane == 0) { const int k = atomicAdd(a.c.ovf_count, 1); a.c.ovf_list[k] = vox; }
+    } else {
+    if (st == kIterCap && lane == 0) atomicAdd(&a.c.status[ST_ITCAP], 1);
+    if (st > kIterCap && lane == 0) { atomicAdd(&a.c.status[ST_GUARD], 1); a.c.status[ST_GUARDVOX] = vox * 8 + st; }
+    const bool act = lane < S.np;
+    const double xs = act ? S.x : 0.0;
+    // models.pyx:1241-1256
+    const double x_sum = wave_sum(xs) + 1e-16;
+    const double v = wave_sum((act && S.idx < n_perp) ? xs : 0.0) / x_sum;
+    const double vb = wave_sum((act && S.idx == n_perp) ? xs : 0.0) / x_sum;
+    const double vc = wave_sum((act && S.idx == n_perp + 1) ? xs : 0.0) / x_sum;
+    double rsq = 0.0, ysq = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < NR; rr++) { rsq += S.r[rr] * S.r[rr]; ysq += yr[rr] * yr[rr]; }
+    if (a.c.flags & 3u) { rsq = wave_sum(rsq); ysq = wave_sum(ysq); }
+    if (lane == 0) {
+        double *e = a.est + (size_t)vox * a.n_maps;
+        e[0] = v; e[1] = 1.0 - v;
+        if (a.is_mouse) { e[2] = vb; e[3] = vc; }
+        if (a.rmse) a.rmse[vox] = sqrt(rsq / (double)nS);
+        if (a.nrmse) a.nrmse[vox] = (ysq > 1e-16) ? sqrt(rsq / ysq) : 0.0;
+    }
+    if (a.ycorr) {
+        // models.pyx:1264-1274: y - A[:, iso atoms] x_iso, clipped at 0
+        double fw[NR];
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) fw[rr] = 0.0;
+        for (int s = 0; s < S.np; s++) {
+            const int at = bcast_i(S.idx, s);
+            if (at >= n_perp) {
+                const double xv = bcast(S.x, s);
+#pragma unroll
+                for (int rr = 0; rr < NR; rr++) {
+                    const int i = lane + kWave * rr;
+                    if (i < nS) fw[rr] += (double)As[i * ldA + at] * xv;
+                }
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) {
+            const int i = lane + kWave * rr;
+            if (i < nS) { const double yc = yr[rr] - fw[rr]; a.ycorr[(size_t)vox * nS + i] = yc < 0.0 ? 0.0 : yc; }
+        }
+    }
+    }   // st != kOverflow
+    }   // ok
+}
+
+// ------------------------------------------------------------------ SANDI
+struct SandiArgs {
+    FitCommon c;
+    const double *norms, *Rs, *d_in, *d_isos;
+    int n_rs, n_in, n_iso;
+    double *est, *rmse, *nrmse;
+};
+
+template <int NR, int NQ, int MAXP>
+__device__ __forceinline__ void sandi_voxel(const SandiArgs &a, const double *As, double *rs, int vox, int lane)
+{
+    const int nS = a.c.nS, ldA = a.c.ldA, n_atoms = a.c.n_atoms;
+    const int n_rs = a.n_rs, n_in = a.n_in;
+    double yr[NR];
+    const bool ok = load_rows<NR>(a.c.y + (size_t)vox * nS, nS, lane, yr);
+    bool rowok[NR];
+    double scl[NQ];
+    unsigned long long allowed[NQ];
+#pragma unroll
+    for (int rr = 0; rr < NR; rr++) rowok[rr] = (lane + kWave * rr) < nS;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const int cnt = n_atoms - kWave * q;
+        allowed[q] = cnt >= 64 ? ~0ull : (cnt > 0 ? ((1ull << cnt) - 1ull) : 0ull);
+        scl[q] = 1.0;
+    }
+    if (!ok) {
+        if (lane < 6) a.est[(size_t)vox * 6 + lane] = __builtin_nan("");
+        if (lane == 0 && a.rmse) a.rmse[vox] = __builtin_nan("");
+        if (lane == 0 && a.nrmse) a.nrmse[vox] = __builtin_nan("");
+    }
+    if (ok) {
+    NNSolver<NR, NQ, MAXP, true, double> S;
+    const int st = __builtin_amdgcn_readfirstlane(S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed, a.c.lam1, a.c.lam2, rs, lane));
+    if (st == kOverflow) {
+        if (lane == 0) { const int k = atomicAdd(a.c.ovf_count, 1); a.c.ovf_list[k] = vox; }
+    } else {
+    if (st == kIterCap && lane == 0) atomicAdd(&a.c.status[ST_ITCAP], 1);
+    if (st > kIterCap && lane == 0) { atomicAdd(&a.c.status[ST_GUARD], 1); a.c.status[ST_GUARDVOX] = vox * 8 + st; }
+    const bool act = lane < S.np;
+    const int at = act ? S.idx : 0;
+    const double xs = act ? S.x * a.norms[at] : 0.0;                       // models.pyx:1570-1571
+    const bool sph = act && at < n_rs, stk = act && at >= n_rs && at < n_rs + n_in, iso = act && at >= n_rs + n_in;
+    const double x_sum = wave_sum(xs) + 1e-16;
+    double xsph = wave_sum(sph ? xs : 0.0), xstk = wave_sum(stk ? xs : 0.0), xiso = wave_sum(iso ? xs : 0.0);
+    const double Rsoma = wave_sum(sph ? a.Rs[at] * xs : 0.0);
+    const double Din = wave_sum(stk ? a.d_in[at - n_rs] * xs : 0.0);
+    const double De = wave_sum(iso ? a.d_isos[at - n_rs - n_in] * xs : 0.0);
+    if (lane == 0) {
+        double *e = a.est + (size_t)vox * 6;
+        e[0] = xsph / x_sum; e[1] = xstk / x_sum; e[2] = xiso / x_sum;
+        e[3] = 1e6 * Rsoma / (xsph + 1e-16);
+        e[4] = 1e3 * Din / (xstk + 1e-16);
+        e[5] = 1e3 * De / (xiso + 1e-16);
+    }
+    if (a.c.flags & 3u) {
+        // quirk kept (models.pyx:1571 then 1615): errors use the RESCALED x with the NORMALISED A
+        double est[NR];
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) est[rr] = 0.0;
+        for (int s = 0; s < S.np; s++) {
+            const int as = bcast_i(S.idx, s);
+            const double xv = bcast(xs, s);
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++) {
+                const int i = lane + kWave * rr;
+                if (i < nS) est[rr] += As[i * ldA + as] * xv;
+            }
+        }
+        double rsq = 0.0, ysq = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) { const double t = yr[rr] - est[rr]; rsq += t * t; ysq += yr[rr] * yr[rr]; }
+        rsq = wave_sum(rsq); ysq = wave_sum(ysq);
+        if (lane == 0) {
+            if (a.rmse) a.rmse[vox] = sqrt(rsq / (double)nS);
+            if (a.nrmse) a.nrmse[vox] = (ysq > 1e-16) ? sqrt(rsq / ysq) : 0.0;
+        }
+    }
+    }   // st != kOverflow
+    }   // ok
+}
+
+// ------------------------------------------------------------------ kernel skeleton
+// One workgroup = NW wavefronts sharing one dictionary tile in LDS; each wavefront pulls
+// voxels of the chunk from an LDS ticket counter (iteration counts vary per voxel).
+// LIST mode re-runs single voxels (large-MAXP variant): tile staged per voxel.
+template <typename AT, int NQ>
+__device__ __forceinline__ int tile_words(int nS, int ldA) { return nS * ldA; }
+
+#define AMX_KERNEL_PROLOGUE(AT, NRv, NQv, NWv)                                                        \
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                              \
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;                                       \
+    const int words = a.c.nS * a.c.ldA;                                                               \
+    const int words_pad = (words + kWave * NQv + 3) & ~3;                                             \
+    AT *As = reinterpret_cast<AT *>(smem);                                                            \
+    double *rs_all = reinterpret_cast<double *>(smem + (((size_t)words_pad * sizeof(AT) + 15) & ~(size_t)15)); \
+    double *rs = rs_all + wave * (NRv * kWave);                                                       \
+    unsigned long long *wm_all = reinterpret_cast<unsigned long long *>(rs_all + NWv * NRv * kWave);  \
+    unsigned long long *wmask = wm_all + wave * 4;                                                    \
+    int *ticket = reinterpret_cast<int *>(wm_all + NWv * 4);
+
+template <int STAGE, int NR, int NQ, int MAXP, int NW, bool LIST>
+__global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
+{
+    AMX_KERNEL_PROLOGUE(float, NR, NQ, NW)
+    const float *tiles = reinterpret_cast<const float *>(a.c.tiles);
+    if (!LIST) {
+        if ((int)blockIdx.x >= *a.c.n_chunks) return;
+        const Chunk ck = a.c.chunks[blockIdx.x];
+        stage_tile<float>(As, tiles + (size_t)ck.dir * a.c.tile_stride, words, words_pad - words);
+        __syncthreads();
+        // static round-robin over the chunk: wave w takes voxels w, w+NW, ... (purely scalar loop
+        // control; no LDS ticket, no lane-0 atomics in the hot loop)
+        for (int k = wave; k < ck.count; k += NW) {
+            noddi_voxel<STAGE, NR, NQ, MAXP>(a, As, rs, wmask, a.c.perm[ck.start + k], lane);
+        }
+    } else {
+        const int cnt = *a.c.list_count;
+        for (int it = blockIdx.x; it < cnt; it += gridDim.x) {
+            const int vox = a.c.list[it];
+            __syncthreads();
+            stage_tile<float>(As, tiles + (size_t)a.c.lutidx[vox] * a.c.tile_stride, words, words_pad - words);
+            __syncthreads();
+            noddi_voxel<STAGE, NR, NQ, MAXP>(a, As, rs, wmask, vox, lane);
+        }
+    }
+}
+
+template <int NR, int NQ, int MAXP, int NW, bool LIST>
+__global__ void __launch_bounds__(NW * 64) k_freewater(const FwArgs a)
+{
+    AMX_KERNEL_PROLOGUE(float, NR, NQ, NW)
+    (void)wmask;
+    const float *tiles = reinterpret_cast<const float *>(a.c.tiles);
+    if (!LIST) {
+        if ((int)blockIdx.x >= *a.c.n_chunks) return;
+        const Chunk ck = a.c.chunks[blockIdx.x];
+        stage_tile<float>(As, tiles + (size_t)ck.dir * a.c.tile_stride, words, words_pad - words);
+        __syncthreads();
+        // static round-robin over the chunk: wave w takes voxels w, w+NW, ... (purely scalar loop
+        // control; no LDS ticket, no lane-0 atomics in the hot loop)
+        for (int k = wave; k < ck.count; k += NW) {
+            fw_voxel<NR, NQ, MAXP>(a, As, rs, a.c.perm[ck.start + k], lane);
+        }
+    } else {
+        const int cnt = *a.c.list_count;
+        for (int it = blockIdx.x; it < cnt; it += gridDim.x) {
+            const int vox = a.c.list[it];
+            __syncthreads();
+            stage_tile<float>(As, tiles + (size_t)a.c.lutidx[vox] * a.c.tile_stride, words, words_pad - words);
+            __syncthreads();
+            fw_voxel<NR, NQ, MAXP>(a, As, rs, vox, lane);
+        }
+    }
+}
+
+template <int NR, int NQ, int MAXP, int NW, bool LIST>
+__global__ void __launch_bounds__(NW * 64) k_sandi(const SandiArgs a)
+{
+    AMX_KERNEL_PROLOGUE(double, NR, NQ, NW)
+    (void)wmask;
+    const double *tiles = reinterpret_cast<const double *>(a.c.tiles);
+    if (!LIST) {
+        if ((int)blockIdx.x >= *a.c.n_chunks) return;
+        const Chunk ck = a.c.chunks[blockIdx.x];
+        stage_tile<double>(As, tiles, words, words_pad - words);
+        __syncthreads();
+        // static round-robin over the chunk: wave w takes voxels w, w+NW, ... (purely scalar loop
+        // control; no LDS ticket, no lane-0 atomics in the hot loop)
+        for (int k = wave; k < ck.count; k += NW) {
+            volatile int *tw = a.c.trace ? a.c.trace + 4 * (((int)blockIdx.x & 15) * 4 + wave) : nullptr;
+            if (tw && lane == 0) { tw[0] = a.c.perm[ck.start + k]; tw[1] = 1; tw[2] = tw[2] + 1; }
+            sandi_voxel<NR, NQ, MAXP>(a, As, rs, a.c.perm[ck.start + k], lane);
+            if (tw && lane == 0) tw[1] = 2;
+        }
+    } else {
+        const int cnt = *a.c.list_count;
+        stage_tile<double>(As, tiles, words, words_pad - words);
+        __syncthreads();
+        for (int it = blockIdx.x; it < cnt; it += gridDim.x) sandi_voxel<NR, NQ, MAXP>(a, As, rs, a.c.list[it], lane);
+    }
+}
+
+template <typename AT>
+static inline size_t fit_lds_bytes(int nS, int ldA, int NR, int NQ, int NW)
+{
+    const size_t words_pad = ((size_t)nS * ldA + kWave * NQ + 3) & ~(size_t)3;
+    size_t b = (words_pad * sizeof(AT) + 15) & ~(size_t)15;
+    b += (size_t)NW * NR * kWave * sizeof(double);
+    b += (size_t)NW * 4 * sizeof(unsigned long long);
+    b += 16;
+    return b;
+}
+
+}  // namespace amx

@@ -1,0 +1,37 @@
+// amx_launch.hpp -- launch helpers used by the per-model units.  Every unit is compiled on
+// its own (make -j) and carries its own gfx950 code object; nothing is linked device-side.
+#pragma once
+#include "amx_host.hpp"
+
+template <typename K>
+static int set_lds(amx_ctx *ctx, K kern, size_t bytes)
+{
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return AMX_OK;
+}
+
+// main pass over the orientation chunks + re-run of the voxels whose passive set overflowed
+template <typename Args, typename KM, typename KL>
+static int launch_pair(amx_ctx *ctx, Args &a, const Plan &pl, hipStream_t s, KM km, KL kl, size_t lds_main,
+                       size_t lds_list, int slot, int ev)
+{
+    int rc;
+    a.c.ovf_count = pl.ovf_count + slot;
+    a.c.ovf_list = pl.ovf_list + (size_t)slot * pl.n;
+    a.c.list = a.c.ovf_list;
+    a.c.list_count = a.c.ovf_count;
+    if ((rc = set_lds(ctx, km, lds_main))) return rc;
+    if ((rc = set_lds(ctx, kl, lds_list))) return rc;
+    rec(ctx, ev, s);
+    hipLaunchKernelGGL(km, dim3(pl.max_chunks), dim3(kNW * 64), lds_main, s, a);
+    AMX_TRACE(ctx, s, "solver main pass");
+    Args b = a;
+    b.c.ovf_count = pl.ovf_count + 8;
+    b.c.ovf_list = pl.ovf_list + 3 * pl.n;
+    hipLaunchKernelGGL(kl, dim3(kListGrid), dim3(64), lds_list, s, b);
+    AMX_TRACE(ctx, s, "solver re-run pass");
+    rec(ctx, ev + 1, s);
+    HIPCHK(ctx, hipGetLastError());
+    return AMX_OK;
+}

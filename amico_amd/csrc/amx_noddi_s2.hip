@@ -1,0 +1,17 @@
+// amx_noddi_s2.hip -- NODDI solver stage 2 (models.pyx:914-926)
+#include "amx_launch.hpp"
+using namespace amx;
+
+template <int NR>
+static int go(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
+{
+    constexpr int NQ = 3, MP = 24, MB = 64;
+    return launch_pair(ctx, a, pl, s, k_noddi<2, NR, NQ, MP, kNW, false>, k_noddi<2, NR, NQ, MB, 1, true>,
+                       fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, kNW), fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1),
+                       1, 4);
+}
+
+int amx_launch_noddi_s2(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
+{
+    return a.c.nS <= 128 ? go<2>(ctx, a, pl, s) : go<4>(ctx, a, pl, s);
+}

@@ -1,0 +1,133 @@
+// amx_prep.hpp -- small bandwidth kernels around the solvers (included by amx_api.hip only):
+// direction -> LUT index (lut.pyx:316-356), counting sort by orientation, dictionary tiles.
+#pragma once
+#include "amx_kernels.hpp"
+
+namespace amx {
+
+// ------------------------------------------------------------------ lut.pyx:316-356
+__device__ __forceinline__ int dir_to_lut_idx_dev(double d0, double d1, double d2,
+                                                  const short *__restrict__ ht, int &ii1, int &ii2)
+{
+    const double pi = 3.14159265358979323846;
+    if (d1 < 0.0) { d0 = -d0; d1 = -d1; d2 = -d2; }          // on a copy: caller's DIRs stay const
+    double i1, i2 = fmod(atan2(d1, d0), 2.0 * pi);
+    if (i2 < 0.0) i2 = fmod(i2 + 2.0 * pi, 2.0 * pi);
+    if (i2 > pi) {
+        i2 = fmod(atan2(-d1, -d0), 2.0 * pi);
+        i1 = atan2(sqrt(d0 * d0 + d1 * d1), -d2);
+    } else {
+        i1 = atan2(sqrt(d0 * d0 + d1 * d1), d2);
+    }
+    const double r1 = round(i1 / pi * 180.0), r2 = round(i2 / pi * 180.0);
+    if (!(r1 >= -1.0 && r1 <= 181.0) || !(r2 >= -1.0 && r2 <= 181.0)) { ii1 = -1; ii2 = -1; return -1; }
+    ii1 = (int)r1; ii2 = (int)r2;
+    if (ii1 < 0 || ii1 > 180 || ii2 < 0 || ii2 > 180) return -1;
+    return (int)ht[ii1 * 181 + ii2];
+}
+
+__global__ void k_dir_to_lut(const double *__restrict__ dirs, int n, const short *__restrict__ ht,
+                             int ndirs, int *__restrict__ lutidx, int *__restrict__ counts,
+                             int *__restrict__ status)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    int ii1, ii2;
+    int idx = dir_to_lut_idx_dev(dirs[3 * (size_t)v], dirs[3 * (size_t)v + 1], dirs[3 * (size_t)v + 2], ht, ii1, ii2);
+    if (idx < 0 || idx >= ndirs) {
+        idx = -1;
+        const int old = atomicMin(&status[ST_ERRVOX], v);
+        if (old > v) { status[ST_II1] = ii1; status[ST_II2] = ii2; }
+    } else if (counts) {
+        atomicAdd(&counts[idx], 1);
+    }
+    lutidx[v] = idx;
+}
+
+// single block: dir_start = exclusive scan(counts); chunks of <= ch voxels per orientation
+__global__ void k_plan(const int *__restrict__ counts, int ndirs, int ch, int *__restrict__ dir_start,
+                       int *__restrict__ cursor, Chunk *__restrict__ chunks, int *__restrict__ n_chunks)
+{
+    __shared__ int s_off, s_chk;
+    if (threadIdx.x == 0) { s_off = 0; s_chk = 0; }
+    __syncthreads();
+    // ndirs is small (500..32761): a serial scan by one thread per 1024-wide tile is enough
+    for (int base = 0; base < ndirs; base += blockDim.x) {
+        const int dsel = base + threadIdx.x;
+        const int c = (dsel < ndirs) ? counts[dsel] : 0;
+        const int nc = (c + ch - 1) / ch;
+        // block-wide exclusive scans through shared memory (Hillis-Steele on 2 values)
+        __shared__ int sa[1024], sb[1024];
+        sa[threadIdx.x] = c; sb[threadIdx.x] = nc;
+        __syncthreads();
+        for (int off = 1; off < (int)blockDim.x; off <<= 1) {
+            int ta = 0, tb = 0;
+            if ((int)threadIdx.x >= off) { ta = sa[threadIdx.x - off]; tb = sb[threadIdx.x - off]; }
+            __syncthreads();
+            sa[threadIdx.x] += ta; sb[threadIdx.x] += tb;
+            __syncthreads();
+        }
+        const int start = s_off + sa[threadIdx.x] - c;
+        const int cstart = s_chk + sb[threadIdx.x] - nc;
+        if (dsel < ndirs) {
+            dir_start[dsel] = start;
+            cursor[dsel] = 0;
+            for (int k = 0; k < nc; k++) {
+                Chunk ck;
+                ck.dir = dsel; ck.start = start + k * ch;
+                ck.count = (k == nc - 1) ? (c - k * ch) : ch; ck.pad = 0;
+                chunks[cstart + k] = ck;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == blockDim.x - 1) { s_off += sa[threadIdx.x]; s_chk += sb[threadIdx.x]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { dir_start[ndirs] = s_off; *n_chunks = s_chk; }
+}
+
+__global__ void k_bucket(const int *__restrict__ lutidx, int n, const int *__restrict__ dir_start,
+                         int *__restrict__ cursor, int *__restrict__ perm)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const int d = lutidx[v];
+    if (d < 0) return;
+    perm[dir_start[d] + atomicAdd(&cursor[d], 1)] = v;
+}
+
+// contiguous chunks for models without orientations (SANDI)
+__global__ void k_plan_linear(int n, int ch, Chunk *__restrict__ chunks, int *__restrict__ n_chunks,
+                              int *__restrict__ perm)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < n) perm[v] = v;
+    const int nc = (n + ch - 1) / ch;
+    if (v < nc) {
+        Chunk ck; ck.dir = 0; ck.start = v * ch; ck.count = (v == nc - 1) ? n - v * ch : ch; ck.pad = 0;
+        chunks[v] = ck;
+    }
+    if (v == 0) *n_chunks = nc;
+}
+
+// ------------------------------------------------------------------ dictionary tiles
+// out[dir][i][j], j < n_lut from src[j][dir][i]; then n_fix shared columns from fix[c][i]
+// (iso / CSF, or a column of ones when fix_ones[c] != 0); remaining columns zero.
+__global__ void k_build_lut(const float *__restrict__ src, const float *__restrict__ fix,
+                            const int *__restrict__ fix_ones, int n_lut, int n_fix, int ndirs, int nS,
+                            int ldA, int tile_stride, float *__restrict__ out)
+{
+    const size_t per = (size_t)nS * ldA, tot = (size_t)ndirs * per;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < tot; o += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(o % ldA);
+        const int i = (int)((o / ldA) % nS);
+        const int dsel = (int)(o / per);
+        float val = 0.f;
+        if (j < n_lut) val = src[((size_t)j * ndirs + dsel) * nS + i];
+        else if (j < n_lut + n_fix) val = fix_ones[j - n_lut] ? 1.0f : fix[(size_t)(j - n_lut) * nS + i];
+        out[(size_t)dsel * tile_stride + (o - (size_t)dsel * per)] = val;
+    }
+}
+
+
+}  // namespace amx

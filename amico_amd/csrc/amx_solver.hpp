@@ -1,0 +1,406 @@
+// amx_solver.hpp -- one-wavefront-per-voxel non-negative (elastic-net) least squares for gfx950.
+//
+// Replaces the per-voxel calls cyspams.interfaces.nnls / .lasso of the reference
+// (amico/models.pyx:911, 926, 940, 1238, 1569) by ONE device routine:
+//
+//     min_x  1/2 || y - A diag(s) x ||^2 + lambda1 * sum(x) + lambda2/2 * ||x||^2 ,  x >= 0
+//
+// solved to the KKT point by an active-set method in A-space (never on the Gram matrix:
+// the AMICO dictionaries are numerically rank deficient, cond(A) ~ 1e20, passive sets
+// reach cond ~ 1e6..1e8, so normal equations lose the support decisions the reference's
+// QR-based Lawson-Hanson solver gets right -- see DESIGN.md "Why not Gram space").
+//
+// Mapping onto a 64-lane wavefront
+//   * dictionary slice A (nS x n_atoms) of the voxel's orientation: staged once per
+//     workgroup in LDS, row-major with an ODD leading dimension (conflict-free both for
+//     the row sweep of the gradient and for column gathers);
+//   * "row space"  : lane l owns signal rows l, l+64, ...   (NR rows per lane)
+//   * "atom space" : lane l owns atoms      l, l+64, ...   (NQ atoms per lane)
+//   * "slot space" : lane s owns the s-th passive atom (its coefficient, one row of the
+//     triangular factor R, one augmented ridge row of Q);
+//   * thin QR of the passive columns kept in REGISTERS: Q[k][NR] (row space), built by
+//     blocked classical Gram-Schmidt with re-orthogonalisation, down-dated by Givens
+//     rotations when an atom leaves;
+//   * gradient w = s * A'(y - A s x) - lambda1: one LDS sweep of A per outer iteration,
+//     fp32 storage, fp64 accumulation; arg-max / sums by DPP wavefront reductions;
+//   * ridge term: the sqrt(lambda2) identity rows of the augmented system only touch
+//     passive atoms, so they live in slot space (Qa); the l1 term needs e = R^-T 1.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace amx {
+
+constexpr int kWave = 64;
+
+enum SolveStatus : int { kSolved = 0, kOverflow = 1, kIterCap = 2, kGuardSelect = 3, kGuardOuter = 4 };
+
+// ------------------------------------------------------------------ wavefront primitives
+__device__ __forceinline__ double bcast(double v, int l)   // l must be wave-uniform
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int bcast_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
+template <int CTRL, int ROWM, int BANKM>
+__device__ __forceinline__ double dpp_move(double v, double ident)
+{
+    // lanes whose source is invalid or masked off keep `ident`
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(ident), __double2loint(v), CTRL, ROWM, BANKM, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(ident), __double2hiint(v), CTRL, ROWM, BANKM, false);
+    return __hiloint2double(hi, lo);
+}
+// DPP controls (GFX9 family): row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143
+__device__ __forceinline__ double wave_sum(double v)
+{
+    double t = v + dpp_move<0x111, 0xf, 0xf>(v, 0.0);
+    t += dpp_move<0x112, 0xf, 0xf>(v, 0.0);
+    t += dpp_move<0x113, 0xf, 0xf>(v, 0.0);
+    t += dpp_move<0x114, 0xf, 0xe>(t, 0.0);
+    t += dpp_move<0x118, 0xf, 0xc>(t, 0.0);
+    t += dpp_move<0x142, 0xa, 0xf>(t, 0.0);
+    t += dpp_move<0x143, 0xc, 0xf>(t, 0.0);
+    return bcast(t, 63);
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+    const double ninf = -__builtin_huge_val();
+    double t = fmax(v, dpp_move<0x111, 0xf, 0xf>(v, ninf));
+    t = fmax(t, dpp_move<0x112, 0xf, 0xf>(v, ninf));
+    t = fmax(t, dpp_move<0x113, 0xf, 0xf>(v, ninf));
+    t = fmax(t, dpp_move<0x114, 0xf, 0xe>(t, ninf));
+    t = fmax(t, dpp_move<0x118, 0xf, 0xc>(t, ninf));
+    t = fmax(t, dpp_move<0x142, 0xa, 0xf>(t, ninf));
+    t = fmax(t, dpp_move<0x143, 0xc, 0xf>(t, ninf));
+    return bcast(t, 63);
+}
+__device__ __forceinline__ double wave_min(double v) { return -wave_max(-v); }
+
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __ballot(p); }
+// wave-uniform predicate as a scalar (SGPR) value: makes the branch on it a scalar branch
+__device__ __forceinline__ bool uni(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
+
+// value of lane+1 (used to compact slot space after an atom left)
+__device__ __forceinline__ double from_next_lane(double v) { return __shfl_down(v, 1, kWave); }
+__device__ __forceinline__ int from_next_lane(int v) { return __shfl_down(v, 1, kWave); }
+
+// ------------------------------------------------------------------ the solver
+// NR   rows per lane   (nS      <= 64*NR)
+// NQ   atoms per lane  (n_atoms <= 64*NQ)
+// MAXP capacity of the passive set (slot space, <= 64)
+// RIDGE lambda2 > 0 (augmented rows kept); AT storage type of A in LDS
+template <int NR, int NQ, int MAXP, bool RIDGE, typename AT>
+struct NNSolver {
+    static_assert(MAXP <= kWave, "passive set lives in the lanes of one wavefront");
+    // thin QR of the passive columns
+    double Q[MAXP][NR];   // row space: Q[k][r] = q_k(row lane+64r)
+    double Qa[MAXP];      // slot space (RIDGE): entry of q_k in the ridge row of this slot's atom
+    double Rr[MAXP];      // lane i: row i of R (entries c >= i)
+    double d, e, rinv;    // lane i: (Q'y)_i, (R^-T 1)_i, 1/R_ii
+    double x, sc;         // lane s: coefficient and column scale of slot s
+    int idx;              // lane s: atom of slot s
+    int np;               // passive-set size (uniform)
+    double r[NR];         // row space: residual y - A s x at exit
+    int iters;
+
+    // fl: per-lane atom flags (bit q: allowed, bit 8+q: passive, bit 16+q: banned) of atom lane+64q
+    __device__ __forceinline__ void remove_slot(int k, int lane, unsigned &fl)
+    {
+        const int a = bcast_i(idx, k);
+        if (lane == (a & 63)) fl &= ~(0x100u << (a >> 6));
+        // re-triangularise R without column k: rotate rows (j, j+1), j = k .. np-2
+#pragma unroll
+        for (int j = 0; j < MAXP - 1; j++) {
+            if (j >= k && j < np - 1) {
+                const double ga = bcast(Rr[j + 1], j), gb = bcast(Rr[j + 1], j + 1);
+                const double rr = sqrt(ga * ga + gb * gb);
+                const double c = (rr > 0.0) ? ga / rr : 1.0, s = (rr > 0.0) ? gb / rr : 0.0;
+#pragma unroll
+                for (int m = j + 1; m < MAXP; m++) {
+                    if (m < np) {
+                        const double up = bcast(Rr[m], j), lo = bcast(Rr[m], j + 1);
+                        const double nu = c * up + s * lo, nl = c * lo - s * up;
+                        Rr[m] = (lane == j) ? nu : ((lane == j + 1) ? nl : Rr[m]);
+                    }
+                }
+#pragma unroll
+                for (int rr_ = 0; rr_ < NR; rr_++) {
+                    const double q0 = Q[j][rr_], q1 = Q[j + 1][rr_];
+                    Q[j][rr_] = c * q0 + s * q1;
+                    Q[j + 1][rr_] = c * q1 - s * q0;
+                }
+                if (RIDGE) {
+                    const double q0 = Qa[j], q1 = Qa[j + 1];
+                    Qa[j] = c * q0 + s * q1;
+                    Qa[j + 1] = c * q1 - s * q0;
+                }
+                {
+                    const double d0 = bcast(d, j), d1 = bcast(d, j + 1);
+                    const double e0 = bcast(e, j), e1 = bcast(e, j + 1);
+                    if (lane == j) { d = c * d0 + s * d1; e = c * e0 + s * e1; rinv = 1.0 / rr; }
+                    if (lane == j + 1) { d = c * d1 - s * d0; e = c * e1 - s * e0; }
+                }
+            }
+        }
+        // columns k+1.. move one to the left (rows stay in their lanes)
+#pragma unroll
+        for (int m = 0; m < MAXP - 1; m++)
+            if (m >= k) Rr[m] = Rr[m + 1];
+        // slot-indexed data of lanes > k move one lane down
+        {
+            const double xn = from_next_lane(x), sn = from_next_lane(sc);
+            const int in = from_next_lane(idx);
+            if (lane >= k) { x = xn; sc = sn; idx = in; }
+            if (RIDGE) {
+#pragma unroll
+                for (int m = 0; m < MAXP; m++) {
+                    const double qn = from_next_lane(Qa[m]);
+                    if (lane >= k) Qa[m] = qn;
+                }
+            }
+        }
+        np = __builtin_amdgcn_readfirstlane(np - 1);
+        if (lane >= np) {
+            x = 0.0; d = 0.0; e = 0.0; idx = -1;
+            if (RIDGE) {
+#pragma unroll
+                for (int m = 0; m < MAXP; m++) Qa[m] = 0.0;
+            }
+        }
+        if (RIDGE) {
+#pragma unroll
+            for (int m = 0; m < MAXP; m++)
+                if (m >= np) Qa[m] = 0.0;
+        }
+    }
+
+    // yr     row space, 0 on rows >= nS and on rows excluded by rowok
+    // rowok  row space, rows that belong to the problem
+    // scl    atom space column scales, allowed[q] uniform bit masks of admissible atoms
+    // rs     per-wave LDS scratch of NR*64 doubles
+    // Control flow is wave-uniform by construction; every branch condition goes through uni()
+    // (v_readfirstlane) so that the compiler emits scalar branches and never masks EXEC around
+    // the cross-lane operations.
+    __device__ __forceinline__ int solve(const AT *As, int ldA, int nS, int n_atoms,
+                                         const double (&yr)[NR], const bool (&rowok)[NR],
+                                         const double (&scl)[NQ],
+                                         const unsigned long long (&allowed)[NQ],
+                                         double lam1, double lam2, double *rs, int lane,
+                                         volatile int *trace = nullptr)
+    {
+#define AMX_TR(slot, val) do { if (trace && lane == 0) { trace[slot] = (val); } } while (0)
+        const double tol = 1e-12;            // KKT tolerance on the dual vector
+        const double dep2 = 1e-20;           // (1e-10)^2: relative independence of a new column
+        const double inf = __builtin_huge_val();
+        const int itmax = 3 * n_atoms + 10;  // Lawson-Hanson's cap
+        const double sqlam2 = RIDGE ? sqrt(lam2) : 0.0;
+        // atom flags live per lane (VGPR bits), not as wave-uniform 64-bit masks: keeps SGPRs free
+        unsigned fl = 0u;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) fl |= (unsigned)((allowed[q] >> lane) & 1ull) << q;
+        np = 0; d = 0.0; e = 0.0; rinv = 0.0; x = 0.0; sc = 1.0; idx = -1; iters = 0;
+        if (RIDGE) {
+#pragma unroll
+            for (int m = 0; m < MAXP; m++) Qa[m] = 0.0;
+        }
+        int status = kSolved;
+        int last_added = -1;
+
+        for (int outer = 0; status == kSolved; ++outer) {
+            if (outer > 2 * itmax) { status = kGuardOuter; break; }   // never spin
+            AMX_TR(1, outer); AMX_TR(2, np); AMX_TR(0, 10);
+            // ---- residual of the current passive least-squares solution: r = y - Q (d - l1 e)
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++) r[rr] = yr[rr];
+            {
+                const double coef = d - lam1 * e;
+#pragma unroll
+                for (int k = 0; k < MAXP; k++) {
+                    if (k < np) {
+                        const double ck = bcast(coef, k);
+#pragma unroll
+                        for (int rr = 0; rr < NR; rr++) r[rr] -= Q[k][rr] * ck;
+                    }
+                }
+            }
+            // ---- dual vector w = s * A' r - l1 (atom space): one sweep over the LDS tile
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++) rs[lane + kWave * rr] = r[rr];
+            double w[NQ], w2[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; q++) { w[q] = 0.0; w2[q] = 0.0; }
+            {
+                const AT *ap = As + lane;
+                int i = 0;
+                for (; i + 1 < nS; i += 2) {
+                    const double r0 = rs[i], r1 = rs[i + 1];
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) {
+                        w[q] += (double)ap[i * ldA + kWave * q] * r0;
+                        w2[q] += (double)ap[(i + 1) * ldA + kWave * q] * r1;
+                    }
+                }
+                if (i < nS) {
+                    const double r0 = rs[i];
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) w[q] += (double)ap[i * ldA + kWave * q] * r0;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; q++) w[q] = scl[q] * (w[q] + w2[q]) - lam1;
+            AMX_TR(0, 20);
+
+            // ---- pick the most violating admissible atom; test it; maybe take the next one
+            bool added = false;
+            for (int sel = 0; status == kSolved && !added; ++sel) {
+                if (sel > kWave * NQ + 2) { status = kGuardSelect; break; }
+                double best = -inf;
+                int bj = -1;
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    const bool cand = ((fl >> q) & 1u) && !((fl >> (8 + q)) & 1u) && !((fl >> (16 + q)) & 1u);
+                    if (cand && w[q] > best) { best = w[q]; bj = lane + kWave * q; }
+                }
+                const double wmax = wave_max(best);
+                if (!uni(wmax > tol)) break;                      // KKT point reached
+                const unsigned long long who = ballot64(best == wmax);
+                if (uni(who == 0ull)) { status = kGuardSelect; break; }
+                const int t = bcast_i(bj, __builtin_ctzll(who));
+                if (uni(t < 0 || t >= n_atoms)) { status = kGuardSelect; break; }
+                if (np >= MAXP) { status = kOverflow; break; }
+                const int tq = t >> 6, tl = t & 63;
+                double sct = 0.0;
+#pragma unroll
+                for (int q = 0; q < NQ; q++)
+                    if (q == tq) sct = bcast(scl[q], tl);
+                // candidate column (row space) and its ridge rows (slot space)
+                double v[NR];
+                double vsq = 0.0;
+#pragma unroll
+                for (int rr = 0; rr < NR; rr++) {
+                    const int i = lane + kWave * rr;
+                    v[rr] = (i < nS && rowok[rr]) ? sct * (double)As[i * ldA + t] : 0.0;
+                    vsq += v[rr] * v[rr];
+                }
+                double va = (RIDGE && lane == np) ? sqlam2 : 0.0;
+                const double n0 = wave_sum(vsq) + lam2;
+                double rho = 0.0;                 // lane k: R[k][new]
+                // two Gram-Schmidt passes, 4 projections in flight at a time
+#pragma unroll
+                for (int pass = 0; pass < 2; pass++) {
+#pragma unroll
+                    for (int kb = 0; kb < MAXP; kb += 4) {
+                        if (kb < np) {
+                            double p[4];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                p[u] = 0.0;
+                                if (kb + u < MAXP && kb + u < np) {
+#pragma unroll
+                                    for (int rr = 0; rr < NR; rr++) p[u] += Q[kb + u][rr] * v[rr];
+                                    if (RIDGE) p[u] += Qa[kb + u] * va;
+                                }
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; u++)
+                                if (kb + u < MAXP && kb + u < np) p[u] = wave_sum(p[u]);
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                if (kb + u < MAXP && kb + u < np) {
+#pragma unroll
+                                    for (int rr = 0; rr < NR; rr++) v[rr] -= p[u] * Q[kb + u][rr];
+                                    if (RIDGE) va -= p[u] * Qa[kb + u];
+                                    if (lane == kb + u) rho += p[u];
+                                }
+                            }
+                        }
+                    }
+                }
+                vsq = va * va;
+#pragma unroll
+                for (int rr = 0; rr < NR; rr++) vsq += v[rr] * v[rr];
+                const double b2 = wave_sum(vsq);
+                bool reject = !uni(b2 > dep2 * n0);
+                double beta = 0.0, binv = 0.0, dnew = 0.0, enew = 0.0;
+                if (!reject) {
+                    beta = sqrt(b2);
+                    binv = 1.0 / beta;
+                    double vy = 0.0;
+#pragma unroll
+                    for (int rr = 0; rr < NR; rr++) vy += v[rr] * yr[rr];
+                    dnew = wave_sum(vy) * binv;
+                    enew = (1.0 - wave_sum((lane < np) ? rho * e : 0.0)) * binv;
+                    const double znew = (dnew - lam1 * enew) * binv;   // Lawson-Hanson "ztest"
+                    reject = !uni(znew > 0.0);
+                }
+                if (reject) {
+                    if (lane == tl) fl |= 0x10000u << tq;
+                } else {
+                    // ---- commit column np
+                    const int kn = np;
+#pragma unroll
+                    for (int m = 0; m < MAXP; m++) {
+                        if (m == kn) {
+#pragma unroll
+                            for (int rr = 0; rr < NR; rr++) Q[m][rr] = v[rr] * binv;
+                            Rr[m] = (lane == kn) ? beta : rho;
+                            if (RIDGE) Qa[m] = (lane <= kn) ? va * binv : 0.0;
+                        }
+                    }
+                    if (lane == kn) { d = dnew; e = enew; rinv = binv; x = 0.0; sc = sct; idx = t; }
+                    fl &= 0xffffu;                               // forget the rejected candidates
+                    if (lane == tl) fl |= 0x100u << tq;
+                    np = kn + 1;
+                    last_added = t;
+                    added = true;
+                }
+            }
+            if (!added) break;   // KKT point (or a guard tripped)
+
+            // ---- Lawson-Hanson inner loop: restore feasibility of the passive solution
+            for (bool feasible = false; !feasible && status == kSolved;) {
+                if (++iters > itmax) { status = kIterCap; break; }
+                AMX_TR(4, iters); AMX_TR(0, 40);
+                double rhs = d - lam1 * e, z = 0.0;
+#pragma unroll
+                for (int j = MAXP - 1; j >= 0; j--) {
+                    if (j < np) {
+                        const double zj = bcast(rhs * rinv, j);
+                        if (lane == j) z = zj;
+                        if (lane < j) rhs -= Rr[j] * zj;
+                    }
+                }
+                const bool act = lane < np;
+                const bool neg = act && !(z > 0.0);
+                if (ballot64(neg) == 0ull) {
+                    x = act ? z : 0.0;
+                    feasible = true;
+                } else {
+                    const double den = x - z;
+                    const double ratio = neg ? ((den > 0.0) ? x / den : 0.0) : inf;
+                    const double alpha = wave_min(ratio);
+                    const unsigned long long hit = ballot64(neg && ratio == alpha);
+                    const int kmin = hit ? __builtin_ctzll(hit) : -1;
+                    x = act ? x + alpha * (z - x) : 0.0;
+                    if (lane == kmin) x = 0.0;
+                    unsigned long long rem = ballot64(act && !(x > 0.0));
+                    for (int guard = 0; rem != 0ull && guard < kWave; ++guard) {
+                        const int k = 63 - __builtin_clzll(rem);
+                        rem &= ~(1ull << k);
+                        const int a = bcast_i(idx, k);
+                        if (a == last_added && lane == (a & 63)) fl |= 0x10000u << (a >> 6);   // no add/remove cycling
+                        remove_slot(k, lane, fl);
+                    }
+                    if (np == 0) { x = 0.0; feasible = true; }
+                }
+            }
+        }
+        AMX_TR(0, 99); AMX_TR(6, status);
+        return status;
+#undef AMX_TR
+    }
+};
+
+}  // namespace amx

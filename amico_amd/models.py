@@ -1,0 +1,230 @@
+"""Model plug-ins with the surface of ``amico.models`` (amico/models.pyx:75-217, 655-991,
+995-1286, 1344-1627): same names, constructor defaults, ``set`` / ``get_params`` /
+``set_solver`` and ``fit(evaluation) -> dict``; the per-voxel work is done by the HIP library
+through the C ABI (``amico_amd._capi``).  LUT generation / resampling (``generate``,
+``resample``) is out of scope of this path: dictionaries arrive as the reference's
+``KERNELS`` dict (``amico_amd.synthetic`` builds realistic ones for tests and benchmarks).
+"""
+from abc import ABC, abstractmethod
+import numpy as np
+from . import _capi
+
+_CTX = None
+
+
+def get_context():
+    """process-wide amx_ctx on the current HIP device (created on first use)"""
+    global _CTX
+    if _CTX is None:
+        _CTX = _capi.Context(-1)
+    return _CTX
+
+
+class BaseModel(ABC):
+    """models.pyx:75-217"""
+
+    @abstractmethod
+    def __init__(self):
+        self.id = 'BaseModel'
+        self.name = 'Base Model'
+        self.maps_name = []
+        self.maps_descr = []
+        self.scheme = None
+
+    @abstractmethod
+    def set(self, *args, **kwargs):
+        return
+
+    @abstractmethod
+    def get_params(self):
+        return
+
+    @abstractmethod
+    def set_solver(self):
+        self.solver_params = {}
+
+    def generate(self, out_path, aux, idx_in, idx_out, ndirs):
+        raise NotImplementedError('LUT generation is outside the MI355X fit path (SURVEY.md 8(f) row 4)')
+
+    def resample(self, in_path, idx_out, Ylm_out, doMergeB0, ndirs):
+        raise NotImplementedError('LUT resampling is outside the MI355X fit path (SURVEY.md 8(f) row 4)')
+
+    @abstractmethod
+    def fit(self, evaluation):
+        # models.pyx:204-217: chunks are only kept for introspection -- the GPU path shards
+        # nothing across host threads, results are voxel-order identical by construction
+        n = evaluation.y.shape[0]
+        nthreads = max(1, int(evaluation.nthreads or 1))
+        c = max(1, n // nthreads)
+        self.chunks = [(i, j) for i, j in zip(range(0, n, c), range(c, n + 1, c))]
+        if self.chunks and self.chunks[-1][1] != n:
+            self.chunks[-1] = (self.chunks[-1][0], n)
+        self.configs = {
+            'compute_rmse': evaluation.get_config('doComputeRMSE'),
+            'compute_nrmse': evaluation.get_config('doComputeNRMSE'),
+        }
+
+    # ---- dictionary cache: one upload per (KERNELS, htable) object pair
+    def _lut(self, evaluation, builder):
+        key = (id(evaluation.KERNELS), id(getattr(evaluation, 'htable', None)))
+        cache = getattr(self, '_lut_cache', None)
+        if cache is None or cache[0] != key:
+            if evaluation.KERNELS.get('model') != self.id:
+                raise ValueError('Response functions were not created with the same model')
+            self._lut_cache = (key, builder())
+        return self._lut_cache[1]
+
+
+class NODDI(BaseModel):
+    """models.pyx:655-991"""
+
+    def __init__(self):
+        self.id = 'NODDI'
+        self.name = 'NODDI'
+        self.maps_name = ['NDI', 'ODI', 'FWF']
+        self.maps_descr = ['Neurite Density Index', 'Orientation Dispersion Index', 'Free Water Fraction']
+        self.scheme = None
+        self.set()
+        self.set_solver()
+
+    def set(self, dPar=1.7E-3, dIso=3.0E-3, IC_VFs=np.linspace(0.1, 0.99, 12),
+            IC_ODs=np.hstack((np.array([0.03, 0.06]), np.linspace(0.09, 0.99, 10))), isExvivo=False):
+        self.dPar = dPar
+        self.dIso = dIso
+        self.IC_VFs = np.array(IC_VFs) if isinstance(IC_VFs, list) else IC_VFs
+        self.IC_ODs = np.array(IC_ODs) if isinstance(IC_ODs, list) else IC_ODs
+        self.isExvivo = isExvivo
+        if isExvivo:
+            self.maps_name.append('dot')
+            self.maps_descr.append('Dot volume fraction')
+
+    def get_params(self):
+        return {'id': self.id, 'name': self.name, 'dPar': self.dPar, 'dIso': self.dIso, 'IC_VFs': self.IC_VFs,
+                'IC_ODs': self.IC_ODs, 'isExvivo': self.isExvivo}
+
+    def set_solver(self, lambda1=5e-1, lambda2=1e-3):
+        super().set_solver()
+        self.solver_params['lambda1'] = lambda1
+        self.solver_params['lambda2'] = lambda2
+
+    def fit(self, evaluation):
+        super().fit(evaluation)
+        self.configs['compute_modulated_maps'] = evaluation.get_config('doSaveModulatedMaps')
+        ctx = get_context()
+        n_wm = len(self.IC_ODs) * len(self.IC_VFs)
+        if evaluation.KERNELS['wm'].shape[0] != n_wm:
+            raise ValueError('KERNELS do not match IC_VFs / IC_ODs of the model')
+        lut = self._lut(evaluation, lambda: _capi.upload_noddi(ctx, evaluation.KERNELS, evaluation.htable,
+                                                               self.scheme.dwi_idx, self.isExvivo))
+        est, rmse, nrmse, mod = _capi.noddi_fit(
+            ctx, lut, evaluation.y, evaluation.DIRs, self.solver_params['lambda1'], self.solver_params['lambda2'],
+            len(self.maps_name), rmse=bool(self.configs['compute_rmse']), nrmse=bool(self.configs['compute_nrmse']),
+            mod=bool(self.configs['compute_modulated_maps']))
+        results = {'estimates': est}
+        if self.configs['compute_rmse']:
+            results['rmse'] = rmse
+        if self.configs['compute_nrmse']:
+            results['nrmse'] = nrmse
+        if self.configs['compute_modulated_maps']:
+            results['estimates_mod'] = mod
+        return results
+
+
+class FreeWater(BaseModel):
+    """models.pyx:995-1286"""
+
+    def __init__(self):
+        self.id = 'FreeWater'
+        self.name = 'Free-Water'
+        self.scheme = None
+        self.set()
+        self.set_solver()
+
+    def set(self, d_par=None, d_perps=None, d_isos=None, type='Human'):
+        self.type = type
+        if self.type == 'Mouse':
+            self.maps_name = ['FiberVolume', 'FW', 'FW_blood', 'FW_csf']
+            self.maps_descr = ['fiber volume fraction', 'Isotropic free-water volume fraction', 'FW blood', 'FW csf']
+            self.d_par = 1.0E-3 if d_par is None else d_par
+            self.d_perps = np.linspace(0.15, 0.55, 10) * 1E-3 if d_perps is None else d_perps
+            self.d_isos = [1.5E-3, 3E-3] if d_isos is None else d_isos
+        else:
+            self.maps_name = ['FiberVolume', 'FW']
+            self.maps_descr = ['fiber volume fraction', 'Isotropic free-water volume fraction']
+            self.d_par = 1.0E-3 if d_par is None else d_par
+            self.d_perps = np.linspace(0.1, 1.0, 10) * 1E-3 if d_perps is None else d_perps
+            self.d_isos = [2.5E-3] if d_isos is None else d_isos
+
+    def get_params(self):
+        return {'id': self.id, 'name': self.name, 'd_par': self.d_par, 'd_perps': self.d_perps,
+                'd_isos': self.d_isos, 'type': self.type}
+
+    def set_solver(self, lambda1=0.0, lambda2=1e-3):
+        super().set_solver()
+        self.solver_params['lambda1'] = lambda1
+        self.solver_params['lambda2'] = lambda2
+        # NB: the reference assigns lambda2 = 0.25 for Mouse to a dead local (models.pyx:1082-1085):
+        # it has no effect there and therefore none here.
+
+    def fit(self, evaluation):
+        super().fit(evaluation)
+        self.configs['save_corrected_DWI'] = evaluation.get_config('doSaveCorrectedDWI')
+        ctx = get_context()
+        lut = self._lut(evaluation, lambda: _capi.upload_freewater(ctx, evaluation.KERNELS, evaluation.htable))
+        est, rmse, nrmse, yc = _capi.freewater_fit(
+            ctx, lut, evaluation.y, evaluation.DIRs, self.solver_params['lambda1'], self.solver_params['lambda2'],
+            self.type == 'Mouse', rmse=bool(self.configs['compute_rmse']), nrmse=bool(self.configs['compute_nrmse']),
+            corrected=bool(self.configs['save_corrected_DWI']))
+        results = {'estimates': est}
+        if self.configs['compute_rmse']:
+            results['rmse'] = rmse
+        if self.configs['compute_nrmse']:
+            results['nrmse'] = nrmse
+        if self.configs['save_corrected_DWI']:
+            results['y_corrected'] = yc
+        return results
+
+
+class SANDI(BaseModel):
+    """models.pyx:1344-1627"""
+
+    def __init__(self):
+        self.id = 'SANDI'
+        self.name = 'SANDI'
+        self.maps_name = ['fsoma', 'fneurite', 'fextra', 'Rsoma', 'Din', 'De']
+        self.maps_descr = ['Intra-soma volume fraction', 'Intra-neurite volume fraction',
+                           'Extra-cellular volume fraction', 'Apparent soma radius', 'Neurite axial diffusivity',
+                           'Extra-cellular mean diffusivity']
+        self.scheme = None
+        self.set()
+        self.set_solver()
+
+    def set(self, d_is=3.0E-3, Rs=np.linspace(1.0, 12.0, 5) * 1E-6, d_in=np.linspace(0.25, 3.0, 5) * 1E-3,
+            d_isos=np.linspace(0.25, 3.0, 5) * 1E-3):
+        self.d_is = d_is
+        self.Rs = np.array(Rs)
+        self.d_in = np.array(d_in)
+        self.d_isos = np.array(d_isos)
+
+    def get_params(self):
+        return {'id': self.id, 'name': self.name, 'd_is': self.d_is, 'Rs': self.Rs, 'd_in': self.d_in,
+                'd_isos': self.d_isos}
+
+    def set_solver(self, lambda1=0.0, lambda2=5.0E-3):
+        super().set_solver()
+        self.solver_params['lambda1'] = lambda1
+        self.solver_params['lambda2'] = lambda2
+
+    def fit(self, evaluation):
+        super().fit(evaluation)
+        ctx = get_context()
+        lut = self._lut(evaluation, lambda: _capi.upload_sandi(ctx, evaluation.KERNELS, self.Rs, self.d_in, self.d_isos))
+        est, rmse, nrmse = _capi.sandi_fit(ctx, lut, evaluation.y, self.solver_params['lambda1'],
+                                           self.solver_params['lambda2'], rmse=bool(self.configs['compute_rmse']),
+                                           nrmse=bool(self.configs['compute_nrmse']))
+        results = {'estimates': est}
+        if self.configs['compute_rmse']:
+            results['rmse'] = rmse
+        if self.configs['compute_nrmse']:
+            results['nrmse'] = nrmse
+        return results

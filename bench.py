@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""bench.py -- NODDI fit throughput on MI355X (BASELINE.json metric: voxels/sec, whole node).
+
+A "step" is one pass of the whole hot path (direction -> LUT index, bucketing, the three
+solver stages, maps) over one batch of synthetic voxels that is already resident in HBM.
+Workload at N=1 (BASELINE.json configs[1]): NODDI, 1 M masked voxels, 99-volume 2-shell
+scheme (9 b0 + 30 @ b700 + 60 @ b2000), 145 atoms, 500 LUT orientations.  With --gpus N each
+rank fits its own 1 M-voxel shard (weak scaling) and one RCCL all_gather of the maps ends
+every step.
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BYTES_PER_VOXEL = 8 * 99 + 24 + 24          # y f64[99] + DIRs f64[3] + 3 maps f64 = 840 B
+HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--voxels', type=int, default=1_000_000, help='voxels per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from amico_amd import _capi, synthetic as S
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the fit path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)     # "nccl" is RCCL on ROCm
+
+    n = args.voxels
+    # ---- synthetic workload (same dictionary on every rank, different voxels per rank)
+    lut_dirs = S.fibonacci_hemisphere(500)
+    htable = S.build_htable(lut_dirs)
+    scheme = S.make_scheme(seed=0)
+    K = S.noddi_kernels(scheme, lut_dirs)
+    y_h, d_h = S.noddi_signals(n, K, htable, scheme, seed=1 + rank)
+
+    ctx = _capi.Context(local_rank)
+    lut = _capi.upload_noddi(ctx, K, htable, scheme.dwi_idx, False)
+    y = torch.from_numpy(y_h).to(dev)
+    d = torch.from_numpy(d_h).to(dev)
+    est = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+    gathered = torch.zeros((world * n, 3), dtype=torch.float64, device=dev) if world > 1 else None
+    stream = torch.cuda.current_stream().cuda_stream
+    L = _capi.lib()
+    ctx.set_profiling(True)
+
+    def step():
+        ctx.check(L.amx_noddi_fit_device(ctx._h, lut._h, y.data_ptr(), d.data_ptr(), n, 0.5, 1e-3, 0,
+                                         est.data_ptr(), None, None, None, stream))
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, est)      # the single collective of the path
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+        ctx.sync(stream)
+    barrier()
+    t0 = time.perf_counter()
+    kms = np.zeros(4)
+    for _ in range(args.steps):
+        step()
+        ctx.sync(stream)                                    # status of the step (raises on error)
+        kms += [ctx.last_kernel_ms(w) for w in range(4)]    # HIP events on the launch stream
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kms /= max(1, args.steps)
+    stats = ctx.last_stats()
+
+    if rank == 0:
+        value = world * n * args.steps / elapsed
+        stage = int(np.argmax(kms[1:4])) + 1
+        dom_ms = float(kms[stage])
+        achieved = BYTES_PER_VOXEL * n / (dom_ms * 1e-3) / 1e9
+        out = {
+            'metric': 'voxels/sec (whole node), NODDI fit',
+            'value': value, 'unit': 'voxels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'NODDI fit, %d masked voxels per GPU, 99-volume 2-shell scheme '
+                                   '(9 b0 + 30@b700 + 60@b2000), 145 atoms, ndirs=500, inputs resident in HBM' % n,
+                       'voxels_per_gpu': n, 'global_voxels': world * n,
+                       'parallelism': 'voxel shards x%d, one RCCL all_gather of the maps per step' % world},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'kernel': 'k_noddi<stage %d>' % stage, 'kernel_ms': dom_ms,
+                         'stage_ms': [float(v) for v in kms[1:4]], 'all_kernels_ms': float(kms[0]),
+                         'note': 'path is fp64-VALU/LDS bound, not HBM bound (DESIGN.md section 5)'},
+            'solver_stats': stats,
+        }
+        if world == 1:
+            from oracle import oracle
+            # parity on a sample of the benchmarked voxels (max |dmap| of BASELINE.json's metric)
+            ns = min(n, 20000)
+            cores = os.cpu_count() or 1
+            ref = oracle.noddi_fit(y_h[:ns], d_h[:ns], K, htable, scheme.dwi_idx, nthreads=cores)
+            diff = np.abs(est[:ns].cpu().numpy() - ref['estimates']).max(axis=1)
+            out['parity'] = {'sample_voxels': ns, 'max_abs_dmap': float(diff.max()),
+                             'median_abs_dmap': float(np.median(diff)),
+                             'frac_within_1e-6': float((diff < 1e-6).mean()),
+                             'frac_within_1e-4': float((diff < 1e-4).mean())}
+            if not args.no_cpu_baseline:
+                # bounded CPU leg: the oracle (a port: the reference's cyspams path cannot be built),
+                # same chunk-per-thread structure as BaseModel.fit, on all host cores, ~15 s
+                t1 = time.perf_counter()
+                oracle.noddi_fit(y_h[:2000], d_h[:2000], K, htable, scheme.dwi_idx, nthreads=cores)
+                rate = 2000 / (time.perf_counter() - t1)
+                m = int(min(n, max(4000, rate * 15)))
+                t1 = time.perf_counter()
+                oracle.noddi_fit(y_h[:m], d_h[:m], K, htable, scheme.dwi_idx, nthreads=cores)
+                dt = time.perf_counter() - t1
+                out['cpu_baseline'] = {'value': m / dt, 'unit': 'voxels/s', 'cores': cores, 'kind': 'port',
+                                       'sample': 'first %d voxels of the same workload, oracle/amico_oracle.c '
+                                                 '(Lawson-Hanson NNLS + LARS lasso), %d threads, %.1f s' % (m, cores, dt)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,124 @@
+/*
+ * amico_amd.h -- C ABI of the MI355X-native AMICO per-voxel fitter (libamico_amd.so).
+ *
+ * Drop-in boundary for the hot path `model.fit(evaluation)` of daducci/AMICO v2.1.0.
+ * The reference has no C ABI for this path: its native boundary is Cython `cdef` calls
+ * (amico/lut.pxd:4 `dir_to_lut_idx`; amico/models.pyx:18 `cyspams.interfaces.nnls/lasso`)
+ * made from the `_fit` hot loops (models.pyx:816-991 NODDI, 1168-1286 FreeWater,
+ * 1509-1627 SANDI).  Each entry point below cites the reference interface it replaces.
+ *
+ * Conventions: plain pointers + sizes, no C++/torch types; every call returns an int
+ * status (0 = ok, negative = error, see AMX_E_*); the library never keeps host pointers
+ * after a call returns; device memory is owned by amx_ctx / amx_lut handles.
+ * Arrays use the reference's layouts and dtypes (C-order, float64 signals / maps).
+ */
+#ifndef AMICO_AMD_H
+#define AMICO_AMD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMX_OK              0
+#define AMX_E_BADARG       -1   /* NULL / negative size / unsupported protocol size          */
+#define AMX_E_HIP          -2   /* HIP runtime error (message in amx_last_error)             */
+#define AMX_E_DIR_OOB      -3   /* lut.pyx:352-354 "index out of bounds" (voxel in last_error) */
+#define AMX_E_OVERFLOW     -4   /* a voxel needed more active atoms than the kernels support  */
+#define AMX_E_NODEVICE     -5   /* no HIP device / wrong architecture                         */
+
+/* flags of the *_fit calls (Evaluation.get_config(...) switches read by BaseModel.fit,
+ * models.pyx:214-217, 797, 1149) */
+#define AMX_F_RMSE          1u  /* doComputeRMSE        -> out_rmse   f64[n_vox]      */
+#define AMX_F_NRMSE         2u  /* doComputeNRMSE       -> out_nrmse  f64[n_vox]      */
+#define AMX_F_MODULATED     4u  /* doSaveModulatedMaps  -> out_mod    f64[n_vox][2]   */
+#define AMX_F_CORRECTED     8u  /* doSaveCorrectedDWI   -> out_ycorr  f64[n_vox][nS]  */
+
+typedef struct amx_ctx amx_ctx;   /* one per process+GPU: stream-ordered workspace, error state */
+typedef struct amx_lut amx_lut;   /* device-resident dictionary (KERNELS) of one model          */
+
+int  amx_version(void);
+/* device < 0: current HIP device.  Fails with AMX_E_NODEVICE when no gfx950 GPU is visible. */
+int  amx_ctx_create(int device, amx_ctx **out);
+void amx_ctx_destroy(amx_ctx *ctx);
+/* last error text of this ctx ("" if none); valid until the next call on ctx */
+const char *amx_last_error(amx_ctx *ctx);
+
+/* ---- dictionaries: replace the per-thread re-materialisation of KERNELS in _fit
+ *      (models.pyx:840-847 NODDI, 1190-1191 FreeWater, 1527-1528 SANDI) by ONE upload.   */
+
+/* NODDI.  KERNELS['wm'] f32[n_wm][ndirs][nS], ['iso'] f32[nS], ['norms'] f64[dwi][n_wm]
+ * (rows identical, models.pyx:781-784), ['icvf'],['kappa'] f32[n_wm] (models.pyx:763-789);
+ * htable int16[181*181] (lut.pyx:71-91); dwi_idx = scheme.dwi_idx int64[dwi_count].       */
+int amx_lut_upload_noddi(amx_ctx *ctx, const float *wm, const float *iso, const double *norms,
+                         const float *icvf, const float *kappa, const int16_t *htable,
+                         const int64_t *dwi_idx, int n_wm, int ndirs, int nS, int dwi_count,
+                         int is_exvivo, amx_lut **out);
+/* FreeWater.  KERNELS['D'] f32[n_perp][ndirs][nS], ['CSF'] f32[n_iso][nS] (models.pyx:1122-1123) */
+int amx_lut_upload_freewater(amx_ctx *ctx, const float *D, const float *CSF, const int16_t *htable,
+                             int n_perp, int n_iso, int ndirs, int nS, amx_lut **out);
+/* SANDI.  KERNELS['signal'] f64 column-major [nS][n_atoms], ['norms'] f64[n_atoms]
+ * (models.pyx:1456-1482); Rs, d_in, d_isos = model parameters used by the maps (:1540-1542) */
+int amx_lut_upload_sandi(amx_ctx *ctx, const double *signal, const double *norms, const double *Rs,
+                         const double *d_in, const double *d_isos, int nS, int n_rs, int n_in,
+                         int n_iso, amx_lut **out);
+void amx_lut_destroy(amx_lut *lut);
+
+/* ---- lut.pxd:4  cdef int dir_to_lut_idx(double[::1] direction, short[::1] hash_table)
+ * batched; dirs f64[n][3] (host, NOT modified -- the reference flips it in place,
+ * lut.pyx:335-338); out_idx int32[n].  AMX_E_DIR_OOB mirrors the RuntimeError.             */
+int amx_dir_to_lut_idx(amx_ctx *ctx, const amx_lut *lut, const double *dirs, int64_t n,
+                       int32_t *out_idx);
+
+/* ---- model.fit hot loops, HOST buffers in / out (H2D + kernels + D2H, blocking).
+ * y f64[n_vox][nS] (evaluation.y, core.py:451-452), dirs f64[n_vox][3] (evaluation.DIRs).  */
+
+/* NODDI._fit models.pyx:816-991: estimates f64[n_vox][3 (+1 ex-vivo)] = NDI, ODI, FWF(, dot) */
+int amx_noddi_fit(amx_ctx *ctx, const amx_lut *lut, const double *y, const double *dirs,
+                  int64_t n_vox, double lambda1, double lambda2, unsigned flags,
+                  double *out_estimates, double *out_rmse, double *out_nrmse, double *out_mod);
+/* FreeWater._fit models.pyx:1168-1286: estimates f64[n_vox][2 (Human) | 4 (Mouse)] */
+int amx_freewater_fit(amx_ctx *ctx, const amx_lut *lut, const double *y, const double *dirs,
+                      int64_t n_vox, double lambda1, double lambda2, int is_mouse, unsigned flags,
+                      double *out_estimates, double *out_rmse, double *out_nrmse, double *out_ycorr);
+/* SANDI._fit models.pyx:1509-1627: estimates f64[n_vox][6] */
+int amx_sandi_fit(amx_ctx *ctx, const amx_lut *lut, const double *y, int64_t n_vox,
+                  double lambda1, double lambda2, unsigned flags,
+                  double *out_estimates, double *out_rmse, double *out_nrmse);
+
+/* ---- the same with DEVICE buffers (inputs already resident in HBM, e.g. torch tensors'
+ * data_ptr()); work is enqueued on `hip_stream` (a hipStream_t, NULL = default stream) and
+ * the call returns without synchronising.  amx_sync_status() waits for the stream and
+ * returns the status of everything enqueued since the previous amx_sync_status().          */
+int amx_noddi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, const double *d_dirs,
+                         int64_t n_vox, double lambda1, double lambda2, unsigned flags,
+                         double *d_estimates, double *d_rmse, double *d_nrmse, double *d_mod,
+                         void *hip_stream);
+int amx_freewater_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y,
+                             const double *d_dirs, int64_t n_vox, double lambda1, double lambda2,
+                             int is_mouse, unsigned flags, double *d_estimates, double *d_rmse,
+                             double *d_nrmse, double *d_ycorr, void *hip_stream);
+int amx_sandi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, int64_t n_vox,
+                         double lambda1, double lambda2, unsigned flags, double *d_estimates,
+                         double *d_rmse, double *d_nrmse, void *hip_stream);
+int amx_sync_status(amx_ctx *ctx, void *hip_stream);
+
+/* ---- measurement hooks (bench.py): HIP-event time of the solver kernels of the LAST
+ * *_fit_device call on this ctx, measured on the stream they were launched on.
+ * which: 0 = all kernels of the call, 1..3 = solver stage kernels (NODDI: NNLS-1, LASSO,
+ * NNLS-3; FreeWater/SANDI: 1 = the single solver kernel).  Requires amx_set_profiling(1). */
+int amx_set_profiling(amx_ctx *ctx, int enable);
+int amx_last_kernel_ms(amx_ctx *ctx, int which, float *out_ms);
+/* solver statistics of the last call: out[0]=voxels re-run with the large active-set
+ * variant (stage sum), out[1]=voxels hitting the iteration cap, out[2..3] reserved        */
+int amx_last_stats(amx_ctx *ctx, int64_t out[4]);
+
+/* device self-test of the wavefront primitives (DPP reductions, broadcasts): writes 8 rows of
+ * 64 doubles (sum, max, min, bcast lane 37, next-lane, popcount(ballot v>0), int bcast, v) */
+int amx_selftest(amx_ctx *ctx, double *out512);
+/* AMX_DEBUG=1 only: 64 progress words the solver kernels write to host-visible memory */
+int amx_debug_trace(amx_ctx *ctx, int *out64);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMICO_AMD_H */
