@@ -6,8 +6,9 @@ template <int NR>
 static int go(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s)
 {
     constexpr int NQ = 1, MP = 16, MB = 64;
-    return launch_pair(ctx, a, pl, s, k_freewater<NR, NQ, MP, kNW, false>, k_freewater<NR, NQ, MB, 1, true>,
-                       fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, kNW), fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1), 0, 2);
+    constexpr int NW = 8;
+    return launch_pair<NW>(ctx, a, pl, s, k_freewater<NR, NQ, MP, NW, false>, k_freewater<NR, NQ, MB, 1, true>,
+                       fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, NW), fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1), 0, 2);
 }
 
 int amx_launch_fw(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s)

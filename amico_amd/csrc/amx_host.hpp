@@ -9,8 +9,7 @@
 #include <string>
 #include <vector>
 
-constexpr int kChunk = 256;        // voxels of one orientation per workgroup
-constexpr int kNW = 4;             // wavefronts per workgroup (main pass)
+constexpr int kChunk = 512;        // voxels of one orientation per workgroup
 constexpr int kListGrid = 512;     // workgroups of the large-MAXP re-run pass
 constexpr int kEv = 10;
 

@@ -12,7 +12,7 @@ static int set_lds(amx_ctx *ctx, K kern, size_t bytes)
 }
 
 // main pass over the orientation chunks + re-run of the voxels whose passive set overflowed
-template <typename Args, typename KM, typename KL>
+template <int NW, typename Args, typename KM, typename KL>
 static int launch_pair(amx_ctx *ctx, Args &a, const Plan &pl, hipStream_t s, KM km, KL kl, size_t lds_main,
                        size_t lds_list, int slot, int ev)
 {
@@ -24,7 +24,7 @@ static int launch_pair(amx_ctx *ctx, Args &a, const Plan &pl, hipStream_t s, KM 
     if ((rc = set_lds(ctx, km, lds_main))) return rc;
     if ((rc = set_lds(ctx, kl, lds_list))) return rc;
     rec(ctx, ev, s);
-    hipLaunchKernelGGL(km, dim3(pl.max_chunks), dim3(kNW * 64), lds_main, s, a);
+    hipLaunchKernelGGL(km, dim3(pl.max_chunks), dim3(NW * 64), lds_main, s, a);
     AMX_TRACE(ctx, s, "solver main pass");
     Args b = a;
     b.c.ovf_count = pl.ovf_count + 8;

@@ -6,8 +6,9 @@ template <int NR>
 static int go(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
 {
     constexpr int NQ = 3, MP = 16, MB = 32;
-    return launch_pair(ctx, a, pl, s, k_noddi<1, NR, NQ, MP, kNW, false>, k_noddi<1, NR, NQ, MB, 1, true>,
-                       fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, kNW), fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1),
+    constexpr int NW = 8;   // wavefronts per workgroup: as many as the register budget of this stage allows
+    return launch_pair<NW>(ctx, a, pl, s, k_noddi<1, NR, NQ, MP, NW, false>, k_noddi<1, NR, NQ, MB, 1, true>,
+                       fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, NW), fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1),
                        0, 2);
 }
 

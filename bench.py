@@ -35,6 +35,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--voxels', type=int, default=1_000_000, help='voxels per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--host', action='store_true', help='also time the host-buffer entry point (PCIe inclusive)')
     args = ap.parse_args()
 
     import torch
@@ -136,6 +137,12 @@ def main():
                              'median_abs_dmap': float(np.median(diff)),
                              'frac_within_1e-6': float((diff < 1e-6).mean()),
                              'frac_within_1e-4': float((diff < 1e-4).mean())}
+            if args.host:
+                # host numpy in -> host numpy out through amx_noddi_fit (H2D + kernels + D2H); never `value`
+                _capi.noddi_fit(ctx, lut, y_h, d_h, 0.5, 1e-3, 3)
+                t1 = time.perf_counter()
+                _capi.noddi_fit(ctx, lut, y_h, d_h, 0.5, 1e-3, 3)
+                out['host_buffers_voxels_per_s'] = n / (time.perf_counter() - t1)
             if not args.no_cpu_baseline:
                 # bounded CPU leg: the oracle (a port: the reference's cyspams path cannot be built),
                 # same chunk-per-thread structure as BaseModel.fit, on all host cores, ~15 s
