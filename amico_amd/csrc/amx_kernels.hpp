@@ -75,7 +75,7 @@ struct NoddiArgs {
 };
 
 template <int STAGE, int NR, int NQ, int MAXP>
-__device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const float *As, double *rs,
+__device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const float *As, double *rs, double *rl,
                                             unsigned long long *wmask, int vox, int lane)
 {
     const int nS = a.c.nS, ldA = a.c.ldA, n_atoms = a.c.n_atoms, n_wm = a.n_wm;
@@ -140,7 +140,7 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const float *As,
 
     NNSolver<NR, NQ, MAXP, STAGE == 2, float> S;
     const int st = __builtin_amdgcn_readfirstlane(S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed,
-                           STAGE == 2 ? a.c.lam1 : 0.0, STAGE == 2 ? a.c.lam2 : 0.0, rs, lane,
+                           STAGE == 2 ? a.c.lam1 : 0.0, STAGE == 2 ? a.c.lam2 : 0.0, rs, rl, lane,
                            (a.c.trace && vox < 7) ? a.c.trace + 64 * STAGE + 8 + 8 * vox : nullptr));
     volatile int *tr = (a.c.trace && vox < 7) ? a.c.trace + 64 * STAGE + 8 + 8 * vox : nullptr;
     if (tr && lane == 0) tr[7] = 70 + st;
@@ -214,7 +214,7 @@ struct FwArgs {
 };
 
 template <int NR, int NQ, int MAXP>
-__device__ __forceinline__ void fw_voxel(const FwArgs &a, const float *As, double *rs, int vox, int lane)
+__device__ __forceinline__ void fw_voxel(const FwArgs &a, const float *As, double *rs, double *rl, int vox, int lane)
 {
     const int nS = a.c.nS, ldA = a.c.ldA, n_atoms = a.c.n_atoms, n_perp = a.n_perp;
     double yr[NR];
@@ -239,7 +239,7 @@ __device__ __forceinline__ void fw_voxel(const FwArgs &a, const float *As, doubl
     }
     if (ok) {
     NNSolver<NR, NQ, MAXP, true, float> S;
-    const int st = __builtin_amdgcn_readfirstlane(S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed, a.c.lam1, a.c.lam2, rs, lane));
+    const int st = __builtin_amdgcn_readfirstlane(S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed, a.c.lam1, a.c.lam2, rs, rl, lane));
     if (st == kOverflow) {
         if (lane == 0) { const int k = atomicAdd(a.c.ovf_count, 1); a.c.ovf_list[k] = vox; }
     } else {
@@ -298,7 +298,7 @@ struct SandiArgs {
 };
 
 template <int NR, int NQ, int MAXP>
-__device__ __forceinline__ void sandi_voxel(const SandiArgs &a, const double *As, double *rs, int vox, int lane)
+__device__ __forceinline__ void sandi_voxel(const SandiArgs &a, const double *As, double *rs, double *rl, int vox, int lane)
 {
     const int nS = a.c.nS, ldA = a.c.ldA, n_atoms = a.c.n_atoms;
     const int n_rs = a.n_rs, n_in = a.n_in;
@@ -322,7 +322,7 @@ __device__ __forceinline__ void sandi_voxel(const SandiArgs &a, const double *As
     }
     if (ok) {
     NNSolver<NR, NQ, MAXP, true, double> S;
-    const int st = __builtin_amdgcn_readfirstlane(S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed, a.c.lam1, a.c.lam2, rs, lane));
+    const int st = __builtin_amdgcn_readfirstlane(S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed, a.c.lam1, a.c.lam2, rs, rl, lane));
     if (st == kOverflow) {
         if (lane == 0) { const int k = atomicAdd(a.c.ovf_count, 1); a.c.ovf_list[k] = vox; }
     } else {
@@ -378,7 +378,7 @@ __device__ __forceinline__ void sandi_voxel(const SandiArgs &a, const double *As
 template <typename AT, int NQ>
 __device__ __forceinline__ int tile_words(int nS, int ldA) { return nS * ldA; }
 
-#define AMX_KERNEL_PROLOGUE(AT, NRv, NQv, NWv)                                                        \
+#define AMX_KERNEL_PROLOGUE(AT, NRv, NQv, NWv, MPv)                                                        \
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                              \
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;                                       \
     const int words = a.c.nS * a.c.ldA;                                                               \
@@ -386,14 +386,16 @@ __device__ __forceinline__ int tile_words(int nS, int ldA) { return nS * ldA; }
     AT *As = reinterpret_cast<AT *>(smem);                                                            \
     double *rs_all = reinterpret_cast<double *>(smem + (((size_t)words_pad * sizeof(AT) + 15) & ~(size_t)15)); \
     double *rs = rs_all + wave * (NRv * kWave);                                                       \
-    unsigned long long *wm_all = reinterpret_cast<unsigned long long *>(rs_all + NWv * NRv * kWave);  \
+    double *rl_all = rs_all + NWv * NRv * kWave;                                                      \
+    double *rl = rl_all + wave * ((MPv + 1) * (MPv + 1));                                             \
+    unsigned long long *wm_all = reinterpret_cast<unsigned long long *>(rl_all + NWv * (MPv + 1) * (MPv + 1)); \
     unsigned long long *wmask = wm_all + wave * 4;                                                    \
     int *ticket = reinterpret_cast<int *>(wm_all + NWv * 4);
 
 template <int STAGE, int NR, int NQ, int MAXP, int NW, bool LIST>
 __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
 {
-    AMX_KERNEL_PROLOGUE(float, NR, NQ, NW)
+    AMX_KERNEL_PROLOGUE(float, NR, NQ, NW, MAXP)
     const float *tiles = reinterpret_cast<const float *>(a.c.tiles);
     if (!LIST) {
         if ((int)blockIdx.x >= *a.c.n_chunks) return;
@@ -403,7 +405,7 @@ __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
         // static round-robin over the chunk: wave w takes voxels w, w+NW, ... (purely scalar loop
         // control; no LDS ticket, no lane-0 atomics in the hot loop)
         for (int k = wave; k < ck.count; k += NW) {
-            noddi_voxel<STAGE, NR, NQ, MAXP>(a, As, rs, wmask, a.c.perm[ck.start + k], lane);
+            noddi_voxel<STAGE, NR, NQ, MAXP>(a, As, rs, rl, wmask, a.c.perm[ck.start + k], lane);
         }
     } else {
         const int cnt = *a.c.list_count;
@@ -412,7 +414,7 @@ __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
             __syncthreads();
             stage_tile<float>(As, tiles + (size_t)a.c.lutidx[vox] * a.c.tile_stride, words, words_pad - words);
             __syncthreads();
-            noddi_voxel<STAGE, NR, NQ, MAXP>(a, As, rs, wmask, vox, lane);
+            noddi_voxel<STAGE, NR, NQ, MAXP>(a, As, rs, rl, wmask, vox, lane);
         }
     }
 }
@@ -420,7 +422,7 @@ __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
 template <int NR, int NQ, int MAXP, int NW, bool LIST>
 __global__ void __launch_bounds__(NW * 64) k_freewater(const FwArgs a)
 {
-    AMX_KERNEL_PROLOGUE(float, NR, NQ, NW)
+    AMX_KERNEL_PROLOGUE(float, NR, NQ, NW, MAXP)
     (void)wmask;
     const float *tiles = reinterpret_cast<const float *>(a.c.tiles);
     if (!LIST) {
@@ -431,7 +433,7 @@ __global__ void __launch_bounds__(NW * 64) k_freewater(const FwArgs a)
         // static round-robin over the chunk: wave w takes voxels w, w+NW, ... (purely scalar loop
         // control; no LDS ticket, no lane-0 atomics in the hot loop)
         for (int k = wave; k < ck.count; k += NW) {
-            fw_voxel<NR, NQ, MAXP>(a, As, rs, a.c.perm[ck.start + k], lane);
+            fw_voxel<NR, NQ, MAXP>(a, As, rs, rl, a.c.perm[ck.start + k], lane);
         }
     } else {
         const int cnt = *a.c.list_count;
@@ -440,7 +442,7 @@ __global__ void __launch_bounds__(NW * 64) k_freewater(const FwArgs a)
             __syncthreads();
             stage_tile<float>(As, tiles + (size_t)a.c.lutidx[vox] * a.c.tile_stride, words, words_pad - words);
             __syncthreads();
-            fw_voxel<NR, NQ, MAXP>(a, As, rs, vox, lane);
+            fw_voxel<NR, NQ, MAXP>(a, As, rs, rl, vox, lane);
         }
     }
 }
@@ -448,7 +450,7 @@ __global__ void __launch_bounds__(NW * 64) k_freewater(const FwArgs a)
 template <int NR, int NQ, int MAXP, int NW, bool LIST>
 __global__ void __launch_bounds__(NW * 64) k_sandi(const SandiArgs a)
 {
-    AMX_KERNEL_PROLOGUE(double, NR, NQ, NW)
+    AMX_KERNEL_PROLOGUE(double, NR, NQ, NW, MAXP)
     (void)wmask;
     const double *tiles = reinterpret_cast<const double *>(a.c.tiles);
     if (!LIST) {
@@ -461,23 +463,24 @@ __global__ void __launch_bounds__(NW * 64) k_sandi(const SandiArgs a)
         for (int k = wave; k < ck.count; k += NW) {
             volatile int *tw = a.c.trace ? a.c.trace + 4 * (((int)blockIdx.x & 15) * 4 + wave) : nullptr;
             if (tw && lane == 0) { tw[0] = a.c.perm[ck.start + k]; tw[1] = 1; tw[2] = tw[2] + 1; }
-            sandi_voxel<NR, NQ, MAXP>(a, As, rs, a.c.perm[ck.start + k], lane);
+            sandi_voxel<NR, NQ, MAXP>(a, As, rs, rl, a.c.perm[ck.start + k], lane);
             if (tw && lane == 0) tw[1] = 2;
         }
     } else {
         const int cnt = *a.c.list_count;
         stage_tile<double>(As, tiles, words, words_pad - words);
         __syncthreads();
-        for (int it = blockIdx.x; it < cnt; it += gridDim.x) sandi_voxel<NR, NQ, MAXP>(a, As, rs, a.c.list[it], lane);
+        for (int it = blockIdx.x; it < cnt; it += gridDim.x) sandi_voxel<NR, NQ, MAXP>(a, As, rs, rl, a.c.list[it], lane);
     }
 }
 
 template <typename AT>
-static inline size_t fit_lds_bytes(int nS, int ldA, int NR, int NQ, int NW)
+static inline size_t fit_lds_bytes(int nS, int ldA, int NR, int NQ, int NW, int MAXP)
 {
     const size_t words_pad = ((size_t)nS * ldA + kWave * NQ + 3) & ~(size_t)3;
     size_t b = (words_pad * sizeof(AT) + 15) & ~(size_t)15;
     b += (size_t)NW * NR * kWave * sizeof(double);
+    b += (size_t)NW * (MAXP + 1) * (MAXP + 1) * sizeof(double);
     b += (size_t)NW * 4 * sizeof(unsigned long long);
     b += 16;
     return b;

@@ -97,7 +97,8 @@ struct NNSolver {
     // thin QR of the passive columns
     double Q[MAXP][NR];   // row space: Q[k][r] = q_k(row lane+64r)
     double Qa[MAXP];      // slot space (RIDGE): entry of q_k in the ridge row of this slot's atom
-    double Rr[MAXP];      // lane i: row i of R (entries c >= i)
+    static constexpr int LDR = MAXP + 1;   // odd leading dimension: rows AND columns of R are conflict-free
+    double *Rl;           // per-wave LDS: R[i][c] at Rl[i*LDR + c] (upper triangle used)
     double d, e, rinv;    // lane i: (Q'y)_i, (R^-T 1)_i, 1/R_ii
     double x, sc;         // lane s: coefficient and column scale of slot s
     int idx;              // lane s: atom of slot s
@@ -114,16 +115,15 @@ struct NNSolver {
 #pragma unroll
         for (int j = 0; j < MAXP - 1; j++) {
             if (j >= k && j < np - 1) {
-                const double ga = bcast(Rr[j + 1], j), gb = bcast(Rr[j + 1], j + 1);
+                // rows j, j+1 of R: lane m owns column m (two contiguous LDS rows, no bank conflicts)
+                const int lc = lane < MAXP ? lane : MAXP;      // column MAXP is padding
+                const double ra = Rl[j * LDR + lc], rb = Rl[(j + 1) * LDR + lc];
+                const double ga = bcast(ra, j + 1), gb = bcast(rb, j + 1);
                 const double rr = sqrt(ga * ga + gb * gb);
                 const double c = (rr > 0.0) ? ga / rr : 1.0, s = (rr > 0.0) ? gb / rr : 0.0;
-#pragma unroll
-                for (int m = j + 1; m < MAXP; m++) {
-                    if (m < np) {
-                        const double up = bcast(Rr[m], j), lo = bcast(Rr[m], j + 1);
-                        const double nu = c * up + s * lo, nl = c * lo - s * up;
-                        Rr[m] = (lane == j) ? nu : ((lane == j + 1) ? nl : Rr[m]);
-                    }
+                if (lane > j && lane < np) {
+                    Rl[j * LDR + lane] = c * ra + s * rb;
+                    Rl[(j + 1) * LDR + lane] = c * rb - s * ra;
                 }
 #pragma unroll
                 for (int rr_ = 0; rr_ < NR; rr_++) {
@@ -144,10 +144,11 @@ struct NNSolver {
                 }
             }
         }
-        // columns k+1.. move one to the left (rows stay in their lanes)
-#pragma unroll
-        for (int m = 0; m < MAXP - 1; m++)
-            if (m >= k) Rr[m] = Rr[m + 1];
+        // columns k+1.. move one to the left (rows stay where they are)
+        for (int i = 0; i < np - 1; i++) {
+            const double t = Rl[i * LDR + (lane < MAXP ? lane + 1 : MAXP)];
+            if (lane >= k && lane < np - 1) Rl[i * LDR + lane] = t;
+        }
         // slot-indexed data of lanes > k move one lane down
         {
             const double xn = from_next_lane(x), sn = from_next_lane(sc);
@@ -179,7 +180,7 @@ struct NNSolver {
     // yr     row space, 0 on rows >= nS and on rows excluded by rowok
     // rowok  row space, rows that belong to the problem
     // scl    atom space column scales, allowed[q] uniform bit masks of admissible atoms
-    // rs     per-wave LDS scratch of NR*64 doubles
+    // rs     per-wave LDS scratch of NR*64 doubles; rl per-wave LDS for R: (MAXP+1)*LDR doubles
     // Control flow is wave-uniform by construction; every branch condition goes through uni()
     // (v_readfirstlane) so that the compiler emits scalar branches and never masks EXEC around
     // the cross-lane operations.
@@ -187,9 +188,10 @@ struct NNSolver {
                                          const double (&yr)[NR], const bool (&rowok)[NR],
                                          const double (&scl)[NQ],
                                          const unsigned long long (&allowed)[NQ],
-                                         double lam1, double lam2, double *rs, int lane,
+                                         double lam1, double lam2, double *rs, double *rl, int lane,
                                          volatile int *trace = nullptr)
     {
+        Rl = rl;
 #define AMX_TR(slot, val) do { if (trace && lane == 0) { trace[slot] = (val); } } while (0)
         const double tol = 1e-12;            // KKT tolerance on the dual vector
         const double dep2 = 1e-20;           // (1e-10)^2: relative independence of a new column
@@ -345,10 +347,10 @@ struct NNSolver {
                         if (m == kn) {
 #pragma unroll
                             for (int rr = 0; rr < NR; rr++) Q[m][rr] = v[rr] * binv;
-                            Rr[m] = (lane == kn) ? beta : rho;
                             if (RIDGE) Qa[m] = (lane <= kn) ? va * binv : 0.0;
                         }
                     }
+                    if (lane <= kn) Rl[lane * LDR + kn] = (lane == kn) ? beta : rho;     // column kn of R
                     if (lane == kn) { d = dnew; e = enew; rinv = binv; x = 0.0; sc = sct; idx = t; }
                     fl &= 0xffffu;                               // forget the rejected candidates
                     if (lane == tl) fl |= 0x100u << tq;
@@ -364,12 +366,16 @@ struct NNSolver {
                 if (++iters > itmax) { status = kIterCap; break; }
                 AMX_TR(4, iters); AMX_TR(0, 40);
                 double rhs = d - lam1 * e, z = 0.0;
-#pragma unroll
-                for (int j = MAXP - 1; j >= 0; j--) {
-                    if (j < np) {
+                {
+                    // R z = rhs: column j of R is read one step ahead of its use
+                    const int li = (lane < MAXP ? lane : MAXP - 1) * LDR;
+                    double col = (np > 0) ? Rl[li + np - 1] : 0.0;
+                    for (int j = np - 1; j >= 0; j--) {
+                        const double nxt = (j > 0) ? Rl[li + j - 1] : 0.0;
                         const double zj = bcast(rhs * rinv, j);
                         if (lane == j) z = zj;
-                        if (lane < j) rhs -= Rr[j] * zj;
+                        if (lane < j) rhs -= col * zj;
+                        col = nxt;
                     }
                 }
                 const bool act = lane < np;
