@@ -387,8 +387,8 @@ __device__ __forceinline__ int tile_words(int nS, int ldA) { return nS * ldA; }
     double *rs_all = reinterpret_cast<double *>(smem + (((size_t)words_pad * sizeof(AT) + 15) & ~(size_t)15)); \
     double *rs = rs_all + wave * (NRv * kWave);                                                       \
     double *rl_all = rs_all + NWv * NRv * kWave;                                                      \
-    double *rl = rl_all + wave * ((MPv + 1) * (MPv + 1));                                             \
-    unsigned long long *wm_all = reinterpret_cast<unsigned long long *>(rl_all + NWv * (MPv + 1) * (MPv + 1)); \
+    double *rl = rl_all + wave * (2 * (MPv + 1) * (MPv + 1));                                         \
+    unsigned long long *wm_all = reinterpret_cast<unsigned long long *>(rl_all + NWv * 2 * (MPv + 1) * (MPv + 1)); \
     unsigned long long *wmask = wm_all + wave * 4;                                                    \
     int *ticket = reinterpret_cast<int *>(wm_all + NWv * 4);
 
@@ -480,7 +480,7 @@ static inline size_t fit_lds_bytes(int nS, int ldA, int NR, int NQ, int NW, int 
     const size_t words_pad = ((size_t)nS * ldA + kWave * NQ + 3) & ~(size_t)3;
     size_t b = (words_pad * sizeof(AT) + 15) & ~(size_t)15;
     b += (size_t)NW * NR * kWave * sizeof(double);
-    b += (size_t)NW * (MAXP + 1) * (MAXP + 1) * sizeof(double);
+    b += (size_t)NW * 2 * (MAXP + 1) * (MAXP + 1) * sizeof(double);
     b += (size_t)NW * 4 * sizeof(unsigned long long);
     b += 16;
     return b;

@@ -96,7 +96,7 @@ struct NNSolver {
     static_assert(MAXP <= kWave, "passive set lives in the lanes of one wavefront");
     // thin QR of the passive columns
     double Q[MAXP][NR];   // row space: Q[k][r] = q_k(row lane+64r)
-    double Qa[MAXP];      // slot space (RIDGE): entry of q_k in the ridge row of this slot's atom
+    double *Ql;           // per-wave LDS (RIDGE): Ql[s*LDR + k] = entry of q_k in the ridge row of slot s's atom
     static constexpr int LDR = MAXP + 1;   // odd leading dimension: rows AND columns of R are conflict-free
     double *Rl;           // per-wave LDS: R[i][c] at Rl[i*LDR + c] (upper triangle used)
     double d, e, rinv;    // lane i: (Q'y)_i, (R^-T 1)_i, 1/R_ii
@@ -131,10 +131,10 @@ struct NNSolver {
                     Q[j][rr_] = c * q0 + s * q1;
                     Q[j + 1][rr_] = c * q1 - s * q0;
                 }
-                if (RIDGE) {
-                    const double q0 = Qa[j], q1 = Qa[j + 1];
-                    Qa[j] = c * q0 + s * q1;
-                    Qa[j + 1] = c * q1 - s * q0;
+                if (RIDGE && lane < np) {
+                    const double q0 = Ql[lane * LDR + j], q1 = Ql[lane * LDR + j + 1];
+                    Ql[lane * LDR + j] = c * q0 + s * q1;
+                    Ql[lane * LDR + j + 1] = c * q1 - s * q0;
                 }
                 {
                     const double d0 = bcast(d, j), d1 = bcast(d, j + 1);
@@ -155,32 +155,24 @@ struct NNSolver {
             const int in = from_next_lane(idx);
             if (lane >= k) { x = xn; sc = sn; idx = in; }
             if (RIDGE) {
-#pragma unroll
-                for (int m = 0; m < MAXP; m++) {
-                    const double qn = from_next_lane(Qa[m]);
-                    if (lane >= k) Qa[m] = qn;
+                // ridge rows follow their slots (row s <- row s+1 for s >= k); the vacated last
+                // row and the dropped last column are cleared (rows/columns >= np stay zero)
+                for (int m = 0; m < np; m++) {
+                    const double qn = Ql[(lane < MAXP - 1 ? lane + 1 : MAXP - 1) * LDR + m];
+                    if (lane >= k && lane < np - 1) Ql[lane * LDR + m] = qn;
+                    if (lane == np - 1) Ql[lane * LDR + m] = 0.0;
                 }
+                if (lane < np) Ql[lane * LDR + np - 1] = 0.0;
             }
         }
         np = __builtin_amdgcn_readfirstlane(np - 1);
-        if (lane >= np) {
-            x = 0.0; d = 0.0; e = 0.0; idx = -1;
-            if (RIDGE) {
-#pragma unroll
-                for (int m = 0; m < MAXP; m++) Qa[m] = 0.0;
-            }
-        }
-        if (RIDGE) {
-#pragma unroll
-            for (int m = 0; m < MAXP; m++)
-                if (m >= np) Qa[m] = 0.0;
-        }
+        if (lane >= np) { x = 0.0; d = 0.0; e = 0.0; idx = -1; }
     }
 
     // yr     row space, 0 on rows >= nS and on rows excluded by rowok
     // rowok  row space, rows that belong to the problem
     // scl    atom space column scales, allowed[q] uniform bit masks of admissible atoms
-    // rs     per-wave LDS scratch of NR*64 doubles; rl per-wave LDS for R: (MAXP+1)*LDR doubles
+    // rs     per-wave LDS scratch of NR*64 doubles; rl per-wave LDS for R and the ridge rows: 2*(MAXP+1)*LDR doubles
     // Control flow is wave-uniform by construction; every branch condition goes through uni()
     // (v_readfirstlane) so that the compiler emits scalar branches and never masks EXEC around
     // the cross-lane operations.
@@ -192,6 +184,7 @@ struct NNSolver {
                                          volatile int *trace = nullptr)
     {
         Rl = rl;
+        Ql = rl + (MAXP + 1) * LDR;
 #define AMX_TR(slot, val) do { if (trace && lane == 0) { trace[slot] = (val); } } while (0)
         const double tol = 1e-12;            // KKT tolerance on the dual vector
         const double dep2 = 1e-20;           // (1e-10)^2: relative independence of a new column
@@ -203,9 +196,8 @@ struct NNSolver {
 #pragma unroll
         for (int q = 0; q < NQ; q++) fl |= (unsigned)((allowed[q] >> lane) & 1ull) << q;
         np = 0; d = 0.0; e = 0.0; rinv = 0.0; x = 0.0; sc = 1.0; idx = -1; iters = 0;
-        if (RIDGE) {
-#pragma unroll
-            for (int m = 0; m < MAXP; m++) Qa[m] = 0.0;
+        if (RIDGE && lane < MAXP) {
+            for (int m = 0; m < LDR; m++) Ql[lane * LDR + m] = 0.0;
         }
         int status = kSolved;
         int last_added = -1;
@@ -287,6 +279,7 @@ struct NNSolver {
                     vsq += v[rr] * v[rr];
                 }
                 double va = (RIDGE && lane == np) ? sqlam2 : 0.0;
+                const int ls = (lane < MAXP ? lane : MAXP - 1) * LDR;   // this lane's ridge row in Ql
                 const double n0 = wave_sum(vsq) + lam2;
                 double rho = 0.0;                 // lane k: R[k][new]
                 // two Gram-Schmidt passes, 4 projections in flight at a time
@@ -302,7 +295,7 @@ struct NNSolver {
                                 if (kb + u < MAXP && kb + u < np) {
 #pragma unroll
                                     for (int rr = 0; rr < NR; rr++) p[u] += Q[kb + u][rr] * v[rr];
-                                    if (RIDGE) p[u] += Qa[kb + u] * va;
+                                    if (RIDGE) p[u] += Ql[ls + kb + u] * va;
                                 }
                             }
 #pragma unroll
@@ -313,7 +306,7 @@ struct NNSolver {
                                 if (kb + u < MAXP && kb + u < np) {
 #pragma unroll
                                     for (int rr = 0; rr < NR; rr++) v[rr] -= p[u] * Q[kb + u][rr];
-                                    if (RIDGE) va -= p[u] * Qa[kb + u];
+                                    if (RIDGE) va -= p[u] * Ql[ls + kb + u];
                                     if (lane == kb + u) rho += p[u];
                                 }
                             }
@@ -347,10 +340,10 @@ struct NNSolver {
                         if (m == kn) {
 #pragma unroll
                             for (int rr = 0; rr < NR; rr++) Q[m][rr] = v[rr] * binv;
-                            if (RIDGE) Qa[m] = (lane <= kn) ? va * binv : 0.0;
                         }
                     }
                     if (lane <= kn) Rl[lane * LDR + kn] = (lane == kn) ? beta : rho;     // column kn of R
+                    if (RIDGE && lane <= kn) Ql[lane * LDR + kn] = va * binv;               // ridge rows of q_kn
                     if (lane == kn) { d = dnew; e = enew; rinv = binv; x = 0.0; sc = sct; idx = t; }
                     fl &= 0xffffu;                               // forget the rejected candidates
                     if (lane == tl) fl |= 0x100u << tq;
