@@ -140,10 +140,7 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const float *As,
 
     NNSolver<NR, NQ, MAXP, STAGE == 2, float> S;
     const int st = __builtin_amdgcn_readfirstlane(S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed,
-                           STAGE == 2 ? a.c.lam1 : 0.0, STAGE == 2 ? a.c.lam2 : 0.0, rs, rl, lane,
-                           (a.c.trace && vox < 7) ? a.c.trace + 64 * STAGE + 8 + 8 * vox : nullptr));
-    volatile int *tr = (a.c.trace && vox < 7) ? a.c.trace + 64 * STAGE + 8 + 8 * vox : nullptr;
-    if (tr && lane == 0) tr[7] = 70 + st;
+                           STAGE == 2 ? a.c.lam1 : 0.0, STAGE == 2 ? a.c.lam2 : 0.0, rs, rl, lane));
     if (st == kOverflow) {
         if (lane == 0) {
             const int k = atomicAdd(a.c.ovf_count, 1);
@@ -156,11 +153,8 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const float *As,
 
     if (STAGE == 1) {
         const double xi = wave_sum((act && S.idx == iso_atom) ? S.x : 0.0);
-        if (tr && lane == 0) tr[7] = 81;
         const double xd = wave_sum((act && S.idx == dot_atom) ? S.x : 0.0);
-        if (tr && lane == 0) tr[7] = 82;
         if (lane == 0) { a.xiso[(size_t)vox * 2] = xi; a.xiso[(size_t)vox * 2 + 1] = xd; }
-        if (tr && lane == 0) tr[7] = 83;
     } else if (STAGE == 2) {
         if (lane < 4) wmask[lane] = 0ull;
         if (act && S.x > 0.0) atomicOr(&wmask[S.idx >> 6], 1ull << (S.idx & 63));
@@ -169,7 +163,6 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const float *As,
         // models.pyx:945-967
         const double xs = act ? S.x : 0.0;
         const bool iswm = act && S.idx < n_wm;
-        if (tr && lane == 0) tr[7] = 84;
         const double sum_atoms = wave_sum(xs) + 1e-16;
         const double sum_wm = wave_sum(iswm ? xs / sum_atoms : 0.0) + 1e-16;
         double f1 = 0.0, f2 = 0.0, k1 = 0.0;
@@ -180,9 +173,7 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const float *As,
             f2 = (double)((float)(1.0 - (double)ic)) * t;
             k1 = (double)a.kappa[S.idx] * t;
         }
-        if (tr && lane == 0) tr[7] = 85;
         f1 = wave_sum(f1); f2 = wave_sum(f2); k1 = wave_sum(k1);
-        if (tr && lane == 0) tr[7] = 86;
         const double ndi = f1 / (f1 + f2 + 1e-16);
         const double odi = 2.0 / 3.14159265358979323846 * atan2(1.0, k1);
         const double fwf = wave_sum((act && S.idx == iso_atom) ? xs : 0.0) / sum_atoms;
@@ -191,7 +182,6 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const float *As,
 #pragma unroll
         for (int rr = 0; rr < NR; rr++) { rsq += S.r[rr] * S.r[rr]; ysq += yr[rr] * yr[rr]; }
         if (a.c.flags & 3u) { rsq = wave_sum(rsq); ysq = wave_sum(ysq); }
-        if (tr && lane == 0) tr[7] = 87;
         if (lane == 0) {
             double *e = a.est + (size_t)vox * a.n_maps;
             e[0] = ndi; e[1] = odi; e[2] = fwf;
@@ -200,7 +190,6 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const float *As,
             if (a.nrmse) a.nrmse[vox] = (ysq > 1e-16) ? sqrt(rsq / ysq) : 0.0;      // models.pyx:58-71
             if (a.mod) { const double tf = 1.0 - fwf; a.mod[(size_t)vox * 2] = ndi * tf; a.mod[(size_t)vox * 2 + 1] = odi * tf; }
         }
-        if (tr && lane == 0) tr[7] = 88;
     }
     }   // st != kOverflow
     }   // ok
@@ -461,10 +450,7 @@ __global__ void __launch_bounds__(NW * 64) k_sandi(const SandiArgs a)
         // static round-robin over the chunk: wave w takes voxels w, w+NW, ... (purely scalar loop
         // control; no LDS ticket, no lane-0 atomics in the hot loop)
         for (int k = wave; k < ck.count; k += NW) {
-            volatile int *tw = a.c.trace ? a.c.trace + 4 * (((int)blockIdx.x & 15) * 4 + wave) : nullptr;
-            if (tw && lane == 0) { tw[0] = a.c.perm[ck.start + k]; tw[1] = 1; tw[2] = tw[2] + 1; }
             sandi_voxel<NR, NQ, MAXP>(a, As, rs, rl, a.c.perm[ck.start + k], lane);
-            if (tw && lane == 0) tw[1] = 2;
         }
     } else {
         const int cnt = *a.c.list_count;

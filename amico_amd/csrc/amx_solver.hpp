@@ -185,7 +185,11 @@ struct NNSolver {
     {
         Rl = rl;
         Ql = rl + (MAXP + 1) * LDR;
+#ifdef AMX_TRACE_BUILD
 #define AMX_TR(slot, val) do { if (trace && lane == 0) { trace[slot] = (val); } } while (0)
+#else
+#define AMX_TR(slot, val) do { (void)trace; } while (0)
+#endif
         const double tol = 1e-12;            // KKT tolerance on the dual vector
         const double dep2 = 1e-20;           // (1e-10)^2: relative independence of a new column
         const double inf = __builtin_huge_val();

@@ -28,6 +28,71 @@ BYTES_PER_VOXEL = 8 * 99 + 24 + 24          # y f64[99] + DIRs f
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def other_models(args):
+    """FreeWater (config 3) / SANDI (config 4) throughput on one GPU; same timing protocol, shorter line."""
+    import torch
+    from amico_amd import _capi, synthetic as S
+    from oracle import oracle
+    dev = torch.device('cuda', 0)
+    n = args.voxels
+    ctx = _capi.Context(0)
+    L = _capi.lib()
+    lut_dirs = S.fibonacci_hemisphere(500)
+    htable = S.build_htable(lut_dirs)
+    if args.model == 'freewater':
+        scheme = S.make_scheme(1, ((1000.0, 64),), seed=3)
+        K = S.freewater_kernels(scheme, lut_dirs)
+        y_h, d_h = S.freewater_signals(n, K, htable, scheme, seed=1)
+        lut = _capi.upload_freewater(ctx, K, htable)
+        y = torch.from_numpy(y_h).to(dev); d = torch.from_numpy(d_h).to(dev)
+        est = torch.zeros((n, 2), dtype=torch.float64, device=dev)
+        bpv = 8 * scheme.nS + 24 + 16
+
+        def step():
+            ctx.check(L.amx_freewater_fit_device(ctx._h, lut._h, y.data_ptr(), d.data_ptr(), n, 0.0, 1e-3, 0, 0,
+                                                 est.data_ptr(), None, None, None, None))
+        ref = lambda m: oracle.freewater_fit(y_h[:m], d_h[:m], K, htable, nthreads=os.cpu_count())['estimates']
+        name = 'FreeWater fit, %d voxels, 65-volume single shell (1 b0 + 64@b1000), 11 atoms, ndirs=500' % n
+    else:
+        full = S.make_sandi_scheme()
+        avg = S.directional_average_scheme(full)
+        K, Rs, d_in, d_isos = S.sandi_kernels(avg)
+        y_h = S.sandi_signals(n, K, avg, seed=1)
+        lut = _capi.upload_sandi(ctx, K, Rs, d_in, d_isos)
+        y = torch.from_numpy(y_h).to(dev)
+        est = torch.zeros((n, 6), dtype=torch.float64, device=dev)
+        bpv = 8 * avg.nS + 48
+
+        def step():
+            ctx.check(L.amx_sandi_fit_device(ctx._h, lut._h, y.data_ptr(), n, 0.0, 5e-3, 0, est.data_ptr(), None, None, None))
+        ref = lambda m: oracle.sandi_fit(y_h[:m], K, Rs, d_in, d_isos, nthreads=os.cpu_count())['estimates']
+        name = 'SANDI fit, %d voxels, 5 shells direction-averaged (6 values per voxel), 15 atoms' % n
+    ctx.set_profiling(True)
+    for _ in range(args.warmup):
+        step(); ctx.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kms = 0.0
+    for _ in range(args.steps):
+        step(); ctx.sync()
+        kms += ctx.last_kernel_ms(1)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    kms /= args.steps
+    m = min(n, 20000)
+    diff = np.abs(est[:m].cpu().numpy() - ref(m))
+    t1 = time.perf_counter(); ref(min(n, 200000)); cpu = min(n, 200000) / (time.perf_counter() - t1)
+    print(json.dumps({'metric': 'voxels/sec, %s fit' % args.model, 'value': n * args.steps / el, 'unit': 'voxels/s',
+                      'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * el / args.steps,
+                      'dtype': 'f64', 'data': 'synthetic', 'config': {'workload': name},
+                      'roofline': {'bound': 'hbm', 'achieved': bpv * n / (kms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
+                                   'unit': 'GB/s', 'frac': bpv * n / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                                   'kernel_ms': kms, 'bytes_per_voxel': bpv},
+                      'parity': {'sample_voxels': m, 'max_abs_dmap': float(diff.max())},
+                      'cpu_baseline': {'value': cpu, 'unit': 'voxels/s', 'cores': os.cpu_count(), 'kind': 'port'},
+                      'solver_stats': ctx.last_stats()}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -36,7 +101,11 @@ def main():
     ap.add_argument('--voxels', type=int, default=1_000_000, help='voxels per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--host', action='store_true', help='also time the host-buffer entry point (PCIe inclusive)')
+    ap.add_argument('--model', default='noddi', choices=['noddi', 'freewater', 'sandi'],
+                    help='noddi = the BASELINE.json headline; the others are extra measurements (configs 3, 4)')
     args = ap.parse_args()
+    if args.model != 'noddi':
+        return other_models(args)
 
     import torch
     import torch.distributed as dist
