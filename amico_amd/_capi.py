@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libamico_amd.so')
+LIB_PATH = os.environ.get('AMICO_AMD_LIB') or os.path.join(_HERE, 'csrc', 'libamico_amd.so')   # override: A/B builds
 
 AMX_OK, AMX_E_BADARG, AMX_E_HIP, AMX_E_DIR_OOB, AMX_E_OVERFLOW, AMX_E_NODEVICE = 0, -1, -2, -3, -4, -5
 F_RMSE, F_NRMSE, F_MODULATED, F_CORRECTED = 1, 2, 4, 8

@@ -147,7 +147,7 @@ void amx_lut_destroy(amx_lut *lut)
 {
     if (!lut) return;
     if (lut->ctx) hipSetDevice(lut->ctx->device);
-    void *ps[] = {lut->tiles, lut->htable, lut->rowdwi, lut->colscale, lut->icvf, lut->kappa,
+    void *ps[] = {lut->gram, lut->gram_dwi, lut->tiles, lut->htable, lut->rowdwi, lut->colscale, lut->icvf, lut->kappa,
                   lut->norms, lut->Rs, lut->d_in, lut->d_isos};
     for (void *p : ps) if (p) hipFree(p);
     delete lut;
@@ -210,6 +210,26 @@ int amx_lut_upload_noddi(amx_ctx *ctx, const float *wm, const float *iso, const 
         (rc = upload(ctx, &lut->colscale, colscale.data(), colscale.size())) ||
         (rc = upload(ctx, &lut->icvf, icvf, (size_t)n_wm)) || (rc = upload(ctx, &lut->kappa, kappa, (size_t)n_wm)) ||
         (rc = upload(ctx, &lut->htable, ht.data(), ht.size()))) { amx_lut_destroy(lut); return rc; }
+    // Gram matrices of every orientation (all rows for the NNLS stages, stage-2 rows for the LASSO):
+    // they let the solver update the dual vector without sweeping the tile (amx_solver.hpp)
+    {
+        const char *env = getenv("AMX_NO_GRAM");
+        if (!(env && *env && *env != '0')) {
+            lut->ldG = 192;
+            const size_t gbytes = (size_t)ndirs * n_atoms * lut->ldG * sizeof(double);
+            const size_t lds = (size_t)nS * lut->ldA * sizeof(float);
+            HIPCHK(ctx, hipMalloc((void **)&lut->gram, gbytes));
+            HIPCHK(ctx, hipMalloc((void **)&lut->gram_dwi, gbytes));
+            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_build_gram),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_build_gram, dim3(ndirs), dim3(512), lds, nullptr, (const float *)lut->tiles,
+                               lut->tile_stride, nS, lut->ldA, n_atoms, (const unsigned char *)nullptr, lut->ldG, lut->gram);
+            hipLaunchKernelGGL(k_build_gram, dim3(ndirs), dim3(512), lds, nullptr, (const float *)lut->tiles,
+                               lut->tile_stride, nS, lut->ldA, n_atoms, (const unsigned char *)lut->rowdwi, lut->ldG, lut->gram_dwi);
+            HIPCHK(ctx, hipGetLastError());
+            HIPCHK(ctx, hipDeviceSynchronize());
+        }
+    }
     *out = lut;
     return AMX_OK;
 }
@@ -284,6 +304,7 @@ int amx_sync_status(amx_ctx *ctx, void *hip_stream)
     ctx->stats[1] = st[ST_ITCAP];
     ctx->stats[2] = ov[8];
     ctx->stats[3] = ((int64_t)st[ST_GUARD] << 32) | (unsigned)st[ST_GUARDVOX];
+    if (amx_debug()) fprintf(stderr, "[amx] dual-vector evaluations per stage: exact %d %d %d  gram %d %d %d  inner iterations %d %d %d\n", st[ST_EXACT], st[ST_EXACT + 1], st[ST_EXACT + 2], st[ST_GRAM], st[ST_GRAM + 1], st[ST_GRAM + 2], st[ST_ITERS], st[ST_ITERS + 1], st[ST_ITERS + 2]);
     if (st[ST_ERRVOX] != 0x7f7f7f7f) {
         char b[256];
         snprintf(b, sizeof b, "\"amico.lut.dir_to_lut_idx\" index out of bounds (%d, %d) [voxel %d]", st[ST_II1], st[ST_II2], st[ST_ERRVOX]);
@@ -373,6 +394,7 @@ int amx_noddi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
     a.c.n_atoms = lut->n_atoms; a.c.tile_stride = lut->tile_stride; a.c.lam1 = lambda1; a.c.lam2 = lambda2; a.c.flags = flags;
     a.rowdwi = lut->rowdwi; a.colscale = lut->colscale; a.icvf = lut->icvf; a.kappa = lut->kappa;
     a.n_wm = lut->n_wm; a.is_exvivo = lut->is_exvivo; a.n_maps = 3 + (lut->is_exvivo ? 1 : 0);
+    a.gram = lut->gram; a.gram_dwi = lut->gram_dwi; a.ldG = lut->ldG;
     a.xiso = (double *)ctx->xiso.p; a.supp = (unsigned long long *)ctx->supp.p;
     a.est = d_estimates; a.rmse = (flags & AMX_F_RMSE) ? d_rmse : nullptr;
     a.nrmse = (flags & AMX_F_NRMSE) ? d_nrmse : nullptr; a.mod = (flags & AMX_F_MODULATED) ? d_mod : nullptr;

@@ -40,6 +40,8 @@ struct amx_lut {
     int n_perp = 0, n_iso = 0;     // FreeWater
     int n_rs = 0, n_in = 0, n_isos = 0;   // SANDI
     void *tiles = nullptr;
+    double *gram = nullptr, *gram_dwi = nullptr;   // per-orientation Gram matrices (NODDI)
+    int ldG = 0;
     short *htable = nullptr;
     unsigned char *rowdwi = nullptr;
     double *colscale = nullptr;

@@ -15,7 +15,7 @@ namespace amx {
 
 struct Chunk { int dir, start, count, pad; };
 
-enum StatusSlot { ST_ERRVOX = 0, ST_II1 = 1, ST_II2 = 2, ST_OVERFLOW = 3, ST_ITCAP = 4, ST_RERUN = 5, ST_GUARD = 6, ST_GUARDVOX = 7, ST_WORDS = 8 };
+enum StatusSlot { ST_ERRVOX = 0, ST_II1 = 1, ST_II2 = 2, ST_OVERFLOW = 3, ST_ITCAP = 4, ST_RERUN = 5, ST_GUARD = 6, ST_GUARDVOX = 7, ST_EXACT = 8, ST_GRAM = 11, ST_ITERS = 14, ST_WORDS = 20 };
 
 // ------------------------------------------------------------------ shared pieces
 struct FitCommon {
@@ -69,6 +69,9 @@ struct NoddiArgs {
     const double *colscale;       // [n_atoms] KERNELS['norms'][0][k] (1.0 for iso/dot)
     const float *icvf, *kappa;    // [n_wm]
     int n_wm, is_exvivo, n_maps;
+    const double *gram;           // [ndirs][n_atoms][ldG] A'A of every orientation tile (all rows), or null
+    const double *gram_dwi;       // same restricted to the stage-2 rows
+    int ldG;
     double *xiso;                 // [n_vox][2]  x_iso, x_dot after stage 1
     unsigned long long *supp;     // [n_vox][4]  stage-2 support bit set
     double *est, *rmse, *nrmse, *mod;
@@ -76,7 +79,7 @@ struct NoddiArgs {
 
 template <int STAGE, int NR, int NQ, int MAXP>
 __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const float *As, double *rs, double *rl,
-                                            unsigned long long *wmask, int vox, int lane)
+                                            unsigned long long *wmask, int vox, int dir, int lane)
 {
     const int nS = a.c.nS, ldA = a.c.ldA, n_atoms = a.c.n_atoms, n_wm = a.n_wm;
     const int iso_atom = n_atoms - 1, dot_atom = a.is_exvivo ? n_atoms - 2 : -1;
@@ -138,9 +141,11 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const float *As,
         }
     }
 
+    const double *gm = (STAGE == 2) ? a.gram_dwi : a.gram;
     NNSolver<NR, NQ, MAXP, STAGE == 2, float> S;
     const int st = __builtin_amdgcn_readfirstlane(S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed,
-                           STAGE == 2 ? a.c.lam1 : 0.0, STAGE == 2 ? a.c.lam2 : 0.0, rs, rl, lane));
+                           STAGE == 2 ? a.c.lam1 : 0.0, STAGE == 2 ? a.c.lam2 : 0.0, rs, rl, lane,
+                           gm ? gm + (size_t)dir * n_atoms * a.ldG : nullptr, a.ldG));
     if (st == kOverflow) {
         if (lane == 0) {
             const int k = atomicAdd(a.c.ovf_count, 1);
@@ -149,6 +154,9 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const float *As,
     } else {
     if (st == kIterCap && lane == 0) atomicAdd(&a.c.status[ST_ITCAP], 1);
     if (st > kIterCap && lane == 0) { atomicAdd(&a.c.status[ST_GUARD], 1); a.c.status[ST_GUARDVOX] = vox * 8 + st; }
+#ifdef AMX_STATS
+    if (lane == 0) { atomicAdd(&a.c.status[ST_EXACT + STAGE - 1], S.n_exact); atomicAdd(&a.c.status[ST_GRAM + STAGE - 1], S.n_gram); atomicAdd(&a.c.status[ST_ITERS + STAGE - 1], S.iters); }
+#endif
     const bool act = lane < S.np;
 
     if (STAGE == 1) {
@@ -394,7 +402,7 @@ __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
         // static round-robin over the chunk: wave w takes voxels w, w+NW, ... (purely scalar loop
         // control; no LDS ticket, no lane-0 atomics in the hot loop)
         for (int k = wave; k < ck.count; k += NW) {
-            noddi_voxel<STAGE, NR, NQ, MAXP>(a, As, rs, rl, wmask, a.c.perm[ck.start + k], lane);
+            noddi_voxel<STAGE, NR, NQ, MAXP>(a, As, rs, rl, wmask, a.c.perm[ck.start + k], ck.dir, lane);
         }
     } else {
         const int cnt = *a.c.list_count;
@@ -403,7 +411,7 @@ __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
             __syncthreads();
             stage_tile<float>(As, tiles + (size_t)a.c.lutidx[vox] * a.c.tile_stride, words, words_pad - words);
             __syncthreads();
-            noddi_voxel<STAGE, NR, NQ, MAXP>(a, As, rs, rl, wmask, vox, lane);
+            noddi_voxel<STAGE, NR, NQ, MAXP>(a, As, rs, rl, wmask, vox, a.c.lutidx[vox], lane);
         }
     }
 }

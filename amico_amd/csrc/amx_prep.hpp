@@ -130,4 +130,28 @@ __global__ void k_build_lut(const float *__restrict__ src, const float *__restri
 }
 
 
+// Gram matrices of the orientation tiles: G[dir][j][k] = sum_{i in rows} A[i][j] A[i][k] in fp64
+// (products of fp32 values are exact in fp64); one workgroup per orientation, tile staged in LDS.
+// rowsel == nullptr: all rows.  Row stride ldG (>= n_atoms, padding stays zero).
+__global__ void k_build_gram(const float *__restrict__ tiles, int tile_stride, int nS, int ldA, int n_atoms,
+                             const unsigned char *__restrict__ rowsel, int ldG, double *__restrict__ G)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
+    float *As = reinterpret_cast<float *>(smem_g);
+    const float *g = tiles + (size_t)blockIdx.x * tile_stride;
+    for (int k = threadIdx.x; k < nS * ldA; k += blockDim.x) {
+        const int i = k / ldA;
+        As[k] = (rowsel == nullptr || rowsel[i]) ? g[k] : 0.f;
+    }
+    __syncthreads();
+    double *out = G + (size_t)blockIdx.x * n_atoms * ldG;
+    for (int e = threadIdx.x; e < n_atoms * ldG; e += blockDim.x) {
+        const int j = e / ldG, c = e % ldG;
+        double acc = 0.0;
+        if (c < n_atoms)
+            for (int i = 0; i < nS; i++) acc += (double)As[i * ldA + j] * (double)As[i * ldA + c];
+        out[e] = acc;
+    }
+}
+
 }  // namespace amx

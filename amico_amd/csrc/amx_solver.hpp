@@ -101,10 +101,12 @@ struct NNSolver {
     double *Rl;           // per-wave LDS: R[i][c] at Rl[i*LDR + c] (upper triangle used)
     double d, e, rinv;    // lane i: (Q'y)_i, (R^-T 1)_i, 1/R_ii
     double x, sc;         // lane s: coefficient and column scale of slot s
+    double xprev;         // lane s: coefficient at the last update of the dual vector (Gram updates)
     int idx;              // lane s: atom of slot s
     int np;               // passive-set size (uniform)
     double r[NR];         // row space: residual y - A s x at exit
     int iters;
+    int n_exact, n_gram;  // dual-vector evaluations: exact sweeps / Gram updates (statistics)
 
     // fl: per-lane atom flags (bit q: allowed, bit 8+q: passive, bit 16+q: banned) of atom lane+64q
     __device__ __forceinline__ void remove_slot(int k, int lane, unsigned &fl)
@@ -151,9 +153,9 @@ struct NNSolver {
         }
         // slot-indexed data of lanes > k move one lane down
         {
-            const double xn = from_next_lane(x), sn = from_next_lane(sc);
+            const double xn = from_next_lane(x), sn = from_next_lane(sc), pn = from_next_lane(xprev);
             const int in = from_next_lane(idx);
-            if (lane >= k) { x = xn; sc = sn; idx = in; }
+            if (lane >= k) { x = xn; sc = sn; idx = in; xprev = pn; }
             if (RIDGE) {
                 // ridge rows follow their slots (row s <- row s+1 for s >= k); the vacated last
                 // row and the dropped last column are cleared (rows/columns >= np stay zero)
@@ -166,13 +168,17 @@ struct NNSolver {
             }
         }
         np = __builtin_amdgcn_readfirstlane(np - 1);
-        if (lane >= np) { x = 0.0; d = 0.0; e = 0.0; idx = -1; }
+        if (lane >= np) { x = 0.0; xprev = 0.0; d = 0.0; e = 0.0; idx = -1; }
     }
 
     // yr     row space, 0 on rows >= nS and on rows excluded by rowok
     // rowok  row space, rows that belong to the problem
     // scl    atom space column scales, allowed[q] uniform bit masks of admissible atoms
     // rs     per-wave LDS scratch of NR*64 doubles; rl per-wave LDS for R and the ridge rows: 2*(MAXP+1)*LDR doubles
+    // G      optional Gram matrix A'A of this orientation (global memory, row stride ldG >= 64*NQ,
+    //        restricted to the rows in rowok): lets the dual vector follow coefficient changes by
+    //        a few column loads instead of a full sweep of A; every decision near convergence
+    //        (and the final KKT check) is still taken on the exactly recomputed dual vector.
     // Control flow is wave-uniform by construction; every branch condition goes through uni()
     // (v_readfirstlane) so that the compiler emits scalar branches and never masks EXEC around
     // the cross-lane operations.
@@ -181,12 +187,17 @@ struct NNSolver {
                                          const double (&scl)[NQ],
                                          const unsigned long long (&allowed)[NQ],
                                          double lam1, double lam2, double *rs, double *rl, int lane,
+                                         const double *__restrict__ G = nullptr, int ldG = 0,
                                          volatile int *trace = nullptr)
     {
         Rl = rl;
         Ql = rl + (MAXP + 1) * LDR;
 #ifdef AMX_TRACE_BUILD
+#ifdef AMX_TRACE_BUILD
 #define AMX_TR(slot, val) do { if (trace && lane == 0) { trace[slot] = (val); } } while (0)
+#else
+#define AMX_TR(slot, val) do { (void)trace; } while (0)
+#endif
 #else
 #define AMX_TR(slot, val) do { (void)trace; } while (0)
 #endif
@@ -199,59 +210,99 @@ struct NNSolver {
         unsigned fl = 0u;
 #pragma unroll
         for (int q = 0; q < NQ; q++) fl |= (unsigned)((allowed[q] >> lane) & 1ull) << q;
-        np = 0; d = 0.0; e = 0.0; rinv = 0.0; x = 0.0; sc = 1.0; idx = -1; iters = 0;
+        np = 0; d = 0.0; e = 0.0; rinv = 0.0; x = 0.0; xprev = 0.0; sc = 1.0; idx = -1; iters = 0;
         if (RIDGE && lane < MAXP) {
             for (int m = 0; m < LDR; m++) Ql[lane * LDR + m] = 0.0;
         }
         int status = kSolved;
         int last_added = -1;
+        n_exact = 0; n_gram = 0;
+        constexpr int kMaxGramSteps = 6;     // bound the drift of the Gram-updated dual vector
+        const double kExactBelow = 1e-7;     // decisions on smaller dual values use the exact sweep
+        double u[NQ];                        // atom space: A' r (unscaled, without the l1 shift)
+        bool have_u = false, force_exact = false;
+        int gram_steps = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) u[q] = 0.0;
 
         for (int outer = 0; status == kSolved; ++outer) {
             if (outer > 2 * itmax) { status = kGuardOuter; break; }   // never spin
             AMX_TR(1, outer); AMX_TR(2, np); AMX_TR(0, 10);
-            // ---- residual of the current passive least-squares solution: r = y - Q (d - l1 e)
+            double w[NQ];
+            const bool exact = (G == nullptr) || !have_u || force_exact || gram_steps >= kMaxGramSteps;
+            if (exact) {
+                // ---- residual of the current passive least-squares solution: r = y - Q (d - l1 e)
 #pragma unroll
-            for (int rr = 0; rr < NR; rr++) r[rr] = yr[rr];
-            {
-                const double coef = d - lam1 * e;
+                for (int rr = 0; rr < NR; rr++) r[rr] = yr[rr];
+                {
+                    const double coef = d - lam1 * e;
 #pragma unroll
-                for (int k = 0; k < MAXP; k++) {
-                    if (k < np) {
-                        const double ck = bcast(coef, k);
+                    for (int k = 0; k < MAXP; k++) {
+                        if (k < np) {
+                            const double ck = bcast(coef, k);
 #pragma unroll
-                        for (int rr = 0; rr < NR; rr++) r[rr] -= Q[k][rr] * ck;
+                            for (int rr = 0; rr < NR; rr++) r[rr] -= Q[k][rr] * ck;
+                        }
                     }
                 }
-            }
-            // ---- dual vector w = s * A' r - l1 (atom space): one sweep over the LDS tile
+                // ---- u = A' r (atom space): one sweep over the LDS tile
 #pragma unroll
-            for (int rr = 0; rr < NR; rr++) rs[lane + kWave * rr] = r[rr];
-            double w[NQ], w2[NQ];
+                for (int rr = 0; rr < NR; rr++) rs[lane + kWave * rr] = r[rr];
+                double w2[NQ];
 #pragma unroll
-            for (int q = 0; q < NQ; q++) { w[q] = 0.0; w2[q] = 0.0; }
-            {
-                const AT *ap = As + lane;
-                int i = 0;
-                for (; i + 1 < nS; i += 2) {
-                    const double r0 = rs[i], r1 = rs[i + 1];
+                for (int q = 0; q < NQ; q++) { u[q] = 0.0; w2[q] = 0.0; }
+                {
+                    const AT *ap = As + lane;
+                    int i = 0;
+                    for (; i + 1 < nS; i += 2) {
+                        const double r0 = rs[i], r1 = rs[i + 1];
 #pragma unroll
-                    for (int q = 0; q < NQ; q++) {
-                        w[q] += (double)ap[i * ldA + kWave * q] * r0;
-                        w2[q] += (double)ap[(i + 1) * ldA + kWave * q] * r1;
+                        for (int q = 0; q < NQ; q++) {
+                            u[q] += (double)ap[i * ldA + kWave * q] * r0;
+                            w2[q] += (double)ap[(i + 1) * ldA + kWave * q] * r1;
+                        }
+                    }
+                    if (i < nS) {
+                        const double r0 = rs[i];
+#pragma unroll
+                        for (int q = 0; q < NQ; q++) u[q] += (double)ap[i * ldA + kWave * q] * r0;
                     }
                 }
-                if (i < nS) {
-                    const double r0 = rs[i];
 #pragma unroll
-                    for (int q = 0; q < NQ; q++) w[q] += (double)ap[i * ldA + kWave * q] * r0;
+                for (int q = 0; q < NQ; q++) u[q] += w2[q];
+                have_u = true; force_exact = false; gram_steps = 0; n_exact++;
+            } else {
+                // ---- u -= G[:, P] (s (x - xprev)): the passive coefficients moved, nothing else did
+                // (4 columns = 4*NQ loads in flight per trip: the loop is bound by L2/MALL latency)
+                {
+                    const double delta = sc * (x - xprev);
+                    for (int s0 = 0; s0 < np; s0 += 4) {
+                        double gv[4][NQ], dls[4];
+#pragma unroll
+                        for (int t4 = 0; t4 < 4; t4++) {
+                            const int sl = (s0 + t4 < np) ? s0 + t4 : np - 1;
+                            const double dv = bcast(delta, sl);
+                            dls[t4] = (s0 + t4 < np) ? dv : 0.0;
+                            const double *gc = G + (size_t)bcast_i(idx, sl) * ldG + lane;
+#pragma unroll
+                            for (int q = 0; q < NQ; q++) gv[t4][q] = gc[kWave * q];
+                        }
+#pragma unroll
+                        for (int t4 = 0; t4 < 4; t4++) {
+#pragma unroll
+                            for (int q = 0; q < NQ; q++) u[q] -= gv[t4][q] * dls[t4];
+                        }
+                    }
                 }
+                gram_steps++; n_gram++;
             }
+            xprev = x;
 #pragma unroll
-            for (int q = 0; q < NQ; q++) w[q] = scl[q] * (w[q] + w2[q]) - lam1;
+            for (int q = 0; q < NQ; q++) w[q] = scl[q] * u[q] - lam1;
             AMX_TR(0, 20);
 
             // ---- pick the most violating admissible atom; test it; maybe take the next one
-            bool added = false;
+            bool added = false, redo = false;
             for (int sel = 0; status == kSolved && !added; ++sel) {
                 if (sel > kWave * NQ + 2) { status = kGuardSelect; break; }
                 double best = -inf;
@@ -262,6 +313,7 @@ struct NNSolver {
                     if (cand && w[q] > best) { best = w[q]; bj = lane + kWave * q; }
                 }
                 const double wmax = wave_max(best);
+                if (!exact && uni(!(wmax > kExactBelow))) { force_exact = true; redo = true; break; }
                 if (!uni(wmax > tol)) break;                      // KKT point reached
                 const unsigned long long who = ballot64(best == wmax);
                 if (uni(who == 0ull)) { status = kGuardSelect; break; }
@@ -288,7 +340,10 @@ struct NNSolver {
                 double rho = 0.0;                 // lane k: R[k][new]
                 // two Gram-Schmidt passes, 4 projections in flight at a time
 #pragma unroll
-                for (int pass = 0; pass < 2; pass++) {
+#ifndef AMX_CGS_PASSES
+#define AMX_CGS_PASSES 2
+#endif
+                for (int pass = 0; pass < AMX_CGS_PASSES; pass++) {
 #pragma unroll
                     for (int kb = 0; kb < MAXP; kb += 4) {
                         if (kb < np) {
@@ -356,6 +411,7 @@ struct NNSolver {
                     added = true;
                 }
             }
+            if (redo) continue;  // small dual values: decide on the exactly recomputed vector
             if (!added) break;   // KKT point (or a guard tripped)
 
             // ---- Lawson-Hanson inner loop: restore feasibility of the passive solution
@@ -394,6 +450,12 @@ struct NNSolver {
                         rem &= ~(1ull << k);
                         const int a = bcast_i(idx, k);
                         if (a == last_added && lane == (a & 63)) fl |= 0x10000u << (a >> 6);   // no add/remove cycling
+                        if (G != nullptr) {       // the atom leaves with coefficient 0: fold its change into u now
+                            const double dl = -bcast(sc * xprev, k);
+                            const double *gc = G + (size_t)a * ldG + lane;
+#pragma unroll
+                            for (int q = 0; q < NQ; q++) u[q] -= gc[kWave * q] * dl;
+                        }
                         remove_slot(k, lane, fl);
                     }
                     if (np == 0) { x = 0.0; feasible = true; }
