@@ -383,11 +383,12 @@ __device__ __forceinline__ int tile_words(int nS, int ldA) { return nS * ldA; }
     AT *As = reinterpret_cast<AT *>(smem);                                                            \
     double *rs_all = reinterpret_cast<double *>(smem + (((size_t)words_pad * sizeof(AT) + 15) & ~(size_t)15)); \
     double *rs = rs_all + wave * (NRv * kWave);                                                       \
-    double *rl_all = rs_all + NWv * NRv * kWave;                                                      \
+    const int nw_ = (int)blockDim.x >> 6;   /* wavefronts actually launched (<= NWv) */                  \
+    double *rl_all = rs_all + nw_ * NRv * kWave;                                                      \
     double *rl = rl_all + wave * (2 * (MPv + 1) * (MPv + 1));                                         \
-    unsigned long long *wm_all = reinterpret_cast<unsigned long long *>(rl_all + NWv * 2 * (MPv + 1) * (MPv + 1)); \
+    unsigned long long *wm_all = reinterpret_cast<unsigned long long *>(rl_all + nw_ * 2 * (MPv + 1) * (MPv + 1)); \
     unsigned long long *wmask = wm_all + wave * 4;                                                    \
-    int *ticket = reinterpret_cast<int *>(wm_all + NWv * 4);
+    int *ticket = reinterpret_cast<int *>(wm_all + nw_ * 4);
 
 template <int STAGE, int NR, int NQ, int MAXP, int NW, bool LIST>
 __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
@@ -401,7 +402,7 @@ __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
         __syncthreads();
         // static round-robin over the chunk: wave w takes voxels w, w+NW, ... (purely scalar loop
         // control; no LDS ticket, no lane-0 atomics in the hot loop)
-        for (int k = wave; k < ck.count; k += NW) {
+        for (int k = wave; k < ck.count; k += nw_) {
             noddi_voxel<STAGE, NR, NQ, MAXP>(a, As, rs, rl, wmask, a.c.perm[ck.start + k], ck.dir, lane);
         }
     } else {
@@ -429,7 +430,7 @@ __global__ void __launch_bounds__(NW * 64) k_freewater(const FwArgs a)
         __syncthreads();
         // static round-robin over the chunk: wave w takes voxels w, w+NW, ... (purely scalar loop
         // control; no LDS ticket, no lane-0 atomics in the hot loop)
-        for (int k = wave; k < ck.count; k += NW) {
+        for (int k = wave; k < ck.count; k += nw_) {
             fw_voxel<NR, NQ, MAXP>(a, As, rs, rl, a.c.perm[ck.start + k], lane);
         }
     } else {
@@ -457,7 +458,7 @@ __global__ void __launch_bounds__(NW * 64) k_sandi(const SandiArgs a)
         __syncthreads();
         // static round-robin over the chunk: wave w takes voxels w, w+NW, ... (purely scalar loop
         // control; no LDS ticket, no lane-0 atomics in the hot loop)
-        for (int k = wave; k < ck.count; k += NW) {
+        for (int k = wave; k < ck.count; k += nw_) {
             sandi_voxel<NR, NQ, MAXP>(a, As, rs, rl, a.c.perm[ck.start + k], lane);
         }
     } else {

@@ -12,11 +12,21 @@ static int set_lds(amx_ctx *ctx, K kern, size_t bytes)
 }
 
 // main pass over the orientation chunks + re-run of the voxels whose passive set overflowed
-template <int NW, typename Args, typename KM, typename KL>
-static int launch_pair(amx_ctx *ctx, Args &a, const Plan &pl, hipStream_t s, KM km, KL kl, size_t lds_main,
+constexpr size_t kLdsPerCU = 160 * 1024;
+
+// LDSF(nw) -> dynamic LDS bytes of the main kernel with nw wavefronts per workgroup
+template <int NW, typename Args, typename KM, typename KL, typename LDSF>
+static int launch_pair(amx_ctx *ctx, Args &a, const Plan &pl, hipStream_t s, KM km, KL kl, LDSF ldsf,
                        size_t lds_list, int slot, int ev)
 {
     int rc;
+    int nw = NW;                               // fewer wavefronts per workgroup for long protocols
+    while (nw > 1 && ldsf(nw) > kLdsPerCU) nw >>= 1;
+    const size_t lds_main = ldsf(nw);
+    if (lds_main > kLdsPerCU || lds_list > kLdsPerCU) {
+        ctx->err = "dictionary tile does not fit the 160 KB LDS of a CU (nS x n_atoms too large)";
+        return AMX_E_BADARG;
+    }
     a.c.ovf_count = pl.ovf_count + slot;
     a.c.ovf_list = pl.ovf_list + (size_t)slot * pl.n;
     a.c.list = a.c.ovf_list;
@@ -24,7 +34,7 @@ static int launch_pair(amx_ctx *ctx, Args &a, const Plan &pl, hipStream_t s, KM 
     if ((rc = set_lds(ctx, km, lds_main))) return rc;
     if ((rc = set_lds(ctx, kl, lds_list))) return rc;
     rec(ctx, ev, s);
-    hipLaunchKernelGGL(km, dim3(pl.max_chunks), dim3(NW * 64), lds_main, s, a);
+    hipLaunchKernelGGL(km, dim3(pl.max_chunks), dim3(nw * 64), lds_main, s, a);
     AMX_TRACE(ctx, s, "solver main pass");
     Args b = a;
     b.c.ovf_count = pl.ovf_count + 8;

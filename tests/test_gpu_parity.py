@@ -206,3 +206,42 @@ def test_wave_primitives():
     assert np.array_equal(out[4][:63], v[1:])
     assert np.array_equal(out[5], np.full(64, float((v > 0).sum())))
     assert np.array_equal(out[6], np.full(64, 63.0))
+
+
+def test_other_protocol_shapes(htable500):
+    """generic instantiations: small dictionary + single b0 (the `single_b0` row rule of
+    models.pyx:820,917-918), a long protocol (nS > 128 -> 4 rows per lane), few LUT orientations"""
+    from amico_amd import NODDI, FreeWater, synthetic as S
+    from oracle import oracle
+    ht = htable500['htable']
+    dirs = htable500['dirs']
+    # (a) 12-atom NODDI dictionary, 1 b0 + 24 + 16 volumes
+    sch = S.make_scheme(1, ((1000.0, 24), (2500.0, 16)), seed=7)
+    vfs, ods = np.linspace(0.2, 0.9, 4), np.array([0.05, 0.3, 0.8])
+    K = S.noddi_kernels(sch, dirs, IC_VFs=vfs, IC_ODs=ods)
+    y, d = S.noddi_signals(2000, K, ht, sch, seed=3)
+    m = NODDI()
+    m.set(IC_VFs=vfs, IC_ODs=ods)
+    m.scheme = sch
+    out = m.fit(Holder(y, d, ht, K, doComputeNRMSE=True))
+    ref = oracle.noddi_fit(y, d, K, ht, sch.dwi_idx, nthreads=8, nrmse=True)
+    diff = np.abs(out['estimates'] - ref['estimates']).max(axis=1)
+    assert (diff < TOL).mean() > 0.998, (diff > TOL).sum()
+    assert np.abs(out['nrmse'] - ref['nrmse']).max() < 1e-6
+    # (b) 150-volume protocol, default dictionary
+    sch2 = S.make_scheme(10, ((700.0, 40), (2000.0, 60), (3000.0, 40)), seed=8)
+    K2 = S.noddi_kernels(sch2, dirs)
+    y2, d2 = S.noddi_signals(1500, K2, ht, sch2, seed=4)
+    m2 = NODDI()
+    m2.scheme = sch2
+    out2 = m2.fit(Holder(y2, d2, ht, K2))
+    ref2 = oracle.noddi_fit(y2, d2, K2, ht, sch2.dwi_idx, nthreads=8)
+    diff2 = np.abs(out2['estimates'] - ref2['estimates']).max(axis=1)
+    assert (diff2 < TOL).mean() > 0.998, (diff2 > TOL).sum()
+    # (c) FreeWater with 33 volumes
+    sch3 = S.make_scheme(1, ((1000.0, 32),), seed=9)
+    K3 = S.freewater_kernels(sch3, dirs)
+    y3, d3 = S.freewater_signals(2000, K3, ht, sch3, seed=5)
+    out3 = FreeWater().fit(Holder(y3, d3, ht, K3))
+    ref3 = oracle.freewater_fit(y3, d3, K3, ht, nthreads=8)
+    assert np.abs(out3['estimates'] - ref3['estimates']).max() < TOL
