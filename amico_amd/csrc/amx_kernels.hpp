@@ -368,6 +368,17 @@ __device__ __forceinline__ void sandi_voxel(const SandiArgs &a, const double *As
     }   // ok
 }
 
+// XCD-aware block -> chunk map.  Workgroup b runs on XCD b % 8 (observed dispatch order; only a
+// speed assumption).  The chunk list is sorted by orientation, so XCD x takes the x-th CONTIGUOUS
+// eighth of it: the dictionary tile and the Gram columns of one orientation are then fetched into
+// ONE XCD's L2 instead of all eight.
+__device__ __forceinline__ int xcd_chunk(int b, int n_chunks)
+{
+    const int per = (n_chunks + 7) >> 3;
+    const int cid = (b & 7) * per + (b >> 3);
+    return ((b >> 3) < per && cid < n_chunks) ? cid : -1;
+}
+
 // ------------------------------------------------------------------ kernel skeleton
 // One workgroup = NW wavefronts sharing one dictionary tile in LDS; each wavefront pulls
 // voxels of the chunk from an LDS ticket counter (iteration counts vary per voxel).
@@ -396,8 +407,9 @@ __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
     AMX_KERNEL_PROLOGUE(float, NR, NQ, NW, MAXP)
     const float *tiles = reinterpret_cast<const float *>(a.c.tiles);
     if (!LIST) {
-        if ((int)blockIdx.x >= *a.c.n_chunks) return;
-        const Chunk ck = a.c.chunks[blockIdx.x];
+        const int cid = xcd_chunk((int)blockIdx.x, *a.c.n_chunks);
+        if (cid < 0) return;
+        const Chunk ck = a.c.chunks[cid];
         stage_tile<float>(As, tiles + (size_t)ck.dir * a.c.tile_stride, words, words_pad - words);
         __syncthreads();
         // static round-robin over the chunk: wave w takes voxels w, w+NW, ... (purely scalar loop
@@ -424,8 +436,9 @@ __global__ void __launch_bounds__(NW * 64) k_freewater(const FwArgs a)
     (void)wmask;
     const float *tiles = reinterpret_cast<const float *>(a.c.tiles);
     if (!LIST) {
-        if ((int)blockIdx.x >= *a.c.n_chunks) return;
-        const Chunk ck = a.c.chunks[blockIdx.x];
+        const int cid = xcd_chunk((int)blockIdx.x, *a.c.n_chunks);
+        if (cid < 0) return;
+        const Chunk ck = a.c.chunks[cid];
         stage_tile<float>(As, tiles + (size_t)ck.dir * a.c.tile_stride, words, words_pad - words);
         __syncthreads();
         // static round-robin over the chunk: wave w takes voxels w, w+NW, ... (purely scalar loop
@@ -452,8 +465,9 @@ __global__ void __launch_bounds__(NW * 64) k_sandi(const SandiArgs a)
     (void)wmask;
     const double *tiles = reinterpret_cast<const double *>(a.c.tiles);
     if (!LIST) {
-        if ((int)blockIdx.x >= *a.c.n_chunks) return;
-        const Chunk ck = a.c.chunks[blockIdx.x];
+        const int cid = xcd_chunk((int)blockIdx.x, *a.c.n_chunks);
+        if (cid < 0) return;
+        const Chunk ck = a.c.chunks[cid];
         stage_tile<double>(As, tiles, words, words_pad - words);
         __syncthreads();
         // static round-robin over the chunk: wave w takes voxels w, w+NW, ... (purely scalar loop

@@ -34,7 +34,7 @@ static int launch_pair(amx_ctx *ctx, Args &a, const Plan &pl, hipStream_t s, KM 
     if ((rc = set_lds(ctx, km, lds_main))) return rc;
     if ((rc = set_lds(ctx, kl, lds_list))) return rc;
     rec(ctx, ev, s);
-    hipLaunchKernelGGL(km, dim3(pl.max_chunks), dim3(nw * 64), lds_main, s, a);
+    hipLaunchKernelGGL(km, dim3(((pl.max_chunks + 7) / 8) * 8), dim3(nw * 64), lds_main, s, a);   // see xcd_chunk()
     AMX_TRACE(ctx, s, "solver main pass");
     Args b = a;
     b.c.ovf_count = pl.ovf_count + 8;
