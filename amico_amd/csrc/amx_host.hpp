@@ -92,3 +92,7 @@ int amx_launch_noddi_s2(amx_ctx *ctx, amx::NoddiArgs &a, const Plan &pl, hipStre
 int amx_launch_noddi_s3(amx_ctx *ctx, amx::NoddiArgs &a, const Plan &pl, hipStream_t s);
 int amx_launch_fw(amx_ctx *ctx, amx::FwArgs &a, const Plan &pl, hipStream_t s);
 int amx_launch_sandi(amx_ctx *ctx, amx::SandiArgs &a, const Plan &pl, hipStream_t s);
+// lane-per-voxel variants for dictionaries of <= 16 atoms (amx_small.hip)
+int amx_launch_fw_small(amx_ctx *ctx, amx::FwArgs &a, const Plan &pl, hipStream_t s);
+int amx_launch_sandi_small(amx_ctx *ctx, amx::SandiArgs &a, const Plan &pl, hipStream_t s);
+static inline bool amx_use_lane_solver(int n_atoms) { const char *e = getenv("AMX_WAVE_PER_VOXEL"); return n_atoms <= 16 && !(e && *e && *e != '0'); }

@@ -1,0 +1,315 @@
+// amx_small.hip -- FreeWater / SANDI fit for small dictionaries (n_atoms <= 16): ONE VOXEL PER LANE.
+//
+// models.pyx:1231-1276 (FreeWater) and :1567-1619 (SANDI) solve, per voxel,
+//     min_x 1/2||y - A x||^2 + lambda1*sum(x) + lambda2/2*||x||^2 ,  x >= 0      (cyspams lasso)
+// with 11..15 atoms and lambda2 > 0.  A wavefront per voxel (amx_solver.hpp) leaves most lanes idle
+// on such problems, so this unit maps one voxel to one LANE:
+//   * the workgroup's voxels share one orientation (bucketing) => A (nS x n) and the regularised
+//     Gram matrix H = A'A + lambda2*I (n x n, built by the workgroup itself in its prologue) sit in
+//     LDS and are read with wave-uniform (broadcast) addresses;
+//   * each lane forms c = A'y from its own signal row and runs a Lawson-Hanson active set on
+//     (H, c) entirely in registers: the passive set is a bit mask, the passive system is solved by a
+//     MASKED Cholesky factorisation (rows/columns outside the set replaced by identity), all loops
+//     are fully unrolled over the compile-time dictionary size => no cross-lane traffic, and lane
+//     divergence is plain SIMT predication.
+// H is well conditioned thanks to the ridge (cond <= ~1e6 for AMICO's defaults), so Gram space is
+// safe here (it is NOT for NODDI's unregularised NNLS stages).
+#include "amx_launch.hpp"
+using namespace amx;
+
+namespace {
+
+template <int N>
+__device__ __forceinline__ constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+
+// per-lane NNQP: min 1/2 x'Hx - cc'x, x >= 0 (cc = c - lambda1); Hs in LDS, row-major N x N.
+// returns 0, or 2 if an iteration cap tripped.
+template <int N>
+__device__ __forceinline__ int lane_nnqp(const double *__restrict__ Hs, const double (&cc)[N], double (&x)[N])
+{
+    const double tol = 1e-12, inf = __builtin_huge_val();
+    double L[N * (N + 1) / 2], linv[N], z[N];
+    unsigned P = 0u;
+    int status = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) x[j] = 0.0;
+    for (int it = 0; status == 0; ++it) {
+        if (it > 3 * N + 8) { status = 2; break; }
+        // dual vector g = cc - H x, most violating atom outside the passive set
+        double best = -inf;
+        int t = -1;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            double g = cc[j];
+#pragma unroll
+            for (int k = 0; k < N; k++) g -= Hs[j * N + k] * x[k];
+            if (!((P >> j) & 1u) && g > best) { best = g; t = j; }
+        }
+        if (!(best > tol)) break;               // KKT point
+        P |= 1u << t;
+        for (int in = 0;; ++in) {
+            if (in > N + 2) { status = 2; break; }
+            // masked Cholesky of H restricted to P (identity elsewhere) and the two triangular solves
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                const bool pj = (P >> j) & 1u;
+                double s = Hs[j * N + j];
+#pragma unroll
+                for (int k = 0; k < j; k++) s -= L[tri<N>(j, k)] * L[tri<N>(j, k)];
+                const double iv = pj ? rsqrt(s) : 1.0;
+                linv[j] = iv;
+                L[tri<N>(j, j)] = pj ? s * iv : 1.0;
+#pragma unroll
+                for (int i = j + 1; i < N; i++) {
+                    double tt = Hs[i * N + j];
+#pragma unroll
+                    for (int k = 0; k < j; k++) tt -= L[tri<N>(i, k)] * L[tri<N>(j, k)];
+                    L[tri<N>(i, j)] = (pj && ((P >> i) & 1u)) ? tt * iv : 0.0;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                double s = ((P >> j) & 1u) ? cc[j] : 0.0;
+#pragma unroll
+                for (int k = 0; k < j; k++) s -= L[tri<N>(j, k)] * z[k];
+                z[j] = s * linv[j];
+            }
+#pragma unroll
+            for (int j = N - 1; j >= 0; j--) {
+                double s = z[j];
+#pragma unroll
+                for (int i = j + 1; i < N; i++) s -= L[tri<N>(i, j)] * z[i];
+                z[j] = s * linv[j];
+            }
+            bool feasible = true;
+#pragma unroll
+            for (int j = 0; j < N; j++)
+                if (((P >> j) & 1u) && !(z[j] > 0.0)) feasible = false;
+            if (feasible) {
+#pragma unroll
+                for (int j = 0; j < N; j++) x[j] = ((P >> j) & 1u) ? z[j] : 0.0;
+                break;
+            }
+            double alpha = inf;
+            int jm = -1;
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                if (((P >> j) & 1u) && !(z[j] > 0.0)) {
+                    const double den = x[j] - z[j];
+                    const double r = (den > 0.0) ? x[j] / den : 0.0;
+                    if (r < alpha) { alpha = r; jm = j; }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                if ((P >> j) & 1u) {
+                    x[j] += alpha * (z[j] - x[j]);
+                    if (j == jm || !(x[j] > 0.0)) { x[j] = 0.0; P &= ~(1u << j); }
+                }
+            }
+            if (P == 0u) break;
+        }
+    }
+    return status;
+}
+
+// workgroup prologue: tile -> LDS, H = A'A + lambda2*I (identity on the padding atoms)
+template <int N, typename AT>
+__device__ __forceinline__ void small_prologue(const AT *__restrict__ tile, int words, AT *As, double *Hs, int nS,
+                                               int ldA, int n_atoms, double lam2)
+{
+    for (int k = threadIdx.x; k < words; k += blockDim.x) As[k] = tile[k];
+    __syncthreads();
+    for (int e = threadIdx.x; e < N * N; e += blockDim.x) {
+        const int j = e / N, k = e % N;
+        double acc = (j == k) ? ((j < n_atoms) ? lam2 : 1.0) : 0.0;
+        if (j < n_atoms && k < n_atoms)
+            for (int i = 0; i < nS; i++) acc += (double)As[i * ldA + j] * (double)As[i * ldA + k];
+        Hs[e] = acc;
+    }
+    __syncthreads();
+}
+
+// c = A'y for this lane's voxel (+ sum y^2); A read with wave-uniform LDS addresses
+template <int N, typename AT>
+__device__ __forceinline__ bool lane_aty(const AT *As, const double *__restrict__ yv, int nS, int ldA, int n_atoms,
+                                         double (&c)[N], double &ysq)
+{
+    bool finite = true;
+    ysq = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; j++) c[j] = 0.0;
+    for (int i = 0; i < nS; i++) {
+        const double yi = yv[i];
+        finite = finite && (fabs(yi) <= 1.79769313486231570e308);
+        ysq += yi * yi;
+#pragma unroll
+        for (int j = 0; j < N; j++)
+            if (j < n_atoms) c[j] += (double)As[i * ldA + j] * yi;
+    }
+    return finite;
+}
+
+template <int N, typename AT>
+__device__ __forceinline__ double lane_rss(const AT *As, const double *__restrict__ yv, int nS, int ldA, int n_atoms,
+                                           const double (&x)[N])
+{
+    double rss = 0.0;
+    for (int i = 0; i < nS; i++) {
+        double e = yv[i];
+#pragma unroll
+        for (int j = 0; j < N; j++)
+            if (j < n_atoms) e -= (double)As[i * ldA + j] * x[j];
+        rss += e * e;
+    }
+    return rss;
+}
+
+#define AMX_SMALL_LDS(AT)                                                                        \
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];                      \
+    const int words = a.c.nS * a.c.ldA;                                                          \
+    AT *As = reinterpret_cast<AT *>(smem_s);                                                     \
+    double *Hs = reinterpret_cast<double *>(smem_s + (((size_t)words * sizeof(AT) + 15) & ~(size_t)15));
+
+template <int N>
+__global__ void __launch_bounds__(256) k_freewater_lane(const FwArgs a)
+{
+    AMX_SMALL_LDS(float)
+    const int cid = xcd_chunk((int)blockIdx.x, *a.c.n_chunks);
+    if (cid < 0) return;
+    const Chunk ck = a.c.chunks[cid];
+    const int nS = a.c.nS, ldA = a.c.ldA, n_atoms = a.c.n_atoms, n_perp = a.n_perp;
+    small_prologue<N, float>(reinterpret_cast<const float *>(a.c.tiles) + (size_t)ck.dir * a.c.tile_stride, words, As,
+                             Hs, nS, ldA, n_atoms, a.c.lam2);
+    for (int v = threadIdx.x; v < ck.count; v += blockDim.x) {
+        const int vox = a.c.perm[ck.start + v];
+        const double *yv = a.c.y + (size_t)vox * nS;
+        double c[N], x[N], ysq;
+        const bool ok = lane_aty<N, float>(As, yv, nS, ldA, n_atoms, c, ysq);
+        double *e = a.est + (size_t)vox * a.n_maps;
+        if (!ok) {
+            const double nan = __builtin_nan("");
+            for (int m = 0; m < a.n_maps; m++) e[m] = nan;
+            if (a.rmse) a.rmse[vox] = nan;
+            if (a.nrmse) a.nrmse[vox] = nan;
+            if (a.ycorr) for (int i = 0; i < nS; i++) a.ycorr[(size_t)vox * nS + i] = nan;
+            continue;
+        }
+#pragma unroll
+        for (int j = 0; j < N; j++) c[j] -= a.c.lam1;
+        if (lane_nnqp<N>(Hs, c, x) != 0) atomicAdd(&a.c.status[ST_ITCAP], 1);
+        // models.pyx:1241-1256
+        double x_sum = 0.0, x_perp = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; j++) { x_sum += x[j]; if (j < n_perp) x_perp += x[j]; }
+        x_sum += 1e-16;
+        const double vv = x_perp / x_sum;
+        e[0] = vv; e[1] = 1.0 - vv;
+        if (a.is_mouse) {
+            double xb = 0.0, xc = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; j++) { if (j == n_perp) xb = x[j]; if (j == n_perp + 1) xc = x[j]; }
+            e[2] = xb / x_sum; e[3] = xc / x_sum;
+        }
+        if (a.rmse || a.nrmse) {
+            const double rss = lane_rss<N, float>(As, yv, nS, ldA, n_atoms, x);
+            if (a.rmse) a.rmse[vox] = sqrt(rss / (double)nS);
+            if (a.nrmse) a.nrmse[vox] = (ysq > 1e-16) ? sqrt(rss / ysq) : 0.0;
+        }
+        if (a.ycorr) {                                   // models.pyx:1264-1274
+            for (int i = 0; i < nS; i++) {
+                double fw = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; j++)
+                    if (j >= n_perp && j < n_atoms) fw += (double)As[i * ldA + j] * x[j];
+                const double yc = yv[i] - fw;
+                a.ycorr[(size_t)vox * nS + i] = yc < 0.0 ? 0.0 : yc;
+            }
+        }
+    }
+}
+
+template <int N>
+__global__ void __launch_bounds__(256) k_sandi_lane(const SandiArgs a)
+{
+    AMX_SMALL_LDS(double)
+    const int cid = xcd_chunk((int)blockIdx.x, *a.c.n_chunks);
+    if (cid < 0) return;
+    const Chunk ck = a.c.chunks[cid];
+    const int nS = a.c.nS, ldA = a.c.ldA, n_atoms = a.c.n_atoms, n_rs = a.n_rs, n_in = a.n_in;
+    small_prologue<N, double>(reinterpret_cast<const double *>(a.c.tiles), words, As, Hs, nS, ldA, n_atoms, a.c.lam2);
+    for (int v = threadIdx.x; v < ck.count; v += blockDim.x) {
+        const int vox = a.c.perm[ck.start + v];
+        const double *yv = a.c.y + (size_t)vox * nS;
+        double c[N], x[N], ysq;
+        const bool ok = lane_aty<N, double>(As, yv, nS, ldA, n_atoms, c, ysq);
+        double *e = a.est + (size_t)vox * 6;
+        if (!ok) {
+            const double nan = __builtin_nan("");
+            for (int m = 0; m < 6; m++) e[m] = nan;
+            if (a.rmse) a.rmse[vox] = nan;
+            if (a.nrmse) a.nrmse[vox] = nan;
+            continue;
+        }
+#pragma unroll
+        for (int j = 0; j < N; j++) c[j] -= a.c.lam1;
+        if (lane_nnqp<N>(Hs, c, x) != 0) atomicAdd(&a.c.status[ST_ITCAP], 1);
+        // models.pyx:1570-1612
+        double x_sum = 0.0, xsph = 0.0, xstk = 0.0, xiso = 0.0, Rsoma = 0.0, Din = 0.0, De = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            if (j < n_atoms) {
+                x[j] *= a.norms[j];
+                x_sum += x[j];
+                if (j < n_rs) { xsph += x[j]; Rsoma += a.Rs[j] * x[j]; }
+                else if (j < n_rs + n_in) { xstk += x[j]; Din += a.d_in[j - n_rs] * x[j]; }
+                else { xiso += x[j]; De += a.d_isos[j - n_rs - n_in] * x[j]; }
+            }
+        }
+        x_sum += 1e-16;
+        e[0] = xsph / x_sum; e[1] = xstk / x_sum; e[2] = xiso / x_sum;
+        e[3] = 1e6 * Rsoma / (xsph + 1e-16);
+        e[4] = 1e3 * Din / (xstk + 1e-16);
+        e[5] = 1e3 * De / (xiso + 1e-16);
+        if (a.rmse || a.nrmse) {
+            // quirk kept (models.pyx:1571 then 1615): errors use the RESCALED x with the NORMALISED A
+            const double rss = lane_rss<N, double>(As, yv, nS, ldA, n_atoms, x);
+            if (a.rmse) a.rmse[vox] = sqrt(rss / (double)nS);
+            if (a.nrmse) a.nrmse[vox] = (ysq > 1e-16) ? sqrt(rss / ysq) : 0.0;
+        }
+    }
+}
+
+template <typename Args, typename K>
+int launch_lane(amx_ctx *ctx, Args &a, const Plan &pl, hipStream_t s, K kern, size_t elem, int N)
+{
+    const size_t lds = (((size_t)a.c.nS * a.c.ldA * elem + 15) & ~(size_t)15) + (size_t)N * N * sizeof(double);
+    if (lds > 160 * 1024) { ctx->err = "dictionary tile does not fit the 160 KB LDS of a CU"; return AMX_E_BADARG; }
+    int rc;
+    if ((rc = set_lds(ctx, kern, lds))) return rc;
+    rec(ctx, 2, s);
+    hipLaunchKernelGGL(kern, dim3(((pl.max_chunks + 7) / 8) * 8), dim3(256), lds, s, a);
+    AMX_TRACE(ctx, s, "lane-per-voxel solver");
+    rec(ctx, 3, s);
+    HIPCHK(ctx, hipGetLastError());
+    return AMX_OK;
+}
+
+}  // namespace
+
+int amx_launch_fw_small(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s)
+{
+    // compile-time dictionary sizes: the reference's defaults (11 Human, 12 Mouse) exactly, 16 otherwise
+    const int n = a.c.n_atoms;
+    if (n <= 11) return launch_lane(ctx, a, pl, s, k_freewater_lane<11>, sizeof(float), 11);
+    if (n == 12) return launch_lane(ctx, a, pl, s, k_freewater_lane<12>, sizeof(float), 12);
+    return launch_lane(ctx, a, pl, s, k_freewater_lane<16>, sizeof(float), 16);
+}
+
+int amx_launch_sandi_small(amx_ctx *ctx, SandiArgs &a, const Plan &pl, hipStream_t s)
+{
+    const int n = a.c.n_atoms;                // SANDI default: 5 + 5 + 5 = 15 atoms
+    if (n <= 12) return launch_lane(ctx, a, pl, s, k_sandi_lane<12>, sizeof(double), 12);
+    if (n <= 15) return launch_lane(ctx, a, pl, s, k_sandi_lane<15>, sizeof(double), 15);
+    return launch_lane(ctx, a, pl, s, k_sandi_lane<16>, sizeof(double), 16);
+}

@@ -245,3 +245,24 @@ def test_other_protocol_shapes(htable500):
     out3 = FreeWater().fit(Holder(y3, d3, ht, K3))
     ref3 = oracle.freewater_fit(y3, d3, K3, ht, nthreads=8)
     assert np.abs(out3['estimates'] - ref3['estimates']).max() < TOL
+
+
+def test_small_models_both_mappings(fw_fix, sandi_fix, htable500, monkeypatch):
+    """FreeWater / SANDI have two device mappings (one voxel per lane for <= 16 atoms, one voxel
+    per wavefront otherwise); both must reproduce the golden maps."""
+    from amico_amd import FreeWater, SANDI
+    res = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('AMX_WAVE_PER_VOXEL', mode)
+        f = fw_fix
+        out = FreeWater().fit(Holder(f['y'], f['dirs'], htable500['htable'], f['kernels'], doSaveCorrectedDWI=True,
+                                     doComputeRMSE=True, doComputeNRMSE=True))
+        assert np.abs(out['estimates'] - f['estimates']).max() < TOL
+        assert np.abs(out['y_corrected'] - f['y_corrected']).max() < TOL
+        s = sandi_fix
+        outs = SANDI().fit(Holder(s['y'], None, None, s['kernels'], doComputeRMSE=True))
+        assert np.abs(outs['estimates'][:, :3] - s['estimates'][:, :3]).max() < TOL
+        res[mode] = (out, outs)
+    assert np.abs(res['0'][0]['rmse'] - res['1'][0]['rmse']).max() < 1e-9
+    assert np.abs(res['0'][0]['nrmse'] - res['1'][0]['nrmse']).max() < 1e-9
+    assert np.abs(res['0'][1]['rmse'] - res['1'][1]['rmse']).max() < 1e-9
