@@ -19,7 +19,7 @@ SYMBOLS = ['amx_version', 'amx_ctx_create', 'amx_ctx_destroy', 'amx_last_error',
            'amx_lut_upload_noddi', 'amx_lut_upload_freewater', 'amx_lut_upload_sandi', 'amx_lut_destroy',
            'amx_dir_to_lut_idx', 'amx_noddi_fit', 'amx_freewater_fit', 'amx_sandi_fit',
            'amx_noddi_fit_device', 'amx_freewater_fit_device', 'amx_sandi_fit_device', 'amx_sync_status',
-           'amx_set_profiling', 'amx_last_kernel_ms', 'amx_last_stats', 'amx_selftest', 'amx_debug_trace']
+           'amx_set_profiling', 'amx_last_kernel_ms', 'amx_last_stats', 'amx_selftest']
 
 _lib = None
 c_vp, c_dp, c_fp = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float)
@@ -73,7 +73,6 @@ def lib():
     L.amx_last_kernel_ms.argtypes = [c_vp, C.c_int, C.POINTER(C.c_float)]
     L.amx_last_stats.argtypes = [c_vp, c_i64p]
     L.amx_selftest.argtypes = [c_vp, c_dp]
-    L.amx_debug_trace.argtypes = [c_vp, c_i32p]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ('amx_version',):

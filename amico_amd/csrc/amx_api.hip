@@ -119,7 +119,6 @@ int amx_ctx_create(int device, amx_ctx **out)
         return AMX_E_HIP;
     }
     for (int k = 0; k < kEv; k++) { hipEventCreate(&ctx->ev[k]); ctx->ev_valid[k] = false; }
-    if (amx_debug() && hipHostMalloc((void **)&ctx->trace_h, 256 * sizeof(int)) == hipSuccess) memset(ctx->trace_h, 0, 256 * sizeof(int));
     reset_status(ctx, nullptr);
     hipStreamSynchronize(nullptr);
     *out = ctx;
@@ -332,14 +331,6 @@ int amx_selftest(amx_ctx *ctx, double *out512)
     return AMX_OK;
 }
 
-int amx_debug_trace(amx_ctx *ctx, int *out64)
-{
-    if (!ctx || !out64) return AMX_E_BADARG;
-    if (!ctx->trace_h) return bad(ctx, "amx_debug_trace: run with AMX_DEBUG=1");
-    for (int k = 0; k < 256; k++) out64[k] = ((volatile int *)ctx->trace_h)[k];
-    return AMX_OK;
-}
-
 int amx_set_profiling(amx_ctx *ctx, int enable)
 {
     if (!ctx) return AMX_E_BADARG;
@@ -390,7 +381,7 @@ int amx_noddi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
     NoddiArgs a;
     memset(&a, 0, sizeof a);
     a.c.tiles = lut->tiles; a.c.y = d_y; a.c.perm = pl.perm; a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks;
-    a.c.lutidx = pl.lutidx; a.c.status = ctx->status_d; a.c.trace = ctx->trace_h; a.c.nS = lut->nS; a.c.ldA = lut->ldA;
+    a.c.lutidx = pl.lutidx; a.c.status = ctx->status_d; a.c.nS = lut->nS; a.c.ldA = lut->ldA;
     a.c.n_atoms = lut->n_atoms; a.c.tile_stride = lut->tile_stride; a.c.lam1 = lambda1; a.c.lam2 = lambda2; a.c.flags = flags;
     a.rowdwi = lut->rowdwi; a.colscale = lut->colscale; a.icvf = lut->icvf; a.kappa = lut->kappa;
     a.n_wm = lut->n_wm; a.is_exvivo = lut->is_exvivo; a.n_maps = 3 + (lut->is_exvivo ? 1 : 0);
@@ -430,7 +421,7 @@ int amx_freewater_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y
     FwArgs a;
     memset(&a, 0, sizeof a);
     a.c.tiles = lut->tiles; a.c.y = d_y; a.c.perm = pl.perm; a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks;
-    a.c.lutidx = pl.lutidx; a.c.status = ctx->status_d; a.c.trace = ctx->trace_h; a.c.nS = lut->nS; a.c.ldA = lut->ldA;
+    a.c.lutidx = pl.lutidx; a.c.status = ctx->status_d; a.c.nS = lut->nS; a.c.ldA = lut->ldA;
     a.c.n_atoms = lut->n_atoms; a.c.tile_stride = lut->tile_stride; a.c.lam1 = lambda1; a.c.lam2 = lambda2; a.c.flags = flags;
     a.n_perp = lut->n_perp; a.n_iso = lut->n_iso; a.is_mouse = is_mouse; a.n_maps = is_mouse ? 4 : 2;
     a.est = d_estimates; a.rmse = (flags & AMX_F_RMSE) ? d_rmse : nullptr;
@@ -465,7 +456,7 @@ int amx_sandi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, in
     SandiArgs a;
     memset(&a, 0, sizeof a);
     a.c.tiles = lut->tiles; a.c.y = d_y; a.c.perm = pl.perm; a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks;
-    a.c.lutidx = pl.lutidx; a.c.status = ctx->status_d; a.c.trace = ctx->trace_h; a.c.nS = lut->nS; a.c.ldA = lut->ldA;
+    a.c.lutidx = pl.lutidx; a.c.status = ctx->status_d; a.c.nS = lut->nS; a.c.ldA = lut->ldA;
     a.c.n_atoms = lut->n_atoms; a.c.tile_stride = lut->tile_stride; a.c.lam1 = lambda1; a.c.lam2 = lambda2; a.c.flags = flags;
     a.norms = lut->norms; a.Rs = lut->Rs; a.d_in = lut->d_in; a.d_isos = lut->d_isos;
     a.n_rs = lut->n_rs; a.n_in = lut->n_in; a.n_iso = lut->n_isos;

@@ -25,7 +25,6 @@ struct amx_ctx {
     DevBuf hy, hdirs, hest, hrmse, hnrmse, hextra;   // staging for the host-pointer entry points
     int *status_d = nullptr;       // ST_WORDS ints
     int *status_h = nullptr;       // pinned mirror (+16 words: copy of the misc counters)
-    int *trace_h = nullptr;        // AMX_DEBUG: 64 host-visible progress words written by the kernels
     bool profiling = false;
     hipEvent_t ev[kEv];
     bool ev_valid[kEv];

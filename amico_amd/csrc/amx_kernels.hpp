@@ -30,7 +30,6 @@ struct FitCommon {
     int *ovf_list;                // voxels whose passive set did not fit MAXP
     int *ovf_count;
     int *status;
-    int *trace;                   // debug: host-visible progress words of the first voxel (or null)
     int nS, ldA, n_atoms;
     int tile_stride;              // elements between consecutive orientation tiles (multiple of 4)
     double lam1, lam2;
@@ -380,11 +379,9 @@ __device__ __forceinline__ int xcd_chunk(int b, int n_chunks)
 }
 
 // ------------------------------------------------------------------ kernel skeleton
-// One workgroup = NW wavefronts sharing one dictionary tile in LDS; each wavefront pulls
-// voxels of the chunk from an LDS ticket counter (iteration counts vary per voxel).
-// LIST mode re-runs single voxels (large-MAXP variant): tile staged per voxel.
-template <typename AT, int NQ>
-__device__ __forceinline__ int tile_words(int nS, int ldA) { return nS * ldA; }
+// One workgroup = up to NW wavefronts sharing one dictionary tile in LDS; wavefront w takes the
+// voxels w, w+nw, ... of its chunk.  LIST mode re-runs single voxels (large-MAXP variant): tile
+// staged per voxel.
 
 #define AMX_KERNEL_PROLOGUE(AT, NRv, NQv, NWv, MPv)                                                        \
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                              \
@@ -399,7 +396,7 @@ __device__ __forceinline__ int tile_words(int nS, int ldA) { return nS * ldA; }
     double *rl = rl_all + wave * (2 * (MPv + 1) * (MPv + 1));                                         \
     unsigned long long *wm_all = reinterpret_cast<unsigned long long *>(rl_all + nw_ * 2 * (MPv + 1) * (MPv + 1)); \
     unsigned long long *wmask = wm_all + wave * 4;                                                    \
-    int *ticket = reinterpret_cast<int *>(wm_all + nw_ * 4);
+
 
 template <int STAGE, int NR, int NQ, int MAXP, int NW, bool LIST>
 __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)

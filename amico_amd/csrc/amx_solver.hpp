@@ -187,20 +187,10 @@ struct NNSolver {
                                          const double (&scl)[NQ],
                                          const unsigned long long (&allowed)[NQ],
                                          double lam1, double lam2, double *rs, double *rl, int lane,
-                                         const double *__restrict__ G = nullptr, int ldG = 0,
-                                         volatile int *trace = nullptr)
+                                         const double *__restrict__ G = nullptr, int ldG = 0)
     {
         Rl = rl;
         Ql = rl + (MAXP + 1) * LDR;
-#ifdef AMX_TRACE_BUILD
-#ifdef AMX_TRACE_BUILD
-#define AMX_TR(slot, val) do { if (trace && lane == 0) { trace[slot] = (val); } } while (0)
-#else
-#define AMX_TR(slot, val) do { (void)trace; } while (0)
-#endif
-#else
-#define AMX_TR(slot, val) do { (void)trace; } while (0)
-#endif
         const double tol = 1e-12;            // KKT tolerance on the dual vector
         const double dep2 = 1e-20;           // (1e-10)^2: relative independence of a new column
         const double inf = __builtin_huge_val();
@@ -227,7 +217,6 @@ struct NNSolver {
 
         for (int outer = 0; status == kSolved; ++outer) {
             if (outer > 2 * itmax) { status = kGuardOuter; break; }   // never spin
-            AMX_TR(1, outer); AMX_TR(2, np); AMX_TR(0, 10);
             double w[NQ];
             const bool exact = (G == nullptr) || !have_u || force_exact || gram_steps >= kMaxGramSteps;
             if (exact) {
@@ -299,7 +288,6 @@ struct NNSolver {
             xprev = x;
 #pragma unroll
             for (int q = 0; q < NQ; q++) w[q] = scl[q] * u[q] - lam1;
-            AMX_TR(0, 20);
 
             // ---- pick the most violating admissible atom; test it; maybe take the next one
             bool added = false, redo = false;
@@ -417,7 +405,6 @@ struct NNSolver {
             // ---- Lawson-Hanson inner loop: restore feasibility of the passive solution
             for (bool feasible = false; !feasible && status == kSolved;) {
                 if (++iters > itmax) { status = kIterCap; break; }
-                AMX_TR(4, iters); AMX_TR(0, 40);
                 double rhs = d - lam1 * e, z = 0.0;
                 {
                     // R z = rhs: column j of R is read one step ahead of its use
@@ -462,9 +449,7 @@ struct NNSolver {
                 }
             }
         }
-        AMX_TR(0, 99); AMX_TR(6, status);
         return status;
-#undef AMX_TR
     }
 };
 

@@ -115,8 +115,6 @@ int amx_last_stats(amx_ctx *ctx, int64_t out[4]);
 /* device self-test of the wavefront primitives (DPP reductions, broadcasts): writes 8 rows of
  * 64 doubles (sum, max, min, bcast lane 37, next-lane, popcount(ballot v>0), int bcast, v) */
 int amx_selftest(amx_ctx *ctx, double *out512);
-/* AMX_DEBUG=1 only: 64 progress words the solver kernels write to host-visible memory */
-int amx_debug_trace(amx_ctx *ctx, int *out64);
 
 #ifdef __cplusplus
 }
