@@ -79,6 +79,14 @@ __device__ __forceinline__ double wave_max(double v)
 __device__ __forceinline__ double wave_min(double v) { return -wave_max(-v); }
 
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __ballot(p); }
+// 1/sqrt(a) to full double precision: hardware estimate + two Newton steps (a > 0, normal range)
+__device__ __forceinline__ double inv_sqrt(double a)
+{
+    double y = __builtin_amdgcn_rsq(a);
+    y = y * (1.5 - 0.5 * a * y * y);
+    y = y * (1.5 - 0.5 * a * y * y);
+    return y;
+}
 // wave-uniform predicate as a scalar (SGPR) value: makes the branch on it a scalar branch
 __device__ __forceinline__ bool uni(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
 
@@ -121,8 +129,11 @@ struct NNSolver {
                 const int lc = lane < MAXP ? lane : MAXP;      // column MAXP is padding
                 const double ra = Rl[j * LDR + lc], rb = Rl[(j + 1) * LDR + lc];
                 const double ga = bcast(ra, j + 1), gb = bcast(rb, j + 1);
-                const double rr = sqrt(ga * ga + gb * gb);
-                const double c = (rr > 0.0) ? ga / rr : 1.0, s = (rr > 0.0) ? gb / rr : 0.0;
+                // one reciprocal square root (v_rsq_f64 + Newton) instead of sqrt and three divisions
+                const double h2 = ga * ga + gb * gb;
+                const double ri = (h2 > 0.0) ? inv_sqrt(h2) : 0.0;
+                const double rr = h2 * ri;
+                const double c = (h2 > 0.0) ? ga * ri : 1.0, s = gb * ri;
                 if (lane > j && lane < np) {
                     Rl[j * LDR + lane] = c * ra + s * rb;
                     Rl[(j + 1) * LDR + lane] = c * rb - s * ra;
@@ -141,7 +152,7 @@ struct NNSolver {
                 {
                     const double d0 = bcast(d, j), d1 = bcast(d, j + 1);
                     const double e0 = bcast(e, j), e1 = bcast(e, j + 1);
-                    if (lane == j) { d = c * d0 + s * d1; e = c * e0 + s * e1; rinv = 1.0 / rr; }
+                    if (lane == j) { d = c * d0 + s * d1; e = c * e0 + s * e1; rinv = ri; }
                     if (lane == j + 1) { d = c * d1 - s * d0; e = c * e1 - s * e0; }
                 }
             }
@@ -207,7 +218,7 @@ struct NNSolver {
         int status = kSolved;
         int last_added = -1;
         n_exact = 0; n_gram = 0;
-        constexpr int kMaxGramSteps = 6;     // bound the drift of the Gram-updated dual vector
+        constexpr int kMaxGramSteps = 12;    // bound the drift of the Gram-updated dual vector
         const double kExactBelow = 1e-7;     // decisions on smaller dual values use the exact sweep
         double u[NQ];                        // atom space: A' r (unscaled, without the l1 shift)
         bool have_u = false, force_exact = false;
@@ -367,13 +378,13 @@ struct NNSolver {
                 bool reject = !uni(b2 > dep2 * n0);
                 double beta = 0.0, binv = 0.0, dnew = 0.0, enew = 0.0;
                 if (!reject) {
-                    beta = sqrt(b2);
-                    binv = 1.0 / beta;
+                    binv = inv_sqrt(b2);
+                    beta = b2 * binv;
                     double vy = 0.0;
 #pragma unroll
                     for (int rr = 0; rr < NR; rr++) vy += v[rr] * yr[rr];
                     dnew = wave_sum(vy) * binv;
-                    enew = (1.0 - wave_sum((lane < np) ? rho * e : 0.0)) * binv;
+                    enew = (lam1 != 0.0) ? (1.0 - wave_sum((lane < np) ? rho * e : 0.0)) * binv : 0.0;   // only the l1 term needs e
                     const double znew = (dnew - lam1 * enew) * binv;   // Lawson-Hanson "ztest"
                     reject = !uni(znew > 0.0);
                 }
