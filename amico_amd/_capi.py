@@ -133,7 +133,7 @@ class Context:
                 'guard_trips': out[3] >> 32, 'guard_last': out[3] & 0xffffffff}
 
     def selftest(self):
-        out = np.zeros((8, 64))
+        out = np.zeros((12, 64))
         self.check(lib().amx_selftest(self._h, _p(out, c_dp)))
         return out
 

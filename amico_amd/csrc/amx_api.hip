@@ -84,6 +84,9 @@ __global__ void k_selftest(double *out)
     out[5 * 64 + lane] = (double)__builtin_popcountll(ballot64(v > 0.0));
     out[6 * 64 + lane] = (double)bcast_i(lane * 3, 21);
     out[7 * 64 + lane] = v;
+    double q4[4] = {v, v * v, 1.0 / (1.0 + lane), (double)(lane & 7) - v};
+    wave_sum4(q4, lane);
+    out[8 * 64 + lane] = q4[0]; out[9 * 64 + lane] = q4[1]; out[10 * 64 + lane] = q4[2]; out[11 * 64 + lane] = q4[3];
 }
 
 int bad(amx_ctx *ctx, const char *msg)
@@ -324,10 +327,10 @@ int amx_selftest(amx_ctx *ctx, double *out512)
     if (!ctx || !out512) return AMX_E_BADARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc;
-    if ((rc = ensure(ctx, ctx->hest, 512 * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->hest, 768 * sizeof(double)))) return rc;
     hipLaunchKernelGGL(k_selftest, dim3(1), dim3(64), 0, nullptr, (double *)ctx->hest.p);
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemcpy(out512, ctx->hest.p, 512 * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(out512, ctx->hest.p, 768 * sizeof(double), hipMemcpyDeviceToHost));
     return AMX_OK;
 }
 

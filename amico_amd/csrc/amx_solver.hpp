@@ -78,6 +78,35 @@ __device__ __forceinline__ double wave_max(double v)
 }
 __device__ __forceinline__ double wave_min(double v) { return -wave_max(-v); }
 
+// Four wavefront sums at once (all lanes receive all four totals).  Instead of four 7-step
+// reductions the values are "transposed" while they are summed: after the two quad_perm
+// exchanges every lane owns ONE of the four partial sums (over its quad), which is then reduced
+// across the 16 quads.  ~43 VALU instead of ~100.
+template <int CTRL>
+__device__ __forceinline__ double dpp_quad(double v)
+{
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void wave_sum4(double (&p)[4], int lane)
+{
+    const bool o1 = lane & 1, o2 = lane & 2;
+    double k0 = o1 ? p[2] : p[0], k1 = o1 ? p[3] : p[1];          // kept pair
+    const double s0 = o1 ? p[0] : p[2], s1 = o1 ? p[1] : p[3];    // pair handed to lane ^ 1
+    k0 += dpp_quad<0xB1>(s0);                                      // quad_perm:[1,0,3,2]
+    k1 += dpp_quad<0xB1>(s1);
+    double k = o2 ? k1 : k0;
+    const double s = o2 ? k0 : k1;                                 // handed to lane ^ 2
+    k += dpp_quad<0x4E>(s);                                        // quad_perm:[2,3,0,1]
+    k += dpp_move<0x114, 0xf, 0xe>(k, 0.0);                        // across the quads of a row
+    k += dpp_move<0x118, 0xf, 0xc>(k, 0.0);
+    k += __shfl_xor(k, 16, kWave);                                 // across the four rows
+    k += __shfl_xor(k, 32, kWave);
+    // lanes 12..15 hold the totals of value 2*(lane&1) + ((lane>>1)&1)
+    p[0] = bcast(k, 12); p[2] = bcast(k, 13); p[1] = bcast(k, 14); p[3] = bcast(k, 15);
+}
+
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __ballot(p); }
 // 1/sqrt(a) to full double precision: hardware estimate + two Newton steps (a > 0, normal range)
 __device__ __forceinline__ double inv_sqrt(double a)
@@ -356,9 +385,8 @@ struct NNSolver {
                                     if (RIDGE) p[u] += Ql[ls + kb + u] * va;
                                 }
                             }
-#pragma unroll
-                            for (int u = 0; u < 4; u++)
-                                if (kb + u < MAXP && kb + u < np) p[u] = wave_sum(p[u]);
+                            if (kb + 1 < np) wave_sum4(p, lane);        // >= 2 live projections: batched
+                            else p[0] = wave_sum(p[0]);
 #pragma unroll
                             for (int u = 0; u < 4; u++) {
                                 if (kb + u < MAXP && kb + u < np) {

@@ -112,9 +112,10 @@ int amx_last_kernel_ms(amx_ctx *ctx, int which, float *out_ms);
  * variant (stage sum), out[1]=voxels hitting the iteration cap, out[2..3] reserved        */
 int amx_last_stats(amx_ctx *ctx, int64_t out[4]);
 
-/* device self-test of the wavefront primitives (DPP reductions, broadcasts): writes 8 rows of
- * 64 doubles (sum, max, min, bcast lane 37, next-lane, popcount(ballot v>0), int bcast, v) */
-int amx_selftest(amx_ctx *ctx, double *out512);
+/* device self-test of the wavefront primitives (DPP reductions, broadcasts): writes 12 rows of
+ * 64 doubles (sum, max, min, bcast lane 37, next-lane, popcount(ballot v>0), int bcast, v, and
+ * the four batched sums of wave_sum4) */
+int amx_selftest(amx_ctx *ctx, double *out768);
 
 #ifdef __cplusplus
 }

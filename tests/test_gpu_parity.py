@@ -206,6 +206,8 @@ def test_wave_primitives():
     assert np.array_equal(out[4][:63], v[1:])
     assert np.array_equal(out[5], np.full(64, float((v > 0).sum())))
     assert np.array_equal(out[6], np.full(64, 63.0))
+    for row, ref in zip(out[8:12], (v, v * v, 1.0 / (1.0 + lane), (lane & 7) - v)):
+        assert np.allclose(row, ref.sum(), rtol=1e-13)      # batched four-value reduction
 
 
 def test_other_protocol_shapes(htable500):
