@@ -1,0 +1,272 @@
+// amx_gram_solver.hpp -- wavefront-per-voxel non-negative elastic net in GRAM space (lambda2 > 0).
+//
+// Same problem and same outer logic as NNSolver (amx_solver.hpp):
+//     min_x 1/2||y - A diag(s) x||^2 + lambda1*sum(x) + lambda2/2*||x||^2 ,  x >= 0
+// but the passive system is solved on H_PP = (S A'A S + lambda2 I)_PP by a Cholesky factor kept in the
+// wavefront's LDS block instead of a thin QR of the passive columns in registers.  This is only
+// legitimate because the ridge bounds cond(H_PP) (~1e5 for NODDI's LASSO stage): it is what SPAMS'
+// LARS does as well.  It is NOT used for the unregularised NNLS stages ("Why not Gram
+// space").  What it buys on gfx950: no Q[MAXP][NR] register block (-64..96 VGPRs => more wavefronts per
+// SIMD) and no Gram-Schmidt reductions (the new row of the factor comes from MAXP gathered Gram entries
+// and one forward substitution).  The dual vector is handled exactly as in NNSolver: Gram-column
+// updates between exact sweeps of the LDS tile, and the final KKT decision on the exact vector.
+#pragma once
+#include "amx_solver.hpp"
+
+namespace amx {
+
+template <int NR, int NQ, int MAXP, typename AT>
+struct GramSolver {
+    static_assert(MAXP <= kWave, "passive set lives in the lanes of one wavefront");
+    static constexpr int LDR = MAXP + 1;
+    double *Hl, *Ll;      // per-wave LDS: H_PP (symmetric, full) and its lower Cholesky factor, row s at s*LDR
+    double x, xprev, sc;  // lane s: coefficient, coefficient at the last dual update, column scale
+    double cs, linv;      // lane s: (s A'y - lambda1) of the slot's atom, 1 / L_ss
+    int idx, np;
+    double r[NR];         // row space: residual y - A s x at exit
+    int iters, n_exact, n_gram;
+
+    __device__ __forceinline__ int row(int lane) const { return (lane < MAXP ? lane : MAXP) * LDR; }
+
+    // Cholesky of the np x np matrix in Hl from scratch (left-looking, lane = row)
+    __device__ __forceinline__ void refactor(int lane)
+    {
+        const int ls = row(lane);
+        for (int k = 0; k < np; k++) {
+            double t = Hl[ls + k];
+            for (int m = 0; m < k; m++) t -= Ll[ls + m] * Ll[k * LDR + m];
+            const double iv = inv_sqrt(bcast(t, k));
+            if (lane >= k && lane < np) Ll[ls + k] = t * iv;
+            if (lane == k) linv = iv;
+        }
+    }
+
+    // z = H_PP^-1 cs by the two triangular solves
+    __device__ __forceinline__ double solve_passive(int lane)
+    {
+        const int ls = row(lane);
+        double f = (lane < np) ? cs : 0.0, wv = 0.0, z = 0.0;
+        for (int k = 0; k < np; k++) {
+            const double lk = Ll[ls + k];
+            const double wk = bcast(f * linv, k);
+            if (lane == k) wv = wk;
+            if (lane > k) f -= lk * wk;
+        }
+        double b = wv;
+        const int lc = lane < MAXP ? lane : MAXP;
+        for (int k = np - 1; k >= 0; k--) {
+            const double lk = Ll[k * LDR + lc];
+            const double zk = bcast(b * linv, k);
+            if (lane == k) z = zk;
+            if (lane < k) b -= lk * zk;
+        }
+        return z;
+    }
+
+    __device__ __forceinline__ void remove_slot(int k, int lane, unsigned &fl)
+    {
+        const int a = bcast_i(idx, k);
+        if (lane == (a & 63)) fl &= ~(0x100u << (a >> 6));
+        // delete row and column k of H_PP (ascending columns: a written entry was already consumed)
+        const int src = row(lane >= k ? lane + 1 : lane), dst = row(lane);
+        for (int m = 0; m < np; m++) {
+            const double v = Hl[src + m];
+            if (m != k && lane < np - 1) Hl[dst + (m > k ? m - 1 : m)] = v;
+        }
+        const double xn = from_next_lane(x), sn = from_next_lane(sc), pn = from_next_lane(xprev), cn = from_next_lane(cs);
+        const int in = from_next_lane(idx);
+        if (lane >= k) { x = xn; sc = sn; idx = in; xprev = pn; cs = cn; }
+        np = __builtin_amdgcn_readfirstlane(np - 1);
+        if (lane >= np) { x = 0.0; xprev = 0.0; cs = 0.0; idx = -1; }
+        refactor(lane);
+    }
+
+    // G: Gram matrix A'A of this orientation restricted to the rows in rowok (REQUIRED here)
+    __device__ __forceinline__ int solve(const AT *As, int ldA, int nS, int n_atoms, const double (&yr)[NR],
+                                         const bool (&rowok)[NR], const double (&scl)[NQ],
+                                         const unsigned long long (&allowed)[NQ], double lam1, double lam2,
+                                         double *rs, double *rl, int lane, const double *__restrict__ G, int ldG)
+    {
+        Hl = rl;
+        Ll = rl + (MAXP + 1) * LDR;
+        const double tol = 1e-12, inf = __builtin_huge_val();
+        const int itmax = 3 * n_atoms + 10;
+        constexpr int kMaxGramSteps = 12;
+        const double kExactBelow = 1e-7;
+        unsigned fl = 0u;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) fl |= (unsigned)((allowed[q] >> lane) & 1ull) << q;
+        np = 0; x = 0.0; xprev = 0.0; sc = 1.0; cs = 0.0; linv = 0.0; idx = -1; iters = 0; n_exact = 0; n_gram = 0;
+        int status = kSolved, last_added = -1, gram_steps = 0;
+        bool have_u = false, force_exact = false;
+        double u[NQ], uy[NQ];                 // atom space: A'r and A'y (unscaled)
+#pragma unroll
+        for (int q = 0; q < NQ; q++) { u[q] = 0.0; uy[q] = 0.0; }
+
+        for (int outer = 0; status == kSolved; ++outer) {
+            if (outer > 2 * itmax) { status = kGuardOuter; break; }
+            const bool exact = !have_u || force_exact || gram_steps >= kMaxGramSteps;
+            if (exact) {
+                // ---- r = y - A (s x) from the tile columns of the passive atoms, then u = A'r
+#pragma unroll
+                for (int rr = 0; rr < NR; rr++) r[rr] = yr[rr];
+                for (int sl = 0; sl < np; sl++) {
+                    const int a = bcast_i(idx, sl);
+                    const double cx = bcast(sc * x, sl);
+#pragma unroll
+                    for (int rr = 0; rr < NR; rr++) {
+                        const int i = lane + kWave * rr;
+                        if (i < nS && rowok[rr]) r[rr] -= (double)As[i * ldA + a] * cx;
+                    }
+                }
+#pragma unroll
+                for (int rr = 0; rr < NR; rr++) rs[lane + kWave * rr] = r[rr];
+                double w2[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; q++) { u[q] = 0.0; w2[q] = 0.0; }
+                {
+                    const AT *ap = As + lane;
+                    int i = 0;
+                    for (; i + 1 < nS; i += 2) {
+                        const double r0 = rs[i], r1 = rs[i + 1];
+#pragma unroll
+                        for (int q = 0; q < NQ; q++) {
+                            u[q] += (double)ap[i * ldA + kWave * q] * r0;
+                            w2[q] += (double)ap[(i + 1) * ldA + kWave * q] * r1;
+                        }
+                    }
+                    if (i < nS) {
+                        const double r0 = rs[i];
+#pragma unroll
+                        for (int q = 0; q < NQ; q++) u[q] += (double)ap[i * ldA + kWave * q] * r0;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NQ; q++) u[q] += w2[q];
+                if (!have_u) {
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) uy[q] = u[q];          // x == 0: u is A'y
+                }
+                have_u = true; force_exact = false; gram_steps = 0; n_exact++;
+            } else {
+                const double delta = sc * (x - xprev);
+                for (int s0 = 0; s0 < np; s0 += 4) {
+                    double gv[4][NQ], dls[4];
+#pragma unroll
+                    for (int t4 = 0; t4 < 4; t4++) {
+                        const int sl = (s0 + t4 < np) ? s0 + t4 : np - 1;
+                        const double dv = bcast(delta, sl);
+                        dls[t4] = (s0 + t4 < np) ? dv : 0.0;
+                        const double *gc = G + (size_t)bcast_i(idx, sl) * ldG + lane;
+#pragma unroll
+                        for (int q = 0; q < NQ; q++) gv[t4][q] = gc[kWave * q];
+                    }
+#pragma unroll
+                    for (int t4 = 0; t4 < 4; t4++) {
+#pragma unroll
+                        for (int q = 0; q < NQ; q++) u[q] -= gv[t4][q] * dls[t4];
+                    }
+                }
+                gram_steps++; n_gram++;
+            }
+            xprev = x;
+            double w[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; q++) w[q] = scl[q] * u[q] - lam1;
+
+            // ---- pick the most violating admissible atom
+            bool added = false, redo = false;
+            for (int sel = 0; status == kSolved && !added; ++sel) {
+                if (sel > kWave * NQ + 2) { status = kGuardSelect; break; }
+                double best = -inf;
+                int bj = -1;
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    const bool cand = ((fl >> q) & 1u) && !((fl >> (8 + q)) & 1u) && !((fl >> (16 + q)) & 1u);
+                    if (cand && w[q] > best) { best = w[q]; bj = lane + kWave * q; }
+                }
+                const double wmax = wave_max(best);
+                if (!exact && uni(!(wmax > kExactBelow))) { force_exact = true; redo = true; break; }
+                if (!uni(wmax > tol)) break;
+                const unsigned long long who = ballot64(best == wmax);
+                if (uni(who == 0ull)) { status = kGuardSelect; break; }
+                const int t = bcast_i(bj, __builtin_ctzll(who));
+                if (uni(t < 0 || t >= n_atoms)) { status = kGuardSelect; break; }
+                if (np >= MAXP) { status = kOverflow; break; }
+                const int tq = t >> 6, tl = t & 63;
+                double sct = 0.0, uyt = 0.0;
+#pragma unroll
+                for (int q = 0; q < NQ; q++)
+                    if (q == tq) { sct = bcast(scl[q], tl); uyt = bcast(uy[q], tl); }
+                // ---- new row of H_PP and of its Cholesky factor
+                const int ls = row(lane);
+                const double h = (lane < np) ? sc * sct * G[(size_t)idx * ldG + t] : 0.0;
+                const double htt = sct * sct * G[(size_t)t * ldG + t] + lam2;
+                double hh = h, lrow = 0.0;
+                for (int k = 0; k < np; k++) {
+                    const double lk_ = Ll[ls + k];
+                    const double lk = bcast(hh * linv, k);
+                    if (lane == k) lrow = lk;
+                    if (lane > k) hh -= lk_ * lk;
+                }
+                const double d2 = htt - wave_sum((lane < np) ? lrow * lrow : 0.0);
+                if (!uni(d2 > 1e-13 * htt)) {                 // cannot happen with lambda2 > 0 (d2 >= lambda2)
+                    if (lane == tl) fl |= 0x10000u << tq;
+                } else {
+                    const int kn = np;
+                    const double iv = inv_sqrt(d2);
+                    if (lane < kn) { Hl[ls + kn] = h; Hl[kn * LDR + lane] = h; Ll[kn * LDR + lane] = lrow; }
+                    if (lane == kn) {
+                        Hl[ls + kn] = htt; Ll[ls + kn] = d2 * iv; linv = iv;
+                        x = 0.0; xprev = 0.0; sc = sct; idx = t; cs = sct * uyt - lam1;
+                    }
+                    fl &= 0xffffu;
+                    if (lane == tl) fl |= 0x100u << tq;
+                    np = kn + 1;
+                    last_added = t;
+                    added = true;
+                }
+            }
+            if (redo) continue;
+            if (!added) break;
+
+            // ---- Lawson-Hanson inner loop
+            for (bool feasible = false; !feasible && status == kSolved;) {
+                if (++iters > itmax) { status = kIterCap; break; }
+                const double z = solve_passive(lane);
+                const bool act = lane < np;
+                const bool neg = act && !(z > 0.0);
+                if (ballot64(neg) == 0ull) {
+                    x = act ? z : 0.0;
+                    feasible = true;
+                } else {
+                    const double den = x - z;
+                    const double ratio = neg ? ((den > 0.0) ? x / den : 0.0) : inf;
+                    const double alpha = wave_min(ratio);
+                    const unsigned long long hit = ballot64(neg && ratio == alpha);
+                    const int kmin = hit ? __builtin_ctzll(hit) : -1;
+                    x = act ? x + alpha * (z - x) : 0.0;
+                    if (lane == kmin) x = 0.0;
+                    unsigned long long rem = ballot64(act && !(x > 0.0));
+                    for (int guard = 0; rem != 0ull && guard < kWave; ++guard) {
+                        const int k = 63 - __builtin_clzll(rem);
+                        rem &= ~(1ull << k);
+                        const int a = bcast_i(idx, k);
+                        if (a == last_added && lane == (a & 63)) fl |= 0x10000u << (a >> 6);
+                        {   // the atom leaves with coefficient 0: fold its change into u now
+                            const double dl = -bcast(sc * xprev, k);
+                            const double *gc = G + (size_t)a * ldG + lane;
+#pragma unroll
+                            for (int q = 0; q < NQ; q++) u[q] -= gc[kWave * q] * dl;
+                        }
+                        remove_slot(k, lane, fl);
+                    }
+                    if (np == 0) { x = 0.0; feasible = true; }
+                }
+            }
+        }
+        return status;
+    }
+};
+
+}  // namespace amx

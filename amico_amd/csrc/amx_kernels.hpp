@@ -9,7 +9,9 @@
 //   k_freewater       models.pyx:1231-1276
 //   k_sandi           models.pyx:1567-1619
 #pragma once
+#include <type_traits>
 #include "amx_solver.hpp"
+#include "amx_gram_solver.hpp"
 
 namespace amx {
 
@@ -76,10 +78,13 @@ struct NoddiArgs {
     double *est, *rmse, *nrmse, *mod;
 };
 
+// STAGE 1 = NNLS (models.pyx:911), 2 = LASSO by the QR solver, 4 = LASSO by the Gram solver
+// (models.pyx:914-926), 3 = debias NNLS + maps (models.pyx:929-967)
 template <int STAGE, int NR, int NQ, int MAXP>
 __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const float *As, double *rs, double *rl,
                                             unsigned long long *wmask, int vox, int dir, int lane)
 {
+    constexpr bool kLasso = (STAGE == 2 || STAGE == 4);
     const int nS = a.c.nS, ldA = a.c.ldA, n_atoms = a.c.n_atoms, n_wm = a.n_wm;
     const int iso_atom = n_atoms - 1, dot_atom = a.is_exvivo ? n_atoms - 2 : -1;
     double yr[NR];
@@ -90,7 +95,7 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const float *As,
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
         const int lo = kWave * q;
-        const int cnt = (STAGE == 2 ? n_wm : n_atoms) - lo;
+        const int cnt = (kLasso ? n_wm : n_atoms) - lo;
         allowed[q] = cnt >= 64 ? ~0ull : (cnt > 0 ? ((1ull << cnt) - 1ull) : 0ull);
         scl[q] = 1.0;
     }
@@ -102,10 +107,10 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const float *As,
             if (a.nrmse) a.nrmse[vox] = __builtin_nan("");
             if (a.mod) { a.mod[(size_t)vox * 2] = __builtin_nan(""); a.mod[(size_t)vox * 2 + 1] = __builtin_nan(""); }
         }
-        if (STAGE == 2 && lane < 4) a.supp[(size_t)vox * 4 + lane] = 0ull;
+        if (kLasso && lane < 4) a.supp[(size_t)vox * 4 + lane] = 0ull;
     }
     if (ok) {
-    if (STAGE == 2) {
+    if (kLasso) {
         // models.pyx:914-925: y2 = max(0, y_dwi - x_iso*iso_dwi (- x_dot)), columns scaled by norms
         const double xiso = a.xiso[(size_t)vox * 2], xdot = a.xiso[(size_t)vox * 2 + 1];
 #pragma unroll
@@ -140,11 +145,11 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const float *As,
         }
     }
 
-    const double *gm = (STAGE == 2) ? a.gram_dwi : a.gram;
-    NNSolver<NR, NQ, MAXP, STAGE == 2, float> S;
+    const double *gm = kLasso ? a.gram_dwi : a.gram;
+    const double *gdir = gm ? gm + (size_t)dir * n_atoms * a.ldG : nullptr;
+    typename std::conditional<STAGE == 4, GramSolver<NR, NQ, MAXP, float>, NNSolver<NR, NQ, MAXP, STAGE == 2, float>>::type S;
     const int st = __builtin_amdgcn_readfirstlane(S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed,
-                           STAGE == 2 ? a.c.lam1 : 0.0, STAGE == 2 ? a.c.lam2 : 0.0, rs, rl, lane,
-                           gm ? gm + (size_t)dir * n_atoms * a.ldG : nullptr, a.ldG));
+                           kLasso ? a.c.lam1 : 0.0, kLasso ? a.c.lam2 : 0.0, rs, rl, lane, gdir, a.ldG));
     if (st == kOverflow) {
         if (lane == 0) {
             const int k = atomicAdd(a.c.ovf_count, 1);
@@ -154,7 +159,7 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const float *As,
     if (st == kIterCap && lane == 0) atomicAdd(&a.c.status[ST_ITCAP], 1);
     if (st > kIterCap && lane == 0) { atomicAdd(&a.c.status[ST_GUARD], 1); a.c.status[ST_GUARDVOX] = vox * 8 + st; }
 #ifdef AMX_STATS
-    if (lane == 0) { atomicAdd(&a.c.status[ST_EXACT + STAGE - 1], S.n_exact); atomicAdd(&a.c.status[ST_GRAM + STAGE - 1], S.n_gram); atomicAdd(&a.c.status[ST_ITERS + STAGE - 1], S.iters); }
+    if (lane == 0) { constexpr int sx = kLasso ? 1 : STAGE - 1; atomicAdd(&a.c.status[ST_EXACT + sx], S.n_exact); atomicAdd(&a.c.status[ST_GRAM + sx], S.n_gram); atomicAdd(&a.c.status[ST_ITERS + sx], S.iters); }
 #endif
     const bool act = lane < S.np;
 
@@ -162,7 +167,7 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const float *As,
         const double xi = wave_sum((act && S.idx == iso_atom) ? S.x : 0.0);
         const double xd = wave_sum((act && S.idx == dot_atom) ? S.x : 0.0);
         if (lane == 0) { a.xiso[(size_t)vox * 2] = xi; a.xiso[(size_t)vox * 2 + 1] = xd; }
-    } else if (STAGE == 2) {
+    } else if (kLasso) {
         if (lane < 4) wmask[lane] = 0ull;
         if (act && S.x > 0.0) atomicOr(&wmask[S.idx >> 6], 1ull << (S.idx & 63));
         if (lane < 4) a.supp[(size_t)vox * 4 + lane] = wmask[lane];

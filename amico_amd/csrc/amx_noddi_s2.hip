@@ -1,9 +1,10 @@
-// amx_noddi_s2.hip -- NODDI solver stage 2 (models.pyx:914-926)
+// amx_noddi_s2.hip -- NODDI solver stage 2, the LASSO (models.pyx:914-926)
 #include "amx_launch.hpp"
 using namespace amx;
 
+// QR (A-space) variant: any lambda2 > 0
 template <int NR>
-static int go(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
+static int go_qr(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
 {
     constexpr int NQ = 3, MP = 20, MB = 64;
     constexpr int NW = 8;   // wavefronts per workgroup: as many as the register budget of this stage allows
@@ -12,7 +13,21 @@ static int go(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
                        1, 4);
 }
 
+// Gram-space variant (amx_gram_solver.hpp): needs the Gram matrices and a ridge that bounds cond(H)
+template <int NR>
+static int go_gram(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
+{
+    constexpr int NQ = 3, MP = 20, MB = 64;
+    constexpr int NW = AMX_S2_NW;
+    return launch_pair<NW>(ctx, a, pl, s, k_noddi<4, NR, NQ, MP, NW, false>, k_noddi<4, NR, NQ, MB, 1, true>,
+                       [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MP); }, fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB),
+                       1, 4);
+}
+
 int amx_launch_noddi_s2(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
 {
-    return a.c.nS <= 128 ? go<2>(ctx, a, pl, s) : go<4>(ctx, a, pl, s);
+    const char *e = getenv("AMX_LASSO_QR");
+    const bool gram = a.gram_dwi != nullptr && a.c.lam2 >= 1e-5 && !(e && *e && *e != '0');
+    if (gram) return a.c.nS <= 128 ? go_gram<2>(ctx, a, pl, s) : go_gram<4>(ctx, a, pl, s);
+    return a.c.nS <= 128 ? go_qr<2>(ctx, a, pl, s) : go_qr<4>(ctx, a, pl, s);
 }
