@@ -18,15 +18,18 @@ namespace amx {
 template <int NR, int NQ, int MAXP, typename AT>
 struct GramSolver {
     static_assert(MAXP <= kWave, "passive set lives in the lanes of one wavefront");
-    static constexpr int LDR = MAXP + 1;
-    double *Hl, *Ll;      // per-wave LDS: H_PP (symmetric, full) and its lower Cholesky factor, row s at s*LDR
+    // per-wave LDS: lower triangles of H_PP and of its Cholesky factor, packed: (i, j <= i) at i(i+1)/2 + j
+    static constexpr int kTri = (MAXP + 1) * (MAXP + 2) / 2;      // one spare row for lanes >= MAXP
+    static constexpr int kLdsWords = 2 * kTri;
+    double *Hl, *Ll;
     double x, xprev, sc;  // lane s: coefficient, coefficient at the last dual update, column scale
     double cs, linv;      // lane s: (s A'y - lambda1) of the slot's atom, 1 / L_ss
     int idx, np;
     double r[NR];         // row space: residual y - A s x at exit
     int iters, n_exact, n_gram;
 
-    __device__ __forceinline__ int row(int lane) const { return (lane < MAXP ? lane : MAXP) * LDR; }
+    __device__ __forceinline__ static int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+    __device__ __forceinline__ static int row(int lane) { const int i = lane < MAXP ? lane : MAXP; return i * (i + 1) / 2; }
 
     // Cholesky of the np x np matrix in Hl from scratch (left-looking, lane = row)
     __device__ __forceinline__ void refactor(int lane)
@@ -34,7 +37,7 @@ struct GramSolver {
         const int ls = row(lane);
         for (int k = 0; k < np; k++) {
             double t = Hl[ls + k];
-            for (int m = 0; m < k; m++) t -= Ll[ls + m] * Ll[k * LDR + m];
+            for (int m = 0; m < k; m++) t -= Ll[ls + m] * Ll[tri(k, m)];
             const double iv = inv_sqrt(bcast(t, k));
             if (lane >= k && lane < np) Ll[ls + k] = t * iv;
             if (lane == k) linv = iv;
@@ -53,9 +56,8 @@ struct GramSolver {
             if (lane > k) f -= lk * wk;
         }
         double b = wv;
-        const int lc = lane < MAXP ? lane : MAXP;
         for (int k = np - 1; k >= 0; k--) {
-            const double lk = Ll[k * LDR + lc];
+            const double lk = Ll[tri(k, lane < k ? lane : k)];
             const double zk = bcast(b * linv, k);
             if (lane == k) z = zk;
             if (lane < k) b -= lk * zk;
@@ -67,11 +69,16 @@ struct GramSolver {
     {
         const int a = bcast_i(idx, k);
         if (lane == (a & 63)) fl &= ~(0x100u << (a >> 6));
-        // delete row and column k of H_PP (ascending columns: a written entry was already consumed)
-        const int src = row(lane >= k ? lane + 1 : lane), dst = row(lane);
-        for (int m = 0; m < np; m++) {
-            const double v = Hl[src + m];
-            if (m != k && lane < np - 1) Hl[dst + (m > k ? m - 1 : m)] = v;
+        // delete row and column k of H_PP in place: new (s, m <= s) <- old (s + [s>=k], m + [m>=k]);
+        // ascending m, and every step reads before it writes, so no entry is consumed after its overwrite
+        {
+            const int s_new = lane < MAXP ? lane : MAXP;
+            const int s_old = (s_new >= k && s_new < MAXP) ? s_new + 1 : s_new;
+            for (int m = 0; m < np - 1; m++) {
+                const int mo = (m >= k) ? m + 1 : m;
+                const double v = Hl[tri(s_old, mo <= s_old ? mo : s_old)];
+                if (lane < np - 1 && m <= s_new) Hl[tri(s_new, m)] = v;
+            }
         }
         const double xn = from_next_lane(x), sn = from_next_lane(sc), pn = from_next_lane(xprev), cn = from_next_lane(cs);
         const int in = from_next_lane(idx);
@@ -88,7 +95,7 @@ struct GramSolver {
                                          double *rs, double *rl, int lane, const double *__restrict__ G, int ldG)
     {
         Hl = rl;
-        Ll = rl + (MAXP + 1) * LDR;
+        Ll = rl + kTri;
         const double tol = 1e-12, inf = __builtin_huge_val();
         const int itmax = 3 * n_atoms + 10;
         constexpr int kMaxGramSteps = 12;
@@ -215,9 +222,9 @@ struct GramSolver {
                 } else {
                     const int kn = np;
                     const double iv = inv_sqrt(d2);
-                    if (lane < kn) { Hl[ls + kn] = h; Hl[kn * LDR + lane] = h; Ll[kn * LDR + lane] = lrow; }
+                    if (lane < kn) { Hl[tri(kn, lane)] = h; Ll[tri(kn, lane)] = lrow; }
                     if (lane == kn) {
-                        Hl[ls + kn] = htt; Ll[ls + kn] = d2 * iv; linv = iv;
+                        Hl[tri(kn, kn)] = htt; Ll[tri(kn, kn)] = d2 * iv; linv = iv;
                         x = 0.0; xprev = 0.0; sc = sct; idx = t; cs = sct * uyt - lam1;
                     }
                     fl &= 0xffffu;

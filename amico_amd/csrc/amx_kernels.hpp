@@ -372,6 +372,13 @@ __device__ __forceinline__ void sandi_voxel(const SandiArgs &a, const double *As
     }   // ok
 }
 
+// doubles of per-wavefront LDS the solver needs besides the residual scratch:
+// QR solver: R and the ridge rows, (MAXP+1)^2 each; Gram solver: two packed triangles
+__host__ __device__ constexpr int solver_lds_words(bool gram, int maxp)
+{
+    return gram ? (maxp + 1) * (maxp + 2) : 2 * (maxp + 1) * (maxp + 1);
+}
+
 // XCD-aware block -> chunk map.  Workgroup b runs on XCD b % 8 (observed dispatch order; only a
 // speed assumption).  The chunk list is sorted by orientation, so XCD x takes the x-th CONTIGUOUS
 // eighth of it: the dictionary tile and the Gram columns of one orientation are then fetched into
@@ -388,7 +395,7 @@ __device__ __forceinline__ int xcd_chunk(int b, int n_chunks)
 // voxels w, w+nw, ... of its chunk.  LIST mode re-runs single voxels (large-MAXP variant): tile
 // staged per voxel.
 
-#define AMX_KERNEL_PROLOGUE(AT, NRv, NQv, NWv, MPv)                                                        \
+#define AMX_KERNEL_PROLOGUE(AT, NRv, NQv, NWv, RLWv)                                                        \
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                              \
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;                                       \
     const int words = a.c.nS * a.c.ldA;                                                               \
@@ -398,15 +405,16 @@ __device__ __forceinline__ int xcd_chunk(int b, int n_chunks)
     double *rs = rs_all + wave * (NRv * kWave);                                                       \
     const int nw_ = (int)blockDim.x >> 6;   /* wavefronts actually launched (<= NWv) */                  \
     double *rl_all = rs_all + nw_ * NRv * kWave;                                                      \
-    double *rl = rl_all + wave * (2 * (MPv + 1) * (MPv + 1));                                         \
-    unsigned long long *wm_all = reinterpret_cast<unsigned long long *>(rl_all + nw_ * 2 * (MPv + 1) * (MPv + 1)); \
+    double *rl = rl_all + wave * (RLWv);                                                              \
+    unsigned long long *wm_all = reinterpret_cast<unsigned long long *>(rl_all + nw_ * (RLWv)); \
     unsigned long long *wmask = wm_all + wave * 4;                                                    \
 
 
 template <int STAGE, int NR, int NQ, int MAXP, int NW, bool LIST>
 __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
 {
-    AMX_KERNEL_PROLOGUE(float, NR, NQ, NW, MAXP)
+    constexpr int RLW = solver_lds_words(STAGE == 4, MAXP);
+    AMX_KERNEL_PROLOGUE(float, NR, NQ, NW, RLW)
     const float *tiles = reinterpret_cast<const float *>(a.c.tiles);
     if (!LIST) {
         const int cid = xcd_chunk((int)blockIdx.x, *a.c.n_chunks);
@@ -434,7 +442,7 @@ __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
 template <int NR, int NQ, int MAXP, int NW, bool LIST>
 __global__ void __launch_bounds__(NW * 64) k_freewater(const FwArgs a)
 {
-    AMX_KERNEL_PROLOGUE(float, NR, NQ, NW, MAXP)
+    AMX_KERNEL_PROLOGUE(float, NR, NQ, NW, solver_lds_words(false, MAXP))
     (void)wmask;
     const float *tiles = reinterpret_cast<const float *>(a.c.tiles);
     if (!LIST) {
@@ -463,7 +471,7 @@ __global__ void __launch_bounds__(NW * 64) k_freewater(const FwArgs a)
 template <int NR, int NQ, int MAXP, int NW, bool LIST>
 __global__ void __launch_bounds__(NW * 64) k_sandi(const SandiArgs a)
 {
-    AMX_KERNEL_PROLOGUE(double, NR, NQ, NW, MAXP)
+    AMX_KERNEL_PROLOGUE(double, NR, NQ, NW, solver_lds_words(false, MAXP))
     (void)wmask;
     const double *tiles = reinterpret_cast<const double *>(a.c.tiles);
     if (!LIST) {
@@ -486,12 +494,12 @@ __global__ void __launch_bounds__(NW * 64) k_sandi(const SandiArgs a)
 }
 
 template <typename AT>
-static inline size_t fit_lds_bytes(int nS, int ldA, int NR, int NQ, int NW, int MAXP)
+static inline size_t fit_lds_bytes(int nS, int ldA, int NR, int NQ, int NW, int MAXP, bool gram = false)
 {
     const size_t words_pad = ((size_t)nS * ldA + kWave * NQ + 3) & ~(size_t)3;
     size_t b = (words_pad * sizeof(AT) + 15) & ~(size_t)15;
     b += (size_t)NW * NR * kWave * sizeof(double);
-    b += (size_t)NW * 2 * (MAXP + 1) * (MAXP + 1) * sizeof(double);
+    b += (size_t)NW * solver_lds_words(gram, MAXP) * sizeof(double);
     b += (size_t)NW * 4 * sizeof(unsigned long long);
     b += 16;
     return b;
