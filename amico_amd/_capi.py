@@ -19,7 +19,8 @@ SYMBOLS = ['amx_version', 'amx_ctx_create', 'amx_ctx_destroy', 'amx_last_error',
            'amx_lut_upload_noddi', 'amx_lut_upload_freewater', 'amx_lut_upload_sandi', 'amx_lut_destroy',
            'amx_dir_to_lut_idx', 'amx_noddi_fit', 'amx_freewater_fit', 'amx_sandi_fit',
            'amx_noddi_fit_device', 'amx_freewater_fit_device', 'amx_sandi_fit_device', 'amx_sync_status',
-           'amx_set_profiling', 'amx_last_kernel_ms', 'amx_last_stats', 'amx_selftest']
+           'amx_set_profiling', 'amx_last_kernel_ms', 'amx_last_stats', 'amx_selftest',
+           'amx_dti_create', 'amx_dti_destroy', 'amx_dti_directions', 'amx_dti_directions_device']
 
 _lib = None
 c_vp, c_dp, c_fp = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float)
@@ -73,6 +74,11 @@ def lib():
     L.amx_last_kernel_ms.argtypes = [c_vp, C.c_int, C.POINTER(C.c_float)]
     L.amx_last_stats.argtypes = [c_vp, c_i64p]
     L.amx_selftest.argtypes = [c_vp, c_dp]
+    L.amx_dti_create.argtypes = [c_vp, c_dp, C.c_int, C.c_double, C.POINTER(c_vp)]
+    L.amx_dti_destroy.argtypes = [c_vp]
+    L.amx_dti_destroy.restype = None
+    L.amx_dti_directions.argtypes = [c_vp, c_vp, c_dp, C.c_int64, c_dp]
+    L.amx_dti_directions_device.argtypes = [c_vp, c_vp, c_vp, C.c_int64, c_vp, c_vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ('amx_version',):
@@ -266,3 +272,40 @@ def dir_to_lut_idx(ctx, lut, dirs):
     out = np.zeros(dirs.shape[0], dtype=np.int32)
     ctx.check(lib().amx_dir_to_lut_idx(ctx._h, lut._h, _p(dirs, c_dp), dirs.shape[0], _p(out, c_i32p)))
     return out
+
+
+class Dti:
+    """amx_dti: principal-direction estimator of one acquisition scheme (include/amico_amd.h, row f1)."""
+
+    def __init__(self, ctx, inv_design, min_signal=1e-4):
+        w = np.ascontiguousarray(inv_design, dtype=np.float64)
+        if w.ndim != 2 or w.shape[0] != 7:
+            raise ValueError('inv_design must be pinv(design matrix), shape [7, nS]')
+        self.ctx, self.nS = ctx, w.shape[1]
+        self._h = c_vp()
+        ctx.check(lib().amx_dti_create(ctx._h, _p(w, c_dp), self.nS, float(min_signal), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, '_h', None) and getattr(self.ctx, '_h', None):
+            lib().amx_dti_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def directions(self, y):
+        """y f64[n_vox, nS] (host) -> f64[n_vox, 3]."""
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        if y.ndim != 2 or y.shape[1] != self.nS:
+            raise ValueError('y must be [n_vox, %d]' % self.nS)
+        out = np.zeros((y.shape[0], 3))
+        self.ctx.check(lib().amx_dti_directions(self.ctx._h, self._h, _p(y, c_dp), y.shape[0], _p(out, c_dp)))
+        return out
+
+    def directions_device(self, d_y, n_vox, d_dirs, stream=None):
+        """device pointers (ints), enqueued on `stream`; check with ctx.sync(stream)."""
+        self.ctx.check(lib().amx_dti_directions_device(self.ctx._h, self._h, c_vp(d_y), int(n_vox), c_vp(d_dirs),
+                                                       c_vp(stream or 0)))

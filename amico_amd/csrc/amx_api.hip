@@ -7,16 +7,7 @@ using namespace amx;
 
 namespace {
 
-int ensure(amx_ctx *ctx, DevBuf &b, size_t bytes)
-{
-    if (bytes <= b.cap && b.p) return AMX_OK;
-    if (b.p) HIPCHK(ctx, hipFree(b.p));
-    b.p = nullptr; b.cap = 0;
-    const size_t want = bytes + bytes / 8 + 256;
-    HIPCHK(ctx, hipMalloc(&b.p, want));
-    b.cap = want;
-    return AMX_OK;
-}
+int ensure(amx_ctx *ctx, DevBuf &b, size_t bytes) { return amx_ensure(ctx, b, bytes); }
 
 template <typename T>
 int upload(amx_ctx *ctx, T **dst, const T *src, size_t n)
@@ -89,11 +80,7 @@ __global__ void k_selftest(double *out)
     out[8 * 64 + lane] = q4[0]; out[9 * 64 + lane] = q4[1]; out[10 * 64 + lane] = q4[2]; out[11 * 64 + lane] = q4[3];
 }
 
-int bad(amx_ctx *ctx, const char *msg)
-{
-    if (ctx) ctx->err = msg;
-    return AMX_E_BADARG;
-}
+int bad(amx_ctx *ctx, const char *msg) { return amx_bad(ctx, msg); }
 
 }  // namespace
 
@@ -344,7 +331,7 @@ int amx_set_profiling(amx_ctx *ctx, int enable)
 
 int amx_last_kernel_ms(amx_ctx *ctx, int which, float *out_ms)
 {
-    if (!ctx || !out_ms || which < 0 || which > 3) return AMX_E_BADARG;
+    if (!ctx || !out_ms || which < 0 || which > 4) return AMX_E_BADARG;
     const int a = which == 0 ? 0 : 2 * which, b = which == 0 ? 1 : 2 * which + 1;
     if (!ctx->ev_valid[a] || !ctx->ev_valid[b]) return bad(ctx, "amx_last_kernel_ms: no profiled call");
     HIPCHK(ctx, hipEventSynchronize(ctx->ev[b]));

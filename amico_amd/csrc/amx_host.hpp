@@ -48,6 +48,14 @@ struct amx_lut {
     double *norms = nullptr, *Rs = nullptr, *d_in = nullptr, *d_isos = nullptr;
 };
 
+// principal-direction estimator of one acquisition scheme (amx_signal.hip)
+struct amx_dti {
+    amx_ctx *ctx = nullptr;
+    int nS = 0;
+    double min_signal = 0.0;
+    double *wt = nullptr;          // device f64[nS][6]: transposed first six rows of pinv(design matrix)
+};
+
 #define HIPCHK(ctx, call)                                                                         \
     do {                                                                                          \
         hipError_t e_ = (call);                                                                   \
@@ -59,6 +67,24 @@ struct amx_lut {
             return AMX_E_HIP;                                                                     \
         }                                                                                         \
     } while (0)
+
+static inline int amx_bad(amx_ctx *ctx, const char *msg)
+{
+    if (ctx) ctx->err = msg;
+    return AMX_E_BADARG;
+}
+
+// grow-only device workspace
+static inline int amx_ensure(amx_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap && b.p) return AMX_OK;
+    if (b.p) HIPCHK(ctx, hipFree(b.p));
+    b.p = nullptr; b.cap = 0;
+    const size_t want = bytes + bytes / 8 + 256;
+    HIPCHK(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return AMX_OK;
+}
 
 // misc buffer layout (ints): [0] n_chunks, [4..6] overflow counters of the 3 stages,
 // [12] voxels that did not fit the large-MAXP variant either

@@ -1,0 +1,238 @@
+// amx_signal.hip -- the steps either side of model.fit (SURVEY section 8 f): principal directions from the
+// log-linear tensor fit (core.py:431-436, 456-458) -- streaming, HBM-bound kernels.
+#include "amx_host.hpp"
+
+using namespace amx;
+
+namespace amx {
+
+constexpr int kDtiVox = 64;                 // voxels per tile
+constexpr int kDtiThreads = 4 * kDtiVox;    // four lanes share one voxel's contraction
+
+// One Jacobi rotation annihilating a[P][Q] of the symmetric 3x3 matrix a; v accumulates the eigenvectors (columns).
+template <int P, int Q>
+__device__ __forceinline__ void jacobi_rotate(double (&a)[3][3], double (&v)[3][3])
+{
+    constexpr int R = 3 - P - Q;
+    const double apq = a[P][Q];
+    // t = tan(rotation angle), the smaller root of t^2 + 2 t theta - 1 = 0 with theta = (aqq - app) / (2 apq)
+    const double w = a[Q][Q] - a[P][P];
+    const double den = fabs(w) + sqrt(w * w + 4.0 * apq * apq);
+    double t = den > 0.0 ? 2.0 * apq / den : 0.0;
+    t = w < 0.0 ? -t : t;
+    const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+    a[P][P] -= t * apq;
+    a[Q][Q] += t * apq;
+    a[P][Q] = a[Q][P] = 0.0;
+    const double arp = a[R][P], arq = a[R][Q];
+    a[R][P] = a[P][R] = c * arp - s * arq;
+    a[R][Q] = a[Q][R] = s * arp + c * arq;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const double vip = v[i][P], viq = v[i][Q];
+        v[i][P] = c * vip - s * viq;
+        v[i][Q] = s * vip + c * viq;
+    }
+}
+
+// Eigenvector of the largest eigenvalue of the symmetric tensor (lower-triangular order Dxx Dxy Dyy Dxz Dyz Dzz):
+// what `decompose_tensor` (dipy/reconst/dti.py) returns as evecs[:, 0] after sorting eigh's output in descending
+// order -- up to the sign, which LAPACK leaves unspecified and dir_to_lut_idx folds away (lut.pyx:335-338).
+__device__ inline void principal_direction(const double d[6], double out[3])
+{
+    double a[3][3] = {{d[0], d[1], d[3]}, {d[1], d[2], d[4]}, {d[3], d[4], d[5]}};
+    double v[3][3] = {{1.0, 0.0, 0.0}, {0.0, 1.0, 0.0}, {0.0, 0.0, 1.0}};
+#pragma unroll 1
+    for (int sweep = 0; sweep < 6; sweep++) {     // cyclic Jacobi converges quadratically: 6 sweeps >> fp64 for 3x3
+        jacobi_rotate<0, 1>(a, v);
+        jacobi_rotate<0, 2>(a, v);
+        jacobi_rotate<1, 2>(a, v);
+    }
+    const bool c1 = a[1][1] > a[0][0];
+    double best = c1 ? a[1][1] : a[0][0];
+    double x = c1 ? v[0][1] : v[0][0], y = c1 ? v[1][1] : v[1][0], z = c1 ? v[2][1] : v[2][0];
+    const bool c2 = a[2][2] > best;
+    x = c2 ? v[0][2] : x; y = c2 ? v[1][2] : y; z = c2 ? v[2][2] : z;
+    const double inv = 1.0 / sqrt(x * x + y * y + z * z);
+    out[0] = x * inv; out[1] = y * inv; out[2] = z * inv;
+}
+
+// y f64[n][nS] -> dirs f64[n][3].  Tiles of `tv` voxels (tv * nS <= kDtiPre * 2 * kDtiThreads doubles):
+// (1) the tile is streamed with 16-byte lane loads into registers one tile AHEAD of its use, so that the HBM
+// latency is covered by the arithmetic of the previous tile; (2) log(max(y, min_signal)) (TensorModel.fit +
+// ols_fit_tensor, dipy/reconst/dti.py) goes to LDS; (3) four lanes per voxel contract the log-signal with the first
+// six rows of pinv(design matrix) (LDS, [nS][6]); (4) wavefront 0 diagonalises the tile's tensors (one per lane)
+// while the other wavefronts already take the logarithms of the next tile.
+constexpr int kDtiPre = 16;                 // double2 registers per thread holding the tile in flight
+
+__device__ __forceinline__ void dti_prefetch(double2 (&pre)[kDtiPre], const double *__restrict__ src, int cnt, int tid)
+{
+#pragma unroll
+    for (int i = 0; i < kDtiPre; i++) {
+        const int e = 2 * (tid + i * kDtiThreads);
+        if (e + 1 < cnt) pre[i] = *reinterpret_cast<const double2 *>(src + e);
+        else if (e < cnt) pre[i] = make_double2(src[e], 1.0);
+    }
+}
+
+__global__ __launch_bounds__(kDtiThreads) void k_dti_dirs(const double *__restrict__ y, const double *__restrict__ wt,
+                                                         int nS, int ldl, int tv, long long n, double min_signal,
+                                                         double *__restrict__ dirs)
+{
+    extern __shared__ double sm[];
+    double *wl = sm;                                   // nS * 6
+    double *yl = sm + ((nS * 6 + 1) & ~1);             // tv * ldl
+    double *dl = yl + tv * ldl;                        // tv * 7 (6 tensor entries, odd stride)
+    const int tid = threadIdx.x;
+    for (int i = tid; i < nS * 6; i += kDtiThreads) wl[i] = wt[i];
+    const long long n_tiles = (n + tv - 1) / tv;
+    const float inv_nS = 1.0f / (float)nS;
+    double2 pre[kDtiPre];
+    long long tile = blockIdx.x;
+    if (tile < n_tiles) {
+        const long long v0 = tile * tv;
+        dti_prefetch(pre, y + v0 * nS, (int)((n - v0) < tv ? (n - v0) : tv) * nS, tid);
+    }
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const long long v0 = tile * tv;
+        const int nv = (int)((n - v0) < tv ? (n - v0) : tv);
+        const int cnt = nv * nS;
+#pragma unroll
+        for (int i = 0; i < kDtiPre; i++) {
+            const int e = 2 * (tid + i * kDtiThreads);
+            if (e < cnt) {
+                const int vx0 = (int)(((float)e + 0.5f) * inv_nS);
+                yl[vx0 * ldl + (e - vx0 * nS)] = log(fmax(pre[i].x, min_signal));
+            }
+            if (e + 1 < cnt) {
+                const int vx1 = (int)(((float)e + 1.5f) * inv_nS);
+                yl[vx1 * ldl + (e + 1 - vx1 * nS)] = log(fmax(pre[i].y, min_signal));
+            }
+        }
+        __syncthreads();                               // log-signals of this tile are in LDS
+        const long long nt = tile + gridDim.x;
+        if (nt < n_tiles) {
+            const long long w0 = nt * tv;
+            dti_prefetch(pre, y + w0 * nS, (int)((n - w0) < tv ? (n - w0) : tv) * nS, tid);
+        }
+        const int vox = tid >> 2, q = tid & 3;
+        double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (vox < nv) {
+            const double *yr = yl + vox * ldl;
+            for (int v = q; v < nS; v += 4) {
+                const double ly = yr[v];
+                const double *w = wl + v * 6;
+#pragma unroll
+                for (int k = 0; k < 6; k++) acc[k] = fma(w[k], ly, acc[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            acc[k] += __shfl_xor(acc[k], 1);
+            acc[k] += __shfl_xor(acc[k], 2);
+        }
+        if (q == 0 && vox < nv) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) dl[vox * 7 + k] = acc[k];
+        }
+        __syncthreads();                               // tensors in LDS; the log-signal rows may be overwritten
+        if (tid < nv) {
+            double d[6], o[3];
+#pragma unroll
+            for (int k = 0; k < 6; k++) d[k] = dl[tid * 7 + k];
+            principal_direction(d, o);
+            double *dst = dirs + (v0 + tid) * 3;
+            dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+        }
+    }
+}
+
+}  // namespace amx
+
+extern "C" {
+
+int amx_dti_create(amx_ctx *ctx, const double *inv_design, int nS, double min_signal, amx_dti **out)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!inv_design || !out || nS < 7 || nS > 2048) return amx_bad(ctx, "amx_dti_create: need inv_design f64[7][nS], 7 <= nS <= 2048");
+    if (!(min_signal > 0.0)) return amx_bad(ctx, "amx_dti_create: min_signal must be positive");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<double> wt((size_t)nS * 6);
+    for (int v = 0; v < nS; v++)
+        for (int k = 0; k < 6; k++) wt[(size_t)v * 6 + k] = inv_design[(size_t)k * nS + v];
+    amx_dti *h = new amx_dti;
+    h->ctx = ctx; h->nS = nS; h->min_signal = min_signal;
+    hipError_t e = hipMalloc((void **)&h->wt, wt.size() * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(h->wt, wt.data(), wt.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (h->wt) (void)hipFree(h->wt);
+        delete h;
+        ctx->err = std::string("amx_dti_create: ") + hipGetErrorString(e);
+        return AMX_E_HIP;
+    }
+    *out = h;
+    return AMX_OK;
+}
+
+void amx_dti_destroy(amx_dti *h)
+{
+    if (!h) return;
+    if (h->ctx) (void)hipSetDevice(h->ctx->device);
+    if (h->wt) (void)hipFree(h->wt);
+    delete h;
+}
+
+int amx_dti_directions_device(amx_ctx *ctx, const amx_dti *h, const double *d_y, int64_t n_vox, double *d_dirs,
+                              void *hip_stream)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!h || h->ctx != ctx) return amx_bad(ctx, "amx_dti_directions: not an estimator of this ctx");
+    if (n_vox < 0) return amx_bad(ctx, "amx_dti_directions: bad n_vox");
+    if (n_vox == 0) return AMX_OK;
+    if (!d_y || !d_dirs) return amx_bad(ctx, "amx_dti_directions: null buffer");
+    if (((uintptr_t)d_y & 15) != 0) return amx_bad(ctx, "amx_dti_directions: y must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)hip_stream;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int nS = h->nS;
+    int ldl = (nS + 3) & ~3;                  // row stride = 4 * odd doubles: the 16 quads of a wavefront read
+    if (((ldl >> 2) & 1) == 0) ldl += 4;      // conflict-free LDS rows
+    int tv = (kDtiPre * 2 * kDtiThreads) / nS;   // voxels per tile: what the prefetch registers hold, even, <= kDtiVox
+    tv = tv > kDtiVox ? kDtiVox : (tv & ~1);
+    const size_t lds = ((size_t)((nS * 6 + 1) & ~1) + (size_t)tv * ldl + (size_t)tv * 7) * sizeof(double);
+    if (tv < 2 || lds > 160 * 1024) return amx_bad(ctx, "amx_dti_directions: scheme too long for the LDS tile");
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_dti_dirs, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const long long n_tiles = (n_vox + tv - 1) / tv;
+    const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
+    long long grid = 256LL * (per_cu > 8 ? 8 : per_cu);
+    if (grid > n_tiles) grid = n_tiles;
+    rec(ctx, 8, s);
+    hipLaunchKernelGGL(k_dti_dirs, dim3((unsigned)grid), dim3(kDtiThreads), lds, s, d_y, h->wt, nS, ldl, tv,
+                       (long long)n_vox, h->min_signal, d_dirs);
+    HIPCHK(ctx, hipGetLastError());
+    rec(ctx, 9, s);
+    return AMX_OK;
+}
+
+int amx_dti_directions(amx_ctx *ctx, const amx_dti *h, const double *y, int64_t n_vox, double *out_dirs)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!h || h->ctx != ctx) return amx_bad(ctx, "amx_dti_directions: not an estimator of this ctx");
+    if (n_vox == 0) return AMX_OK;
+    if (n_vox < 0 || !y || !out_dirs) return amx_bad(ctx, "amx_dti_directions: bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    const size_t yb = (size_t)n_vox * h->nS * sizeof(double), db = (size_t)n_vox * 3 * sizeof(double);
+    if ((rc = amx_ensure(ctx, ctx->hy, yb))) return rc;
+    if ((rc = amx_ensure(ctx, ctx->hdirs, db))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->hy.p, y, yb, hipMemcpyHostToDevice, nullptr));
+    if ((rc = amx_dti_directions_device(ctx, h, (const double *)ctx->hy.p, n_vox, (double *)ctx->hdirs.p, nullptr))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(out_dirs, ctx->hdirs.p, db, hipMemcpyDeviceToHost, nullptr));
+    HIPCHK(ctx, hipStreamSynchronize(nullptr));
+    return AMX_OK;
+}
+
+}  // extern "C"

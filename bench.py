@@ -93,6 +93,65 @@ def other_models(args):
                       'solver_stats': ctx.last_stats()}))
 
 
+def dti_directions(args):
+    """Principal-direction step before the fit (SURVEY section 8 f row 1): y f64[n, 99] -> dirs f64[n, 3], HBM-bound."""
+    import torch
+    from amico_amd import dti, synthetic as S
+    from oracle import signal_np
+    dev = torch.device('cuda', 0)
+    n = args.voxels
+    lut_dirs = S.fibonacci_hemisphere(500)
+    scheme = S.make_scheme()
+    K = S.noddi_kernels(scheme, lut_dirs)
+    y_h, _ = S.noddi_signals(n, K, S.build_htable(lut_dirs), scheme, seed=1)
+    est = dti.TensorDirections.from_scheme(scheme)
+    ctx = est.ctx
+    y = torch.from_numpy(y_h).to(dev)
+    d = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+    ctx.set_profiling(True)
+    for _ in range(args.warmup):
+        est.fit_device(y.data_ptr(), n, d.data_ptr()); ctx.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kms = 0.0
+    for _ in range(args.steps):
+        est.fit_device(y.data_ptr(), n, d.data_ptr()); ctx.sync()
+        kms += ctx.last_kernel_ms(4)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    kms /= args.steps
+    m = min(n, 200000)
+    t1 = time.perf_counter()
+    ref, ev = signal_np.dti_directions(y_h[:m], scheme.b, scheme.raw[:, :3], return_evals=True)
+    cpu = m / (time.perf_counter() - t1)
+    ok = (ev[:, 0] - ev[:, 1]) > 1e-6 * np.abs(ev[:, 0])
+    g = d[:m].cpu().numpy()
+    err = np.linalg.norm(np.cross(g[ok], ref[ok]), axis=1)
+    bpv = 8 * scheme.nS + 24
+    print(json.dumps({'metric': 'voxels/sec, principal directions (log-linear tensor fit)', 'value': n * args.steps / el,
+                      'unit': 'voxels/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+                      'ms_per_step': 1e3 * el / args.steps, 'dtype': 'f64', 'data': 'synthetic',
+                      'config': {'workload': 'DTI OLS directions, %d voxels, 99-volume 2-shell scheme' % n},
+                      'roofline': {'bound': 'hbm', 'achieved': bpv * n / (kms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
+                                   'unit': 'GB/s', 'frac': bpv * n / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                                   'kernel': 'k_dti_dirs', 'kernel_ms': kms, 'bytes_per_voxel': bpv},
+                      'parity': {'sample_voxels': int(ok.sum()), 'max_sin_angle': float(err.max())},
+                      'cpu_baseline': {'value': cpu, 'unit': 'voxels/s', 'cores': 1, 'kind': 'port',
+                                       'sample': '%d voxels, numpy restatement of dipy OLS (pinv + log + batched eigh)' % m}}))
+
+
+def pmc_traffic(stage, n):
+    """HBM bytes per launch of the stage kernel from the committed rocprofv3 PMC passes (profiles/), scaled to
+    this run's voxels per launch; None when the profile summary is not there."""
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')
+    try:
+        with open(p) as f:
+            t = json.load(f)
+        return float(t['stage_bytes_per_launch'][str(stage)]) * n / t['voxels_per_launch']
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -101,9 +160,11 @@ def main():
     ap.add_argument('--voxels', type=int, default=1_000_000, help='voxels per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--host', action='store_true', help='also time the host-buffer entry point (PCIe inclusive)')
-    ap.add_argument('--model', default='noddi', choices=['noddi', 'freewater', 'sandi'],
+    ap.add_argument('--model', default='noddi', choices=['noddi', 'freewater', 'sandi', 'dti'],
                     help='noddi = the BASELINE.json headline; the others are extra measurements (configs 3, 4)')
     args = ap.parse_args()
+    if args.model == 'dti':
+        return dti_directions(args)
     if args.model != 'noddi':
         return other_models(args)
 
@@ -179,6 +240,7 @@ def main():
         stage = int(np.argmax(kms[1:4])) + 1
         dom_ms = float(kms[stage])
         achieved = BYTES_PER_VOXEL * n / (dom_ms * 1e-3) / 1e9
+        traffic = pmc_traffic(stage, n)
         out = {
             'metric': 'voxels/sec (whole node), NODDI fit',
             'value': value, 'unit': 'voxels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -189,7 +251,9 @@ def main():
                        'voxels_per_gpu': n, 'global_voxels': world * n,
                        'parallelism': 'voxel shards x%d, one RCCL all_gather of the maps per step' % world},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'traffic_source': 'profiles/pmc_traffic.json (rocprofv3 --pmc, bytes per launch)'
+                                           if traffic is not None else None,
                          'kernel': 'k_noddi<stage %d>' % stage, 'kernel_ms': dom_ms,
                          'stage_ms': [float(v) for v in kms[1:4]], 'all_kernels_ms': float(kms[0]),
                          'note': 'path is fp64-VALU/LDS bound, not HBM bound (DESIGN.md section 5)'},

@@ -102,10 +102,29 @@ int amx_sandi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, in
                          double *d_rmse, double *d_nrmse, void *hip_stream);
 int amx_sync_status(amx_ctx *ctx, void *hip_stream);
 
+/* ---- next rows of the hot-path table (SURVEY.md section 8 f): the steps either side of model.fit ---- */
+
+/* (f1) principal directions, core.py:431-436 + 456-458:
+ *     DTI = dipy.reconst.dti.TensorModel(gtab, fit_method='OLS');  DIRs = np.squeeze(DTI.fit(y).directions)
+ * i.e. per voxel  p = pinv(design_matrix(gtab)) @ log(max(y, min_signal)),  D = lower-triangular p[0:6]
+ * (Dxx Dxy Dyy Dxz Dyz Dzz), direction = eigenvector of the largest eigenvalue of D (dipy/reconst/dti.py:
+ * TensorModel.fit, ols_fit_tensor, decompose_tensor; dipy>=1.4.1, requirements.txt:3).  The sign of an
+ * eigenvector is not defined (LAPACK's choice in the reference); dir_to_lut_idx folds it away (lut.pyx:335-338).
+ * inv_design f64[7][nS] (host, C-order) = numpy.linalg.pinv(design matrix) -- one-off per scheme, host side;
+ * min_signal = dipy's MIN_POSITIVE_SIGNAL (1e-4) unless the caller configured another.                        */
+typedef struct amx_dti amx_dti;
+int  amx_dti_create(amx_ctx *ctx, const double *inv_design, int nS, double min_signal, amx_dti **out);
+void amx_dti_destroy(amx_dti *h);
+/* y f64[n_vox][nS] -> dirs f64[n_vox][3]; host buffers (blocking) / device buffers (enqueued on hip_stream) */
+int amx_dti_directions(amx_ctx *ctx, const amx_dti *h, const double *y, int64_t n_vox, double *out_dirs);
+int amx_dti_directions_device(amx_ctx *ctx, const amx_dti *h, const double *d_y, int64_t n_vox,
+                              double *d_dirs, void *hip_stream);
+
 /* ---- measurement hooks (bench.py): HIP-event time of the solver kernels of the LAST
  * *_fit_device call on this ctx, measured on the stream they were launched on.
  * which: 0 = all kernels of the call, 1..3 = solver stage kernels (NODDI: NNLS-1, LASSO,
- * NNLS-3; FreeWater/SANDI: 1 = the single solver kernel).  Requires amx_set_profiling(1). */
+ * NNLS-3; FreeWater/SANDI: 1 = the single solver kernel), 4 = the last amx_dti_directions_device kernel.
+ * Requires amx_set_profiling(1). */
 int amx_set_profiling(amx_ctx *ctx, int enable);
 int amx_last_kernel_ms(amx_ctx *ctx, int which, float *out_ms);
 /* solver statistics of the last call: out[0]=voxels re-run with the large active-set
