@@ -20,7 +20,9 @@ SYMBOLS = ['amx_version', 'amx_ctx_create', 'amx_ctx_destroy', 'amx_last_error',
            'amx_dir_to_lut_idx', 'amx_noddi_fit', 'amx_freewater_fit', 'amx_sandi_fit',
            'amx_noddi_fit_device', 'amx_freewater_fit_device', 'amx_sandi_fit_device', 'amx_sync_status',
            'amx_set_profiling', 'amx_last_kernel_ms', 'amx_last_stats', 'amx_selftest',
-           'amx_dti_create', 'amx_dti_destroy', 'amx_dti_directions', 'amx_dti_directions_device']
+           'amx_dti_create', 'amx_dti_destroy', 'amx_dti_directions', 'amx_dti_directions_device',
+           'amx_prep_create', 'amx_prep_destroy', 'amx_prep_gather', 'amx_prep_gather_device',
+           'amx_prep_mean_b0', 'amx_prep_mean_b0_device', 'amx_prep_scatter', 'amx_prep_scatter_device']
 
 _lib = None
 c_vp, c_dp, c_fp = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float)
@@ -79,6 +81,16 @@ def lib():
     L.amx_dti_destroy.restype = None
     L.amx_dti_directions.argtypes = [c_vp, c_vp, c_dp, C.c_int64, c_dp]
     L.amx_dti_directions_device.argtypes = [c_vp, c_vp, c_vp, C.c_int64, c_vp, c_vp]
+    L.amx_prep_create.argtypes = [c_vp, c_i64p, c_i64p, C.c_int, c_i32p, C.c_int64, c_i32p, c_i32p, C.c_int,
+                                  c_i32p, C.c_int, C.c_int, C.POINTER(c_vp)]
+    L.amx_prep_destroy.argtypes = [c_vp]
+    L.amx_prep_destroy.restype = None
+    L.amx_prep_gather.argtypes = [c_vp, c_vp, c_fp, C.c_int, C.c_float, c_dp, c_fp]
+    L.amx_prep_gather_device.argtypes = [c_vp, c_vp, c_vp, C.c_int, C.c_float, c_vp, c_vp, c_vp]
+    L.amx_prep_mean_b0.argtypes = [c_vp, c_vp, c_fp, c_fp]
+    L.amx_prep_mean_b0_device.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp]
+    L.amx_prep_scatter.argtypes = [c_vp, c_vp, c_dp, C.c_int, c_fp]
+    L.amx_prep_scatter_device.argtypes = [c_vp, c_vp, c_vp, C.c_int, c_vp, c_vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ('amx_version',):
@@ -309,3 +321,74 @@ class Dti:
         """device pointers (ints), enqueued on `stream`; check with ctx.sync(stream)."""
         self.ctx.check(lib().amx_dti_directions_device(self.ctx._h, self._h, c_vp(d_y), int(n_vox), c_vp(d_dirs),
                                                        c_vp(stream or 0)))
+
+
+class Prep:
+    """amx_prep: signal-preparation / result-scatter plan of one image geometry + mask + volume grouping."""
+
+    def __init__(self, ctx, shape, strides, rank, groups, b0_idx, overwrite_in_order=False):
+        """shape (X, Y, Z, nS); strides = element strides of the float32 image; rank int32[X, Y, Z] (C order);
+        groups = list of index lists (one per output volume)."""
+        self.ctx = ctx
+        self.shape = tuple(int(v) for v in shape)
+        self.strides = tuple(int(v) for v in strides)
+        dims = np.asarray(self.shape[:3], dtype=np.int64)
+        st = np.asarray(self.strides, dtype=np.int64)
+        rank = np.ascontiguousarray(rank, dtype=np.int32)
+        if rank.shape != self.shape[:3]:
+            raise ValueError('rank must have the spatial shape of the image')
+        self.n_vox = int((rank >= 0).sum())
+        gptr = np.zeros(len(groups) + 1, dtype=np.int32)
+        gptr[1:] = np.cumsum([len(g) for g in groups])
+        gidx = np.ascontiguousarray(np.concatenate([np.asarray(g, dtype=np.int32).ravel() for g in groups]), dtype=np.int32)
+        b0 = np.ascontiguousarray(b0_idx, dtype=np.int32)
+        self.n_out = len(groups)
+        self.extent = 1 + sum((d - 1) * s for d, s in zip(self.shape, self.strides))
+        self._h = c_vp()
+        ctx.check(lib().amx_prep_create(ctx._h, _p(dims, c_i64p), _p(st, c_i64p), self.shape[3], _p(rank, c_i32p),
+                                        self.n_vox, _p(gptr, c_i32p), _p(gidx, c_i32p), self.n_out,
+                                        _p(b0, c_i32p) if len(b0) else None, len(b0), int(bool(overwrite_in_order)),
+                                        C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, '_h', None) and getattr(self.ctx, '_h', None):
+            lib().amx_prep_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _img_buffer(self, img):
+        """the float32 image as the flat element buffer the strides refer to (no copy for C / Fortran arrays)"""
+        if img.dtype != np.float32 or img.shape != self.shape or \
+                tuple(s // 4 for s in img.strides) != self.strides:
+            raise ValueError('image does not match the plan (dtype float32, shape, strides)')
+        flat = np.lib.stride_tricks.as_strided(img, shape=(self.extent,), strides=(4,))
+        return flat
+
+    def gather(self, img, normalize=True, b0_threshold=0.0):
+        buf = self._img_buffer(img)
+        y = np.zeros((self.n_vox, self.n_out))
+        mb0 = np.zeros(self.n_vox, dtype=np.float32)
+        self.ctx.check(lib().amx_prep_gather(self.ctx._h, self._h, _p(buf, c_fp), int(bool(normalize)),
+                                             float(b0_threshold), _p(y, c_dp), _p(mb0, c_fp)))
+        return y, (mb0 if normalize else None)
+
+    def mean_b0(self, img):
+        buf = self._img_buffer(img)
+        out = np.zeros(self.shape[:3], dtype=np.float32)
+        self.ctx.check(lib().amx_prep_mean_b0(self.ctx._h, self._h, _p(buf, c_fp), _p(out, c_fp)))
+        return out
+
+    def scatter(self, values):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        if v.ndim == 1:
+            v = v[:, None]
+        if v.shape[0] != self.n_vox:
+            raise ValueError('values must have one row per masked voxel')
+        out = np.zeros(self.shape[:3] + (v.shape[1],), dtype=np.float32)
+        self.ctx.check(lib().amx_prep_scatter(self.ctx._h, self._h, _p(v, c_dp), v.shape[1], _p(out, c_fp)))
+        return out

@@ -56,6 +56,21 @@ struct amx_dti {
     double *wt = nullptr;          // device f64[nS][6]: transposed first six rows of pinv(design matrix)
 };
 
+// signal preparation plan of one (image geometry, mask, scheme, options) combination (amx_volume.hip)
+struct amx_prep {
+    amx_ctx *ctx = nullptr;
+    long long d[3] = {0, 0, 0};    // spatial extents, d[0] = axis that is fastest in the image's memory
+    long long s[3] = {0, 0, 0};    // element strides of those axes in the image
+    long long c[3] = {0, 0, 0};    // strides of those axes in a C-ordered [X][Y][Z] volume
+    long long sv = 0;              // element stride of the volume axis
+    long long extent = 0;          // elements spanned by the image (largest offset + 1)
+    long long n_total = 0, n_vox = 0;
+    int nS = 0, n_out = 0, n_b0 = 0, inplace = 0, layout = 0;   // layout: 1 planar (s[0]==1), 2 interleaved (sv==1), 0 generic
+    int *rank = nullptr;           // device int32[d2][d1][d0]: index in the masked list or -1
+    long long *cidx = nullptr;     // device int64[n_vox]: C-order linear index of the masked voxels
+    int *gptr = nullptr, *gidx = nullptr, *b0idx = nullptr;
+};
+
 #define HIPCHK(ctx, call)                                                                         \
     do {                                                                                          \
         hipError_t e_ = (call);                                                                   \

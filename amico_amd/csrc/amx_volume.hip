@@ -1,0 +1,344 @@
+// amx_volume.hip -- the bandwidth kernels either side of the fit (SURVEY section 8 f, rows 2 and 3):
+// 4-D float32 image -> masked, b0-normalised, (b0-merged | shell-averaged), clipped float64 signals, and the
+// scatter of the per-voxel results back into float32 volumes.  Reference: core.py:209-223 (normalisation),
+// 225-268 (b0 merge, directional average), 451-452 (mask gather + clip), 472-498 (scatter).
+#include "amx_host.hpp"
+
+using namespace amx;
+
+namespace amx {
+
+// the lanes of a wavefront exchange data through LDS: order the accesses, no workgroup barrier needed
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+constexpr int kPrepWaves = 2;               // wavefronts per workgroup, one 64-voxel tile each
+
+struct PrepArgs {
+    const float *img; const int *rank; double *y; float *mean_b0;
+    long long d0, d1, d2, s0, s1, s2, sv;
+    long long n_tiles, tiles_per_row;
+    int nS, n_out, n_b0, ldt, inplace, layout, normalize;
+    const int *gptr, *gidx, *b0idx;
+    float thr;
+};
+
+// One wavefront per tile of 64 voxels that are consecutive along the image's fastest spatial axis.
+//  (1) the tile's nS values per voxel go to LDS T[voxel][volume] (odd row stride) with coalesced loads in either
+//      memory layout: planar (x fastest, one 256-byte run per volume) or interleaved (volume fastest, one row per voxel);
+//  (2) lane = voxel: mean of the b0 volumes (float32, summed in index order like numpy reduces the fancy-indexed
+//      array of core.py:213), norm factor (core.py:216-220), row scaled in place (core.py:221-222), then every output
+//      volume = float32 mean of its group of input volumes in index order (core.py:225-227 / 236-252);
+//  (3) rows are written to y[rank][:] as float64 with negative values clipped (core.py:451-452), coalesced per row.
+__global__ __launch_bounds__(64 * kPrepWaves) void k_prep_gather(PrepArgs a)
+{
+    extern __shared__ float smf[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per_wave = 64 * a.ldt * (a.inplace ? 1 : 2);
+    float *T = smf + (size_t)wave * per_wave;
+    float *O = a.inplace ? T : T + 64 * a.ldt;
+    const long long wave_id = (long long)blockIdx.x * kPrepWaves + wave, n_waves = (long long)gridDim.x * kPrepWaves;
+    for (long long t = wave_id; t < a.n_tiles; t += n_waves) {
+        const long long row = t / a.tiles_per_row;
+        const long long x0 = (t - row * a.tiles_per_row) * 64;
+        const long long i2 = row / a.d1, i1 = row - i2 * a.d1;
+        const long long x = x0 + lane;
+        const int r = x < a.d0 ? a.rank[(i2 * a.d1 + i1) * a.d0 + x] : -1;
+        const unsigned long long live = __ballot(r >= 0);
+        if (live == 0ull) continue;
+        const long long base = x0 * a.s0 + i1 * a.s1 + i2 * a.s2;
+        float *row_l = T + lane * a.ldt;
+        if (a.layout == 2) {
+            // interleaved: lanes run over the volumes of one voxel
+            for (int k = 0; k < 64; k++) {
+                if (!((live >> k) & 1ull)) continue;
+                const float *src = a.img + base + k * a.s0;
+                for (int v = lane; v < a.nS; v += 64) T[k * a.ldt + v] = src[v];
+            }
+        } else if (r >= 0) {
+            // planar (or generic strides): lanes run over the voxels of one volume
+            const float *src = a.img + base + lane * a.s0;
+            int v = 0;
+            for (; v + 8 <= a.nS; v += 8) {
+                float t8[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) t8[u] = src[(long long)(v + u) * a.sv];
+#pragma unroll
+                for (int u = 0; u < 8; u++) row_l[v + u] = t8[u];
+            }
+            for (; v < a.nS; v++) row_l[v] = src[(long long)v * a.sv];
+        }
+        WAVE_SYNC();
+        if (r >= 0) {
+            if (a.normalize) {
+                float m = 0.0f;
+                for (int i = 0; i < a.n_b0; i++) m = m + row_l[a.b0idx[i]];
+                m = m / (float)a.n_b0;
+                if (a.mean_b0) a.mean_b0[r] = m;
+                const float f = (m <= a.thr) ? 0.0f : 1.0f / m;      // norm_factor[idx] = 0, else 1 / mean_b0
+                for (int v = 0; v < a.nS; v++) row_l[v] = row_l[v] * f;
+            }
+            float *out_l = O + lane * a.ldt;
+            for (int j = 0; j < a.n_out; j++) {
+                const int g0 = a.gptr[j], g1 = a.gptr[j + 1];
+                float acc = row_l[a.gidx[g0]];
+                if (g1 - g0 > 1) {
+                    for (int g = g0 + 1; g < g1; g++) acc = acc + row_l[a.gidx[g]];
+                    acc = acc / (float)(g1 - g0);
+                }
+                out_l[j] = acc;
+            }
+        }
+        WAVE_SYNC();
+        for (int k = 0; k < 64; k++) {
+            if (!((live >> k) & 1ull)) continue;
+            const int rk = __builtin_amdgcn_readlane(r, k);
+            double *dst = a.y + (long long)rk * a.n_out;
+            for (int j = lane; j < a.n_out; j += 64) {
+                const float val = O[k * a.ldt + j];
+                dst[j] = (double)(val < 0.0f ? 0.0f : val);
+            }
+        }
+        WAVE_SYNC();
+    }
+}
+
+// float32 mean of the b0 volumes of EVERY voxel (self.mean_b0s, core.py:213), written in C order [X][Y][Z]
+__global__ void k_mean_b0(const float *img, long long d0, long long d1, long long d2, long long s0, long long s1,
+                          long long s2, long long sv, long long c0, long long c1, long long c2, const int *b0idx,
+                          int n_b0, float *out)
+{
+    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= d0 * d1 * d2) return;
+    const long long i0 = m % d0, i1 = (m / d0) % d1, i2 = m / (d0 * d1);
+    const float *src = img + i0 * s0 + i1 * s1 + i2 * s2;
+    float acc = 0.0f;
+    for (int i = 0; i < n_b0; i++) acc = acc + src[(long long)b0idx[i] * sv];
+    out[i0 * c0 + i1 * c1 + i2 * c2] = acc / (float)n_b0;
+}
+
+// RESULTS[...][mask == 1, :] = values (core.py:472-498): f64[n][k] -> float32 volume [X][Y][Z][k] (C order, zeroed by the host)
+__global__ void k_scatter(const double *src, const long long *cidx, long long n, int k, float *vol)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * k) return;
+    const long long v = i / k;
+    vol[cidx[v] * k + (i - v * k)] = (float)src[i];
+}
+
+}  // namespace amx
+
+namespace {
+
+template <typename T>
+int dev_copy(amx_ctx *ctx, T **dst, const T *src, size_t n)
+{
+    HIPCHK(ctx, hipMalloc((void **)dst, (n ? n : 1) * sizeof(T)));
+    if (n) HIPCHK(ctx, hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return AMX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void amx_prep_destroy(amx_prep *p)
+{
+    if (!p) return;
+    if (p->ctx) (void)hipSetDevice(p->ctx->device);
+    void *ps[] = {p->rank, p->cidx, p->gptr, p->gidx, p->b0idx};
+    for (void *q : ps) if (q) (void)hipFree(q);
+    delete p;
+}
+
+int amx_prep_create(amx_ctx *ctx, const int64_t dims[3], const int64_t strides[4], int nS, const int32_t *rank,
+                    int64_t n_vox, const int32_t *group_ptr, const int32_t *group_idx, int n_out,
+                    const int32_t *b0_idx, int n_b0, int overwrite_in_order, amx_prep **out)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!dims || !strides || !rank || !group_ptr || !group_idx || !out) return amx_bad(ctx, "amx_prep_create: null argument");
+    if (nS < 1 || n_out < 1 || n_out > nS || n_b0 < 0 || (n_b0 > 0 && !b0_idx) || n_vox < 0)
+        return amx_bad(ctx, "amx_prep_create: bad sizes (need 1 <= n_out <= nS)");
+    for (int k = 0; k < 3; k++) if (dims[k] < 1 || strides[k] < 1) return amx_bad(ctx, "amx_prep_create: dims and strides must be positive");
+    if (strides[3] < 1) return amx_bad(ctx, "amx_prep_create: strides must be positive");
+    const long long total = (long long)dims[0] * dims[1] * dims[2];
+    if (total > INT_MAX || n_vox > total) return amx_bad(ctx, "amx_prep_create: volume too large");
+    if (group_ptr[0] != 0) return amx_bad(ctx, "amx_prep_create: group_ptr[0] must be 0");
+    int inplace = 1;
+    for (int j = 0; j < n_out; j++) {
+        if (group_ptr[j + 1] <= group_ptr[j]) return amx_bad(ctx, "amx_prep_create: empty output group");
+        for (int g = group_ptr[j]; g < group_ptr[j + 1]; g++) {
+            if (group_idx[g] < 0 || group_idx[g] >= nS) return amx_bad(ctx, "amx_prep_create: group index out of range");
+            // output j would overwrite an input a later group still needs -- unless that is what the caller asks
+            // for (the shell average of core.py:231-245 writes into a VIEW of the image it keeps reading from)
+            if (group_idx[g] < j && !overwrite_in_order) inplace = 0;
+        }
+    }
+    for (int i = 0; i < n_b0; i++) if (b0_idx[i] < 0 || b0_idx[i] >= nS) return amx_bad(ctx, "amx_prep_create: b0 index out of range");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // spatial axes sorted by stride: ax[0] is the fastest one in memory
+    int ax[3] = {0, 1, 2};
+    for (int i = 0; i < 3; i++)
+        for (int j = i + 1; j < 3; j++)
+            if (strides[ax[j]] < strides[ax[i]]) { const int t = ax[i]; ax[i] = ax[j]; ax[j] = t; }
+    const long long cstride[3] = {(long long)dims[1] * dims[2], (long long)dims[2], 1};
+    amx_prep *p = new amx_prep;
+    p->ctx = ctx; p->nS = nS; p->n_out = n_out; p->n_b0 = n_b0; p->inplace = inplace;
+    p->n_total = total; p->n_vox = n_vox; p->sv = strides[3];
+    for (int k = 0; k < 3; k++) { p->d[k] = dims[ax[k]]; p->s[k] = strides[ax[k]]; p->c[k] = cstride[ax[k]]; }
+    p->layout = p->s[0] == 1 ? 1 : (p->sv == 1 ? 2 : 0);
+    p->extent = 1 + (long long)(nS - 1) * strides[3];
+    for (int k = 0; k < 3; k++) p->extent += (long long)(dims[k] - 1) * strides[k];
+    // rank in the image's memory-axis order, C-order positions of the masked voxels
+    std::vector<int> rank_mem((size_t)total);
+    std::vector<long long> cidx((size_t)n_vox, -1);
+    long long seen = 0;
+    bool ok = true;
+    for (long long i2 = 0; i2 < p->d[2]; i2++)
+        for (long long i1 = 0; i1 < p->d[1]; i1++)
+            for (long long i0 = 0; i0 < p->d[0]; i0++) {
+                const long long c = i0 * cstride[ax[0]] + i1 * cstride[ax[1]] + i2 * cstride[ax[2]];
+                const int r = rank[c];
+                rank_mem[(size_t)((i2 * p->d[1] + i1) * p->d[0] + i0)] = r;
+                if (r >= 0) {
+                    if (r >= n_vox || cidx[(size_t)r] != -1) ok = false;
+                    else { cidx[(size_t)r] = c; seen++; }
+                }
+            }
+    if (!ok || seen != n_vox) { delete p; return amx_bad(ctx, "amx_prep_create: rank must number the masked voxels 0..n_vox-1 exactly once"); }
+    int rc = dev_copy(ctx, &p->rank, rank_mem.data(), rank_mem.size());
+    if (!rc) rc = dev_copy(ctx, &p->cidx, cidx.data(), cidx.size());
+    if (!rc) rc = dev_copy(ctx, &p->gptr, group_ptr, (size_t)n_out + 1);
+    if (!rc) rc = dev_copy(ctx, &p->gidx, group_idx, (size_t)group_ptr[n_out]);
+    if (!rc) rc = dev_copy(ctx, &p->b0idx, b0_idx, (size_t)n_b0);
+    if (rc) { amx_prep_destroy(p); return rc; }
+    *out = p;
+    return AMX_OK;
+}
+
+int amx_prep_gather_device(amx_ctx *ctx, const amx_prep *p, const float *d_img, int normalize, float b0_threshold,
+                           double *d_y, float *d_mean_b0, void *hip_stream)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!p || p->ctx != ctx) return amx_bad(ctx, "amx_prep_gather: not a plan of this ctx");
+    if (normalize && p->n_b0 == 0) return amx_bad(ctx, "amx_prep_gather: no b0 volume to normalize signal with");   // core.py:214-215
+    if (p->n_vox == 0) return AMX_OK;
+    if (!d_img || !d_y) return amx_bad(ctx, "amx_prep_gather: null buffer");
+    hipStream_t s = (hipStream_t)hip_stream;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PrepArgs a;
+    memset(&a, 0, sizeof a);
+    a.img = d_img; a.rank = p->rank; a.y = d_y; a.mean_b0 = normalize ? d_mean_b0 : nullptr;
+    a.d0 = p->d[0]; a.d1 = p->d[1]; a.d2 = p->d[2]; a.s0 = p->s[0]; a.s1 = p->s[1]; a.s2 = p->s[2]; a.sv = p->sv;
+    a.tiles_per_row = (p->d[0] + 63) / 64;
+    a.n_tiles = a.tiles_per_row * p->d[1] * p->d[2];
+    a.nS = p->nS; a.n_out = p->n_out; a.n_b0 = p->n_b0; a.ldt = p->nS | 1; a.inplace = p->inplace;
+    a.layout = p->layout; a.normalize = normalize ? 1 : 0;
+    a.gptr = p->gptr; a.gidx = p->gidx; a.b0idx = p->b0idx; a.thr = b0_threshold;
+    const size_t lds = (size_t)kPrepWaves * 64 * a.ldt * (a.inplace ? 1 : 2) * sizeof(float);
+    if (lds > 160 * 1024) return amx_bad(ctx, "amx_prep_gather: scheme too long for the LDS tile");
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_prep_gather, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int per_cu = (int)((160 * 1024) / lds) > 8 ? 8 : (int)((160 * 1024) / lds);
+    long long grid = 256LL * per_cu * 2;
+    const long long need = (a.n_tiles + kPrepWaves - 1) / kPrepWaves;
+    if (grid > need) grid = need;
+    rec(ctx, 8, s);
+    hipLaunchKernelGGL(k_prep_gather, dim3((unsigned)grid), dim3(64 * kPrepWaves), lds, s, a);
+    HIPCHK(ctx, hipGetLastError());
+    rec(ctx, 9, s);
+    return AMX_OK;
+}
+
+int amx_prep_mean_b0_device(amx_ctx *ctx, const amx_prep *p, const float *d_img, float *d_mean_b0_volume, void *hip_stream)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!p || p->ctx != ctx) return amx_bad(ctx, "amx_prep_mean_b0: not a plan of this ctx");
+    if (p->n_b0 == 0) return amx_bad(ctx, "amx_prep_mean_b0: no b0 volume to normalize signal with");
+    if (!d_img || !d_mean_b0_volume) return amx_bad(ctx, "amx_prep_mean_b0: null buffer");
+    hipStream_t s = (hipStream_t)hip_stream;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const long long blocks = (p->n_total + 255) / 256;
+    hipLaunchKernelGGL(k_mean_b0, dim3((unsigned)blocks), dim3(256), 0, s, d_img, p->d[0], p->d[1], p->d[2], p->s[0],
+                       p->s[1], p->s[2], p->sv, p->c[0], p->c[1], p->c[2], p->b0idx, p->n_b0, d_mean_b0_volume);
+    HIPCHK(ctx, hipGetLastError());
+    return AMX_OK;
+}
+
+int amx_prep_scatter_device(amx_ctx *ctx, const amx_prep *p, const double *d_values, int n_cols, float *d_volume,
+                            void *hip_stream)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!p || p->ctx != ctx) return amx_bad(ctx, "amx_prep_scatter: not a plan of this ctx");
+    if (n_cols < 1 || !d_volume || (p->n_vox > 0 && !d_values)) return amx_bad(ctx, "amx_prep_scatter: bad argument");
+    hipStream_t s = (hipStream_t)hip_stream;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemsetAsync(d_volume, 0, (size_t)p->n_total * n_cols * sizeof(float), s));     // np.zeros(...)
+    if (p->n_vox == 0) return AMX_OK;
+    const long long blocks = (p->n_vox * n_cols + 255) / 256;
+    hipLaunchKernelGGL(k_scatter, dim3((unsigned)blocks), dim3(256), 0, s, d_values, p->cidx, p->n_vox, n_cols, d_volume);
+    HIPCHK(ctx, hipGetLastError());
+    return AMX_OK;
+}
+
+// ---- host-buffer variants (H2D + kernel + D2H, blocking)
+int amx_prep_gather(amx_ctx *ctx, const amx_prep *p, const float *img, int normalize, float b0_threshold,
+                    double *out_y, float *out_mean_b0)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!p || p->ctx != ctx) return amx_bad(ctx, "amx_prep_gather: not a plan of this ctx");
+    if (p->n_vox == 0) return AMX_OK;
+    if (!img || !out_y) return amx_bad(ctx, "amx_prep_gather: null buffer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    const size_t ib = (size_t)p->extent * sizeof(float), yb = (size_t)p->n_vox * p->n_out * sizeof(double);
+    if ((rc = amx_ensure(ctx, ctx->hextra, ib))) return rc;
+    if ((rc = amx_ensure(ctx, ctx->hy, yb))) return rc;
+    if ((rc = amx_ensure(ctx, ctx->hrmse, (size_t)p->n_vox * sizeof(float)))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->hextra.p, img, ib, hipMemcpyHostToDevice, nullptr));
+    if ((rc = amx_prep_gather_device(ctx, p, (const float *)ctx->hextra.p, normalize, b0_threshold, (double *)ctx->hy.p,
+                                     (float *)ctx->hrmse.p, nullptr))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(out_y, ctx->hy.p, yb, hipMemcpyDeviceToHost, nullptr));
+    if (normalize && out_mean_b0)
+        HIPCHK(ctx, hipMemcpyAsync(out_mean_b0, ctx->hrmse.p, (size_t)p->n_vox * sizeof(float), hipMemcpyDeviceToHost, nullptr));
+    HIPCHK(ctx, hipStreamSynchronize(nullptr));
+    return AMX_OK;
+}
+
+int amx_prep_mean_b0(amx_ctx *ctx, const amx_prep *p, const float *img, float *out_mean_b0_volume)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!p || p->ctx != ctx) return amx_bad(ctx, "amx_prep_mean_b0: not a plan of this ctx");
+    if (!img || !out_mean_b0_volume) return amx_bad(ctx, "amx_prep_mean_b0: null buffer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    const size_t ib = (size_t)p->extent * sizeof(float), ob = (size_t)p->n_total * sizeof(float);
+    if ((rc = amx_ensure(ctx, ctx->hextra, ib))) return rc;
+    if ((rc = amx_ensure(ctx, ctx->hrmse, ob))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->hextra.p, img, ib, hipMemcpyHostToDevice, nullptr));
+    if ((rc = amx_prep_mean_b0_device(ctx, p, (const float *)ctx->hextra.p, (float *)ctx->hrmse.p, nullptr))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(out_mean_b0_volume, ctx->hrmse.p, ob, hipMemcpyDeviceToHost, nullptr));
+    HIPCHK(ctx, hipStreamSynchronize(nullptr));
+    return AMX_OK;
+}
+
+int amx_prep_scatter(amx_ctx *ctx, const amx_prep *p, const double *values, int n_cols, float *out_volume)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!p || p->ctx != ctx) return amx_bad(ctx, "amx_prep_scatter: not a plan of this ctx");
+    if (n_cols < 1 || !out_volume || (p->n_vox > 0 && !values)) return amx_bad(ctx, "amx_prep_scatter: bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    const size_t vb = (size_t)p->n_vox * n_cols * sizeof(double), ob = (size_t)p->n_total * n_cols * sizeof(float);
+    if ((rc = amx_ensure(ctx, ctx->hy, vb))) return rc;
+    if ((rc = amx_ensure(ctx, ctx->hextra, ob))) return rc;
+    if (vb) HIPCHK(ctx, hipMemcpyAsync(ctx->hy.p, values, vb, hipMemcpyHostToDevice, nullptr));
+    if ((rc = amx_prep_scatter_device(ctx, p, (const double *)ctx->hy.p, n_cols, (float *)ctx->hextra.p, nullptr))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(out_volume, ctx->hextra.p, ob, hipMemcpyDeviceToHost, nullptr));
+    HIPCHK(ctx, hipStreamSynchronize(nullptr));
+    return AMX_OK;
+}
+
+}  // extern "C"

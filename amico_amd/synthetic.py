@@ -71,6 +71,26 @@ class SimpleScheme:
     def nS(self):
         return self.b0_count + self.dwi_count
 
+    @property
+    def shells(self):
+        """one dict per distinct acquisition row raw[:, 3:] above the b0 threshold, in order of first appearance,
+        with the indices of its volumes (scheme.py:88-120)"""
+        out, seen = [], []
+        tmp = self.raw[:, 3:]
+        for i in range(tmp.shape[0]):
+            if any(np.array_equal(tmp[i], k) for k in seen):
+                continue
+            seen.append(tmp[i].copy())
+            if self.b[i] <= self.b0_thr:
+                continue
+            sh = {'b': self.b[i], 'G': None, 'Delta': None, 'delta': None, 'TE': None}
+            if self.version == 1:
+                sh['G'], sh['Delta'], sh['delta'], sh['TE'] = (float(v) for v in tmp[i])
+            sh['idx'] = np.where((tmp == tmp[i]).all(axis=1))[0]
+            sh['grad'] = self.raw[sh['idx'], 0:3]
+            out.append(sh)
+        return out
+
 
 def make_scheme(n_b0=9, shells=((700.0, 30), (2000.0, 60)), seed=0):
     """Nx4 b-value scheme, b0 volumes first (the 99-volume 2-shell protocol by default)."""

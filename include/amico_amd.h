@@ -120,10 +120,51 @@ int amx_dti_directions(amx_ctx *ctx, const amx_dti *h, const double *y, int64_t 
 int amx_dti_directions_device(amx_ctx *ctx, const amx_dti *h, const double *d_y, int64_t n_vox,
                               double *d_dirs, void *hip_stream);
 
+/* (f2, f3) signal preparation and result scatter, fused around the masked voxel list:
+ *   core.py:209-223  mean_b0s = mean(img[..., b0_idx], axis=3); norm_factor = 1 / mean_b0s, 0 where
+ *                    mean_b0s <= b0_min_signal * mean(mean_b0s[mean_b0s > 0]);  img[..., i] *= norm_factor
+ *   core.py:225-227  doMergeB0: volumes -> [mean of the b0 volumes] + the DWI volumes
+ *   core.py:229-252  doDirectionalAverage: volumes -> [mean of the b0s] + the mean of every shell (sorted by b)
+ *   core.py:451-452  y = img[mask == 1, :].astype(double); y[y < 0] = 0
+ *   core.py:472-498  RESULTS[...] = zeros(float32 volume); RESULTS[...][mask == 1, :] = per-voxel values
+ * All arithmetic before the float64 cast is float32 in the reference's operation order (numpy reduces the
+ * fancy-indexed volumes sequentially in index order), so `y` is bit-identical to the reference's.
+ *
+ * A plan holds the geometry: dims = (X, Y, Z); strides = element strides of the float32 image along
+ * (x, y, z, volume) -- any layout: C order, or the Fortran order nibabel hands out; rank = int32[X][Y][Z]
+ * (host, C order): position of the voxel in the masked list (its row in `y`), -1 outside the mask -- i.e.
+ * cumsum(mask == 1) - 1 in C order, which is the order `img[mask == 1, :]` enumerates voxels in.
+ * Output volume j of `y` is the float32 mean of the input volumes group_idx[group_ptr[j] .. group_ptr[j+1])
+ * (a group of one = plain copy): identity groups, the b0-merge or the shell average.  b0_idx = scheme.b0_idx.
+ * overwrite_in_order != 0 reproduces core.py:231-245 literally: the shell averages are written into a VIEW of
+ * the first n_out volumes of the image while later groups still read from it, so output j replaces input
+ * volume j before group j+1 is averaged (harmless when the b0 volumes come first and the shells are stored in
+ * b-value order; otherwise the reference averages already-replaced volumes, and so does this).            */
+typedef struct amx_prep amx_prep;
+int  amx_prep_create(amx_ctx *ctx, const int64_t dims[3], const int64_t strides[4], int nS,
+                     const int32_t *rank, int64_t n_vox, const int32_t *group_ptr,
+                     const int32_t *group_idx, int n_out, const int32_t *b0_idx, int n_b0,
+                     int overwrite_in_order, amx_prep **out);
+void amx_prep_destroy(amx_prep *p);
+/* img -> y f64[n_vox][n_out] (+ mean_b0 f32[n_vox] of the masked voxels when normalize != 0 and the pointer is
+ * not NULL).  normalize = doNormalizeSignal; b0_threshold = the right-hand side of core.py:217 (0 by default).  */
+int amx_prep_gather(amx_ctx *ctx, const amx_prep *p, const float *img, int normalize, float b0_threshold,
+                    double *out_y, float *out_mean_b0);
+int amx_prep_gather_device(amx_ctx *ctx, const amx_prep *p, const float *d_img, int normalize,
+                           float b0_threshold, double *d_y, float *d_mean_b0, void *hip_stream);
+/* self.mean_b0s of EVERY voxel (core.py:213), float32 [X][Y][Z] in C order: input of the threshold above */
+int amx_prep_mean_b0(amx_ctx *ctx, const amx_prep *p, const float *img, float *out_mean_b0_volume);
+int amx_prep_mean_b0_device(amx_ctx *ctx, const amx_prep *p, const float *d_img, float *d_mean_b0_volume,
+                            void *hip_stream);
+/* values f64[n_vox][n_cols] -> float32 volume [X][Y][Z][n_cols] (C order), zero outside the mask */
+int amx_prep_scatter(amx_ctx *ctx, const amx_prep *p, const double *values, int n_cols, float *out_volume);
+int amx_prep_scatter_device(amx_ctx *ctx, const amx_prep *p, const double *d_values, int n_cols,
+                            float *d_volume, void *hip_stream);
+
 /* ---- measurement hooks (bench.py): HIP-event time of the solver kernels of the LAST
  * *_fit_device call on this ctx, measured on the stream they were launched on.
  * which: 0 = all kernels of the call, 1..3 = solver stage kernels (NODDI: NNLS-1, LASSO,
- * NNLS-3; FreeWater/SANDI: 1 = the single solver kernel), 4 = the last amx_dti_directions_device kernel.
+ * NNLS-3; FreeWater/SANDI: 1 = the single solver kernel), 4 = the last amx_dti_directions_device / amx_prep_gather_device kernel.
  * Requires amx_set_profiling(1). */
 int amx_set_profiling(amx_ctx *ctx, int enable);
 int amx_last_kernel_ms(amx_ctx *ctx, int which, float *out_ms);

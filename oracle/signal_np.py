@@ -62,3 +62,44 @@ def dti_directions(y, bvals, bvecs, min_signal=None, return_evals=False):
     if return_evals:
         return dirs, np.take_along_axis(evals, order, axis=1)
     return dirs
+
+
+# ----------------------------------------------------------------------------- signal preparation (numpy IS the
+# reference's arithmetic here: core.py:209-268 and 451-452 are numpy expressions on the float32 image)
+def prepare_signal(img, mask, b0_idx, dwi_idx, shells=None, do_normalize=True, do_merge_b0=False,
+                   do_directional_average=False, b0_min_signal=0):
+    """float32 image [X,Y,Z,nS] -> (y f64[n_vox, n_out], mean_b0s float32 volume or None), following load_data's
+    preprocessing (core.py:209-252) and fit's gather (core.py:451-452) statement by statement."""
+    img = np.array(img, dtype=np.float32, copy=True, order='K')
+    mean_b0s = None
+    if do_normalize:
+        if len(b0_idx) == 0:
+            raise RuntimeError('No b0 volume to normalize signal with')
+        mean_b0s = np.mean(img[:, :, :, b0_idx], axis=3)
+        norm_factor = mean_b0s.copy()
+        idx = norm_factor <= b0_min_signal * norm_factor[norm_factor > 0].mean()
+        norm_factor[idx] = 1
+        norm_factor = 1 / norm_factor
+        norm_factor[idx] = 0
+        for i in range(img.shape[3]):
+            img[:, :, :, i] *= norm_factor
+    if do_merge_b0:
+        mean = np.expand_dims(np.mean(img[:, :, :, b0_idx], axis=3), axis=3)
+        img = np.concatenate((mean, img[:, :, :, dwi_idx]), axis=3)
+    if do_directional_average:
+        n_sh = len(shells)
+        avg = img[:, :, :, :(n_sh + 1)]
+        avg[:, :, :, 0] = np.mean(img[:, :, :, b0_idx], axis=3)
+        for k, s in enumerate(np.argsort([sh['b'] for sh in shells])):
+            avg[:, :, :, k + 1] = np.mean(img[:, :, :, shells[s]['idx']], axis=3)
+        img = avg.astype(np.float32)
+    y = img[np.asarray(mask) == 1, :].astype(np.double)
+    y[y < 0] = 0
+    return y, mean_b0s
+
+
+def scatter_results(values, mask, dtype=np.float32):
+    values = np.asarray(values)
+    out = np.zeros(mask.shape + values.shape[1:], dtype=dtype)
+    out[np.asarray(mask) == 1] = values
+    return out

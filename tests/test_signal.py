@@ -115,3 +115,95 @@ def test_dti_other_schemes_and_merge_b0(htable500):
             y = np.hstack([y[:, sc.b0_idx].mean(1, keepdims=True), y[:, sc.dwi_idx]])
         d = dti.TensorDirections.from_scheme(sc, do_merge_b0=merge).fit(y)
         assert axis_error(d, q[:, 0][None, :].repeat(130, 0)).max() < 1e-10
+
+
+# ============================================================================= signal preparation / scatter
+def _volume(shape, scheme, order, seed=0, with_bad=True):
+    rng = np.random.default_rng(seed)
+    img = rng.uniform(0.0, 900.0, shape + (scheme.nS,)).astype(np.float32)
+    img[..., scheme.b0_idx] += 600.0
+    if with_bad:
+        img[0, 0, 0, :] = 0.0                      # b0 mean 0 -> norm factor 0
+        img[1, 2, 1, 3] = -7.5                     # negative sample -> clipped
+        img[2, 1, 0, scheme.b0_idx] = -1.0         # negative b0 mean -> norm factor 0 (mean <= 0)
+    mask = (rng.uniform(size=shape) < 0.6).astype(np.uint8)
+    mask[0, 0, 0] = mask[1, 2, 1] = mask[2, 1, 0] = 1
+    mask[3, 3, 2] = 2                              # only == 1 counts (core.py:451)
+    return np.asarray(img, order=order), mask
+
+
+def test_oracle_prepare_signal_hand_cases():
+    sc = S.make_scheme(n_b0=3, shells=((1000.0, 4),), seed=1)
+    img = np.ones((2, 2, 2, sc.nS), dtype=np.float32)
+    img[..., sc.b0_idx] = [2.0, 4.0, 6.0]          # mean b0 = 4
+    img[1, 1, 1] = 0.0
+    mask = np.ones((2, 2, 2), dtype=np.uint8)
+    mask[0, 0, 1] = 0
+    y, mb0 = signal_np.prepare_signal(img, mask, sc.b0_idx, sc.dwi_idx)
+    assert y.shape == (7, sc.nS) and mb0[0, 0, 0] == 4.0
+    assert np.array_equal(y[0, sc.b0_idx], [0.5, 1.0, 1.5]) and np.all(y[0, sc.dwi_idx] == 0.25)
+    assert np.all(y[-1] == 0.0)                                          # b0 = 0 voxel: factor 0
+    ym, _ = signal_np.prepare_signal(img, mask, sc.b0_idx, sc.dwi_idx, do_merge_b0=True)
+    assert ym.shape == (7, 5) and ym[0, 0] == 1.0 and np.all(ym[0, 1:] == 0.25)
+    vol = signal_np.scatter_results(np.arange(14.0).reshape(7, 2), mask)
+    assert vol.dtype == np.float32 and vol.shape == (2, 2, 2, 2) and np.all(vol[0, 0, 1] == 0) and vol[0, 1, 0, 1] == 3.0
+
+
+def test_volume_groups_follow_the_reference_rules():
+    from amico_amd import prep
+    sc = S.make_sandi_scheme(bvals=(4000.0, 1000.0, 2500.0), ndir_per_shell=5, n_b0=2)
+    g = prep.volume_groups(sc, do_directional_average=True)
+    assert g[0] == [0, 1] and g[1] == list(range(7, 12)) and g[2] == list(range(12, 17)) and g[3] == list(range(2, 7))
+    t = prep.directional_average_table(sc)
+    assert t.shape == (4, 7) and t[0].tolist() == [1, 0, 0, 0, 0, 0, 0] and np.all(np.diff(t[1:, 3]) > 0)
+    sc2 = S.make_scheme(n_b0=2, shells=((700.0, 3),), seed=0)
+    assert prep.volume_groups(sc2, do_merge_b0=True) == [[0, 1], [2], [3], [4]]
+    assert prep.volume_groups(sc2) == [[0], [1], [2], [3], [4]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('order', ['F', 'C'])
+@pytest.mark.parametrize('opts', [dict(), dict(do_normalize=False), dict(do_merge_b0=True), dict(b0_min_signal=0.9)])
+def test_prepare_signal_bit_exact(order, opts):
+    from amico_amd import prep
+    sc = S.make_scheme()
+    img, mask = _volume((70, 9, 5), sc, order, seed=3)
+    ref, mb0 = signal_np.prepare_signal(img, mask, sc.b0_idx, sc.dwi_idx, **opts)
+    sp = prep.SignalPreparation(sc, img, mask, **opts)
+    y, m = sp.gather(img)
+    assert y.shape == ref.shape and np.array_equal(y, ref)               # bit-exact, incl. -0.0 / clipping
+    if opts.get('do_normalize', True):
+        assert np.array_equal(m, mb0[mask == 1])
+        assert np.array_equal(sp._plan.mean_b0(img), mb0)
+    vals = np.random.default_rng(0).normal(size=(sp.n_vox, 3))
+    assert np.array_equal(sp.scatter(vals), signal_np.scatter_results(vals, mask))
+    assert np.array_equal(sp.scatter(vals[:, 0]), signal_np.scatter_results(vals[:, 0], mask))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('order', ['F', 'C'])
+def test_directional_average_bit_exact_including_the_view_aliasing(order):
+    from amico_amd import prep
+    for bvals in ((1000.0, 2500.0, 4000.0, 6000.0, 8000.0), (4000.0, 1000.0, 2500.0)):   # 2nd: shells not in b order
+        sc = S.make_sandi_scheme(bvals=bvals, ndir_per_shell=12 if len(bvals) == 3 else 60, n_b0=2 if len(bvals) == 3 else 6)
+        img, mask = _volume((33, 6, 4), sc, order, seed=5, with_bad=False)
+        ref, _ = signal_np.prepare_signal(img, mask, sc.b0_idx, sc.dwi_idx, shells=sc.shells, do_directional_average=True)
+        sp = prep.SignalPreparation(sc, img, mask, do_directional_average=True)
+        y, _ = sp.gather(img)
+        assert y.shape == (int((mask == 1).sum()), len(bvals) + 1) and np.array_equal(y, ref)
+
+
+@pytest.mark.gpu
+def test_prepare_signal_errors_and_edges():
+    from amico_amd import prep
+    sc = S.make_scheme(n_b0=0, shells=((1000.0, 8),), seed=1)
+    img = np.ones((4, 4, 4, 8), dtype=np.float32)
+    with pytest.raises(RuntimeError):
+        prep.SignalPreparation(sc, img, np.ones((4, 4, 4)))              # no b0 to normalise with
+    sp = prep.SignalPreparation(sc, img, np.zeros((4, 4, 4)), do_normalize=False)   # empty mask
+    y, _ = sp.gather(img)
+    assert y.shape == (0, 8) and not sp.scatter(np.zeros((0, 2))).any()
+    with pytest.raises(ValueError):
+        prep.SignalPreparation(sc, img[..., :5], np.ones((4, 4, 4)), do_normalize=False)
+    with pytest.raises(ValueError):
+        sp.gather(np.ones((4, 4, 5, 8), dtype=np.float32))
