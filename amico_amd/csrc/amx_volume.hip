@@ -17,7 +17,7 @@ struct PrepArgs {
     const float *img; const int *rank; double *y; float *mean_b0;
     long long d0, d1, d2, s0, s1, s2, sv;
     long long n_tiles, tiles_per_row;
-    int nS, n_out, n_b0, ldt, inplace, layout, normalize;
+    int nS, n_out, n_b0, n_gidx, ldt, inplace, layout, normalize;
     const int *gptr, *gidx, *b0idx;
     float thr;
 };
@@ -26,14 +26,25 @@ struct PrepArgs {
 //  (1) the tile's nS values per voxel go to LDS T[voxel][volume] (odd row stride) with coalesced loads in either
 //      memory layout: planar (x fastest, one 256-byte run per volume) or interleaved (volume fastest, one row per voxel);
 //  (2) lane = voxel: mean of the b0 volumes (float32, summed in index order like numpy reduces the fancy-indexed
-//      array of core.py:213), norm factor (core.py:216-220), row scaled in place (core.py:221-222), then every output
-//      volume = float32 mean of its group of input volumes in index order (core.py:225-227 / 236-252);
+//      array of core.py:213), norm factor (core.py:216-220); when volumes are grouped (IDENTITY = false) the row is
+//      scaled in place (core.py:221-222) and every output volume = float32 mean of its group in index order
+//      (core.py:225-227 / 236-252); with identity groups the single multiplication is applied on the way out;
 //  (3) rows are written to y[rank][:] as float64 with negative values clipped (core.py:451-452), coalesced per row.
+// The plan's index lists live in LDS (P): scalar loads from global memory would serialise phase 2.
+template <bool IDENTITY>
 __global__ __launch_bounds__(64 * kPrepWaves) void k_prep_gather(PrepArgs a)
 {
     extern __shared__ float smf[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int per_wave = 64 * a.ldt * (a.inplace ? 1 : 2);
+    int *P = reinterpret_cast<int *>(smf + (size_t)kPrepWaves * per_wave);
+    int *Pb0 = P, *Pgp = P + a.n_b0, *Pgi = Pgp + a.n_out + 1;
+    for (int i = threadIdx.x; i < a.n_b0; i += blockDim.x) Pb0[i] = a.b0idx[i];
+    if (!IDENTITY) {
+        for (int i = threadIdx.x; i <= a.n_out; i += blockDim.x) Pgp[i] = a.gptr[i];
+        for (int i = threadIdx.x; i < a.n_gidx; i += blockDim.x) Pgi[i] = a.gidx[i];
+    }
+    __syncthreads();
     float *T = smf + (size_t)wave * per_wave;
     float *O = a.inplace ? T : T + 64 * a.ldt;
     const long long wave_id = (long long)blockIdx.x * kPrepWaves + wave, n_waves = (long long)gridDim.x * kPrepWaves;
@@ -48,53 +59,72 @@ __global__ __launch_bounds__(64 * kPrepWaves) void k_prep_gather(PrepArgs a)
         const long long base = x0 * a.s0 + i1 * a.s1 + i2 * a.s2;
         float *row_l = T + lane * a.ldt;
         if (a.layout == 2) {
-            // interleaved: lanes run over the volumes of one voxel
-            for (int k = 0; k < 64; k++) {
-                if (!((live >> k) & 1ull)) continue;
-                const float *src = a.img + base + k * a.s0;
-                for (int v = lane; v < a.nS; v += 64) T[k * a.ldt + v] = src[v];
+            // interleaved: lanes run over the volumes of one voxel; sixteen rows in flight
+            for (int k = 0; k < 64; k += 16) {
+                if (!((live >> k) & 0xffffull)) continue;
+                for (int v = lane; v < a.nS; v += 64) {
+                    float tr[16];
+#pragma unroll
+                    for (int u = 0; u < 16; u++) tr[u] = ((live >> (k + u)) & 1ull) ? a.img[base + (k + u) * a.s0 + v] : 0.0f;
+#pragma unroll
+                    for (int u = 0; u < 16; u++) T[(k + u) * a.ldt + v] = tr[u];
+                }
             }
         } else if (r >= 0) {
-            // planar (or generic strides): lanes run over the voxels of one volume
+            // planar (or generic strides): lanes run over the voxels of one volume; 32 volumes in flight
             const float *src = a.img + base + lane * a.s0;
             int v = 0;
-            for (; v + 8 <= a.nS; v += 8) {
-                float t8[8];
+            for (; v + 32 <= a.nS; v += 32) {
+                float tv[32];
 #pragma unroll
-                for (int u = 0; u < 8; u++) t8[u] = src[(long long)(v + u) * a.sv];
+                for (int u = 0; u < 32; u++) tv[u] = src[(long long)(v + u) * a.sv];
 #pragma unroll
-                for (int u = 0; u < 8; u++) row_l[v + u] = t8[u];
+                for (int u = 0; u < 32; u++) row_l[v + u] = tv[u];
+            }
+            for (; v + 4 <= a.nS; v += 4) {
+                float tv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) tv[u] = src[(long long)(v + u) * a.sv];
+#pragma unroll
+                for (int u = 0; u < 4; u++) row_l[v + u] = tv[u];
             }
             for (; v < a.nS; v++) row_l[v] = src[(long long)v * a.sv];
         }
         WAVE_SYNC();
+        float f = 1.0f;
         if (r >= 0) {
             if (a.normalize) {
                 float m = 0.0f;
-                for (int i = 0; i < a.n_b0; i++) m = m + row_l[a.b0idx[i]];
+                for (int i = 0; i < a.n_b0; i++) m = m + row_l[Pb0[i]];
                 m = m / (float)a.n_b0;
                 if (a.mean_b0) a.mean_b0[r] = m;
-                const float f = (m <= a.thr) ? 0.0f : 1.0f / m;      // norm_factor[idx] = 0, else 1 / mean_b0
-                for (int v = 0; v < a.nS; v++) row_l[v] = row_l[v] * f;
+                f = (m <= a.thr) ? 0.0f : 1.0f / m;                  // norm_factor[idx] = 0, else 1 / mean_b0
             }
-            float *out_l = O + lane * a.ldt;
-            for (int j = 0; j < a.n_out; j++) {
-                const int g0 = a.gptr[j], g1 = a.gptr[j + 1];
-                float acc = row_l[a.gidx[g0]];
-                if (g1 - g0 > 1) {
-                    for (int g = g0 + 1; g < g1; g++) acc = acc + row_l[a.gidx[g]];
-                    acc = acc / (float)(g1 - g0);
+            if (!IDENTITY) {
+                if (a.normalize)
+                    for (int v = 0; v < a.nS; v++) row_l[v] = row_l[v] * f;
+                float *out_l = O + lane * a.ldt;
+                for (int j = 0; j < a.n_out; j++) {
+                    const int g0 = Pgp[j], g1 = Pgp[j + 1];
+                    float acc = row_l[Pgi[g0]];
+                    if (g1 - g0 > 1) {
+                        for (int g = g0 + 1; g < g1; g++) acc = acc + row_l[Pgi[g]];
+                        acc = acc / (float)(g1 - g0);
+                    }
+                    out_l[j] = acc;
                 }
-                out_l[j] = acc;
             }
         }
-        WAVE_SYNC();
+        if (!IDENTITY) WAVE_SYNC();
+        const bool scale = IDENTITY && a.normalize;
         for (int k = 0; k < 64; k++) {
             if (!((live >> k) & 1ull)) continue;
             const int rk = __builtin_amdgcn_readlane(r, k);
+            const float fk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, f), k));
             double *dst = a.y + (long long)rk * a.n_out;
             for (int j = lane; j < a.n_out; j += 64) {
-                const float val = O[k * a.ldt + j];
+                float val = O[k * a.ldt + j];
+                if (scale) val = val * fk;
                 dst[j] = (double)(val < 0.0f ? 0.0f : val);
             }
         }
@@ -183,6 +213,10 @@ int amx_prep_create(amx_ctx *ctx, const int64_t dims[3], const int64_t strides[4
     const long long cstride[3] = {(long long)dims[1] * dims[2], (long long)dims[2], 1};
     amx_prep *p = new amx_prep;
     p->ctx = ctx; p->nS = nS; p->n_out = n_out; p->n_b0 = n_b0; p->inplace = inplace;
+    p->n_gidx = group_ptr[n_out];
+    p->identity = n_out == nS;
+    for (int j = 0; j < n_out && p->identity; j++)
+        if (group_ptr[j + 1] != j + 1 || group_idx[j] != j) p->identity = 0;
     p->n_total = total; p->n_vox = n_vox; p->sv = strides[3];
     for (int k = 0; k < 3; k++) { p->d[k] = dims[ax[k]]; p->s[k] = strides[ax[k]]; p->c[k] = cstride[ax[k]]; }
     p->layout = p->s[0] == 1 ? 1 : (p->sv == 1 ? 2 : 0);
@@ -234,11 +268,14 @@ int amx_prep_gather_device(amx_ctx *ctx, const amx_prep *p, const float *d_img, 
     a.nS = p->nS; a.n_out = p->n_out; a.n_b0 = p->n_b0; a.ldt = p->nS | 1; a.inplace = p->inplace;
     a.layout = p->layout; a.normalize = normalize ? 1 : 0;
     a.gptr = p->gptr; a.gidx = p->gidx; a.b0idx = p->b0idx; a.thr = b0_threshold;
-    const size_t lds = (size_t)kPrepWaves * 64 * a.ldt * (a.inplace ? 1 : 2) * sizeof(float);
+    a.n_gidx = p->n_gidx;
+    const bool identity = p->identity != 0;
+    const size_t lds = ((size_t)kPrepWaves * 64 * a.ldt * (a.inplace ? 1 : 2) + (size_t)p->n_b0 + p->n_out + 1 + p->n_gidx) * sizeof(float);
     if (lds > 160 * 1024) return amx_bad(ctx, "amx_prep_gather: scheme too long for the LDS tile");
     static bool attr_set = false;
     if (!attr_set) {
-        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_prep_gather, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_prep_gather<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_prep_gather<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     const int per_cu = (int)((160 * 1024) / lds) > 8 ? 8 : (int)((160 * 1024) / lds);
@@ -246,7 +283,8 @@ int amx_prep_gather_device(amx_ctx *ctx, const amx_prep *p, const float *d_img, 
     const long long need = (a.n_tiles + kPrepWaves - 1) / kPrepWaves;
     if (grid > need) grid = need;
     rec(ctx, 8, s);
-    hipLaunchKernelGGL(k_prep_gather, dim3((unsigned)grid), dim3(64 * kPrepWaves), lds, s, a);
+    if (identity) hipLaunchKernelGGL(k_prep_gather<true>, dim3((unsigned)grid), dim3(64 * kPrepWaves), lds, s, a);
+    else hipLaunchKernelGGL(k_prep_gather<false>, dim3((unsigned)grid), dim3(64 * kPrepWaves), lds, s, a);
     HIPCHK(ctx, hipGetLastError());
     rec(ctx, 9, s);
     return AMX_OK;

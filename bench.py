@@ -140,6 +140,72 @@ def dti_directions(args):
                                        'sample': '%d voxels, numpy restatement of dipy OLS (pinv + log + batched eigh)' % m}}))
 
 
+def signal_preparation(args):
+    """Mask gather + b0 normalisation + clip + float64 (SURVEY section 8 f rows 2-3): image f32 -> y f64, HBM-bound."""
+    import torch
+    from amico_amd import prep, synthetic as S
+    from oracle import signal_np
+    dev = torch.device('cuda', 0)
+    scheme = S.make_scheme()
+    shape = (128, 128, 80)
+    rng = np.random.default_rng(1)
+    out = {}
+    for order in os.environ.get('PREP_ORDERS', 'F,C').split(','):
+        img = rng.uniform(0.0, 900.0, shape + (scheme.nS,)).astype(np.float32)
+        img[..., scheme.b0_idx] += 600.0
+        img = np.asarray(img, order=order)
+        xx, yy, zz = np.meshgrid(*[np.linspace(-1, 1, s) for s in shape], indexing='ij')
+        mask = ((xx * xx + yy * yy + zz * zz) < 0.92).astype(np.uint8)           # brain-sized blob: ~50 % of the box
+        sp = prep.SignalPreparation(scheme, img, mask)
+        ctx = sp.ctx
+        n = sp.n_vox
+        flat = np.lib.stride_tricks.as_strided(img, shape=(img.size,), strides=(4,))
+        d_img = torch.from_numpy(flat.copy()).to(dev)
+        d_y = torch.zeros((n, scheme.nS), dtype=torch.float64, device=dev)
+        d_m = torch.zeros(n, dtype=torch.float32, device=dev)
+        L = _capi_lib()
+        ctx.set_profiling(True)
+
+        def step():
+            ctx.check(L.amx_prep_gather_device(ctx._h, sp._plan._h, d_img.data_ptr(), 1, 0.0, d_y.data_ptr(),
+                                               d_m.data_ptr(), None))
+        for _ in range(args.warmup):
+            step(); ctx.sync()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        kms = 0.0
+        for _ in range(args.steps):
+            step(); ctx.sync()
+            kms += ctx.last_kernel_ms(4)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        kms /= args.steps
+        t1 = time.perf_counter()
+        ref, _ = signal_np.prepare_signal(img, mask, scheme.b0_idx, scheme.dwi_idx)
+        cpu = n / (time.perf_counter() - t1)
+        exact = bool(np.array_equal(d_y.cpu().numpy(), ref))
+        bpv = 4 * scheme.nS + 8 * scheme.nS + 4
+        out[order] = {'voxels': n, 'voxels_per_s': n * args.steps / el, 'kernel_ms': kms,
+                      'achieved_GBs': bpv * n / (kms * 1e-3) / 1e9, 'bit_exact_vs_numpy': exact, 'numpy_voxels_per_s': cpu}
+    best = out.get('F') or out['C']
+    print(json.dumps({'metric': 'voxels/sec, signal preparation (mask gather + b0 normalisation + clip)',
+                      'value': best['voxels_per_s'], 'unit': 'voxels/s', 'n_gpus': 1, 'steps': args.steps,
+                      'warmup': args.warmup, 'dtype': 'f32->f64', 'data': 'synthetic',
+                      'config': {'workload': '128x128x80x99 float32 image, %d masked voxels, Fortran order (nibabel) '
+                                             '[C order alongside]' % best['voxels']},
+                      'roofline': {'bound': 'hbm', 'achieved': best['achieved_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                   'frac': best['achieved_GBs'] / HBM_PEAK_GBS, 'traffic': None, 'kernel': 'k_prep_gather',
+                                   'kernel_ms': best['kernel_ms'], 'bytes_per_voxel': 12 * scheme.nS + 4},
+                      'layouts': out,
+                      'cpu_baseline': {'value': best['numpy_voxels_per_s'], 'unit': 'voxels/s', 'cores': 1,
+                                       'kind': 'reference', 'sample': 'the numpy statements of core.py:209-223, 451-452 on the same image'}}))
+
+
+def _capi_lib():
+    from amico_amd import _capi
+    return _capi.lib()
+
+
 def pmc_traffic(stage, n):
     """HBM bytes per launch of the stage kernel from the committed rocprofv3 PMC passes (profiles/), scaled to
     this run's voxels per launch; None when the profile summary is not there."""
@@ -160,11 +226,13 @@ def main():
     ap.add_argument('--voxels', type=int, default=1_000_000, help='voxels per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--host', action='store_true', help='also time the host-buffer entry point (PCIe inclusive)')
-    ap.add_argument('--model', default='noddi', choices=['noddi', 'freewater', 'sandi', 'dti'],
+    ap.add_argument('--model', default='noddi', choices=['noddi', 'freewater', 'sandi', 'dti', 'prep'],
                     help='noddi = the BASELINE.json headline; the others are extra measurements (configs 3, 4)')
     args = ap.parse_args()
     if args.model == 'dti':
         return dti_directions(args)
+    if args.model == 'prep':
+        return signal_preparation(args)
     if args.model != 'noddi':
         return other_models(args)
 
