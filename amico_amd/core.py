@@ -1,14 +1,23 @@
-"""A thin ``Evaluation`` holder with the fields ``model.fit(evaluation)`` reads
-(amico/core.py:42-104, 407-498): ``y``, ``DIRs``, ``htable``, ``KERNELS``, ``nthreads``,
-``get_config``.  It reproduces the caller contract around the hot path -- mask gather + clip
-(core.py:451-452) and the scatter of the results into float32 volumes (core.py:472-498) --
-for in-memory (synthetic) volumes; NIfTI I/O, DTI and LUT generation stay out of scope.
+"""``Evaluation`` with the fields ``model.fit(evaluation)`` reads (amico/core.py:42-104, 407-498): ``y``,
+``DIRs``, ``htable``, ``KERNELS``, ``nthreads``, ``get_config`` -- and the caller contract around the hot path for
+in-memory volumes, every per-voxel step on the GPU:
+
+  set_data   ~ load_data's preprocessing inputs (core.py:209-268): raw float32 image, scheme, mask
+  fit        b0 normalisation / b0 merge / shell average + mask gather + clip  -> ``y``      (amx_prep_gather)
+             principal directions from the log-linear tensor fit                -> ``DIRs``   (amx_dti_directions)
+             model.fit(self)                                                    -> maps       (amx_*_fit)
+             scatter into float32 volumes (core.py:472-498)                     -> ``RESULTS`` (amx_prep_scatter)
+
+NIfTI / scheme-file I/O, Rician debiasing and LUT generation stay out of scope.
 """
 import inspect
 import time
 from os import cpu_count
 import numpy as np
 from . import models as _models
+from . import prep as _prep
+from . import dti as _dti
+from .synthetic import SimpleScheme
 
 
 class Evaluation:
@@ -52,14 +61,35 @@ class Evaluation:
         return self.CONFIG.get(key)
 
     # ---- in-memory replacement of load_data (core.py:107-278): volumes are given directly
-    def set_data(self, dwi, scheme, mask=None, directions=None):
-        """dwi [X,Y,Z,nS] (already b0-normalised), mask [X,Y,Z], directions [X,Y,Z,3]"""
-        self.niiDWI_img = np.asarray(dwi, dtype=np.float32)          # core.py:136
-        self.scheme = scheme
+    def set_data(self, dwi, scheme, mask=None, directions=None, b0_min_signal=0):
+        """dwi [X,Y,Z,nS] raw signal (C or Fortran order), mask [X,Y,Z], directions [X,Y,Z,3] (optional peaks,
+        core.py:438-447: when absent they come from the tensor fit).  The options doNormalizeSignal / doMergeB0 /
+        doDirectionalAverage are read here, like load_data reads them."""
+        img = np.asarray(dwi)
+        if img.ndim != 4:
+            raise ValueError('DWI file is not a 4D image')                       # core.py:138-139
+        self.niiDWI_img = img.astype(np.float32, copy=False)                     # core.py:136
+        if any(st % 4 or st <= 0 for st in self.niiDWI_img.strides):
+            self.niiDWI_img = np.ascontiguousarray(self.niiDWI_img)
         self.set_config('dim', self.niiDWI_img.shape[:3])
+        self.set_config('b0_min_signal', b0_min_signal)
+        if scheme.nS != self.niiDWI_img.shape[3]:
+            raise ValueError('Scheme does not match with DWI data')
         self.niiMASK_img = np.ones(self.niiDWI_img.shape[:3], dtype=np.uint8) if mask is None \
             else np.asarray(mask, dtype=np.uint8)
-        self._dirs_img = None if directions is None else np.asarray(directions, dtype=np.float64)
+        if self.niiMASK_img.shape != self.niiDWI_img.shape[:3]:
+            raise ValueError('MASK geometry does not match with DWI data')
+        if directions is not None and np.shape(directions)[:3] != self.niiMASK_img.shape:
+            raise ValueError('PEAKS geometry does not match with DWI data')      # core.py:444-445
+        self._dirs_img = None if directions is None else np.asarray(directions, dtype=np.float32)   # core.py:442
+        self._raw_scheme = scheme
+        self._prep = _prep.SignalPreparation(
+            scheme, self.niiDWI_img, self.niiMASK_img, do_normalize=self.get_config('doNormalizeSignal'),
+            do_merge_b0=self.get_config('doMergeB0'), do_directional_average=self.get_config('doDirectionalAverage'),
+            b0_min_signal=b0_min_signal)
+        # the scheme the model sees: one row per shell after the directional average (core.py:254-255)
+        self.scheme = SimpleScheme(_prep.directional_average_table(scheme), scheme.b0_thr) \
+            if self.get_config('doDirectionalAverage') else scheme
 
     def set_model(self, model_name):
         if not hasattr(_models, model_name):
@@ -95,32 +125,39 @@ class Evaluation:
         self.nthreads = nt if nt > 0 else cpu_count()
         self.model.scheme = self.scheme
         sel = self.niiMASK_img == 1                                   # core.py:451 (== 1, not nonzero)
-        self.y = self.niiDWI_img[sel, :].astype(np.double)
-        self.y[self.y < 0] = 0
-        if self.model.id != 'SANDI':
-            if self._dirs_img is None:
-                raise RuntimeError('principal directions not set (DTI estimation is outside this path)')
+        t = time.time()
+        self.y, self.mean_b0s = self._prep.gather(self.niiDWI_img)    # core.py:209-268 + 451-452
+        # precompute directions (core.py:428-458)
+        if self.get_config('doDirectionalAverage'):
+            self.DIRs = None
+        elif self._dirs_img is not None:
             self.DIRs = np.ascontiguousarray(self._dirs_img[sel, :], dtype=np.float64)
+        else:
+            if self.get_config('DTI_fit_method') not in ('OLS', 'LS'):
+                raise NotImplementedError('only the default DTI_fit_method (OLS) runs on the GPU')
+            est = _dti.TensorDirections.from_scheme(self._raw_scheme, do_merge_b0=self.get_config('doMergeB0'))
+            self.DIRs = est.fit(self.y)
+        self.set_config('dirs_precomputing_time', time.time() - t)
         t = time.time()
         results = self.model.fit(self)
         self.set_config('fit_time', time.time() - t)
-        dim = self.get_config('dim')
+        sc = self._prep.scatter
         self.RESULTS = {}
-        self.RESULTS['MAPs'] = np.zeros([dim[0], dim[1], dim[2], len(self.model.maps_name)], dtype=np.float32)
-        self.RESULTS['MAPs'][sel, :] = results['estimates']
+        self.RESULTS['MAPs'] = sc(results['estimates'])
         if self.DIRs is not None:
-            self.RESULTS['DIRs'] = np.zeros([dim[0], dim[1], dim[2], 3], dtype=np.float32)
-            self.RESULTS['DIRs'][sel, :] = self.DIRs
+            self.RESULTS['DIRs'] = sc(self.DIRs)
         if self.get_config('doComputeRMSE'):
-            self.RESULTS['RMSE'] = np.zeros(dim, dtype=np.float32)
-            self.RESULTS['RMSE'][sel] = results['rmse']
+            self.RESULTS['RMSE'] = sc(results['rmse'])
         if self.get_config('doComputeNRMSE'):
-            self.RESULTS['NRMSE'] = np.zeros(dim, dtype=np.float32)
-            self.RESULTS['NRMSE'][sel] = results['nrmse']
+            self.RESULTS['NRMSE'] = sc(results['nrmse'])
         if self.model.name == 'NODDI' and self.get_config('doSaveModulatedMaps'):
-            self.RESULTS['MAPs_mod'] = np.zeros([dim[0], dim[1], dim[2], 2], dtype=np.float32)
-            self.RESULTS['MAPs_mod'][sel, :] = results['estimates_mod']
+            self.RESULTS['MAPs_mod'] = sc(results['estimates_mod'])
         if self.model.name == 'Free-Water' and self.get_config('doSaveCorrectedDWI'):
-            self.RESULTS['DWI_corrected'] = np.zeros(self.niiDWI_img.shape, dtype=np.float32)
-            self.RESULTS['DWI_corrected'][sel, :] = results['y_corrected']
+            y_corrected = results['y_corrected']                      # core.py:488-498
+            b0_idx = self.scheme.b0_idx
+            if self.get_config('doNormalizeSignal') and self.scheme.b0_count > 0:
+                y_corrected = y_corrected * np.reshape(self.mean_b0s, (-1, 1))
+            if self.get_config('doKeepb0Intact') and self.scheme.b0_count > 0:
+                y_corrected[:, b0_idx] = self.y[:, b0_idx] * np.reshape(self.mean_b0s, (-1, 1))
+            self.RESULTS['DWI_corrected'] = sc(y_corrected)
         return results

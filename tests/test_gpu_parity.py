@@ -166,30 +166,67 @@ def test_errors_and_edge_cases(noddi_fix, htable500):
 
 
 def test_evaluation_harness_plumbing(htable500):
-    """config 1 of BASELINE.json: 32x32x8 volume end-to-end through the Evaluation surface"""
+    """config 1 of BASELINE.json: 32x32x8 volume end-to-end through the Evaluation surface (peaks given)"""
     import amico_amd
     from amico_amd import synthetic as S
-    from oracle import oracle
+    from oracle import oracle, signal_np
     ht = htable500['htable']
     sch = S.make_scheme(seed=0)
     K = S.noddi_kernels(sch, htable500['dirs'])
     n = 32 * 32 * 8
     y, d = S.noddi_signals(n, K, ht, sch, seed=0)
+    img = (y.reshape(32, 32, 8, -1) * 850.0).astype(np.float32)          # raw scanner units: b0 ~ 850
     ae = amico_amd.Evaluation()
     mask = np.ones((32, 32, 8), dtype=np.uint8)
     mask[0, 0, :] = 0
-    ae.set_data(y.reshape(32, 32, 8, -1), sch, mask, d.reshape(32, 32, 8, 3))
+    ae.set_data(img, sch, mask, d.reshape(32, 32, 8, 3))
     ae.set_model('NODDI')
     ae.set_kernels(K, ht)
     ae.set_config('doComputeRMSE', True)
     ae.fit()
     assert ae.RESULTS['MAPs'].shape == (32, 32, 8, 3) and ae.RESULTS['MAPs'].dtype == np.float32
     sel = mask == 1
-    ref = oracle.noddi_fit(y.reshape(32, 32, 8, -1)[sel], d.reshape(32, 32, 8, 3)[sel], K, ht, sch.dwi_idx,
-                           nthreads=8)
+    y_ref, _ = signal_np.prepare_signal(img, mask, sch.b0_idx, sch.dwi_idx)
+    assert np.array_equal(ae.y, y_ref)
+    d_ref = d.reshape(32, 32, 8, 3).astype(np.float32)[sel].astype(np.float64)       # peaks are float32 (core.py:442)
+    ref = oracle.noddi_fit(y_ref, d_ref, K, ht, sch.dwi_idx, nthreads=8, rmse=True)
     diff = np.abs(ae.RESULTS['MAPs'][sel] - ref['estimates'].astype(np.float32)).max(axis=1)
     assert (diff < 1e-5).mean() > 0.999
     assert not ae.RESULTS['MAPs'][0, 0].any()
+    assert ae.RESULTS['RMSE'].shape == (32, 32, 8) and np.allclose(ae.RESULTS['RMSE'][sel], ref['rmse'], atol=1e-6)
+
+
+def test_evaluation_end_to_end_from_raw_volume(htable500):
+    """Fortran-ordered raw image, no peaks: normalisation + gather, tensor directions, fit and scatter all on the GPU;
+    compared with the oracle chain (numpy preprocessing -> numpy/LAPACK tensor fit -> C oracle fit)"""
+    import amico_amd
+    from amico_amd import synthetic as S
+    from oracle import oracle, signal_np
+    ht = htable500['htable']
+    sch = S.make_scheme(seed=0)
+    K = S.noddi_kernels(sch, htable500['dirs'])
+    shape = (24, 20, 10)
+    n = int(np.prod(shape))
+    y, _ = S.noddi_signals(n, K, ht, sch, seed=4)
+    img = np.asfortranarray((y.reshape(shape + (-1,)) * 1000.0).astype(np.float32))
+    mask = (np.random.default_rng(2).uniform(size=shape) < 0.7).astype(np.uint8)
+    ae = amico_amd.Evaluation()
+    ae.set_config('doSaveModulatedMaps', True)
+    ae.set_data(img, sch, mask)
+    ae.set_model('NODDI')
+    ae.set_kernels(K, ht)
+    ae.fit()
+    sel = mask == 1
+    y_ref, _ = signal_np.prepare_signal(img, mask, sch.b0_idx, sch.dwi_idx)
+    assert np.array_equal(ae.y, y_ref)
+    d_ref, ev = signal_np.dti_directions(y_ref, sch.b, sch.raw[:, :3], return_evals=True)
+    ok = (ev[:, 0] - ev[:, 1]) > 1e-6 * np.abs(ev[:, 0])
+    assert np.abs(np.abs((ae.DIRs[ok] * d_ref[ok]).sum(1)) - 1.0).max() < 1e-12
+    ref = oracle.noddi_fit(y_ref, d_ref, K, ht, sch.dwi_idx, nthreads=8)
+    diff = np.abs(ae.RESULTS['MAPs'][sel] - ref['estimates'].astype(np.float32)).max(axis=1)
+    assert (diff < 1e-5).mean() > 0.999
+    assert ae.RESULTS['DIRs'].shape == shape + (3,) and ae.RESULTS['MAPs_mod'].shape == shape + (2,)
+    assert not ae.RESULTS['MAPs'][~sel].any()
 
 
 def test_wave_primitives():
