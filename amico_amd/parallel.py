@@ -42,9 +42,11 @@ def gather_maps(local, n_total, group=None):
     return torch.cat(parts, dim=0)
 
 
-def fit_sharded(model, evaluation, group=None):
+def fit_sharded(model, evaluation, group=None, directions=None):
     """`model.fit(evaluation)` with the voxels of `evaluation` split over the ranks of `group`;
-    returns the same dict as the single-GPU call on every rank."""
+    returns the same dict as the single-GPU call on every rank.  `directions` (optional): an estimator with
+    `.fit(y) -> dirs` (amico_amd.dti.TensorDirections) run on each rank's shard when `evaluation.DIRs` is
+    None -- the step before the fit shards the same way; the gathered result then carries 'DIRs' too."""
     import copy
     import torch
     import torch.distributed as dist
@@ -55,7 +57,12 @@ def fit_sharded(model, evaluation, group=None):
     ev = copy.copy(evaluation)
     ev.y = evaluation.y[i:j]
     ev.DIRs = None if evaluation.DIRs is None else evaluation.DIRs[i:j]
-    res = model.fit(ev)
+    estimated = ev.DIRs is None and directions is not None
+    if estimated:
+        ev.DIRs = directions.fit(ev.y)
+    res = dict(model.fit(ev))
+    if estimated:
+        res['DIRs'] = ev.DIRs
     dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' else torch.device('cpu')
     out = {}
     for key, val in res.items():
