@@ -193,7 +193,10 @@ struct GramSolver {
                     if (cand && w[q] > best) { best = w[q]; bj = lane + kWave * q; }
                 }
                 const double wmax = wave_max(best);
-                if (!exact && uni(!(wmax > kExactBelow))) { force_exact = true; redo = true; break; }
+                if (!exact) {
+                    if (uni(wmax < -kExactBelow)) break;           // clearly a KKT point: no exact confirmation needed
+                    if (uni(!(wmax > kExactBelow))) { force_exact = true; redo = true; break; }
+                }
                 if (!uni(wmax > tol)) break;
                 const unsigned long long who = ballot64(best == wmax);
                 if (uni(who == 0ull)) { status = kGuardSelect; break; }

@@ -163,11 +163,11 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const float *As,
 #endif
     const bool act = lane < S.np;
 
-    if (STAGE == 1) {
+    if constexpr (STAGE == 1) {
         const double xi = wave_sum((act && S.idx == iso_atom) ? S.x : 0.0);
         const double xd = wave_sum((act && S.idx == dot_atom) ? S.x : 0.0);
         if (lane == 0) { a.xiso[(size_t)vox * 2] = xi; a.xiso[(size_t)vox * 2 + 1] = xd; }
-    } else if (kLasso) {
+    } else if constexpr (kLasso) {
         if (lane < 4) wmask[lane] = 0ull;
         if (act && S.x > 0.0) atomicOr(&wmask[S.idx >> 6], 1ull << (S.idx & 63));
         if (lane < 4) a.supp[(size_t)vox * 4 + lane] = wmask[lane];
@@ -191,9 +191,12 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const float *As,
         const double fwf = wave_sum((act && S.idx == iso_atom) ? xs : 0.0) / sum_atoms;
         const double dot = wave_sum((act && S.idx == dot_atom) ? xs : 0.0) / sum_atoms;
         double rsq = 0.0, ysq = 0.0;
+        if (a.c.flags & 3u) {
+            S.residual(yr, 0.0);
 #pragma unroll
-        for (int rr = 0; rr < NR; rr++) { rsq += S.r[rr] * S.r[rr]; ysq += yr[rr] * yr[rr]; }
-        if (a.c.flags & 3u) { rsq = wave_sum(rsq); ysq = wave_sum(ysq); }
+            for (int rr = 0; rr < NR; rr++) { rsq += S.r[rr] * S.r[rr]; ysq += yr[rr] * yr[rr]; }
+            rsq = wave_sum(rsq); ysq = wave_sum(ysq);
+        }
         if (lane == 0) {
             double *e = a.est + (size_t)vox * a.n_maps;
             e[0] = ndi; e[1] = odi; e[2] = fwf;

@@ -222,6 +222,23 @@ struct NNSolver {
     // Control flow is wave-uniform by construction; every branch condition goes through uni()
     // (v_readfirstlane) so that the compiler emits scalar branches and never masks EXEC around
     // the cross-lane operations.
+    // r = y - Q (d - l1 e): residual of the current passive solution (the member `r` is only refreshed by the exact
+    // sweeps of solve(); callers that need it afterwards -- the error maps -- recompute it here)
+    __device__ __forceinline__ void residual(const double (&yr)[NR], double lam1)
+    {
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) r[rr] = yr[rr];
+        const double coef = d - lam1 * e;
+#pragma unroll
+        for (int k = 0; k < MAXP; k++) {
+            if (k < np) {
+                const double ck = bcast(coef, k);
+#pragma unroll
+                for (int rr = 0; rr < NR; rr++) r[rr] -= Q[k][rr] * ck;
+            }
+        }
+    }
+
     __device__ __forceinline__ int solve(const AT *As, int ldA, int nS, int n_atoms,
                                          const double (&yr)[NR], const bool (&rowok)[NR],
                                          const double (&scl)[NQ],
@@ -247,7 +264,7 @@ struct NNSolver {
         int status = kSolved;
         int last_added = -1;
         n_exact = 0; n_gram = 0;
-        constexpr int kMaxGramSteps = 12;    // bound the drift of the Gram-updated dual vector
+        constexpr int kMaxGramSteps = 48;    // bound the drift of the Gram-updated dual vector
         const double kExactBelow = 1e-7;     // decisions on smaller dual values use the exact sweep
         double u[NQ];                        // atom space: A' r (unscaled, without the l1 shift)
         bool have_u = false, force_exact = false;
@@ -341,7 +358,12 @@ struct NNSolver {
                     if (cand && w[q] > best) { best = w[q]; bj = lane + kWave * q; }
                 }
                 const double wmax = wave_max(best);
-                if (!exact && uni(!(wmax > kExactBelow))) { force_exact = true; redo = true; break; }
+                if (!exact) {
+                    // every admissible dual value is negative by far more than the Gram updates can have drifted:
+                    // the exact sweep would confirm the KKT point and change nothing
+                    if (uni(wmax < -kExactBelow)) break;
+                    if (uni(!(wmax > kExactBelow))) { force_exact = true; redo = true; break; }
+                }
                 if (!uni(wmax > tol)) break;                      // KKT point reached
                 const unsigned long long who = ballot64(best == wmax);
                 if (uni(who == 0ull)) { status = kGuardSelect; break; }
