@@ -9,7 +9,10 @@
 #include <string>
 #include <vector>
 
-constexpr int kChunk = 512;        // voxels of one orientation per workgroup
+#ifndef AMX_CHUNK
+#define AMX_CHUNK 256
+#endif
+constexpr int kChunk = AMX_CHUNK;        // voxels of one orientation per workgroup
 constexpr int kListGrid = 512;     // workgroups of the large-MAXP re-run pass
 constexpr int kEv = 10;
 

@@ -172,6 +172,14 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const float *As,
         if (act && S.x > 0.0) atomicOr(&wmask[S.idx >> 6], 1ull << (S.idx & 63));
         if (lane < 4) a.supp[(size_t)vox * 4 + lane] = wmask[lane];
     } else {
+        // error maps first: the factor Q is dead afterwards (keeps it out of the registers of the map arithmetic)
+        double rsq = 0.0, ysq = 0.0;
+        if (a.c.flags & 3u) {
+            S.residual(yr, 0.0);
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++) { rsq += S.r[rr] * S.r[rr]; ysq += yr[rr] * yr[rr]; }
+            rsq = wave_sum(rsq); ysq = wave_sum(ysq);
+        }
         // models.pyx:945-967
         const double xs = act ? S.x : 0.0;
         const bool iswm = act && S.idx < n_wm;
@@ -190,13 +198,6 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const float *As,
         const double odi = 2.0 / 3.14159265358979323846 * atan2(1.0, k1);
         const double fwf = wave_sum((act && S.idx == iso_atom) ? xs : 0.0) / sum_atoms;
         const double dot = wave_sum((act && S.idx == dot_atom) ? xs : 0.0) / sum_atoms;
-        double rsq = 0.0, ysq = 0.0;
-        if (a.c.flags & 3u) {
-            S.residual(yr, 0.0);
-#pragma unroll
-            for (int rr = 0; rr < NR; rr++) { rsq += S.r[rr] * S.r[rr]; ysq += yr[rr] * yr[rr]; }
-            rsq = wave_sum(rsq); ysq = wave_sum(ysq);
-        }
         if (lane == 0) {
             double *e = a.est + (size_t)vox * a.n_maps;
             e[0] = ndi; e[1] = odi; e[2] = fwf;
@@ -398,6 +399,17 @@ __device__ __forceinline__ int xcd_chunk(int b, int n_chunks)
 // voxels w, w+nw, ... of its chunk.  LIST mode re-runs single voxels (large-MAXP variant): tile
 // staged per voxel.
 
+// Next voxel ticket of the workgroup.  All 64 lanes execute the LDS atomic (lane 0 adds 1, the others 0): no divergent
+// branch around it -- a lane-0-only atomic in this loop made ROCm 7.2's structuriser emit a loop that never exits.
+__device__ __forceinline__ int next_ticket(unsigned *ticket, int lane)
+{
+    const unsigned off = (unsigned)(uintptr_t)ticket;      // LDS offset = low 32 bits of the flat shared address
+    const unsigned inc = lane == 0 ? 1u : 0u;
+    unsigned old;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(off), "v"(inc) : "memory");
+    return __builtin_amdgcn_readfirstlane((int)old);
+}
+
 #define AMX_KERNEL_PROLOGUE(AT, NRv, NQv, NWv, RLWv)                                                        \
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                              \
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;                                       \
@@ -423,13 +435,21 @@ __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
         const int cid = xcd_chunk((int)blockIdx.x, *a.c.n_chunks);
         if (cid < 0) return;
         const Chunk ck = a.c.chunks[cid];
+        unsigned *ticket = reinterpret_cast<unsigned *>(wm_all + nw_ * 4);     // the 16 spare bytes of fit_lds_bytes
+        if (threadIdx.x == 0) *ticket = (unsigned)nw_;
         stage_tile<float>(As, tiles + (size_t)ck.dir * a.c.tile_stride, words, words_pad - words);
         __syncthreads();
-        // static round-robin over the chunk: wave w takes voxels w, w+NW, ... (purely scalar loop
-        // control; no LDS ticket, no lane-0 atomics in the hot loop)
+#ifdef AMX_STATIC_VOXELS
         for (int k = wave; k < ck.count; k += nw_) {
             noddi_voxel<STAGE, NR, NQ, MAXP>(a, As, rs, rl, wmask, a.c.perm[ck.start + k], ck.dir, lane);
         }
+#else
+        // voxels differ 2-3x in solver iterations: the wavefronts draw the next voxel of the chunk from an LDS ticket
+        // (next_ticket keeps the control flow wave-uniform: every lane takes part in the atomic)
+        for (int k = wave; k < ck.count; k = next_ticket(ticket, lane)) {
+            noddi_voxel<STAGE, NR, NQ, MAXP>(a, As, rs, rl, wmask, a.c.perm[ck.start + k], ck.dir, lane);
+        }
+#endif
     } else {
         const int cnt = *a.c.list_count;
         for (int it = blockIdx.x; it < cnt; it += gridDim.x) {

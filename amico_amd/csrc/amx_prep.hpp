@@ -44,7 +44,7 @@ __global__ void k_dir_to_lut(const double *__restrict__ dirs, int n, const short
     lutidx[v] = idx;
 }
 
-// single block: dir_start = exclusive scan(counts); chunks of <= ch voxels per orientation
+// single block: dir_start = exclusive scan(counts); ceil(count / ch) equal chunks of <= ch voxels per orientation
 __global__ void k_plan(const int *__restrict__ counts, int ndirs, int ch, int *__restrict__ dir_start,
                        int *__restrict__ cursor, Chunk *__restrict__ chunks, int *__restrict__ n_chunks)
 {
@@ -72,10 +72,13 @@ __global__ void k_plan(const int *__restrict__ counts, int ndirs, int ch, int *_
         if (dsel < ndirs) {
             dir_start[dsel] = start;
             cursor[dsel] = 0;
+            // nc chunks of equal size (+-1) instead of full chunks plus a short remainder: no workgroup stages a
+            // tile for a handful of voxels
+            const int base = nc ? c / nc : 0, rem = nc ? c - base * nc : 0;
             for (int k = 0; k < nc; k++) {
                 Chunk ck;
-                ck.dir = dsel; ck.start = start + k * ch;
-                ck.count = (k == nc - 1) ? (c - k * ch) : ch; ck.pad = 0;
+                ck.dir = dsel; ck.start = start + k * base + (k < rem ? k : rem);
+                ck.count = base + (k < rem ? 1 : 0); ck.pad = 0;
                 chunks[cstart + k] = ck;
             }
         }

@@ -264,6 +264,10 @@ struct NNSolver {
         int status = kSolved;
         int last_added = -1;
         n_exact = 0; n_gram = 0;
+#ifndef AMX_GRAM_COLS
+#define AMX_GRAM_COLS 4
+#endif
+        constexpr int kGramCols = AMX_GRAM_COLS;   // Gram columns in flight per trip of the dual-vector update
         constexpr int kMaxGramSteps = 48;    // bound the drift of the Gram-updated dual vector
         const double kExactBelow = 1e-7;     // decisions on smaller dual values use the exact sweep
         double u[NQ];                        // atom space: A' r (unscaled, without the l1 shift)
@@ -322,10 +326,10 @@ struct NNSolver {
                 // (4 columns = 4*NQ loads in flight per trip: the loop is bound by L2/MALL latency)
                 {
                     const double delta = sc * (x - xprev);
-                    for (int s0 = 0; s0 < np; s0 += 4) {
-                        double gv[4][NQ], dls[4];
+                    for (int s0 = 0; s0 < np; s0 += kGramCols) {
+                        double gv[kGramCols][NQ], dls[kGramCols];
 #pragma unroll
-                        for (int t4 = 0; t4 < 4; t4++) {
+                        for (int t4 = 0; t4 < kGramCols; t4++) {
                             const int sl = (s0 + t4 < np) ? s0 + t4 : np - 1;
                             const double dv = bcast(delta, sl);
                             dls[t4] = (s0 + t4 < np) ? dv : 0.0;
@@ -334,7 +338,7 @@ struct NNSolver {
                             for (int q = 0; q < NQ; q++) gv[t4][q] = gc[kWave * q];
                         }
 #pragma unroll
-                        for (int t4 = 0; t4 < 4; t4++) {
+                        for (int t4 = 0; t4 < kGramCols; t4++) {
 #pragma unroll
                             for (int q = 0; q < NQ; q++) u[q] -= gv[t4][q] * dls[t4];
                         }

@@ -149,6 +149,42 @@ def test_oracle_prepare_signal_hand_cases():
     assert vol.dtype == np.float32 and vol.shape == (2, 2, 2, 2) and np.all(vol[0, 0, 1] == 0) and vol[0, 1, 0, 1] == 3.0
 
 
+def _prep_scheme(b):
+    g = np.zeros((len(b), 3))
+    g[b > 0, 0] = 1.0
+    return S.SimpleScheme(np.hstack([g, b[:, None]]))
+
+
+def test_oracle_prepare_signal_vs_golden():
+    f = load_npz('prep_fixture.npz')
+    sc = _prep_scheme(f['b'])
+    img, mask = f['img'], f['mask']
+    y, mb0 = signal_np.prepare_signal(img, mask, sc.b0_idx, sc.dwi_idx)
+    assert np.array_equal(y, f['y_plain']) and np.array_equal(mb0, f['mean_b0s'])
+    assert np.array_equal(signal_np.prepare_signal(img, mask, sc.b0_idx, sc.dwi_idx, do_normalize=False)[0], f['y_raw'])
+    assert np.array_equal(signal_np.prepare_signal(img, mask, sc.b0_idx, sc.dwi_idx, b0_min_signal=0.9)[0], f['y_b0min'])
+    assert np.array_equal(signal_np.prepare_signal(img, mask, sc.b0_idx, sc.dwi_idx, do_merge_b0=True)[0], f['y_merge'])
+    assert np.array_equal(signal_np.prepare_signal(np.asfortranarray(img), mask, sc.b0_idx, sc.dwi_idx, shells=sc.shells,
+                                                   do_directional_average=True)[0], f['y_diravg'])
+    assert np.array_equal(signal_np.scatter_results(f['values'], mask), f['volume'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('order', ['F', 'C'])
+def test_prepare_signal_golden(order):
+    from amico_amd import prep
+    f = load_npz('prep_fixture.npz')
+    sc = _prep_scheme(f['b'])
+    img, mask = np.asarray(f['img'], order=order), f['mask']
+    for key, opts in (('y_plain', {}), ('y_raw', dict(do_normalize=False)), ('y_b0min', dict(b0_min_signal=0.9)),
+                      ('y_merge', dict(do_merge_b0=True)), ('y_diravg', dict(do_directional_average=True))):
+        sp = prep.SignalPreparation(sc, img, mask, **opts)
+        y, _ = sp.gather(img)
+        assert np.array_equal(y, f[key]), key
+    assert np.array_equal(sp.scatter(f['values']), f['volume'])
+    assert np.array_equal(prep.SignalPreparation(sc, img, mask)._plan.mean_b0(img), f['mean_b0s'])
+
+
 def test_volume_groups_follow_the_reference_rules():
     from amico_amd import prep
     sc = S.make_sandi_scheme(bvals=(4000.0, 1000.0, 2500.0), ndir_per_shell=5, n_b0=2)
