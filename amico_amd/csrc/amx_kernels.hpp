@@ -472,11 +472,11 @@ __global__ void __launch_bounds__(NW * 64) k_freewater(const FwArgs a)
         const int cid = xcd_chunk((int)blockIdx.x, *a.c.n_chunks);
         if (cid < 0) return;
         const Chunk ck = a.c.chunks[cid];
+        unsigned *ticket = reinterpret_cast<unsigned *>(wm_all + nw_ * 4);
+        if (threadIdx.x == 0) *ticket = (unsigned)nw_;
         stage_tile<float>(As, tiles + (size_t)ck.dir * a.c.tile_stride, words, words_pad - words);
         __syncthreads();
-        // static round-robin over the chunk: wave w takes voxels w, w+NW, ... (purely scalar loop
-        // control; no LDS ticket, no lane-0 atomics in the hot loop)
-        for (int k = wave; k < ck.count; k += nw_) {
+        for (int k = wave; k < ck.count; k = next_ticket(ticket, lane)) {   // LDS voxel ticket, see k_noddi
             fw_voxel<NR, NQ, MAXP>(a, As, rs, rl, a.c.perm[ck.start + k], lane);
         }
     } else {
@@ -501,11 +501,11 @@ __global__ void __launch_bounds__(NW * 64) k_sandi(const SandiArgs a)
         const int cid = xcd_chunk((int)blockIdx.x, *a.c.n_chunks);
         if (cid < 0) return;
         const Chunk ck = a.c.chunks[cid];
+        unsigned *ticket = reinterpret_cast<unsigned *>(wm_all + nw_ * 4);
+        if (threadIdx.x == 0) *ticket = (unsigned)nw_;
         stage_tile<double>(As, tiles, words, words_pad - words);
         __syncthreads();
-        // static round-robin over the chunk: wave w takes voxels w, w+NW, ... (purely scalar loop
-        // control; no LDS ticket, no lane-0 atomics in the hot loop)
-        for (int k = wave; k < ck.count; k += nw_) {
+        for (int k = wave; k < ck.count; k = next_ticket(ticket, lane)) {   // LDS voxel ticket, see k_noddi
             sandi_voxel<NR, NQ, MAXP>(a, As, rs, rl, a.c.perm[ck.start + k], lane);
         }
     } else {

@@ -6,7 +6,10 @@ template <int NR>
 static int go(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
 {
     constexpr int NQ = 3, MP = 12, MB = 32;
-    constexpr int NW = 12; // wavefronts per workgroup: as many as the register budget of this stage allows
+#ifndef AMX_S1_NW
+#define AMX_S1_NW 12
+#endif
+    constexpr int NW = AMX_S1_NW; // wavefronts per workgroup: as many as the register budget of this stage allows
     return launch_pair<NW>(ctx, a, pl, s, k_noddi<1, NR, NQ, MP, NW, false>, k_noddi<1, NR, NQ, MB, 1, true>,
                        [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MP); }, fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB),
                        0, 2);
