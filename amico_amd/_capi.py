@@ -22,7 +22,8 @@ SYMBOLS = ['amx_version', 'amx_ctx_create', 'amx_ctx_destroy', 'amx_last_error',
            'amx_set_profiling', 'amx_last_kernel_ms', 'amx_last_stats', 'amx_selftest',
            'amx_dti_create', 'amx_dti_destroy', 'amx_dti_directions', 'amx_dti_directions_device',
            'amx_prep_create', 'amx_prep_destroy', 'amx_prep_gather', 'amx_prep_gather_device',
-           'amx_prep_mean_b0', 'amx_prep_mean_b0_device', 'amx_prep_scatter', 'amx_prep_scatter_device']
+           'amx_prep_mean_b0', 'amx_prep_mean_b0_device', 'amx_prep_scatter', 'amx_prep_scatter_device',
+           'amx_lut_resample']
 
 _lib = None
 c_vp, c_dp, c_fp = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float)
@@ -91,6 +92,7 @@ def lib():
     L.amx_prep_mean_b0_device.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp]
     L.amx_prep_scatter.argtypes = [c_vp, c_vp, c_dp, C.c_int, c_fp]
     L.amx_prep_scatter_device.argtypes = [c_vp, c_vp, c_vp, C.c_int, c_vp, c_vp]
+    L.amx_lut_resample.argtypes = [c_vp, c_fp, C.c_int64, C.c_int, c_fp, c_i32p, C.c_int, C.c_int, c_fp]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ('amx_version',):
@@ -392,3 +394,17 @@ class Prep:
         out = np.zeros(self.shape[:3] + (v.shape[1],), dtype=np.float32)
         self.ctx.check(lib().amx_prep_scatter(self.ctx._h, self._h, _p(v, c_dp), v.shape[1], _p(out, c_fp)))
         return out
+
+
+def lut_resample(ctx, lm, ylm_out, idx_out, nS):
+    """lm f32[..., n_sh] -> f32[..., nS] with ones outside idx_out (resample_kernel, lut.pyx:274-311, batched)"""
+    lm = np.ascontiguousarray(lm, dtype=np.float32)
+    y = np.ascontiguousarray(ylm_out, dtype=np.float32)
+    idx = np.ascontiguousarray(idx_out, dtype=np.int32)
+    if y.ndim != 2 or lm.shape[-1] != y.shape[1] or idx.shape != (y.shape[0],):
+        raise ValueError('Outdated LUT. Call "generate_kernels( regenerate=True )" to update the LUT')   # lut.pyx:301
+    rows = int(np.prod(lm.shape[:-1], dtype=np.int64))
+    out = np.empty(lm.shape[:-1] + (int(nS),), dtype=np.float32)
+    ctx.check(lib().amx_lut_resample(ctx._h, _p(lm, c_fp), rows, lm.shape[-1], _p(y, c_fp), _p(idx, c_i32p),
+                                     y.shape[0], int(nS), _p(out, c_fp)))
+    return out

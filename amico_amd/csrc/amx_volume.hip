@@ -380,3 +380,86 @@ int amx_prep_scatter(amx_ctx *ctx, const amx_prep *p, const double *values, int 
 }
 
 }  // extern "C"
+
+// ============================================================================ LUT resampling (SURVEY section 8 f, row 4)
+// lut.pyx:274-311 `resample_kernel`:  KR = ones(ndirs, nS);  KR[i, idx_out] = dot(Ylm_out, KRlm[i, :])  for every
+// orientation i -- batched over all atoms as ONE float32 GEMM  C[M x N] = L[M x K] * Ylm^T[K x N]  (M = atoms * ndirs rows
+// of rotated SH coefficients, K = nSH * shells, N = number of DWI volumes) on the matrix cores.
+namespace amx {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+__global__ void k_fill_ones(float *out, long long n)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = 1.0f;
+}
+
+// One wavefront = 32 rows of L against 32 columns (volumes) at a time with v_mfma_f32_32x32x2_f32.  The reduction
+// index is split in two halves, one per half-wavefront (lane l works on k = (l / 32) * Kh + j), so that every lane
+// streams a contiguous piece of its row of L and of its row of Ylm; the order of a sum does not matter to the GEMM.
+__global__ __launch_bounds__(256) void k_lut_resample(const float *__restrict__ L, const float *__restrict__ Y,
+                                                      const int *__restrict__ idx_out, long long M, int K, int N, int nS,
+                                                      float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int Kh = (K + 1) / 2;
+    const long long m0 = ((long long)blockIdx.x * 4 + wave) * 32;
+    if (m0 >= M) return;
+    const long long row = m0 + l32;
+    const float *lrow = L + (row < M ? row : M - 1) * K + (long long)half * Kh;
+    const int kcnt = half == 0 ? Kh : K - Kh;                        // elements of this lane's half
+    for (int n0 = 0; n0 < N; n0 += 32) {
+        const int n = n0 + l32;
+        const float *yrow = Y + (long long)(n < N ? n : N - 1) * K + (long long)half * Kh;
+        floatx16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+        for (int j = 0; j < Kh; j++) {
+            const float av = (j < kcnt && row < M) ? lrow[j] : 0.0f;
+            const float bv = (j < kcnt && n < N) ? yrow[j] : 0.0f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        if (n < N) {
+            const int col = idx_out[n];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const long long r = m0 + 8 * (i / 4) + 4 * half + (i % 4);
+                if (r < M) out[r * nS + col] = acc[i];
+            }
+        }
+    }
+}
+
+}  // namespace amx
+
+extern "C" int amx_lut_resample(amx_ctx *ctx, const float *lm, int64_t n_rows, int n_sh, const float *ylm_out,
+                                const int32_t *idx_out, int n_out, int nS, float *out)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!lm || !ylm_out || !idx_out || !out || n_rows < 1 || n_sh < 1 || n_out < 1 || nS < n_out)
+        return amx_bad(ctx, "amx_lut_resample: bad argument");
+    for (int k = 0; k < n_out; k++) if (idx_out[k] < 0 || idx_out[k] >= nS) return amx_bad(ctx, "amx_lut_resample: idx_out out of range");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    const size_t lb = (size_t)n_rows * n_sh * sizeof(float), yb = (size_t)n_out * n_sh * sizeof(float);
+    const size_t ob = (size_t)n_rows * nS * sizeof(float);
+    if ((rc = amx_ensure(ctx, ctx->hy, lb))) return rc;
+    if ((rc = amx_ensure(ctx, ctx->hdirs, yb))) return rc;
+    if ((rc = amx_ensure(ctx, ctx->hrmse, (size_t)n_out * sizeof(int)))) return rc;
+    if ((rc = amx_ensure(ctx, ctx->hextra, ob))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->hy.p, lm, lb, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->hdirs.p, ylm_out, yb, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->hrmse.p, idx_out, (size_t)n_out * sizeof(int), hipMemcpyHostToDevice, nullptr));
+    hipLaunchKernelGGL(k_fill_ones, dim3(2048), dim3(256), 0, nullptr, (float *)ctx->hextra.p, (long long)n_rows * nS);
+    const long long blocks = (n_rows + 127) / 128;
+    rec(ctx, 8, nullptr);
+    hipLaunchKernelGGL(k_lut_resample, dim3((unsigned)blocks), dim3(256), 0, nullptr, (const float *)ctx->hy.p,
+                       (const float *)ctx->hdirs.p, (const int *)ctx->hrmse.p, (long long)n_rows, n_sh, n_out, nS,
+                       (float *)ctx->hextra.p);
+    HIPCHK(ctx, hipGetLastError());
+    rec(ctx, 9, nullptr);
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->hextra.p, ob, hipMemcpyDeviceToHost, nullptr));
+    HIPCHK(ctx, hipStreamSynchronize(nullptr));
+    return AMX_OK;
+}

@@ -44,10 +44,41 @@ class BaseModel(ABC):
         self.solver_params = {}
 
     def generate(self, out_path, aux, idx_in, idx_out, ndirs):
-        raise NotImplementedError('LUT generation is outside the MI355X fit path (SURVEY.md 8(f) row 4)')
+        raise NotImplementedError('response-function synthesis is outside the MI355X path (one-off per protocol, '
+                                  'amico/synthesis.py); amico_amd.lut.rotate_kernel rotates a synthesised kernel')
+
+    # ---- resampling of the rotated SH coefficients to the subject's scheme (models.pyx:754-792, 1113-1144,
+    #      1446-1486): `in_path` is the reference's folder of A_###.npy files or a list of the arrays themselves.
+    @staticmethod
+    def _load_lm(in_path, n_atoms):
+        if isinstance(in_path, (str, bytes)):
+            from os.path import join as pjoin
+            return [np.load(pjoin(in_path, f'A_{i + 1:03d}.npy')) for i in range(n_atoms)]
+        if len(in_path) != n_atoms:
+            raise ValueError('Outdated LUT. Call "generate_kernels( regenerate=True )" to update the LUT')
+        return list(in_path)
+
+    def _merge(self, doMergeB0):
+        """(nS of the resampled kernels, columns kept): with doMergeB0 the first b0 + the DWI volumes"""
+        sc = self.scheme
+        if doMergeB0:
+            return 1 + sc.dwi_count, np.hstack((sc.b0_idx[0], sc.dwi_idx))
+        return sc.nS, np.arange(sc.nS)
+
+    def _resample_rotated(self, lms, idx_out, Ylm_out, ndirs):
+        """all anisotropic atoms in ONE GEMM on the GPU (amx_lut_resample) -> f32[n, ndirs, scheme.nS]"""
+        from . import lut as _lut
+        for lm in lms:
+            if np.ndim(lm) != 2 or lm.shape[0] != ndirs:
+                raise ValueError('Outdated LUT. Call "generate_kernels( regenerate=True )" to update the LUT')
+        return _lut.resample_kernels(np.stack(lms).astype(np.float32, copy=False), self.scheme.nS, idx_out, Ylm_out)
+
+    def _resample_isotropic(self, lms, idx_out, Ylm_out):
+        from . import lut as _lut
+        return _lut.resample_kernels(np.stack(lms).astype(np.float32, copy=False), self.scheme.nS, idx_out, Ylm_out)
 
     def resample(self, in_path, idx_out, Ylm_out, doMergeB0, ndirs):
-        raise NotImplementedError('LUT resampling is outside the MI355X fit path (SURVEY.md 8(f) row 4)')
+        raise NotImplementedError
 
     @abstractmethod
     def fit(self, evaluation):
@@ -106,6 +137,22 @@ class NODDI(BaseModel):
         super().set_solver()
         self.solver_params['lambda1'] = lambda1
         self.solver_params['lambda2'] = lambda2
+
+    def resample(self, in_path, idx_out, Ylm_out, doMergeB0, ndirs):
+        """models.pyx:754-792"""
+        n_wm = len(self.IC_ODs) * len(self.IC_VFs)
+        lms = self._load_lm(in_path, n_wm + 1)
+        nS, merge_idx = self._merge(doMergeB0)
+        K = {'model': self.id}
+        K['wm'] = np.ascontiguousarray(self._resample_rotated(lms[:n_wm], idx_out, Ylm_out, ndirs)[:, :, merge_idx])
+        K['iso'] = self._resample_isotropic(lms[n_wm:], idx_out, Ylm_out)[0][merge_idx]
+        K['kappa'] = np.repeat(1.0 / np.tan(np.asarray(self.IC_ODs) * np.pi / 2.0), len(self.IC_VFs)).astype(np.float32)
+        K['icvf'] = np.tile(np.asarray(self.IC_VFs), len(self.IC_ODs)).astype(np.float32)
+        K['norms'] = np.zeros((self.scheme.dwi_count, n_wm))
+        cols = slice(1, None) if doMergeB0 else self.scheme.dwi_idx
+        for a in range(n_wm):
+            K['norms'][:, a] = 1 / np.linalg.norm(K['wm'][a, 0, cols])     # norm of coupled atoms (for l1 minimization)
+        return K
 
     def fit(self, evaluation):
         super().fit(evaluation)
@@ -166,6 +213,16 @@ class FreeWater(BaseModel):
         # NB: the reference assigns lambda2 = 0.25 for Mouse to a dead local (models.pyx:1082-1085):
         # it has no effect there and therefore none here.
 
+    def resample(self, in_path, idx_out, Ylm_out, doMergeB0, ndirs):
+        """models.pyx:1113-1144"""
+        n_t, n_i = len(self.d_perps), len(self.d_isos)
+        lms = self._load_lm(in_path, n_t + n_i)
+        _, merge_idx = self._merge(doMergeB0)
+        K = {'model': self.id}
+        K['D'] = np.ascontiguousarray(self._resample_rotated(lms[:n_t], idx_out, Ylm_out, ndirs)[:, :, merge_idx])
+        K['CSF'] = np.ascontiguousarray(self._resample_isotropic(lms[n_t:], idx_out, Ylm_out)[:, merge_idx])
+        return K
+
     def fit(self, evaluation):
         super().fit(evaluation)
         self.configs['save_corrected_DWI'] = evaluation.get_config('doSaveCorrectedDWI')
@@ -214,6 +271,19 @@ class SANDI(BaseModel):
         super().set_solver()
         self.solver_params['lambda1'] = lambda1
         self.solver_params['lambda2'] = lambda2
+
+    def resample(self, in_path, idx_out, Ylm_out, doMergeB0, ndirs):
+        """models.pyx:1446-1486: isotropic atoms, each scaled to unit norm"""
+        n_atoms = len(self.Rs) + len(self.d_in) + len(self.d_isos)
+        lms = self._load_lm(in_path, n_atoms)
+        nS, merge_idx = self._merge(doMergeB0)
+        sig = self._resample_isotropic(lms, idx_out, Ylm_out)[:, merge_idx]
+        K = {'model': self.id, 'signal': np.zeros((nS, n_atoms), dtype=np.float64, order='F'),
+             'norms': np.zeros(n_atoms, dtype=np.float64)}
+        for a in range(n_atoms):
+            K['norms'][a] = 1.0 / np.linalg.norm(sig[a])
+            K['signal'][:, a] = sig[a] * K['norms'][a]
+        return K
 
     def fit(self, evaluation):
         super().fit(evaluation)

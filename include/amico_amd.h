@@ -161,6 +161,16 @@ int amx_prep_scatter(amx_ctx *ctx, const amx_prep *p, const double *values, int 
 int amx_prep_scatter_device(amx_ctx *ctx, const amx_prep *p, const double *d_values, int n_cols,
                             float *d_volume, void *hip_stream);
 
+/* (f4) LUT resampling to the subject's scheme, lut.pyx:274-311 `resample_kernel` (called per atom by
+ * NODDI.resample models.pyx:754-792, FreeWater.resample :1113-1144, ...):
+ *     KR = np.ones((ndirs, nS), float32);  KR[i, idx_out] = np.dot(Ylm_out, KRlm[i, :])   for i in range(ndirs)
+ * batched over all atoms: lm f32[n_rows][n_sh] = the rotated SH coefficients of n_rows = atoms * ndirs
+ * (atom, orientation) pairs (an isotropic atom is one row), ylm_out f32[n_out][n_sh] and idx_out int32[n_out]
+ * from aux_structures_resample (lut.pyx:196-224); out f32[n_rows][nS] (host).  One float32 GEMM on the matrix
+ * cores; sums are ordered differently from the reference's BLAS sgemv (float32 rounding, ~1e-6 relative).     */
+int amx_lut_resample(amx_ctx *ctx, const float *lm, int64_t n_rows, int n_sh, const float *ylm_out,
+                     const int32_t *idx_out, int n_out, int nS, float *out);
+
 /* ---- measurement hooks (bench.py): HIP-event time of the solver kernels of the LAST
  * *_fit_device call on this ctx, measured on the stream they were launched on.
  * which: 0 = all kernels of the call, 1..3 = solver stage kernels (NODDI: NNLS-1, LASSO,
