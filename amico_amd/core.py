@@ -112,6 +112,25 @@ class Evaluation:
         if self.model is not None:
             self.model.scheme = self.scheme
 
+    def load_kernels(self, in_path, lut_dirs, lmax=12):
+        """core.py:374-404 `load_kernels`: resample the rotated SH coefficients (folder of A_###.npy files written by
+        generate_kernels, or the list of arrays) to this subject's scheme -- one GEMM on the GPU -- and set KERNELS /
+        htable.  `lut_dirs` [ndirs, 3]: the LUT orientations (amico/directions/ndirs=*.bin in the reference)."""
+        from . import lut as _lut
+        from .synthetic import build_htable
+        if self.model is None:
+            raise RuntimeError('Model not set; call "set_model()" method first')
+        if self.scheme is None:
+            raise RuntimeError('Scheme not loaded; call "set_data()" first')
+        t = time.time()
+        self.model.scheme = self.scheme
+        idx_out, ylm_out = _lut.aux_structures_resample(self.scheme, lmax)
+        self.KERNELS = self.model.resample(in_path, idx_out, ylm_out, self.get_config('doMergeB0'), len(lut_dirs))
+        self.htable = build_htable(np.asarray(lut_dirs, dtype=np.float64))
+        self.set_config('ndirs', len(lut_dirs))
+        self.set_config('lmax', lmax)
+        self.set_config('load_kernels_time', time.time() - t)
+
     def fit(self):
         if self.niiDWI_img is None:
             raise RuntimeError('Data not loaded; call "set_data()" first')

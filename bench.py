@@ -201,6 +201,43 @@ def signal_preparation(args):
                                        'kind': 'reference', 'sample': 'the numpy statements of core.py:209-223, 451-452 on the same image'}}))
 
 
+def lut_resampling(args):
+    """load_kernels' resampling (SURVEY section 8 f row 4): 144 atoms x 500 orientations, lmax 12, 2 shells -> 90 DWI volumes"""
+    from amico_amd import lut, synthetic as S
+    from amico_amd.models import get_context
+    from oracle import lut_np
+    scheme = S.make_scheme()
+    rng = np.random.default_rng(0)
+    n_atoms, ndirs = 144, 500
+    idx_out, ylm_out = lut.aux_structures_resample(scheme, 12)
+    lm = rng.normal(size=(n_atoms, ndirs, ylm_out.shape[1])).astype(np.float32)
+    ctx = get_context()
+    ctx.set_profiling(True)
+    for _ in range(args.warmup):
+        lut.resample_kernels(lm, scheme.nS, idx_out, ylm_out)
+    t0 = time.perf_counter()
+    kms = 0.0
+    for _ in range(args.steps):
+        out = lut.resample_kernels(lm, scheme.nS, idx_out, ylm_out)
+        kms += ctx.last_kernel_ms(4)
+    el = (time.perf_counter() - t0) / args.steps
+    kms /= args.steps
+    t1 = time.perf_counter()
+    na = 8
+    ref = np.stack([lut_np.resample_kernel(lm[a], scheme.nS, idx_out, ylm_out, False, ndirs) for a in range(na)])
+    cpu = (time.perf_counter() - t1) / na * n_atoms
+    flop = 2.0 * n_atoms * ndirs * ylm_out.shape[1] * ylm_out.shape[0]
+    print(json.dumps({'metric': 'seconds, LUT resampling of one subject (host arrays in/out)', 'value': el, 'unit': 's',
+                      'higher_is_better': False, 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'dtype': 'f32',
+                      'data': 'synthetic', 'config': {'workload': '144 atoms x 500 orientations, 182 SH coefficients -> 90 DWI volumes of 99'},
+                      'roofline': {'bound': 'mfma', 'achieved': flop / (kms * 1e-3) / 1e12, 'peak': 157.3, 'unit': 'TFLOP/s',
+                                   'frac': flop / (kms * 1e-3) / 1e12 / 157.3, 'traffic': None, 'kernel': 'k_lut_resample',
+                                   'kernel_ms': kms, 'note': 'one-off per subject; the call is bound by the PCIe copies of lm (52 MB) and KERNELS (28 MB)'},
+                      'parity': {'atoms_checked': na, 'max_abs_diff': float(np.abs(out[:na] - ref).max())},
+                      'cpu_baseline': {'value': cpu, 'unit': 's', 'cores': 1, 'kind': 'reference',
+                                       'sample': 'the numpy statement of lut.pyx:274-311 on %d of 144 atoms, scaled' % na}}))
+
+
 def _capi_lib():
     from amico_amd import _capi
     return _capi.lib()
@@ -226,13 +263,15 @@ def main():
     ap.add_argument('--voxels', type=int, default=1_000_000, help='voxels per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--host', action='store_true', help='also time the host-buffer entry point (PCIe inclusive)')
-    ap.add_argument('--model', default='noddi', choices=['noddi', 'freewater', 'sandi', 'dti', 'prep'],
+    ap.add_argument('--model', default='noddi', choices=['noddi', 'freewater', 'sandi', 'dti', 'prep', 'lut'],
                     help='noddi = the BASELINE.json headline; the others are extra measurements (configs 3, 4)')
     args = ap.parse_args()
     if args.model == 'dti':
         return dti_directions(args)
     if args.model == 'prep':
         return signal_preparation(args)
+    if args.model == 'lut':
+        return lut_resampling(args)
     if args.model != 'noddi':
         return other_models(args)
 
