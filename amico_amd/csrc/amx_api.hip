@@ -565,3 +565,13 @@ int amx_dir_to_lut_idx(amx_ctx *ctx, const amx_lut *lut, const double *dirs, int
 }
 
 }  // extern "C"
+
+#ifdef AMX_PEEK
+// diagnosis only (never built into the shipped library): read back the stage intermediates of one voxel
+extern "C" int amx_peek(amx_ctx *ctx, int64_t vox, double *xiso2, unsigned long long *supp4)
+{
+    HIPCHK(ctx, hipMemcpy(xiso2, (double *)ctx->xiso.p + vox * 2, 2 * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(supp4, (unsigned long long *)ctx->supp.p + vox * 4, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return AMX_OK;
+}
+#endif

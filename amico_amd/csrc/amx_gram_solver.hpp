@@ -104,7 +104,8 @@ struct GramSolver {
 #pragma unroll
         for (int q = 0; q < NQ; q++) fl |= (unsigned)((allowed[q] >> lane) & 1ull) << q;
         np = 0; x = 0.0; xprev = 0.0; sc = 1.0; cs = 0.0; linv = 0.0; idx = -1; iters = 0; n_exact = 0; n_gram = 0;
-        int status = kSolved, last_added = -1, gram_steps = 0;
+        int status = kSolved, last_added = -1, gram_steps = 0, second_looks = 0;
+        bool cyc_banned = false;
         bool have_u = false, force_exact = false;
         double u[NQ], uy[NQ];                 // atom space: A'r and A'y (unscaled)
 #pragma unroll
@@ -194,7 +195,9 @@ struct GramSolver {
                 }
                 const double wmax = wave_max(best);
                 if (!exact) {
+#ifndef AMX_ALWAYS_CONFIRM
                     if (uni(wmax < -kExactBelow)) break;           // clearly a KKT point: no exact confirmation needed
+#endif
                     if (uni(!(wmax > kExactBelow))) { force_exact = true; redo = true; break; }
                 }
                 if (!uni(wmax > tol)) break;
@@ -230,15 +233,25 @@ struct GramSolver {
                         Hl[tri(kn, kn)] = htt; Ll[tri(kn, kn)] = d2 * iv; linv = iv;
                         x = 0.0; xprev = 0.0; sc = sct; idx = t; cs = sct * uyt - lam1;
                     }
-                    fl &= 0xffffu;
+                    fl &= 0xffffu; cyc_banned = false;
                     if (lane == tl) fl |= 0x100u << tq;
                     np = kn + 1;
                     last_added = t;
                     added = true;
                 }
             }
-            if (redo) continue;
-            if (!added) break;
+            if (redo) continue;  // small dual values: decide on the exactly recomputed vector
+            if (!added) {
+                // An atom that left the passive set in the very step that brought it in is barred from re-entering until
+                // another atom has been added (add/remove cycles on rounding noise).  Lawson-Hanson itself forgets such
+                // history after every step, so before declaring a KKT point give the barred atoms another look -- on an
+                // exact dual vector, a bounded number of times.
+                if (status == kSolved && cyc_banned && second_looks < 3) {
+                    fl &= 0xffffu; cyc_banned = false; second_looks++; force_exact = true; last_added = -1;
+                    continue;
+                }
+                break;   // KKT point (or a guard tripped)
+            }
 
             // ---- Lawson-Hanson inner loop
             for (bool feasible = false; !feasible && status == kSolved;) {
@@ -262,7 +275,7 @@ struct GramSolver {
                         const int k = 63 - __builtin_clzll(rem);
                         rem &= ~(1ull << k);
                         const int a = bcast_i(idx, k);
-                        if (a == last_added && lane == (a & 63)) fl |= 0x10000u << (a >> 6);
+                        if (a == last_added) { cyc_banned = true; if (lane == (a & 63)) fl |= 0x10000u << (a >> 6); }
                         {   // the atom leaves with coefficient 0: fold its change into u now
                             const double dl = -bcast(sc * xprev, k);
                             const double *gc = G + (size_t)a * ldG + lane;

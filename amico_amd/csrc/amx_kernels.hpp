@@ -64,6 +64,13 @@ __device__ __forceinline__ bool load_rows(const double *__restrict__ yv, int nS,
 }
 
 // ------------------------------------------------------------------ NODDI
+// models.pyx:966: ODI = 2/pi * atan2(1, kappa).  Kept out of line: inlined, the constants of ocml's atan2 are
+// hoisted out of the voxel loop and stay live across the solver (tens of VGPRs -> scratch spills).
+__device__ __attribute__((noinline)) double odi_from_kappa(double k1)
+{
+    return 2.0 / 3.14159265358979323846 * atan2(1.0, k1);
+}
+
 struct NoddiArgs {
     FitCommon c;
     const unsigned char *rowdwi;  // [nS] rows entering stage 2 (scheme.dwi_idx / single_b0 rule)
@@ -195,7 +202,7 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const float *As,
         }
         f1 = wave_sum(f1); f2 = wave_sum(f2); k1 = wave_sum(k1);
         const double ndi = f1 / (f1 + f2 + 1e-16);
-        const double odi = 2.0 / 3.14159265358979323846 * atan2(1.0, k1);
+        const double odi = odi_from_kappa(k1);
         const double fwf = wave_sum((act && S.idx == iso_atom) ? xs : 0.0) / sum_atoms;
         const double dot = wave_sum((act && S.idx == dot_atom) ? xs : 0.0) / sum_atoms;
         if (lane == 0) {

@@ -5,7 +5,10 @@ using namespace amx;
 template <int NR>
 static int go(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
 {
-    constexpr int NQ = 3, MP = 12, MB = 32;
+#ifndef AMX_S1_MP
+#define AMX_S1_MP 8
+#endif
+    constexpr int NQ = 3, MP = AMX_S1_MP, MB = 32;
 #ifndef AMX_S1_NW
 #define AMX_S1_NW 12
 #endif

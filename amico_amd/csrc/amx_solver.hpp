@@ -248,8 +248,16 @@ struct NNSolver {
     {
         Rl = rl;
         Ql = rl + (MAXP + 1) * LDR;
-        const double tol = 1e-12;            // KKT tolerance on the dual vector
-        const double dep2 = 1e-20;           // (1e-10)^2: relative independence of a new column
+        // KKT tolerance on the (exactly recomputed) dual vector.  Lawson-Hanson -- the unregularised solver of the
+        // reference -- continues while any admissible dual value is > 0 and leaves it to the z-test to refuse
+        // candidates that are rounding noise; with nearly collinear atoms a dual value of 5e-13 still moves the maps
+        // by 1e-3, so the NNLS problems use the same strict rule.  The l1 problems keep a small positive tolerance.
+        const double tol = (lam1 > 0.0) ? 1e-12 : 0.0;
+        // Lawson-Hanson's independence test of a candidate column, `unorm + |pivot| * 0.01 != unorm` with unorm = the
+        // norm of its component inside span(Q) and pivot = the norm b of the component outside: accept iff
+        // b * 0.01 exceeds half an ulp of unorm, i.e. b^2 > (1.1e-16 / 0.01)^2 unorm^2 (1.2e-28 .. 4.9e-28 depending
+        // on where unorm sits in its binade; 2e-28 here).  A stricter test bans atoms the reference's solver accepts.
+        const double dep2 = 2e-28;
         const double inf = __builtin_huge_val();
         const int itmax = 3 * n_atoms + 10;  // Lawson-Hanson's cap
         const double sqlam2 = RIDGE ? sqrt(lam2) : 0.0;
@@ -262,13 +270,17 @@ struct NNSolver {
             for (int m = 0; m < LDR; m++) Ql[lane * LDR + m] = 0.0;
         }
         int status = kSolved;
-        int last_added = -1;
+        int last_added = -1, second_looks = 0;
+        bool cyc_banned = false;
         n_exact = 0; n_gram = 0;
 #ifndef AMX_GRAM_COLS
 #define AMX_GRAM_COLS 4
 #endif
         constexpr int kGramCols = AMX_GRAM_COLS;   // Gram columns in flight per trip of the dual-vector update
-        constexpr int kMaxGramSteps = 48;    // bound the drift of the Gram-updated dual vector
+#ifndef AMX_GRAM_STEPS
+#define AMX_GRAM_STEPS 48
+#endif
+        constexpr int kMaxGramSteps = AMX_GRAM_STEPS;    // bound the drift of the Gram-updated dual vector
         const double kExactBelow = 1e-7;     // decisions on smaller dual values use the exact sweep
         double u[NQ];                        // atom space: A' r (unscaled, without the l1 shift)
         bool have_u = false, force_exact = false;
@@ -365,7 +377,9 @@ struct NNSolver {
                 if (!exact) {
                     // every admissible dual value is negative by far more than the Gram updates can have drifted:
                     // the exact sweep would confirm the KKT point and change nothing
+#ifndef AMX_ALWAYS_CONFIRM
                     if (uni(wmax < -kExactBelow)) break;
+#endif
                     if (uni(!(wmax > kExactBelow))) { force_exact = true; redo = true; break; }
                 }
                 if (!uni(wmax > tol)) break;                      // KKT point reached
@@ -429,7 +443,7 @@ struct NNSolver {
 #pragma unroll
                 for (int rr = 0; rr < NR; rr++) vsq += v[rr] * v[rr];
                 const double b2 = wave_sum(vsq);
-                bool reject = !uni(b2 > dep2 * n0);
+                bool reject = !uni(b2 > dep2 * (n0 - b2));
                 double beta = 0.0, binv = 0.0, dnew = 0.0, enew = 0.0;
                 if (!reject) {
                     binv = inv_sqrt(b2);
@@ -457,7 +471,7 @@ struct NNSolver {
                     if (lane <= kn) Rl[lane * LDR + kn] = (lane == kn) ? beta : rho;     // column kn of R
                     if (RIDGE && lane <= kn) Ql[lane * LDR + kn] = va * binv;               // ridge rows of q_kn
                     if (lane == kn) { d = dnew; e = enew; rinv = binv; x = 0.0; sc = sct; idx = t; }
-                    fl &= 0xffffu;                               // forget the rejected candidates
+                    fl &= 0xffffu; cyc_banned = false;                               // forget the rejected candidates
                     if (lane == tl) fl |= 0x100u << tq;
                     np = kn + 1;
                     last_added = t;
@@ -465,7 +479,17 @@ struct NNSolver {
                 }
             }
             if (redo) continue;  // small dual values: decide on the exactly recomputed vector
-            if (!added) break;   // KKT point (or a guard tripped)
+            if (!added) {
+                // An atom that left the passive set in the very step that brought it in is barred from re-entering until
+                // another atom has been added (add/remove cycles on rounding noise).  Lawson-Hanson itself forgets such
+                // history after every step, so before declaring a KKT point give the barred atoms another look -- on an
+                // exact dual vector, a bounded number of times.
+                if (status == kSolved && cyc_banned && second_looks < 3) {
+                    fl &= 0xffffu; cyc_banned = false; second_looks++; force_exact = true; last_added = -1;
+                    continue;
+                }
+                break;   // KKT point (or a guard tripped)
+            }
 
             // ---- Lawson-Hanson inner loop: restore feasibility of the passive solution
             for (bool feasible = false; !feasible && status == kSolved;) {
@@ -501,7 +525,7 @@ struct NNSolver {
                         const int k = 63 - __builtin_clzll(rem);
                         rem &= ~(1ull << k);
                         const int a = bcast_i(idx, k);
-                        if (a == last_added && lane == (a & 63)) fl |= 0x10000u << (a >> 6);   // no add/remove cycling
+                        if (a == last_added) { cyc_banned = true; if (lane == (a & 63)) fl |= 0x10000u << (a >> 6); }   // no add/remove cycling
                         if (G != nullptr) {       // the atom leaves with coefficient 0: fold its change into u now
                             const double dl = -bcast(sc * xprev, k);
                             const double *gc = G + (size_t)a * ldG + lane;
