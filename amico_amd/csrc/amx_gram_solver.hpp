@@ -259,10 +259,10 @@ struct GramSolver {
                 const double z = solve_passive(lane);
                 const bool act = lane < np;
                 const bool neg = act && !(z > 0.0);
-                if (ballot64(neg) == 0ull) {
-                    x = act ? z : 0.0;
-                    feasible = true;
-                } else {
+                // (state changes only inside the removal loop, which makes zero trips when feasible: see NNSolver)
+                const bool any = ballot64(neg) != 0ull;
+                unsigned long long rem = 0ull;
+                if (any) {
                     const double den = x - z;
                     const double ratio = neg ? ((den > 0.0) ? x / den : 0.0) : inf;
                     const double alpha = wave_min(ratio);
@@ -270,22 +270,25 @@ struct GramSolver {
                     const int kmin = hit ? __builtin_ctzll(hit) : -1;
                     x = act ? x + alpha * (z - x) : 0.0;
                     if (lane == kmin) x = 0.0;
-                    unsigned long long rem = ballot64(act && !(x > 0.0));
-                    for (int guard = 0; rem != 0ull && guard < kWave; ++guard) {
-                        const int k = 63 - __builtin_clzll(rem);
-                        rem &= ~(1ull << k);
-                        const int a = bcast_i(idx, k);
-                        if (a == last_added) { cyc_banned = true; if (lane == (a & 63)) fl |= 0x10000u << (a >> 6); }
-                        {   // the atom leaves with coefficient 0: fold its change into u now
-                            const double dl = -bcast(sc * xprev, k);
-                            const double *gc = G + (size_t)a * ldG + lane;
-#pragma unroll
-                            for (int q = 0; q < NQ; q++) u[q] -= gc[kWave * q] * dl;
-                        }
-                        remove_slot(k, lane, fl);
-                    }
-                    if (np == 0) { x = 0.0; feasible = true; }
+                    rem = ballot64(act && !(x > 0.0));
+                } else {
+                    x = act ? z : 0.0;
                 }
+                for (int guard = 0; rem != 0ull && guard < kWave; ++guard) {
+                    const int k = 63 - __builtin_clzll(rem);
+                    rem &= ~(1ull << k);
+                    const int a = bcast_i(idx, k);
+                    if (a == last_added) { cyc_banned = true; if (lane == (a & 63)) fl |= 0x10000u << (a >> 6); }
+                    {   // the atom leaves with coefficient 0: fold its change into u now
+                        const double dl = -bcast(sc * xprev, k);
+                        const double *gc = G + (size_t)a * ldG + lane;
+#pragma unroll
+                        for (int q = 0; q < NQ; q++) u[q] -= gc[kWave * q] * dl;
+                    }
+                    remove_slot(k, lane, fl);
+                }
+                if (np == 0) x = 0.0;
+                feasible = !any || np == 0;
             }
         }
         return status;

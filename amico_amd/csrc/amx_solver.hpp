@@ -53,15 +53,24 @@ __device__ __forceinline__ double dpp_move(double v, double ident)
     return __hiloint2double(hi, lo);
 }
 // DPP controls (GFX9 family): row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143
+// Source lanes that do not exist read as 0 (bound_ctrl) -- the identity of a sum -- so no lane needs a prepared
+// `old` value and no row/bank masks: 6 doubling steps of 2 DPP moves + 1 add.  Lanes other than 63 end up with
+// partial sums nobody reads.
+template <int CTRL>
+__device__ __forceinline__ double dpp_zero(double v)
+{
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v)
 {
-    double t = v + dpp_move<0x111, 0xf, 0xf>(v, 0.0);
-    t += dpp_move<0x112, 0xf, 0xf>(v, 0.0);
-    t += dpp_move<0x113, 0xf, 0xf>(v, 0.0);
-    t += dpp_move<0x114, 0xf, 0xe>(t, 0.0);
-    t += dpp_move<0x118, 0xf, 0xc>(t, 0.0);
-    t += dpp_move<0x142, 0xa, 0xf>(t, 0.0);
-    t += dpp_move<0x143, 0xc, 0xf>(t, 0.0);
+    double t = v + dpp_zero<0x111>(v);      // lanes i-1..i
+    t += dpp_zero<0x112>(t);                // i-3..i
+    t += dpp_zero<0x114>(t);                // i-7..i
+    t += dpp_zero<0x118>(t);                // lane 15 of each row: the row's sum
+    t += dpp_zero<0x142>(t);                // lanes 31, 63: two rows
+    t += dpp_zero<0x143>(t);                // lane 63: all four rows
     return bcast(t, 63);
 }
 __device__ __forceinline__ double wave_max(double v)
@@ -99,8 +108,8 @@ __device__ __forceinline__ void wave_sum4(double (&p)[4], int lane)
     double k = o2 ? k1 : k0;
     const double s = o2 ? k0 : k1;                                 // handed to lane ^ 2
     k += dpp_quad<0x4E>(s);                                        // quad_perm:[2,3,0,1]
-    k += dpp_move<0x114, 0xf, 0xe>(k, 0.0);                        // across the quads of a row
-    k += dpp_move<0x118, 0xf, 0xc>(k, 0.0);
+    k += dpp_zero<0x114>(k);                                       // across the quads of a row
+    k += dpp_zero<0x118>(k);
     k += __shfl_xor(k, 16, kWave);                                 // across the four rows
     k += __shfl_xor(k, 32, kWave);
     // lanes 12..15 hold the totals of value 2*(lane&1) + ((lane>>1)&1)
@@ -509,10 +518,11 @@ struct NNSolver {
                 }
                 const bool act = lane < np;
                 const bool neg = act && !(z > 0.0);
-                if (ballot64(neg) == 0ull) {
-                    x = act ? z : 0.0;
-                    feasible = true;
-                } else {
+                // The heavy state (Q, R, d, ...) changes only inside the removal loop below, which makes zero trips for a
+                // feasible solution: an if/else around it cost two full copies of that state per pass (phi copies).
+                const bool any = ballot64(neg) != 0ull;
+                unsigned long long rem = 0ull;
+                if (any) {
                     const double den = x - z;
                     const double ratio = neg ? ((den > 0.0) ? x / den : 0.0) : inf;
                     const double alpha = wave_min(ratio);
@@ -520,22 +530,25 @@ struct NNSolver {
                     const int kmin = hit ? __builtin_ctzll(hit) : -1;
                     x = act ? x + alpha * (z - x) : 0.0;
                     if (lane == kmin) x = 0.0;
-                    unsigned long long rem = ballot64(act && !(x > 0.0));
-                    for (int guard = 0; rem != 0ull && guard < kWave; ++guard) {
-                        const int k = 63 - __builtin_clzll(rem);
-                        rem &= ~(1ull << k);
-                        const int a = bcast_i(idx, k);
-                        if (a == last_added) { cyc_banned = true; if (lane == (a & 63)) fl |= 0x10000u << (a >> 6); }   // no add/remove cycling
-                        if (G != nullptr) {       // the atom leaves with coefficient 0: fold its change into u now
-                            const double dl = -bcast(sc * xprev, k);
-                            const double *gc = G + (size_t)a * ldG + lane;
-#pragma unroll
-                            for (int q = 0; q < NQ; q++) u[q] -= gc[kWave * q] * dl;
-                        }
-                        remove_slot(k, lane, fl);
-                    }
-                    if (np == 0) { x = 0.0; feasible = true; }
+                    rem = ballot64(act && !(x > 0.0));
+                } else {
+                    x = act ? z : 0.0;
                 }
+                for (int guard = 0; rem != 0ull && guard < kWave; ++guard) {
+                    const int k = 63 - __builtin_clzll(rem);
+                    rem &= ~(1ull << k);
+                    const int a = bcast_i(idx, k);
+                    if (a == last_added) { cyc_banned = true; if (lane == (a & 63)) fl |= 0x10000u << (a >> 6); }   // no add/remove cycling
+                    if (G != nullptr) {       // the atom leaves with coefficient 0: fold its change into u now
+                        const double dl = -bcast(sc * xprev, k);
+                        const double *gc = G + (size_t)a * ldG + lane;
+#pragma unroll
+                        for (int q = 0; q < NQ; q++) u[q] -= gc[kWave * q] * dl;
+                    }
+                    remove_slot(k, lane, fl);
+                }
+                if (np == 0) x = 0.0;
+                feasible = !any || np == 0;
             }
         }
         return status;
