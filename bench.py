@@ -238,6 +238,52 @@ def lut_resampling(args):
                                        'sample': 'the numpy statement of lut.pyx:274-311 on %d of 144 atoms, scaled' % na}}))
 
 
+def volume_pipeline(args):
+    """raw image in HBM -> NDI/ODI/FWF volumes in HBM: prepare + tensor directions + NODDI fit + scatter on one stream"""
+    import torch
+    from amico_amd import pipeline, synthetic as S
+    from oracle import oracle, signal_np
+    dev = torch.device('cuda', 0)
+    scheme = S.make_scheme()
+    lut_dirs = S.fibonacci_hemisphere(500)
+    ht = S.build_htable(lut_dirs)
+    K = S.noddi_kernels(scheme, lut_dirs)
+    shape = (128, 128, 80)
+    n_all = int(np.prod(shape))
+    y, _ = S.noddi_signals(n_all, K, ht, scheme, seed=1)
+    img = np.asfortranarray((y.reshape(shape + (-1,)) * 900.0).astype(np.float32))     # nibabel hands out Fortran order
+    xx, yy, zz = np.meshgrid(*[np.linspace(-1, 1, s) for s in shape], indexing='ij')
+    mask = ((xx * xx + yy * yy + zz * zz) < 0.92).astype(np.uint8)
+    pl = pipeline.NoddiVolumePipeline(scheme, img, mask, K, ht)
+    flat = np.lib.stride_tricks.as_strided(img, shape=(img.size,), strides=(4,))
+    d_img = torch.from_numpy(flat.copy()).to(dev)
+    for _ in range(args.warmup):
+        pl.run(d_img)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pl.run(d_img)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / args.steps
+    n = pl.n_vox
+    # parity of the whole chain on a sample: numpy preprocessing -> numpy/LAPACK tensor fit -> C oracle
+    sel = mask == 1
+    y_ref, _ = signal_np.prepare_signal(img, mask, scheme.b0_idx, scheme.dwi_idx)
+    exact_y = bool(np.array_equal(pl.y.cpu().numpy(), y_ref))
+    m = 20000
+    d_ref = signal_np.dti_directions(y_ref[:m], scheme.b, scheme.raw[:, :3])
+    ref = oracle.noddi_fit(y_ref[:m], d_ref, K, ht, scheme.dwi_idx, nthreads=os.cpu_count())['estimates']
+    diff = np.abs(pl.est[:m].cpu().numpy() - ref).max(axis=1)
+    print(json.dumps({'metric': 'voxels/sec, raw image -> map volumes (prepare + tensor directions + NODDI fit + scatter)',
+                      'value': n / el, 'unit': 'voxels/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+                      'ms_per_step': 1e3 * el, 'dtype': 'f32 -> f64 -> f32', 'data': 'synthetic',
+                      'config': {'workload': '128x128x80x99 float32 image (Fortran order), %d masked voxels, NODDI' % n},
+                      'parity': {'y_bit_exact': exact_y, 'sample_voxels': m, 'frac_within_1e-6': float((diff < 1e-6).mean()),
+                                 'median_abs_dmap': float(np.median(diff)),
+                                 'note': 'directions differ from LAPACK\'s by ~1e-13: a voxel whose LUT index flips gets another dictionary orientation'}}))
+
+
 def _capi_lib():
     from amico_amd import _capi
     return _capi.lib()
@@ -263,7 +309,7 @@ def main():
     ap.add_argument('--voxels', type=int, default=1_000_000, help='voxels per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--host', action='store_true', help='also time the host-buffer entry point (PCIe inclusive)')
-    ap.add_argument('--model', default='noddi', choices=['noddi', 'freewater', 'sandi', 'dti', 'prep', 'lut'],
+    ap.add_argument('--model', default='noddi', choices=['noddi', 'freewater', 'sandi', 'dti', 'prep', 'lut', 'pipeline'],
                     help='noddi = the BASELINE.json headline; the others are extra measurements (configs 3, 4)')
     args = ap.parse_args()
     if args.model == 'dti':
@@ -272,6 +318,8 @@ def main():
         return signal_preparation(args)
     if args.model == 'lut':
         return lut_resampling(args)
+    if args.model == 'pipeline':
+        return volume_pipeline(args)
     if args.model != 'noddi':
         return other_models(args)
 

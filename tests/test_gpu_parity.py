@@ -305,3 +305,27 @@ def test_small_models_both_mappings(fw_fix, sandi_fix, htable500, monkeypatch):
     assert np.abs(res['0'][0]['rmse'] - res['1'][0]['rmse']).max() < 1e-9
     assert np.abs(res['0'][0]['nrmse'] - res['1'][0]['nrmse']).max() < 1e-9
     assert np.abs(res['0'][1]['rmse'] - res['1'][1]['rmse']).max() < 1e-9
+
+
+def test_device_resident_volume_pipeline(htable500):
+    """raw image in HBM -> map volumes in HBM on one stream (amico_amd.pipeline) == the Evaluation chain on host arrays"""
+    import torch
+    import amico_amd
+    from amico_amd import pipeline, synthetic as S
+    ht = htable500['htable']
+    sch = S.make_scheme(seed=0)
+    K = S.noddi_kernels(sch, htable500['dirs'])
+    shape = (20, 12, 9)
+    y, _ = S.noddi_signals(int(np.prod(shape)), K, ht, sch, seed=8)
+    img = np.asfortranarray((y.reshape(shape + (-1,)) * 700.0).astype(np.float32))
+    mask = (np.random.default_rng(3).uniform(size=shape) < 0.8).astype(np.uint8)
+    pl = pipeline.NoddiVolumePipeline(sch, img, mask, K, ht)
+    flat = np.lib.stride_tricks.as_strided(img, shape=(img.size,), strides=(4,))
+    maps, dirs = pl.run(torch.from_numpy(flat.copy()).to('cuda:0'))
+    ae = amico_amd.Evaluation()
+    ae.set_data(img, sch, mask)
+    ae.set_model('NODDI')
+    ae.set_kernels(K, ht)
+    ae.fit()
+    assert np.array_equal(maps.cpu().numpy(), ae.RESULTS['MAPs'])
+    assert np.array_equal(dirs.cpu().numpy(), ae.RESULTS['DIRs'])

@@ -243,3 +243,32 @@ def test_prepare_signal_errors_and_edges():
         prep.SignalPreparation(sc, img[..., :5], np.ones((4, 4, 4)), do_normalize=False)
     with pytest.raises(ValueError):
         sp.gather(np.ones((4, 4, 5, 8), dtype=np.float32))
+
+
+@pytest.mark.gpu
+def test_c_abi_argument_checks_of_the_widened_rows():
+    """bad arguments come back as AMX_E_BADARG (ValueError) with a message, never as a crash"""
+    from amico_amd import _capi, get_context
+    ctx = get_context()
+    with pytest.raises(ValueError):
+        _capi.Dti(ctx, np.zeros((7, 3)))                                 # fewer volumes than parameters
+    with pytest.raises(ValueError):
+        _capi.Dti(ctx, np.zeros((6, 30)))                                # not pinv of a 7-column design matrix
+    with pytest.raises(ValueError):
+        _capi.Dti(ctx, np.zeros((7, 30)), min_signal=0.0)
+    rank = np.full((3, 3, 3), -1, dtype=np.int32)
+    rank[0, 0, 0] = 0
+    rank[1, 1, 1] = 0                                                    # row 0 used twice
+    with pytest.raises(ValueError):
+        _capi.Prep(ctx, (3, 3, 3, 4), (36, 12, 4, 1), rank, [[0], [1], [2], [3]], [0])
+    rank[1, 1, 1] = 1
+    with pytest.raises(ValueError):
+        _capi.Prep(ctx, (3, 3, 3, 4), (36, 12, 4, 1), rank, [[0], [7]], [0])          # group index out of range
+    with pytest.raises(ValueError):
+        _capi.Prep(ctx, (3, 3, 3, 4), (36, 12, 4, 0), rank, [[0]], [0])               # zero stride
+    p = _capi.Prep(ctx, (3, 3, 3, 4), (36, 12, 4, 1), rank, [[0], [1], [2], [3]], [])
+    with pytest.raises(ValueError):
+        p.gather(np.zeros((3, 3, 3, 4), dtype=np.float32), normalize=True)            # no b0 to normalise with
+    y, _ = p.gather(np.arange(108, dtype=np.float32).reshape(3, 3, 3, 4), normalize=False)
+    assert y.tolist() == [[0.0, 1.0, 2.0, 3.0], [52.0, 53.0, 54.0, 55.0]]
+    assert ctx.selftest().shape == (12, 64)                              # the context is still usable
