@@ -45,6 +45,13 @@ def lib():
         raise RuntimeError(f'amico_amd: HIP library {LIB_PATH} not found -- run `python -c "import '
                            f'__graft_entry__ as g; g.build()"` (or `make -C amico_amd/csrc -j`). '
                            f'There is no CPU fallback.')
+    # torch ships its own copy of the ROCm runtime under the same SONAMEs as /opt/rocm's, and the copy that is loaded
+    # first serves the whole process; torch only finds its GPUs on its own copy.  Load torch's first when torch is
+    # installed, so that device buffers / streams / torch.distributed keep working next to this library.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     L.amx_version.restype = C.c_int
     L.amx_ctx_create.argtypes = [C.c_int, C.POINTER(c_vp)]

@@ -98,6 +98,23 @@ __device__ __forceinline__ double dpp_quad(double v)
     int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
+// Sum of the four 16-lane rows, lane by lane, left in every row: gfx950's v_permlane16_swap / v_permlane32_swap
+// exchange whole rows between two registers (probed: tools/probes/permlane_probe.hip), so r[0] + r[1] of a swap of
+// a value with itself is the pairwise row sum -- 2 swaps + 1 add per level, no LDS round trip (ds_bpermute).
+__device__ __forceinline__ double rows_allreduce(double k)
+{
+    {
+        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(k), (unsigned)__double2loint(k), false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(k), (unsigned)__double2hiint(k), false, false);
+        k = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+    }
+    {
+        const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(k), (unsigned)__double2loint(k), false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(k), (unsigned)__double2hiint(k), false, false);
+        k = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+    }
+    return k;
+}
 __device__ __forceinline__ void wave_sum4(double (&p)[4], int lane)
 {
     const bool o1 = lane & 1, o2 = lane & 2;
@@ -110,8 +127,7 @@ __device__ __forceinline__ void wave_sum4(double (&p)[4], int lane)
     k += dpp_quad<0x4E>(s);                                        // quad_perm:[2,3,0,1]
     k += dpp_zero<0x114>(k);                                       // across the quads of a row
     k += dpp_zero<0x118>(k);
-    k += __shfl_xor(k, 16, kWave);                                 // across the four rows
-    k += __shfl_xor(k, 32, kWave);
+    k = rows_allreduce(k);                                         // across the four rows
     // lanes 12..15 hold the totals of value 2*(lane&1) + ((lane>>1)&1)
     p[0] = bcast(k, 12); p[2] = bcast(k, 13); p[1] = bcast(k, 14); p[3] = bcast(k, 15);
 }
