@@ -52,38 +52,53 @@ __device__ __forceinline__ double dpp_move(double v, double ident)
     int hi = __builtin_amdgcn_update_dpp(__double2hiint(ident), __double2hiint(v), CTRL, ROWM, BANKM, false);
     return __hiloint2double(hi, lo);
 }
-// DPP controls (GFX9 family): row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143
-// Source lanes that do not exist read as 0 (bound_ctrl) -- the identity of a sum -- so no lane needs a prepared
-// `old` value and no row/bank masks: 6 doubling steps of 2 DPP moves + 1 add.  Lanes other than 63 end up with
-// partial sums nobody reads.
+// DPP controls (GFX9 family): quad_perm:[1,0,3,2] = 0xB1, quad_perm:[2,3,0,1] = 0x4E, row_half_mirror = 0x141,
+// row_mirror = 0x140, row_shr:n = 0x110+n.
 template <int CTRL>
-__device__ __forceinline__ double dpp_zero(double v)
+__device__ __forceinline__ double dpp_zero(double v)       // source lanes that do not exist read as 0
 {
     int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
     int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
+// The two row-swap steps of gfx950 (v_permlane16_swap / v_permlane32_swap exchange whole 16-lane rows between two
+// registers; probed: tools/probes/permlane_probe.hip): a swap of a value with itself returns (rows 0,0,2,2) and
+// (rows 1,1,3,3), resp. (lanes 0-31 twice) and (lanes 32-63 twice).
+#define AMX_ROW_SWAP(BUILTIN, k, A, B)                                                                             \
+    do {                                                                                                           \
+        const auto lo_ = BUILTIN((unsigned)__double2loint(k), (unsigned)__double2loint(k), false, false);          \
+        const auto hi_ = BUILTIN((unsigned)__double2hiint(k), (unsigned)__double2hiint(k), false, false);          \
+        A = __hiloint2double((int)hi_[0], (int)lo_[0]); B = __hiloint2double((int)hi_[1], (int)lo_[1]);            \
+    } while (0)
+// Sum of the four 16-lane rows, lane by lane, left in every row (no LDS round trip as with ds_bpermute).
+__device__ __forceinline__ double rows_allreduce(double k)
+{
+    double a, b;
+    AMX_ROW_SWAP(__builtin_amdgcn_permlane16_swap, k, a, b); k = a + b;
+    AMX_ROW_SWAP(__builtin_amdgcn_permlane32_swap, k, a, b); k = a + b;
+    return k;
+}
+// Butterfly all-reductions: every lane ends with the result (xor 1, xor 2 by quad_perm; the mirrors act as xor 4 and
+// xor 8 on values that are already equal within groups of 4 / 8 lanes; then the two row swaps).  All source lanes
+// exist, so no identity has to be prepared: 6 levels of 2 moves + 1 op, no readlane.
 __device__ __forceinline__ double wave_sum(double v)
 {
-    double t = v + dpp_zero<0x111>(v);      // lanes i-1..i
-    t += dpp_zero<0x112>(t);                // i-3..i
-    t += dpp_zero<0x114>(t);                // i-7..i
-    t += dpp_zero<0x118>(t);                // lane 15 of each row: the row's sum
-    t += dpp_zero<0x142>(t);                // lanes 31, 63: two rows
-    t += dpp_zero<0x143>(t);                // lane 63: all four rows
-    return bcast(t, 63);
+    double t = v + dpp_zero<0xB1>(v);
+    t += dpp_zero<0x4E>(t);
+    t += dpp_zero<0x141>(t);
+    t += dpp_zero<0x140>(t);
+    return rows_allreduce(t);
 }
 __device__ __forceinline__ double wave_max(double v)
 {
-    const double ninf = -__builtin_huge_val();
-    double t = fmax(v, dpp_move<0x111, 0xf, 0xf>(v, ninf));
-    t = fmax(t, dpp_move<0x112, 0xf, 0xf>(v, ninf));
-    t = fmax(t, dpp_move<0x113, 0xf, 0xf>(v, ninf));
-    t = fmax(t, dpp_move<0x114, 0xf, 0xe>(t, ninf));
-    t = fmax(t, dpp_move<0x118, 0xf, 0xc>(t, ninf));
-    t = fmax(t, dpp_move<0x142, 0xa, 0xf>(t, ninf));
-    t = fmax(t, dpp_move<0x143, 0xc, 0xf>(t, ninf));
-    return bcast(t, 63);
+    double t = fmax(v, dpp_zero<0xB1>(v));
+    t = fmax(t, dpp_zero<0x4E>(t));
+    t = fmax(t, dpp_zero<0x141>(t));
+    t = fmax(t, dpp_zero<0x140>(t));
+    double a, b;
+    AMX_ROW_SWAP(__builtin_amdgcn_permlane16_swap, t, a, b); t = fmax(a, b);
+    AMX_ROW_SWAP(__builtin_amdgcn_permlane32_swap, t, a, b); t = fmax(a, b);
+    return t;
 }
 __device__ __forceinline__ double wave_min(double v) { return -wave_max(-v); }
 
@@ -97,23 +112,6 @@ __device__ __forceinline__ double dpp_quad(double v)
     int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
     int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
-}
-// Sum of the four 16-lane rows, lane by lane, left in every row: gfx950's v_permlane16_swap / v_permlane32_swap
-// exchange whole rows between two registers (probed: tools/probes/permlane_probe.hip), so r[0] + r[1] of a swap of
-// a value with itself is the pairwise row sum -- 2 swaps + 1 add per level, no LDS round trip (ds_bpermute).
-__device__ __forceinline__ double rows_allreduce(double k)
-{
-    {
-        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(k), (unsigned)__double2loint(k), false, false);
-        const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(k), (unsigned)__double2hiint(k), false, false);
-        k = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
-    }
-    {
-        const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(k), (unsigned)__double2loint(k), false, false);
-        const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(k), (unsigned)__double2hiint(k), false, false);
-        k = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
-    }
-    return k;
 }
 __device__ __forceinline__ void wave_sum4(double (&p)[4], int lane)
 {
@@ -519,19 +517,20 @@ struct NNSolver {
             // ---- Lawson-Hanson inner loop: restore feasibility of the passive solution
             for (bool feasible = false; !feasible && status == kSolved;) {
                 if (++iters > itmax) { status = kIterCap; break; }
-                double rhs = d - lam1 * e, z = 0.0;
+                double rhs = d - lam1 * e;
                 {
-                    // R z = rhs: column j of R is read one step ahead of its use
+                    // R z = rhs: column j of R is read one step ahead of its use.  Lane j's rhs is final once step j has
+                    // run (only lanes < j are updated afterwards), so z = rhs * rinv is formed once, after the loop.
                     const int li = (lane < MAXP ? lane : MAXP - 1) * LDR;
                     double col = (np > 0) ? Rl[li + np - 1] : 0.0;
                     for (int j = np - 1; j >= 0; j--) {
                         const double nxt = (j > 0) ? Rl[li + j - 1] : 0.0;
                         const double zj = bcast(rhs * rinv, j);
-                        if (lane == j) z = zj;
                         if (lane < j) rhs -= col * zj;
                         col = nxt;
                     }
                 }
+                const double z = (lane < np) ? rhs * rinv : 0.0;
                 const bool act = lane < np;
                 const bool neg = act && !(z > 0.0);
                 // The heavy state (Q, R, d, ...) changes only inside the removal loop below, which makes zero trips for a
