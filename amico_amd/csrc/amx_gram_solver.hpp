@@ -48,21 +48,21 @@ struct GramSolver {
     __device__ __forceinline__ double solve_passive(int lane)
     {
         const int ls = row(lane);
-        double f = (lane < np) ? cs : 0.0, wv = 0.0, z = 0.0;
+        // lane k's right-hand side is final once step k has run (later steps only touch lanes beyond k), so the
+        // division by the diagonal happens once per sweep, after the loop, instead of a select in every step
+        double f = (lane < np) ? cs : 0.0;
         for (int k = 0; k < np; k++) {
             const double lk = Ll[ls + k];
             const double wk = bcast(f * linv, k);
-            if (lane == k) wv = wk;
             if (lane > k) f -= lk * wk;
         }
-        double b = wv;
+        double b = f * linv;
         for (int k = np - 1; k >= 0; k--) {
             const double lk = Ll[tri(k, lane < k ? lane : k)];
             const double zk = bcast(b * linv, k);
-            if (lane == k) z = zk;
             if (lane < k) b -= lk * zk;
         }
-        return z;
+        return (lane < np) ? b * linv : 0.0;
     }
 
     __device__ __forceinline__ void remove_slot(int k, int lane, unsigned &fl)
@@ -215,14 +215,14 @@ struct GramSolver {
                 const int ls = row(lane);
                 const double h = (lane < np) ? sc * sct * G[(size_t)idx * ldG + t] : 0.0;
                 const double htt = sct * sct * G[(size_t)t * ldG + t] + lam2;
-                double hh = h, lrow = 0.0;
+                double hh = h;
                 for (int k = 0; k < np; k++) {
                     const double lk_ = Ll[ls + k];
                     const double lk = bcast(hh * linv, k);
-                    if (lane == k) lrow = lk;
                     if (lane > k) hh -= lk_ * lk;
                 }
-                const double d2 = htt - wave_sum((lane < np) ? lrow * lrow : 0.0);
+                const double lrow = (lane < np) ? hh * linv : 0.0;     // lane k's hh is final after step k
+                const double d2 = htt - wave_sum(lrow * lrow);
                 if (!uni(d2 > 1e-13 * htt)) {                 // cannot happen with lambda2 > 0 (d2 >= lambda2)
                     if (lane == tl) fl |= 0x10000u << tq;
                 } else {
