@@ -289,6 +289,21 @@ def _capi_lib():
     return _capi.lib()
 
 
+def pmc_valu(stage, n, kernel_ms):
+    """compute-side reading of the stage kernel: VALU wave-instructions per voxel (committed rocprofv3 PMC pass) and the
+    share of the SIMDs' issue cycles they fill at the live kernel time (1024 SIMDs, 2.4 GHz, 4 cycles per wave64 VALU op)"""
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')
+    try:
+        with open(p) as f:
+            t = json.load(f)
+        insts = float(t['stage_valu_insts_per_launch'][str(stage)]) / t['voxels_per_launch']
+    except (OSError, KeyError, ValueError):
+        return None
+    busy = insts * n * 4.0 / 1024.0 / (kernel_ms * 1e-3 * 2.4e9)
+    return {'bound': 'fp64 VALU issue', 'valu_wave_insts_per_voxel': insts, 'issue_cycles_filled': busy,
+            'source': 'profiles/pmc_traffic.json (SQ_INSTS_VALU) x live kernel time'}
+
+
 def pmc_traffic(stage, n):
     """HBM bytes per launch of the stage kernel from the committed rocprofv3 PMC passes (profiles/), scaled to
     this run's voxels per launch; None when the profile summary is not there."""
@@ -411,7 +426,8 @@ def main():
                                            if traffic is not None else None,
                          'kernel': 'k_noddi<stage %d>' % stage, 'kernel_ms': dom_ms,
                          'stage_ms': [float(v) for v in kms[1:4]], 'all_kernels_ms': float(kms[0]),
-                         'note': 'path is fp64-VALU/LDS bound, not HBM bound (DESIGN.md section 5)'},
+                         'note': 'path is fp64-VALU issue bound, not HBM bound (DESIGN.md section 5): see compute_side'},
+            'compute_side': pmc_valu(stage, n, dom_ms),
             'solver_stats': stats,
         }
         if world == 1:
