@@ -143,8 +143,12 @@ __device__ __forceinline__ double inv_sqrt(double a)
 __device__ __forceinline__ bool uni(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
 
 // value of lane+1 (used to compact slot space after an atom left)
-__device__ __forceinline__ double from_next_lane(double v) { return __shfl_down(v, 1, kWave); }
-__device__ __forceinline__ int from_next_lane(int v) { return __shfl_down(v, 1, kWave); }
+// (DPP wave_shl:1 -- a GFX9-family control -- instead of __shfl_down's ds_bpermute round trip; lane 63 reads 0)
+__device__ __forceinline__ int from_next_lane(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true); }
+__device__ __forceinline__ double from_next_lane(double v)
+{
+    return __hiloint2double(from_next_lane(__double2hiint(v)), from_next_lane(__double2loint(v)));
+}
 
 // ------------------------------------------------------------------ the solver
 // NR   rows per lane   (nS      <= 64*NR)
