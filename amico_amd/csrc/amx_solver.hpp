@@ -118,11 +118,11 @@ __device__ __forceinline__ void wave_sum4(double (&p)[4], int lane)
     const bool o1 = lane & 1, o2 = lane & 2;
     double k0 = o1 ? p[2] : p[0], k1 = o1 ? p[3] : p[1];          // kept pair
     const double s0 = o1 ? p[0] : p[2], s1 = o1 ? p[1] : p[3];    // pair handed to lane ^ 1
-    k0 += dpp_quad<0xB1>(s0);                                      // quad_perm:[1,0,3,2]
-    k1 += dpp_quad<0xB1>(s1);
+    k0 += dpp_zero<0xB1>(s0);                                      // quad_perm:[1,0,3,2]
+    k1 += dpp_zero<0xB1>(s1);
     double k = o2 ? k1 : k0;
     const double s = o2 ? k0 : k1;                                 // handed to lane ^ 2
-    k += dpp_quad<0x4E>(s);                                        // quad_perm:[2,3,0,1]
+    k += dpp_zero<0x4E>(s);                                        // quad_perm:[2,3,0,1]
     k += dpp_zero<0x114>(k);                                       // across the quads of a row
     k += dpp_zero<0x118>(k);
     k = rows_allreduce(k);                                         // across the four rows
@@ -452,8 +452,10 @@ struct NNSolver {
                                     if (RIDGE) p[u] += Ql[ls + kb + u] * va;
                                 }
                             }
+                            // (both paths end in readlanes: the projections stay scalar registers, no vector copies
+                            // where the paths merge)
                             if (kb + 1 < np) wave_sum4(p, lane);        // >= 2 live projections: batched
-                            else p[0] = wave_sum(p[0]);
+                            else { p[0] = bcast(wave_sum(p[0]), 0); p[1] = 0.0; p[2] = 0.0; p[3] = 0.0; }
 #pragma unroll
                             for (int u = 0; u < 4; u++) {
                                 if (kb + u < MAXP && kb + u < np) {
