@@ -10,7 +10,7 @@ static int go(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
 #endif
     constexpr int NQ = 3, MP = AMX_S3_MP, MB = 32;
 #ifndef AMX_S3_NW
-#define AMX_S3_NW 12
+#define AMX_S3_NW 16
 #endif
     constexpr int NW = AMX_S3_NW; // wavefronts per workgroup: as many as the register budget of this stage allows
     return launch_pair<NW>(ctx, a, pl, s, k_noddi<3, NR, NQ, MP, NW, false>, k_noddi<3, NR, NQ, MB, 1, true>,

@@ -213,6 +213,13 @@ struct NNSolver {
                 }
             }
         }
+        // the rotations have moved the dropped direction into row np-1: clear it (rows beyond np stay zero)
+#pragma unroll
+        for (int m = 0; m < MAXP; m++) {       // (selects, not an indexed store: Q must stay in registers)
+            const bool last = (m == np - 1);
+#pragma unroll
+            for (int rr_ = 0; rr_ < NR; rr_++) Q[m][rr_] = last ? 0.0 : Q[m][rr_];
+        }
         // columns k+1.. move one to the left (rows stay where they are)
         for (int i = 0; i < np - 1; i++) {
             const double t = Rl[i * LDR + (lane < MAXP ? lane + 1 : MAXP)];
@@ -293,6 +300,13 @@ struct NNSolver {
 #pragma unroll
         for (int q = 0; q < NQ; q++) fl |= (unsigned)((allowed[q] >> lane) & 1ull) << q;
         np = 0; d = 0.0; e = 0.0; rinv = 0.0; x = 0.0; xprev = 0.0; sc = 1.0; idx = -1; iters = 0;
+        // invariant: rows of Q (and columns of the ridge block Ql) beyond the passive set are zero, so the Gram-Schmidt
+        // blocks need no per-row conditions
+#pragma unroll
+        for (int m = 0; m < MAXP; m++) {
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++) Q[m][rr] = 0.0;
+        }
         if (RIDGE && lane < MAXP) {
             for (int m = 0; m < LDR; m++) Ql[lane * LDR + m] = 0.0;
         }
@@ -444,9 +458,9 @@ struct NNSolver {
                         if (kb < np) {
                             double p[4];
 #pragma unroll
-                            for (int u = 0; u < 4; u++) {
+                            for (int u = 0; u < 4; u++) {      // rows of Q beyond np are zero: no per-row conditions
                                 p[u] = 0.0;
-                                if (kb + u < MAXP && kb + u < np) {
+                                if (kb + u < MAXP) {
 #pragma unroll
                                     for (int rr = 0; rr < NR; rr++) p[u] += Q[kb + u][rr] * v[rr];
                                     if (RIDGE) p[u] += Ql[ls + kb + u] * va;
@@ -458,7 +472,7 @@ struct NNSolver {
                             else { p[0] = bcast(wave_sum(p[0]), 0); p[1] = 0.0; p[2] = 0.0; p[3] = 0.0; }
 #pragma unroll
                             for (int u = 0; u < 4; u++) {
-                                if (kb + u < MAXP && kb + u < np) {
+                                if (kb + u < MAXP) {
 #pragma unroll
                                     for (int rr = 0; rr < NR; rr++) v[rr] -= p[u] * Q[kb + u][rr];
                                     if (RIDGE) va -= p[u] * Ql[ls + kb + u];
