@@ -40,7 +40,7 @@ def summarize(files, pats):
 files = sum([glob.glob('%s/pmc%d/*/*_counter_collection.csv' % (O, i)) for i in (1, 2, 3, 4)], [])
 if len(sys.argv) > 2:
     files += glob.glob(sys.argv[2] + '/*/*_counter_collection.csv')
-a = summarize(files, ['k_noddi<1, 2, 3, 8, 12, false', 'k_noddi<4, 2, 3, 20, 16, false', 'k_noddi<3, 2, 3, 8, 12, false'])
+a = summarize(files, ['k_noddi<1, 2, 3, 8, 16, false', 'k_noddi<4, 2, 3, 20, 16, false', 'k_noddi<3, 2, 3, 8, 16, false'])
 out.append('# --model dti (FETCH_SIZE, WRITE_SIZE passes)')
 summarize(sum([glob.glob('%s/pmc%d/*/*_counter_collection.csv' % (O, i)) for i in (5, 6)], []), ['k_dti_dirs'])
 out.append('# --model prep (FETCH_SIZE, WRITE_SIZE passes; Fortran-order and C-order launches averaged together)')
