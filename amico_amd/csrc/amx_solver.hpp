@@ -539,15 +539,13 @@ struct NNSolver {
                 if (++iters > itmax) { status = kIterCap; break; }
                 double rhs = d - lam1 * e;
                 {
-                    // R z = rhs: column j of R is read one step ahead of its use.  Lane j's rhs is final once step j has
+                    // R z = rhs.  Lane j's rhs is final once step j has
                     // run (only lanes < j are updated afterwards), so z = rhs * rinv is formed once, after the loop.
                     const int li = (lane < MAXP ? lane : MAXP - 1) * LDR;
-                    double col = (np > 0) ? Rl[li + np - 1] : 0.0;
                     for (int j = np - 1; j >= 0; j--) {
-                        const double nxt = (j > 0) ? Rl[li + j - 1] : 0.0;
+                        const double col = Rl[li + j];
                         const double zj = bcast(rhs * rinv, j);
                         if (lane < j) rhs -= col * zj;
-                        col = nxt;
                     }
                 }
                 const double z = (lane < np) ? rhs * rinv : 0.0;
