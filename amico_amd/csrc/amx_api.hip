@@ -49,14 +49,16 @@ int enqueue_bucketing(amx_ctx *ctx, const amx_lut *lut, const double *d_dirs, in
 {
     HIPCHK(ctx, hipMemsetAsync(pl.counts, 0, (size_t)(lut->ndirs + 1) * sizeof(int), s));
     HIPCHK(ctx, hipMemsetAsync(ctx->misc.p, 0, 64 * sizeof(int), s));
-    const int nb = (int)((n + 255) / 256);
-    hipLaunchKernelGGL(k_dir_to_lut, dim3(nb), dim3(256), 0, s, d_dirs, (int)n, lut->htable, lut->ndirs,
-                       pl.lutidx, pl.counts, ctx->status_d);
+    const int nb = (int)((n + kPrepSpan - 1) / kPrepSpan);
+    const int use_lds = lut->ndirs <= 8192 ? 1 : 0;          // LDS histograms: 2 * ndirs ints
+    hipLaunchKernelGGL(k_dir_to_lut, dim3(nb), dim3(1024), use_lds ? (size_t)lut->ndirs * sizeof(int) : 0, s, d_dirs,
+                       (int)n, lut->htable, lut->ndirs, pl.lutidx, pl.counts, ctx->status_d, use_lds);
     AMX_TRACE(ctx, s, "k_dir_to_lut");
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, pl.counts, lut->ndirs, kChunk, pl.dir_start,
                        pl.cursor, pl.chunks, pl.n_chunks);
     AMX_TRACE(ctx, s, "k_plan");
-    hipLaunchKernelGGL(k_bucket, dim3(nb), dim3(256), 0, s, pl.lutidx, (int)n, pl.dir_start, pl.cursor, pl.perm);
+    hipLaunchKernelGGL(k_bucket, dim3(nb), dim3(1024), use_lds ? (size_t)2 * lut->ndirs * sizeof(int) : 0, s, pl.lutidx,
+                       (int)n, lut->ndirs, pl.dir_start, pl.cursor, pl.perm, use_lds);
     AMX_TRACE(ctx, s, "k_bucket");
     HIPCHK(ctx, hipGetLastError());
     return AMX_OK;
@@ -557,8 +559,9 @@ int amx_dir_to_lut_idx(amx_ctx *ctx, const amx_lut *lut, const double *dirs, int
     int rc;
     AMX_H2D(ctx->hdirs, dirs, (size_t)n * 3 * sizeof(double))
     if ((rc = ensure(ctx, ctx->lutidx, (size_t)n * sizeof(int)))) return rc;
-    hipLaunchKernelGGL(k_dir_to_lut, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (const double *)ctx->hdirs.p,
-                       (int)n, lut->htable, lut->ndirs, (int *)ctx->lutidx.p, (int *)nullptr, ctx->status_d);
+    hipLaunchKernelGGL(k_dir_to_lut, dim3((unsigned)((n + kPrepSpan - 1) / kPrepSpan)), dim3(1024), 0, nullptr,
+                       (const double *)ctx->hdirs.p, (int)n, lut->htable, lut->ndirs, (int *)ctx->lutidx.p, (int *)nullptr,
+                       ctx->status_d, 0);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(out_idx, ctx->lutidx.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, nullptr));
     return amx_sync_status(ctx, nullptr);
