@@ -52,7 +52,7 @@ int enqueue_bucketing(amx_ctx *ctx, const amx_lut *lut, const double *d_dirs, in
     const int nb = (int)((n + kPrepSpan - 1) / kPrepSpan);
     const int use_lds = lut->ndirs <= 8192 ? 1 : 0;          // LDS histograms: 2 * ndirs ints
     hipLaunchKernelGGL(k_dir_to_lut, dim3(nb), dim3(1024), use_lds ? (size_t)lut->ndirs * sizeof(int) : 0, s, d_dirs,
-                       (int)n, lut->htable, lut->ndirs, pl.lutidx, pl.counts, ctx->status_d, use_lds);
+                       (int)n, lut->htable, lut->ndirs, pl.lutidx, pl.counts, ctx->status_d, use_lds, (int)ctx->vox_base);
     AMX_TRACE(ctx, s, "k_dir_to_lut");
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, pl.counts, lut->ndirs, kChunk, pl.dir_start,
                        pl.cursor, pl.chunks, pl.n_chunks);
@@ -65,6 +65,15 @@ int enqueue_bucketing(amx_ctx *ctx, const amx_lut *lut, const double *d_dirs, in
 }
 
 // wavefront primitives exercised on the device (tests/test_gpu_parity.py::test_wave_primitives)
+// per-call counters (misc, cleared by the next call) -> status words that accumulate until amx_sync_status
+__global__ void k_fold_counters(const int *misc, int *status)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        status[ST_RERUN] += misc[4] + misc[5] + misc[6];
+        status[ST_OVERFLOW] += misc[12];
+    }
+}
+
 __global__ void k_selftest(double *out)
 {
     const int lane = threadIdx.x & 63;
@@ -129,6 +138,7 @@ void amx_ctx_destroy(amx_ctx *ctx)
     if (ctx->status_d) hipFree(ctx->status_d);
     if (ctx->status_h) hipHostFree(ctx->status_h);
     for (int k = 0; k < kEv; k++) (void)hipEventDestroy(ctx->ev[k]);
+    if (ctx->hs) { (void)hipStreamDestroy(ctx->hs); (void)hipEventDestroy(ctx->hev[0]); (void)hipEventDestroy(ctx->hev[1]); }
     delete ctx;
 }
 
@@ -282,18 +292,13 @@ int amx_sync_status(amx_ctx *ctx, void *hip_stream)
     hipStream_t s = (hipStream_t)hip_stream;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemcpyAsync(ctx->status_h, ctx->status_d, ST_WORDS * sizeof(int), hipMemcpyDeviceToHost, s));
-    if (ctx->misc.p)
-        HIPCHK(ctx, hipMemcpyAsync(ctx->status_h + ST_WORDS, ctx->misc.p, 16 * sizeof(int), hipMemcpyDeviceToHost, s));
-    else
-        memset(ctx->status_h + ST_WORDS, 0, 16 * sizeof(int));
     int rc = reset_status(ctx, s);
     if (rc) return rc;
     HIPCHK(ctx, hipStreamSynchronize(s));
     const int *st = ctx->status_h;
-    const int *ov = st + ST_WORDS + 4;
-    ctx->stats[0] = (int64_t)ov[0] + ov[1] + ov[2];
+    ctx->stats[0] = st[ST_RERUN];
     ctx->stats[1] = st[ST_ITCAP];
-    ctx->stats[2] = ov[8];
+    ctx->stats[2] = st[ST_OVERFLOW];
     ctx->stats[3] = ((int64_t)st[ST_GUARD] << 32) | (unsigned)st[ST_GUARDVOX];
     if (amx_debug()) fprintf(stderr, "[amx] dual-vector evaluations per stage: exact %d %d %d  gram %d %d %d  inner iterations %d %d %d\n", st[ST_EXACT], st[ST_EXACT + 1], st[ST_EXACT + 2], st[ST_GRAM], st[ST_GRAM + 1], st[ST_GRAM + 2], st[ST_ITERS], st[ST_ITERS + 1], st[ST_ITERS + 2]);
     if (st[ST_ERRVOX] != 0x7f7f7f7f) {
@@ -302,9 +307,9 @@ int amx_sync_status(amx_ctx *ctx, void *hip_stream)
         ctx->err = b;
         return AMX_E_DIR_OOB;
     }
-    if (ov[8] > 0) {
+    if (st[ST_OVERFLOW] > 0) {
         char b[256];
-        snprintf(b, sizeof b, "%d voxel(s) exceeded the largest supported active set", ov[8]);
+        snprintf(b, sizeof b, "%d voxel(s) exceeded the largest supported active set", st[ST_OVERFLOW]);
         ctx->err = b;
         return AMX_E_OVERFLOW;
     }
@@ -385,6 +390,7 @@ int amx_noddi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
     HIPCHK(ctx, hipMemsetAsync(d_estimates, 0, (size_t)n_vox * a.n_maps * sizeof(double), s));
     if (!(rc = amx_launch_noddi_s1(ctx, a, pl, s)) && !(rc = amx_launch_noddi_s2(ctx, a, pl, s)))
         rc = amx_launch_noddi_s3(ctx, a, pl, s);
+    hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, s, (const int *)ctx->misc.p, ctx->status_d);
     rec(ctx, 1, s);
     return rc;
 }
@@ -420,6 +426,7 @@ int amx_freewater_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y
     a.nrmse = (flags & AMX_F_NRMSE) ? d_nrmse : nullptr; a.ycorr = (flags & AMX_F_CORRECTED) ? d_ycorr : nullptr;
     HIPCHK(ctx, hipMemsetAsync(d_estimates, 0, (size_t)n_vox * a.n_maps * sizeof(double), s));
     rc = amx_launch_fw(ctx, a, pl, s);
+    hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, s, (const int *)ctx->misc.p, ctx->status_d);
     rec(ctx, 1, s);
     return rc;
 }
@@ -454,6 +461,7 @@ int amx_sandi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, in
     a.n_rs = lut->n_rs; a.n_in = lut->n_in; a.n_iso = lut->n_isos;
     a.est = d_estimates; a.rmse = (flags & AMX_F_RMSE) ? d_rmse : nullptr; a.nrmse = (flags & AMX_F_NRMSE) ? d_nrmse : nullptr;
     rc = amx_launch_sandi(ctx, a, pl, s);
+    hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, s, (const int *)ctx->misc.p, ctx->status_d);
     rec(ctx, 1, s);
     return rc;
 }
@@ -463,6 +471,64 @@ int amx_sandi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, in
     if ((rc = ensure(ctx, buf, bytes))) return rc;                                   \
     HIPCHK(ctx, hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, nullptr));
 #define AMX_D2H(dst, buf, bytes) HIPCHK(ctx, hipMemcpyAsync(dst, buf.p, bytes, hipMemcpyDeviceToHost, nullptr));
+
+// Large host batches: the signals travel in batches of kHostBatch voxels; while the GPU fits batch c (on a
+// non-blocking stream of the context) the blocking host-to-device copy of batch c+1 is already running, so the PCIe
+// time hides behind the solver instead of preceding it.  Two signal buffers; results leave in one copy at the end.
+constexpr int64_t kHostBatch = 262144;
+
+static int noddi_fit_host_pipelined(amx_ctx *ctx, const amx_lut *lut, const double *y, const double *dirs, int64_t n_vox,
+                                    double lambda1, double lambda2, unsigned flags, double *out_estimates,
+                                    double *out_rmse, double *out_nrmse, double *out_mod)
+{
+    int rc;
+    const int n_maps = 3 + (lut->is_exvivo ? 1 : 0), nS = lut->nS;
+    if (!ctx->hs) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->hs, hipStreamNonBlocking));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->hev[0], hipEventDisableTiming));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->hev[1], hipEventDisableTiming));
+    }
+    if ((rc = ensure(ctx, ctx->hy, (size_t)2 * kHostBatch * nS * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->hdirs, (size_t)2 * kHostBatch * 3 * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->hest, (size_t)n_vox * n_maps * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->hrmse, (size_t)n_vox * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->hnrmse, (size_t)n_vox * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->hextra, (size_t)n_vox * 2 * sizeof(double)))) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(nullptr));                      // earlier default-stream work on these buffers
+    const bool was_profiling = ctx->profiling;
+    ctx->profiling = false;
+    int64_t off = 0;
+    for (int c = 0; off < n_vox; c++) {
+        // the last batch absorbs a short remainder
+        const int64_t cnt = (n_vox - off < kHostBatch + kHostBatch / 2) ? n_vox - off : kHostBatch;
+        const int b = c & 1;
+        if (c >= 2) HIPCHK(ctx, hipEventSynchronize(ctx->hev[b]));   // batch c-2 has released this buffer
+        double *yb = (double *)ctx->hy.p + (size_t)b * kHostBatch * nS, *db = (double *)ctx->hdirs.p + (size_t)b * kHostBatch * 3;
+        // (a remainder-absorbing last batch may exceed kHostBatch: it then uses both halves, which are free by then)
+        if (cnt > kHostBatch) {
+            HIPCHK(ctx, hipStreamSynchronize(ctx->hs));
+            yb = (double *)ctx->hy.p; db = (double *)ctx->hdirs.p;
+        }
+        HIPCHK(ctx, hipMemcpy(yb, y + (size_t)off * nS, (size_t)cnt * nS * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(db, dirs + (size_t)off * 3, (size_t)cnt * 3 * sizeof(double), hipMemcpyHostToDevice));
+        ctx->vox_base = off;
+        rc = amx_noddi_fit_device(ctx, lut, yb, db, cnt, lambda1, lambda2, flags, (double *)ctx->hest.p + (size_t)off * n_maps,
+                                  (double *)ctx->hrmse.p + off, (double *)ctx->hnrmse.p + off,
+                                  (double *)ctx->hextra.p + (size_t)off * 2, ctx->hs);
+        ctx->vox_base = 0;
+        if (rc) { ctx->profiling = was_profiling; return rc; }
+        HIPCHK(ctx, hipEventRecord(ctx->hev[b], ctx->hs));
+        off += cnt;
+    }
+    ctx->profiling = was_profiling;
+    rc = amx_sync_status(ctx, ctx->hs);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpy(out_estimates, ctx->hest.p, (size_t)n_vox * n_maps * sizeof(double), hipMemcpyDeviceToHost));
+    if (flags & AMX_F_RMSE) HIPCHK(ctx, hipMemcpy(out_rmse, ctx->hrmse.p, (size_t)n_vox * sizeof(double), hipMemcpyDeviceToHost));
+    if (flags & AMX_F_NRMSE) HIPCHK(ctx, hipMemcpy(out_nrmse, ctx->hnrmse.p, (size_t)n_vox * sizeof(double), hipMemcpyDeviceToHost));
+    if (flags & AMX_F_MODULATED) HIPCHK(ctx, hipMemcpy(out_mod, ctx->hextra.p, (size_t)n_vox * 2 * sizeof(double), hipMemcpyDeviceToHost));
+    return AMX_OK;
+}
 
 int amx_noddi_fit(amx_ctx *ctx, const amx_lut *lut, const double *y, const double *dirs,
                   int64_t n_vox, double lambda1, double lambda2, unsigned flags,
@@ -477,6 +543,9 @@ int amx_noddi_fit(amx_ctx *ctx, const amx_lut *lut, const double *y, const doubl
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc;
     const int n_maps = 3 + (lut->is_exvivo ? 1 : 0);
+    if (n_vox >= 2 * kHostBatch && !getenv("AMX_HOST_ONE_SHOT"))
+        return noddi_fit_host_pipelined(ctx, lut, y, dirs, n_vox, lambda1, lambda2, flags, out_estimates, out_rmse,
+                                        out_nrmse, out_mod);
     AMX_H2D(ctx->hy, y, (size_t)n_vox * lut->nS * sizeof(double))
     AMX_H2D(ctx->hdirs, dirs, (size_t)n_vox * 3 * sizeof(double))
     if ((rc = ensure(ctx, ctx->hest, (size_t)n_vox * n_maps * sizeof(double)))) return rc;
@@ -561,7 +630,7 @@ int amx_dir_to_lut_idx(amx_ctx *ctx, const amx_lut *lut, const double *dirs, int
     if ((rc = ensure(ctx, ctx->lutidx, (size_t)n * sizeof(int)))) return rc;
     hipLaunchKernelGGL(k_dir_to_lut, dim3((unsigned)((n + kPrepSpan - 1) / kPrepSpan)), dim3(1024), 0, nullptr,
                        (const double *)ctx->hdirs.p, (int)n, lut->htable, lut->ndirs, (int *)ctx->lutidx.p, (int *)nullptr,
-                       ctx->status_d, 0);
+                       ctx->status_d, 0, 0);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(out_idx, ctx->lutidx.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, nullptr));
     return amx_sync_status(ctx, nullptr);

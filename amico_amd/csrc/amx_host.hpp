@@ -32,6 +32,9 @@ struct amx_ctx {
     hipEvent_t ev[kEv];
     bool ev_valid[kEv];
     int64_t stats[4] = {0, 0, 0, 0};
+    int64_t vox_base = 0;          // index of the first voxel of the batch being enqueued (chunked host entry points)
+    hipStream_t hs = nullptr;      // non-blocking compute stream of the chunked host entry points
+    hipEvent_t hev[2] = {nullptr, nullptr};
 };
 
 struct amx_lut {

@@ -32,7 +32,7 @@ constexpr int kPrepSpan = 8192;
 
 __global__ __launch_bounds__(1024) void k_dir_to_lut(const double *__restrict__ dirs, int n, const short *__restrict__ ht,
                                                      int ndirs, int *__restrict__ lutidx, int *__restrict__ counts,
-                                                     int *__restrict__ status, int use_lds)
+                                                     int *__restrict__ status, int use_lds, int vbase)
 {
     extern __shared__ int hist[];
     if (use_lds) {
@@ -45,8 +45,8 @@ __global__ __launch_bounds__(1024) void k_dir_to_lut(const double *__restrict__ 
         int idx = dir_to_lut_idx_dev(dirs[3 * (size_t)v], dirs[3 * (size_t)v + 1], dirs[3 * (size_t)v + 2], ht, ii1, ii2);
         if (idx < 0 || idx >= ndirs) {
             idx = -1;
-            const int old = atomicMin(&status[ST_ERRVOX], v);
-            if (old > v) { status[ST_II1] = ii1; status[ST_II2] = ii2; }
+            const int old = atomicMin(&status[ST_ERRVOX], v + vbase);     // vbase: offset of this batch in the caller's arrays
+            if (old > v + vbase) { status[ST_II1] = ii1; status[ST_II2] = ii2; }
         } else if (counts) {
             atomicAdd(use_lds ? &hist[idx] : &counts[idx], 1);
         }

@@ -69,7 +69,8 @@ void amx_lut_destroy(amx_lut *lut);
 int amx_dir_to_lut_idx(amx_ctx *ctx, const amx_lut *lut, const double *dirs, int64_t n,
                        int32_t *out_idx);
 
-/* ---- model.fit hot loops, HOST buffers in / out (H2D + kernels + D2H, blocking).
+/* ---- model.fit hot loops, HOST buffers in / out (H2D + kernels + D2H, blocking; amx_noddi_fit overlaps the
+ * copies of large inputs with the solver, in batches).
  * y f64[n_vox][nS] (evaluation.y, core.py:451-452), dirs f64[n_vox][3] (evaluation.DIRs).  */
 
 /* NODDI._fit models.pyx:816-991: estimates f64[n_vox][3 (+1 ex-vivo)] = NDI, ODI, FWF(, dot) */

@@ -329,3 +329,30 @@ def test_device_resident_volume_pipeline(htable500):
     ae.fit()
     assert np.array_equal(maps.cpu().numpy(), ae.RESULTS['MAPs'])
     assert np.array_equal(dirs.cpu().numpy(), ae.RESULTS['DIRs'])
+
+
+def test_large_host_batches_are_pipelined_identically(htable500, monkeypatch):
+    """amx_noddi_fit with >= 524 288 voxels copies and fits in batches (PCIe hidden behind the solver): same maps as
+    the one-shot path bit for bit, statistics accumulated over the batches, error voxel reported in caller indices"""
+    from amico_amd import _capi, get_context, synthetic as S
+    ctx = get_context()
+    ht = htable500['htable']
+    sch = S.make_scheme(seed=0)
+    K = S.noddi_kernels(sch, htable500['dirs'])
+    n = 2 * 262144 + 70001
+    y, d = S.noddi_signals(n, K, ht, sch, seed=12)
+    lut = _capi.upload_noddi(ctx, K, ht, sch.dwi_idx)
+    est, rmse, _, mod = _capi.noddi_fit(ctx, lut, y, d, 0.5, 1e-3, 3, rmse=True, mod=True)
+    stats = ctx.last_stats()
+    monkeypatch.setenv('AMX_HOST_ONE_SHOT', '1')
+    est1, rmse1, _, mod1 = _capi.noddi_fit(ctx, lut, y, d, 0.5, 1e-3, 3, rmse=True, mod=True)
+    stats1 = ctx.last_stats()
+    monkeypatch.delenv('AMX_HOST_ONE_SHOT')
+    assert np.array_equal(est, est1) and np.array_equal(rmse, rmse1) and np.array_equal(mod, mod1)
+    assert stats['rerun_voxels'] == stats1['rerun_voxels'] > 0
+    d_bad = d.copy()
+    d_bad[400000] = np.nan
+    with pytest.raises(RuntimeError, match=r'voxel 400000\]'):
+        _capi.noddi_fit(ctx, lut, y, d_bad, 0.5, 1e-3, 3)
+    est2, _, _, _ = _capi.noddi_fit(ctx, lut, y[:1000], d[:1000], 0.5, 1e-3, 3)      # context still usable
+    assert np.array_equal(est2, est[:1000])
