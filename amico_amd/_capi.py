@@ -288,6 +288,52 @@ def sandi_fit(ctx, lut, y, lambda1, lambda2, rmse=False, nrmse=False):
     return est, r, nr
 
 
+# ---- the same three fits on DEVICE-resident inputs (torch tensors used as plain device buffers); outputs are torch
+#      tensors on the same device, enqueued on `stream`; the caller synchronises with ctx.sync(stream)
+def _dptr(t):
+    return c_vp(t.data_ptr()) if t is not None else None
+
+
+def noddi_fit_device(ctx, lut, y_t, dirs_t, lambda1, lambda2, n_maps, rmse=False, nrmse=False, mod=False, stream=None):
+    import torch
+    n, f64 = y_t.shape[0], dict(dtype=torch.float64, device=y_t.device)
+    flags = (F_RMSE if rmse else 0) | (F_NRMSE if nrmse else 0) | (F_MODULATED if mod else 0)
+    est = torch.empty((n, n_maps), **f64)
+    r = torch.empty(n, **f64) if rmse else None
+    nr = torch.empty(n, **f64) if nrmse else None
+    md = torch.empty((n, 2), **f64) if mod else None
+    ctx.check(lib().amx_noddi_fit_device(ctx._h, lut._h, _dptr(y_t), _dptr(dirs_t), n, float(lambda1), float(lambda2), flags,
+                                         _dptr(est), _dptr(r), _dptr(nr), _dptr(md), c_vp(stream or 0)))
+    return est, r, nr, md
+
+
+def freewater_fit_device(ctx, lut, y_t, dirs_t, lambda1, lambda2, is_mouse, rmse=False, nrmse=False, corrected=False,
+                         stream=None):
+    import torch
+    n, f64 = y_t.shape[0], dict(dtype=torch.float64, device=y_t.device)
+    flags = (F_RMSE if rmse else 0) | (F_NRMSE if nrmse else 0) | (F_CORRECTED if corrected else 0)
+    est = torch.empty((n, 4 if is_mouse else 2), **f64)
+    r = torch.empty(n, **f64) if rmse else None
+    nr = torch.empty(n, **f64) if nrmse else None
+    yc = torch.empty((n, lut.nS), **f64) if corrected else None
+    ctx.check(lib().amx_freewater_fit_device(ctx._h, lut._h, _dptr(y_t), _dptr(dirs_t), n, float(lambda1), float(lambda2),
+                                             int(bool(is_mouse)), flags, _dptr(est), _dptr(r), _dptr(nr), _dptr(yc),
+                                             c_vp(stream or 0)))
+    return est, r, nr, yc
+
+
+def sandi_fit_device(ctx, lut, y_t, lambda1, lambda2, rmse=False, nrmse=False, stream=None):
+    import torch
+    n, f64 = y_t.shape[0], dict(dtype=torch.float64, device=y_t.device)
+    flags = (F_RMSE if rmse else 0) | (F_NRMSE if nrmse else 0)
+    est = torch.empty((n, 6), **f64)
+    r = torch.empty(n, **f64) if rmse else None
+    nr = torch.empty(n, **f64) if nrmse else None
+    ctx.check(lib().amx_sandi_fit_device(ctx._h, lut._h, _dptr(y_t), n, float(lambda1), float(lambda2), flags, _dptr(est),
+                                         _dptr(r), _dptr(nr), c_vp(stream or 0)))
+    return est, r, nr
+
+
 def dir_to_lut_idx(ctx, lut, dirs):
     dirs = np.ascontiguousarray(np.atleast_2d(dirs), dtype=np.float64)
     out = np.zeros(dirs.shape[0], dtype=np.int32)

@@ -15,6 +15,7 @@ import time
 from os import cpu_count
 import numpy as np
 from . import models as _models
+from . import _capi
 from . import prep as _prep
 from . import dti as _dti
 from .synthetic import SimpleScheme
@@ -27,8 +28,9 @@ class Evaluation:
         self.niiMASK_img = None
         self.model = None
         self.KERNELS = None
-        self.y = None
-        self.DIRs = None
+        self._y = None
+        self._DIRs = None
+        self._dev = None
         self.nthreads = None
         self.RESULTS = None
         self.mean_b0s = None
@@ -53,6 +55,29 @@ class Evaluation:
         self.set_config('nthreads', -1)
         self.set_config('DTI_fit_method', 'OLS')
         self.set_config('BLAS_nthreads', 1)
+
+    # `y` / `DIRs` (core.py:451-458) are produced on the GPU by fit() and stay there for model.fit (self._dev); the
+    # numpy arrays the reference exposes are fetched on first access
+    @property
+    def y(self):
+        if self._y is None and self._dev is not None:
+            self._y = self._dev['y'].cpu().numpy()
+        return self._y
+
+    @y.setter
+    def y(self, value):
+        self._y = value
+        self._dev = None
+
+    @property
+    def DIRs(self):
+        if self._DIRs is None and self._dev is not None and self._dev.get('dirs') is not None:
+            self._DIRs = self._dev['dirs'].cpu().numpy()
+        return self._DIRs
+
+    @DIRs.setter
+    def DIRs(self, value):
+        self._DIRs = value
 
     def set_config(self, key, value):
         self.CONFIG[key] = value
@@ -144,33 +169,70 @@ class Evaluation:
         self.nthreads = nt if nt > 0 else cpu_count()
         self.model.scheme = self.scheme
         sel = self.niiMASK_img == 1                                   # core.py:451 (== 1, not nonzero)
+        import torch                                                  # device buffers only
+        dev = torch.device('cuda', torch.cuda.current_device())
+        L, ctx, plan = _capi.lib(), self._prep.ctx, self._prep._plan
         t = time.time()
-        self.y, self.mean_b0s = self._prep.gather(self.niiDWI_img)    # core.py:209-268 + 451-452
+        # ---- raw image -> HBM once; everything up to the map volumes stays there (one stream, default)
+        img = self.niiDWI_img
+        d_img = torch.from_numpy(np.lib.stride_tricks.as_strided(img, shape=(plan.extent,), strides=(4,))).to(dev)
+        n = self._prep.n_vox
+        d_y = torch.empty((n, self._prep.n_out), dtype=torch.float64, device=dev)
+        d_mb0 = torch.empty(n, dtype=torch.float32, device=dev)
+        thr = 0.0
+        if self._prep.do_normalize and self._prep.b0_min_signal != 0.0:              # core.py:217
+            d_vol = torch.empty(img.shape[:3], dtype=torch.float32, device=dev)
+            ctx.check(L.amx_prep_mean_b0_device(ctx._h, plan._h, d_img.data_ptr(), d_vol.data_ptr(), None))
+            mean_b0s = d_vol.cpu().numpy()
+            thr = float(self._prep.b0_min_signal * mean_b0s[mean_b0s > 0].mean())
+        ctx.check(L.amx_prep_gather_device(ctx._h, plan._h, d_img.data_ptr(), int(self._prep.do_normalize), thr,
+                                           d_y.data_ptr(), d_mb0.data_ptr(), None))  # core.py:209-268 + 451-452
         # precompute directions (core.py:428-458)
+        d_dirs = None
         if self.get_config('doDirectionalAverage'):
-            self.DIRs = None
+            pass
         elif self._dirs_img is not None:
-            self.DIRs = np.ascontiguousarray(self._dirs_img[sel, :], dtype=np.float64)
+            d_dirs = torch.from_numpy(np.ascontiguousarray(self._dirs_img[sel, :], dtype=np.float64)).to(dev)
         else:
             if self.get_config('DTI_fit_method') not in ('OLS', 'LS'):
                 raise NotImplementedError('only the default DTI_fit_method (OLS) runs on the GPU')
-            est = _dti.TensorDirections.from_scheme(self._raw_scheme, do_merge_b0=self.get_config('doMergeB0'))
-            self.DIRs = est.fit(self.y)
+            est = _dti.TensorDirections.from_scheme(self._raw_scheme, do_merge_b0=self.get_config('doMergeB0'), ctx=ctx)
+            d_dirs = torch.empty((n, 3), dtype=torch.float64, device=dev)
+            est.fit_device(d_y.data_ptr(), n, d_dirs.data_ptr())
+        ctx.sync()
+        del d_img
+        self._y, self._DIRs = None, None
+        self._dev = {'y': d_y, 'dirs': d_dirs}
+        self.mean_b0s = d_mb0.cpu().numpy() if self._prep.do_normalize else None
         self.set_config('dirs_precomputing_time', time.time() - t)
         t = time.time()
-        results = self.model.fit(self)
+        results = self.model.fit(self)                                # reads self._dev in place
         self.set_config('fit_time', time.time() - t)
-        sc = self._prep.scatter
+        out = self._dev.get('out', {})
+
+        def sc(key, host_values):
+            """per-voxel values -> float32 volume (core.py:472-498); from the device copy when the fit left one"""
+            t_ = out.get(key)
+            if t_ is None:
+                return self._prep.scatter(host_values)
+            k = 1 if t_.dim() == 1 else t_.shape[1]
+            vol = torch.empty(img.shape[:3] + (k,), dtype=torch.float32, device=dev)
+            ctx.check(L.amx_prep_scatter_device(ctx._h, plan._h, t_.data_ptr(), k, vol.data_ptr(), None))
+            ctx.sync()
+            v = vol.cpu().numpy()
+            return v[..., 0] if t_.dim() == 1 else v
+
         self.RESULTS = {}
-        self.RESULTS['MAPs'] = sc(results['estimates'])
-        if self.DIRs is not None:
-            self.RESULTS['DIRs'] = sc(self.DIRs)
+        self.RESULTS['MAPs'] = sc('estimates', results['estimates'])
+        if d_dirs is not None:
+            out['DIRs'] = d_dirs
+            self.RESULTS['DIRs'] = sc('DIRs', None)
         if self.get_config('doComputeRMSE'):
-            self.RESULTS['RMSE'] = sc(results['rmse'])
+            self.RESULTS['RMSE'] = sc('rmse', results['rmse'])
         if self.get_config('doComputeNRMSE'):
-            self.RESULTS['NRMSE'] = sc(results['nrmse'])
+            self.RESULTS['NRMSE'] = sc('nrmse', results['nrmse'])
         if self.model.name == 'NODDI' and self.get_config('doSaveModulatedMaps'):
-            self.RESULTS['MAPs_mod'] = sc(results['estimates_mod'])
+            self.RESULTS['MAPs_mod'] = sc('estimates_mod', results['estimates_mod'])
         if self.model.name == 'Free-Water' and self.get_config('doSaveCorrectedDWI'):
             y_corrected = results['y_corrected']                      # core.py:488-498
             b0_idx = self.scheme.b0_idx
@@ -178,5 +240,6 @@ class Evaluation:
                 y_corrected = y_corrected * np.reshape(self.mean_b0s, (-1, 1))
             if self.get_config('doKeepb0Intact') and self.scheme.b0_count > 0:
                 y_corrected[:, b0_idx] = self.y[:, b0_idx] * np.reshape(self.mean_b0s, (-1, 1))
-            self.RESULTS['DWI_corrected'] = sc(y_corrected)
+            self.RESULTS['DWI_corrected'] = self._prep.scatter(y_corrected)
+        self._dev.pop('out', None)
         return results

@@ -84,7 +84,8 @@ class BaseModel(ABC):
     def fit(self, evaluation):
         # models.pyx:204-217: chunks are only kept for introspection -- the GPU path shards
         # nothing across host threads, results are voxel-order identical by construction
-        n = evaluation.y.shape[0]
+        dev = getattr(evaluation, '_dev', None)
+        n = dev['y'].shape[0] if dev is not None else evaluation.y.shape[0]     # (no download of a device-resident y)
         nthreads = max(1, int(evaluation.nthreads or 1))
         c = max(1, n // nthreads)
         self.chunks = [(i, j) for i, j in zip(range(0, n, c), range(c, n + 1, c))]
@@ -94,6 +95,14 @@ class BaseModel(ABC):
             'compute_rmse': evaluation.get_config('doComputeRMSE'),
             'compute_nrmse': evaluation.get_config('doComputeNRMSE'),
         }
+
+    # ---- device-resident inputs: Evaluation.fit leaves `y` (and `DIRs`) in HBM (evaluation._dev) when it produced
+    #      them on the GPU; the fit then reads them in place and keeps its outputs there for the scatter
+    @staticmethod
+    def _finish_device(ctx, dev, named):
+        ctx.sync()
+        dev['out'] = {k: v for k, v in named.items() if v is not None}
+        return {k: v.cpu().numpy() for k, v in dev['out'].items()}
 
     # ---- dictionary cache: one upload per (KERNELS, htable) object pair
     def _lut(self, evaluation, builder):
@@ -163,6 +172,13 @@ class NODDI(BaseModel):
             raise ValueError('KERNELS do not match IC_VFs / IC_ODs of the model')
         lut = self._lut(evaluation, lambda: _capi.upload_noddi(ctx, evaluation.KERNELS, evaluation.htable,
                                                                self.scheme.dwi_idx, self.isExvivo))
+        dev = getattr(evaluation, '_dev', None)
+        if dev is not None:
+            est, rmse, nrmse, mod = _capi.noddi_fit_device(
+                ctx, lut, dev['y'], dev['dirs'], self.solver_params['lambda1'], self.solver_params['lambda2'],
+                len(self.maps_name), rmse=bool(self.configs['compute_rmse']), nrmse=bool(self.configs['compute_nrmse']),
+                mod=bool(self.configs['compute_modulated_maps']))
+            return self._finish_device(ctx, dev, {'estimates': est, 'rmse': rmse, 'nrmse': nrmse, 'estimates_mod': mod})
         est, rmse, nrmse, mod = _capi.noddi_fit(
             ctx, lut, evaluation.y, evaluation.DIRs, self.solver_params['lambda1'], self.solver_params['lambda2'],
             len(self.maps_name), rmse=bool(self.configs['compute_rmse']), nrmse=bool(self.configs['compute_nrmse']),
@@ -228,6 +244,13 @@ class FreeWater(BaseModel):
         self.configs['save_corrected_DWI'] = evaluation.get_config('doSaveCorrectedDWI')
         ctx = get_context()
         lut = self._lut(evaluation, lambda: _capi.upload_freewater(ctx, evaluation.KERNELS, evaluation.htable))
+        dev = getattr(evaluation, '_dev', None)
+        if dev is not None:
+            est, rmse, nrmse, yc = _capi.freewater_fit_device(
+                ctx, lut, dev['y'], dev['dirs'], self.solver_params['lambda1'], self.solver_params['lambda2'],
+                self.type == 'Mouse', rmse=bool(self.configs['compute_rmse']), nrmse=bool(self.configs['compute_nrmse']),
+                corrected=bool(self.configs['save_corrected_DWI']))
+            return self._finish_device(ctx, dev, {'estimates': est, 'rmse': rmse, 'nrmse': nrmse, 'y_corrected': yc})
         est, rmse, nrmse, yc = _capi.freewater_fit(
             ctx, lut, evaluation.y, evaluation.DIRs, self.solver_params['lambda1'], self.solver_params['lambda2'],
             self.type == 'Mouse', rmse=bool(self.configs['compute_rmse']), nrmse=bool(self.configs['compute_nrmse']),
@@ -289,6 +312,12 @@ class SANDI(BaseModel):
         super().fit(evaluation)
         ctx = get_context()
         lut = self._lut(evaluation, lambda: _capi.upload_sandi(ctx, evaluation.KERNELS, self.Rs, self.d_in, self.d_isos))
+        dev = getattr(evaluation, '_dev', None)
+        if dev is not None:
+            est, rmse, nrmse = _capi.sandi_fit_device(ctx, lut, dev['y'], self.solver_params['lambda1'],
+                                                      self.solver_params['lambda2'], rmse=bool(self.configs['compute_rmse']),
+                                                      nrmse=bool(self.configs['compute_nrmse']))
+            return self._finish_device(ctx, dev, {'estimates': est, 'rmse': rmse, 'nrmse': nrmse})
         est, rmse, nrmse = _capi.sandi_fit(ctx, lut, evaluation.y, self.solver_params['lambda1'],
                                            self.solver_params['lambda2'], rmse=bool(self.configs['compute_rmse']),
                                            nrmse=bool(self.configs['compute_nrmse']))
