@@ -356,3 +356,73 @@ def test_large_host_batches_are_pipelined_identically(htable500, monkeypatch):
         _capi.noddi_fit(ctx, lut, y, d_bad, 0.5, 1e-3, 3)
     est2, _, _, _ = _capi.noddi_fit(ctx, lut, y[:1000], d[:1000], 0.5, 1e-3, 3)      # context still usable
     assert np.array_equal(est2, est[:1000])
+
+
+def test_evaluation_sandi_with_directional_average():
+    """306-volume 5-shell image -> shell averages on the GPU (core.py:229-252) -> SANDI fit -> volumes, against the
+    numpy preprocessing + C oracle chain"""
+    import amico_amd
+    from amico_amd import synthetic as S
+    from oracle import oracle, signal_np
+    full = S.make_sandi_scheme(ndir_per_shell=24, n_b0=4)
+    rng = np.random.default_rng(5)
+    shape = (14, 9, 6)
+    avg = S.directional_average_scheme(full)
+    K, Rs, d_in, d_isos = S.sandi_kernels(avg)
+    # per-voxel shell means that follow the SANDI dictionary, spread over the shell's directions with noise
+    ya = S.sandi_signals(int(np.prod(shape)), K, avg, seed=3)
+    img = np.zeros(shape + (full.nS,), dtype=np.float32)
+    img[..., full.b0_idx] = 1000.0
+    shells = sorted(full.shells, key=lambda s: s['b'])
+    for k, sh in enumerate(shells):
+        img[..., sh['idx']] = (1000.0 * ya[:, k + 1].reshape(shape + (1,)) *
+                               (1.0 + 0.05 * rng.standard_normal(shape + (len(sh['idx']),)))).astype(np.float32)
+    img = np.asfortranarray(img)
+    mask = (rng.uniform(size=shape) < 0.8).astype(np.uint8)
+    ae = amico_amd.Evaluation()
+    ae.set_config('doDirectionalAverage', True)
+    ae.set_config('doComputeNRMSE', True)
+    ae.set_data(img, full, mask)
+    assert ae.scheme.nS == 6
+    ae.set_model('SANDI')
+    Ke = S.sandi_kernels(ae.scheme)[0]                                   # dictionary of the averaged scheme
+    ae.set_kernels(Ke)
+    res = ae.fit()
+    y_ref, _ = signal_np.prepare_signal(img, mask, full.b0_idx, full.dwi_idx, shells=full.shells, do_directional_average=True)
+    assert np.array_equal(ae.y, y_ref) and ae.DIRs is None and 'DIRs' not in ae.RESULTS
+    ref = oracle.sandi_fit(y_ref, Ke, Rs, d_in, d_isos, nrmse=True)
+    assert np.abs(res['estimates'] - ref['estimates']).max() < 1e-6
+    assert ae.RESULTS['MAPs'].shape == shape + (6,) and np.allclose(ae.RESULTS['NRMSE'][mask == 1], ref['nrmse'], atol=1e-6)
+
+
+def test_evaluation_freewater_corrected_dwi(htable500):
+    """Free-Water through Evaluation with doSaveCorrectedDWI / doKeepb0Intact (core.py:488-498)"""
+    import amico_amd
+    from amico_amd import synthetic as S
+    from oracle import oracle, signal_np
+    ht = htable500['htable']
+    sch = S.make_scheme(2, ((1000.0, 40),), seed=3)
+    K = S.freewater_kernels(sch, htable500['dirs'])
+    shape = (12, 10, 7)
+    y, d = S.freewater_signals(int(np.prod(shape)), K, ht, sch, seed=2)
+    img = (y.reshape(shape + (-1,)) * 640.0).astype(np.float32)
+    mask = np.ones(shape, dtype=np.uint8)
+    mask[:, :, 0] = 0
+    ae = amico_amd.Evaluation()
+    ae.set_config('doSaveCorrectedDWI', True)
+    ae.set_config('doKeepb0Intact', True)
+    ae.set_data(img, sch, mask, d.reshape(shape + (3,)))
+    ae.set_model('FreeWater')
+    ae.set_kernels(K, ht)
+    res = ae.fit()
+    sel = mask == 1
+    y_ref, mb0 = signal_np.prepare_signal(img, mask, sch.b0_idx, sch.dwi_idx)
+    d_ref = d.reshape(shape + (3,)).astype(np.float32)[sel].astype(np.float64)
+    ref = oracle.freewater_fit(y_ref, d_ref, K, ht, corrected=True)
+    assert np.abs(res['estimates'] - ref['estimates']).max() < 1e-6
+    yc = ref['y_corrected'] * mb0[sel][:, None]
+    yc[:, sch.b0_idx] = y_ref[:, sch.b0_idx] * mb0[sel][:, None]
+    vol = ae.RESULTS['DWI_corrected']
+    assert vol.shape == img.shape and not vol[:, :, 0].any()
+    assert np.allclose(vol[sel], yc.astype(np.float32), rtol=1e-5, atol=1e-3)
+    assert np.allclose(vol[sel][:, sch.b0_idx], img[sel][:, sch.b0_idx], rtol=1e-6)      # b0 volumes intact
