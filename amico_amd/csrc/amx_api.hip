@@ -292,9 +292,25 @@ int amx_sync_status(amx_ctx *ctx, void *hip_stream)
     hipStream_t s = (hipStream_t)hip_stream;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemcpyAsync(ctx->status_h, ctx->status_d, ST_WORDS * sizeof(int), hipMemcpyDeviceToHost, s));
+#ifdef AMX_PHASES
+    unsigned long long ph_[16];
+    if (ctx->misc.p) HIPCHK(ctx, hipMemcpyAsync(ph_, (int *)ctx->misc.p + 16, sizeof ph_, hipMemcpyDeviceToHost, s));
+#endif
     int rc = reset_status(ctx, s);
     if (rc) return rc;
     HIPCHK(ctx, hipStreamSynchronize(s));
+#ifdef AMX_PHASES
+    if (ctx->misc.p) {
+        static const char *nm[8] = {"sweep", "gram-update", "selection", "column+CGS", "commit", "tri-solve", "step/removal", "other"};
+        for (int st_ = 0; st_ < 2; st_++) {
+            unsigned long long tot = 0;
+            for (int k = 0; k < 8; k++) tot += ph_[st_ * 8 + k];
+            fprintf(stderr, "[amx] NNLS stage %d phases:", st_ == 0 ? 1 : 3);
+            for (int k = 0; k < 7; k++) fprintf(stderr, " %s %.1f%%", nm[k], tot ? 100.0 * ph_[st_ * 8 + k] / tot : 0.0);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     const int *st = ctx->status_h;
     ctx->stats[0] = st[ST_RERUN];
     ctx->stats[1] = st[ST_ITCAP];

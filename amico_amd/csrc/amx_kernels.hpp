@@ -165,6 +165,14 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const float *As,
     } else {
     if (st == kIterCap && lane == 0) atomicAdd(&a.c.status[ST_ITCAP], 1);
     if (st > kIterCap && lane == 0) { atomicAdd(&a.c.status[ST_GUARD], 1); a.c.status[ST_GUARDVOX] = vox * 8 + st; }
+#ifdef AMX_PHASES
+    if constexpr (STAGE == 1 || STAGE == 3) {
+        if (lane == 0) {
+            unsigned long long *acc = reinterpret_cast<unsigned long long *>(const_cast<int *>(a.c.n_chunks) + 16) + (STAGE == 1 ? 0 : 8);
+            for (int k = 0; k < 8; k++) atomicAdd(&acc[k], (unsigned long long)S.ph[k]);
+        }
+    }
+#endif
 #ifdef AMX_STATS
     if (lane == 0) { constexpr int sx = kLasso ? 1 : STAGE - 1; atomicAdd(&a.c.status[ST_EXACT + sx], S.n_exact); atomicAdd(&a.c.status[ST_GRAM + sx], S.n_gram); atomicAdd(&a.c.status[ST_ITERS + sx], S.iters); }
 #endif

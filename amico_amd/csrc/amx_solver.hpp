@@ -33,6 +33,12 @@ namespace amx {
 
 constexpr int kWave = 64;
 
+// -DAMX_PHASES: wall-clock split of solve() by phase (s_memtime), accumulated per wavefront (diagnosis builds only)
+#ifdef AMX_PHASES
+#define AMX_PH(k) do { const long long t__ = (long long)__builtin_readcyclecounter(); ph[k] += t__ - pht; pht = t__; } while (0)
+#else
+#define AMX_PH(k) do { } while (0)
+#endif
 enum SolveStatus : int { kSolved = 0, kOverflow = 1, kIterCap = 2, kGuardSelect = 3, kGuardOuter = 4 };
 
 // ------------------------------------------------------------------ wavefront primitives
@@ -171,6 +177,9 @@ struct NNSolver {
     double r[NR];         // row space: residual y - A s x at exit
     int iters;
     int n_exact, n_gram;  // dual-vector evaluations: exact sweeps / Gram updates (statistics)
+#ifdef AMX_PHASES
+    long long ph[8], pht; // 0 sweep, 1 gram update, 2 selection, 3 column + Gram-Schmidt, 4 commit, 5 triangular solve, 6 step/removal, 7 other
+#endif
 
     // fl: per-lane atom flags (bit q: allowed, bit 8+q: passive, bit 16+q: banned) of atom lane+64q
     __device__ __forceinline__ void remove_slot(int k, int lane, unsigned &fl)
@@ -314,6 +323,10 @@ struct NNSolver {
         int last_added = -1, second_looks = 0;
         bool cyc_banned = false;
         n_exact = 0; n_gram = 0;
+#ifdef AMX_PHASES
+        for (int k = 0; k < 8; k++) ph[k] = 0;
+        pht = (long long)__builtin_readcyclecounter();
+#endif
 #ifndef AMX_GRAM_COLS
 #define AMX_GRAM_COLS 4
 #endif
@@ -374,6 +387,7 @@ struct NNSolver {
 #pragma unroll
                 for (int q = 0; q < NQ; q++) u[q] += w2[q];
                 have_u = true; force_exact = false; gram_steps = 0; n_exact++;
+                AMX_PH(0);
             } else {
                 // ---- u -= G[:, P] (s (x - xprev)): the passive coefficients moved, nothing else did
                 // (4 columns = 4*NQ loads in flight per trip: the loop is bound by L2/MALL latency)
@@ -398,6 +412,7 @@ struct NNSolver {
                     }
                 }
                 gram_steps++; n_gram++;
+                AMX_PH(1);
             }
             xprev = x;
 #pragma unroll
@@ -434,6 +449,7 @@ struct NNSolver {
 #pragma unroll
                 for (int q = 0; q < NQ; q++)
                     if (q == tq) sct = bcast(scl[q], tl);
+                AMX_PH(2);
                 // candidate column (row space) and its ridge rows (slot space)
                 double v[NR];
                 double vsq = 0.0;
@@ -502,6 +518,7 @@ struct NNSolver {
                 if (reject) {
                     if (lane == tl) fl |= 0x10000u << tq;
                 } else {
+                    AMX_PH(3);
                     // ---- commit column np
                     const int kn = np;
 #pragma unroll
@@ -519,6 +536,7 @@ struct NNSolver {
                     np = kn + 1;
                     last_added = t;
                     added = true;
+
                 }
             }
             if (redo) continue;  // small dual values: decide on the exactly recomputed vector
@@ -534,6 +552,7 @@ struct NNSolver {
                 break;   // KKT point (or a guard tripped)
             }
 
+            AMX_PH(4);
             // ---- Lawson-Hanson inner loop: restore feasibility of the passive solution
             for (bool feasible = false; !feasible && status == kSolved;) {
                 if (++iters > itmax) { status = kIterCap; break; }
@@ -553,6 +572,7 @@ struct NNSolver {
                 const bool neg = act && !(z > 0.0);
                 // The heavy state (Q, R, d, ...) changes only inside the removal loop below, which makes zero trips for a
                 // feasible solution: an if/else around it cost two full copies of that state per pass (phi copies).
+                AMX_PH(5);
                 const bool any = ballot64(neg) != 0ull;
                 unsigned long long rem = 0ull;
                 if (any) {
@@ -582,6 +602,7 @@ struct NNSolver {
                 }
                 if (np == 0) x = 0.0;
                 feasible = !any || np == 0;
+                AMX_PH(6);
             }
         }
         return status;
