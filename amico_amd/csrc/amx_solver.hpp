@@ -424,10 +424,10 @@ struct NNSolver {
                 if (sel > kWave * NQ + 2) { status = kGuardSelect; break; }
                 double best = -inf;
                 int bj = -1;
+                const unsigned cm = fl & ~(fl >> 8) & ~(fl >> 16);     // bit q: allowed, not passive, not barred
 #pragma unroll
                 for (int q = 0; q < NQ; q++) {
-                    const bool cand = ((fl >> q) & 1u) && !((fl >> (8 + q)) & 1u) && !((fl >> (16 + q)) & 1u);
-                    if (cand && w[q] > best) { best = w[q]; bj = lane + kWave * q; }
+                    if (((cm >> q) & 1u) && w[q] > best) { best = w[q]; bj = lane + kWave * q; }
                 }
                 const double wmax = wave_max(best);
                 if (!exact) {
