@@ -71,7 +71,7 @@ struct amx_prep {
     long long sv = 0;              // element stride of the volume axis
     long long extent = 0;          // elements spanned by the image (largest offset + 1)
     long long n_total = 0, n_vox = 0;
-    int nS = 0, n_out = 0, n_b0 = 0, n_gidx = 0, identity = 0, inplace = 0, layout = 0;   // layout: 1 planar (s[0]==1), 2 interleaved (sv==1), 0 generic
+    int nS = 0, n_out = 0, n_b0 = 0, n_gidx = 0, identity = 0, inplace = 0, hazard = 0, layout = 0;   // layout: 1 planar (s[0]==1), 2 interleaved (sv==1), 0 generic
     int *rank = nullptr;           // device int32[d2][d1][d0]: index in the masked list or -1
     long long *cidx = nullptr;     // device int64[n_vox]: C-order linear index of the masked voxels
     int *gptr = nullptr, *gidx = nullptr, *b0idx = nullptr;

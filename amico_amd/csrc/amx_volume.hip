@@ -132,6 +132,70 @@ __global__ __launch_bounds__(64 * kPrepWaves) void k_prep_gather(PrepArgs a)
     }
 }
 
+// Streaming variant for GROUPED outputs on a planar image (x fastest) -- the shell average of SANDI, the b0 merge:
+// lane = voxel, no transposition tile.  Each volume plane is read with coalesced 256-byte wavefront loads, the group
+// sums are accumulated in index order in a register (float32, exactly as k_prep_gather does), and the few output
+// values of a voxel are stored directly.  Without the 25-80 KB LDS tile per wavefront the occupancy is limited by
+// registers only, which is what a 1.2 KB-in / 48 B-out reduction needs to approach the HBM rate.  Used when no group
+// reads a volume index that an earlier output occupies (plan flag `hazard` clear), i.e. when order does not matter.
+// img[..., i] *= norm_factor is a float32 operation of its own in the reference: the product must be rounded before
+// it enters a sum, so it is hidden from the compiler's fma contraction behind an empty asm
+__device__ __forceinline__ float scaled(float v, float f)
+{
+    float p = v * f;
+    asm volatile("" : "+v"(p));
+    return p;
+}
+
+__global__ __launch_bounds__(256) void k_prep_stream(PrepArgs a)
+{
+    extern __shared__ int P[];
+    int *Pb0 = P, *Pgp = P + a.n_b0, *Pgi = Pgp + a.n_out + 1;
+    for (int i = threadIdx.x; i < a.n_b0; i += blockDim.x) Pb0[i] = a.b0idx[i];
+    for (int i = threadIdx.x; i <= a.n_out; i += blockDim.x) Pgp[i] = a.gptr[i];
+    for (int i = threadIdx.x; i < a.n_gidx; i += blockDim.x) Pgi[i] = a.gidx[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    const long long wave_id = (long long)blockIdx.x * nwv + wave, n_waves = (long long)gridDim.x * nwv;
+    for (long long t = wave_id; t < a.n_tiles; t += n_waves) {
+        const long long row = t / a.tiles_per_row;
+        const long long x0 = (t - row * a.tiles_per_row) * 64;
+        const long long i2 = row / a.d1, i1 = row - i2 * a.d1;
+        const long long x = x0 + lane;
+        const int r = x < a.d0 ? a.rank[(i2 * a.d1 + i1) * a.d0 + x] : -1;
+        if (__ballot(r >= 0) == 0ull) continue;
+        if (r < 0) continue;
+        const float *src = a.img + x * a.s0 + i1 * a.s1 + i2 * a.s2;
+        float f = 1.0f;
+        if (a.normalize) {
+            float m = 0.0f;
+            for (int i = 0; i < a.n_b0; i++) m = m + src[(long long)Pb0[i] * a.sv];
+            m = m / (float)a.n_b0;
+            if (a.mean_b0) a.mean_b0[r] = m;
+            f = (m <= a.thr) ? 0.0f : 1.0f / m;
+        }
+        double *dst = a.y + (long long)r * a.n_out;
+        for (int j = 0; j < a.n_out; j++) {
+            const int g0 = Pgp[j], g1 = Pgp[j + 1];
+            float acc = 0.0f;
+            int g = g0;
+            for (; g + 8 <= g1; g += 8) {               // eight loads in flight, summed in index order
+                float t8[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) t8[u] = src[(long long)Pgi[g + u] * a.sv];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const float v = scaled(t8[u], f);
+                    acc = (g + u == g0) ? v : acc + v;
+                }
+            }
+            for (; g < g1; g++) { const float v = scaled(src[(long long)Pgi[g] * a.sv], f); acc = (g == g0) ? v : acc + v; }
+            if (g1 - g0 > 1) acc = acc / (float)(g1 - g0);
+            dst[j] = (double)(acc < 0.0f ? 0.0f : acc);
+        }
+    }
+}
+
 // float32 mean of the b0 volumes of EVERY voxel (self.mean_b0s, core.py:213), written in C order [X][Y][Z]
 __global__ void k_mean_b0(const float *img, long long d0, long long d1, long long d2, long long s0, long long s1,
                           long long s2, long long sv, long long c0, long long c1, long long c2, const int *b0idx,
@@ -193,13 +257,14 @@ int amx_prep_create(amx_ctx *ctx, const int64_t dims[3], const int64_t strides[4
     const long long total = (long long)dims[0] * dims[1] * dims[2];
     if (total > INT_MAX || n_vox > total) return amx_bad(ctx, "amx_prep_create: volume too large");
     if (group_ptr[0] != 0) return amx_bad(ctx, "amx_prep_create: group_ptr[0] must be 0");
-    int inplace = 1;
+    int inplace = 1, hazard = 0;       // hazard: some group reads a volume index that an earlier output occupies
     for (int j = 0; j < n_out; j++) {
         if (group_ptr[j + 1] <= group_ptr[j]) return amx_bad(ctx, "amx_prep_create: empty output group");
         for (int g = group_ptr[j]; g < group_ptr[j + 1]; g++) {
             if (group_idx[g] < 0 || group_idx[g] >= nS) return amx_bad(ctx, "amx_prep_create: group index out of range");
             // output j would overwrite an input a later group still needs -- unless that is what the caller asks
             // for (the shell average of core.py:231-245 writes into a VIEW of the image it keeps reading from)
+            if (group_idx[g] < j) hazard = 1;
             if (group_idx[g] < j && !overwrite_in_order) inplace = 0;
         }
     }
@@ -214,6 +279,7 @@ int amx_prep_create(amx_ctx *ctx, const int64_t dims[3], const int64_t strides[4
     amx_prep *p = new amx_prep;
     p->ctx = ctx; p->nS = nS; p->n_out = n_out; p->n_b0 = n_b0; p->inplace = inplace;
     p->n_gidx = group_ptr[n_out];
+    p->hazard = hazard;
     p->identity = n_out == nS;
     for (int j = 0; j < n_out && p->identity; j++)
         if (group_ptr[j + 1] != j + 1 || group_idx[j] != j) p->identity = 0;
@@ -282,6 +348,17 @@ int amx_prep_gather_device(amx_ctx *ctx, const amx_prep *p, const float *d_img, 
     long long grid = 256LL * per_cu * 2;
     const long long need = (a.n_tiles + kPrepWaves - 1) / kPrepWaves;
     if (grid > need) grid = need;
+    if (!identity && !p->hazard && p->layout == 1 && !getenv("AMX_PREP_TILE")) {
+        // grouped outputs on a planar image: streaming kernel, no transposition tile
+        const size_t lds_s = ((size_t)p->n_b0 + p->n_out + 1 + p->n_gidx) * sizeof(int);
+        long long g2 = (a.n_tiles + 3) / 4;
+        if (g2 > 256LL * 16) g2 = 256LL * 16;
+        rec(ctx, 8, s);
+        hipLaunchKernelGGL(k_prep_stream, dim3((unsigned)g2), dim3(256), lds_s, s, a);
+        HIPCHK(ctx, hipGetLastError());
+        rec(ctx, 9, s);
+        return AMX_OK;
+    }
     rec(ctx, 8, s);
     if (identity) hipLaunchKernelGGL(k_prep_gather<true>, dim3((unsigned)grid), dim3(64 * kPrepWaves), lds, s, a);
     else hipLaunchKernelGGL(k_prep_gather<false>, dim3((unsigned)grid), dim3(64 * kPrepWaves), lds, s, a);

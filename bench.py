@@ -187,6 +187,33 @@ def signal_preparation(args):
         bpv = 4 * scheme.nS + 8 * scheme.nS + 4
         out[order] = {'voxels': n, 'voxels_per_s': n * args.steps / el, 'kernel_ms': kms,
                       'achieved_GBs': bpv * n / (kms * 1e-3) / 1e9, 'bit_exact_vs_numpy': exact, 'numpy_voxels_per_s': cpu}
+    if os.environ.get('PREP_DIRAVG', '1') != '0':
+        # SANDI preprocessing: 306 volumes (6 b0 + 5 shells x 60) -> b0 mean + 5 shell means per masked voxel (core.py:229-252)
+        full = S.make_sandi_scheme()
+        shp = (128, 128, 40)
+        img = np.asfortranarray(rng.uniform(0.0, 900.0, shp + (full.nS,)).astype(np.float32))
+        xx, yy, zz = np.meshgrid(*[np.linspace(-1, 1, s) for s in shp], indexing='ij')
+        mask = ((xx * xx + yy * yy + zz * zz) < 0.92).astype(np.uint8)
+        sp = prep.SignalPreparation(full, img, mask, do_directional_average=True)
+        ctx = sp.ctx
+        n = sp.n_vox
+        flat = np.lib.stride_tricks.as_strided(img, shape=(img.size,), strides=(4,))
+        d_img = torch.from_numpy(flat.copy()).to(dev)
+        d_y = torch.zeros((n, 6), dtype=torch.float64, device=dev)
+        d_m = torch.zeros(n, dtype=torch.float32, device=dev)
+        L = _capi_lib()
+        ctx.set_profiling(True)
+        kms = 0.0
+        for it in range(args.warmup + args.steps):
+            ctx.check(L.amx_prep_gather_device(ctx._h, sp._plan._h, d_img.data_ptr(), 1, 0.0, d_y.data_ptr(), d_m.data_ptr(), None))
+            ctx.sync()
+            if it >= args.warmup:
+                kms += ctx.last_kernel_ms(4)
+        kms /= args.steps
+        ref, _ = signal_np.prepare_signal(img, mask, full.b0_idx, full.dwi_idx, shells=full.shells, do_directional_average=True)
+        bpv = 4 * full.nS + 8 * 6 + 4
+        out['diravg_F'] = {'voxels': n, 'kernel_ms': kms, 'achieved_GBs': bpv * n / (kms * 1e-3) / 1e9, 'bytes_per_voxel': bpv,
+                           'bit_exact_vs_numpy': bool(np.array_equal(d_y.cpu().numpy(), ref))}
     best = out.get('F') or out['C']
     print(json.dumps({'metric': 'voxels/sec, signal preparation (mask gather + b0 normalisation + clip)',
                       'value': best['voxels_per_s'], 'unit': 'voxels/s', 'n_gpus': 1, 'steps': args.steps,
