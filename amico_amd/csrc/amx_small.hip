@@ -280,6 +280,233 @@ __global__ void __launch_bounds__(256) k_sandi_lane(const SandiArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// SANDI after the directional average has M = 6 signal values and N = 15 atoms: the passive system
+//     (A_P' A_P + lambda2 I) x_P = c_P           (|P| x |P|, up to 15 x 15)
+// is solved in ROW space by the Woodbury identity
+//     x_P = (c_P - A_P' w) / lambda2,   (lambda2 I_M + A_P A_P') w = A_P c_P      (M x M, 6 x 6)
+// so a lane keeps one 6 x 6 matrix B = lambda2 I + sum_{j in P} a_j a_j' (updated by +- a a' when an atom enters or
+// leaves) and its Cholesky factor instead of a 15 x 15 masked factor: 21 + 21 doubles instead of 120, no register
+// spills, ~1/5 of the arithmetic.  The dictionary (M x N doubles, the same for every voxel) is read through
+// wave-uniform addresses.  cond(B) <= 1 + |P| / lambda2 (~3e3 for the defaults): harmless in fp64.
+// the dictionary is loop invariant; without these barriers the compiler keeps all M x N entries in vector registers
+// across the fully unrolled passes (180 VGPRs) and spills everything else
+#define AMX_RELOAD() asm volatile("" ::: "memory")
+template <int M, int N>
+__device__ __forceinline__ int lane_nnqp_rows(const double *__restrict__ A, int ldA, const double (&y)[M], double lam1,
+                                              double lam2, double (&x)[N])
+{
+    const double tol = 1e-12, inf = __builtin_huge_val(), il2 = 1.0 / lam2;
+    double c[N], B[M * (M + 1) / 2], L[M * (M + 1) / 2], li[M], w[M], z[N];
+    unsigned P = 0u;
+    int status = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        x[j] = 0.0;
+        double s = -lam1;
+#pragma unroll
+        for (int i = 0; i < M; i++) s += A[i * ldA + j] * y[i];
+        c[j] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < M; i++)
+#pragma unroll
+        for (int k = 0; k <= i; k++) B[tri<M>(i, k)] = (i == k) ? lam2 : 0.0;
+    for (int it = 0; status == 0; ++it) {
+        if (it > 3 * N + 8) { status = 2; break; }
+        AMX_RELOAD();
+        // dual vector g_j = a_j'(y - A x) - lambda1 - lambda2 x_j = c_j - a_j' (A x) - lambda2 x_j; most violating atom
+        double ax[M];
+#pragma unroll
+        for (int i = 0; i < M; i++) ax[i] = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            const double xj = x[j];                       // 0 outside the passive set
+#pragma unroll
+            for (int i = 0; i < M; i++) ax[i] += A[i * ldA + j] * xj;
+        }
+        AMX_RELOAD();
+        double best = -inf;
+        int t = -1;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            double g = c[j] - lam2 * x[j];
+#pragma unroll
+            for (int i = 0; i < M; i++) g -= A[i * ldA + j] * ax[i];
+            if (!((P >> j) & 1u) && g > best) { best = g; t = j; }
+        }
+        if (!(best > tol)) break;                         // KKT point
+        P |= 1u << t;
+        AMX_RELOAD();
+#pragma unroll
+        for (int j = 0; j < N; j++) {                     // B += a_t a_t'
+            if (j == t) {
+#pragma unroll
+                for (int i = 0; i < M; i++)
+#pragma unroll
+                    for (int k = 0; k <= i; k++) B[tri<M>(i, k)] += A[i * ldA + j] * A[k * ldA + j];
+            }
+        }
+        for (int in = 0;; ++in) {
+            if (in > N + 2) { status = 2; break; }
+            // Cholesky of B (M x M), w = B^-1 (A_P c_P), z_P = (c_P - A_P' w) / lambda2
+#pragma unroll
+            for (int j = 0; j < M; j++) {
+                double d = B[tri<M>(j, j)];
+#pragma unroll
+                for (int k = 0; k < j; k++) d -= L[tri<M>(j, k)] * L[tri<M>(j, k)];
+                const double iv = rsqrt(d);
+                li[j] = iv;
+                L[tri<M>(j, j)] = d * iv;
+#pragma unroll
+                for (int i = j + 1; i < M; i++) {
+                    double tt = B[tri<M>(i, j)];
+#pragma unroll
+                    for (int k = 0; k < j; k++) tt -= L[tri<M>(i, k)] * L[tri<M>(j, k)];
+                    L[tri<M>(i, j)] = tt * iv;
+                }
+            }
+            AMX_RELOAD();
+#pragma unroll
+            for (int i = 0; i < M; i++) w[i] = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                const double cj = ((P >> j) & 1u) ? c[j] : 0.0;
+#pragma unroll
+                for (int i = 0; i < M; i++) w[i] += A[i * ldA + j] * cj;
+            }
+#pragma unroll
+            for (int j = 0; j < M; j++) {
+                double sacc = w[j];
+#pragma unroll
+                for (int k = 0; k < j; k++) sacc -= L[tri<M>(j, k)] * w[k];
+                w[j] = sacc * li[j];
+            }
+#pragma unroll
+            for (int j = M - 1; j >= 0; j--) {
+                double sacc = w[j];
+#pragma unroll
+                for (int i = j + 1; i < M; i++) sacc -= L[tri<M>(i, j)] * w[i];
+                w[j] = sacc * li[j];
+            }
+            AMX_RELOAD();
+            bool feasible = true;
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                double sacc = c[j];
+#pragma unroll
+                for (int i = 0; i < M; i++) sacc -= A[i * ldA + j] * w[i];
+                z[j] = sacc * il2;
+                if (((P >> j) & 1u) && !(z[j] > 0.0)) feasible = false;
+            }
+            if (feasible) {
+#pragma unroll
+                for (int j = 0; j < N; j++) x[j] = ((P >> j) & 1u) ? z[j] : 0.0;
+                break;
+            }
+            AMX_RELOAD();
+            double alpha = inf;
+            int jm = -1;
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                if (((P >> j) & 1u) && !(z[j] > 0.0)) {
+                    const double den = x[j] - z[j];
+                    const double r = (den > 0.0) ? x[j] / den : 0.0;
+                    if (r < alpha) { alpha = r; jm = j; }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                if ((P >> j) & 1u) {
+                    x[j] += alpha * (z[j] - x[j]);
+                    if (j == jm || !(x[j] > 0.0)) {
+                        x[j] = 0.0;
+                        P &= ~(1u << j);
+#pragma unroll
+                        for (int i = 0; i < M; i++)      // B -= a_j a_j'
+#pragma unroll
+                            for (int k = 0; k <= i; k++) B[tri<M>(i, k)] -= A[i * ldA + j] * A[k * ldA + j];
+                    }
+                }
+            }
+            if (P == 0u) {
+#pragma unroll
+                for (int i = 0; i < M; i++)               // exact reset: no drift left from the +- updates
+#pragma unroll
+                    for (int k = 0; k <= i; k++) B[tri<M>(i, k)] = (i == k) ? lam2 : 0.0;
+                break;
+            }
+        }
+    }
+    return status;
+}
+
+#ifndef AMX_ROWS_OCC
+#define AMX_ROWS_OCC 1
+#endif
+// SANDI, nS == M (<= 8) values per voxel: row-space solver; the dictionary is read from global memory with
+// wave-uniform addresses (scalar loads), y from the voxel's row.
+template <int M, int N>
+__global__ void __launch_bounds__(256, AMX_ROWS_OCC) k_sandi_rows(const SandiArgs a)
+{
+    const int cid = xcd_chunk((int)blockIdx.x, *a.c.n_chunks);
+    if (cid < 0) return;
+    const Chunk ck = a.c.chunks[cid];
+    const int ldA = a.c.ldA, n_atoms = a.c.n_atoms, n_rs = a.n_rs, n_in = a.n_in;
+    const double *__restrict__ A = reinterpret_cast<const double *>(a.c.tiles);
+    for (int v = threadIdx.x; v < ck.count; v += blockDim.x) {
+        const int vox = a.c.perm[ck.start + v];
+        const double *yv = a.c.y + (size_t)vox * M;
+        double y[M], x[N], ysq = 0.0;
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < M; i++) {
+            y[i] = yv[i];
+            ok = ok && (fabs(y[i]) <= 1.79769313486231570e308);
+            ysq += y[i] * y[i];
+        }
+        double *e = a.est + (size_t)vox * 6;
+        if (!ok) {
+            const double nan = __builtin_nan("");
+            for (int m = 0; m < 6; m++) e[m] = nan;
+            if (a.rmse) a.rmse[vox] = nan;
+            if (a.nrmse) a.nrmse[vox] = nan;
+            continue;
+        }
+        if (lane_nnqp_rows<M, N>(A, ldA, y, a.c.lam1, a.c.lam2, x) != 0) atomicAdd(&a.c.status[ST_ITCAP], 1);
+        // models.pyx:1570-1612
+        double x_sum = 0.0, xsph = 0.0, xstk = 0.0, xiso = 0.0, Rsoma = 0.0, Din = 0.0, De = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            if (j < n_atoms) {
+                x[j] *= a.norms[j];
+                x_sum += x[j];
+                if (j < n_rs) { xsph += x[j]; Rsoma += a.Rs[j] * x[j]; }
+                else if (j < n_rs + n_in) { xstk += x[j]; Din += a.d_in[j - n_rs] * x[j]; }
+                else { xiso += x[j]; De += a.d_isos[j - n_rs - n_in] * x[j]; }
+            }
+        }
+        x_sum += 1e-16;
+        e[0] = xsph / x_sum; e[1] = xstk / x_sum; e[2] = xiso / x_sum;
+        e[3] = 1e6 * Rsoma / (xsph + 1e-16);
+        e[4] = 1e3 * Din / (xstk + 1e-16);
+        e[5] = 1e3 * De / (xiso + 1e-16);
+        if (a.rmse || a.nrmse) {
+            // quirk kept (models.pyx:1571 then 1615): errors use the RESCALED x with the NORMALISED A
+            double rss = 0.0;
+#pragma unroll
+            for (int i = 0; i < M; i++) {
+                double ei = y[i];
+#pragma unroll
+                for (int j = 0; j < N; j++) ei -= A[i * ldA + j] * x[j];
+                rss += ei * ei;
+            }
+            if (a.rmse) a.rmse[vox] = sqrt(rss / (double)M);
+            if (a.nrmse) a.nrmse[vox] = (ysq > 1e-16) ? sqrt(rss / ysq) : 0.0;
+        }
+    }
+}
+
 template <typename Args, typename K>
 int launch_lane(amx_ctx *ctx, Args &a, const Plan &pl, hipStream_t s, K kern, size_t elem, int N)
 {
@@ -309,6 +536,15 @@ int amx_launch_fw_small(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s)
 int amx_launch_sandi_small(amx_ctx *ctx, SandiArgs &a, const Plan &pl, hipStream_t s)
 {
     const int n = a.c.n_atoms;                // SANDI default: 5 + 5 + 5 = 15 atoms
+    // the default protocol after the directional average (b0 + 5 shells = 6 values, 15 atoms): row-space solver
+    if (a.c.nS == 6 && n == 15 && a.c.lam2 >= 1e-6 && !getenv("AMX_SANDI_ATOM_SPACE")) {
+        rec(ctx, 2, s);
+        hipLaunchKernelGGL((k_sandi_rows<6, 15>), dim3(((pl.max_chunks + 7) / 8) * 8), dim3(256), 0, s, a);
+        AMX_TRACE(ctx, s, "row-space SANDI solver");
+        rec(ctx, 3, s);
+        HIPCHK(ctx, hipGetLastError());
+        return AMX_OK;
+    }
     if (n <= 12) return launch_lane(ctx, a, pl, s, k_sandi_lane<12>, sizeof(double), 12);
     if (n <= 15) return launch_lane(ctx, a, pl, s, k_sandi_lane<15>, sizeof(double), 15);
     return launch_lane(ctx, a, pl, s, k_sandi_lane<16>, sizeof(double), 16);
