@@ -305,6 +305,14 @@ def test_small_models_both_mappings(fw_fix, sandi_fix, htable500, monkeypatch):
     assert np.abs(res['0'][0]['rmse'] - res['1'][0]['rmse']).max() < 1e-9
     assert np.abs(res['0'][0]['nrmse'] - res['1'][0]['nrmse']).max() < 1e-9
     assert np.abs(res['0'][1]['rmse'] - res['1'][1]['rmse']).max() < 1e-9
+    # SANDI's third mapping: one voxel per lane in ATOM space (the default 6 x 15 problem runs in row space)
+    monkeypatch.setenv('AMX_WAVE_PER_VOXEL', '0')
+    monkeypatch.setenv('AMX_SANDI_ATOM_SPACE', '1')
+    s = sandi_fix
+    outa = SANDI().fit(Holder(s['y'], None, None, s['kernels'], doComputeRMSE=True))
+    assert np.abs(outa['estimates'][:, :3] - s['estimates'][:, :3]).max() < TOL
+    assert np.abs(outa['estimates'] - res['0'][1]['estimates']).max() < 1e-6
+    assert np.abs(outa['rmse'] - res['0'][1]['rmse']).max() < 1e-9
 
 
 def test_device_resident_volume_pipeline(htable500):
