@@ -22,6 +22,10 @@ namespace {
 template <int N>
 __device__ __forceinline__ constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
 
+// H / the dictionary are loop invariant: without these barriers the compiler keeps their entries in vector registers
+// across the fully unrolled passes (hundreds of VGPRs) and spills everything else
+#define AMX_RELOAD() asm volatile("" ::: "memory")
+
 // per-lane NNQP: min 1/2 x'Hx - cc'x, x >= 0 (cc = c - lambda1); Hs in LDS, row-major N x N.
 // returns 0, or 2 if an iteration cap tripped.
 template <int N>
@@ -36,6 +40,7 @@ __device__ __forceinline__ int lane_nnqp(const double *__restrict__ Hs, const do
     for (int it = 0; status == 0; ++it) {
         if (it > 3 * N + 8) { status = 2; break; }
         // dual vector g = cc - H x, most violating atom outside the passive set
+        AMX_RELOAD();
         double best = -inf;
         int t = -1;
 #pragma unroll
@@ -50,6 +55,7 @@ __device__ __forceinline__ int lane_nnqp(const double *__restrict__ Hs, const do
         for (int in = 0;; ++in) {
             if (in > N + 2) { status = 2; break; }
             // masked Cholesky of H restricted to P (identity elsewhere) and the two triangular solves
+            AMX_RELOAD();
 #pragma unroll
             for (int j = 0; j < N; j++) {
                 const bool pj = (P >> j) & 1u;
@@ -139,7 +145,23 @@ __device__ __forceinline__ bool lane_aty(const AT *As, const double *__restrict_
     ysq = 0.0;
 #pragma unroll
     for (int j = 0; j < N; j++) c[j] = 0.0;
-    for (int i = 0; i < nS; i++) {
+    // the lane's signal row is strided in memory (one cache line per lane and load): keep sixteen loads in flight
+    int i = 0;
+    for (; i + 16 <= nS; i += 16) {
+        double yb[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) yb[u] = yv[i + u];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const double yi = yb[u];
+            finite = finite && (fabs(yi) <= 1.79769313486231570e308);
+            ysq += yi * yi;
+#pragma unroll
+            for (int j = 0; j < N; j++)
+                if (j < n_atoms) c[j] += (double)As[(i + u) * ldA + j] * yi;
+        }
+    }
+    for (; i < nS; i++) {
         const double yi = yv[i];
         finite = finite && (fabs(yi) <= 1.79769313486231570e308);
         ysq += yi * yi;
@@ -197,7 +219,12 @@ __global__ void __launch_bounds__(256) k_freewater_lane(const FwArgs a)
         }
 #pragma unroll
         for (int j = 0; j < N; j++) c[j] -= a.c.lam1;
+#ifdef AMX_FW_SKIP_SOLVE
+#pragma unroll
+        for (int j = 0; j < N; j++) x[j] = c[j] > 0.0 ? 1e-3 * c[j] : 0.0;
+#else
         if (lane_nnqp<N>(Hs, c, x) != 0) atomicAdd(&a.c.status[ST_ITCAP], 1);
+#endif
         // models.pyx:1241-1256
         double x_sum = 0.0, x_perp = 0.0;
 #pragma unroll
@@ -289,9 +316,6 @@ __global__ void __launch_bounds__(256) k_sandi_lane(const SandiArgs a)
 // leaves) and its Cholesky factor instead of a 15 x 15 masked factor: 21 + 21 doubles instead of 120, no register
 // spills, ~1/5 of the arithmetic.  The dictionary (M x N doubles, the same for every voxel) is read through
 // wave-uniform addresses.  cond(B) <= 1 + |P| / lambda2 (~3e3 for the defaults): harmless in fp64.
-// the dictionary is loop invariant; without these barriers the compiler keeps all M x N entries in vector registers
-// across the fully unrolled passes (180 VGPRs) and spills everything else
-#define AMX_RELOAD() asm volatile("" ::: "memory")
 template <int M, int N>
 __device__ __forceinline__ int lane_nnqp_rows(const double *__restrict__ A, int ldA, const double (&y)[M], double lam1,
                                               double lam2, double (&x)[N])
