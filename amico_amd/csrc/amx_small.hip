@@ -466,7 +466,7 @@ __device__ __forceinline__ int lane_nnqp_rows(const double *__restrict__ A, int 
 }
 
 #ifndef AMX_ROWS_OCC
-#define AMX_ROWS_OCC 1
+#define AMX_ROWS_OCC 2
 #endif
 // SANDI, nS == M (<= 8) values per voxel: row-space solver; the dictionary is read from global memory with
 // wave-uniform addresses (scalar loads), y from the voxel's row.
