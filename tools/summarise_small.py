@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/small_<tag>/ (tools/profile_small.sh) into committed summaries under profiles/:
+<tag>_kernel_stats_{freewater_2M,sandi_1M,lut,prep}.txt and <tag>_pmc_small.txt.
+usage: python tools/summarise_small.py r02a"""
+import collections, csv, glob, os, subprocess, sys
+tag = sys.argv[1]
+O = 'gpurun_out/small_%s' % tag
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def stats(db):
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'rocpd_summary.py'), db], capture_output=True, text=True).stdout
+
+
+def bench_line(log):
+    for ln in open(log):
+        if ln.startswith('{'):
+            return ln.strip()
+    return ''
+
+
+for key, name, cmd in (('fw', 'freewater_2M', '--model freewater --voxels 2000000'), ('sandi', 'sandi_1M', '--model sandi --voxels 1000000'),
+                       ('lut', 'lut', '--model lut'), ('prep', 'prep', '--model prep')):
+    db = '%s/%s/%s_results.db' % (O, key, key)
+    if not os.path.exists(db):
+        continue
+    with open('profiles/%s_kernel_stats_%s.txt' % (tag, name), 'w') as f:
+        f.write('# rocprofv3 --kernel-trace --stats -- python bench.py %s --steps 5 --warmup 1\n' % cmd)
+        f.write(stats(db))
+        f.write('\n# bench.py line of the same run\n# ' + bench_line('%s/%s_bench.log' % (O, key)) + '\n')
+out = ['# rocprofv3 --kernel-trace --pmc <set> --output-format csv -- python bench.py --model {freewater --voxels 2000000 | sandi --voxels 1000000 | lut} '
+       '--steps 2 --warmup 1; separate passes (never combined with other trace domains); mean per launch',
+       '# FETCH_SIZE / WRITE_SIZE in KiB (FETCH_SIZE under-reports wide coalesced reads 2x on gfx950); SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* in quad-cycles']
+for m, pats in (('freewater', ['k_freewater']), ('sandi', ['k_sandi']), ('lut', ['k_lut_resample'])):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for fn in glob.glob('%s/pmc_%s_*/*/*_counter_collection.csv' % (O, m)):
+        for r in csv.DictReader(open(fn)):
+            if any(p in r['Kernel_Name'] for p in pats):
+                acc[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
+    out.append('## --model %s' % m)
+    for k in acc:
+        out.append(k)
+        for c, v in sorted(acc[k].items()):
+            out.append('    %-30s n=%d mean=%.6g' % (c, len(v), sum(v) / len(v)))
+open('profiles/%s_pmc_small.txt' % tag, 'w').write('\n'.join(out) + '\n')
+print('\n'.join(out))
