@@ -12,13 +12,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('AMICO_AMD_LIB') or os.path.join(_HERE, 'csrc', 'libamico_amd.so')   # override: A/B builds
 
 AMX_OK, AMX_E_BADARG, AMX_E_HIP, AMX_E_DIR_OOB, AMX_E_OVERFLOW, AMX_E_NODEVICE = 0, -1, -2, -3, -4, -5
-F_RMSE, F_NRMSE, F_MODULATED, F_CORRECTED = 1, 2, 4, 8
+F_RMSE, F_NRMSE, F_MODULATED, F_CORRECTED, F_DEBUG_X = 1, 2, 4, 8, 16
 
 # every symbol include/amico_amd.h declares (tests check that the library exports them all)
 SYMBOLS = ['amx_version', 'amx_ctx_create', 'amx_ctx_destroy', 'amx_last_error',
            'amx_lut_upload_noddi', 'amx_lut_upload_freewater', 'amx_lut_upload_sandi', 'amx_lut_destroy',
            'amx_dir_to_lut_idx', 'amx_noddi_fit', 'amx_freewater_fit', 'amx_sandi_fit',
            'amx_noddi_fit_device', 'amx_freewater_fit_device', 'amx_sandi_fit_device', 'amx_sync_status',
+           'amx_set_debug_x',
            'amx_set_profiling', 'amx_last_kernel_ms', 'amx_last_stats', 'amx_selftest',
            'amx_dti_create', 'amx_dti_destroy', 'amx_dti_directions', 'amx_dti_directions_device',
            'amx_prep_create', 'amx_prep_destroy', 'amx_prep_gather', 'amx_prep_gather_device',
@@ -80,6 +81,7 @@ def lib():
     L.amx_sandi_fit_device.argtypes = [c_vp, c_vp, c_vp, C.c_int64, C.c_double, C.c_double, C.c_uint,
                                        c_vp, c_vp, c_vp, c_vp]
     L.amx_sync_status.argtypes = [c_vp, c_vp]
+    L.amx_set_debug_x.argtypes = [c_vp, c_vp]
     L.amx_set_profiling.argtypes = [c_vp, C.c_int]
     L.amx_last_kernel_ms.argtypes = [c_vp, C.c_int, C.POINTER(C.c_float)]
     L.amx_last_stats.argtypes = [c_vp, c_i64p]
@@ -168,8 +170,8 @@ class Context:
 class Lut:
     """amx_lut: device-resident dictionary."""
 
-    def __init__(self, ctx, handle, model, nS, n_maps=None):
-        self.ctx, self._h, self.model, self.nS = ctx, handle, model, nS
+    def __init__(self, ctx, handle, model, nS, n_atoms, n_maps=None):
+        self.ctx, self._h, self.model, self.nS, self.n_atoms, self.n_maps = ctx, handle, model, nS, n_atoms, n_maps
 
     def close(self):
         if getattr(self, '_h', None) and getattr(self.ctx, '_h', None):
@@ -201,7 +203,7 @@ def upload_noddi(ctx, kernels, htable, dwi_idx, is_exvivo=False):
     ctx.check(lib().amx_lut_upload_noddi(ctx._h, _p(wm, c_fp), _p(iso, c_fp), _p(norms, c_dp), _p(icvf, c_fp),
                                          _p(kappa, c_fp), _p(ht, c_i16p), _p(dwi, c_i64p), n_wm, ndirs, nS,
                                          len(dwi), int(bool(is_exvivo)), C.byref(h)))
-    return Lut(ctx, h, 'NODDI', nS)
+    return Lut(ctx, h, 'NODDI', nS, n_wm + 1 + (1 if is_exvivo else 0), 3 + (1 if is_exvivo else 0))
 
 
 def upload_freewater(ctx, kernels, htable):
@@ -215,7 +217,7 @@ def upload_freewater(ctx, kernels, htable):
     h = c_vp()
     ctx.check(lib().amx_lut_upload_freewater(ctx._h, _p(D, c_fp), _p(CSF, c_fp), _p(ht, c_i16p), D.shape[0],
                                              CSF.shape[0], D.shape[1], D.shape[2], C.byref(h)))
-    return Lut(ctx, h, 'FreeWater', D.shape[2])
+    return Lut(ctx, h, 'FreeWater', D.shape[2], D.shape[0] + CSF.shape[0])
 
 
 def upload_sandi(ctx, kernels, Rs, d_in, d_isos):
@@ -230,7 +232,7 @@ def upload_sandi(ctx, kernels, Rs, d_in, d_isos):
     h = c_vp()
     ctx.check(lib().amx_lut_upload_sandi(ctx._h, _p(sig, c_dp), _p(norms, c_dp), _p(Rs, c_dp), _p(d_in, c_dp),
                                          _p(d_isos, c_dp), nS, len(Rs), len(d_in), len(d_isos), C.byref(h)))
-    return Lut(ctx, h, 'SANDI', nS)
+    return Lut(ctx, h, 'SANDI', nS, n_atoms, 6)
 
 
 def _check_y(y, nS):
@@ -294,24 +296,53 @@ def _dptr(t):
     return c_vp(t.data_ptr()) if t is not None else None
 
 
-def noddi_fit_device(ctx, lut, y_t, dirs_t, lambda1, lambda2, n_maps, rmse=False, nrmse=False, mod=False, stream=None):
+def _check_dev(lut, y_t, dirs_t=None):
+    """the kernels index `y` with the dictionary's nS as the row stride and `DIRs` with stride 3: anything else
+    would read foreign memory and return garbage maps without an error"""
     import torch
+    if y_t.dtype != torch.float64 or y_t.dim() != 2 or y_t.shape[1] != lut.nS or not y_t.is_contiguous():
+        raise ValueError(f'y must be a contiguous float64 device tensor [n_vox, {lut.nS}] (the dictionary was built for '
+                         f'{lut.nS} volumes per voxel)')
+    if dirs_t is not None and (dirs_t.dtype != torch.float64 or tuple(dirs_t.shape) != (y_t.shape[0], 3)
+                               or not dirs_t.is_contiguous() or dirs_t.device != y_t.device):
+        raise ValueError('DIRs must be a contiguous float64 device tensor [n_vox, 3] on the device of y')
+
+
+def _debug_x(ctx, shape, like, want):
+    """registers a zeroed coefficient buffer for AMX_F_DEBUG_X (include/amico_amd.h) and returns (tensor, flag)"""
+    import torch
+    if not want:
+        return None, 0
+    x = torch.zeros(shape, dtype=torch.float64, device=like.device)
+    ctx.check(lib().amx_set_debug_x(ctx._h, _dptr(x)))
+    return x, F_DEBUG_X
+
+
+def noddi_fit_device(ctx, lut, y_t, dirs_t, lambda1, lambda2, n_maps, rmse=False, nrmse=False, mod=False, stream=None,
+                     return_x=False):
+    import torch
+    _check_dev(lut, y_t, dirs_t)
+    if lut.n_maps is not None and n_maps != lut.n_maps:
+        raise ValueError(f'the dictionary writes {lut.n_maps} maps per voxel, the model expects {n_maps} (isExvivo changed?)')
     n, f64 = y_t.shape[0], dict(dtype=torch.float64, device=y_t.device)
-    flags = (F_RMSE if rmse else 0) | (F_NRMSE if nrmse else 0) | (F_MODULATED if mod else 0)
+    xd, fx = _debug_x(ctx, (n, 3, lut.n_atoms), y_t, return_x)
+    flags = (F_RMSE if rmse else 0) | (F_NRMSE if nrmse else 0) | (F_MODULATED if mod else 0) | fx
     est = torch.empty((n, n_maps), **f64)
     r = torch.empty(n, **f64) if rmse else None
     nr = torch.empty(n, **f64) if nrmse else None
     md = torch.empty((n, 2), **f64) if mod else None
     ctx.check(lib().amx_noddi_fit_device(ctx._h, lut._h, _dptr(y_t), _dptr(dirs_t), n, float(lambda1), float(lambda2), flags,
                                          _dptr(est), _dptr(r), _dptr(nr), _dptr(md), c_vp(stream or 0)))
-    return est, r, nr, md
+    return (est, r, nr, md, xd) if return_x else (est, r, nr, md)
 
 
 def freewater_fit_device(ctx, lut, y_t, dirs_t, lambda1, lambda2, is_mouse, rmse=False, nrmse=False, corrected=False,
-                         stream=None):
+                         stream=None, return_x=False):
     import torch
+    _check_dev(lut, y_t, dirs_t)
     n, f64 = y_t.shape[0], dict(dtype=torch.float64, device=y_t.device)
-    flags = (F_RMSE if rmse else 0) | (F_NRMSE if nrmse else 0) | (F_CORRECTED if corrected else 0)
+    xd, fx = _debug_x(ctx, (n, lut.n_atoms), y_t, return_x)
+    flags = (F_RMSE if rmse else 0) | (F_NRMSE if nrmse else 0) | (F_CORRECTED if corrected else 0) | fx
     est = torch.empty((n, 4 if is_mouse else 2), **f64)
     r = torch.empty(n, **f64) if rmse else None
     nr = torch.empty(n, **f64) if nrmse else None
@@ -319,19 +350,21 @@ def freewater_fit_device(ctx, lut, y_t, dirs_t, lambda1, lambda2, is_mouse, rmse
     ctx.check(lib().amx_freewater_fit_device(ctx._h, lut._h, _dptr(y_t), _dptr(dirs_t), n, float(lambda1), float(lambda2),
                                              int(bool(is_mouse)), flags, _dptr(est), _dptr(r), _dptr(nr), _dptr(yc),
                                              c_vp(stream or 0)))
-    return est, r, nr, yc
+    return (est, r, nr, yc, xd) if return_x else (est, r, nr, yc)
 
 
-def sandi_fit_device(ctx, lut, y_t, lambda1, lambda2, rmse=False, nrmse=False, stream=None):
+def sandi_fit_device(ctx, lut, y_t, lambda1, lambda2, rmse=False, nrmse=False, stream=None, return_x=False):
     import torch
+    _check_dev(lut, y_t)
     n, f64 = y_t.shape[0], dict(dtype=torch.float64, device=y_t.device)
-    flags = (F_RMSE if rmse else 0) | (F_NRMSE if nrmse else 0)
+    xd, fx = _debug_x(ctx, (n, lut.n_atoms), y_t, return_x)
+    flags = (F_RMSE if rmse else 0) | (F_NRMSE if nrmse else 0) | fx
     est = torch.empty((n, 6), **f64)
     r = torch.empty(n, **f64) if rmse else None
     nr = torch.empty(n, **f64) if nrmse else None
     ctx.check(lib().amx_sandi_fit_device(ctx._h, lut._h, _dptr(y_t), n, float(lambda1), float(lambda2), flags, _dptr(est),
                                          _dptr(r), _dptr(nr), c_vp(stream or 0)))
-    return est, r, nr
+    return (est, r, nr, xd) if return_x else (est, r, nr)
 
 
 def dir_to_lut_idx(ctx, lut, dirs):

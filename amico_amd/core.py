@@ -78,6 +78,8 @@ class Evaluation:
     @DIRs.setter
     def DIRs(self, value):
         self._DIRs = value
+        if self._dev is not None:
+            self._dev.pop('dirs', None)       # directions assigned by the caller replace the ones held in HBM
 
     def set_config(self, key, value):
         self.CONFIG[key] = value
@@ -104,9 +106,11 @@ class Evaluation:
             else np.asarray(mask, dtype=np.uint8)
         if self.niiMASK_img.shape != self.niiDWI_img.shape[:3]:
             raise ValueError('MASK geometry does not match with DWI data')
-        if directions is not None and np.shape(directions)[:3] != self.niiMASK_img.shape:
+        if directions is not None and (np.ndim(directions) != 4 or np.shape(directions)[:3] != self.niiMASK_img.shape
+                                       or np.shape(directions)[3] < 3):
             raise ValueError('PEAKS geometry does not match with DWI data')      # core.py:444-445
-        self._dirs_img = None if directions is None else np.asarray(directions, dtype=np.float32)   # core.py:442
+        # a peaks file holds 3*npeaks values per voxel: the fit uses the first peak
+        self._dirs_img = None if directions is None else np.ascontiguousarray(np.asarray(directions, dtype=np.float32)[..., :3])   # core.py:442
         self._raw_scheme = scheme
         self._prep = _prep.SignalPreparation(
             scheme, self.niiDWI_img, self.niiMASK_img, do_normalize=self.get_config('doNormalizeSignal'),

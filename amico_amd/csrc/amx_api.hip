@@ -332,6 +332,13 @@ int amx_sync_status(amx_ctx *ctx, void *hip_stream)
     return AMX_OK;
 }
 
+int amx_set_debug_x(amx_ctx *ctx, double *d_x)
+{
+    if (!ctx) return AMX_E_BADARG;
+    ctx->dbg_x = d_x;
+    return AMX_OK;
+}
+
 int amx_selftest(amx_ctx *ctx, double *out512)
 {
     if (!ctx || !out512) return AMX_E_BADARG;
@@ -399,6 +406,10 @@ int amx_noddi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
     a.rowdwi = lut->rowdwi; a.colscale = lut->colscale; a.icvf = lut->icvf; a.kappa = lut->kappa;
     a.n_wm = lut->n_wm; a.is_exvivo = lut->is_exvivo; a.n_maps = 3 + (lut->is_exvivo ? 1 : 0);
     a.gram = lut->gram; a.gram_dwi = lut->gram_dwi; a.ldG = lut->ldG;
+    if (flags & AMX_F_DEBUG_X) {
+        if (!ctx->dbg_x) return bad(ctx, "amx_noddi_fit: AMX_F_DEBUG_X without a buffer (amx_set_debug_x)");
+        a.c.xdbg = ctx->dbg_x + (size_t)ctx->vox_base * 3 * lut->n_atoms;
+    }
     a.xiso = (double *)ctx->xiso.p; a.supp = (unsigned long long *)ctx->supp.p;
     a.est = d_estimates; a.rmse = (flags & AMX_F_RMSE) ? d_rmse : nullptr;
     a.nrmse = (flags & AMX_F_NRMSE) ? d_nrmse : nullptr; a.mod = (flags & AMX_F_MODULATED) ? d_mod : nullptr;
@@ -438,6 +449,10 @@ int amx_freewater_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y
     a.c.lutidx = pl.lutidx; a.c.status = ctx->status_d; a.c.nS = lut->nS; a.c.ldA = lut->ldA;
     a.c.n_atoms = lut->n_atoms; a.c.tile_stride = lut->tile_stride; a.c.lam1 = lambda1; a.c.lam2 = lambda2; a.c.flags = flags;
     a.n_perp = lut->n_perp; a.n_iso = lut->n_iso; a.is_mouse = is_mouse; a.n_maps = is_mouse ? 4 : 2;
+    if (flags & AMX_F_DEBUG_X) {
+        if (!ctx->dbg_x) return bad(ctx, "amx_freewater_fit: AMX_F_DEBUG_X without a buffer (amx_set_debug_x)");
+        a.c.xdbg = ctx->dbg_x + (size_t)ctx->vox_base * lut->n_atoms;
+    }
     a.est = d_estimates; a.rmse = (flags & AMX_F_RMSE) ? d_rmse : nullptr;
     a.nrmse = (flags & AMX_F_NRMSE) ? d_nrmse : nullptr; a.ycorr = (flags & AMX_F_CORRECTED) ? d_ycorr : nullptr;
     HIPCHK(ctx, hipMemsetAsync(d_estimates, 0, (size_t)n_vox * a.n_maps * sizeof(double), s));
@@ -475,6 +490,10 @@ int amx_sandi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, in
     a.c.n_atoms = lut->n_atoms; a.c.tile_stride = lut->tile_stride; a.c.lam1 = lambda1; a.c.lam2 = lambda2; a.c.flags = flags;
     a.norms = lut->norms; a.Rs = lut->Rs; a.d_in = lut->d_in; a.d_isos = lut->d_isos;
     a.n_rs = lut->n_rs; a.n_in = lut->n_in; a.n_iso = lut->n_isos;
+    if (flags & AMX_F_DEBUG_X) {
+        if (!ctx->dbg_x) return bad(ctx, "amx_sandi_fit: AMX_F_DEBUG_X without a buffer (amx_set_debug_x)");
+        a.c.xdbg = ctx->dbg_x + (size_t)ctx->vox_base * lut->n_atoms;
+    }
     a.est = d_estimates; a.rmse = (flags & AMX_F_RMSE) ? d_rmse : nullptr; a.nrmse = (flags & AMX_F_NRMSE) ? d_nrmse : nullptr;
     rc = amx_launch_sandi(ctx, a, pl, s);
     hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, s, (const int *)ctx->misc.p, ctx->status_d);

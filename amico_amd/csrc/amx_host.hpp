@@ -33,6 +33,7 @@ struct amx_ctx {
     bool ev_valid[kEv];
     int64_t stats[4] = {0, 0, 0, 0};
     int64_t vox_base = 0;          // index of the first voxel of the batch being enqueued (chunked host entry points)
+    double *dbg_x = nullptr;       // AMX_F_DEBUG_X destination (caller-owned device buffer, amx_set_debug_x)
     hipStream_t hs = nullptr;      // non-blocking compute stream of the chunked host entry points
     hipEvent_t hev[2] = {nullptr, nullptr};
 };

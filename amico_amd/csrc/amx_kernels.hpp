@@ -36,6 +36,7 @@ struct FitCommon {
     int tile_stride;              // elements between consecutive orientation tiles (multiple of 4)
     double lam1, lam2;
     unsigned flags;
+    double *xdbg;                 // AMX_F_DEBUG_X: coefficient vectors, [n_vox][n_stage][n_atoms] (null = off)
 };
 
 template <typename AT>
@@ -61,6 +62,21 @@ __device__ __forceinline__ bool load_rows(const double *__restrict__ yv, int nS,
         finite = finite && (fabs(yr[rr]) <= 1.79769313486231570e308);
     }
     return ballot64(!finite) == 0ull;
+}
+
+// AMX_F_DEBUG_X: dense coefficient vector of one voxel from slot space (lane s < np: atom idx, value xv); exact zeros
+// off the passive set (the contract of cyspams nnls / lasso: `x` fully written).  Diagnosis path: two store phases
+// separated by a wait, so the zeros cannot overtake the values.
+template <int NQ>
+__device__ __forceinline__ void store_x_dense(double *dst, int n_atoms, int lane, int np, int idx, double xv)
+{
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const int j = lane + kWave * q;
+        if (j < n_atoms) dst[j] = 0.0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane < np && idx >= 0 && idx < n_atoms) dst[idx] = xv;
 }
 
 // ------------------------------------------------------------------ NODDI
@@ -177,6 +193,18 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const float *As,
     if (lane == 0) { constexpr int sx = kLasso ? 1 : STAGE - 1; atomicAdd(&a.c.status[ST_EXACT + sx], S.n_exact); atomicAdd(&a.c.status[ST_GRAM + sx], S.n_gram); atomicAdd(&a.c.status[ST_ITERS + sx], S.iters); }
 #endif
     const bool act = lane < S.np;
+    if (a.c.xdbg) {
+        // rows: 0 = NNLS over all atoms, 1 = LASSO coefficients (normalised columns) with the stage-1 iso (dot)
+        // coefficients kept behind them (the reference reuses one `x` array, models.pyx:911-926), 2 = debiased x
+        constexpr int row = (STAGE == 1) ? 0 : (kLasso ? 1 : 2);
+        double *dst = a.c.xdbg + ((size_t)vox * 3 + row) * n_atoms;
+        store_x_dense<NQ>(dst, n_atoms, lane, S.np, S.idx, S.x);
+        if (kLasso && lane == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            dst[iso_atom] = a.xiso[(size_t)vox * 2];
+            if (dot_atom >= 0) dst[dot_atom] = a.xiso[(size_t)vox * 2 + 1];
+        }
+    }
 
     if constexpr (STAGE == 1) {
         const double xi = wave_sum((act && S.idx == iso_atom) ? S.x : 0.0);
@@ -267,6 +295,7 @@ __device__ __forceinline__ void fw_voxel(const FwArgs &a, const float *As, doubl
     if (st > kIterCap && lane == 0) { atomicAdd(&a.c.status[ST_GUARD], 1); a.c.status[ST_GUARDVOX] = vox * 8 + st; }
     const bool act = lane < S.np;
     const double xs = act ? S.x : 0.0;
+    if (a.c.xdbg) store_x_dense<NQ>(a.c.xdbg + (size_t)vox * n_atoms, n_atoms, lane, S.np, S.idx, S.x);
     // models.pyx:1241-1256
     const double x_sum = wave_sum(xs) + 1e-16;
     const double v = wave_sum((act && S.idx < n_perp) ? xs : 0.0) / x_sum;
@@ -351,6 +380,7 @@ __device__ __forceinline__ void sandi_voxel(const SandiArgs &a, const double *As
     const bool act = lane < S.np;
     const int at = act ? S.idx : 0;
     const double xs = act ? S.x * a.norms[at] : 0.0;                       // models.pyx:1570-1571
+    if (a.c.xdbg) store_x_dense<NQ>(a.c.xdbg + (size_t)vox * n_atoms, n_atoms, lane, S.np, S.idx, xs);
     const bool sph = act && at < n_rs, stk = act && at >= n_rs && at < n_rs + n_in, iso = act && at >= n_rs + n_in;
     const double x_sum = wave_sum(xs) + 1e-16;
     double xsph = wave_sum(sph ? xs : 0.0), xstk = wave_sum(stk ? xs : 0.0), xiso = wave_sum(iso ? xs : 0.0);

@@ -225,6 +225,10 @@ __global__ void __launch_bounds__(256) k_freewater_lane(const FwArgs a)
 #else
         if (lane_nnqp<N>(Hs, c, x) != 0) atomicAdd(&a.c.status[ST_ITCAP], 1);
 #endif
+        if (a.c.xdbg) {
+#pragma unroll
+            for (int j = 0; j < N; j++) if (j < n_atoms) a.c.xdbg[(size_t)vox * n_atoms + j] = x[j];
+        }
         // models.pyx:1241-1256
         double x_sum = 0.0, x_perp = 0.0;
 #pragma unroll
@@ -292,6 +296,10 @@ __global__ void __launch_bounds__(256) k_sandi_lane(const SandiArgs a)
                 else if (j < n_rs + n_in) { xstk += x[j]; Din += a.d_in[j - n_rs] * x[j]; }
                 else { xiso += x[j]; De += a.d_isos[j - n_rs - n_in] * x[j]; }
             }
+        }
+        if (a.c.xdbg) {                                   // the rescaled x (models.pyx:1570-1571)
+#pragma unroll
+            for (int j = 0; j < N; j++) if (j < n_atoms) a.c.xdbg[(size_t)vox * n_atoms + j] = x[j];
         }
         x_sum += 1e-16;
         e[0] = xsph / x_sum; e[1] = xstk / x_sum; e[2] = xiso / x_sum;
@@ -509,6 +517,10 @@ __global__ void __launch_bounds__(256, AMX_ROWS_OCC) k_sandi_rows(const SandiArg
                 else if (j < n_rs + n_in) { xstk += x[j]; Din += a.d_in[j - n_rs] * x[j]; }
                 else { xiso += x[j]; De += a.d_isos[j - n_rs - n_in] * x[j]; }
             }
+        }
+        if (a.c.xdbg) {                                   // the rescaled x (models.pyx:1570-1571)
+#pragma unroll
+            for (int j = 0; j < N; j++) if (j < n_atoms) a.c.xdbg[(size_t)vox * n_atoms + j] = x[j];
         }
         x_sum += 1e-16;
         e[0] = xsph / x_sum; e[1] = xstk / x_sum; e[2] = xiso / x_sum;

@@ -104,14 +104,35 @@ class BaseModel(ABC):
         dev['out'] = {k: v for k, v in named.items() if v is not None}
         return {k: v.cpu().numpy() for k, v in dev['out'].items()}
 
-    # ---- dictionary cache: one upload per (KERNELS, htable) object pair
+    @staticmethod
+    def _dev_dirs(evaluation, dev):
+        """directions of the device-resident path: the tensor Evaluation.fit left in HBM, or -- when the caller has
+        assigned `evaluation.DIRs` since -- that array, uploaded"""
+        d = dev.get('dirs')
+        if d is None and getattr(evaluation, '_DIRs', None) is not None:
+            import torch
+            d = torch.from_numpy(np.ascontiguousarray(evaluation._DIRs, dtype=np.float64)).to(dev['y'].device)
+            dev['dirs'] = d
+        return d
+
+    # ---- dictionary cache: one upload per (KERNELS, htable) object pair AND model / scheme state that shapes the
+    #      device dictionary.  The keyed objects are held (an id() can be recycled once its object is collected), and
+    #      a cheap content fingerprint catches in-place edits of KERNELS.
+    def _lut_extra_key(self):
+        return ()
+
     def _lut(self, evaluation, builder):
-        key = (id(evaluation.KERNELS), id(getattr(evaluation, 'htable', None)))
+        K, ht = evaluation.KERNELS, getattr(evaluation, 'htable', None)
+        finger = tuple((k, getattr(v, 'shape', None), float(np.asarray(v).ravel()[:: max(1, np.asarray(v).size // 64)].sum()))
+                       for k, v in sorted(K.items()) if isinstance(v, np.ndarray))
+        sc = self.scheme
+        skey = None if sc is None else (int(getattr(sc, 'nS', 0)), tuple(np.asarray(getattr(sc, 'dwi_idx', ())).tolist()))
+        key = (id(K), id(ht), finger, skey, self._lut_extra_key())
         cache = getattr(self, '_lut_cache', None)
         if cache is None or cache[0] != key:
-            if evaluation.KERNELS.get('model') != self.id:
+            if K.get('model') != self.id:
                 raise ValueError('Response functions were not created with the same model')
-            self._lut_cache = (key, builder())
+            self._lut_cache = (key, builder(), K, ht)          # K, ht: strong references to the keyed objects
         return self._lut_cache[1]
 
 
@@ -141,6 +162,9 @@ class NODDI(BaseModel):
     def get_params(self):
         return {'id': self.id, 'name': self.name, 'dPar': self.dPar, 'dIso': self.dIso, 'IC_VFs': self.IC_VFs,
                 'IC_ODs': self.IC_ODs, 'isExvivo': self.isExvivo}
+
+    def _lut_extra_key(self):
+        return (bool(self.isExvivo),)
 
     def set_solver(self, lambda1=5e-1, lambda2=1e-3):
         super().set_solver()
@@ -175,7 +199,7 @@ class NODDI(BaseModel):
         dev = getattr(evaluation, '_dev', None)
         if dev is not None:
             est, rmse, nrmse, mod = _capi.noddi_fit_device(
-                ctx, lut, dev['y'], dev['dirs'], self.solver_params['lambda1'], self.solver_params['lambda2'],
+                ctx, lut, dev['y'], self._dev_dirs(evaluation, dev), self.solver_params['lambda1'], self.solver_params['lambda2'],
                 len(self.maps_name), rmse=bool(self.configs['compute_rmse']), nrmse=bool(self.configs['compute_nrmse']),
                 mod=bool(self.configs['compute_modulated_maps']))
             return self._finish_device(ctx, dev, {'estimates': est, 'rmse': rmse, 'nrmse': nrmse, 'estimates_mod': mod})
@@ -247,7 +271,7 @@ class FreeWater(BaseModel):
         dev = getattr(evaluation, '_dev', None)
         if dev is not None:
             est, rmse, nrmse, yc = _capi.freewater_fit_device(
-                ctx, lut, dev['y'], dev['dirs'], self.solver_params['lambda1'], self.solver_params['lambda2'],
+                ctx, lut, dev['y'], self._dev_dirs(evaluation, dev), self.solver_params['lambda1'], self.solver_params['lambda2'],
                 self.type == 'Mouse', rmse=bool(self.configs['compute_rmse']), nrmse=bool(self.configs['compute_nrmse']),
                 corrected=bool(self.configs['save_corrected_DWI']))
             return self._finish_device(ctx, dev, {'estimates': est, 'rmse': rmse, 'nrmse': nrmse, 'y_corrected': yc})
@@ -289,6 +313,9 @@ class SANDI(BaseModel):
     def get_params(self):
         return {'id': self.id, 'name': self.name, 'd_is': self.d_is, 'Rs': self.Rs, 'd_in': self.d_in,
                 'd_isos': self.d_isos}
+
+    def _lut_extra_key(self):
+        return tuple(np.asarray(v, dtype=np.float64).tobytes() for v in (self.Rs, self.d_in, self.d_isos))
 
     def set_solver(self, lambda1=0.0, lambda2=5.0E-3):
         super().set_solver()

@@ -32,6 +32,7 @@ extern "C" {
 #define AMX_F_NRMSE         2u  /* doComputeNRMSE       -> out_nrmse  f64[n_vox]      */
 #define AMX_F_MODULATED     4u  /* doSaveModulatedMaps  -> out_mod    f64[n_vox][2]   */
 #define AMX_F_CORRECTED     8u  /* doSaveCorrectedDWI   -> out_ycorr  f64[n_vox][nS]  */
+#define AMX_F_DEBUG_X      16u  /* solver coefficients  -> the buffer registered with amx_set_debug_x */
 
 typedef struct amx_ctx amx_ctx;   /* one per process+GPU: stream-ordered workspace, error state */
 typedef struct amx_lut amx_lut;   /* device-resident dictionary (KERNELS) of one model          */
@@ -102,6 +103,18 @@ int amx_sandi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, in
                          double lambda1, double lambda2, unsigned flags, double *d_estimates,
                          double *d_rmse, double *d_nrmse, void *hip_stream);
 int amx_sync_status(amx_ctx *ctx, void *hip_stream);
+
+/* ---- the solvers' own output: the coefficient vectors `x` that cyspams.interfaces.nnls / lasso hand back to
+ * _fit (models.pyx:911, 926, 940, 1238, 1569: `x` fully written, exact zeros off the support).  The reference keeps
+ * them internal; here they are observable so that tests can certify the DEVICE solution itself (KKT conditions,
+ * supports), not only the maps derived from it.  d_x is a DEVICE buffer the caller owns (zero it first; NULL
+ * unregisters).  Every later *_fit / *_fit_device call on this ctx whose flags carry AMX_F_DEBUG_X fills it:
+ *   NODDI      f64[n_vox][3][n_atoms]: row 0 = stage-1 NNLS over all atoms (wm..., [dot,] iso); row 1 = LASSO
+ *              coefficients of the wm atoms (column-normalised dictionary, models.pyx:917-921) followed by the
+ *              stage-1 iso (dot) coefficients (the reference reuses one array); row 2 = the debiased x (:940-942)
+ *   FreeWater  f64[n_vox][n_atoms]    the lasso solution (models.pyx:1238)
+ *   SANDI      f64[n_vox][n_atoms]    the lasso solution rescaled by KERNELS['norms'] (models.pyx:1570-1571)   */
+int amx_set_debug_x(amx_ctx *ctx, double *d_x);
 
 /* ---- next rows of the hot-path table (SURVEY.md section 8 f): the steps either side of model.fit ---- */
 

@@ -7,6 +7,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-6
+CAP = 1e-4      # BASELINE.json's bar, held on EVERY voxel (no voxel may be an uncapped outlier)
 
 
 class Holder:
@@ -80,6 +81,7 @@ def test_noddi_vs_oracle_synthetic(htable500):
     # support decisions on numerically degenerate voxels may differ between ANY two solvers;
     # allow a vanishing fraction of such voxels
     assert (diff < TOL).mean() > 0.999, (diff > TOL).sum()
+    assert diff.max() < CAP, diff.max()
     assert np.abs(out['rmse'] - ref['rmse']).max() < 1e-6
     assert np.median(diff) < 1e-10
 
@@ -100,6 +102,7 @@ def test_noddi_exvivo_and_lambdas(htable500):
     assert out['estimates'].shape == (1500, 4)
     diff = np.abs(out['estimates'] - ref['estimates']).max(axis=1)
     assert (diff < TOL).mean() > 0.998
+    assert diff.max() < CAP, diff.max()
 
 
 def test_freewater_golden_and_oracle(fw_fix, htable500):
@@ -192,6 +195,7 @@ def test_evaluation_harness_plumbing(htable500):
     ref = oracle.noddi_fit(y_ref, d_ref, K, ht, sch.dwi_idx, nthreads=8, rmse=True)
     diff = np.abs(ae.RESULTS['MAPs'][sel] - ref['estimates'].astype(np.float32)).max(axis=1)
     assert (diff < 1e-5).mean() > 0.999
+    assert diff.max() < CAP, diff.max()             # same directions on both sides: every voxel is held to the cap
     assert not ae.RESULTS['MAPs'][0, 0].any()
     assert ae.RESULTS['RMSE'].shape == (32, 32, 8) and np.allclose(ae.RESULTS['RMSE'][sel], ref['rmse'], atol=1e-6)
 
@@ -224,6 +228,8 @@ def test_evaluation_end_to_end_from_raw_volume(htable500):
     assert np.abs(np.abs((ae.DIRs[ok] * d_ref[ok]).sum(1)) - 1.0).max() < 1e-12
     ref = oracle.noddi_fit(y_ref, d_ref, K, ht, sch.dwi_idx, nthreads=8)
     diff = np.abs(ae.RESULTS['MAPs'][sel] - ref['estimates'].astype(np.float32)).max(axis=1)
+    # (directions come from two eigen-solvers here, ~1e-13 apart: a voxel on the boundary of two LUT cells may get
+    #  the neighbouring dictionary orientation, so only this test keeps a fraction instead of a cap on every voxel)
     assert (diff < 1e-5).mean() > 0.999
     assert ae.RESULTS['DIRs'].shape == shape + (3,) and ae.RESULTS['MAPs_mod'].shape == shape + (2,)
     assert not ae.RESULTS['MAPs'][~sel].any()
@@ -266,6 +272,7 @@ def test_other_protocol_shapes(htable500):
     ref = oracle.noddi_fit(y, d, K, ht, sch.dwi_idx, nthreads=8, nrmse=True)
     diff = np.abs(out['estimates'] - ref['estimates']).max(axis=1)
     assert (diff < TOL).mean() > 0.998, (diff > TOL).sum()
+    assert diff.max() < CAP, diff.max()
     assert np.abs(out['nrmse'] - ref['nrmse']).max() < 1e-6
     # (b) 150-volume protocol, default dictionary
     sch2 = S.make_scheme(10, ((700.0, 40), (2000.0, 60), (3000.0, 40)), seed=8)
@@ -277,6 +284,7 @@ def test_other_protocol_shapes(htable500):
     ref2 = oracle.noddi_fit(y2, d2, K2, ht, sch2.dwi_idx, nthreads=8)
     diff2 = np.abs(out2['estimates'] - ref2['estimates']).max(axis=1)
     assert (diff2 < TOL).mean() > 0.998, (diff2 > TOL).sum()
+    assert diff2.max() < CAP, diff2.max()
     # (c) FreeWater with 33 volumes
     sch3 = S.make_scheme(1, ((1000.0, 32),), seed=9)
     K3 = S.freewater_kernels(sch3, dirs)
