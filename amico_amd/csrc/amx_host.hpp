@@ -142,4 +142,9 @@ int amx_launch_sandi(amx_ctx *ctx, amx::SandiArgs &a, const Plan &pl, hipStream_
 // lane-per-voxel variants for dictionaries of <= 16 atoms (amx_small.hip)
 int amx_launch_fw_small(amx_ctx *ctx, amx::FwArgs &a, const Plan &pl, hipStream_t s);
 int amx_launch_sandi_small(amx_ctx *ctx, amx::SandiArgs &a, const Plan &pl, hipStream_t s);
+// NODDI NNLS stages, two voxels per wavefront (amx_pair.hpp; protocols that fit 32-lane halves: 4 volumes, 5 atoms per
+// lane).  OPT-IN (AMX_PAIR=1): certified by the same KKT tests, but measured SLOWER than the wavefront-per-voxel
+// kernels on MI355X (stage 1 17.9 vs 15.3 ms, stage 3 8.4 vs 7.8 ms per 1 M voxels; four voxels per wavefront 21.6 /
+// 9.4 ms) -- DESIGN.md section 5.
+static inline bool amx_use_pair(int nS, int n_atoms) { const char *e = getenv("AMX_PAIR"); return nS <= 128 && n_atoms <= 160 && e && *e && *e != '0'; }
 static inline bool amx_use_lane_solver(int n_atoms) { const char *e = getenv("AMX_WAVE_PER_VOXEL"); return n_atoms <= 16 && !(e && *e && *e != '0'); }

@@ -69,9 +69,12 @@ def _noddi_certificates(K, sch, ht, y, d, x, lam1, lam2):
     return out
 
 
-@pytest.mark.parametrize('snr', [30.0, 10.0])
-def test_noddi_kkt_certificates_and_supports(htable500, snr):
+@pytest.mark.parametrize('snr,mapping', [(30.0, 'wave'), (10.0, 'wave'), (10.0, 'pair')])
+def test_noddi_kkt_certificates_and_supports(htable500, snr, mapping, monkeypatch):
+    """mapping: 'wave' = one wavefront per voxel (default), 'pair' = two voxels per wavefront in the NNLS stages (opt-in)"""
     import torch
+    if mapping == 'pair':
+        monkeypatch.setenv('AMX_PAIR', '1')
     from amico_amd import _capi, get_context, synthetic as S
     from oracle import oracle
     dirs, ht = htable500['dirs'], htable500['htable']
