@@ -45,7 +45,7 @@ int make_plan(amx_ctx *ctx, int64_t n, int ndirs, Plan &pl)
     return AMX_OK;
 }
 
-int enqueue_bucketing(amx_ctx *ctx, const amx_lut *lut, const double *d_dirs, int64_t n, Plan &pl, hipStream_t s)
+int enqueue_bucketing(amx_ctx *ctx, const amx_lut *lut, const double *d_dirs, int64_t n, Plan &pl, hipStream_t s, int chunk = kChunk)
 {
     HIPCHK(ctx, hipMemsetAsync(pl.counts, 0, (size_t)(lut->ndirs + 1) * sizeof(int), s));
     HIPCHK(ctx, hipMemsetAsync(ctx->misc.p, 0, 64 * sizeof(int), s));
@@ -54,7 +54,7 @@ int enqueue_bucketing(amx_ctx *ctx, const amx_lut *lut, const double *d_dirs, in
     hipLaunchKernelGGL(k_dir_to_lut, dim3(nb), dim3(1024), use_lds ? (size_t)lut->ndirs * sizeof(int) : 0, s, d_dirs,
                        (int)n, lut->htable, lut->ndirs, pl.lutidx, pl.counts, ctx->status_d, use_lds, (int)ctx->vox_base);
     AMX_TRACE(ctx, s, "k_dir_to_lut");
-    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, pl.counts, lut->ndirs, kChunk, pl.dir_start,
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, pl.counts, lut->ndirs, chunk, pl.dir_start,
                        pl.cursor, pl.chunks, pl.n_chunks);
     AMX_TRACE(ctx, s, "k_plan");
     hipLaunchKernelGGL(k_bucket, dim3(nb), dim3(1024), use_lds ? (size_t)2 * lut->ndirs * sizeof(int) : 0, s, pl.lutidx,
@@ -442,7 +442,8 @@ int amx_freewater_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y
     Plan pl; int rc;
     if ((rc = make_plan(ctx, n_vox, lut->ndirs, pl))) return rc;
     rec(ctx, 0, s);
-    if ((rc = enqueue_bucketing(ctx, lut, d_dirs, n_vox, pl, s))) return rc;
+    const bool refill = amx_use_lane_solver(lut->n_atoms) && amx_fw_use_refill(lut->n_atoms, lut->nS, flags);
+    if ((rc = enqueue_bucketing(ctx, lut, d_dirs, n_vox, pl, s, refill ? amx_refill_chunk(n_vox) : kChunk))) return rc;
     FwArgs a;
     memset(&a, 0, sizeof a);
     a.c.tiles = lut->tiles; a.c.y = d_y; a.c.perm = pl.perm; a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks;

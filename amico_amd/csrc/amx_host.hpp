@@ -147,4 +147,24 @@ int amx_launch_sandi_small(amx_ctx *ctx, amx::SandiArgs &a, const Plan &pl, hipS
 // kernels on MI355X (stage 1 17.9 vs 15.3 ms, stage 3 8.4 vs 7.8 ms per 1 M voxels; four voxels per wavefront 21.6 /
 // 9.4 ms) -- DESIGN.md section 5.
 static inline bool amx_use_pair(int nS, int n_atoms) { const char *e = getenv("AMX_PAIR"); return nS <= 128 && n_atoms <= 160 && e && *e && *e != '0'; }
+// FreeWater with lanes that never idle (k_freewater_refill, amx_small.hip): maps only (the error maps / corrected DWI
+// need the signal again and stay with k_freewater_lane), <= 12 atoms; chunks of up to 4096 voxels per workgroup
+// voxels of one orientation per workgroup of the refill kernel: large enough to keep the lanes fed (the buffer needs a
+// pool to draw from), small enough for ~3 rounds of workgroups over the chip (measured on 2 M voxels: 512 -> 1.83 ms,
+// 1024 -> 1.79, 2048 -> 1.93, 4096 -> 2.54)
+static inline int amx_refill_chunk(long long n_vox)
+{
+    const char *e = getenv("AMX_REFILL_CHUNK");
+    const int v = e ? atoi(e) : 0;
+    if (v >= 64) return v;
+    const long long c = n_vox / 1536;
+    return (int)(c < 512 ? 512 : (c > 2048 ? 2048 : c));
+}
+static inline bool amx_fw_use_refill(int n_atoms, int nS, unsigned flags)
+{
+    const char *e = getenv("AMX_NO_REFILL"), *w = getenv("AMX_WAVE_PER_VOXEL");
+    if ((e && *e && *e != '0') || (w && *w && *w != '0')) return false;
+    return n_atoms <= 12 && (flags & (AMX_F_RMSE | AMX_F_NRMSE | AMX_F_CORRECTED)) == 0 &&
+           ((size_t)nS * 12 + 144 + 4 * (16 * 65 + 12 * 64 + 32)) * sizeof(double) + 16 <= 80 * 1024;
+}
 static inline bool amx_use_lane_solver(int n_atoms) { const char *e = getenv("AMX_WAVE_PER_VOXEL"); return n_atoms <= 16 && !(e && *e && *e != '0'); }

@@ -543,6 +543,266 @@ __global__ void __launch_bounds__(256, AMX_ROWS_OCC) k_sandi_rows(const SandiArg
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// FreeWater, lanes that never idle: k_freewater_refill.
+//
+// k_freewater_lane runs one active-set solve per lane and a wavefront waits for its slowest lane: voxels need 3..20
+// steps (one Cholesky each), so a pass over 64 voxels costs the MAXIMUM step count (measured: ~23 steps' worth of
+// instructions for a mean of ~8), and every lane walks its own 520-byte signal row with 8-byte loads (one cache line
+// per lane and load; 64 rows = 33 KB per wavefront thrash the 32 KB L1).  Here
+//   * phase 1 (per batch of 64 voxels of the wavefront): the signal rows are read with COALESCED 16-byte loads (8
+//     lanes per row segment of 16 values), transposed through a small LDS tile (odd leading dimension: conflict-free
+//     both ways) and contracted with the fp64 dictionary to c = A'y by the lane that owns the voxel; the c vectors
+//     wait in an LDS buffer of the wavefront;
+//   * phase 2: every lane runs ONE active-set step per trip of a flat loop (select an atom if its solution is
+//     feasible, masked Cholesky + solves, accept or step back); a lane whose voxel reached its KKT point writes the
+//     maps and takes the next c vector from the buffer at once -- the wavefront refills the buffer (phase 1) when it
+//     runs dry.  The same per-voxel arithmetic as lane_nnqp, in the same order.
+// Chunks of amx_refill_chunk() voxels of one orientation per workgroup (the buffer needs a pool to draw from).
+constexpr int kTileRows = 16;          // signal values per voxel and transposition pass
+constexpr int kTileLd = 65;            // odd leading dimension (doubles) of the transposition tile [row][voxel]
+
+template <int N>
+__global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
+    const int cid = xcd_chunk((int)blockIdx.x, *a.c.n_chunks);
+    if (cid < 0) return;
+    const Chunk ck = a.c.chunks[cid];
+    const int nS = a.c.nS, ldA = a.c.ldA, n_atoms = a.c.n_atoms, n_perp = a.n_perp;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
+    // LDS: Ad f64 [nS][N] | Hs f64 [N][N] | per wavefront: Tt [kTileRows][kTileLd], Cb [N][64], Vb int[64] | ticket
+    double *Ad = reinterpret_cast<double *>(smem_r);
+    double *Hs = Ad + (size_t)nS * N;
+    double *wbase = Hs + N * N;
+    constexpr int kWaveWords = kTileRows * kTileLd + N * 64 + 32;
+    double *Tt = wbase + (size_t)wave * kWaveWords;
+    double *Cb = Tt + kTileRows * kTileLd;
+    int *Vb = reinterpret_cast<int *>(Cb + N * 64);
+    unsigned *ticket = reinterpret_cast<unsigned *>(wbase + (size_t)nw * kWaveWords);
+    {
+        const float *tile = reinterpret_cast<const float *>(a.c.tiles) + (size_t)ck.dir * a.c.tile_stride;
+        for (int e = threadIdx.x; e < nS * N; e += blockDim.x) {
+            const int i = e / N, j = e % N;
+            Ad[e] = (j < n_atoms) ? (double)tile[i * ldA + j] : 0.0;
+        }
+        if (threadIdx.x == 0) *ticket = 0u;
+        __syncthreads();
+        for (int e = threadIdx.x; e < N * N; e += blockDim.x) {
+            const int j = e / N, k = e % N;
+            double acc = (j == k) ? ((j < n_atoms) ? a.c.lam2 : 1.0) : 0.0;
+            if (j < n_atoms && k < n_atoms)
+                for (int i = 0; i < nS; i++) acc += Ad[i * N + j] * Ad[i * N + k];
+            Hs[e] = acc;
+        }
+        __syncthreads();
+    }
+    const double tol = 1e-12, inf = __builtin_huge_val();
+    const int n_batches = (ck.count + 63) >> 6;
+    // lane state
+    bool active = false;
+    int vox = 0, st = 0, its = 0;            // st: 0 = pick an atom first, 1 = passive set changed, solve
+    unsigned P = 0u;
+    double c[N], x[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) { c[j] = 0.0; x[j] = 0.0; }
+    int buf_pos = 0, buf_cnt = 0;            // wave-uniform: next entry / entries left in Cb
+    bool more = true;                        // wave-uniform: the chunk may still have batches
+
+    for (int trip = 0; trip < (1 << 22); ++trip) {
+        const unsigned long long freem = __ballot(!active);
+        // ------------------------------------------------------------ phase 1: refill the wavefront's buffer
+        if (freem != 0ull && buf_cnt == 0 && more) {
+            const int b = next_ticket(ticket, lane);
+            if (b >= n_batches) {
+                more = false;
+            } else {
+                const int cnt = min(64, ck.count - (b << 6));
+                const int myvox = (lane < cnt) ? a.c.perm[ck.start + (b << 6) + lane] : -1;
+                Vb[lane] = myvox;
+                double cn[N];
+                bool finite = true;
+#pragma unroll
+                for (int j = 0; j < N; j++) cn[j] = 0.0;
+                const int seg = lane & 7, grp = lane >> 3;      // 8 lanes x 16 B = one 16-value segment of a row
+                for (int r0 = 0; r0 < nS; r0 += kTileRows) {
+                    const int rows = min(kTileRows, nS - r0);
+#pragma unroll
+                    for (int it = 0; it < 8; it++) {
+                        const int e = it * 8 + grp;
+                        const int ve = Vb[e];
+                        const int i = 2 * seg;
+                        double y0 = 0.0, y1 = 0.0;
+                        if (ve >= 0) {
+                            const double *yp = a.c.y + (size_t)ve * nS + r0 + i;
+                            if (i + 1 < rows) { y0 = yp[0]; y1 = yp[1]; }       // one 16-byte load
+                            else if (i < rows) y0 = yp[0];
+                        }
+                        Tt[i * kTileLd + e] = y0;
+                        Tt[(i + 1) * kTileLd + e] = y1;
+                    }
+                    AMX_RELOAD();
+                    for (int r = 0; r < rows; r++) {
+                        const double yi = Tt[r * kTileLd + lane];
+                        finite = finite && (fabs(yi) <= 1.79769313486231570e308);
+                        const double *ar = Ad + (size_t)(r0 + r) * N;
+#pragma unroll
+                        for (int j = 0; j < N; j++) cn[j] += ar[j] * yi;
+                    }
+                    AMX_RELOAD();
+                }
+#pragma unroll
+                for (int j = 0; j < N; j++) Cb[j * 64 + lane] = finite ? cn[j] - a.c.lam1 : __builtin_nan("");
+                buf_pos = 0; buf_cnt = cnt;
+            }
+        }
+        // ------------------------------------------------------------ free lanes take the next voxels of the buffer
+        if (freem != 0ull && buf_cnt > 0) {
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(freem >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)freem, 0u));
+            const bool take = !active && rank < buf_cnt;
+            const int e = take ? buf_pos + rank : 0;
+            const int nv = Vb[e];
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                const double cj = Cb[j * 64 + e];
+                c[j] = take ? cj : c[j];
+                x[j] = take ? 0.0 : x[j];
+            }
+            if (take) { active = true; vox = nv; P = 0u; st = 0; its = 0; }
+            const int taken = min(__builtin_popcountll(freem), buf_cnt);
+            buf_pos += taken; buf_cnt -= taken;
+        }
+        if (__ballot(active) == 0ull) {
+            if (!more) break;
+            continue;
+        }
+        // ------------------------------------------------------------ phase 2: one active-set step per lane
+        bool done = false;
+        if (active && !(c[0] == c[0])) done = true;             // non-finite signal: NaN maps, never iterate
+        const bool pick = active && !done && st == 0;
+        if (__ballot(pick) != 0ull) {
+            AMX_RELOAD();
+            double best = -inf;
+            int t = -1;
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                double g = c[j];
+#pragma unroll
+                for (int k = 0; k < N; k++) g -= Hs[j * N + k] * x[k];
+                if (!((P >> j) & 1u) && g > best) { best = g; t = j; }
+            }
+            if (pick) {
+                if (!(best > tol) || its > 3 * N + 8) done = true;      // KKT point (or the iteration cap of lane_nnqp)
+                else { P |= 1u << t; st = 1; its++; }
+            }
+        }
+        const bool slv = active && !done;                         // st == 1 for all of them now
+        if (__ballot(slv) != 0ull) {
+            // masked Cholesky of H restricted to P (identity elsewhere) and the two triangular solves
+            double L[N * (N + 1) / 2], linv[N], z[N];
+            AMX_RELOAD();
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                const bool pj = (P >> j) & 1u;
+                double s = Hs[j * N + j];
+#pragma unroll
+                for (int k = 0; k < j; k++) s -= L[tri<N>(j, k)] * L[tri<N>(j, k)];
+                const double iv = pj ? rsqrt(s) : 1.0;
+                linv[j] = iv;
+                L[tri<N>(j, j)] = pj ? s * iv : 1.0;
+#pragma unroll
+                for (int i = j + 1; i < N; i++) {
+                    double tt = Hs[i * N + j];
+#pragma unroll
+                    for (int k = 0; k < j; k++) tt -= L[tri<N>(i, k)] * L[tri<N>(j, k)];
+                    L[tri<N>(i, j)] = (pj && ((P >> i) & 1u)) ? tt * iv : 0.0;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                double s = ((P >> j) & 1u) ? c[j] : 0.0;
+#pragma unroll
+                for (int k = 0; k < j; k++) s -= L[tri<N>(j, k)] * z[k];
+                z[j] = s * linv[j];
+            }
+#pragma unroll
+            for (int j = N - 1; j >= 0; j--) {
+                double s = z[j];
+#pragma unroll
+                for (int i = j + 1; i < N; i++) s -= L[tri<N>(i, j)] * z[i];
+                z[j] = s * linv[j];
+            }
+            bool feasible = true;
+#pragma unroll
+            for (int j = 0; j < N; j++)
+                if (((P >> j) & 1u) && !(z[j] > 0.0)) feasible = false;
+            if (__ballot(slv && !feasible) != 0ull) {
+                double alpha = inf;
+                int jm = -1;
+#pragma unroll
+                for (int j = 0; j < N; j++) {
+                    if (((P >> j) & 1u) && !(z[j] > 0.0)) {
+                        const double den = x[j] - z[j];
+                        const double r = (den > 0.0) ? x[j] / den : 0.0;
+                        if (r < alpha) { alpha = r; jm = j; }
+                    }
+                }
+                if (slv && !feasible) {
+#pragma unroll
+                    for (int j = 0; j < N; j++) {
+                        if ((P >> j) & 1u) {
+                            x[j] += alpha * (z[j] - x[j]);
+                            if (j == jm || !(x[j] > 0.0)) { x[j] = 0.0; P &= ~(1u << j); }
+                        }
+                    }
+                    its++;
+                    st = (P == 0u) ? 0 : 1;
+                    if (its > 4 * N + 16) done = true;
+                }
+            }
+            if (slv && feasible) {
+#pragma unroll
+                for (int j = 0; j < N; j++) x[j] = ((P >> j) & 1u) ? z[j] : 0.0;
+                st = 0;
+            }
+        }
+        // ------------------------------------------------------------ finished voxels: maps (models.pyx:1241-1256)
+        if (__ballot(done) != 0ull) {
+            if (done) {
+                double *e = a.est + (size_t)vox * a.n_maps;
+                if (!(c[0] == c[0])) {
+                    const double nan = __builtin_nan("");
+                    for (int m = 0; m < a.n_maps; m++) e[m] = nan;
+                } else {
+                    if (its > 3 * N + 8) atomicAdd(&a.c.status[ST_ITCAP], 1);
+                    if (a.c.xdbg) {
+#pragma unroll
+                        for (int j = 0; j < N; j++) if (j < n_atoms) a.c.xdbg[(size_t)vox * n_atoms + j] = x[j];
+                    }
+                    double x_sum = 0.0, x_perp = 0.0;
+#pragma unroll
+                    for (int j = 0; j < N; j++) { x_sum += x[j]; if (j < n_perp) x_perp += x[j]; }
+                    x_sum += 1e-16;
+                    const double vv = x_perp / x_sum;
+                    e[0] = vv; e[1] = 1.0 - vv;
+                    if (a.is_mouse) {
+                        double xb = 0.0, xc = 0.0;
+#pragma unroll
+                        for (int j = 0; j < N; j++) { if (j == n_perp) xb = x[j]; if (j == n_perp + 1) xc = x[j]; }
+                        e[2] = xb / x_sum; e[3] = xc / x_sum;
+                    }
+                }
+                active = false;
+            }
+        }
+    }
+}
+
+static size_t refill_lds_bytes(int nS, int N, int nw)
+{
+    return ((size_t)nS * N + (size_t)N * N + (size_t)nw * (kTileRows * kTileLd + N * 64 + 32)) * sizeof(double) + 16;
+}
+
 template <typename Args, typename K>
 int launch_lane(amx_ctx *ctx, Args &a, const Plan &pl, hipStream_t s, K kern, size_t elem, int N)
 {
@@ -560,10 +820,28 @@ int launch_lane(amx_ctx *ctx, Args &a, const Plan &pl, hipStream_t s, K kern, si
 
 }  // namespace
 
+template <typename K>
+static int launch_refill(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s, K kern, int N)
+{
+    const size_t lds = refill_lds_bytes(a.c.nS, N, 4);
+    int rc;
+    if ((rc = set_lds(ctx, kern, lds))) return rc;
+    rec(ctx, 2, s);
+    hipLaunchKernelGGL(kern, dim3(((pl.max_chunks + 7) / 8) * 8), dim3(256), lds, s, a);
+    AMX_TRACE(ctx, s, "lane-per-voxel solver with refill");
+    rec(ctx, 3, s);
+    HIPCHK(ctx, hipGetLastError());
+    return AMX_OK;
+}
+
 int amx_launch_fw_small(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s)
 {
     // compile-time dictionary sizes: the reference's defaults (11 Human, 12 Mouse) exactly, 16 otherwise
     const int n = a.c.n_atoms;
+    if (amx_fw_use_refill(n, a.c.nS, a.c.flags)) {
+        if (n <= 11) return launch_refill(ctx, a, pl, s, k_freewater_refill<11>, 11);
+        return launch_refill(ctx, a, pl, s, k_freewater_refill<12>, 12);
+    }
     if (n <= 11) return launch_lane(ctx, a, pl, s, k_freewater_lane<11>, sizeof(float), 11);
     if (n == 12) return launch_lane(ctx, a, pl, s, k_freewater_lane<12>, sizeof(float), 12);
     return launch_lane(ctx, a, pl, s, k_freewater_lane<16>, sizeof(float), 16);

@@ -134,14 +134,18 @@ def _lasso_certificate(A, Y, X, lam1, lam2):
 
 
 @pytest.mark.parametrize('snr', [30.0, 10.0])
-@pytest.mark.parametrize('mapping', ['lane', 'wave'])
+@pytest.mark.parametrize('mapping', ['refill', 'lane', 'wave'])
 def test_freewater_kkt_certificates(htable500, snr, mapping, monkeypatch):
+    """mapping: 'refill' = lane per voxel, lanes refilled from a buffer (default), 'lane' = one solve per lane and pass,
+    'wave' = one wavefront per voxel"""
     import torch
     from amico_amd import _capi, get_context, synthetic as S
     from oracle import oracle
     if mapping == 'wave':
         monkeypatch.setenv('AMX_WAVE_PER_VOXEL', '1')
-    n = N_VOX if mapping == 'lane' else 20_000
+    if mapping == 'lane':
+        monkeypatch.setenv('AMX_NO_REFILL', '1')
+    n = 20_000 if mapping == 'wave' else N_VOX
     dirs, ht = htable500['dirs'], htable500['htable']
     sch = S.make_scheme(1, ((1000.0, 64),), seed=3)
     K = S.freewater_kernels(sch, dirs)
