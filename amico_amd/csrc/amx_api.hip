@@ -114,6 +114,7 @@ int amx_ctx_create(int device, amx_ctx **out)
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return AMX_E_NODEVICE;   // code objects are gfx950 only
     amx_ctx *ctx = new amx_ctx();
     ctx->device = device;
+    ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipMalloc((void **)&ctx->status_d, ST_WORDS * sizeof(int)) != hipSuccess ||
         hipHostMalloc((void **)&ctx->status_h, (ST_WORDS + 16) * sizeof(int)) != hipSuccess) {
         delete ctx;

@@ -22,6 +22,7 @@ struct DevBuf {
 
 struct amx_ctx {
     int device = 0;
+    int n_cu = 256;                // compute units of the device (persistent-grid launches)
     std::string err;
     // stream-ordered workspace (grow-only)
     DevBuf lutidx, perm, counts, dir_start, cursor, chunks, misc, xiso, supp, ovf;

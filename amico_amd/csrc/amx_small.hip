@@ -851,6 +851,9 @@ int amx_launch_sandi_small(amx_ctx *ctx, SandiArgs &a, const Plan &pl, hipStream
 {
     const int n = a.c.n_atoms;                // SANDI default: 5 + 5 + 5 = 15 atoms
     // the default protocol after the directional average (b0 + 5 shells = 6 values, 15 atoms): row-space solver
+    // (a refill variant of this kernel -- lanes drawing the next voxel from a global counter -- was measured SLOWER,
+    //  2.65 vs 2.29 ms per 1 M voxels: SANDI's optimum is dense, 12 of 15 atoms, so the lanes of a wavefront need
+    //  nearly the same number of steps and there is no idle time to win back)
     if (a.c.nS == 6 && n == 15 && a.c.lam2 >= 1e-6 && !getenv("AMX_SANDI_ATOM_SPACE")) {
         rec(ctx, 2, s);
         hipLaunchKernelGGL((k_sandi_rows<6, 15>), dim3(((pl.max_chunks + 7) / 8) * 8), dim3(256), 0, s, a);
