@@ -19,7 +19,7 @@ SYMBOLS = ['amx_version', 'amx_ctx_create', 'amx_ctx_destroy', 'amx_last_error',
            'amx_lut_upload_noddi', 'amx_lut_upload_freewater', 'amx_lut_upload_sandi', 'amx_lut_destroy',
            'amx_dir_to_lut_idx', 'amx_noddi_fit', 'amx_freewater_fit', 'amx_sandi_fit',
            'amx_noddi_fit_device', 'amx_freewater_fit_device', 'amx_sandi_fit_device', 'amx_sync_status',
-           'amx_set_debug_x',
+           'amx_set_debug_x', 'amx_noddi_fit_f32', 'amx_freewater_fit_f32', 'amx_sandi_fit_f32', 'amx_set_progress',
            'amx_set_profiling', 'amx_last_kernel_ms', 'amx_last_stats', 'amx_selftest',
            'amx_dti_create', 'amx_dti_destroy', 'amx_dti_directions', 'amx_dti_directions_device',
            'amx_prep_create', 'amx_prep_destroy', 'amx_prep_gather', 'amx_prep_gather_device',
@@ -29,6 +29,7 @@ SYMBOLS = ['amx_version', 'amx_ctx_create', 'amx_ctx_destroy', 'amx_last_error',
 _lib = None
 c_vp, c_dp, c_fp = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float)
 c_i16p, c_i32p, c_i64p = C.POINTER(C.c_int16), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+PROGRESS_CB = C.CFUNCTYPE(None, C.c_int64, C.c_int64, c_vp)
 
 
 class AmxError(RuntimeError):
@@ -82,6 +83,11 @@ def lib():
                                        c_vp, c_vp, c_vp, c_vp]
     L.amx_sync_status.argtypes = [c_vp, c_vp]
     L.amx_set_debug_x.argtypes = [c_vp, c_vp]
+    L.amx_noddi_fit_f32.argtypes = [c_vp, c_vp, c_fp, c_dp, C.c_int64, C.c_double, C.c_double, C.c_uint, c_dp, c_dp, c_dp, c_dp]
+    L.amx_freewater_fit_f32.argtypes = [c_vp, c_vp, c_fp, c_dp, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_uint,
+                                        c_dp, c_dp, c_dp, c_dp]
+    L.amx_sandi_fit_f32.argtypes = [c_vp, c_vp, c_fp, C.c_int64, C.c_double, C.c_double, C.c_uint, c_dp, c_dp, c_dp]
+    L.amx_set_progress.argtypes = [c_vp, PROGRESS_CB, c_vp]
     L.amx_set_profiling.argtypes = [c_vp, C.c_int]
     L.amx_last_kernel_ms.argtypes = [c_vp, C.c_int, C.POINTER(C.c_float)]
     L.amx_last_stats.argtypes = [c_vp, c_i64p]
@@ -146,6 +152,11 @@ class Context:
 
     def sync(self, stream=None):
         self.check(lib().amx_sync_status(self._h, c_vp(stream or 0)))
+
+    def set_progress(self, fn=None):
+        """fn(done, total) is called while a host-buffer fit runs (batches of voxels complete); None unregisters"""
+        self._progress_cb = PROGRESS_CB(lambda done, total, _u: fn(int(done), int(total))) if fn else PROGRESS_CB()
+        self.check(lib().amx_set_progress(self._h, self._progress_cb, None))
 
     def set_profiling(self, on=True):
         self.check(lib().amx_set_profiling(self._h, int(bool(on))))
@@ -236,10 +247,16 @@ def upload_sandi(ctx, kernels, Rs, d_in, d_isos):
 
 
 def _check_y(y, nS):
-    y = np.ascontiguousarray(y, dtype=np.float64)
+    """float32 signals stay float32 (amx_*_fit_f32: the image dtype of the reference, half the PCIe bytes, same results);
+    anything else is passed as float64 like evaluation.y"""
+    y = np.ascontiguousarray(y, dtype=np.float32 if getattr(y, 'dtype', None) == np.float32 else np.float64)
     if y.ndim != 2 or y.shape[1] != nS:
-        raise ValueError(f'y must be [n_vox, {nS}] float64')
+        raise ValueError(f'y must be [n_vox, {nS}] float64 (or float32)')
     return y
+
+
+def _yp(y):
+    return (True, _p(y, c_fp)) if y.dtype == np.float32 else (False, _p(y, c_dp))
 
 
 def _check_dirs(dirs, n):
@@ -258,8 +275,10 @@ def noddi_fit(ctx, lut, y, dirs, lambda1, lambda2, n_maps, rmse=False, nrmse=Fal
     r = np.zeros(n) if rmse else None
     nr = np.zeros(n) if nrmse else None
     md = np.zeros((n, 2), dtype=np.float64, order='C') if mod else None
-    ctx.check(lib().amx_noddi_fit(ctx._h, lut._h, _p(y, c_dp), _p(dirs, c_dp), n, float(lambda1), float(lambda2),
-                                  flags, _p(est, c_dp), _p(r, c_dp), _p(nr, c_dp), _p(md, c_dp)))
+    f32, yp = _yp(y)
+    fn = lib().amx_noddi_fit_f32 if f32 else lib().amx_noddi_fit
+    ctx.check(fn(ctx._h, lut._h, yp, _p(dirs, c_dp), n, float(lambda1), float(lambda2),
+                 flags, _p(est, c_dp), _p(r, c_dp), _p(nr, c_dp), _p(md, c_dp)))
     return est, r, nr, md
 
 
@@ -272,9 +291,10 @@ def freewater_fit(ctx, lut, y, dirs, lambda1, lambda2, is_mouse, rmse=False, nrm
     r = np.zeros(n) if rmse else None
     nr = np.zeros(n) if nrmse else None
     yc = np.zeros((n, lut.nS), dtype=np.float64, order='C') if corrected else None
-    ctx.check(lib().amx_freewater_fit(ctx._h, lut._h, _p(y, c_dp), _p(dirs, c_dp), n, float(lambda1),
-                                      float(lambda2), int(bool(is_mouse)), flags, _p(est, c_dp), _p(r, c_dp),
-                                      _p(nr, c_dp), _p(yc, c_dp)))
+    f32, yp = _yp(y)
+    fn = lib().amx_freewater_fit_f32 if f32 else lib().amx_freewater_fit
+    ctx.check(fn(ctx._h, lut._h, yp, _p(dirs, c_dp), n, float(lambda1), float(lambda2), int(bool(is_mouse)), flags,
+                 _p(est, c_dp), _p(r, c_dp), _p(nr, c_dp), _p(yc, c_dp)))
     return est, r, nr, yc
 
 
@@ -285,8 +305,9 @@ def sandi_fit(ctx, lut, y, lambda1, lambda2, rmse=False, nrmse=False):
     est = np.zeros((n, 6), dtype=np.float64, order='C')
     r = np.zeros(n) if rmse else None
     nr = np.zeros(n) if nrmse else None
-    ctx.check(lib().amx_sandi_fit(ctx._h, lut._h, _p(y, c_dp), n, float(lambda1), float(lambda2), flags,
-                                  _p(est, c_dp), _p(r, c_dp), _p(nr, c_dp)))
+    f32, yp = _yp(y)
+    fn = lib().amx_sandi_fit_f32 if f32 else lib().amx_sandi_fit
+    ctx.check(fn(ctx._h, lut._h, yp, n, float(lambda1), float(lambda2), flags, _p(est, c_dp), _p(r, c_dp), _p(nr, c_dp)))
     return est, r, nr
 
 

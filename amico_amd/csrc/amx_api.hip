@@ -93,6 +93,23 @@ __global__ void k_selftest(double *out)
 
 int bad(amx_ctx *ctx, const char *msg) { return amx_bad(ctx, msg); }
 
+// float32 signals (the image dtype of the reference, core.py:136) -> the float64 rows the solvers read: exact
+__global__ void k_widen(const float *__restrict__ src, double *__restrict__ dst, size_t n)
+{
+    const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i0 + 3 < n) {
+        const float4 v = *reinterpret_cast<const float4 *>(src + i0);
+        dst[i0] = (double)v.x; dst[i0 + 1] = (double)v.y; dst[i0 + 2] = (double)v.z; dst[i0 + 3] = (double)v.w;
+    } else {
+        for (size_t i = i0; i < n; i++) dst[i] = (double)src[i];
+    }
+}
+
+void progress(amx_ctx *ctx, int64_t done, int64_t total)
+{
+    if (ctx->progress) ctx->progress(done, total, ctx->progress_user);
+}
+
 }  // namespace
 
 // =================================================================== C ABI
@@ -134,7 +151,7 @@ void amx_ctx_destroy(amx_ctx *ctx)
     hipDeviceSynchronize();
     DevBuf *bufs[] = {&ctx->lutidx, &ctx->perm, &ctx->counts, &ctx->dir_start, &ctx->cursor, &ctx->chunks,
                       &ctx->misc, &ctx->xiso, &ctx->supp, &ctx->ovf, &ctx->hy, &ctx->hdirs, &ctx->hest,
-                      &ctx->hrmse, &ctx->hnrmse, &ctx->hextra};
+                      &ctx->hrmse, &ctx->hnrmse, &ctx->hextra, &ctx->hy32};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     if (ctx->status_d) hipFree(ctx->status_d);
     if (ctx->status_h) hipHostFree(ctx->status_h);
@@ -333,6 +350,14 @@ int amx_sync_status(amx_ctx *ctx, void *hip_stream)
     return AMX_OK;
 }
 
+int amx_set_progress(amx_ctx *ctx, void (*callback)(int64_t done, int64_t total, void *user), void *user)
+{
+    if (!ctx) return AMX_E_BADARG;
+    ctx->progress = callback;
+    ctx->progress_user = user;
+    return AMX_OK;
+}
+
 int amx_set_debug_x(amx_ctx *ctx, double *d_x)
 {
     if (!ctx) return AMX_E_BADARG;
@@ -390,7 +415,7 @@ int amx_noddi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
     if (!d_y || !d_dirs || !d_estimates) return bad(ctx, "amx_noddi_fit: null buffer");
     if (((flags & AMX_F_RMSE) && !d_rmse) || ((flags & AMX_F_NRMSE) && !d_nrmse) || ((flags & AMX_F_MODULATED) && !d_mod))
         return bad(ctx, "amx_noddi_fit: flag set but output buffer is null");
-    if (!(lambda2 > 0.0) || !(lambda1 >= 0.0)) return bad(ctx, "amx_noddi_fit: need lambda1 >= 0 and lambda2 > 0");
+    if (!(lambda2 >= 0.0) || !(lambda1 >= 0.0)) return bad(ctx, "amx_noddi_fit: need lambda1 >= 0 and lambda2 >= 0");
     hipStream_t s = (hipStream_t)hip_stream;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     Plan pl; int rc;
@@ -436,14 +461,14 @@ int amx_freewater_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y
     if (!d_y || !d_dirs || !d_estimates) return bad(ctx, "amx_freewater_fit: null buffer");
     if (((flags & AMX_F_RMSE) && !d_rmse) || ((flags & AMX_F_NRMSE) && !d_nrmse) || ((flags & AMX_F_CORRECTED) && !d_ycorr))
         return bad(ctx, "amx_freewater_fit: flag set but output buffer is null");
-    if (!(lambda2 > 0.0) || !(lambda1 >= 0.0)) return bad(ctx, "amx_freewater_fit: need lambda1 >= 0 and lambda2 > 0");
+    if (!(lambda2 >= 0.0) || !(lambda1 >= 0.0)) return bad(ctx, "amx_freewater_fit: need lambda1 >= 0 and lambda2 >= 0");
     if (is_mouse && lut->n_iso < 2) return bad(ctx, "amx_freewater_fit: Mouse needs two isotropic atoms");
     hipStream_t s = (hipStream_t)hip_stream;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     Plan pl; int rc;
     if ((rc = make_plan(ctx, n_vox, lut->ndirs, pl))) return rc;
     rec(ctx, 0, s);
-    const bool refill = amx_use_lane_solver(lut->n_atoms) && amx_fw_use_refill(lut->n_atoms, lut->nS, flags);
+    const bool refill = amx_use_lane_solver(lut->n_atoms, lambda2) && amx_fw_use_refill(lut->n_atoms, lut->nS, flags);
     if ((rc = enqueue_bucketing(ctx, lut, d_dirs, n_vox, pl, s, refill ? amx_refill_chunk(n_vox) : kChunk))) return rc;
     FwArgs a;
     memset(&a, 0, sizeof a);
@@ -476,7 +501,7 @@ int amx_sandi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, in
     if (!d_y || !d_estimates) return bad(ctx, "amx_sandi_fit: null buffer");
     if (((flags & AMX_F_RMSE) && !d_rmse) || ((flags & AMX_F_NRMSE) && !d_nrmse))
         return bad(ctx, "amx_sandi_fit: flag set but output buffer is null");
-    if (!(lambda2 > 0.0) || !(lambda1 >= 0.0)) return bad(ctx, "amx_sandi_fit: need lambda1 >= 0 and lambda2 > 0");
+    if (!(lambda2 >= 0.0) || !(lambda1 >= 0.0)) return bad(ctx, "amx_sandi_fit: need lambda1 >= 0 and lambda2 >= 0");
     hipStream_t s = (hipStream_t)hip_stream;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     Plan pl; int rc;
@@ -503,73 +528,91 @@ int amx_sandi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, in
     return rc;
 }
 
+}  // extern "C"
+
 // ------------------------------------------------------------------ host-pointer entry points
 #define AMX_H2D(buf, src, bytes)                                                     \
     if ((rc = ensure(ctx, buf, bytes))) return rc;                                   \
     HIPCHK(ctx, hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, nullptr));
-#define AMX_D2H(dst, buf, bytes) HIPCHK(ctx, hipMemcpyAsync(dst, buf.p, bytes, hipMemcpyDeviceToHost, nullptr));
 
-// Large host batches: the signals travel in batches of kHostBatch voxels; while the GPU fits batch c (on a
-// non-blocking stream of the context) the blocking host-to-device copy of batch c+1 is already running, so the PCIe
-// time hides behind the solver instead of preceding it.  Two signal buffers; results leave in one copy at the end.
+// Host buffers in, host buffers out, for all three models and both signal dtypes (float64 = evaluation.y of the
+// reference; float32 = the dtype the image has before core.py:451 casts it -- lossless, half the PCIe bytes).
+// Large inputs travel in batches of kHostBatch voxels: while the GPU fits batch c (on a non-blocking stream of the
+// context) the blocking host-to-device copy of batch c+1 is already running, so the PCIe time hides behind the solver
+// instead of preceding it.  Two signal buffers; results leave in one copy per output at the end.  The progress
+// callback (amx_set_progress; models.pyx:28-43, 981 keep a per-thread counter for the same purpose) is called as
+// batches complete.
 constexpr int64_t kHostBatch = 262144;
 
-static int noddi_fit_host_pipelined(amx_ctx *ctx, const amx_lut *lut, const double *y, const double *dirs, int64_t n_vox,
-                                    double lambda1, double lambda2, unsigned flags, double *out_estimates,
-                                    double *out_rmse, double *out_nrmse, double *out_mod)
+struct HostOut { void *dst; DevBuf *buf; size_t cols; bool on; };
+
+// enqueue(y_dev, dirs_dev, count, est, rmse, nrmse, extra, stream) -> the model's *_fit_device
+template <typename T, typename Enqueue>
+static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox, int nS, HostOut (&outs)[4], Enqueue enqueue)
 {
     int rc;
-    const int n_maps = 3 + (lut->is_exvivo ? 1 : 0), nS = lut->nS;
+    constexpr bool kF32 = sizeof(T) == 4;
+    const bool pipelined = n_vox >= 2 * kHostBatch && !getenv("AMX_HOST_ONE_SHOT");
+    const int64_t cap = pipelined ? 2 * kHostBatch : n_vox;
+    if ((rc = ensure(ctx, ctx->hy, (size_t)cap * nS * sizeof(double)))) return rc;
+    if (kF32 && (rc = ensure(ctx, ctx->hy32, (size_t)cap * nS * sizeof(float)))) return rc;
+    if (dirs && (rc = ensure(ctx, ctx->hdirs, (size_t)cap * 3 * sizeof(double)))) return rc;
+    for (HostOut &o : outs)
+        if (o.on && (rc = ensure(ctx, *o.buf, (size_t)n_vox * o.cols * sizeof(double)))) return rc;
     if (!ctx->hs) {
         HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->hs, hipStreamNonBlocking));
         HIPCHK(ctx, hipEventCreateWithFlags(&ctx->hev[0], hipEventDisableTiming));
         HIPCHK(ctx, hipEventCreateWithFlags(&ctx->hev[1], hipEventDisableTiming));
     }
-    if ((rc = ensure(ctx, ctx->hy, (size_t)2 * kHostBatch * nS * sizeof(double)))) return rc;
-    if ((rc = ensure(ctx, ctx->hdirs, (size_t)2 * kHostBatch * 3 * sizeof(double)))) return rc;
-    if ((rc = ensure(ctx, ctx->hest, (size_t)n_vox * n_maps * sizeof(double)))) return rc;
-    if ((rc = ensure(ctx, ctx->hrmse, (size_t)n_vox * sizeof(double)))) return rc;
-    if ((rc = ensure(ctx, ctx->hnrmse, (size_t)n_vox * sizeof(double)))) return rc;
-    if ((rc = ensure(ctx, ctx->hextra, (size_t)n_vox * 2 * sizeof(double)))) return rc;
     HIPCHK(ctx, hipStreamSynchronize(nullptr));                      // earlier default-stream work on these buffers
     const bool was_profiling = ctx->profiling;
-    ctx->profiling = false;
+    if (pipelined) ctx->profiling = false;
+    hipStream_t s = pipelined ? ctx->hs : nullptr;
     int64_t off = 0;
     for (int c = 0; off < n_vox; c++) {
         // the last batch absorbs a short remainder
-        const int64_t cnt = (n_vox - off < kHostBatch + kHostBatch / 2) ? n_vox - off : kHostBatch;
-        const int b = c & 1;
-        if (c >= 2) HIPCHK(ctx, hipEventSynchronize(ctx->hev[b]));   // batch c-2 has released this buffer
-        double *yb = (double *)ctx->hy.p + (size_t)b * kHostBatch * nS, *db = (double *)ctx->hdirs.p + (size_t)b * kHostBatch * 3;
-        // (a remainder-absorbing last batch may exceed kHostBatch: it then uses both halves, which are free by then)
-        if (cnt > kHostBatch) {
-            HIPCHK(ctx, hipStreamSynchronize(ctx->hs));
-            yb = (double *)ctx->hy.p; db = (double *)ctx->hdirs.p;
+        const int64_t cnt = !pipelined ? n_vox : ((n_vox - off < kHostBatch + kHostBatch / 2) ? n_vox - off : kHostBatch);
+        int b = c & 1;
+        if (pipelined && c >= 2) {
+            HIPCHK(ctx, hipEventSynchronize(ctx->hev[b]));           // batch c-2 has released this buffer
+            progress(ctx, (int64_t)(c - 1) * kHostBatch, n_vox);     // batches 0 .. c-2 are complete
         }
-        HIPCHK(ctx, hipMemcpy(yb, y + (size_t)off * nS, (size_t)cnt * nS * sizeof(double), hipMemcpyHostToDevice));
-        HIPCHK(ctx, hipMemcpy(db, dirs + (size_t)off * 3, (size_t)cnt * 3 * sizeof(double), hipMemcpyHostToDevice));
+        // (a remainder-absorbing last batch may exceed kHostBatch: it then uses both halves, which are free by then)
+        if (cnt > kHostBatch && pipelined) { HIPCHK(ctx, hipStreamSynchronize(ctx->hs)); b = 0; }
+        double *yb = (double *)ctx->hy.p + (size_t)b * kHostBatch * nS;
+        double *db = dirs ? (double *)ctx->hdirs.p + (size_t)b * kHostBatch * 3 : nullptr;
+        if (kF32) {
+            float *y32 = (float *)ctx->hy32.p + (size_t)b * kHostBatch * nS;
+            const size_t nel = (size_t)cnt * nS;
+            HIPCHK(ctx, hipMemcpy(y32, y + (size_t)off * nS, nel * sizeof(float), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_widen, dim3((unsigned)((nel / 4 + 256) / 256)), dim3(256), 0, s, y32, yb, nel);
+        } else {
+            HIPCHK(ctx, hipMemcpy(yb, y + (size_t)off * nS, (size_t)cnt * nS * sizeof(double), hipMemcpyHostToDevice));
+        }
+        if (dirs) HIPCHK(ctx, hipMemcpy(db, dirs + (size_t)off * 3, (size_t)cnt * 3 * sizeof(double), hipMemcpyHostToDevice));
+        // the copy above took a while: has the previous batch finished meanwhile? (a query, never a wait)
+        if (pipelined && c >= 1 && ctx->progress && hipEventQuery(ctx->hev[(c - 1) & 1]) == hipSuccess) progress(ctx, off, n_vox);
         ctx->vox_base = off;
-        rc = amx_noddi_fit_device(ctx, lut, yb, db, cnt, lambda1, lambda2, flags, (double *)ctx->hest.p + (size_t)off * n_maps,
-                                  (double *)ctx->hrmse.p + off, (double *)ctx->hnrmse.p + off,
-                                  (double *)ctx->hextra.p + (size_t)off * 2, ctx->hs);
+        rc = enqueue(yb, db, cnt, (double *)outs[0].buf->p + (size_t)off * outs[0].cols,
+                     outs[1].on ? (double *)outs[1].buf->p + off : nullptr, outs[2].on ? (double *)outs[2].buf->p + off : nullptr,
+                     outs[3].on ? (double *)outs[3].buf->p + (size_t)off * outs[3].cols : nullptr, s);
         ctx->vox_base = 0;
         if (rc) { ctx->profiling = was_profiling; return rc; }
-        HIPCHK(ctx, hipEventRecord(ctx->hev[b], ctx->hs));
+        if (pipelined) HIPCHK(ctx, hipEventRecord(ctx->hev[b], ctx->hs));
         off += cnt;
     }
     ctx->profiling = was_profiling;
-    rc = amx_sync_status(ctx, ctx->hs);
+    rc = amx_sync_status(ctx, s);
     if (rc) return rc;
-    HIPCHK(ctx, hipMemcpy(out_estimates, ctx->hest.p, (size_t)n_vox * n_maps * sizeof(double), hipMemcpyDeviceToHost));
-    if (flags & AMX_F_RMSE) HIPCHK(ctx, hipMemcpy(out_rmse, ctx->hrmse.p, (size_t)n_vox * sizeof(double), hipMemcpyDeviceToHost));
-    if (flags & AMX_F_NRMSE) HIPCHK(ctx, hipMemcpy(out_nrmse, ctx->hnrmse.p, (size_t)n_vox * sizeof(double), hipMemcpyDeviceToHost));
-    if (flags & AMX_F_MODULATED) HIPCHK(ctx, hipMemcpy(out_mod, ctx->hextra.p, (size_t)n_vox * 2 * sizeof(double), hipMemcpyDeviceToHost));
+    for (HostOut &o : outs)
+        if (o.on) HIPCHK(ctx, hipMemcpy(o.dst, o.buf->p, (size_t)n_vox * o.cols * sizeof(double), hipMemcpyDeviceToHost));
+    progress(ctx, n_vox, n_vox);
     return AMX_OK;
 }
 
-int amx_noddi_fit(amx_ctx *ctx, const amx_lut *lut, const double *y, const double *dirs,
-                  int64_t n_vox, double lambda1, double lambda2, unsigned flags,
-                  double *out_estimates, double *out_rmse, double *out_nrmse, double *out_mod)
+template <typename T>
+static int noddi_fit_any(amx_ctx *ctx, const amx_lut *lut, const T *y, const double *dirs, int64_t n_vox, double lambda1,
+                         double lambda2, unsigned flags, double *out_estimates, double *out_rmse, double *out_nrmse, double *out_mod)
 {
     if (!ctx) return AMX_E_BADARG;
     if (!lut || lut->model != 1) return bad(ctx, "amx_noddi_fit: not a NODDI dictionary");
@@ -578,31 +621,19 @@ int amx_noddi_fit(amx_ctx *ctx, const amx_lut *lut, const double *y, const doubl
     if (((flags & AMX_F_RMSE) && !out_rmse) || ((flags & AMX_F_NRMSE) && !out_nrmse) || ((flags & AMX_F_MODULATED) && !out_mod))
         return bad(ctx, "amx_noddi_fit: flag set but output buffer is null");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    int rc;
-    const int n_maps = 3 + (lut->is_exvivo ? 1 : 0);
-    if (n_vox >= 2 * kHostBatch && !getenv("AMX_HOST_ONE_SHOT"))
-        return noddi_fit_host_pipelined(ctx, lut, y, dirs, n_vox, lambda1, lambda2, flags, out_estimates, out_rmse,
-                                        out_nrmse, out_mod);
-    AMX_H2D(ctx->hy, y, (size_t)n_vox * lut->nS * sizeof(double))
-    AMX_H2D(ctx->hdirs, dirs, (size_t)n_vox * 3 * sizeof(double))
-    if ((rc = ensure(ctx, ctx->hest, (size_t)n_vox * n_maps * sizeof(double)))) return rc;
-    if ((rc = ensure(ctx, ctx->hrmse, (size_t)n_vox * sizeof(double)))) return rc;
-    if ((rc = ensure(ctx, ctx->hnrmse, (size_t)n_vox * sizeof(double)))) return rc;
-    if ((rc = ensure(ctx, ctx->hextra, (size_t)n_vox * 2 * sizeof(double)))) return rc;
-    rc = amx_noddi_fit_device(ctx, lut, (const double *)ctx->hy.p, (const double *)ctx->hdirs.p, n_vox, lambda1,
-                              lambda2, flags, (double *)ctx->hest.p, (double *)ctx->hrmse.p,
-                              (double *)ctx->hnrmse.p, (double *)ctx->hextra.p, nullptr);
-    if (rc) return rc;
-    AMX_D2H(out_estimates, ctx->hest, (size_t)n_vox * n_maps * sizeof(double))
-    if (flags & AMX_F_RMSE) AMX_D2H(out_rmse, ctx->hrmse, (size_t)n_vox * sizeof(double))
-    if (flags & AMX_F_NRMSE) AMX_D2H(out_nrmse, ctx->hnrmse, (size_t)n_vox * sizeof(double))
-    if (flags & AMX_F_MODULATED) AMX_D2H(out_mod, ctx->hextra, (size_t)n_vox * 2 * sizeof(double))
-    return amx_sync_status(ctx, nullptr);
+    HostOut outs[4] = {{out_estimates, &ctx->hest, (size_t)(3 + (lut->is_exvivo ? 1 : 0)), true},
+                       {out_rmse, &ctx->hrmse, 1, (flags & AMX_F_RMSE) != 0}, {out_nrmse, &ctx->hnrmse, 1, (flags & AMX_F_NRMSE) != 0},
+                       {out_mod, &ctx->hextra, 2, (flags & AMX_F_MODULATED) != 0}};
+    return fit_host<T>(ctx, y, dirs, n_vox, lut->nS, outs,
+                       [&](double *yb, double *db, int64_t cnt, double *e, double *r, double *nr, double *x, hipStream_t s) {
+                           return amx_noddi_fit_device(ctx, lut, yb, db, cnt, lambda1, lambda2, flags, e, r, nr, x, s);
+                       });
 }
 
-int amx_freewater_fit(amx_ctx *ctx, const amx_lut *lut, const double *y, const double *dirs,
-                      int64_t n_vox, double lambda1, double lambda2, int is_mouse, unsigned flags,
-                      double *out_estimates, double *out_rmse, double *out_nrmse, double *out_ycorr)
+template <typename T>
+static int freewater_fit_any(amx_ctx *ctx, const amx_lut *lut, const T *y, const double *dirs, int64_t n_vox, double lambda1,
+                             double lambda2, int is_mouse, unsigned flags, double *out_estimates, double *out_rmse,
+                             double *out_nrmse, double *out_ycorr)
 {
     if (!ctx) return AMX_E_BADARG;
     if (!lut || lut->model != 2) return bad(ctx, "amx_freewater_fit: not a FreeWater dictionary");
@@ -611,28 +642,18 @@ int amx_freewater_fit(amx_ctx *ctx, const amx_lut *lut, const double *y, const d
     if (((flags & AMX_F_RMSE) && !out_rmse) || ((flags & AMX_F_NRMSE) && !out_nrmse) || ((flags & AMX_F_CORRECTED) && !out_ycorr))
         return bad(ctx, "amx_freewater_fit: flag set but output buffer is null");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    int rc;
-    const int n_maps = is_mouse ? 4 : 2;
-    AMX_H2D(ctx->hy, y, (size_t)n_vox * lut->nS * sizeof(double))
-    AMX_H2D(ctx->hdirs, dirs, (size_t)n_vox * 3 * sizeof(double))
-    if ((rc = ensure(ctx, ctx->hest, (size_t)n_vox * n_maps * sizeof(double)))) return rc;
-    if ((rc = ensure(ctx, ctx->hrmse, (size_t)n_vox * sizeof(double)))) return rc;
-    if ((rc = ensure(ctx, ctx->hnrmse, (size_t)n_vox * sizeof(double)))) return rc;
-    if ((flags & AMX_F_CORRECTED) && (rc = ensure(ctx, ctx->hextra, (size_t)n_vox * lut->nS * sizeof(double)))) return rc;
-    rc = amx_freewater_fit_device(ctx, lut, (const double *)ctx->hy.p, (const double *)ctx->hdirs.p, n_vox, lambda1,
-                                  lambda2, is_mouse, flags, (double *)ctx->hest.p, (double *)ctx->hrmse.p,
-                                  (double *)ctx->hnrmse.p, (double *)ctx->hextra.p, nullptr);
-    if (rc) return rc;
-    AMX_D2H(out_estimates, ctx->hest, (size_t)n_vox * n_maps * sizeof(double))
-    if (flags & AMX_F_RMSE) AMX_D2H(out_rmse, ctx->hrmse, (size_t)n_vox * sizeof(double))
-    if (flags & AMX_F_NRMSE) AMX_D2H(out_nrmse, ctx->hnrmse, (size_t)n_vox * sizeof(double))
-    if (flags & AMX_F_CORRECTED) AMX_D2H(out_ycorr, ctx->hextra, (size_t)n_vox * lut->nS * sizeof(double))
-    return amx_sync_status(ctx, nullptr);
+    HostOut outs[4] = {{out_estimates, &ctx->hest, (size_t)(is_mouse ? 4 : 2), true},
+                       {out_rmse, &ctx->hrmse, 1, (flags & AMX_F_RMSE) != 0}, {out_nrmse, &ctx->hnrmse, 1, (flags & AMX_F_NRMSE) != 0},
+                       {out_ycorr, &ctx->hextra, (size_t)lut->nS, (flags & AMX_F_CORRECTED) != 0}};
+    return fit_host<T>(ctx, y, dirs, n_vox, lut->nS, outs,
+                       [&](double *yb, double *db, int64_t cnt, double *e, double *r, double *nr, double *x, hipStream_t s) {
+                           return amx_freewater_fit_device(ctx, lut, yb, db, cnt, lambda1, lambda2, is_mouse, flags, e, r, nr, x, s);
+                       });
 }
 
-int amx_sandi_fit(amx_ctx *ctx, const amx_lut *lut, const double *y, int64_t n_vox,
-                  double lambda1, double lambda2, unsigned flags,
-                  double *out_estimates, double *out_rmse, double *out_nrmse)
+template <typename T>
+static int sandi_fit_any(amx_ctx *ctx, const amx_lut *lut, const T *y, int64_t n_vox, double lambda1, double lambda2,
+                         unsigned flags, double *out_estimates, double *out_rmse, double *out_nrmse)
 {
     if (!ctx) return AMX_E_BADARG;
     if (!lut || lut->model != 3) return bad(ctx, "amx_sandi_fit: not a SANDI dictionary");
@@ -641,18 +662,52 @@ int amx_sandi_fit(amx_ctx *ctx, const amx_lut *lut, const double *y, int64_t n_v
     if (((flags & AMX_F_RMSE) && !out_rmse) || ((flags & AMX_F_NRMSE) && !out_nrmse))
         return bad(ctx, "amx_sandi_fit: flag set but output buffer is null");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    int rc;
-    AMX_H2D(ctx->hy, y, (size_t)n_vox * lut->nS * sizeof(double))
-    if ((rc = ensure(ctx, ctx->hest, (size_t)n_vox * 6 * sizeof(double)))) return rc;
-    if ((rc = ensure(ctx, ctx->hrmse, (size_t)n_vox * sizeof(double)))) return rc;
-    if ((rc = ensure(ctx, ctx->hnrmse, (size_t)n_vox * sizeof(double)))) return rc;
-    rc = amx_sandi_fit_device(ctx, lut, (const double *)ctx->hy.p, n_vox, lambda1, lambda2, flags,
-                              (double *)ctx->hest.p, (double *)ctx->hrmse.p, (double *)ctx->hnrmse.p, nullptr);
-    if (rc) return rc;
-    AMX_D2H(out_estimates, ctx->hest, (size_t)n_vox * 6 * sizeof(double))
-    if (flags & AMX_F_RMSE) AMX_D2H(out_rmse, ctx->hrmse, (size_t)n_vox * sizeof(double))
-    if (flags & AMX_F_NRMSE) AMX_D2H(out_nrmse, ctx->hnrmse, (size_t)n_vox * sizeof(double))
-    return amx_sync_status(ctx, nullptr);
+    HostOut outs[4] = {{out_estimates, &ctx->hest, 6, true}, {out_rmse, &ctx->hrmse, 1, (flags & AMX_F_RMSE) != 0},
+                       {out_nrmse, &ctx->hnrmse, 1, (flags & AMX_F_NRMSE) != 0}, {nullptr, &ctx->hextra, 1, false}};
+    return fit_host<T>(ctx, y, (const double *)nullptr, n_vox, lut->nS, outs,
+                       [&](double *yb, double *, int64_t cnt, double *e, double *r, double *nr, double *, hipStream_t s) {
+                           return amx_sandi_fit_device(ctx, lut, yb, cnt, lambda1, lambda2, flags, e, r, nr, s);
+                       });
+}
+
+extern "C" {
+
+int amx_noddi_fit(amx_ctx *ctx, const amx_lut *lut, const double *y, const double *dirs, int64_t n_vox, double lambda1,
+                  double lambda2, unsigned flags, double *out_estimates, double *out_rmse, double *out_nrmse, double *out_mod)
+{
+    return noddi_fit_any<double>(ctx, lut, y, dirs, n_vox, lambda1, lambda2, flags, out_estimates, out_rmse, out_nrmse, out_mod);
+}
+
+int amx_noddi_fit_f32(amx_ctx *ctx, const amx_lut *lut, const float *y, const double *dirs, int64_t n_vox, double lambda1,
+                      double lambda2, unsigned flags, double *out_estimates, double *out_rmse, double *out_nrmse, double *out_mod)
+{
+    return noddi_fit_any<float>(ctx, lut, y, dirs, n_vox, lambda1, lambda2, flags, out_estimates, out_rmse, out_nrmse, out_mod);
+}
+
+int amx_freewater_fit(amx_ctx *ctx, const amx_lut *lut, const double *y, const double *dirs, int64_t n_vox, double lambda1,
+                      double lambda2, int is_mouse, unsigned flags, double *out_estimates, double *out_rmse, double *out_nrmse,
+                      double *out_ycorr)
+{
+    return freewater_fit_any<double>(ctx, lut, y, dirs, n_vox, lambda1, lambda2, is_mouse, flags, out_estimates, out_rmse, out_nrmse, out_ycorr);
+}
+
+int amx_freewater_fit_f32(amx_ctx *ctx, const amx_lut *lut, const float *y, const double *dirs, int64_t n_vox, double lambda1,
+                          double lambda2, int is_mouse, unsigned flags, double *out_estimates, double *out_rmse,
+                          double *out_nrmse, double *out_ycorr)
+{
+    return freewater_fit_any<float>(ctx, lut, y, dirs, n_vox, lambda1, lambda2, is_mouse, flags, out_estimates, out_rmse, out_nrmse, out_ycorr);
+}
+
+int amx_sandi_fit(amx_ctx *ctx, const amx_lut *lut, const double *y, int64_t n_vox, double lambda1, double lambda2,
+                  unsigned flags, double *out_estimates, double *out_rmse, double *out_nrmse)
+{
+    return sandi_fit_any<double>(ctx, lut, y, n_vox, lambda1, lambda2, flags, out_estimates, out_rmse, out_nrmse);
+}
+
+int amx_sandi_fit_f32(amx_ctx *ctx, const amx_lut *lut, const float *y, int64_t n_vox, double lambda1, double lambda2,
+                      unsigned flags, double *out_estimates, double *out_rmse, double *out_nrmse)
+{
+    return sandi_fit_any<float>(ctx, lut, y, n_vox, lambda1, lambda2, flags, out_estimates, out_rmse, out_nrmse);
 }
 
 int amx_dir_to_lut_idx(amx_ctx *ctx, const amx_lut *lut, const double *dirs, int64_t n, int32_t *out_idx)

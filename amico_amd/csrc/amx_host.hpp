@@ -35,6 +35,9 @@ struct amx_ctx {
     int64_t stats[4] = {0, 0, 0, 0};
     int64_t vox_base = 0;          // index of the first voxel of the batch being enqueued (chunked host entry points)
     double *dbg_x = nullptr;       // AMX_F_DEBUG_X destination (caller-owned device buffer, amx_set_debug_x)
+    void (*progress)(int64_t, int64_t, void *) = nullptr;   // amx_set_progress
+    void *progress_user = nullptr;
+    DevBuf hy32;                   // float32 signals of the *_fit_f32 entry points
     hipStream_t hs = nullptr;      // non-blocking compute stream of the chunked host entry points
     hipEvent_t hev[2] = {nullptr, nullptr};
 };
@@ -168,4 +171,7 @@ static inline bool amx_fw_use_refill(int n_atoms, int nS, unsigned flags)
     return n_atoms <= 12 && (flags & (AMX_F_RMSE | AMX_F_NRMSE | AMX_F_CORRECTED)) == 0 &&
            ((size_t)nS * 12 + 144 + 4 * (16 * 65 + 12 * 64 + 32)) * sizeof(double) + 16 <= 80 * 1024;
 }
-static inline bool amx_use_lane_solver(int n_atoms) { const char *e = getenv("AMX_WAVE_PER_VOXEL"); return n_atoms <= 16 && !(e && *e && *e != '0'); }
+// lane-per-voxel solvers work on H = A'A + lambda2 I (Gram space): they need the ridge to bound cond(H); with
+// lambda2 (nearly) 0 the problem goes to the QR solver in A-space (wavefront per voxel), like the reference's lasso,
+// which accepts any lambda2 >= 0
+static inline bool amx_use_lane_solver(int n_atoms, double lam2) { const char *e = getenv("AMX_WAVE_PER_VOXEL"); return n_atoms <= 16 && lam2 >= 1e-9 && !(e && *e && *e != '0'); }

@@ -28,18 +28,44 @@ BYTES_PER_VOXEL = 8 * 99 + 24 + 24          # y f64[99] + DIRs f
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def other_models(args):
-    """FreeWater (config 3) / SANDI (config 4) throughput on one GPU; same timing protocol, shorter line."""
+def physical_cores():
+    try:
+        import psutil
+        return int(psutil.cpu_count(logical=False) or 0) or None
+    except Exception:
+        return None
+
+
+def median_rate(fn, n, runs=5):
+    """voxels/s of fn(): one warm-up, then the median of `runs` timed runs"""
+    fn()
+    ts = []
+    for _ in range(runs):
+        t = time.perf_counter(); fn(); ts.append(time.perf_counter() - t)
+    return n / float(np.median(ts)), float(np.median(ts))
+
+
+def pmc_small(model, key):
+    """per-launch counter figure of the lane kernels from the committed profile summary (profiles/pmc_traffic.json)"""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
+            return json.load(f)['small_models'][model][key]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def small_model(model, n, steps, warmup, cpu=True):
+    """FreeWater (config 3) / SANDI (config 4) on one GPU: same timing protocol as the headline, returns the record"""
     import torch
     from amico_amd import _capi, synthetic as S
     from oracle import oracle
     dev = torch.device('cuda', 0)
-    n = args.voxels
     ctx = _capi.Context(0)
     L = _capi.lib()
     lut_dirs = S.fibonacci_hemisphere(500)
     htable = S.build_htable(lut_dirs)
-    if args.model == 'freewater':
+    cores = os.cpu_count() or 1
+    if model == 'freewater':
         scheme = S.make_scheme(1, ((1000.0, 64),), seed=3)
         K = S.freewater_kernels(scheme, lut_dirs)
         y_h, d_h = S.freewater_signals(n, K, htable, scheme, seed=1)
@@ -51,8 +77,9 @@ def other_models(args):
         def step():
             ctx.check(L.amx_freewater_fit_device(ctx._h, lut._h, y.data_ptr(), d.data_ptr(), n, 0.0, 1e-3, 0, 0,
                                                  est.data_ptr(), None, None, None, None))
-        ref = lambda m: oracle.freewater_fit(y_h[:m], d_h[:m], K, htable, nthreads=os.cpu_count())['estimates']
+        ref = lambda m: oracle.freewater_fit(y_h[:m], d_h[:m], K, htable, nthreads=cores)['estimates']
         name = 'FreeWater fit, %d voxels, 65-volume single shell (1 b0 + 64@b1000), 11 atoms, ndirs=500' % n
+        kernel = 'k_freewater_refill<11>'
     else:
         full = S.make_sandi_scheme()
         avg = S.directional_average_scheme(full)
@@ -65,32 +92,48 @@ def other_models(args):
 
         def step():
             ctx.check(L.amx_sandi_fit_device(ctx._h, lut._h, y.data_ptr(), n, 0.0, 5e-3, 0, est.data_ptr(), None, None, None))
-        ref = lambda m: oracle.sandi_fit(y_h[:m], K, Rs, d_in, d_isos, nthreads=os.cpu_count())['estimates']
+        ref = lambda m: oracle.sandi_fit(y_h[:m], K, Rs, d_in, d_isos, nthreads=cores)['estimates']
         name = 'SANDI fit, %d voxels, 5 shells direction-averaged (6 values per voxel), 15 atoms' % n
+        kernel = 'k_sandi_rows<6, 15>'
     ctx.set_profiling(True)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step(); ctx.sync()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     kms = 0.0
-    for _ in range(args.steps):
+    for _ in range(steps):
         step(); ctx.sync()
         kms += ctx.last_kernel_ms(1)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    kms /= args.steps
+    kms /= steps
     m = min(n, 20000)
-    diff = np.abs(est[:m].cpu().numpy() - ref(m))
-    t1 = time.perf_counter(); ref(min(n, 200000)); cpu = min(n, 200000) / (time.perf_counter() - t1)
-    print(json.dumps({'metric': 'voxels/sec, %s fit' % args.model, 'value': n * args.steps / el, 'unit': 'voxels/s',
-                      'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * el / args.steps,
-                      'dtype': 'f64', 'data': 'synthetic', 'config': {'workload': name},
-                      'roofline': {'bound': 'hbm', 'achieved': bpv * n / (kms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
-                                   'unit': 'GB/s', 'frac': bpv * n / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
-                                   'kernel_ms': kms, 'bytes_per_voxel': bpv},
-                      'parity': {'sample_voxels': m, 'max_abs_dmap': float(diff.max())},
-                      'cpu_baseline': {'value': cpu, 'unit': 'voxels/s', 'cores': os.cpu_count(), 'kind': 'port'},
-                      'solver_stats': ctx.last_stats()}))
+    got = est[:m].cpu().numpy()
+    want = ref(m)
+    diff = np.abs(got - want)
+    rel = diff / (np.abs(want) + 1e-3)
+    ach = bpv * n / (kms * 1e-3) / 1e9
+    out = {'metric': 'voxels/sec, %s fit' % model, 'value': n * steps / el, 'unit': 'voxels/s', 'n_gpus': 1, 'steps': steps,
+           'warmup': warmup, 'ms_per_step': 1e3 * el / steps, 'dtype': 'f64', 'data': 'synthetic', 'config': {'workload': name},
+           'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+                        'traffic': pmc_small(model, 'bytes_per_voxel_measured') and pmc_small(model, 'bytes_per_voxel_measured') * n,
+                        'kernel': kernel, 'kernel_ms': kms, 'bytes_per_voxel': bpv},
+           'parity': {'sample_voxels': m, 'max_abs_dmap': float(diff.max()), 'max_rel_dmap': float(rel.max())},
+           'solver_stats': ctx.last_stats()}
+    if cpu:
+        oracle.use_fast_build(True)
+        mc = min(n, 500000)
+        rate, dt = median_rate(lambda: ref(mc), mc, runs=3)
+        oracle.use_fast_build(False)
+        out['cpu_baseline'] = {'value': rate, 'unit': 'voxels/s', 'cores': cores, 'physical_cores': physical_cores(), 'kind': 'port',
+                               'sample': 'first %d voxels, oracle/amico_oracle.c -O3 -march=native, %d threads, median of 3 runs (%.2f s)' % (mc, cores, dt)}
+    del y, est
+    torch.cuda.empty_cache()
+    return out
+
+
+def other_models(args):
+    print(json.dumps(small_model(args.model, args.voxels, args.steps, args.warmup)))
 
 
 def dti_directions(args):
@@ -350,7 +393,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--voxels', type=int, default=1_000_000, help='voxels per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--host', action='store_true', help='also time the host-buffer entry point (PCIe inclusive)')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip configs 3 / 4 (FreeWater 2 M, SANDI 1 M) of the default run')
     ap.add_argument('--model', default='noddi', choices=['noddi', 'freewater', 'sandi', 'dti', 'prep', 'lut', 'pipeline'],
                     help='noddi = the BASELINE.json headline; the others are extra measurements (configs 3, 4)')
     args = ap.parse_args()
@@ -468,25 +511,62 @@ def main():
                              'median_abs_dmap': float(np.median(diff)),
                              'frac_within_1e-6': float((diff < 1e-6).mean()),
                              'frac_within_1e-4': float((diff < 1e-4).mean())}
-            if args.host:
-                # host numpy in -> host numpy out through amx_noddi_fit (H2D + kernels + D2H); never `value`
-                _capi.noddi_fit(ctx, lut, y_h, d_h, 0.5, 1e-3, 3)
+            # host numpy in -> host numpy out through amx_noddi_fit (H2D + kernels + D2H): the PCIe-inclusive rate,
+            # reported beside the headline, never as `value`
+            _capi.noddi_fit(ctx, lut, y_h, d_h, 0.5, 1e-3, 3)
+            hb = []
+            for _ in range(3):
                 t1 = time.perf_counter()
                 _capi.noddi_fit(ctx, lut, y_h, d_h, 0.5, 1e-3, 3)
-                out['host_buffers_voxels_per_s'] = n / (time.perf_counter() - t1)
+                hb.append(time.perf_counter() - t1)
+            other = {'noddi_host_buffers': {'metric': 'voxels/sec, NODDI fit, host buffers in/out (PCIe inclusive)',
+                                            'value': n / float(np.median(hb)), 'unit': 'voxels/s', 'voxels': n,
+                                            'ms_per_call': 1e3 * float(np.median(hb)),
+                                            'note': 'float64 signals from pageable host memory, batches pipelined behind the solver'}}
+            try:
+                y32 = y_h.astype(np.float32)
+                _capi.noddi_fit(ctx, lut, y32, d_h, 0.5, 1e-3, 3)
+                hb = []
+                for _ in range(3):
+                    t1 = time.perf_counter()
+                    e32 = _capi.noddi_fit(ctx, lut, y32, d_h, 0.5, 1e-3, 3)[0]
+                    hb.append(time.perf_counter() - t1)
+                other['noddi_host_buffers_f32'] = {'metric': 'voxels/sec, NODDI fit, float32 signals from host buffers (PCIe inclusive)',
+                                                   'value': n / float(np.median(hb)), 'unit': 'voxels/s', 'voxels': n,
+                                                   'ms_per_call': 1e3 * float(np.median(hb)),
+                                                   'max_abs_dmap_vs_f64_upload': float(np.abs(e32[:ns] - est[:ns].cpu().numpy()).max()),
+                                                   'note': 'lossless for AMICO (the image is float32, core.py:136): half the PCIe bytes'}
+                del y32
+            except (TypeError, AttributeError, ValueError):
+                pass
             if not args.no_cpu_baseline:
-                # bounded CPU leg: the oracle (a port: the reference's cyspams path cannot be built),
-                # same chunk-per-thread structure as BaseModel.fit, on all host cores, ~15 s
-                t1 = time.perf_counter()
-                oracle.noddi_fit(y_h[:2000], d_h[:2000], K, htable, scheme.dwi_idx, nthreads=cores)
-                rate = 2000 / (time.perf_counter() - t1)
-                m = int(min(n, max(4000, rate * 15)))
-                t1 = time.perf_counter()
-                oracle.noddi_fit(y_h[:m], d_h[:m], K, htable, scheme.dwi_idx, nthreads=cores)
-                dt = time.perf_counter() - t1
-                out['cpu_baseline'] = {'value': m / dt, 'unit': 'voxels/s', 'cores': cores, 'kind': 'port',
-                                       'sample': 'first %d voxels of the same workload, oracle/amico_oracle.c '
-                                                 '(Lawson-Hanson NNLS + LARS lasso), %d threads, %.1f s' % (m, cores, dt)}
+                # bounded CPU legs on the host cores of this box: the oracle -- a port, the reference's
+                # cyspams path cannot be built -- at -O3 -march=native, the reference's chunk-per-thread structure
+                # (models.pyx:204-211), one warm-up + median of 5 runs.  "faithful": voxels in the caller's order, so the
+                # LUT slice is copied per voxel like models.pyx:905; "optimised": voxels presented sorted by LUT index
+                # (one copy per orientation and thread)
+                oracle.use_fast_build(True)
+                m = min(n, 100000)
+                fit = lambda yy, dd: oracle.noddi_fit(yy, dd, K, htable, scheme.dwi_idx, nthreads=cores)
+                rate_f, dt_f = median_rate(lambda: fit(y_h[:m], d_h[:m]), m)
+                order = np.argsort(S.lut_indices(d_h[:m], htable), kind='stable')
+                ys, ds = np.ascontiguousarray(y_h[:m][order]), np.ascontiguousarray(d_h[:m][order])
+                rate_o, dt_o = median_rate(lambda: fit(ys, ds), m)
+                oracle.use_fast_build(False)
+                out['cpu_baseline'] = {'value': rate_f, 'unit': 'voxels/s', 'cores': cores, 'physical_cores': physical_cores(),
+                                       'kind': 'port', 'variant': 'faithful',
+                                       'optimised': {'value': rate_o, 'unit': 'voxels/s',
+                                                     'sample': 'the same voxels sorted by LUT index (one dictionary copy per orientation)'},
+                                       'sample': 'first %d voxels of the same workload, oracle/amico_oracle.c (Lawson-Hanson NNLS + LARS '
+                                                 'lasso) -O3 -march=native, %d threads, warm-up + median of 5 runs (%.2f s / %.2f s)'
+                                                 % (m, cores, dt_f, dt_o)}
+            if not args.no_other_configs:
+                # free the headline's buffers first: configs 3 and 4 run on the same GPU, one after the other
+                del y, d, est
+                torch.cuda.empty_cache()
+                other['freewater_2M'] = small_model('freewater', 2_000_000, 5, 2, cpu=not args.no_cpu_baseline)
+                other['sandi_1M'] = small_model('sandi', 1_000_000, 5, 2, cpu=not args.no_cpu_baseline)
+            out['other_configs'] = other
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

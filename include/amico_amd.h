@@ -70,9 +70,10 @@ void amx_lut_destroy(amx_lut *lut);
 int amx_dir_to_lut_idx(amx_ctx *ctx, const amx_lut *lut, const double *dirs, int64_t n,
                        int32_t *out_idx);
 
-/* ---- model.fit hot loops, HOST buffers in / out (H2D + kernels + D2H, blocking; amx_noddi_fit overlaps the
- * copies of large inputs with the solver, in batches).
- * y f64[n_vox][nS] (evaluation.y, core.py:451-452), dirs f64[n_vox][3] (evaluation.DIRs).  */
+/* ---- model.fit hot loops, HOST buffers in / out (H2D + kernels + D2H, blocking; the copies of large
+ * inputs overlap with the solver, in batches).
+ * y f64[n_vox][nS] (evaluation.y, core.py:451-452), dirs f64[n_vox][3] (evaluation.DIRs).
+ * lambda1 >= 0, lambda2 >= 0 like cyspams' lasso (lambda2 = 0 runs the QR solver in A-space).  */
 
 /* NODDI._fit models.pyx:816-991: estimates f64[n_vox][3 (+1 ex-vivo)] = NDI, ODI, FWF(, dot) */
 int amx_noddi_fit(amx_ctx *ctx, const amx_lut *lut, const double *y, const double *dirs,
@@ -86,6 +87,24 @@ int amx_freewater_fit(amx_ctx *ctx, const amx_lut *lut, const double *y, const d
 int amx_sandi_fit(amx_ctx *ctx, const amx_lut *lut, const double *y, int64_t n_vox,
                   double lambda1, double lambda2, unsigned flags,
                   double *out_estimates, double *out_rmse, double *out_nrmse);
+
+/* The same three calls with FLOAT32 signals: the image is float32 in the reference (core.py:136) and only cast to
+ * float64 when the masked voxels are gathered (core.py:451), so a float32 `y` carries the same values in half the PCIe
+ * bytes; it is widened on the GPU and every result is identical to the float64 call.                           */
+int amx_noddi_fit_f32(amx_ctx *ctx, const amx_lut *lut, const float *y, const double *dirs,
+                      int64_t n_vox, double lambda1, double lambda2, unsigned flags,
+                      double *out_estimates, double *out_rmse, double *out_nrmse, double *out_mod);
+int amx_freewater_fit_f32(amx_ctx *ctx, const amx_lut *lut, const float *y, const double *dirs,
+                          int64_t n_vox, double lambda1, double lambda2, int is_mouse, unsigned flags,
+                          double *out_estimates, double *out_rmse, double *out_nrmse, double *out_ycorr);
+int amx_sandi_fit_f32(amx_ctx *ctx, const amx_lut *lut, const float *y, int64_t n_vox,
+                      double lambda1, double lambda2, unsigned flags,
+                      double *out_estimates, double *out_rmse, double *out_nrmse);
+
+/* Progress of the host-buffer calls: models.pyx:28-43, 981 keep a per-thread voxel counter that ProgressBar polls
+ * (util.py); here `callback(done, total, user)` is called from the calling thread as batches of voxels complete (large
+ * inputs are fitted in batches of 262 144 voxels) and once with done == total at the end.  NULL unregisters.       */
+int amx_set_progress(amx_ctx *ctx, void (*callback)(int64_t done, int64_t total, void *user), void *user);
 
 /* ---- the same with DEVICE buffers (inputs already resident in HBM, e.g. torch tensors'
  * data_ptr()); work is enqueued on `hip_stream` (a hipStream_t, NULL = default stream) and

@@ -490,7 +490,7 @@ static void noddi_chunk(void *vctx, int tid, int i0, int i1)
     double *x = (double *)calloc((size_t)n_atoms * 2 + nS + dwi, sizeof(double));
     double *x3 = x + n_atoms, *yest = x3 + n_atoms, *y2 = yest + nS;
     int *posidx = (int *)malloc(sizeof(int) * n_atoms);
-    int i, j, k;
+    int i, j, k, last_lut = -1;
     (void)tid;
     for (i = i0; i < i1; i++) {
         const double *yi = cx->y + (size_t)i * nS;
@@ -503,13 +503,19 @@ static void noddi_chunk(void *vctx, int tid, int i0, int i1)
             pthread_mutex_unlock(&cx->mu);
             continue;
         }
-        /* prepare dictionary (models.pyx:905-908) */
+        /* prepare dictionary (models.pyx:905-908).  The reference copies the LUT slice for every voxel; the copy is
+         * skipped when the previous voxel of this thread had the same orientation (A is never modified by the solvers):
+         * identical results, and callers that present the voxels sorted by LUT index pay one copy per orientation
+         * ("optimised" CPU baseline of bench.py; unsorted input = the reference's cost) */
+        if (lut != last_lut) {
         for (k = 0; k < n_wm; k++) {
             const float *src = a->wm + ((size_t)k * a->ndirs + lut) * nS;
             for (j = 0; j < nS; j++) A[(size_t)k * nS + j] = (double)src[j];
         }
         if (a->is_exvivo) for (j = 0; j < nS; j++) A[(size_t)(n_atoms - 2) * nS + j] = 1.0;
         for (j = 0; j < nS; j++) A[(size_t)(n_atoms - 1) * nS + j] = (double)a->iso[j];
+        last_lut = lut;
+        }
         /* fit_1 (CSF), models.pyx:911 */
         amo_nnls(A, yi, nS, n_atoms, x, &rn);
         if (cx->x_dbg) memcpy(cx->x_dbg + ((size_t)i * 3 + 0) * n_atoms, x, sizeof(double) * n_atoms);

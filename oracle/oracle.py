@@ -40,18 +40,30 @@ class SandiArgs(C.Structure):
                 ("compute_rmse", C.c_int), ("compute_nrmse", C.c_int), ("nthreads", C.c_int)]
 
 
-def build(force=False):
-    so = os.path.join(_HERE, "libamico_oracle.so")
+def build(force=False, fast=False):
+    so = os.path.join(_HERE, "libamico_oracle_fast.so" if fast else "libamico_oracle.so")
     src = os.path.join(_HERE, "amico_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return so
 
 
+def use_fast_build(on=True):
+    """switch to the -O3 -march=native build of the same source (bench.py's cpu_baseline leg only; the checker build
+    stays the default)"""
+    global _LIB, _FAST
+    _FAST, _LIB = bool(on), None
+    if on:      # -march=native: always compile on the machine that is going to run it
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libamico_oracle_fast.so"])
+
+
+_FAST = False
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        L = C.CDLL(build())
+        L = C.CDLL(build(fast=_FAST))
         L.amo_dir_to_lut_idx.restype = C.c_int
         L.amo_dir_to_lut_idx.argtypes = [c_dp, C.POINTER(C.c_int16), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.amo_nnls.restype = C.c_int

@@ -1,0 +1,118 @@
+"""Boundary completions of the C ABI: float32 signal upload, the progress callback of the host-buffer
+calls, lambda2 = 0 (the reference's lasso accepts it), argument validation of the device wrappers."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _noddi(htable500, n, seed=3):
+    from amico_amd import _capi, get_context, synthetic as S
+    dirs, ht = htable500['dirs'], htable500['htable']
+    sch = S.make_scheme(seed=0)
+    K = S.noddi_kernels(sch, dirs)
+    y, d = S.noddi_signals(n, K, ht, sch, seed=seed)
+    ctx = get_context()
+    return ctx, _capi.upload_noddi(ctx, K, ht, sch.dwi_idx), K, ht, sch, y, d
+
+
+def test_float32_upload_is_lossless_and_progress_is_reported(htable500):
+    """y is float32-representable in AMICO (core.py:136, 451): the f32 entry point returns the f64 entry point's maps
+    bit for bit; 900 000 voxels = three pipelined batches, so the callback fires between batches and at the end"""
+    from amico_amd import _capi
+    n = 900_000
+    ctx, lut, K, ht, sch, y, d = _noddi(htable500, n)
+    y32 = y.astype(np.float32)
+    y64 = y32.astype(np.float64)
+    seen = []
+    ctx.set_progress(lambda done, total: seen.append((done, total)))
+    e32, r32, _, _ = _capi.noddi_fit(ctx, lut, y32, d, 0.5, 1e-3, 3, rmse=True)
+    ctx.set_progress(None)
+    e64, r64, _, _ = _capi.noddi_fit(ctx, lut, y64, d, 0.5, 1e-3, 3, rmse=True)
+    assert np.array_equal(e32, e64) and np.array_equal(r32, r64)
+    assert seen and seen[-1] == (n, n)
+    assert all(t == n for _, t in seen) and [s for s, _ in seen] == sorted(s for s, _ in seen)
+    assert len(seen) >= 2 and 0 < seen[0][0] < n
+    # the other two models, small inputs (one-shot path)
+    from amico_amd import synthetic as S
+    s1 = S.make_scheme(1, ((1000.0, 64),), seed=3)
+    Kf = S.freewater_kernels(s1, htable500['dirs'])
+    yf, df = S.freewater_signals(5000, Kf, ht, s1, seed=2)
+    lf = _capi.upload_freewater(ctx, Kf, ht)
+    a = _capi.freewater_fit(ctx, lf, yf.astype(np.float32), df, 0.0, 1e-3, False, corrected=True)
+    b = _capi.freewater_fit(ctx, lf, yf.astype(np.float32).astype(np.float64), df, 0.0, 1e-3, False, corrected=True)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[3], b[3])
+    avg = S.directional_average_scheme(S.make_sandi_scheme())
+    Ks, Rs, d_in, d_isos = S.sandi_kernels(avg)
+    ys = S.sandi_signals(5000, Ks, avg, seed=2)
+    ls = _capi.upload_sandi(ctx, Ks, Rs, d_in, d_isos)
+    a = _capi.sandi_fit(ctx, ls, ys.astype(np.float32), 0.0, 5e-3)
+    b = _capi.sandi_fit(ctx, ls, ys.astype(np.float32).astype(np.float64), 0.0, 5e-3)
+    assert np.array_equal(a[0], b[0])
+
+
+def test_lambda2_zero_is_accepted(htable500):
+    """set_solver(lambda2=0) works in the reference (cyspams lasso); here it runs the QR solver in A-space.  Certified by
+    the KKT conditions of the device coefficients (the optimum need not be unique without the ridge; A x is)"""
+    import torch
+    from amico_amd import _capi, synthetic as S
+    from oracle import oracle
+    ctx, lut, K, ht, sch, y, d = _noddi(htable500, 3000, seed=8)
+    dev = torch.device('cuda', 0)
+    est, _, _, _, xd = _capi.noddi_fit_device(ctx, lut, torch.from_numpy(y).to(dev), torch.from_numpy(d).to(dev), 0.3, 0.0, 3,
+                                              return_x=True)
+    ctx.sync()
+    x = xd.cpu().numpy()
+    assert np.isfinite(est.cpu().numpy()).all()
+    idx = S.lut_indices(d, ht)
+    n_wm = K['wm'].shape[0]
+    iso = K['iso'].astype(np.float64)
+    dwi = np.asarray(sch.dwi_idx)
+    worst_p = worst_z = 0.0
+    for v in range(0, 3000, 7):
+        A = np.concatenate([K['wm'][:, idx[v], :].astype(np.float64), iso[None, :]], axis=0).T
+        A2 = A[dwi][:, :n_wm] * K['norms'][0][None, :]
+        y2 = np.maximum(y[v, dwi] - x[v, 0, -1] * iso[dwi], 0.0)
+        xl = x[v, 1, :n_wm]
+        g = A2.T @ (y2 - A2 @ xl) - 0.3
+        worst_p = max(worst_p, np.abs(g[xl > 0]).max(initial=0.0))
+        worst_z = max(worst_z, g[xl == 0].max(initial=0.0))
+    assert worst_p < 1e-9 and worst_z < 1e-9, (worst_p, worst_z)
+    # FreeWater with lambda1 = lambda2 = 0 is plain NNLS: the fitted signal A x is unique
+    s1 = S.make_scheme(1, ((1000.0, 64),), seed=3)
+    Kf = S.freewater_kernels(s1, htable500['dirs'])
+    yf, df = S.freewater_signals(2000, Kf, ht, s1, seed=4)
+    lf = _capi.upload_freewater(ctx, Kf, ht)
+    estf, _, _, _, xf = _capi.freewater_fit_device(ctx, lf, torch.from_numpy(yf).to(dev), torch.from_numpy(df).to(dev), 0.0, 0.0,
+                                                   False, return_x=True)
+    ctx.sync()
+    xf = xf.cpu().numpy()
+    ii = S.lut_indices(df, ht)
+    for v in range(0, 2000, 11):
+        A = np.concatenate([Kf['D'][:, ii[v], :], Kf['CSF']], axis=0).astype(np.float64).T
+        xr, _, _ = oracle.nnls(A, yf[v])
+        assert np.abs(A @ xf[v] - A @ xr).max() < 1e-8
+        w = A.T @ (yf[v] - A @ xf[v])
+        assert xf[v].min() >= 0.0 and w[xf[v] == 0].max(initial=0.0) < 1e-9 and np.abs(w[xf[v] > 0]).max(initial=0.0) < 1e-9
+
+
+def test_device_wrappers_reject_mismatched_buffers(htable500):
+    """the kernels index y with the dictionary's nS as the row stride: a tensor of another width must raise, not fit garbage"""
+    import torch
+    from amico_amd import _capi
+    ctx, lut, K, ht, sch, y, d = _noddi(htable500, 64)
+    dev = torch.device('cuda', 0)
+    yt, dt = torch.from_numpy(y).to(dev), torch.from_numpy(d).to(dev)
+    with pytest.raises(ValueError):
+        _capi.noddi_fit_device(ctx, lut, yt[:, :90].contiguous(), dt, 0.5, 1e-3, 3)
+    with pytest.raises(ValueError):
+        _capi.noddi_fit_device(ctx, lut, yt.float(), dt, 0.5, 1e-3, 3)
+    with pytest.raises(ValueError):
+        _capi.noddi_fit_device(ctx, lut, yt, dt[:, :2].contiguous(), 0.5, 1e-3, 3)
+    with pytest.raises(ValueError):
+        _capi.noddi_fit_device(ctx, lut, yt, dt, 0.5, 1e-3, 4)           # map count of an ex-vivo model
+    est, _, _, _ = _capi.noddi_fit_device(ctx, lut, yt, dt, 0.5, 1e-3, 3)
+    ctx.sync()
+    assert est.shape == (64, 3)
