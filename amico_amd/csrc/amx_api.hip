@@ -568,14 +568,16 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
     const bool was_profiling = ctx->profiling;
     if (pipelined) ctx->profiling = false;
     hipStream_t s = pipelined ? ctx->hs : nullptr;
-    int64_t off = 0;
+    int64_t off = 0, done_before[2] = {0, 0};         // voxels complete once the event of that buffer has fired
     for (int c = 0; off < n_vox; c++) {
         // the last batch absorbs a short remainder
-        const int64_t cnt = !pipelined ? n_vox : ((n_vox - off < kHostBatch + kHostBatch / 2) ? n_vox - off : kHostBatch);
+        // (the first copy is the only one the solver cannot hide: the batches start small and double up to kHostBatch)
+        const int64_t ramp = kHostBatch >> (c < 3 ? 3 - c : 0);
+        const int64_t cnt = !pipelined ? n_vox : ((n_vox - off < ramp + ramp / 2) ? n_vox - off : ramp);
         int b = c & 1;
         if (pipelined && c >= 2) {
             HIPCHK(ctx, hipEventSynchronize(ctx->hev[b]));           // batch c-2 has released this buffer
-            progress(ctx, (int64_t)(c - 1) * kHostBatch, n_vox);     // batches 0 .. c-2 are complete
+            progress(ctx, done_before[b], n_vox);                    // batches 0 .. c-2 are complete
         }
         // (a remainder-absorbing last batch may exceed kHostBatch: it then uses both halves, which are free by then)
         if (cnt > kHostBatch && pipelined) { HIPCHK(ctx, hipStreamSynchronize(ctx->hs)); b = 0; }
@@ -591,15 +593,15 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
         }
         if (dirs) HIPCHK(ctx, hipMemcpy(db, dirs + (size_t)off * 3, (size_t)cnt * 3 * sizeof(double), hipMemcpyHostToDevice));
         // the copy above took a while: has the previous batch finished meanwhile? (a query, never a wait)
-        if (pipelined && c >= 1 && ctx->progress && hipEventQuery(ctx->hev[(c - 1) & 1]) == hipSuccess) progress(ctx, off, n_vox);
+        if (pipelined && c >= 1 && ctx->progress && hipEventQuery(ctx->hev[(c - 1) & 1]) == hipSuccess) progress(ctx, done_before[(c - 1) & 1], n_vox);
         ctx->vox_base = off;
         rc = enqueue(yb, db, cnt, (double *)outs[0].buf->p + (size_t)off * outs[0].cols,
                      outs[1].on ? (double *)outs[1].buf->p + off : nullptr, outs[2].on ? (double *)outs[2].buf->p + off : nullptr,
                      outs[3].on ? (double *)outs[3].buf->p + (size_t)off * outs[3].cols : nullptr, s);
         ctx->vox_base = 0;
         if (rc) { ctx->profiling = was_profiling; return rc; }
-        if (pipelined) HIPCHK(ctx, hipEventRecord(ctx->hev[b], ctx->hs));
         off += cnt;
+        if (pipelined) { HIPCHK(ctx, hipEventRecord(ctx->hev[b], ctx->hs)); done_before[b] = off; }
     }
     ctx->profiling = was_profiling;
     rc = amx_sync_status(ctx, s);

@@ -386,6 +386,53 @@ def pmc_traffic(stage, n):
         return None
 
 
+def device_barrier(dev, world):
+    """both sides of the timed region: drain the device, meet the other ranks, drain again"""
+    import torch
+    import torch.distributed as dist
+    if dev.type == 'cuda':
+        torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    if dev.type == 'cuda':
+        torch.cuda.synchronize()
+
+
+def sharded_step(fit, est, gathered, world):
+    """one step of the N-GPU path: this rank fits its own shard, then ONE all_gather of the maps (RCCL under nccl)"""
+    from amico_amd.parallel import gather_equal
+
+    def step():
+        fit()
+        if world > 1:
+            gather_equal(est, gathered)
+    return step
+
+
+def timed_steps(step, step_sync, steps, warmup, world, dev, per_step=None):
+    """W untimed warm-up steps, then exactly K steps between two barriers; returns the MAX over ranks of the elapsed
+    seconds (the contract of the driver's scaling runs)"""
+    import torch
+    import torch.distributed as dist
+    for _ in range(warmup):
+        step()
+        step_sync()
+    device_barrier(dev, world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+        step_sync()
+        if per_step is not None:
+            per_step()
+    device_barrier(dev, world)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -444,34 +491,18 @@ def main():
     L = _capi.lib()
     ctx.set_profiling(True)
 
-    def step():
+    def fit():
         ctx.check(L.amx_noddi_fit_device(ctx._h, lut._h, y.data_ptr(), d.data_ptr(), n, 0.5, 1e-3, 0,
                                          est.data_ptr(), None, None, None, stream))
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, est)      # the single collective of the path
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-        ctx.sync(stream)
-    barrier()
-    t0 = time.perf_counter()
+    step = sharded_step(fit, est, gathered, world)          # fit + the single collective of the path
     kms = np.zeros(4)
-    for _ in range(args.steps):
-        step()
-        ctx.sync(stream)                                    # status of the step (raises on error)
-        kms += [ctx.last_kernel_ms(w) for w in range(4)]    # HIP events on the launch stream
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    def per_step():
+        kms[:] += [ctx.last_kernel_ms(w) for w in range(4)]    # HIP events on the launch stream
+
+    # ctx.sync: status of the step (raises on error)
+    elapsed = timed_steps(step, lambda: ctx.sync(stream), args.steps, args.warmup, world, dev, per_step)
     kms /= max(1, args.steps)
     stats = ctx.last_stats()
 

@@ -131,3 +131,66 @@ def test_fit_sharded_world2_gloo(tmp_path, sandi_fix):
         got = np.load(tmp_path / f'fit{r}.npy')
         assert got.shape == (200, 6)
         assert np.allclose(got, sandi_fix['estimates'], rtol=1e-7, atol=1e-7)
+
+
+def _worker_presharded(rank, world, port, tmp):
+    """every rank holds ONLY its shard (n_total given); all results travel in one packed all_gather; then bench.py's own
+    step / timing helpers are driven with a stand-in fit (the GPU library cannot run here)"""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from amico_amd.parallel import fit_sharded, shard_range
+    full = np.load(os.path.join(tmp, 'full.npy'))
+    n = full.shape[0]
+    i, j = shard_range(n, rank, world)
+
+    class StandIn:
+        def fit(self, ev):
+            return {'estimates': ev.y[:, :3] * 2.0, 'rmse': ev.y[:, 3].copy(), 'y_corrected': ev.y + 1.0}
+
+    class Ev:
+        y, DIRs = full[i:j].copy(), full[i:j, :3].copy()          # this rank's rows only
+    out = fit_sharded(StandIn(), Ev(), n_total=n)
+    assert np.array_equal(out['estimates'], full[:, :3] * 2.0) and out['estimates'].shape == (n, 3)
+    assert np.array_equal(out['rmse'], full[:, 3]) and out['rmse'].shape == (n,)
+    assert np.array_equal(out['y_corrected'], full + 1.0)
+    try:
+        fit_sharded(StandIn(), Ev(), n_total=n + world)          # shard length does not match: refused, not mis-gathered
+        raise AssertionError('mismatched shard accepted')
+    except ValueError:
+        pass
+    # bench.py: one rank = one shard of equal size, ONE collective per step, max-over-ranks timing
+    import bench
+    m = 257
+    est = torch.zeros((m, 3), dtype=torch.float64)
+    gathered = torch.zeros((world * m, 3), dtype=torch.float64)
+    calls = []
+
+    def fit():
+        calls.append(1)
+        est[:] = float(rank + 1) * len(calls)
+    step = bench.sharded_step(fit, est, gathered, world)
+    el = bench.timed_steps(step, lambda: None, 3, 2, world, torch.device('cpu'))
+    assert len(calls) == 5
+    for r in range(world):
+        assert torch.all(gathered[r * m:(r + 1) * m] == float(r + 1) * 5)
+    t = torch.tensor([el], dtype=torch.float64)
+    lo = t.clone(); dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    assert float(lo) == el                                       # every rank reports the same (maximum) time
+    np.save(os.path.join(tmp, f'ok{rank}.npy'), np.array([el]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_presharded_fit_and_bench_step_gloo(tmp_path, world):
+    import torch.multiprocessing as mp
+    rng = np.random.default_rng(world)
+    np.save(tmp_path / 'full.npy', rng.random((1003, 7)))       # 1003 = 3 * 334 + 1 = 2 * 501 + 1: odd remainders
+    port = 33500 + (os.getpid() % 2000) + world
+    mp.spawn(_worker_presharded, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert os.path.exists(tmp_path / f'ok{r}.npy')
