@@ -19,7 +19,7 @@ SYMBOLS = ['amx_version', 'amx_ctx_create', 'amx_ctx_destroy', 'amx_last_error',
            'amx_lut_upload_noddi', 'amx_lut_upload_freewater', 'amx_lut_upload_sandi', 'amx_lut_destroy',
            'amx_dir_to_lut_idx', 'amx_noddi_fit', 'amx_freewater_fit', 'amx_sandi_fit',
            'amx_noddi_fit_device', 'amx_freewater_fit_device', 'amx_sandi_fit_device', 'amx_sync_status',
-           'amx_set_debug_x', 'amx_noddi_fit_f32', 'amx_freewater_fit_f32', 'amx_sandi_fit_f32', 'amx_set_progress',
+           'amx_set_debug_x', 'amx_lut_upload_czb', 'amx_czb_fit', 'amx_czb_fit_f32', 'amx_czb_fit_device', 'amx_noddi_fit_f32', 'amx_freewater_fit_f32', 'amx_sandi_fit_f32', 'amx_set_progress',
            'amx_set_profiling', 'amx_last_kernel_ms', 'amx_last_stats', 'amx_selftest',
            'amx_dti_create', 'amx_dti_destroy', 'amx_dti_directions', 'amx_dti_directions_device',
            'amx_prep_create', 'amx_prep_destroy', 'amx_prep_gather', 'amx_prep_gather_device',
@@ -88,6 +88,11 @@ def lib():
                                         c_dp, c_dp, c_dp, c_dp]
     L.amx_sandi_fit_f32.argtypes = [c_vp, c_vp, c_fp, C.c_int64, C.c_double, C.c_double, C.c_uint, c_dp, c_dp, c_dp]
     L.amx_set_progress.argtypes = [c_vp, PROGRESS_CB, c_vp]
+    L.amx_lut_upload_czb.argtypes = [c_vp, c_fp, c_fp, c_fp, c_dp, c_i16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.POINTER(c_vp)]
+    L.amx_czb_fit.argtypes = [c_vp, c_vp, c_dp, c_dp, C.c_int64, C.c_double, C.c_double, C.c_uint, c_dp, c_dp, c_dp]
+    L.amx_czb_fit_f32.argtypes = [c_vp, c_vp, c_fp, c_dp, C.c_int64, C.c_double, C.c_double, C.c_uint, c_dp, c_dp, c_dp]
+    L.amx_czb_fit_device.argtypes = [c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_double, C.c_double, C.c_uint, c_vp, c_vp, c_vp, c_vp]
     L.amx_set_profiling.argtypes = [c_vp, C.c_int]
     L.amx_last_kernel_ms.argtypes = [c_vp, C.c_int, C.POINTER(C.c_float)]
     L.amx_last_stats.argtypes = [c_vp, c_i64p]
@@ -246,6 +251,23 @@ def upload_sandi(ctx, kernels, Rs, d_in, d_isos):
     return Lut(ctx, h, 'SANDI', nS, n_atoms, 6)
 
 
+def upload_czb(ctx, kernels, Rs, htable):
+    wmr = np.ascontiguousarray(kernels['wmr'], dtype=np.float32)
+    wmh = np.ascontiguousarray(kernels['wmh'], dtype=np.float32)
+    iso = np.ascontiguousarray(kernels['iso'], dtype=np.float32)
+    Rs = np.ascontiguousarray(Rs, dtype=np.float64)
+    if wmr.ndim != 3 or wmh.ndim != 3 or iso.ndim != 2 or wmh.shape[1:] != wmr.shape[1:] or iso.shape[1] != wmr.shape[2] \
+            or Rs.shape != (wmr.shape[0],):
+        raise ValueError('CylinderZeppelinBall KERNELS / Rs have inconsistent shapes')
+    ht = np.ascontiguousarray(htable, dtype=np.int16)
+    if ht.size != 181 * 181:
+        raise ValueError('htable must have 181*181 entries')
+    h = c_vp()
+    ctx.check(lib().amx_lut_upload_czb(ctx._h, _p(wmr, c_fp), _p(wmh, c_fp), _p(iso, c_fp), _p(Rs, c_dp), _p(ht, c_i16p),
+                                       wmr.shape[0], wmh.shape[0], iso.shape[0], wmr.shape[1], wmr.shape[2], C.byref(h)))
+    return Lut(ctx, h, 'CylinderZeppelinBall', wmr.shape[2], wmr.shape[0] + wmh.shape[0] + iso.shape[0], 3)
+
+
 def _check_y(y, nS):
     """float32 signals stay float32 (amx_*_fit_f32: the image dtype of the reference, half the PCIe bytes, same results);
     anything else is passed as float64 like evaluation.y"""
@@ -311,6 +333,21 @@ def sandi_fit(ctx, lut, y, lambda1, lambda2, rmse=False, nrmse=False):
     return est, r, nr
 
 
+def czb_fit(ctx, lut, y, dirs, lambda1, lambda2, rmse=False, nrmse=False):
+    y = _check_y(y, lut.nS)
+    n = y.shape[0]
+    dirs = _check_dirs(dirs, n)
+    flags = (F_RMSE if rmse else 0) | (F_NRMSE if nrmse else 0)
+    est = np.zeros((n, 3), dtype=np.float64, order='C')
+    r = np.zeros(n) if rmse else None
+    nr = np.zeros(n) if nrmse else None
+    f32, yp = _yp(y)
+    fn = lib().amx_czb_fit_f32 if f32 else lib().amx_czb_fit
+    ctx.check(fn(ctx._h, lut._h, yp, _p(dirs, c_dp), n, float(lambda1), float(lambda2), flags, _p(est, c_dp), _p(r, c_dp),
+                 _p(nr, c_dp)))
+    return est, r, nr
+
+
 # ---- the same three fits on DEVICE-resident inputs (torch tensors used as plain device buffers); outputs are torch
 #      tensors on the same device, enqueued on `stream`; the caller synchronises with ctx.sync(stream)
 def _dptr(t):
@@ -372,6 +409,20 @@ def freewater_fit_device(ctx, lut, y_t, dirs_t, lambda1, lambda2, is_mouse, rmse
                                              int(bool(is_mouse)), flags, _dptr(est), _dptr(r), _dptr(nr), _dptr(yc),
                                              c_vp(stream or 0)))
     return (est, r, nr, yc, xd) if return_x else (est, r, nr, yc)
+
+
+def czb_fit_device(ctx, lut, y_t, dirs_t, lambda1, lambda2, rmse=False, nrmse=False, stream=None, return_x=False):
+    import torch
+    _check_dev(lut, y_t, dirs_t)
+    n, f64 = y_t.shape[0], dict(dtype=torch.float64, device=y_t.device)
+    xd, fx = _debug_x(ctx, (n, lut.n_atoms), y_t, return_x)
+    flags = (F_RMSE if rmse else 0) | (F_NRMSE if nrmse else 0) | fx
+    est = torch.empty((n, 3), **f64)
+    r = torch.empty(n, **f64) if rmse else None
+    nr = torch.empty(n, **f64) if nrmse else None
+    ctx.check(lib().amx_czb_fit_device(ctx._h, lut._h, _dptr(y_t), _dptr(dirs_t), n, float(lambda1), float(lambda2), flags,
+                                       _dptr(est), _dptr(r), _dptr(nr), c_vp(stream or 0)))
+    return (est, r, nr, xd) if return_x else (est, r, nr)
 
 
 def sandi_fit_device(ctx, lut, y_t, lambda1, lambda2, rmse=False, nrmse=False, stream=None, return_x=False):

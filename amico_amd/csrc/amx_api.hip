@@ -304,6 +304,43 @@ int amx_lut_upload_sandi(amx_ctx *ctx, const double *signal, const double *norms
     return AMX_OK;
 }
 
+int amx_lut_upload_czb(amx_ctx *ctx, const float *wmr, const float *wmh, const float *iso, const double *Rs,
+                       const int16_t *htable, int n_rs, int n_perp, int n_iso, int ndirs, int nS, amx_lut **out)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!wmr || !wmh || !iso || !Rs || !htable || !out || n_rs <= 0 || n_perp <= 0 || n_iso <= 0 || ndirs <= 0 || nS <= 0)
+        return bad(ctx, "amx_lut_upload_czb: bad argument");
+    const int n_atoms = n_rs + n_perp + n_iso;
+    if (n_atoms > 64 || nS > 256) return bad(ctx, "amx_lut_upload_czb: unsupported size (n_atoms <= 64, nS <= 256)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    amx_lut *lut = new amx_lut();
+    lut->ctx = ctx; lut->model = 4; lut->nS = nS; lut->n_atoms = n_atoms; lut->ndirs = ndirs;
+    lut->n_rs = n_rs; lut->n_perp = n_perp; lut->n_iso = n_iso;
+    lut->ldA = (n_atoms & 1) ? n_atoms : n_atoms + 1;
+    lut->tile_stride = (nS * lut->ldA + 3) & ~3;
+    int rc;
+    // columns: cylinders, zeppelins (both per orientation), balls (models.pyx:608-610)
+    std::vector<float> rot((size_t)(n_rs + n_perp) * ndirs * nS);
+    memcpy(rot.data(), wmr, (size_t)n_rs * ndirs * nS * sizeof(float));
+    memcpy(rot.data() + (size_t)n_rs * ndirs * nS, wmh, (size_t)n_perp * ndirs * nS * sizeof(float));
+    std::vector<int> ones(n_iso, 0);
+    if ((rc = build_tiles(ctx, lut, rot.data(), rot.size(), iso, (size_t)n_iso * nS, ones, n_rs + n_perp))) { amx_lut_destroy(lut); return rc; }
+    std::vector<short> ht(htable, htable + 181 * 181);
+    if ((rc = upload(ctx, &lut->htable, ht.data(), ht.size())) || (rc = upload(ctx, &lut->Rs, Rs, (size_t)n_rs))) { amx_lut_destroy(lut); return rc; }
+    // Gram matrices of every orientation: the solver works on A'A + lambda2 I (amx_gram_solver.hpp)
+    lut->ldG = 64;
+    const size_t gbytes = (size_t)ndirs * n_atoms * lut->ldG * sizeof(double);
+    const size_t lds = (size_t)nS * lut->ldA * sizeof(float);
+    if (hipMalloc((void **)&lut->gram, gbytes) != hipSuccess) { amx_lut_destroy(lut); return bad(ctx, "amx_lut_upload_czb: out of device memory"); }
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_build_gram), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_build_gram, dim3(ndirs), dim3(512), lds, nullptr, (const float *)lut->tiles, lut->tile_stride, nS,
+                       lut->ldA, n_atoms, (const unsigned char *)nullptr, lut->ldG, lut->gram);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipDeviceSynchronize());
+    *out = lut;
+    return AMX_OK;
+}
+
 int amx_sync_status(amx_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return AMX_E_BADARG;
@@ -528,6 +565,44 @@ int amx_sandi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, in
     return rc;
 }
 
+// ------------------------------------------------------------------ CylinderZeppelinBall
+int amx_czb_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, const double *d_dirs, int64_t n_vox,
+                       double lambda1, double lambda2, unsigned flags, double *d_estimates, double *d_rmse,
+                       double *d_nrmse, void *hip_stream)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!lut || lut->model != 4 || lut->ctx != ctx) return bad(ctx, "amx_czb_fit: not a CylinderZeppelinBall dictionary of this ctx");
+    if (n_vox < 0 || n_vox > INT_MAX / 4) return bad(ctx, "amx_czb_fit: bad n_vox");
+    if (n_vox == 0) return AMX_OK;
+    if (!d_y || !d_dirs || !d_estimates) return bad(ctx, "amx_czb_fit: null buffer");
+    if (((flags & AMX_F_RMSE) && !d_rmse) || ((flags & AMX_F_NRMSE) && !d_nrmse))
+        return bad(ctx, "amx_czb_fit: flag set but output buffer is null");
+    // the Gram-space solver needs the ridge (models.pyx:439 default: 4.0)
+    if (!(lambda2 >= 1e-6) || !(lambda1 >= 0.0)) return bad(ctx, "amx_czb_fit: need lambda1 >= 0 and lambda2 >= 1e-6");
+    hipStream_t s = (hipStream_t)hip_stream;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Plan pl; int rc;
+    if ((rc = make_plan(ctx, n_vox, lut->ndirs, pl))) return rc;
+    rec(ctx, 0, s);
+    if ((rc = enqueue_bucketing(ctx, lut, d_dirs, n_vox, pl, s))) return rc;
+    CzbArgs a;
+    memset(&a, 0, sizeof a);
+    a.c.tiles = lut->tiles; a.c.y = d_y; a.c.perm = pl.perm; a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks;
+    a.c.lutidx = pl.lutidx; a.c.status = ctx->status_d; a.c.nS = lut->nS; a.c.ldA = lut->ldA;
+    a.c.n_atoms = lut->n_atoms; a.c.tile_stride = lut->tile_stride; a.c.lam1 = lambda1; a.c.lam2 = lambda2; a.c.flags = flags;
+    a.n_rs = lut->n_rs; a.n_perp = lut->n_perp; a.Rs = lut->Rs; a.gram = lut->gram; a.ldG = lut->ldG;
+    if (flags & AMX_F_DEBUG_X) {
+        if (!ctx->dbg_x) return bad(ctx, "amx_czb_fit: AMX_F_DEBUG_X without a buffer (amx_set_debug_x)");
+        a.c.xdbg = ctx->dbg_x + (size_t)ctx->vox_base * lut->n_atoms;
+    }
+    a.est = d_estimates; a.rmse = (flags & AMX_F_RMSE) ? d_rmse : nullptr; a.nrmse = (flags & AMX_F_NRMSE) ? d_nrmse : nullptr;
+    HIPCHK(ctx, hipMemsetAsync(d_estimates, 0, (size_t)n_vox * 3 * sizeof(double), s));
+    rc = amx_launch_czb(ctx, a, pl, s);
+    hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, s, (const int *)ctx->misc.p, ctx->status_d);
+    rec(ctx, 1, s);
+    return rc;
+}
+
 }  // extern "C"
 
 // ------------------------------------------------------------------ host-pointer entry points
@@ -672,6 +747,25 @@ static int sandi_fit_any(amx_ctx *ctx, const amx_lut *lut, const T *y, int64_t n
                        });
 }
 
+template <typename T>
+static int czb_fit_any(amx_ctx *ctx, const amx_lut *lut, const T *y, const double *dirs, int64_t n_vox, double lambda1,
+                       double lambda2, unsigned flags, double *out_estimates, double *out_rmse, double *out_nrmse)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!lut || lut->model != 4) return bad(ctx, "amx_czb_fit: not a CylinderZeppelinBall dictionary");
+    if (n_vox == 0) return AMX_OK;
+    if (n_vox < 0 || !y || !dirs || !out_estimates) return bad(ctx, "amx_czb_fit: bad argument");
+    if (((flags & AMX_F_RMSE) && !out_rmse) || ((flags & AMX_F_NRMSE) && !out_nrmse))
+        return bad(ctx, "amx_czb_fit: flag set but output buffer is null");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HostOut outs[4] = {{out_estimates, &ctx->hest, 3, true}, {out_rmse, &ctx->hrmse, 1, (flags & AMX_F_RMSE) != 0},
+                       {out_nrmse, &ctx->hnrmse, 1, (flags & AMX_F_NRMSE) != 0}, {nullptr, &ctx->hextra, 1, false}};
+    return fit_host<T>(ctx, y, dirs, n_vox, lut->nS, outs,
+                       [&](double *yb, double *db, int64_t cnt, double *e, double *r, double *nr, double *, hipStream_t s) {
+                           return amx_czb_fit_device(ctx, lut, yb, db, cnt, lambda1, lambda2, flags, e, r, nr, s);
+                       });
+}
+
 extern "C" {
 
 int amx_noddi_fit(amx_ctx *ctx, const amx_lut *lut, const double *y, const double *dirs, int64_t n_vox, double lambda1,
@@ -710,6 +804,18 @@ int amx_sandi_fit_f32(amx_ctx *ctx, const amx_lut *lut, const float *y, int64_t 
                       unsigned flags, double *out_estimates, double *out_rmse, double *out_nrmse)
 {
     return sandi_fit_any<float>(ctx, lut, y, n_vox, lambda1, lambda2, flags, out_estimates, out_rmse, out_nrmse);
+}
+
+int amx_czb_fit(amx_ctx *ctx, const amx_lut *lut, const double *y, const double *dirs, int64_t n_vox, double lambda1,
+                double lambda2, unsigned flags, double *out_estimates, double *out_rmse, double *out_nrmse)
+{
+    return czb_fit_any<double>(ctx, lut, y, dirs, n_vox, lambda1, lambda2, flags, out_estimates, out_rmse, out_nrmse);
+}
+
+int amx_czb_fit_f32(amx_ctx *ctx, const amx_lut *lut, const float *y, const double *dirs, int64_t n_vox, double lambda1,
+                    double lambda2, unsigned flags, double *out_estimates, double *out_rmse, double *out_nrmse)
+{
+    return czb_fit_any<float>(ctx, lut, y, dirs, n_vox, lambda1, lambda2, flags, out_estimates, out_rmse, out_nrmse);
 }
 
 int amx_dir_to_lut_idx(amx_ctx *ctx, const amx_lut *lut, const double *dirs, int64_t n, int32_t *out_idx)

@@ -1,0 +1,18 @@
+// amx_czb.hip -- CylinderZeppelinBall solver kernel (models.pyx:526-652)
+#include "amx_launch.hpp"
+using namespace amx;
+
+template <int NR>
+static int go(amx_ctx *ctx, CzbArgs &a, const Plan &pl, hipStream_t s)
+{
+    constexpr int NQ = 1, MP = 32, MB = 64;      // 26 atoms by default: the main kernel's passive set holds them all
+    constexpr int NW = 8;
+    return launch_pair<NW>(ctx, a, pl, s, k_czb<NR, NQ, MP, NW, false>, k_czb<NR, NQ, MB, 1, true>,
+                           [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MP, true); },
+                           fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, true), 0, 2);
+}
+
+int amx_launch_czb(amx_ctx *ctx, CzbArgs &a, const Plan &pl, hipStream_t s)
+{
+    return a.c.nS <= 128 ? go<2>(ctx, a, pl, s) : go<4>(ctx, a, pl, s);
+}

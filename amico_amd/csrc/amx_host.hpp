@@ -44,7 +44,7 @@ struct amx_ctx {
 
 struct amx_lut {
     amx_ctx *ctx = nullptr;
-    int model = 0;                 // 1 NODDI, 2 FreeWater, 3 SANDI
+    int model = 0;                 // 1 NODDI, 2 FreeWater, 3 SANDI, 4 CylinderZeppelinBall
     int nS = 0, ldA = 0, n_atoms = 0, ndirs = 0, tile_stride = 0;
     int n_wm = 0, is_exvivo = 0;   // NODDI
     int n_perp = 0, n_iso = 0;     // FreeWater
@@ -143,6 +143,7 @@ int amx_launch_noddi_s2(amx_ctx *ctx, amx::NoddiArgs &a, const Plan &pl, hipStre
 int amx_launch_noddi_s3(amx_ctx *ctx, amx::NoddiArgs &a, const Plan &pl, hipStream_t s);
 int amx_launch_fw(amx_ctx *ctx, amx::FwArgs &a, const Plan &pl, hipStream_t s);
 int amx_launch_sandi(amx_ctx *ctx, amx::SandiArgs &a, const Plan &pl, hipStream_t s);
+int amx_launch_czb(amx_ctx *ctx, amx::CzbArgs &a, const Plan &pl, hipStream_t s);
 // lane-per-voxel variants for dictionaries of <= 16 atoms (amx_small.hip)
 int amx_launch_fw_small(amx_ctx *ctx, amx::FwArgs &a, const Plan &pl, hipStream_t s);
 int amx_launch_sandi_small(amx_ctx *ctx, amx::SandiArgs &a, const Plan &pl, hipStream_t s);

@@ -421,6 +421,91 @@ __device__ __forceinline__ void sandi_voxel(const SandiArgs &a, const double *As
     }   // ok
 }
 
+// ------------------------------------------------------------------ CylinderZeppelinBall (models.pyx:526-652)
+// A = [cylinders | zeppelins | balls] of the voxel's orientation, lasso with lambda1 = 0, lambda2 = 4 by default
+// (models.pyx:439): a strong ridge, so the optimum is dense (22 of 26 atoms on the fixture) and cond(A'A + lambda2 I) is
+// tiny -- the Gram-space solver (Cholesky of the passive block in LDS, no register-resident Q) with a passive-set
+// capacity that holds every atom.
+struct CzbArgs {
+    FitCommon c;
+    int n_rs, n_perp;
+    const double *Rs;             // [n_rs] model.Rs (metres)
+    const double *gram;           // [ndirs][n_atoms][ldG] A'A of every orientation tile
+    int ldG;
+    double *est, *rmse, *nrmse;
+};
+
+template <int NR, int NQ, int MAXP>
+__device__ __forceinline__ void czb_voxel(const CzbArgs &a, const float *As, double *rs, double *rl, int vox, int dir, int lane)
+{
+    const int nS = a.c.nS, ldA = a.c.ldA, n_atoms = a.c.n_atoms, n_rs = a.n_rs, n_perp = a.n_perp;
+    double yr[NR];
+    const bool ok = load_rows<NR>(a.c.y + (size_t)vox * nS, nS, lane, yr);
+    bool rowok[NR];
+    double scl[NQ];
+    unsigned long long allowed[NQ];
+#pragma unroll
+    for (int rr = 0; rr < NR; rr++) rowok[rr] = (lane + kWave * rr) < nS;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const int cnt = n_atoms - kWave * q;
+        allowed[q] = cnt >= 64 ? ~0ull : (cnt > 0 ? ((1ull << cnt) - 1ull) : 0ull);
+        scl[q] = 1.0;
+    }
+    if (!ok) {
+        if (lane < 3) a.est[(size_t)vox * 3 + lane] = __builtin_nan("");
+        if (lane == 0 && a.rmse) a.rmse[vox] = __builtin_nan("");
+        if (lane == 0 && a.nrmse) a.nrmse[vox] = __builtin_nan("");
+    }
+    if (ok) {
+    GramSolver<NR, NQ, MAXP, float> S;
+    const double *gdir = a.gram + (size_t)dir * n_atoms * a.ldG;
+    const int st = __builtin_amdgcn_readfirstlane(S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed, a.c.lam1, a.c.lam2,
+                                                          rs, rl, lane, gdir, a.ldG));
+    if (st == kOverflow) {
+        if (lane == 0) { const int k = atomicAdd(a.c.ovf_count, 1); a.c.ovf_list[k] = vox; }
+    } else {
+    if (st == kIterCap && lane == 0) atomicAdd(&a.c.status[ST_ITCAP], 1);
+    if (st > kIterCap && lane == 0) { atomicAdd(&a.c.status[ST_GUARD], 1); a.c.status[ST_GUARDVOX] = vox * 8 + st; }
+    const bool act = lane < S.np;
+    const int at = act ? S.idx : 0;
+    const double xs = act ? S.x : 0.0;
+    if (a.c.xdbg) store_x_dense<NQ>(a.c.xdbg + (size_t)vox * n_atoms, n_atoms, lane, S.np, S.idx, xs);
+    // models.pyx:616-633
+    double f1 = wave_sum((act && at < n_rs) ? xs : 0.0);
+    const double f2 = wave_sum((act && at >= n_rs && at < n_rs + n_perp) ? xs : 0.0) + 1e-16;
+    const double v = f1 / (f1 + f2 + 1e-16);
+    f1 += 1e-16;
+    double am = wave_sum((act && at < n_rs) ? a.Rs[at] * xs : 0.0);
+    am = 1e6 * 2.0 * am / f1;
+    const double d = (4.0 * v) / (3.14159265358979323846 * (am * am) + 1e-16);
+    if (lane == 0) { double *e = a.est + (size_t)vox * 3; e[0] = v; e[1] = am; e[2] = d; }
+    if (a.c.flags & 3u) {
+        double est[NR];
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) est[rr] = 0.0;
+        for (int s = 0; s < S.np; s++) {
+            const int as = bcast_i(S.idx, s);
+            const double xv = bcast(xs, s);
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++) {
+                const int i = lane + kWave * rr;
+                if (i < nS) est[rr] += (double)As[i * ldA + as] * xv;
+            }
+        }
+        double rsq = 0.0, ysq = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) { const double t = yr[rr] - est[rr]; rsq += t * t; ysq += yr[rr] * yr[rr]; }
+        rsq = wave_sum(rsq); ysq = wave_sum(ysq);
+        if (lane == 0) {
+            if (a.rmse) a.rmse[vox] = sqrt(rsq / (double)nS);
+            if (a.nrmse) a.nrmse[vox] = (ysq > 1e-16) ? sqrt(rsq / ysq) : 0.0;
+        }
+    }
+    }   // st != kOverflow
+    }   // ok
+}
+
 // doubles of per-wavefront LDS the solver needs besides the residual scratch:
 // QR solver: R and the ridge rows, (MAXP+1)^2 each; Gram solver: two packed triangles
 __host__ __device__ constexpr int solver_lds_words(bool gram, int maxp)
@@ -558,6 +643,35 @@ __global__ void __launch_bounds__(NW * 64) k_sandi(const SandiArgs a)
         stage_tile<double>(As, tiles, words, words_pad - words);
         __syncthreads();
         for (int it = blockIdx.x; it < cnt; it += gridDim.x) sandi_voxel<NR, NQ, MAXP>(a, As, rs, rl, a.c.list[it], lane);
+    }
+}
+
+template <int NR, int NQ, int MAXP, int NW, bool LIST>
+__global__ void __launch_bounds__(NW * 64) k_czb(const CzbArgs a)
+{
+    AMX_KERNEL_PROLOGUE(float, NR, NQ, NW, solver_lds_words(true, MAXP))
+    (void)wmask;
+    const float *tiles = reinterpret_cast<const float *>(a.c.tiles);
+    if (!LIST) {
+        const int cid = xcd_chunk((int)blockIdx.x, *a.c.n_chunks);
+        if (cid < 0) return;
+        const Chunk ck = a.c.chunks[cid];
+        unsigned *ticket = reinterpret_cast<unsigned *>(wm_all + nw_ * 4);
+        if (threadIdx.x == 0) *ticket = (unsigned)nw_;
+        stage_tile<float>(As, tiles + (size_t)ck.dir * a.c.tile_stride, words, words_pad - words);
+        __syncthreads();
+        for (int k = wave; k < ck.count; k = next_ticket(ticket, lane)) {   // LDS voxel ticket, see k_noddi
+            czb_voxel<NR, NQ, MAXP>(a, As, rs, rl, a.c.perm[ck.start + k], ck.dir, lane);
+        }
+    } else {
+        const int cnt = *a.c.list_count;
+        for (int it = blockIdx.x; it < cnt; it += gridDim.x) {
+            const int vox = a.c.list[it];
+            __syncthreads();
+            stage_tile<float>(As, tiles + (size_t)a.c.lutidx[vox] * a.c.tile_stride, words, words_pad - words);
+            __syncthreads();
+            czb_voxel<NR, NQ, MAXP>(a, As, rs, rl, vox, a.c.lutidx[vox], lane);
+        }
     }
 }
 

@@ -136,6 +136,77 @@ class BaseModel(ABC):
         return self._lut_cache[1]
 
 
+class CylinderZeppelinBall(BaseModel):
+    """models.pyx:375-652.  A = [cylinders (Rs) | zeppelins (d_perps) | balls (d_isos)] of the voxel's orientation, one
+    lasso(lambda1=0, lambda2=4) per voxel, maps v (intra-cellular volume fraction), a (mean axonal diameter, um), d (axonal
+    density).  Reference quirk (models.pyx:435, 549): ``get_params`` and ``_fit`` read ``self.isExvivo``, which the class
+    never sets -- there the fit raises AttributeError until the user assigns it; here it is False (the "ex vivo" branch of
+    the reference only appends an all-zero atom, :552-554, so it changes nothing)."""
+
+    def __init__(self):
+        self.id = 'CylinderZeppelinBall'
+        self.name = 'Cylinder-Zeppelin-Ball'
+        self.maps_name = ['v', 'a', 'd']
+        self.maps_descr = ['Intra-cellular volume fraction', 'Mean axonal diameter', 'Axonal density']
+        self.scheme = None
+        self.isExvivo = False
+        self.set()
+        self.set_solver()
+
+    def set(self, d_par=0.6E-3, Rs=np.concatenate(([0.01], np.linspace(0.5, 8.0, 20))) * 1E-6,
+            d_perps=np.array([1.19E-3, 0.85E-3, 0.51E-3, 0.17E-3]), d_isos=np.array([2.0E-3])):
+        self.d_par = d_par
+        self.Rs = np.array(Rs)
+        self.d_perps = np.array(d_perps)
+        self.d_isos = np.array(d_isos)
+
+    def get_params(self):
+        return {'id': self.id, 'name': self.name, 'd_par': self.d_par, 'Rs': self.Rs, 'd_perps': self.d_perps,
+                'd_isos': self.d_isos, 'isExvivo': self.isExvivo}
+
+    def _lut_extra_key(self):
+        return (np.asarray(self.Rs, dtype=np.float64).tobytes(),)
+
+    def set_solver(self, lambda1=0.0, lambda2=4.0):
+        super().set_solver()
+        self.solver_params['lambda1'] = lambda1
+        self.solver_params['lambda2'] = lambda2
+
+    def resample(self, in_path, idx_out, Ylm_out, doMergeB0, ndirs):
+        """models.pyx:480-522"""
+        n_r, n_p, n_i = len(self.Rs), len(self.d_perps), len(self.d_isos)
+        lms = self._load_lm(in_path, n_r + n_p + n_i)
+        _, merge_idx = self._merge(doMergeB0)
+        K = {'model': self.id}
+        rot = self._resample_rotated(lms[:n_r + n_p], idx_out, Ylm_out, ndirs)[:, :, merge_idx]
+        K['wmr'] = np.ascontiguousarray(rot[:n_r])
+        K['wmh'] = np.ascontiguousarray(rot[n_r:])
+        K['iso'] = np.ascontiguousarray(self._resample_isotropic(lms[n_r + n_p:], idx_out, Ylm_out)[:, merge_idx])
+        return K
+
+    def fit(self, evaluation):
+        super().fit(evaluation)
+        ctx = get_context()
+        K = evaluation.KERNELS
+        if K['wmr'].shape[0] != len(self.Rs) or K['wmh'].shape[0] != len(self.d_perps) or K['iso'].shape[0] != len(self.d_isos):
+            raise ValueError('KERNELS do not match Rs / d_perps / d_isos of the model')
+        lut = self._lut(evaluation, lambda: _capi.upload_czb(ctx, K, self.Rs, evaluation.htable))
+        kw = dict(rmse=bool(self.configs['compute_rmse']), nrmse=bool(self.configs['compute_nrmse']))
+        dev = getattr(evaluation, '_dev', None)
+        if dev is not None:
+            est, rmse, nrmse = _capi.czb_fit_device(ctx, lut, dev['y'], self._dev_dirs(evaluation, dev),
+                                                    self.solver_params['lambda1'], self.solver_params['lambda2'], **kw)
+            return self._finish_device(ctx, dev, {'estimates': est, 'rmse': rmse, 'nrmse': nrmse})
+        est, rmse, nrmse = _capi.czb_fit(ctx, lut, evaluation.y, evaluation.DIRs, self.solver_params['lambda1'],
+                                         self.solver_params['lambda2'], **kw)
+        results = {'estimates': est}
+        if self.configs['compute_rmse']:
+            results['rmse'] = rmse
+        if self.configs['compute_nrmse']:
+            results['nrmse'] = nrmse
+        return results
+
+
 class NODDI(BaseModel):
     """models.pyx:655-991"""
 

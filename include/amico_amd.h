@@ -62,6 +62,10 @@ int amx_lut_upload_freewater(amx_ctx *ctx, const float *D, const float *CSF, con
 int amx_lut_upload_sandi(amx_ctx *ctx, const double *signal, const double *norms, const double *Rs,
                          const double *d_in, const double *d_isos, int nS, int n_rs, int n_in,
                          int n_iso, amx_lut **out);
+/* CylinderZeppelinBall.  KERNELS['wmr'] f32[n_rs][ndirs][nS] (cylinders), ['wmh'] f32[n_perp][ndirs][nS] (zeppelins),
+ * ['iso'] f32[n_iso][nS] (balls) (models.pyx:488-520); Rs = model.Rs f64[n_rs] in metres, used by the maps (:627) */
+int amx_lut_upload_czb(amx_ctx *ctx, const float *wmr, const float *wmh, const float *iso, const double *Rs,
+                       const int16_t *htable, int n_rs, int n_perp, int n_iso, int ndirs, int nS, amx_lut **out);
 void amx_lut_destroy(amx_lut *lut);
 
 /* ---- lut.pxd:4  cdef int dir_to_lut_idx(double[::1] direction, short[::1] hash_table)
@@ -87,6 +91,19 @@ int amx_freewater_fit(amx_ctx *ctx, const amx_lut *lut, const double *y, const d
 int amx_sandi_fit(amx_ctx *ctx, const amx_lut *lut, const double *y, int64_t n_vox,
                   double lambda1, double lambda2, unsigned flags,
                   double *out_estimates, double *out_rmse, double *out_nrmse);
+
+/* CylinderZeppelinBall._fit models.pyx:526-652: estimates f64[n_vox][3] = v, a, d (lambda2 >= 1e-6: the default 4.0
+ * makes the Gram-space solver the right tool; the model's `isExvivo`, which the reference never defines, is not a
+ * parameter here) */
+int amx_czb_fit(amx_ctx *ctx, const amx_lut *lut, const double *y, const double *dirs, int64_t n_vox,
+                double lambda1, double lambda2, unsigned flags,
+                double *out_estimates, double *out_rmse, double *out_nrmse);
+int amx_czb_fit_f32(amx_ctx *ctx, const amx_lut *lut, const float *y, const double *dirs, int64_t n_vox,
+                    double lambda1, double lambda2, unsigned flags,
+                    double *out_estimates, double *out_rmse, double *out_nrmse);
+int amx_czb_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, const double *d_dirs,
+                       int64_t n_vox, double lambda1, double lambda2, unsigned flags,
+                       double *d_estimates, double *d_rmse, double *d_nrmse, void *hip_stream);
 
 /* The same three calls with FLOAT32 signals: the image is float32 in the reference (core.py:136) and only cast to
  * float64 when the masked voxels are gathered (core.py:451), so a float32 `y` carries the same values in half the PCIe

@@ -706,3 +706,74 @@ int64_t amo_sandi_fit(const amo_sandi_args *a, const double *y,
     run_chunked(a->n_vox, a->nthreads, sandi_chunk, &cx);
     return 0;
 }
+
+/* ------------------------------------------------------------------ CylinderZeppelinBall models.pyx:526-652 */
+typedef struct {
+    const amo_czb_args *a; const double *y, *dirs;
+    double *est, *rmse, *nrmse, *x_dbg; int64_t err; pthread_mutex_t mu;
+} czb_ctx;
+
+static void czb_chunk(void *vctx, int tid, int i0, int i1)
+{
+    czb_ctx *cx = (czb_ctx *)vctx;
+    const amo_czb_args *a = cx->a;
+    const int nS = a->nS, n_rs = a->n_rs, n_perp = a->n_perp, n_iso = a->n_iso;
+    const int n_atoms = n_rs + n_perp + n_iso;
+    double *A = (double *)calloc((size_t)nS * n_atoms, sizeof(double));
+    double *x = (double *)calloc((size_t)n_atoms + nS, sizeof(double));
+    double *yest = x + n_atoms;
+    int i, j, k;
+    (void)tid;
+    for (k = 0; k < n_iso; k++)                                   /* models.pyx:610 (the same for every voxel) */
+        for (j = 0; j < nS; j++) A[(size_t)(n_rs + n_perp + k) * nS + j] = (double)a->iso[(size_t)k * nS + j];
+    for (i = i0; i < i1; i++) {
+        const double *yi = cx->y + (size_t)i * nS;
+        double f1 = 0.0, f2 = 0.0, v, am = 0.0, d;
+        int lut = amo_dir_to_lut_idx(cx->dirs + (size_t)i * 3, a->htable, NULL, NULL);
+        if (lut < 0 || lut >= a->ndirs) {
+            pthread_mutex_lock(&cx->mu);
+            if (cx->err == 0 || -(int64_t)(i + 1) > cx->err) cx->err = -(int64_t)(i + 1);
+            pthread_mutex_unlock(&cx->mu);
+            continue;
+        }
+        for (k = 0; k < n_rs; k++) {                               /* models.pyx:608 */
+            const float *src = a->wmr + ((size_t)k * a->ndirs + lut) * nS;
+            for (j = 0; j < nS; j++) A[(size_t)k * nS + j] = (double)src[j];
+        }
+        for (k = 0; k < n_perp; k++) {                             /* models.pyx:609 */
+            const float *src = a->wmh + ((size_t)k * a->ndirs + lut) * nS;
+            for (j = 0; j < nS; j++) A[(size_t)(n_rs + k) * nS + j] = (double)src[j];
+        }
+        amo_lasso(A, yi, nS, n_atoms, x, a->lambda1, a->lambda2);  /* models.pyx:613 */
+        if (cx->x_dbg) memcpy(cx->x_dbg + (size_t)i * n_atoms, x, sizeof(double) * n_atoms);
+        /* estimates, models.pyx:616-633 */
+        for (j = 0; j < n_rs + n_perp; j++) {
+            if (j < n_rs) f1 += x[j];
+            if (j >= n_rs && j < n_rs + n_perp) f2 += x[j];
+        }
+        f2 += 1e-16;
+        v = f1 / (f1 + f2 + 1e-16);
+        f1 += 1e-16;
+        for (j = 0; j < n_rs; j++) am += a->Rs[j] * x[j];
+        am = 1e6 * 2.0 * am / f1;
+        d = (4.0 * v) / (M_PI * pow(am, 2.0) + 1e-16);
+        cx->est[(size_t)i * 3 + 0] = v;
+        cx->est[(size_t)i * 3 + 1] = am;
+        cx->est[(size_t)i * 3 + 2] = d;
+        if (a->compute_rmse && cx->rmse) cx->rmse[i] = rmse_of(A, nS, n_atoms, yi, x, yest);
+        if (a->compute_nrmse && cx->nrmse) cx->nrmse[i] = nrmse_of(A, nS, n_atoms, yi, x, yest);
+    }
+    free(x); free(A);
+}
+
+int64_t amo_czb_fit(const amo_czb_args *a, const double *y, const double *dirs,
+                    double *estimates, double *rmse, double *nrmse, double *x_dbg)
+{
+    czb_ctx cx;
+    cx.a = a; cx.y = y; cx.dirs = dirs; cx.est = estimates; cx.rmse = rmse; cx.nrmse = nrmse;
+    cx.x_dbg = x_dbg; cx.err = 0;
+    pthread_mutex_init(&cx.mu, NULL);
+    run_chunked(a->n_vox, a->nthreads, czb_chunk, &cx);
+    pthread_mutex_destroy(&cx.mu);
+    return cx.err;
+}

@@ -86,6 +86,24 @@ typedef struct {
 int64_t amo_sandi_fit(const amo_sandi_args *a, const double *y,
                       double *estimates, double *rmse, double *nrmse, double *x_dbg);
 
+typedef struct {
+    int n_vox, nS, ndirs, n_rs, n_perp, n_iso;
+    const float *wmr;                /* KERNELS['wmr'] f32 [n_rs][ndirs][nS]   (cylinders)  */
+    const float *wmh;                /* KERNELS['wmh'] f32 [n_perp][ndirs][nS] (zeppelins)  */
+    const float *iso;                /* KERNELS['iso'] f32 [n_iso][nS]         (balls)      */
+    const double *Rs;                /* model.Rs f64 [n_rs] (metres) */
+    const int16_t *htable;
+    double lambda1, lambda2;
+    int compute_rmse, compute_nrmse;
+    int nthreads;
+} amo_czb_args;
+
+/* CylinderZeppelinBall._fit models.pyx:526-652. estimates f64[n_vox][3] = v, a, d.
+ * (The reference reads self.isExvivo, which CylinderZeppelinBall never defines, models.pyx:435/549 -- with it set to
+ * False by hand the loop below is what runs; the "ex vivo" branch only adds an all-zero atom, :552-554.) */
+int64_t amo_czb_fit(const amo_czb_args *a, const double *y, const double *dirs,
+                    double *estimates, double *rmse, double *nrmse, double *x_dbg);
+
 #ifdef __cplusplus
 }
 #endif

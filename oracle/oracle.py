@@ -40,6 +40,13 @@ class SandiArgs(C.Structure):
                 ("compute_rmse", C.c_int), ("compute_nrmse", C.c_int), ("nthreads", C.c_int)]
 
 
+class CzbArgs(C.Structure):
+    _fields_ = [("n_vox", C.c_int), ("nS", C.c_int), ("ndirs", C.c_int), ("n_rs", C.c_int), ("n_perp", C.c_int),
+                ("n_iso", C.c_int), ("wmr", c_fp), ("wmh", c_fp), ("iso", c_fp), ("Rs", c_dp),
+                ("htable", C.POINTER(C.c_int16)), ("lambda1", C.c_double), ("lambda2", C.c_double),
+                ("compute_rmse", C.c_int), ("compute_nrmse", C.c_int), ("nthreads", C.c_int)]
+
+
 def build(force=False, fast=False):
     so = os.path.join(_HERE, "libamico_oracle_fast.so" if fast else "libamico_oracle.so")
     src = os.path.join(_HERE, "amico_oracle.c")
@@ -76,6 +83,8 @@ def lib():
         L.amo_freewater_fit.argtypes = [C.POINTER(FwArgs), c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]
         L.amo_sandi_fit.restype = C.c_int64
         L.amo_sandi_fit.argtypes = [C.POINTER(SandiArgs), c_dp, c_dp, c_dp, c_dp, c_dp]
+        L.amo_czb_fit.restype = C.c_int64
+        L.amo_czb_fit.argtypes = [C.POINTER(CzbArgs), c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]
         _LIB = L
     return _LIB
 
@@ -194,6 +203,30 @@ def sandi_fit(y, kernels, Rs, d_in, d_isos, lambda1=0.0, lambda2=5e-3, rmse=Fals
     xd = np.zeros((n_vox, sig.shape[1])) if return_x else None
     lib().amo_sandi_fit(C.byref(a), _dp(y), _dp(est), _dp(r), _dp(nr), _dp(xd))
     out = {'estimates': est, 'err': 0}
+    if rmse: out['rmse'] = r
+    if nrmse: out['nrmse'] = nr
+    if return_x: out['x'] = xd
+    return out
+
+
+def czb_fit(y, dirs, kernels, Rs, htable, lambda1=0.0, lambda2=4.0, rmse=False, nrmse=False, nthreads=1, return_x=False):
+    """CylinderZeppelinBall._fit (models.pyx:526-652): KERNELS['wmr'] / ['wmh'] / ['iso'], model.Rs -> v, a, d"""
+    y = np.ascontiguousarray(y, dtype=np.float64); dirs = np.ascontiguousarray(dirs, dtype=np.float64)
+    wmr = np.ascontiguousarray(kernels['wmr'], dtype=np.float32)
+    wmh = np.ascontiguousarray(kernels['wmh'], dtype=np.float32)
+    iso = np.ascontiguousarray(kernels['iso'], dtype=np.float32)
+    Rs = np.ascontiguousarray(Rs, dtype=np.float64)
+    ht = np.ascontiguousarray(htable, dtype=np.int16)
+    n_vox, nS = y.shape
+    n_rs, ndirs, _ = wmr.shape
+    a = CzbArgs(n_vox, nS, ndirs, n_rs, wmh.shape[0], iso.shape[0], _fp(wmr), _fp(wmh), _fp(iso), _dp(Rs),
+                ht.ctypes.data_as(C.POINTER(C.c_int16)), float(lambda1), float(lambda2), int(rmse), int(nrmse), int(nthreads))
+    est = np.zeros((n_vox, 3))
+    r = np.zeros(n_vox) if rmse else None
+    nr = np.zeros(n_vox) if nrmse else None
+    xd = np.zeros((n_vox, n_rs + wmh.shape[0] + iso.shape[0])) if return_x else None
+    err = lib().amo_czb_fit(C.byref(a), _dp(y), _dp(dirs), _dp(est), _dp(r), _dp(nr), _dp(xd))
+    out = {'estimates': est, 'err': err}
     if rmse: out['rmse'] = r
     if nrmse: out['nrmse'] = nr
     if return_x: out['x'] = xd

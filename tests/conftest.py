@@ -49,3 +49,11 @@ def sandi_fix():
     f = load_npz('sandi_fixture.npz')
     f['kernels'] = {'model': 'SANDI', 'signal': np.asfortranarray(f['signal']), 'norms': f['norms']}
     return f
+
+
+@pytest.fixture(scope='session')
+def czb_fix():
+    f = load_npz('czb_fixture.npz')
+    f['kernels'] = {'model': 'CylinderZeppelinBall', 'wmr': expand_lut(f['wmr_slices'], f['lut_ids']),
+                    'wmh': expand_lut(f['wmh_slices'], f['lut_ids']), 'iso': f['iso']}
+    return f

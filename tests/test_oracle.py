@@ -191,3 +191,23 @@ def test_sandi_fit_vs_golden(sandi_fix):
     assert np.allclose(out['x'], f['x'], atol=1e-8)
     assert np.allclose(out['estimates'], f['estimates'], rtol=1e-7, atol=1e-7)
     assert np.allclose(out['estimates'][0], 0.0)
+
+
+def test_czb_oracle_matches_fixture(czb_fix, htable500):
+    """CylinderZeppelinBall._fit restated (models.pyx:526-652) vs the fixture (scipy NNLS on the augmented system)"""
+    from oracle import oracle
+    f = czb_fix
+    o = oracle.czb_fit(f['y'], f['dirs'], f['kernels'], f['Rs'], htable500['htable'], float(f['lambda1']), float(f['lambda2']),
+                       rmse=True, nthreads=3, return_x=True)
+    assert o['err'] == 0
+    assert np.abs(o['x'] - f['x']).max() < 1e-10
+    assert np.abs(o['estimates'] - f['estimates']).max() < 1e-9
+    assert np.abs(o['rmse'] - f['rmse']).max() < 1e-12
+    assert np.allclose(o['estimates'][0], 0.0)                      # all-zero voxel
+    # KKT certificate of the non-negative ridge (lambda1 = 0): g = A'(y - A x) - lambda2 x
+    K, lut = f['kernels'], f['lut']
+    for v in range(0, len(lut), 9):
+        A = np.concatenate([K['wmr'][:, lut[v]], K['wmh'][:, lut[v]], K['iso']], axis=0).astype(np.float64).T
+        x = o['x'][v]
+        g = A.T @ (f['y'][v] - A @ x) - float(f['lambda2']) * x
+        assert np.abs(g[x > 0]).max(initial=0.0) < 1e-10 and g[x == 0].max(initial=0.0) < 1e-10
