@@ -440,7 +440,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--voxels', type=int, default=1_000_000, help='voxels per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-other-configs', action='store_true', help='skip configs 3 / 4 (FreeWater 2 M, SANDI 1 M) of the default run')
+    ap.add_argument('--no-other-configs', action='store_true', help='headline only: skip configs 3 / 4 (FreeWater 2 M, SANDI 1 M) and the host-buffer legs of the default run')
     ap.add_argument('--model', default='noddi', choices=['noddi', 'freewater', 'sandi', 'dti', 'prep', 'lut', 'pipeline'],
                     help='noddi = the BASELINE.json headline; the others are extra measurements (configs 3, 4)')
     args = ap.parse_args()
@@ -542,34 +542,36 @@ def main():
                              'median_abs_dmap': float(np.median(diff)),
                              'frac_within_1e-6': float((diff < 1e-6).mean()),
                              'frac_within_1e-4': float((diff < 1e-4).mean())}
-            # host numpy in -> host numpy out through amx_noddi_fit (H2D + kernels + D2H): the PCIe-inclusive rate,
-            # reported beside the headline, never as `value`
-            _capi.noddi_fit(ctx, lut, y_h, d_h, 0.5, 1e-3, 3)
-            hb = []
-            for _ in range(3):
-                t1 = time.perf_counter()
+            other = {}
+            if not args.no_other_configs:
+                # host numpy in -> host numpy out through amx_noddi_fit (H2D + kernels + D2H): the PCIe-inclusive rate,
+                # reported beside the headline, never as `value`
                 _capi.noddi_fit(ctx, lut, y_h, d_h, 0.5, 1e-3, 3)
-                hb.append(time.perf_counter() - t1)
-            other = {'noddi_host_buffers': {'metric': 'voxels/sec, NODDI fit, host buffers in/out (PCIe inclusive)',
-                                            'value': n / float(np.median(hb)), 'unit': 'voxels/s', 'voxels': n,
-                                            'ms_per_call': 1e3 * float(np.median(hb)),
-                                            'note': 'float64 signals from pageable host memory, batches pipelined behind the solver'}}
-            try:
-                y32 = y_h.astype(np.float32)
-                _capi.noddi_fit(ctx, lut, y32, d_h, 0.5, 1e-3, 3)
                 hb = []
                 for _ in range(3):
                     t1 = time.perf_counter()
-                    e32 = _capi.noddi_fit(ctx, lut, y32, d_h, 0.5, 1e-3, 3)[0]
+                    _capi.noddi_fit(ctx, lut, y_h, d_h, 0.5, 1e-3, 3)
                     hb.append(time.perf_counter() - t1)
-                other['noddi_host_buffers_f32'] = {'metric': 'voxels/sec, NODDI fit, float32 signals from host buffers (PCIe inclusive)',
-                                                   'value': n / float(np.median(hb)), 'unit': 'voxels/s', 'voxels': n,
-                                                   'ms_per_call': 1e3 * float(np.median(hb)),
-                                                   'max_abs_dmap_vs_f64_upload': float(np.abs(e32[:ns] - est[:ns].cpu().numpy()).max()),
-                                                   'note': 'lossless for AMICO (the image is float32, core.py:136): half the PCIe bytes'}
-                del y32
-            except (TypeError, AttributeError, ValueError):
-                pass
+                other = {'noddi_host_buffers': {'metric': 'voxels/sec, NODDI fit, host buffers in/out (PCIe inclusive)',
+                                                'value': n / float(np.median(hb)), 'unit': 'voxels/s', 'voxels': n,
+                                                'ms_per_call': 1e3 * float(np.median(hb)),
+                                                'note': 'float64 signals from pageable host memory, batches pipelined behind the solver'}}
+                try:
+                    y32 = y_h.astype(np.float32)
+                    _capi.noddi_fit(ctx, lut, y32, d_h, 0.5, 1e-3, 3)
+                    hb = []
+                    for _ in range(3):
+                        t1 = time.perf_counter()
+                        e32 = _capi.noddi_fit(ctx, lut, y32, d_h, 0.5, 1e-3, 3)[0]
+                        hb.append(time.perf_counter() - t1)
+                    other['noddi_host_buffers_f32'] = {'metric': 'voxels/sec, NODDI fit, float32 signals from host buffers (PCIe inclusive)',
+                                                       'value': n / float(np.median(hb)), 'unit': 'voxels/s', 'voxels': n,
+                                                       'ms_per_call': 1e3 * float(np.median(hb)),
+                                                       'max_abs_dmap_vs_f64_upload': float(np.abs(e32[:ns] - est[:ns].cpu().numpy()).max()),
+                                                       'note': 'lossless for AMICO (the image is float32, core.py:136): half the PCIe bytes'}
+                    del y32
+                except (TypeError, AttributeError, ValueError):
+                    pass
             if not args.no_cpu_baseline:
                 # bounded CPU legs on the host cores of this box: the oracle -- a port, the reference's
                 # cyspams path cannot be built -- at -O3 -march=native, the reference's chunk-per-thread structure
@@ -597,7 +599,8 @@ def main():
                 torch.cuda.empty_cache()
                 other['freewater_2M'] = small_model('freewater', 2_000_000, 5, 2, cpu=not args.no_cpu_baseline)
                 other['sandi_1M'] = small_model('sandi', 1_000_000, 5, 2, cpu=not args.no_cpu_baseline)
-            out['other_configs'] = other
+            if other:
+                out['other_configs'] = other
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

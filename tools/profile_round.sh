@@ -6,7 +6,7 @@ cd $GRAFT_REPO_ROOT
 TAG=${1:-rXX}
 O=gpurun_out/prof_$TAG
 mkdir -p $O
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/noddi -o noddi -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/noddi_bench.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/noddi -o noddi -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs > $O/noddi_bench.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/dti -o dti -- python bench.py --model dti --steps 5 --warmup 1 > $O/dti_bench.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prep -o prep -- python bench.py --model prep --steps 5 --warmup 1 > $O/prep_bench.log 2>&1
 i=0
@@ -14,7 +14,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
            "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_INSTS_SMEM" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc$i -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc$i.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc$i -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs > $O/pmc$i.log 2>&1
 done
 for m in dti prep; do
   for set in "FETCH_SIZE" "WRITE_SIZE"; do

@@ -37,7 +37,7 @@ def summarize(files, pats):
     return acc
 
 
-files = sum([glob.glob('%s/pmc%d/*/*_counter_collection.csv' % (O, i)) for i in (1, 2, 3, 4)], [])
+files = sum([glob.glob('%s/pmc%d/*/*_counter_collection.csv' % (O, i)) for i in (1, 2, 3, 4, 11, 12)], [])
 if len(sys.argv) > 2:
     files += glob.glob(sys.argv[2] + '/*/*_counter_collection.csv')
 a = summarize(files, ['k_noddi<1, 2, 3, 8, 16, false', 'k_noddi<4, 2, 3, 20, 16, false', 'k_noddi<3, 2, 3, 8, 16, false'])

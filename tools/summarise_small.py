@@ -43,4 +43,25 @@ for m, pats in (('freewater', ['k_freewater']), ('sandi', ['k_sandi']), ('lut', 
         for c, v in sorted(acc[k].items()):
             out.append('    %-30s n=%d mean=%.6g' % (c, len(v), sum(v) / len(v)))
 open('profiles/%s_pmc_small.txt' % tag, 'w').write('\n'.join(out) + '\n')
+# per-voxel HBM traffic of the lane kernels -> profiles/pmc_traffic.json (read by bench.py for roofline.traffic)
+import json
+small = {}
+for m, pat, n in (('freewater', 'k_freewater', 2000000), ('sandi', 'k_sandi', 1000000)):
+    acc = collections.defaultdict(list)
+    for fn in glob.glob('%s/pmc_%s_*/*/*_counter_collection.csv' % (O, m)):
+        for r in csv.DictReader(open(fn)):
+            if pat in r['Kernel_Name']:
+                acc[r['Counter_Name']].append(float(r['Counter_Value']))
+    if 'FETCH_SIZE' in acc and 'WRITE_SIZE' in acc:
+        mean = lambda v: sum(v) / len(v)
+        small[m] = {'voxels_per_launch': n, 'bytes_per_voxel_measured': (2 * mean(acc['FETCH_SIZE']) + mean(acc['WRITE_SIZE'])) * 1024 / n,
+                    'valu_insts_per_voxel': mean(acc['SQ_INSTS_VALU']) / n,
+                    '_source': 'profiles/%s_pmc_small.txt; bytes = 2 * FETCH_SIZE + WRITE_SIZE (KiB), see _correction' % tag}
+try:
+    t = json.load(open('profiles/pmc_traffic.json'))
+except (OSError, ValueError):
+    t = {}
+t['small_models'] = small
+json.dump(t, open('profiles/pmc_traffic.json', 'w'), indent=2)
+print(json.dumps(small, indent=1))
 print('\n'.join(out))
