@@ -51,6 +51,26 @@ __device__ __forceinline__ void stage_tile(AT *As, const AT *__restrict__ g, int
     for (int k = threadIdx.x; k < pad; k += blockDim.x) As[words + k] = (AT)0;
 }
 
+// the same for a tile kept as fp64 in LDS (the fp32 -> fp64 conversions of the tile reads are paid once per chunk instead
+// of once per read: 5 % / 9 % of the VALU instructions of the NODDI stage-1 / stage-3 kernels)
+__device__ __forceinline__ void stage_tile_widen(double *As, const float *__restrict__ g, int words, int pad)
+{
+    const int nvec = words / 4;
+    const float4 *gv = reinterpret_cast<const float4 *>(g);
+    for (int k = threadIdx.x; k < nvec; k += blockDim.x) {
+        const float4 t = gv[k];
+        As[4 * k] = (double)t.x; As[4 * k + 1] = (double)t.y; As[4 * k + 2] = (double)t.z; As[4 * k + 3] = (double)t.w;
+    }
+    for (int k = nvec * 4 + threadIdx.x; k < words; k += blockDim.x) As[k] = (double)g[k];
+    for (int k = threadIdx.x; k < pad; k += blockDim.x) As[words + k] = 0.0;
+}
+template <typename AT>
+__device__ __forceinline__ void stage_noddi_tile(AT *As, const float *__restrict__ g, int words, int pad)
+{
+    if constexpr (std::is_same<AT, double>::value) stage_tile_widen(As, g, words, pad);
+    else stage_tile<float>(As, g, words, pad);
+}
+
 template <int NR>
 __device__ __forceinline__ bool load_rows(const double *__restrict__ yv, int nS, int lane, double (&yr)[NR])
 {
@@ -103,8 +123,8 @@ struct NoddiArgs {
 
 // STAGE 1 = NNLS (models.pyx:911), 2 = LASSO by the QR solver, 4 = LASSO by the Gram solver
 // (models.pyx:914-926), 3 = debias NNLS + maps (models.pyx:929-967)
-template <int STAGE, int NR, int NQ, int MAXP>
-__device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const float *As, double *rs, double *rl,
+template <int STAGE, int NR, int NQ, int MAXP, typename AT = float>
+__device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const AT *As, double *rs, double *rl,
                                             unsigned long long *wmask, int vox, int dir, int lane)
 {
     constexpr bool kLasso = (STAGE == 2 || STAGE == 4);
@@ -170,7 +190,7 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const float *As,
 
     const double *gm = kLasso ? a.gram_dwi : a.gram;
     const double *gdir = gm ? gm + (size_t)dir * n_atoms * a.ldG : nullptr;
-    typename std::conditional<STAGE == 4, GramSolver<NR, NQ, MAXP, float>, NNSolver<NR, NQ, MAXP, STAGE == 2, float>>::type S;
+    typename std::conditional<STAGE == 4, GramSolver<NR, NQ, MAXP, AT>, NNSolver<NR, NQ, MAXP, STAGE == 2, AT>>::type S;
     const int st = __builtin_amdgcn_readfirstlane(S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed,
                            kLasso ? a.c.lam1 : 0.0, kLasso ? a.c.lam2 : 0.0, rs, rl, lane, gdir, a.ldG));
     if (st == kOverflow) {
@@ -555,11 +575,11 @@ __device__ __forceinline__ int next_ticket(unsigned *ticket, int lane)
     unsigned long long *wmask = wm_all + wave * 4;                                                    \
 
 
-template <int STAGE, int NR, int NQ, int MAXP, int NW, bool LIST>
+template <int STAGE, int NR, int NQ, int MAXP, int NW, bool LIST, typename AT = float>
 __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
 {
     constexpr int RLW = solver_lds_words(STAGE == 4, MAXP);
-    AMX_KERNEL_PROLOGUE(float, NR, NQ, NW, RLW)
+    AMX_KERNEL_PROLOGUE(AT, NR, NQ, NW, RLW)
     const float *tiles = reinterpret_cast<const float *>(a.c.tiles);
     if (!LIST) {
         const int cid = xcd_chunk((int)blockIdx.x, *a.c.n_chunks);
@@ -567,17 +587,17 @@ __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
         const Chunk ck = a.c.chunks[cid];
         unsigned *ticket = reinterpret_cast<unsigned *>(wm_all + nw_ * 4);     // the 16 spare bytes of fit_lds_bytes
         if (threadIdx.x == 0) *ticket = (unsigned)nw_;
-        stage_tile<float>(As, tiles + (size_t)ck.dir * a.c.tile_stride, words, words_pad - words);
+        stage_noddi_tile<AT>(As, tiles + (size_t)ck.dir * a.c.tile_stride, words, words_pad - words);
         __syncthreads();
 #ifdef AMX_STATIC_VOXELS
         for (int k = wave; k < ck.count; k += nw_) {
-            noddi_voxel<STAGE, NR, NQ, MAXP>(a, As, rs, rl, wmask, a.c.perm[ck.start + k], ck.dir, lane);
+            noddi_voxel<STAGE, NR, NQ, MAXP, AT>(a, As, rs, rl, wmask, a.c.perm[ck.start + k], ck.dir, lane);
         }
 #else
         // voxels differ 2-3x in solver iterations: the wavefronts draw the next voxel of the chunk from an LDS ticket
         // (next_ticket keeps the control flow wave-uniform: every lane takes part in the atomic)
         for (int k = wave; k < ck.count; k = next_ticket(ticket, lane)) {
-            noddi_voxel<STAGE, NR, NQ, MAXP>(a, As, rs, rl, wmask, a.c.perm[ck.start + k], ck.dir, lane);
+            noddi_voxel<STAGE, NR, NQ, MAXP, AT>(a, As, rs, rl, wmask, a.c.perm[ck.start + k], ck.dir, lane);
         }
 #endif
     } else {
@@ -585,9 +605,9 @@ __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
         for (int it = blockIdx.x; it < cnt; it += gridDim.x) {
             const int vox = a.c.list[it];
             __syncthreads();
-            stage_tile<float>(As, tiles + (size_t)a.c.lutidx[vox] * a.c.tile_stride, words, words_pad - words);
+            stage_noddi_tile<AT>(As, tiles + (size_t)a.c.lutidx[vox] * a.c.tile_stride, words, words_pad - words);
             __syncthreads();
-            noddi_voxel<STAGE, NR, NQ, MAXP>(a, As, rs, rl, wmask, vox, a.c.lutidx[vox], lane);
+            noddi_voxel<STAGE, NR, NQ, MAXP, AT>(a, As, rs, rl, wmask, vox, a.c.lutidx[vox], lane);
         }
     }
 }

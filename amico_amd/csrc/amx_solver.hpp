@@ -461,7 +461,7 @@ struct NNSolver {
                 }
                 double va = (RIDGE && lane == np) ? sqlam2 : 0.0;
                 const int ls = (lane < MAXP ? lane : MAXP - 1) * LDR;   // this lane's ridge row in Ql
-                const double n0 = wave_sum(vsq) + lam2;
+                const double vsq0 = vsq;          // |a_t|^2 of this lane's rows (reduced with the final batch below)
                 double rho = 0.0;                 // lane k: R[k][new]
                 // two Gram-Schmidt passes, 4 projections in flight at a time
 #pragma unroll
@@ -498,20 +498,23 @@ struct NNSolver {
                         }
                     }
                 }
-                vsq = va * va;
+                // one batched reduction for everything the tests and the commit need: |a_t|^2, |v|^2, v'y, rho'e
+                double fin[4];
+                fin[0] = vsq0;
+                fin[1] = va * va;
+                fin[2] = 0.0;
+                fin[3] = (lam1 != 0.0 && lane < np) ? rho * e : 0.0;        // only the l1 term needs e
 #pragma unroll
-                for (int rr = 0; rr < NR; rr++) vsq += v[rr] * v[rr];
-                const double b2 = wave_sum(vsq);
+                for (int rr = 0; rr < NR; rr++) { fin[1] += v[rr] * v[rr]; fin[2] += v[rr] * yr[rr]; }
+                wave_sum4(fin, lane);
+                const double n0 = fin[0] + lam2, b2 = fin[1];
                 bool reject = !uni(b2 > dep2 * (n0 - b2));
                 double beta = 0.0, binv = 0.0, dnew = 0.0, enew = 0.0;
                 if (!reject) {
                     binv = inv_sqrt(b2);
                     beta = b2 * binv;
-                    double vy = 0.0;
-#pragma unroll
-                    for (int rr = 0; rr < NR; rr++) vy += v[rr] * yr[rr];
-                    dnew = wave_sum(vy) * binv;
-                    enew = (lam1 != 0.0) ? (1.0 - wave_sum((lane < np) ? rho * e : 0.0)) * binv : 0.0;   // only the l1 term needs e
+                    dnew = fin[2] * binv;
+                    enew = (lam1 != 0.0) ? (1.0 - fin[3]) * binv : 0.0;
                     const double znew = (dnew - lam1 * enew) * binv;   // Lawson-Hanson "ztest"
                     reject = !uni(znew > 0.0);
                 }
