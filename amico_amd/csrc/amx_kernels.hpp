@@ -528,9 +528,10 @@ __device__ __forceinline__ void czb_voxel(const CzbArgs &a, const float *As, dou
 
 // doubles of per-wavefront LDS the solver needs besides the residual scratch:
 // QR solver: R and the ridge rows, (MAXP+1)^2 each; Gram solver: two packed triangles
-__host__ __device__ constexpr int solver_lds_words(bool gram, int maxp)
+// (without the ridge the QR solver has no augmented rows: R only)
+__host__ __device__ constexpr int solver_lds_words(bool gram, int maxp, bool ridge = true)
 {
-    return gram ? (maxp + 1) * (maxp + 2) : 2 * (maxp + 1) * (maxp + 1);
+    return gram ? (maxp + 1) * (maxp + 2) : (ridge ? 2 : 1) * (maxp + 1) * (maxp + 1);
 }
 
 // XCD-aware block -> chunk map.  Workgroup b runs on XCD b % 8 (observed dispatch order; only a
@@ -578,7 +579,7 @@ __device__ __forceinline__ int next_ticket(unsigned *ticket, int lane)
 template <int STAGE, int NR, int NQ, int MAXP, int NW, bool LIST, typename AT = float>
 __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
 {
-    constexpr int RLW = solver_lds_words(STAGE == 4, MAXP);
+    constexpr int RLW = solver_lds_words(STAGE == 4, MAXP, STAGE == 2);
     AMX_KERNEL_PROLOGUE(AT, NR, NQ, NW, RLW)
     const float *tiles = reinterpret_cast<const float *>(a.c.tiles);
     if (!LIST) {
@@ -696,12 +697,12 @@ __global__ void __launch_bounds__(NW * 64) k_czb(const CzbArgs a)
 }
 
 template <typename AT>
-static inline size_t fit_lds_bytes(int nS, int ldA, int NR, int NQ, int NW, int MAXP, bool gram = false)
+static inline size_t fit_lds_bytes(int nS, int ldA, int NR, int NQ, int NW, int MAXP, bool gram = false, bool ridge = true)
 {
     const size_t words_pad = ((size_t)nS * ldA + kWave * NQ + 3) & ~(size_t)3;
     size_t b = (words_pad * sizeof(AT) + 15) & ~(size_t)15;
     b += (size_t)NW * NR * kWave * sizeof(double);
-    b += (size_t)NW * solver_lds_words(gram, MAXP) * sizeof(double);
+    b += (size_t)NW * solver_lds_words(gram, MAXP, ridge) * sizeof(double);
     b += (size_t)NW * 4 * sizeof(unsigned long long);
     b += 16;
     return b;

@@ -18,13 +18,13 @@ static int go(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
     // fp32 -> fp64 conversions of the tile reads are then paid once per chunk.  AMX_TILE_F32=1: the fp32 tile.
     {
         const char *e = getenv("AMX_TILE_F32");
-        if (fit_lds_bytes<double>(a.c.nS, a.c.ldA, NR, NQ, NW, MP) <= kLdsPerCU && !(e && *e && *e != '0'))
+        if (fit_lds_bytes<double>(a.c.nS, a.c.ldA, NR, NQ, NW, MP, false, false) <= kLdsPerCU && !(e && *e && *e != '0'))
             return launch_pair<NW>(ctx, a, pl, s, k_noddi<3, NR, NQ, MP, NW, false, double>, k_noddi<3, NR, NQ, MB, 1, true>,
-                                   [&](int nw) { return fit_lds_bytes<double>(a.c.nS, a.c.ldA, NR, NQ, nw, MP); },
-                                   fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB), 2, 6);
+                                   [&](int nw) { return fit_lds_bytes<double>(a.c.nS, a.c.ldA, NR, NQ, nw, MP, false, false); },
+                                   fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, false), 2, 6);
     }
     return launch_pair<NW>(ctx, a, pl, s, k_noddi<3, NR, NQ, MP, NW, false>, k_noddi<3, NR, NQ, MB, 1, true>,
-                       [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MP); }, fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB),
+                       [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MP, false, false); }, fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, false),
                        2, 6);
 }
 
