@@ -513,6 +513,7 @@ int amx_freewater_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y
     a.c.lutidx = pl.lutidx; a.c.status = ctx->status_d; a.c.nS = lut->nS; a.c.ldA = lut->ldA;
     a.c.n_atoms = lut->n_atoms; a.c.tile_stride = lut->tile_stride; a.c.lam1 = lambda1; a.c.lam2 = lambda2; a.c.flags = flags;
     a.n_perp = lut->n_perp; a.n_iso = lut->n_iso; a.is_mouse = is_mouse; a.n_maps = is_mouse ? 4 : 2;
+    { const char *e = getenv("AMX_COLD_START"); if (e && *e && *e != '0') a.c.flags |= 0x80000000u; }
     if (flags & AMX_F_DEBUG_X) {
         if (!ctx->dbg_x) return bad(ctx, "amx_freewater_fit: AMX_F_DEBUG_X without a buffer (amx_set_debug_x)");
         a.c.xdbg = ctx->dbg_x + (size_t)ctx->vox_base * lut->n_atoms;
@@ -554,6 +555,7 @@ int amx_sandi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, in
     a.c.n_atoms = lut->n_atoms; a.c.tile_stride = lut->tile_stride; a.c.lam1 = lambda1; a.c.lam2 = lambda2; a.c.flags = flags;
     a.norms = lut->norms; a.Rs = lut->Rs; a.d_in = lut->d_in; a.d_isos = lut->d_isos;
     a.n_rs = lut->n_rs; a.n_in = lut->n_in; a.n_iso = lut->n_isos;
+    { const char *e = getenv("AMX_COLD_START"); if (e && *e && *e != '0') a.c.flags |= 0x80000000u; }
     if (flags & AMX_F_DEBUG_X) {
         if (!ctx->dbg_x) return bad(ctx, "amx_sandi_fit: AMX_F_DEBUG_X without a buffer (amx_set_debug_x)");
         a.c.xdbg = ctx->dbg_x + (size_t)ctx->vox_base * lut->n_atoms;

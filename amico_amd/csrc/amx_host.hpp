@@ -152,6 +152,10 @@ int amx_launch_sandi_small(amx_ctx *ctx, amx::SandiArgs &a, const Plan &pl, hipS
 // kernels on MI355X (stage 1 17.9 vs 15.3 ms, stage 3 8.4 vs 7.8 ms per 1 M voxels; four voxels per wavefront 21.6 /
 // 9.4 ms) -- DESIGN.md section 5.
 static inline bool amx_use_pair(int nS, int n_atoms) { const char *e = getenv("AMX_PAIR"); return nS <= 128 && n_atoms <= 160 && e && *e && *e != '0'; }
+// Lane-per-voxel solvers: start the active set from ALL atoms and drop the non-positive ones in blocks (unique optimum
+// with lambda2 > 0, so the path is free; dense optima are reached in 3-4 factorisations).  AMX_COLD_START=1: the
+// Lawson-Hanson start from the empty set.  Needs a ridge that keeps the full system well conditioned.
+__host__ __device__ static inline bool amx_warm_start(double lam2, unsigned flags) { return lam2 >= 1e-5 && !(flags & 0x80000000u); }
 // FreeWater with lanes that never idle (k_freewater_refill, amx_small.hip): maps only (the error maps / corrected DWI
 // need the signal again and stay with k_freewater_lane), <= 12 atoms; chunks of up to 4096 voxels per workgroup
 // voxels of one orientation per workgroup of the refill kernel: large enough to keep the lanes fed (the buffer needs a

@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(256) k_sandi_lane(const SandiArgs a)
 // wave-uniform addresses.  cond(B) <= 1 + |P| / lambda2 (~3e3 for the defaults): harmless in fp64.
 template <int M, int N>
 __device__ __forceinline__ int lane_nnqp_rows(const double *__restrict__ A, int ldA, const double (&y)[M], double lam1,
-                                              double lam2, double (&x)[N])
+                                              double lam2, double (&x)[N], int n_atoms, bool warm)
 {
     const double tol = 1e-12, inf = __builtin_huge_val(), il2 = 1.0 / lam2;
     double c[N], B[M * (M + 1) / 2], L[M * (M + 1) / 2], li[M], w[M], z[N];
@@ -344,6 +344,96 @@ __device__ __forceinline__ int lane_nnqp_rows(const double *__restrict__ A, int 
     for (int i = 0; i < M; i++)
 #pragma unroll
         for (int k = 0; k <= i; k++) B[tri<M>(i, k)] = (i == k) ? lam2 : 0.0;
+    if (warm) {
+        // Start from the FULL set instead of the empty one.  With lambda2 > 0 the optimum is unique, so the path does not
+        // matter -- and SANDI's optimum is dense (12 of 15 atoms): solving on all atoms and dropping the negative ones,
+        // a few times, reaches it in 3-4 factorisations where Lawson-Hanson needs one per atom (13-15).  The loop below
+        // then verifies the KKT conditions and repairs what the block removals got wrong.
+        P = (n_atoms >= 32) ? ~0u : ((1u << n_atoms) - 1u);
+        AMX_RELOAD();
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            if (j < n_atoms) {
+#pragma unroll
+                for (int i = 0; i < M; i++)
+#pragma unroll
+                    for (int k = 0; k <= i; k++) B[tri<M>(i, k)] += A[i * ldA + j] * A[k * ldA + j];
+            }
+        }
+        for (int round = 0; round < N && P != 0u; ++round) {
+#pragma unroll
+            for (int j = 0; j < M; j++) {
+                double d = B[tri<M>(j, j)];
+#pragma unroll
+                for (int k = 0; k < j; k++) d -= L[tri<M>(j, k)] * L[tri<M>(j, k)];
+                const double iv = rsqrt(d);
+                li[j] = iv;
+                L[tri<M>(j, j)] = d * iv;
+#pragma unroll
+                for (int i = j + 1; i < M; i++) {
+                    double tt = B[tri<M>(i, j)];
+#pragma unroll
+                    for (int k = 0; k < j; k++) tt -= L[tri<M>(i, k)] * L[tri<M>(j, k)];
+                    L[tri<M>(i, j)] = tt * iv;
+                }
+            }
+            AMX_RELOAD();
+#pragma unroll
+            for (int i = 0; i < M; i++) w[i] = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                const double cj = ((P >> j) & 1u) ? c[j] : 0.0;
+#pragma unroll
+                for (int i = 0; i < M; i++) w[i] += A[i * ldA + j] * cj;
+            }
+#pragma unroll
+            for (int j = 0; j < M; j++) {
+                double sacc = w[j];
+#pragma unroll
+                for (int k = 0; k < j; k++) sacc -= L[tri<M>(j, k)] * w[k];
+                w[j] = sacc * li[j];
+            }
+#pragma unroll
+            for (int j = M - 1; j >= 0; j--) {
+                double sacc = w[j];
+#pragma unroll
+                for (int i = j + 1; i < M; i++) sacc -= L[tri<M>(i, j)] * w[i];
+                w[j] = sacc * li[j];
+            }
+            AMX_RELOAD();
+            unsigned negm = 0u;
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                double sacc = c[j];
+#pragma unroll
+                for (int i = 0; i < M; i++) sacc -= A[i * ldA + j] * w[i];
+                z[j] = sacc * il2;
+                if (((P >> j) & 1u) && !(z[j] > 0.0)) negm |= 1u << j;
+            }
+            if (negm == 0u) {
+#pragma unroll
+                for (int j = 0; j < N; j++) x[j] = ((P >> j) & 1u) ? z[j] : 0.0;
+                break;
+            }
+            P &= ~negm;
+            AMX_RELOAD();
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                if ((negm >> j) & 1u) {
+#pragma unroll
+                    for (int i = 0; i < M; i++)
+#pragma unroll
+                        for (int k = 0; k <= i; k++) B[tri<M>(i, k)] -= A[i * ldA + j] * A[k * ldA + j];
+                }
+            }
+        }
+        if (P == 0u) {
+#pragma unroll
+            for (int i = 0; i < M; i++)
+#pragma unroll
+                for (int k = 0; k <= i; k++) B[tri<M>(i, k)] = (i == k) ? lam2 : 0.0;
+        }
+    }
     for (int it = 0; status == 0; ++it) {
         if (it > 3 * N + 8) { status = 2; break; }
         AMX_RELOAD();
@@ -486,6 +576,7 @@ __global__ void __launch_bounds__(256, AMX_ROWS_OCC) k_sandi_rows(const SandiArg
     const Chunk ck = a.c.chunks[cid];
     const int ldA = a.c.ldA, n_atoms = a.c.n_atoms, n_rs = a.n_rs, n_in = a.n_in;
     const double *__restrict__ A = reinterpret_cast<const double *>(a.c.tiles);
+    const bool warm = amx_warm_start(a.c.lam2, a.c.flags);
     for (int v = threadIdx.x; v < ck.count; v += blockDim.x) {
         const int vox = a.c.perm[ck.start + v];
         const double *yv = a.c.y + (size_t)vox * M;
@@ -505,7 +596,7 @@ __global__ void __launch_bounds__(256, AMX_ROWS_OCC) k_sandi_rows(const SandiArg
             if (a.nrmse) a.nrmse[vox] = nan;
             continue;
         }
-        if (lane_nnqp_rows<M, N>(A, ldA, y, a.c.lam1, a.c.lam2, x) != 0) atomicAdd(&a.c.status[ST_ITCAP], 1);
+        if (lane_nnqp_rows<M, N>(A, ldA, y, a.c.lam1, a.c.lam2, x, n_atoms, warm) != 0) atomicAdd(&a.c.status[ST_ITCAP], 1);
         // models.pyx:1570-1612
         double x_sum = 0.0, xsph = 0.0, xstk = 0.0, xiso = 0.0, Rsoma = 0.0, Din = 0.0, De = 0.0;
 #pragma unroll
@@ -600,7 +691,9 @@ __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
     const double tol = 1e-12, inf = __builtin_huge_val();
     const int n_batches = (ck.count + 63) >> 6;
     // lane state
-    bool active = false;
+    const bool warm0 = amx_warm_start(a.c.lam2, a.c.flags);
+    const unsigned pfull = (1u << n_atoms) - 1u;
+    bool active = false, warm = false;       // warm: still in the block-removal phase that starts from the full set
     int vox = 0, st = 0, its = 0;            // st: 0 = pick an atom first, 1 = passive set changed, solve
     unsigned P = 0u;
     double c[N], x[N];
@@ -668,7 +761,8 @@ __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
                 c[j] = take ? cj : c[j];
                 x[j] = take ? 0.0 : x[j];
             }
-            if (take) { active = true; vox = nv; P = 0u; st = 0; its = 0; }
+            // cold: empty passive set, pick an atom first; warm: all atoms, solve first (see lane_nnqp_rows)
+            if (take) { active = true; vox = nv; P = warm0 ? pfull : 0u; st = warm0 ? 1 : 0; its = 0; warm = warm0; }
             const int taken = min(__builtin_popcountll(freem), buf_cnt);
             buf_pos += taken; buf_cnt -= taken;
         }
@@ -747,7 +841,14 @@ __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
                         if (r < alpha) { alpha = r; jm = j; }
                     }
                 }
-                if (slv && !feasible) {
+                if (slv && !feasible && warm) {
+                    // block removal: every atom whose unconstrained coefficient is not positive leaves at once (x is 0)
+#pragma unroll
+                    for (int j = 0; j < N; j++)
+                        if (((P >> j) & 1u) && !(z[j] > 0.0)) P &= ~(1u << j);
+                    its++;
+                    if (P == 0u) { st = 0; warm = false; }
+                } else if (slv && !feasible) {
 #pragma unroll
                     for (int j = 0; j < N; j++) {
                         if ((P >> j) & 1u) {
@@ -763,7 +864,7 @@ __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
             if (slv && feasible) {
 #pragma unroll
                 for (int j = 0; j < N; j++) x[j] = ((P >> j) & 1u) ? z[j] : 0.0;
-                st = 0;
+                st = 0; warm = false;
             }
         }
         // ------------------------------------------------------------ finished voxels: maps (models.pyx:1241-1256)
