@@ -26,17 +26,74 @@ __device__ __forceinline__ constexpr int tri(int i, int j) { return i * (i + 1) 
 // across the fully unrolled passes (hundreds of VGPRs) and spills everything else
 #define AMX_RELOAD() asm volatile("" ::: "memory")
 
-// per-lane NNQP: min 1/2 x'Hx - cc'x, x >= 0 (cc = c - lambda1); Hs in LDS, row-major N x N.
-// returns 0, or 2 if an iteration cap tripped.
+// masked Cholesky of H restricted to P (identity elsewhere) and the two triangular solves: z = H_PP^-1 cc_P (0 elsewhere)
 template <int N>
-__device__ __forceinline__ int lane_nnqp(const double *__restrict__ Hs, const double (&cc)[N], double (&x)[N])
+__device__ __forceinline__ void lane_solve(const double *__restrict__ Hs, const double (&cc)[N], unsigned P, double (&z)[N])
+{
+    double L[N * (N + 1) / 2], linv[N];
+    AMX_RELOAD();
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        const bool pj = (P >> j) & 1u;
+        double s = Hs[j * N + j];
+#pragma unroll
+        for (int k = 0; k < j; k++) s -= L[tri<N>(j, k)] * L[tri<N>(j, k)];
+        const double iv = pj ? rsqrt(s) : 1.0;
+        linv[j] = iv;
+        L[tri<N>(j, j)] = pj ? s * iv : 1.0;
+#pragma unroll
+        for (int i = j + 1; i < N; i++) {
+            double tt = Hs[i * N + j];
+#pragma unroll
+            for (int k = 0; k < j; k++) tt -= L[tri<N>(i, k)] * L[tri<N>(j, k)];
+            L[tri<N>(i, j)] = (pj && ((P >> i) & 1u)) ? tt * iv : 0.0;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        double s = ((P >> j) & 1u) ? cc[j] : 0.0;
+#pragma unroll
+        for (int k = 0; k < j; k++) s -= L[tri<N>(j, k)] * z[k];
+        z[j] = s * linv[j];
+    }
+#pragma unroll
+    for (int j = N - 1; j >= 0; j--) {
+        double s = z[j];
+#pragma unroll
+        for (int i = j + 1; i < N; i++) s -= L[tri<N>(i, j)] * z[i];
+        z[j] = s * linv[j];
+    }
+}
+
+// per-lane NNQP: min 1/2 x'Hx - cc'x, x >= 0 (cc = c - lambda1); Hs in LDS, row-major N x N.
+// warm: start from all n_atoms atoms and drop the non-positive ones in blocks before the Lawson-Hanson loop takes over
+// (unique optimum with the ridge; see lane_nnqp_rows).  returns 0, or 2 if an iteration cap tripped.
+template <int N>
+__device__ __forceinline__ int lane_nnqp(const double *__restrict__ Hs, const double (&cc)[N], double (&x)[N],
+                                         int n_atoms = N, bool warm = false)
 {
     const double tol = 1e-12, inf = __builtin_huge_val();
-    double L[N * (N + 1) / 2], linv[N], z[N];
+    double z[N];
     unsigned P = 0u;
     int status = 0;
 #pragma unroll
     for (int j = 0; j < N; j++) x[j] = 0.0;
+    if (warm) {
+        P = (1u << n_atoms) - 1u;
+        for (int round = 0; round < N && P != 0u; ++round) {
+            lane_solve<N>(Hs, cc, P, z);
+            unsigned negm = 0u;
+#pragma unroll
+            for (int j = 0; j < N; j++)
+                if (((P >> j) & 1u) && !(z[j] > 0.0)) negm |= 1u << j;
+            if (negm == 0u) {
+#pragma unroll
+                for (int j = 0; j < N; j++) x[j] = ((P >> j) & 1u) ? z[j] : 0.0;
+                break;
+            }
+            P &= ~negm;
+        }
+    }
     for (int it = 0; status == 0; ++it) {
         if (it > 3 * N + 8) { status = 2; break; }
         // dual vector g = cc - H x, most violating atom outside the passive set
@@ -54,39 +111,7 @@ __device__ __forceinline__ int lane_nnqp(const double *__restrict__ Hs, const do
         P |= 1u << t;
         for (int in = 0;; ++in) {
             if (in > N + 2) { status = 2; break; }
-            // masked Cholesky of H restricted to P (identity elsewhere) and the two triangular solves
-            AMX_RELOAD();
-#pragma unroll
-            for (int j = 0; j < N; j++) {
-                const bool pj = (P >> j) & 1u;
-                double s = Hs[j * N + j];
-#pragma unroll
-                for (int k = 0; k < j; k++) s -= L[tri<N>(j, k)] * L[tri<N>(j, k)];
-                const double iv = pj ? rsqrt(s) : 1.0;
-                linv[j] = iv;
-                L[tri<N>(j, j)] = pj ? s * iv : 1.0;
-#pragma unroll
-                for (int i = j + 1; i < N; i++) {
-                    double tt = Hs[i * N + j];
-#pragma unroll
-                    for (int k = 0; k < j; k++) tt -= L[tri<N>(i, k)] * L[tri<N>(j, k)];
-                    L[tri<N>(i, j)] = (pj && ((P >> i) & 1u)) ? tt * iv : 0.0;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < N; j++) {
-                double s = ((P >> j) & 1u) ? cc[j] : 0.0;
-#pragma unroll
-                for (int k = 0; k < j; k++) s -= L[tri<N>(j, k)] * z[k];
-                z[j] = s * linv[j];
-            }
-#pragma unroll
-            for (int j = N - 1; j >= 0; j--) {
-                double s = z[j];
-#pragma unroll
-                for (int i = j + 1; i < N; i++) s -= L[tri<N>(i, j)] * z[i];
-                z[j] = s * linv[j];
-            }
+            lane_solve<N>(Hs, cc, P, z);
             bool feasible = true;
 #pragma unroll
             for (int j = 0; j < N; j++)
@@ -223,7 +248,7 @@ __global__ void __launch_bounds__(256) k_freewater_lane(const FwArgs a)
 #pragma unroll
         for (int j = 0; j < N; j++) x[j] = c[j] > 0.0 ? 1e-3 * c[j] : 0.0;
 #else
-        if (lane_nnqp<N>(Hs, c, x) != 0) atomicAdd(&a.c.status[ST_ITCAP], 1);
+        if (lane_nnqp<N>(Hs, c, x, n_atoms, amx_warm_start(a.c.lam2, a.c.flags)) != 0) atomicAdd(&a.c.status[ST_ITCAP], 1);
 #endif
         if (a.c.xdbg) {
 #pragma unroll
@@ -284,7 +309,7 @@ __global__ void __launch_bounds__(256) k_sandi_lane(const SandiArgs a)
         }
 #pragma unroll
         for (int j = 0; j < N; j++) c[j] -= a.c.lam1;
-        if (lane_nnqp<N>(Hs, c, x) != 0) atomicAdd(&a.c.status[ST_ITCAP], 1);
+        if (lane_nnqp<N>(Hs, c, x, n_atoms, amx_warm_start(a.c.lam2, a.c.flags)) != 0) atomicAdd(&a.c.status[ST_ITCAP], 1);
         // models.pyx:1570-1612
         double x_sum = 0.0, xsph = 0.0, xstk = 0.0, xiso = 0.0, Rsoma = 0.0, Din = 0.0, De = 0.0;
 #pragma unroll
@@ -566,16 +591,23 @@ __device__ __forceinline__ int lane_nnqp_rows(const double *__restrict__ A, int 
 #ifndef AMX_ROWS_OCC
 #define AMX_ROWS_OCC 2
 #endif
-// SANDI, nS == M (<= 8) values per voxel: row-space solver; the dictionary is read from global memory with
-// wave-uniform addresses (scalar loads), y from the voxel's row.
+// SANDI, nS == M (<= 8) values per voxel: row-space solver; the dictionary sits in LDS (wave-uniform reads), y comes
+// from the voxel's row.
 template <int M, int N>
 __global__ void __launch_bounds__(256, AMX_ROWS_OCC) k_sandi_rows(const SandiArgs a)
 {
     const int cid = xcd_chunk((int)blockIdx.x, *a.c.n_chunks);
     if (cid < 0) return;
     const Chunk ck = a.c.chunks[cid];
-    const int ldA = a.c.ldA, n_atoms = a.c.n_atoms, n_rs = a.n_rs, n_in = a.n_in;
-    const double *__restrict__ A = reinterpret_cast<const double *>(a.c.tiles);
+    const int n_atoms = a.c.n_atoms, n_rs = a.n_rs, n_in = a.n_in;
+    // the dictionary (M x N doubles, the same for every voxel) in LDS, read with wave-uniform addresses
+    __shared__ double A[M * N];
+    constexpr int ldA = N;
+    {
+        const double *__restrict__ Ag = reinterpret_cast<const double *>(a.c.tiles);
+        for (int e = threadIdx.x; e < M * N; e += blockDim.x) A[e] = ((e % N) < n_atoms) ? Ag[(e / N) * a.c.ldA + (e % N)] : 0.0;
+        __syncthreads();
+    }
     const bool warm = amx_warm_start(a.c.lam2, a.c.flags);
     for (int v = threadIdx.x; v < ck.count; v += blockDim.x) {
         const int vox = a.c.perm[ck.start + v];
@@ -792,40 +824,8 @@ __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
         }
         const bool slv = active && !done;                         // st == 1 for all of them now
         if (__ballot(slv) != 0ull) {
-            // masked Cholesky of H restricted to P (identity elsewhere) and the two triangular solves
-            double L[N * (N + 1) / 2], linv[N], z[N];
-            AMX_RELOAD();
-#pragma unroll
-            for (int j = 0; j < N; j++) {
-                const bool pj = (P >> j) & 1u;
-                double s = Hs[j * N + j];
-#pragma unroll
-                for (int k = 0; k < j; k++) s -= L[tri<N>(j, k)] * L[tri<N>(j, k)];
-                const double iv = pj ? rsqrt(s) : 1.0;
-                linv[j] = iv;
-                L[tri<N>(j, j)] = pj ? s * iv : 1.0;
-#pragma unroll
-                for (int i = j + 1; i < N; i++) {
-                    double tt = Hs[i * N + j];
-#pragma unroll
-                    for (int k = 0; k < j; k++) tt -= L[tri<N>(i, k)] * L[tri<N>(j, k)];
-                    L[tri<N>(i, j)] = (pj && ((P >> i) & 1u)) ? tt * iv : 0.0;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < N; j++) {
-                double s = ((P >> j) & 1u) ? c[j] : 0.0;
-#pragma unroll
-                for (int k = 0; k < j; k++) s -= L[tri<N>(j, k)] * z[k];
-                z[j] = s * linv[j];
-            }
-#pragma unroll
-            for (int j = N - 1; j >= 0; j--) {
-                double s = z[j];
-#pragma unroll
-                for (int i = j + 1; i < N; i++) s -= L[tri<N>(i, j)] * z[i];
-                z[j] = s * linv[j];
-            }
+            double z[N];
+            lane_solve<N>(Hs, c, P, z);
             bool feasible = true;
 #pragma unroll
             for (int j = 0; j < N; j++)
