@@ -338,11 +338,11 @@ int amx_prep_gather_device(amx_ctx *ctx, const amx_prep *p, const float *d_img, 
     const bool identity = p->identity != 0;
     const size_t lds = ((size_t)kPrepWaves * 64 * a.ldt * (a.inplace ? 1 : 2) + (size_t)p->n_b0 + p->n_out + 1 + p->n_gidx) * sizeof(float);
     if (lds > 160 * 1024) return amx_bad(ctx, "amx_prep_gather: scheme too long for the LDS tile");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64];                                        // per device: the attribute belongs to (function, device)
+    if (!attr_set[ctx->device & 63]) {
         HIPCHK(ctx, hipFuncSetAttribute((const void *)k_prep_gather<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(ctx, hipFuncSetAttribute((const void *)k_prep_gather<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set[ctx->device & 63] = true;
     }
     const int per_cu = (int)((160 * 1024) / lds) > 8 ? 8 : (int)((160 * 1024) / lds);
     long long grid = 256LL * per_cu * 2;
