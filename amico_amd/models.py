@@ -99,8 +99,18 @@ class BaseModel(ABC):
     # ---- device-resident inputs: Evaluation.fit leaves `y` (and `DIRs`) in HBM (evaluation._dev) when it produced
     #      them on the GPU; the fit then reads them in place and keeps its outputs there for the scatter
     @staticmethod
-    def _finish_device(ctx, dev, named):
+    def _warn_if_capped(ctx):
+        """voxels whose active-set iteration hit its cap keep the last iterate: say so (the reference's solvers are silent)"""
+        st = ctx.last_stats()
+        if st['itercap_voxels'] > 0:
+            import warnings
+            warnings.warn('amico_amd: %d voxel(s) stopped at the iteration cap of the active-set solver' % st['itercap_voxels'],
+                          RuntimeWarning)
+
+    @classmethod
+    def _finish_device(cls, ctx, dev, named):
         ctx.sync()
+        cls._warn_if_capped(ctx)
         dev['out'] = {k: v for k, v in named.items() if v is not None}
         return {k: v.cpu().numpy() for k, v in dev['out'].items()}
 
@@ -199,6 +209,7 @@ class CylinderZeppelinBall(BaseModel):
             return self._finish_device(ctx, dev, {'estimates': est, 'rmse': rmse, 'nrmse': nrmse})
         est, rmse, nrmse = _capi.czb_fit(ctx, lut, evaluation.y, evaluation.DIRs, self.solver_params['lambda1'],
                                          self.solver_params['lambda2'], **kw)
+        self._warn_if_capped(ctx)
         results = {'estimates': est}
         if self.configs['compute_rmse']:
             results['rmse'] = rmse
@@ -278,6 +289,7 @@ class NODDI(BaseModel):
             ctx, lut, evaluation.y, evaluation.DIRs, self.solver_params['lambda1'], self.solver_params['lambda2'],
             len(self.maps_name), rmse=bool(self.configs['compute_rmse']), nrmse=bool(self.configs['compute_nrmse']),
             mod=bool(self.configs['compute_modulated_maps']))
+        self._warn_if_capped(ctx)
         results = {'estimates': est}
         if self.configs['compute_rmse']:
             results['rmse'] = rmse
@@ -350,6 +362,7 @@ class FreeWater(BaseModel):
             ctx, lut, evaluation.y, evaluation.DIRs, self.solver_params['lambda1'], self.solver_params['lambda2'],
             self.type == 'Mouse', rmse=bool(self.configs['compute_rmse']), nrmse=bool(self.configs['compute_nrmse']),
             corrected=bool(self.configs['save_corrected_DWI']))
+        self._warn_if_capped(ctx)
         results = {'estimates': est}
         if self.configs['compute_rmse']:
             results['rmse'] = rmse
@@ -419,6 +432,7 @@ class SANDI(BaseModel):
         est, rmse, nrmse = _capi.sandi_fit(ctx, lut, evaluation.y, self.solver_params['lambda1'],
                                            self.solver_params['lambda2'], rmse=bool(self.configs['compute_rmse']),
                                            nrmse=bool(self.configs['compute_nrmse']))
+        self._warn_if_capped(ctx)
         results = {'estimates': est}
         if self.configs['compute_rmse']:
             results['rmse'] = rmse
