@@ -24,7 +24,7 @@ SYMBOLS = ['amx_version', 'amx_ctx_create', 'amx_ctx_destroy', 'amx_last_error',
            'amx_dti_create', 'amx_dti_destroy', 'amx_dti_directions', 'amx_dti_directions_device',
            'amx_prep_create', 'amx_prep_destroy', 'amx_prep_gather', 'amx_prep_gather_device',
            'amx_prep_mean_b0', 'amx_prep_mean_b0_device', 'amx_prep_scatter', 'amx_prep_scatter_device',
-           'amx_lut_resample']
+           'amx_lut_resample', 'amx_lut_rotate_resample']
 
 _lib = None
 c_vp, c_dp, c_fp = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float)
@@ -113,6 +113,7 @@ def lib():
     L.amx_prep_scatter.argtypes = [c_vp, c_vp, c_dp, C.c_int, c_fp]
     L.amx_prep_scatter_device.argtypes = [c_vp, c_vp, c_vp, C.c_int, c_vp, c_vp]
     L.amx_lut_resample.argtypes = [c_vp, c_fp, C.c_int64, C.c_int, c_fp, c_i32p, C.c_int, C.c_int, c_fp]
+    L.amx_lut_rotate_resample.argtypes = [c_vp, c_fp, C.c_int, c_fp, C.c_int, C.c_int, C.c_int, c_fp, c_i32p, C.c_int, C.c_int, c_fp]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ('amx_version',):
@@ -565,4 +566,19 @@ def lut_resample(ctx, lm, ylm_out, idx_out, nS):
     out = np.empty(lm.shape[:-1] + (int(nS),), dtype=np.float32)
     ctx.check(lib().amx_lut_resample(ctx._h, _p(lm, c_fp), rows, lm.shape[-1], _p(y, c_fp), _p(idx, c_i32p),
                                      y.shape[0], int(nS), _p(out, c_fp)))
+    return out
+
+
+def lut_rotate_resample(ctx, zonal, ylm_rot, ylm_out, idx_out, nS):
+    """zonal f32[n_atoms, n_shells * nSH] (const * Klm[idx_m0] per shell), ylm_rot f32[ndirs, nSH] -> f32[n_atoms, ndirs, nS]:
+    rotate_kernel + resample_kernel of lut.pyx:227-311 in one GEMM whose left operand is formed on the fly"""
+    z = np.ascontiguousarray(zonal, dtype=np.float32)
+    r = np.ascontiguousarray(ylm_rot, dtype=np.float32)
+    y = np.ascontiguousarray(ylm_out, dtype=np.float32)
+    idx = np.ascontiguousarray(idx_out, dtype=np.int32)
+    if z.ndim != 2 or r.ndim != 2 or y.ndim != 2 or z.shape[1] % r.shape[1] or y.shape[1] != z.shape[1] or idx.shape != (y.shape[0],):
+        raise ValueError('Outdated LUT. Call "generate_kernels( regenerate=True )" to update the LUT')
+    out = np.empty((z.shape[0], r.shape[0], int(nS)), dtype=np.float32)
+    ctx.check(lib().amx_lut_rotate_resample(ctx._h, _p(z, c_fp), z.shape[0], _p(r, c_fp), r.shape[0], r.shape[1],
+                                            z.shape[1] // r.shape[1], _p(y, c_fp), _p(idx, c_i32p), y.shape[0], int(nS), _p(out, c_fp)))
     return out

@@ -482,10 +482,13 @@ __global__ void k_fill_ones(float *out, long long n)
 // LDS tile (0.13 ms at one workgroup per CU), three independent accumulators (0.10 ms, one wavefront per SIMD).
 constexpr int kLutKhMax = 64;
 
+// Fused mode (Z != nullptr, amx_lut_rotate_resample): row (atom, orientation) of L is never materialised --
+// L[atom * ndirs + dir][k] = Z[atom][k] * R[dir][k mod n_sh]  (rotate_kernel, lut.pyx:262-264: const * Klm[idx_m0] * Ylm_rot).
 template <int KH2>
 __global__ __launch_bounds__(256) void k_lut_resample(const float *__restrict__ L, const float *__restrict__ Y,
                                                       const int *__restrict__ idx_out, long long M, int K, int N, int nS,
-                                                      float *__restrict__ out)
+                                                      float *__restrict__ out, const float *__restrict__ Z = nullptr,
+                                                      const float *__restrict__ R = nullptr, int ndirs = 1, int n_sh = 1)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_l[];
     constexpr int Kp = 4 * KH2;                                      // padded K
@@ -514,15 +517,29 @@ __global__ __launch_bounds__(256) void k_lut_resample(const float *__restrict__ 
         // this lane's half row of L, loaded once with 8-byte loads (rows beyond M repeat the last one; masked at the store)
         const long long row = m0 + l32 < M ? m0 + l32 : M - 1;
         float2 a2[KH2];
-        const float *lrow = L + row * K;
+        if (Z == nullptr) {
+            const float *lrow = L + row * K;
 #pragma unroll
-        for (int j = 0; j < KH2; j++) {
-            const int k = 2 * half * KH2 + 2 * j;
-            if (even && 2 * KH2 + 2 * j + 1 < K) {                   // (holds for both halves: no condition per lane)
-                a2[j] = *reinterpret_cast<const float2 *>(lrow + k);
-            } else {
-                a2[j].x = (k < K) ? lrow[k] : 0.0f;
-                a2[j].y = (k + 1 < K) ? lrow[k + 1] : 0.0f;
+            for (int j = 0; j < KH2; j++) {
+                const int k = 2 * half * KH2 + 2 * j;
+                if (even && 2 * KH2 + 2 * j + 1 < K) {               // (holds for both halves: no condition per lane)
+                    a2[j] = *reinterpret_cast<const float2 *>(lrow + k);
+                } else {
+                    a2[j].x = (k < K) ? lrow[k] : 0.0f;
+                    a2[j].y = (k + 1 < K) ? lrow[k + 1] : 0.0f;
+                }
+            }
+        } else {
+            // rotation by the addition theorem, formed in registers: per-(l, m) factor of the atom x basis value of the orientation
+            const float *zrow = Z + (row / ndirs) * K, *rrow = R + (row % ndirs) * n_sh;
+            int c = (2 * half * KH2) % n_sh;                          // position inside the shell's block of coefficients
+#pragma unroll
+            for (int j = 0; j < KH2; j++) {
+                const int k = 2 * half * KH2 + 2 * j;
+                const int c1 = (c + 1 == n_sh) ? 0 : c + 1;
+                a2[j].x = (k < K) ? zrow[k] * rrow[c] : 0.0f;
+                a2[j].y = (k + 1 < K) ? zrow[k + 1] * rrow[c1] : 0.0f;
+                c = (c1 + 1 == n_sh) ? 0 : c1 + 1;
             }
         }
         for (int n0 = 0; n0 < N; n0 += 32) {
@@ -589,6 +606,42 @@ __global__ __launch_bounds__(256) void k_lut_resample_generic(const float *__res
 
 }  // namespace amx
 
+// shared by amx_lut_resample (lm given) and amx_lut_rotate_resample (zonal factors + basis values given): device buffers
+// d_lm or (d_z, d_r) -> ctx->hextra (f32 [n_rows][nS], ones outside idx_out)
+static int lut_gemm(amx_ctx *ctx, const float *d_lm, const float *d_z, const float *d_r, int ndirs, int n_sh1, int64_t n_rows,
+                    int n_sh, const float *d_ylm, const int *d_idx, int n_out, int nS)
+{
+    int rc = AMX_OK;
+    hipLaunchKernelGGL(amx::k_fill_ones, dim3(2048), dim3(256), 0, nullptr, (float *)ctx->hextra.p, (long long)n_rows * nS);
+    const int kh2 = (n_sh + 3) / 4;
+    const int kh2t = kh2 <= 23 ? 23 : (kh2 <= 46 ? 46 : 64);         // compile-time reduction lengths: 1 / 2 shells of lmax 12, <= 256
+    const size_t lds = (size_t)((n_out + 31) & ~31) * (4 * kh2t + 2) * sizeof(float);
+    if (n_sh > 4 * amx::kLutKhMax || lds > 80 * 1024) {              // generic shapes: operands from L2
+        if (!d_lm) return amx_bad(ctx, "amx_lut_rotate_resample: shape beyond the fused kernel (K <= 256, operator <= 80 KB)");
+        rec(ctx, 8, nullptr);
+        hipLaunchKernelGGL(amx::k_lut_resample_generic, dim3((unsigned)((n_rows + 127) / 128)), dim3(256), 0, nullptr, d_lm, d_ylm,
+                           d_idx, (long long)n_rows, n_sh, n_out, nS, (float *)ctx->hextra.p);
+    } else {
+        auto launch = [&](auto kern) -> int {
+            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            long long blocks = (n_rows + 127) / 128;                  // persistent: the Ylm tile is staged once per workgroup
+            const long long cap = 2LL * ctx->n_cu;
+            if (blocks > cap) blocks = cap;
+            rec(ctx, 8, nullptr);
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, nullptr, d_lm, d_ylm, d_idx, (long long)n_rows, n_sh,
+                               n_out, nS, (float *)ctx->hextra.p, d_z, d_r, ndirs, n_sh1);
+            return AMX_OK;
+        };
+        if (kh2t == 23) rc = launch(amx::k_lut_resample<23>);
+        else if (kh2t == 46) rc = launch(amx::k_lut_resample<46>);
+        else rc = launch(amx::k_lut_resample<64>);
+        if (rc) return rc;
+    }
+    HIPCHK(ctx, hipGetLastError());
+    rec(ctx, 9, nullptr);
+    return AMX_OK;
+}
+
 extern "C" int amx_lut_resample(amx_ctx *ctx, const float *lm, int64_t n_rows, int n_sh, const float *ylm_out,
                                 const int32_t *idx_out, int n_out, int nS, float *out)
 {
@@ -607,34 +660,39 @@ extern "C" int amx_lut_resample(amx_ctx *ctx, const float *lm, int64_t n_rows, i
     HIPCHK(ctx, hipMemcpyAsync(ctx->hy.p, lm, lb, hipMemcpyHostToDevice, nullptr));
     HIPCHK(ctx, hipMemcpyAsync(ctx->hdirs.p, ylm_out, yb, hipMemcpyHostToDevice, nullptr));
     HIPCHK(ctx, hipMemcpyAsync(ctx->hrmse.p, idx_out, (size_t)n_out * sizeof(int), hipMemcpyHostToDevice, nullptr));
-    hipLaunchKernelGGL(k_fill_ones, dim3(2048), dim3(256), 0, nullptr, (float *)ctx->hextra.p, (long long)n_rows * nS);
-    const int kh2 = (n_sh + 3) / 4;
-    const int kh2t = kh2 <= 23 ? 23 : (kh2 <= 46 ? 46 : 64);         // compile-time reduction lengths: 1 / 2 shells of lmax 12, <= 256
-    const size_t lds = (size_t)((n_out + 31) & ~31) * (4 * kh2t + 2) * sizeof(float);
-    if (n_sh > 4 * amx::kLutKhMax || lds > 80 * 1024) {              // generic shapes: operands from L2
-        rec(ctx, 8, nullptr);
-        hipLaunchKernelGGL(amx::k_lut_resample_generic, dim3((unsigned)((n_rows + 127) / 128)), dim3(256), 0, nullptr,
-                           (const float *)ctx->hy.p, (const float *)ctx->hdirs.p, (const int *)ctx->hrmse.p, (long long)n_rows,
-                           n_sh, n_out, nS, (float *)ctx->hextra.p);
-    } else {
-        auto launch = [&](auto kern) -> int {
-            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            long long blocks = (n_rows + 127) / 128;                  // persistent: the Ylm tile is staged once per workgroup
-            const long long cap = 2LL * ctx->n_cu;
-            if (blocks > cap) blocks = cap;
-            rec(ctx, 8, nullptr);
-            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, nullptr, (const float *)ctx->hy.p,
-                               (const float *)ctx->hdirs.p, (const int *)ctx->hrmse.p, (long long)n_rows, n_sh, n_out, nS,
-                               (float *)ctx->hextra.p);
-            return AMX_OK;
-        };
-        if (kh2t == 23) rc = launch(amx::k_lut_resample<23>);
-        else if (kh2t == 46) rc = launch(amx::k_lut_resample<46>);
-        else rc = launch(amx::k_lut_resample<64>);
-        if (rc) return rc;
-    }
-    HIPCHK(ctx, hipGetLastError());
-    rec(ctx, 9, nullptr);
+    if ((rc = lut_gemm(ctx, (const float *)ctx->hy.p, nullptr, nullptr, 1, 1, n_rows, n_sh, (const float *)ctx->hdirs.p,
+                       (const int *)ctx->hrmse.p, n_out, nS))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->hextra.p, ob, hipMemcpyDeviceToHost, nullptr));
+    HIPCHK(ctx, hipStreamSynchronize(nullptr));
+    return AMX_OK;
+}
+
+extern "C" int amx_lut_rotate_resample(amx_ctx *ctx, const float *zonal, int n_atoms, const float *ylm_rot, int ndirs,
+                                       int n_sh_shell, int n_shells, const float *ylm_out, const int32_t *idx_out, int n_out,
+                                       int nS, float *out)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!zonal || !ylm_rot || !ylm_out || !idx_out || !out || n_atoms < 1 || ndirs < 1 || n_sh_shell < 1 || n_shells < 1 ||
+        n_out < 1 || nS < n_out)
+        return amx_bad(ctx, "amx_lut_rotate_resample: bad argument");
+    for (int k = 0; k < n_out; k++) if (idx_out[k] < 0 || idx_out[k] >= nS) return amx_bad(ctx, "amx_lut_rotate_resample: idx_out out of range");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    const int K = n_sh_shell * n_shells;
+    const int64_t n_rows = (int64_t)n_atoms * ndirs;
+    const size_t zb = (size_t)n_atoms * K * sizeof(float), rb = (size_t)ndirs * n_sh_shell * sizeof(float);
+    const size_t yb = (size_t)n_out * K * sizeof(float), ob = (size_t)n_rows * nS * sizeof(float);
+    if ((rc = amx_ensure(ctx, ctx->hy, zb + rb + 64))) return rc;
+    if ((rc = amx_ensure(ctx, ctx->hdirs, yb))) return rc;
+    if ((rc = amx_ensure(ctx, ctx->hrmse, (size_t)n_out * sizeof(int)))) return rc;
+    if ((rc = amx_ensure(ctx, ctx->hextra, ob))) return rc;
+    float *d_z = (float *)ctx->hy.p, *d_r = (float *)((char *)ctx->hy.p + ((zb + 15) & ~(size_t)15));
+    HIPCHK(ctx, hipMemcpyAsync(d_z, zonal, zb, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(ctx, hipMemcpyAsync(d_r, ylm_rot, rb, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->hdirs.p, ylm_out, yb, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->hrmse.p, idx_out, (size_t)n_out * sizeof(int), hipMemcpyHostToDevice, nullptr));
+    if ((rc = lut_gemm(ctx, nullptr, d_z, d_r, ndirs, n_sh_shell, n_rows, K, (const float *)ctx->hdirs.p, (const int *)ctx->hrmse.p,
+                       n_out, nS))) return rc;
     HIPCHK(ctx, hipMemcpyAsync(out, ctx->hextra.p, ob, hipMemcpyDeviceToHost, nullptr));
     HIPCHK(ctx, hipStreamSynchronize(nullptr));
     return AMX_OK;

@@ -4,7 +4,8 @@
     precompute_rotation_matrices  (lut.pyx:94-141)   -> aux_matrices           host numpy, one-off per (lmax, ndirs)
     aux_structures_generate       (lut.pyx:171-193)  -> aux_structures_generate
     aux_structures_resample       (lut.pyx:196-224)  -> aux_structures_resample host numpy, one-off per scheme
-    rotate_kernel                 (lut.pyx:227-271)  -> rotate_kernel           host numpy, one-off per protocol
+    rotate_kernel                 (lut.pyx:227-271)  -> rotate_kernel           host numpy, one-off per protocol;
+                                                         rotate_and_resample     GPU: fused with the resampling GEMM
     resample_kernel               (lut.pyx:274-311)  -> resample_kernels        GPU: one float32 GEMM for ALL atoms
                                                                                 (amx_lut_resample, include/amico_amd.h)
 
@@ -106,6 +107,25 @@ def rotate_kernel(K, aux, idx_in, idx_out, is_isotropic, ndirs):
         zonal = aux['const'] * klm[s][aux['idx_m0']]                    # addition theorem, one factor per (l, m)
         out[:, list(idx_out[s])] = zonal[None, :] * aux['Ylm_rot']
     return out
+
+
+def zonal_factors(K, aux, idx_in, idx_out):
+    """the part of rotate_kernel that depends on the response function only: per shell, const * Klm[idx_m0] with
+    Klm = fit . K[shell] (lut.pyx:249-251, 262-264) -> float64 [nSH * n_shells]"""
+    out = np.zeros(len(idx_in) * aux['fit'].shape[0])
+    for s in range(len(idx_in)):
+        klm = np.dot(aux['fit'], K[list(idx_in[s])])
+        out[list(idx_out[s])] = aux['const'] * klm[aux['idx_m0']]
+    return out
+
+
+def rotate_and_resample(Ks, aux, idx_in, idx_sh, nS, idx_out, ylm_out, ctx=None):
+    """rotate_kernel (lut.pyx:227-271) + resample_kernel (:274-311) for a list of anisotropic response functions Ks (each
+    sampled on the high-resolution shells, symmetric about z) WITHOUT materialising the rotated SH coefficients: the GPU
+    GEMM forms them in registers (amx_lut_rotate_resample).  -> float32 [n_atoms, ndirs, nS]"""
+    from .models import get_context
+    Z = np.stack([zonal_factors(np.asarray(K, dtype=np.float64), aux, idx_in, idx_sh) for K in Ks]).astype(np.float32)
+    return _capi.lut_rotate_resample(ctx if ctx is not None else get_context(), Z, aux['Ylm_rot'], ylm_out, idx_out, nS)
 
 
 def resample_kernels(lm, nS, idx_out, ylm_out, ctx=None):

@@ -221,6 +221,16 @@ int amx_prep_scatter_device(amx_ctx *ctx, const amx_prep *p, const double *d_val
 int amx_lut_resample(amx_ctx *ctx, const float *lm, int64_t n_rows, int n_sh, const float *ylm_out,
                      const int32_t *idx_out, int n_out, int nS, float *out);
 
+/* (f4 tail) lut.pyx:227-271 `rotate_kernel` fused with the resampling above, for all anisotropic atoms of a model:
+ *     KRlm[i, idx_OUT[s]] = AUX['const'] * Klm[s][AUX['idx_m0']] * AUX['Ylm_rot'][i]        (addition theorem, :262-264)
+ * is never materialised (ndirs x nSH x shells floats per atom: 52 MB for NODDI) -- the GEMM forms its left operand in
+ * registers from  zonal f32[n_atoms][n_shells * n_sh_shell] = const * Klm[s][idx_m0]  (host, a few KB per atom: the SH
+ * fit of the z-aligned response function) and  ylm_rot f32[ndirs][n_sh_shell] = AUX['Ylm_rot'];
+ * out f32[n_atoms][ndirs][nS] = what resample_kernel returns for rotate_kernel's output.                          */
+int amx_lut_rotate_resample(amx_ctx *ctx, const float *zonal, int n_atoms, const float *ylm_rot, int ndirs,
+                            int n_sh_shell, int n_shells, const float *ylm_out, const int32_t *idx_out, int n_out,
+                            int nS, float *out);
+
 /* ---- measurement hooks (bench.py): HIP-event time of the solver kernels of the LAST
  * *_fit_device call on this ctx, measured on the stream they were launched on.
  * which: 0 = all kernels of the call, 1..3 = solver stage kernels (NODDI: NNLS-1, LASSO,

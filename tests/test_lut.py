@@ -21,7 +21,8 @@ def pipeline():
     lm_iso = lut.rotate_kernel(Kz['iso'].astype(np.float64), aux, idx_in, idx_o, True, len(lut_dirs))
     idx_out, ylm_out = lut.aux_structures_resample(scheme, 12)
     direct = S.noddi_kernels(scheme, lut_dirs, IC_VFs=vfs, IC_ODs=ods)
-    return dict(scheme=scheme, lut_dirs=lut_dirs, lm=lm, lm_iso=lm_iso, idx_out=idx_out, ylm_out=ylm_out, direct=direct)
+    return dict(scheme=scheme, lut_dirs=lut_dirs, lm=lm, lm_iso=lm_iso, idx_out=idx_out, ylm_out=ylm_out, direct=direct,
+                aux=aux, idx_in=idx_in, idx_o=idx_o, Kz=Kz)
 
 
 def test_sh_basis_is_orthonormal_and_ordered():
@@ -67,6 +68,21 @@ def test_resample_kernels_gemm_vs_numpy(pipeline):
         lut.resample_kernel(p['lm'][0][:5], sc.nS, p['idx_out'], p['ylm_out'], False, n_dirs)
     with pytest.raises(ValueError):
         lut.resample_kernels(p['lm'][..., :50], sc.nS, p['idx_out'], p['ylm_out'])
+
+
+@pytest.mark.gpu
+def test_rotate_and_resample_fused(pipeline):
+    """rotate_kernel + resample_kernel in ONE GEMM whose left operand (zonal factor x basis value) is formed in registers:
+    equal to the two-step path up to float32 rounding of the rotated coefficients"""
+    p = pipeline
+    sc = p['scheme']
+    Ks = [p['Kz']['wm'][a, 0].astype(np.float64) for a in range(p['Kz']['wm'].shape[0])]
+    got = lut.rotate_and_resample(Ks, p['aux'], p['idx_in'], p['idx_o'], sc.nS, p['idx_out'], p['ylm_out'])
+    lm = np.stack([lut.rotate_kernel(K, p['aux'], p['idx_in'], p['idx_o'], False, got.shape[1]) for K in Ks])
+    ref = lut.resample_kernels(lm, sc.nS, p['idx_out'], p['ylm_out'])
+    assert got.shape == ref.shape and got.dtype == np.float32
+    assert np.abs(got - ref).max() < 2e-5
+    assert np.array_equal(got[..., sc.b0_idx], np.ones_like(got[..., sc.b0_idx]))
 
 
 @pytest.mark.gpu
