@@ -69,8 +69,8 @@ int enqueue_bucketing(amx_ctx *ctx, const amx_lut *lut, const double *d_dirs, in
 __global__ void k_fold_counters(const int *misc, int *status)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        status[ST_RERUN] += misc[4] + misc[5] + misc[6];
-        status[ST_OVERFLOW] += misc[12];
+        atomicAdd(&status[ST_RERUN], misc[4] + misc[5] + misc[6]);      // (two batches may fold concurrently: fit_host)
+        atomicAdd(&status[ST_OVERFLOW], misc[12]);
     }
 }
 
@@ -153,10 +153,11 @@ void amx_ctx_destroy(amx_ctx *ctx)
                       &ctx->misc, &ctx->xiso, &ctx->supp, &ctx->ovf, &ctx->hy, &ctx->hdirs, &ctx->hest,
                       &ctx->hrmse, &ctx->hnrmse, &ctx->hextra, &ctx->hy32};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
+    for (DevBuf &b : ctx->alt) if (b.p) hipFree(b.p);
     if (ctx->status_d) hipFree(ctx->status_d);
     if (ctx->status_h) hipHostFree(ctx->status_h);
     for (int k = 0; k < kEv; k++) (void)hipEventDestroy(ctx->ev[k]);
-    if (ctx->hs) { (void)hipStreamDestroy(ctx->hs); (void)hipEventDestroy(ctx->hev[0]); (void)hipEventDestroy(ctx->hev[1]); }
+    if (ctx->hs) { (void)hipStreamDestroy(ctx->hs); (void)hipStreamDestroy(ctx->hs2); for (hipEvent_t e : ctx->hev) (void)hipEventDestroy(e); }
     delete ctx;
 }
 
@@ -614,12 +615,15 @@ int amx_czb_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, cons
 
 // Host buffers in, host buffers out, for all three models and both signal dtypes (float64 = evaluation.y of the
 // reference; float32 = the dtype the image has before core.py:451 casts it -- lossless, half the PCIe bytes).
-// Large inputs travel in batches of kHostBatch voxels: while the GPU fits batch c (on a non-blocking stream of the
-// context) the blocking host-to-device copy of batch c+1 is already running, so the PCIe time hides behind the solver
-// instead of preceding it.  Two signal buffers; results leave in one copy per output at the end.  The progress
+// Large inputs travel in batches: while the GPU fits batches c-1 and c-2 (on the two non-blocking streams of the
+// context, each with its own workspace set) the blocking host-to-device copy of batch c is already running, so the PCIe
+// time hides behind the solver instead of preceding it.  Three signal buffers; results leave in one copy per output at
+// the end.  The progress
 // callback (amx_set_progress; models.pyx:28-43, 981 keep a per-thread counter for the same purpose) is called as
 // batches complete.
-constexpr int64_t kHostBatch = 262144;
+// (largest batch; measured on 1 M NODDI voxels: 131072 -> 38.3 ms, 262144 -> 37.2 ms, 393216 -> 36.3 ms per call)
+static int64_t host_batch() { const char *e = getenv("AMX_HOST_BATCH"); const long v = e ? atol(e) : 0; return v >= 4096 ? (int64_t)v : 393216; }
+constexpr int64_t kPipelineFrom = 524288;      // smaller inputs go in one shot
 
 struct HostOut { void *dst; DevBuf *buf; size_t cols; bool on; };
 
@@ -628,9 +632,11 @@ template <typename T, typename Enqueue>
 static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox, int nS, HostOut (&outs)[4], Enqueue enqueue)
 {
     int rc;
+    const int64_t kHostBatch = host_batch();
     constexpr bool kF32 = sizeof(T) == 4;
-    const bool pipelined = n_vox >= 2 * kHostBatch && !getenv("AMX_HOST_ONE_SHOT");
-    const int64_t cap = pipelined ? 2 * kHostBatch : n_vox;
+    const bool pipelined = n_vox >= kPipelineFrom && !getenv("AMX_HOST_ONE_SHOT");
+    constexpr int kBufs = 3;                      // staging buffers: batch c uploads while c-1 and c-2 are being solved
+    const int64_t cap = pipelined ? kBufs * kHostBatch : n_vox;
     if ((rc = ensure(ctx, ctx->hy, (size_t)cap * nS * sizeof(double)))) return rc;
     if (kF32 && (rc = ensure(ctx, ctx->hy32, (size_t)cap * nS * sizeof(float)))) return rc;
     if (dirs && (rc = ensure(ctx, ctx->hdirs, (size_t)cap * 3 * sizeof(double)))) return rc;
@@ -638,26 +644,29 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
         if (o.on && (rc = ensure(ctx, *o.buf, (size_t)n_vox * o.cols * sizeof(double)))) return rc;
     if (!ctx->hs) {
         HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->hs, hipStreamNonBlocking));
-        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->hev[0], hipEventDisableTiming));
-        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->hev[1], hipEventDisableTiming));
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->hs2, hipStreamNonBlocking));
+        for (hipEvent_t &e : ctx->hev) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     HIPCHK(ctx, hipStreamSynchronize(nullptr));                      // earlier default-stream work on these buffers
     const bool was_profiling = ctx->profiling;
     if (pipelined) ctx->profiling = false;
+    // Batch c runs on stream c & 1 with workspace set c & 1: the kernels of consecutive batches overlap, so the idle tail
+    // of every launch (and the one-wavefront re-run kernels) is filled by the other batch instead of adding up six times.
+    const bool two_streams = pipelined && !getenv("AMX_HOST_ONE_STREAM");
     hipStream_t s = pipelined ? ctx->hs : nullptr;
-    int64_t off = 0, done_before[2] = {0, 0};         // voxels complete once the event of that buffer has fired
+    int64_t off = 0, done_before[kBufs] = {0, 0, 0};         // voxels complete once the event of that buffer has fired
     for (int c = 0; off < n_vox; c++) {
-        // the last batch absorbs a short remainder
-        // (the first copy is the only one the solver cannot hide: the batches start small and double up to kHostBatch)
-        const int64_t ramp = kHostBatch >> (c < 3 ? 3 - c : 0);
-        const int64_t cnt = !pipelined ? n_vox : ((n_vox - off < ramp + ramp / 2) ? n_vox - off : ramp);
-        int b = c & 1;
-        if (pipelined && c >= 2) {
-            HIPCHK(ctx, hipEventSynchronize(ctx->hev[b]));           // batch c-2 has released this buffer
-            progress(ctx, done_before[b], n_vox);                    // batches 0 .. c-2 are complete
+        // the first copy is the only one the solver cannot hide: three short doubling batches, then the rest in equal
+        // batches of at most kHostBatch voxels
+        const int64_t rem = n_vox - off, ramp = (int64_t)32768 << (c < 3 ? c : 3);
+        const int64_t parts = (rem + kHostBatch - 1) / kHostBatch;
+        const int64_t cnt = !pipelined ? n_vox : ((c < 3 && rem > 4 * ramp) ? ramp : (rem + parts - 1) / parts);
+        int b = c % kBufs;
+        if (pipelined && c >= kBufs) {
+            HIPCHK(ctx, hipEventSynchronize(ctx->hev[b]));           // batch c-3 has released this buffer
+            progress(ctx, done_before[b], n_vox);                    // batches 0 .. c-3 are complete
         }
-        // (a remainder-absorbing last batch may exceed kHostBatch: it then uses both halves, which are free by then)
-        if (cnt > kHostBatch && pipelined) { HIPCHK(ctx, hipStreamSynchronize(ctx->hs)); b = 0; }
+        if (two_streams) { s = (c & 1) ? ctx->hs2 : ctx->hs; if (c) ctx->swap_work(); }
         double *yb = (double *)ctx->hy.p + (size_t)b * kHostBatch * nS;
         double *db = dirs ? (double *)ctx->hdirs.p + (size_t)b * kHostBatch * 3 : nullptr;
         if (kF32) {
@@ -670,7 +679,10 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
         }
         if (dirs) HIPCHK(ctx, hipMemcpy(db, dirs + (size_t)off * 3, (size_t)cnt * 3 * sizeof(double), hipMemcpyHostToDevice));
         // the copy above took a while: has the previous batch finished meanwhile? (a query, never a wait)
-        if (pipelined && c >= 1 && ctx->progress && hipEventQuery(ctx->hev[(c - 1) & 1]) == hipSuccess) progress(ctx, done_before[(c - 1) & 1], n_vox);
+        // (batches c-1 and c-2 run on different streams: both must have fired before batch c-1's count is reported)
+        if (pipelined && c >= 1 && ctx->progress && hipEventQuery(ctx->hev[(c - 1) % kBufs]) == hipSuccess &&
+            (c < 2 || hipEventQuery(ctx->hev[(c - 2) % kBufs]) == hipSuccess))
+            progress(ctx, done_before[(c - 1) % kBufs], n_vox);
         ctx->vox_base = off;
         rc = enqueue(yb, db, cnt, (double *)outs[0].buf->p + (size_t)off * outs[0].cols,
                      outs[1].on ? (double *)outs[1].buf->p + off : nullptr, outs[2].on ? (double *)outs[2].buf->p + off : nullptr,
@@ -678,9 +690,10 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
         ctx->vox_base = 0;
         if (rc) { ctx->profiling = was_profiling; return rc; }
         off += cnt;
-        if (pipelined) { HIPCHK(ctx, hipEventRecord(ctx->hev[b], ctx->hs)); done_before[b] = off; }
+        if (pipelined) { HIPCHK(ctx, hipEventRecord(ctx->hev[b], s)); done_before[b] = off; }
     }
     ctx->profiling = was_profiling;
+    if (two_streams) { HIPCHK(ctx, hipStreamSynchronize(s == ctx->hs ? ctx->hs2 : ctx->hs)); }
     rc = amx_sync_status(ctx, s);
     if (rc) return rc;
     for (HostOut &o : outs)

@@ -38,8 +38,16 @@ struct amx_ctx {
     void (*progress)(int64_t, int64_t, void *) = nullptr;   // amx_set_progress
     void *progress_user = nullptr;
     DevBuf hy32;                   // float32 signals of the *_fit_f32 entry points
-    hipStream_t hs = nullptr;      // non-blocking compute stream of the chunked host entry points
-    hipEvent_t hev[2] = {nullptr, nullptr};
+    hipStream_t hs = nullptr;      // non-blocking compute streams of the chunked host entry points: batches alternate
+    hipStream_t hs2 = nullptr;     // between the two, so the tail of one batch's kernels is filled by the next batch's
+    hipEvent_t hev[3] = {nullptr, nullptr, nullptr};
+    // second workspace set for the batch in flight on the other stream (swap_work exchanges it with the named buffers)
+    DevBuf alt[10];
+    void swap_work()
+    {
+        DevBuf *named[10] = {&lutidx, &perm, &counts, &dir_start, &cursor, &chunks, &misc, &xiso, &supp, &ovf};
+        for (int i = 0; i < 10; i++) { DevBuf t = *named[i]; *named[i] = alt[i]; alt[i] = t; }
+    }
 };
 
 struct amx_lut {
