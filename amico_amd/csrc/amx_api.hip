@@ -150,7 +150,7 @@ void amx_ctx_destroy(amx_ctx *ctx)
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
     DevBuf *bufs[] = {&ctx->lutidx, &ctx->perm, &ctx->counts, &ctx->dir_start, &ctx->cursor, &ctx->chunks,
-                      &ctx->misc, &ctx->xiso, &ctx->supp, &ctx->ovf, &ctx->hy, &ctx->hdirs, &ctx->hest,
+                      &ctx->misc, &ctx->xiso, &ctx->supp, &ctx->ovf, &ctx->cproj, &ctx->hy, &ctx->hdirs, &ctx->hest,
                       &ctx->hrmse, &ctx->hnrmse, &ctx->hextra, &ctx->hy32};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     for (DevBuf &b : ctx->alt) if (b.p) hipFree(b.p);
@@ -168,8 +168,9 @@ void amx_lut_destroy(amx_lut *lut)
     if (!lut) return;
     if (lut->ctx) hipSetDevice(lut->ctx->device);
     void *ps[] = {lut->gram, lut->gram_dwi, lut->tiles, lut->htable, lut->rowdwi, lut->colscale, lut->icvf, lut->kappa,
-                  lut->norms, lut->Rs, lut->d_in, lut->d_isos};
+                  lut->norms, lut->Rs, lut->d_in, lut->d_isos, lut->fw_prep};
     for (void *p : ps) if (p) hipFree(p);
+    if (lut->fw_ready) (void)hipEventDestroy(lut->fw_ready);
     delete lut;
 }
 
@@ -522,6 +523,7 @@ int amx_freewater_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y
     a.est = d_estimates; a.rmse = (flags & AMX_F_RMSE) ? d_rmse : nullptr;
     a.nrmse = (flags & AMX_F_NRMSE) ? d_nrmse : nullptr; a.ycorr = (flags & AMX_F_CORRECTED) ? d_ycorr : nullptr;
     HIPCHK(ctx, hipMemsetAsync(d_estimates, 0, (size_t)n_vox * a.n_maps * sizeof(double), s));
+    if (refill && (rc = amx_fw_prepare(ctx, lut, a, s))) return rc;
     rc = amx_launch_fw(ctx, a, pl, s);
     hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, s, (const int *)ctx->misc.p, ctx->status_d);
     rec(ctx, 1, s);

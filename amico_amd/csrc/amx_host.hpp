@@ -25,7 +25,7 @@ struct amx_ctx {
     int n_cu = 256;                // compute units of the device (persistent-grid launches)
     std::string err;
     // stream-ordered workspace (grow-only)
-    DevBuf lutidx, perm, counts, dir_start, cursor, chunks, misc, xiso, supp, ovf;
+    DevBuf lutidx, perm, counts, dir_start, cursor, chunks, misc, xiso, supp, ovf, cproj;
     DevBuf hy, hdirs, hest, hrmse, hnrmse, hextra;   // staging for the host-pointer entry points
     int *status_d = nullptr;       // ST_WORDS ints
     int *status_h = nullptr;       // pinned mirror (+16 words: copy of the misc counters)
@@ -42,11 +42,11 @@ struct amx_ctx {
     hipStream_t hs2 = nullptr;     // between the two, so the tail of one batch's kernels is filled by the next batch's
     hipEvent_t hev[3] = {nullptr, nullptr, nullptr};
     // second workspace set for the batch in flight on the other stream (swap_work exchanges it with the named buffers)
-    DevBuf alt[10];
+    DevBuf alt[11];
     void swap_work()
     {
-        DevBuf *named[10] = {&lutidx, &perm, &counts, &dir_start, &cursor, &chunks, &misc, &xiso, &supp, &ovf};
-        for (int i = 0; i < 10; i++) { DevBuf t = *named[i]; *named[i] = alt[i]; alt[i] = t; }
+        DevBuf *named[11] = {&lutidx, &perm, &counts, &dir_start, &cursor, &chunks, &misc, &xiso, &supp, &ovf, &cproj};
+        for (int i = 0; i < 11; i++) { DevBuf t = *named[i]; *named[i] = alt[i]; alt[i] = t; }
     }
 };
 
@@ -65,6 +65,12 @@ struct amx_lut {
     double *colscale = nullptr;
     float *icvf = nullptr, *kappa = nullptr;
     double *norms = nullptr, *Rs = nullptr, *d_in = nullptr, *d_isos = nullptr;
+    // FreeWater, per orientation and for one lambda2 (k_fw_orient_prep, rebuilt when lambda2 changes): fp64 dictionary
+    // A [nS][NP], H^-1 [N][NP], H = A'A + lambda2 I [N][N]
+    mutable double *fw_prep = nullptr;
+    mutable double fw_lam2 = -1.0;
+    mutable int fw_N = 0;
+    mutable hipEvent_t fw_ready = nullptr;
 };
 
 // principal-direction estimator of one acquisition scheme (amx_signal.hip)
@@ -154,6 +160,7 @@ int amx_launch_sandi(amx_ctx *ctx, amx::SandiArgs &a, const Plan &pl, hipStream_
 int amx_launch_czb(amx_ctx *ctx, amx::CzbArgs &a, const Plan &pl, hipStream_t s);
 // lane-per-voxel variants for dictionaries of <= 16 atoms (amx_small.hip)
 int amx_launch_fw_small(amx_ctx *ctx, amx::FwArgs &a, const Plan &pl, hipStream_t s);
+int amx_fw_prepare(amx_ctx *ctx, const amx_lut *lut, amx::FwArgs &a, hipStream_t s);   // before amx_launch_fw when the refill path runs
 int amx_launch_sandi_small(amx_ctx *ctx, amx::SandiArgs &a, const Plan &pl, hipStream_t s);
 // NODDI NNLS stages, two voxels per wavefront (amx_pair.hpp; protocols that fit 32-lane halves: 4 volumes, 5 atoms per
 // lane).  OPT-IN (AMX_PAIR=1): certified by the same KKT tests, but measured SLOWER than the wavefront-per-voxel

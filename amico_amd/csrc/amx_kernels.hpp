@@ -279,6 +279,10 @@ struct FwArgs {
     FitCommon c;
     int n_perp, n_iso, is_mouse, n_maps;
     double *est, *rmse, *nrmse, *ycorr;
+    double *cproj;                 // k_fw_project -> k_freewater_refill: c = A'y - lambda1 [N][ldC] (bucket order)
+    const double *prep;            // k_fw_orient_prep: per orientation A | H^-1 | H (amx_lut::fw_prep)
+    unsigned *p0;                  // passive set after the first block removal (bit j: atom j), bucket order
+    int ldC;
 };
 
 template <int NR, int NQ, int MAXP>

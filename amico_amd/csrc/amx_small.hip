@@ -682,8 +682,172 @@ __global__ void __launch_bounds__(256, AMX_ROWS_OCC) k_sandi_rows(const SandiArg
 //     maps and takes the next c vector from the buffer at once -- the wavefront refills the buffer (phase 1) when it
 //     runs dry.  The same per-voxel arithmetic as lane_nnqp, in the same order.
 // Chunks of amx_refill_chunk() voxels of one orientation per workgroup (the buffer needs a pool to draw from).
+#ifdef AMX_FW_PHASES
+// diagnosis builds only (tools/fw_phases.py): s_memtime split of the refill kernel, summed over wavefronts
+__device__ unsigned long long g_fw_ph[8], g_fw_pp[8];
+#define FWPH_T() __builtin_readcyclecounter()
+#define FWPH_ADD(k, t0) ph[k] += __builtin_readcyclecounter() - (t0)
+#else
+#define FWPH_T() 0ull
+#define FWPH_ADD(k, t0) (void)(t0)
+#endif
 constexpr int kTileRows = 16;          // signal values per voxel and transposition pass
 constexpr int kTileLd = 65;            // odd leading dimension (doubles) of the transposition tile [row][voxel]
+
+// per orientation, once per (dictionary, lambda2): the fp64 dictionary A [nS][NP], H^-1 [N][NP] and H = A'A + lambda2 I
+// [N][N] (NP = N rounded up to even).  One wavefront per orientation.
+template <int N> constexpr int fw_prep_words(int nS) { return nS * ((N + 1) & ~1) + N * ((N + 1) & ~1) + N * N; }
+
+template <int N>
+__global__ void __launch_bounds__(64) k_fw_orient_prep(const float *__restrict__ tiles, int tile_stride, int ldA, int nS, int n_atoms,
+                                                       double lam2, double *__restrict__ prep)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_o[];
+    constexpr int NP = (N + 1) & ~1;
+    double *Ad = reinterpret_cast<double *>(smem_o);
+    double *Hs = Ad + (size_t)nS * NP;
+    const float *tile = tiles + (size_t)blockIdx.x * tile_stride;
+    double *out = prep + (size_t)blockIdx.x * fw_prep_words<N>(nS);
+    double *Ag = out, *Ig = out + (size_t)nS * NP, *Hg = Ig + N * NP;
+    for (int e = threadIdx.x; e < nS * NP; e += blockDim.x) {
+        const int i = e / NP, j = e % NP;
+        const double v = (j < n_atoms) ? (double)tile[i * ldA + j] : 0.0;
+        Ad[e] = v; Ag[e] = v;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < N * N; e += blockDim.x) {
+        const int j = e / N, k = e % N;
+        double acc = (j == k) ? ((j < n_atoms) ? lam2 : 1.0) : 0.0;
+        if (j < n_atoms && k < n_atoms)
+            for (int i = 0; i < nS; i++) acc += Ad[i * NP + j] * Ad[i * NP + k];
+        Hs[e] = acc; Hg[e] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < N) {                       // row r of the (symmetric) inverse: H z = e_r
+        const int r = threadIdx.x;
+        double rhs[N], z[N];
+#pragma unroll
+        for (int j = 0; j < N; j++) rhs[j] = (j == r) ? 1.0 : 0.0;
+        lane_solve<N>(Hs, rhs, (1u << N) - 1u, z);
+#pragma unroll
+        for (int j = 0; j < N; j++) Ig[r * NP + j] = z[j];
+        if (NP > N) Ig[r * NP + N] = 0.0;
+    }
+}
+
+// phase 1 as its own launch: c = A'y - lambda1 for every voxel, in bucket order, [N][ldC] (atom-major: coalesced for the
+// lanes that write it here and for the lanes that draw from it in the solver), plus H = A'A + lambda2 I of every chunk's
+// orientation.  A streaming kernel (520 B in, 92 B out per voxel) at four wavefronts per SIMD: the signal loads of one
+// wavefront overlap the contractions of the others, which the solver's two wavefronts per SIMD could not do.
+//
+// It also takes the first step of the warm-started active-set method off the solver's hands: the unconstrained optimum on
+// the full set is z0 = H^-1 c, and all the solver needs from it is which coefficients came out positive -- the passive set
+// after the first block removal, p0 [ldC] (11 bits per voxel).  H^-1 is tabulated per orientation; the explicit inverse
+// (cond(H) ~ 1e5 with the ridge) is good enough for a starting guess, the solver's answer does not depend on it.
+#ifndef AMX_FW_PROJ_OCC
+#define AMX_FW_PROJ_OCC 4
+#endif
+template <int N>
+__global__ void __launch_bounds__(256, AMX_FW_PROJ_OCC) k_fw_project(const FwArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_p[];
+    const int cid = xcd_chunk((int)blockIdx.x, *a.c.n_chunks);
+    if (cid < 0) return;
+    const Chunk ck = a.c.chunks[cid];
+    const int nS = a.c.nS, n_atoms = a.c.n_atoms;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
+    constexpr int NP = (N + 1) & ~1;          // row length of Ad / Hi: even, so that a row is read with 16-byte LDS loads
+    // LDS: Ad f64 [nS][NP] | Hi f64 [N][NP] | per wavefront: Tt [kTileRows][kTileLd], Vb int[64]
+    double *Ad = reinterpret_cast<double *>(smem_p);
+    double *Hi = Ad + (size_t)nS * NP;
+    constexpr int kWaveWords = kTileRows * kTileLd + 32;
+    double *Tt = Hi + N * NP + (size_t)wave * kWaveWords;
+    int *Vb = reinterpret_cast<int *>(Tt + kTileRows * kTileLd);
+    {
+        const double *src = a.prep + (size_t)ck.dir * fw_prep_words<N>(nS);
+        for (int e = threadIdx.x; e < (nS + N) * NP; e += blockDim.x) Ad[e] = src[e];                    // A then H^-1
+        __syncthreads();
+    }
+    const int n_batches = (ck.count + 63) >> 6;
+    const int seg = lane & 7, grp = lane >> 3;          // 8 lanes x 16 B = one 16-value segment of a row
+#ifdef AMX_FW_PHASES
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_all = FWPH_T();
+#endif
+    for (int b = wave; b < n_batches; b += nw) {
+        unsigned long long t0 = FWPH_T();
+        const int cnt = min(64, ck.count - (b << 6));
+        const int pos = ck.start + (b << 6) + lane;
+        Vb[lane] = (lane < cnt) ? a.c.perm[pos] : -1;
+        int vrow[8];                                       // the eight voxels this lane loads segments of
+#pragma unroll
+        for (int it = 0; it < 8; it++) vrow[it] = Vb[it * 8 + grp];
+        // the loads of the next 16 signal values are in flight while the current 16 are contracted
+        double yn[8][2];
+        auto issue = [&](int r0) {
+            const int rows = min(kTileRows, nS - r0);
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                double y0 = 0.0, y1 = 0.0;
+                if (vrow[it] >= 0) {
+                    const double *yp = a.c.y + (size_t)vrow[it] * nS + (r0 + 2 * seg);
+                    if (2 * seg + 1 < rows) { y0 = yp[0]; y1 = yp[1]; }       // one 16-byte load
+                    else if (2 * seg < rows) y0 = yp[0];
+                }
+                yn[it][0] = y0; yn[it][1] = y1;
+            }
+        };
+        double cn[NP];
+        bool finite = true;
+#pragma unroll
+        for (int j = 0; j < NP; j++) cn[j] = 0.0;
+        issue(0);
+        FWPH_ADD(0, t0);
+        for (int r0 = 0; r0 < nS; r0 += kTileRows) {
+            const int rows = min(kTileRows, nS - r0);
+            t0 = FWPH_T();
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                Tt[(2 * seg) * kTileLd + it * 8 + grp] = yn[it][0];
+                Tt[(2 * seg + 1) * kTileLd + it * 8 + grp] = yn[it][1];
+            }
+            FWPH_ADD(1, t0); t0 = FWPH_T();
+            if (r0 + kTileRows < nS) issue(r0 + kTileRows);
+            AMX_RELOAD();
+            for (int r = 0; r < rows; r++) {
+                const double yi = Tt[r * kTileLd + lane];
+                finite = finite && (fabs(yi) <= 1.79769313486231570e308);
+                const double *ar = Ad + (size_t)(r0 + r) * NP;
+#pragma unroll
+                for (int j = 0; j < NP; j++) cn[j] += ar[j] * yi;
+            }
+            AMX_RELOAD();
+            FWPH_ADD(2, t0);
+        }
+        t0 = FWPH_T();
+        if (lane < cnt) {
+            unsigned p0 = 0u;
+#pragma unroll
+            for (int j = 0; j < N; j++) cn[j] -= a.c.lam1;
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                a.cproj[(size_t)j * a.ldC + pos] = finite ? cn[j] : __builtin_nan("");
+                double z0 = 0.0;
+#pragma unroll
+                for (int k = 0; k < N; k++) z0 += Hi[j * NP + k] * cn[k];
+                if (j < n_atoms && z0 > 0.0) p0 |= 1u << j;
+            }
+            a.p0[pos] = p0;
+        }
+        FWPH_ADD(3, t0);
+    }
+#ifdef AMX_FW_PHASES
+    ph[7] = FWPH_T() - t_all;
+    ph[5] = (wave < n_batches) ? (n_batches - wave + nw - 1) / nw : 0;
+    if (lane == 0)
+        for (int k = 0; k < 8; k++) atomicAdd(&g_fw_pp[k], ph[k]);
+#endif
+}
 
 template <int N>
 __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
@@ -692,32 +856,20 @@ __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
     const int cid = xcd_chunk((int)blockIdx.x, *a.c.n_chunks);
     if (cid < 0) return;
     const Chunk ck = a.c.chunks[cid];
-    const int nS = a.c.nS, ldA = a.c.ldA, n_atoms = a.c.n_atoms, n_perp = a.n_perp;
+    const int n_atoms = a.c.n_atoms, n_perp = a.n_perp;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
-    // LDS: Ad f64 [nS][N] | Hs f64 [N][N] | per wavefront: Tt [kTileRows][kTileLd], Cb [N][64], Vb int[64] | ticket
-    double *Ad = reinterpret_cast<double *>(smem_r);
-    double *Hs = Ad + (size_t)nS * N;
+    // LDS: Hs f64 [N][N] | per wavefront: Cb [N][64], Vb int[64], Pb unsigned[64] | ticket
+    double *Hs = reinterpret_cast<double *>(smem_r);
     double *wbase = Hs + N * N;
-    constexpr int kWaveWords = kTileRows * kTileLd + N * 64 + 32;
-    double *Tt = wbase + (size_t)wave * kWaveWords;
-    double *Cb = Tt + kTileRows * kTileLd;
+    constexpr int kWaveWords = N * 64 + 64;
+    double *Cb = wbase + (size_t)wave * kWaveWords;
     int *Vb = reinterpret_cast<int *>(Cb + N * 64);
+    unsigned *Pb = reinterpret_cast<unsigned *>(Vb + 64);
     unsigned *ticket = reinterpret_cast<unsigned *>(wbase + (size_t)nw * kWaveWords);
     {
-        const float *tile = reinterpret_cast<const float *>(a.c.tiles) + (size_t)ck.dir * a.c.tile_stride;
-        for (int e = threadIdx.x; e < nS * N; e += blockDim.x) {
-            const int i = e / N, j = e % N;
-            Ad[e] = (j < n_atoms) ? (double)tile[i * ldA + j] : 0.0;
-        }
+        const double *hsrc = a.prep + (size_t)ck.dir * fw_prep_words<N>(a.c.nS) + (a.c.nS + N) * ((N + 1) & ~1);
+        for (int e = threadIdx.x; e < N * N; e += blockDim.x) Hs[e] = hsrc[e];
         if (threadIdx.x == 0) *ticket = 0u;
-        __syncthreads();
-        for (int e = threadIdx.x; e < N * N; e += blockDim.x) {
-            const int j = e / N, k = e % N;
-            double acc = (j == k) ? ((j < n_atoms) ? a.c.lam2 : 1.0) : 0.0;
-            if (j < n_atoms && k < n_atoms)
-                for (int i = 0; i < nS; i++) acc += Ad[i * N + j] * Ad[i * N + k];
-            Hs[e] = acc;
-        }
         __syncthreads();
     }
     const double tol = 1e-12, inf = __builtin_huge_val();
@@ -726,7 +878,7 @@ __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
     const bool warm0 = amx_warm_start(a.c.lam2, a.c.flags);
     const unsigned pfull = (1u << n_atoms) - 1u;
     bool active = false, warm = false;       // warm: still in the block-removal phase that starts from the full set
-    int vox = 0, st = 0, its = 0;            // st: 0 = pick an atom first, 1 = passive set changed, solve
+    int vox = 0, its = 0;
     unsigned P = 0u;
     double c[N], x[N];
 #pragma unroll
@@ -734,8 +886,13 @@ __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
     int buf_pos = 0, buf_cnt = 0;            // wave-uniform: next entry / entries left in Cb
     bool more = true;                        // wave-uniform: the chunk may still have batches
 
+#ifdef AMX_FW_PHASES
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_all = FWPH_T();
+#endif
     for (int trip = 0; trip < (1 << 22); ++trip) {
         const unsigned long long freem = __ballot(!active);
+        unsigned long long t0 = FWPH_T();
         // ------------------------------------------------------------ phase 1: refill the wavefront's buffer
         if (freem != 0ull && buf_cnt == 0 && more) {
             const int b = next_ticket(ticket, lane);
@@ -743,50 +900,22 @@ __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
                 more = false;
             } else {
                 const int cnt = min(64, ck.count - (b << 6));
-                const int myvox = (lane < cnt) ? a.c.perm[ck.start + (b << 6) + lane] : -1;
-                Vb[lane] = myvox;
-                double cn[N];
-                bool finite = true;
+                const int pos = ck.start + (b << 6) + lane;
+                Vb[lane] = (lane < cnt) ? a.c.perm[pos] : -1;
+                Pb[lane] = (lane < cnt) ? a.p0[pos] : 0u;
 #pragma unroll
-                for (int j = 0; j < N; j++) cn[j] = 0.0;
-                const int seg = lane & 7, grp = lane >> 3;      // 8 lanes x 16 B = one 16-value segment of a row
-                for (int r0 = 0; r0 < nS; r0 += kTileRows) {
-                    const int rows = min(kTileRows, nS - r0);
-#pragma unroll
-                    for (int it = 0; it < 8; it++) {
-                        const int e = it * 8 + grp;
-                        const int ve = Vb[e];
-                        const int i = 2 * seg;
-                        double y0 = 0.0, y1 = 0.0;
-                        if (ve >= 0) {
-                            const double *yp = a.c.y + (size_t)ve * nS + r0 + i;
-                            if (i + 1 < rows) { y0 = yp[0]; y1 = yp[1]; }       // one 16-byte load
-                            else if (i < rows) y0 = yp[0];
-                        }
-                        Tt[i * kTileLd + e] = y0;
-                        Tt[(i + 1) * kTileLd + e] = y1;
-                    }
-                    AMX_RELOAD();
-                    for (int r = 0; r < rows; r++) {
-                        const double yi = Tt[r * kTileLd + lane];
-                        finite = finite && (fabs(yi) <= 1.79769313486231570e308);
-                        const double *ar = Ad + (size_t)(r0 + r) * N;
-#pragma unroll
-                        for (int j = 0; j < N; j++) cn[j] += ar[j] * yi;
-                    }
-                    AMX_RELOAD();
-                }
-#pragma unroll
-                for (int j = 0; j < N; j++) Cb[j * 64 + lane] = finite ? cn[j] - a.c.lam1 : __builtin_nan("");
+                for (int j = 0; j < N; j++) Cb[j * 64 + lane] = (lane < cnt) ? a.cproj[(size_t)j * a.ldC + pos] : 0.0;
                 buf_pos = 0; buf_cnt = cnt;
             }
         }
+        FWPH_ADD(0, t0); t0 = FWPH_T();
         // ------------------------------------------------------------ free lanes take the next voxels of the buffer
         if (freem != 0ull && buf_cnt > 0) {
             const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(freem >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)freem, 0u));
             const bool take = !active && rank < buf_cnt;
             const int e = take ? buf_pos + rank : 0;
             const int nv = Vb[e];
+            const unsigned np0 = Pb[e];
 #pragma unroll
             for (int j = 0; j < N; j++) {
                 const double cj = Cb[j * 64 + e];
@@ -794,38 +923,29 @@ __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
                 x[j] = take ? 0.0 : x[j];
             }
             // cold: empty passive set, pick an atom first; warm: all atoms, solve first (see lane_nnqp_rows)
-            if (take) { active = true; vox = nv; P = warm0 ? pfull : 0u; st = warm0 ? 1 : 0; its = 0; warm = warm0; }
+            // warm: the full-set solve and the first block removal happened in k_fw_project (p0: the atoms that stayed)
+            if (take) { active = true; vox = nv; P = warm0 ? np0 : 0u; its = warm0 ? 1 : 0; warm = warm0 && np0 != 0u; }
             const int taken = min(__builtin_popcountll(freem), buf_cnt);
             buf_pos += taken; buf_cnt -= taken;
         }
+        FWPH_ADD(1, t0); t0 = FWPH_T();
         if (__ballot(active) == 0ull) {
             if (!more) break;
             continue;
         }
+#ifdef AMX_FW_PHASES
+        ph[5] += 1; ph[6] += __builtin_popcountll(__ballot(active));
+#endif
         // ------------------------------------------------------------ phase 2: one active-set step per lane
+        // One trip = solve on the passive set, then -- if the solution is feasible -- accept it and look at the dual
+        // vector at once: KKT point (done) or the next atom enters.  (A separate trip for the selection would cost the
+        // whole wavefront another pass through the solve, since some lane always needs one.)
         bool done = false;
         if (active && !(c[0] == c[0])) done = true;             // non-finite signal: NaN maps, never iterate
-        const bool pick = active && !done && st == 0;
-        if (__ballot(pick) != 0ull) {
-            AMX_RELOAD();
-            double best = -inf;
-            int t = -1;
-#pragma unroll
-            for (int j = 0; j < N; j++) {
-                double g = c[j];
-#pragma unroll
-                for (int k = 0; k < N; k++) g -= Hs[j * N + k] * x[k];
-                if (!((P >> j) & 1u) && g > best) { best = g; t = j; }
-            }
-            if (pick) {
-                if (!(best > tol) || its > 3 * N + 8) done = true;      // KKT point (or the iteration cap of lane_nnqp)
-                else { P |= 1u << t; st = 1; its++; }
-            }
-        }
-        const bool slv = active && !done;                         // st == 1 for all of them now
-        if (__ballot(slv) != 0ull) {
+        const bool slv = active && !done;
+        {
             double z[N];
-            lane_solve<N>(Hs, c, P, z);
+            lane_solve<N>(Hs, c, P, z);                           // (an empty passive set gives z = 0: feasible)
             bool feasible = true;
 #pragma unroll
             for (int j = 0; j < N; j++)
@@ -847,7 +967,7 @@ __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
                     for (int j = 0; j < N; j++)
                         if (((P >> j) & 1u) && !(z[j] > 0.0)) P &= ~(1u << j);
                     its++;
-                    if (P == 0u) { st = 0; warm = false; }
+                    if (P == 0u) warm = false;
                 } else if (slv && !feasible) {
 #pragma unroll
                     for (int j = 0; j < N; j++) {
@@ -857,16 +977,34 @@ __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
                         }
                     }
                     its++;
-                    st = (P == 0u) ? 0 : 1;
                     if (its > 4 * N + 16) done = true;
                 }
             }
-            if (slv && feasible) {
+            const bool pick = slv && feasible;
+            FWPH_ADD(2, t0); t0 = FWPH_T();
+            if (pick) {
 #pragma unroll
                 for (int j = 0; j < N; j++) x[j] = ((P >> j) & 1u) ? z[j] : 0.0;
-                st = 0; warm = false;
+                warm = false;
+            }
+            if (__ballot(pick) != 0ull) {
+                AMX_RELOAD();
+                double best = -inf;
+                int t = -1;
+#pragma unroll
+                for (int j = 0; j < N; j++) {
+                    double g = c[j];
+#pragma unroll
+                    for (int k = 0; k < N; k++) g -= Hs[j * N + k] * x[k];
+                    if (!((P >> j) & 1u) && g > best) { best = g; t = j; }
+                }
+                if (pick) {
+                    if (!(best > tol) || its > 3 * N + 8) done = true;      // KKT point (or the iteration cap of lane_nnqp)
+                    else { P |= 1u << t; its++; }
+                }
             }
         }
+        FWPH_ADD(3, t0); t0 = FWPH_T();
         // ------------------------------------------------------------ finished voxels: maps (models.pyx:1241-1256)
         if (__ballot(done) != 0ull) {
             if (done) {
@@ -896,12 +1034,20 @@ __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
                 active = false;
             }
         }
+        FWPH_ADD(4, t0);
     }
+#ifdef AMX_FW_PHASES
+    ph[7] = FWPH_T() - t_all;
+    if (lane == 0)
+        for (int k = 0; k < 8; k++) atomicAdd(&g_fw_ph[k], ph[k]);
+#endif
 }
 
-static size_t refill_lds_bytes(int nS, int N, int nw)
+static size_t refill_lds_bytes(int N, int nw) { return ((size_t)N * N + (size_t)nw * (N * 64 + 64)) * sizeof(double) + 16; }
+static size_t project_lds_bytes(int nS, int N, int nw)
 {
-    return ((size_t)nS * N + (size_t)N * N + (size_t)nw * (kTileRows * kTileLd + N * 64 + 32)) * sizeof(double) + 16;
+    const int NP = (N + 1) & ~1;
+    return ((size_t)(nS + N) * NP + (size_t)nw * (kTileRows * kTileLd + 32)) * sizeof(double);
 }
 
 template <typename Args, typename K>
@@ -921,18 +1067,60 @@ int launch_lane(amx_ctx *ctx, Args &a, const Plan &pl, hipStream_t s, K kern, si
 
 }  // namespace
 
-template <typename K>
-static int launch_refill(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s, K kern, int N)
+template <typename KP, typename K>
+static int launch_refill(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s, KP proj, K kern, int N)
 {
-    const size_t lds = refill_lds_bytes(a.c.nS, N, 4);
     int rc;
-    if ((rc = set_lds(ctx, kern, lds))) return rc;
+    // workspace of the projection: c [N][ldC], p0 [ldC]
+    a.ldC = (int)((pl.n + 63) & ~(size_t)63);
+    const size_t cbytes = (size_t)N * a.ldC * sizeof(double);
+    if ((rc = amx_ensure(ctx, ctx->cproj, cbytes + (size_t)a.ldC * sizeof(unsigned)))) return rc;
+    a.cproj = (double *)ctx->cproj.p;
+    a.p0 = (unsigned *)((char *)ctx->cproj.p + cbytes);
+    const size_t lds_p = project_lds_bytes(a.c.nS, N, 4), lds = refill_lds_bytes(N, 4);
+    if ((rc = set_lds(ctx, proj, lds_p)) || (rc = set_lds(ctx, kern, lds))) return rc;
+    const dim3 grid(((pl.max_chunks + 7) / 8) * 8);
     rec(ctx, 2, s);
-    hipLaunchKernelGGL(kern, dim3(((pl.max_chunks + 7) / 8) * 8), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(proj, grid, dim3(256), lds_p, s, a);
+    AMX_TRACE(ctx, s, "A'y of every voxel");
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
     AMX_TRACE(ctx, s, "lane-per-voxel solver with refill");
     rec(ctx, 3, s);
     HIPCHK(ctx, hipGetLastError());
     return AMX_OK;
+}
+
+template <int N>
+static int fw_prepare_n(amx_ctx *ctx, const amx_lut *lut, FwArgs &a, hipStream_t s)
+{
+    const size_t words = (size_t)fw_prep_words<N>(lut->nS);
+    if (lut->fw_lam2 != a.c.lam2 || lut->fw_N != N || !lut->fw_prep) {
+        // (a fit with the previous lambda2 may still be reading the old tables on another stream)
+        if (lut->fw_prep) HIPCHK(ctx, hipDeviceSynchronize());
+        if (!lut->fw_prep || lut->fw_N != N) {
+            if (lut->fw_prep) HIPCHK(ctx, hipFree(lut->fw_prep));
+            lut->fw_prep = nullptr;
+            HIPCHK(ctx, hipMalloc((void **)&lut->fw_prep, words * lut->ndirs * sizeof(double)));
+        }
+        if (!lut->fw_ready) HIPCHK(ctx, hipEventCreateWithFlags(&lut->fw_ready, hipEventDisableTiming));
+        const int NP = (N + 1) & ~1;
+        const size_t lds = ((size_t)lut->nS * NP + N * N) * sizeof(double);
+        int rc;
+        if ((rc = set_lds(ctx, k_fw_orient_prep<N>, lds))) return rc;
+        hipLaunchKernelGGL(k_fw_orient_prep<N>, dim3(lut->ndirs), dim3(64), lds, s, reinterpret_cast<const float *>(lut->tiles),
+                           lut->tile_stride, lut->ldA, lut->nS, lut->n_atoms, a.c.lam2, lut->fw_prep);
+        AMX_TRACE(ctx, s, "FreeWater per-orientation tables");
+        HIPCHK(ctx, hipEventRecord(lut->fw_ready, s));
+        lut->fw_lam2 = a.c.lam2; lut->fw_N = N;
+    }
+    HIPCHK(ctx, hipStreamWaitEvent(s, lut->fw_ready, 0));      // another stream may have launched the build
+    a.prep = lut->fw_prep;
+    return AMX_OK;
+}
+
+int amx_fw_prepare(amx_ctx *ctx, const amx_lut *lut, FwArgs &a, hipStream_t s)
+{
+    return lut->n_atoms <= 11 ? fw_prepare_n<11>(ctx, lut, a, s) : fw_prepare_n<12>(ctx, lut, a, s);
 }
 
 int amx_launch_fw_small(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s)
@@ -940,8 +1128,8 @@ int amx_launch_fw_small(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s)
     // compile-time dictionary sizes: the reference's defaults (11 Human, 12 Mouse) exactly, 16 otherwise
     const int n = a.c.n_atoms;
     if (amx_fw_use_refill(n, a.c.nS, a.c.flags)) {
-        if (n <= 11) return launch_refill(ctx, a, pl, s, k_freewater_refill<11>, 11);
-        return launch_refill(ctx, a, pl, s, k_freewater_refill<12>, 12);
+        if (n <= 11) return launch_refill(ctx, a, pl, s, k_fw_project<11>, k_freewater_refill<11>, 11);
+        return launch_refill(ctx, a, pl, s, k_fw_project<12>, k_freewater_refill<12>, 12);
     }
     if (n <= 11) return launch_lane(ctx, a, pl, s, k_freewater_lane<11>, sizeof(float), 11);
     if (n == 12) return launch_lane(ctx, a, pl, s, k_freewater_lane<12>, sizeof(float), 12);
@@ -967,3 +1155,17 @@ int amx_launch_sandi_small(amx_ctx *ctx, SandiArgs &a, const Plan &pl, hipStream
     if (n <= 15) return launch_lane(ctx, a, pl, s, k_sandi_lane<15>, sizeof(double), 15);
     return launch_lane(ctx, a, pl, s, k_sandi_lane<16>, sizeof(double), 16);
 }
+
+#ifdef AMX_FW_PHASES
+extern "C" int amx_debug_fw_phases(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fw_ph), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(g_fw_pp), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_fw_ph), z, sizeof z) != hipSuccess) return -1;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_fw_pp), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

@@ -1,0 +1,4 @@
+#!/bin/bash
+# FreeWater 2M: kernel time + parity tests of the small models
+python bench.py --model freewater --voxels 2000000 --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | grep -o '"value": [0-9.]*, "unit"\|"kernel_ms": [0-9.]*\|"max_abs_dmap": [0-9.e-]*' | head -4
+python -m pytest tests/test_gpu_kkt.py tests/test_gpu_parity.py tests/test_gpu_boundary.py -m gpu -x -q -k "free or Free or fw or lambda2 or float32" 2>&1 | tail -3
