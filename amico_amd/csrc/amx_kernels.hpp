@@ -283,6 +283,8 @@ struct FwArgs {
     const double *prep;            // k_fw_orient_prep: per orientation A | H^-1 | H (amx_lut::fw_prep)
     unsigned *p0;                  // passive set after the first block removal (bit j: atom j), bucket order
     int ldC;
+    int *queue;                    // global ticket of the persistent solver wavefronts (sub-chunks)
+    int sub_per_chunk;
 };
 
 template <int NR, int NQ, int MAXP>

@@ -849,63 +849,83 @@ __global__ void __launch_bounds__(256, AMX_FW_PROJ_OCC) k_fw_project(const FwArg
 #endif
 }
 
+// The solver is a set of PERSISTENT wavefronts: each draws sub-chunks of kSubChunk voxels (of one orientation) from a global
+// ticket and keeps TWO H tables in its LDS block -- lanes still iterating on voxels of the previous sub-chunk keep theirs
+// while the free lanes already take voxels of the next one, so lanes only idle at the very end of the launch (a
+// workgroup-per-chunk version lost a third of its lane-trips to the tail of every chunk).
+constexpr int kSubChunk = 256;
+
 template <int N>
 __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
-    const int cid = xcd_chunk((int)blockIdx.x, *a.c.n_chunks);
-    if (cid < 0) return;
-    const Chunk ck = a.c.chunks[cid];
     const int n_atoms = a.c.n_atoms, n_perp = a.n_perp;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
-    // LDS: Hs f64 [N][N] | per wavefront: Cb [N][64], Vb int[64], Pb unsigned[64] | ticket
-    double *Hs = reinterpret_cast<double *>(smem_r);
-    double *wbase = Hs + N * N;
-    constexpr int kWaveWords = N * 64 + 64;
-    double *Cb = wbase + (size_t)wave * kWaveWords;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // LDS per wavefront: Hs f64 [2][kSlot] | Cb [N][64] | Vb int[64] | Pb unsigned[64]
+    constexpr int kSlot = (N * N + 3) & ~1;              // 16-byte aligned slots whose banks do not coincide
+    constexpr int kWaveWords = 2 * kSlot + N * 64 + 64;
+    double *Hs = reinterpret_cast<double *>(smem_r) + (size_t)wave * kWaveWords;
+    double *Cb = Hs + 2 * kSlot;
     int *Vb = reinterpret_cast<int *>(Cb + N * 64);
     unsigned *Pb = reinterpret_cast<unsigned *>(Vb + 64);
-    unsigned *ticket = reinterpret_cast<unsigned *>(wbase + (size_t)nw * kWaveWords);
-    {
-        const double *hsrc = a.prep + (size_t)ck.dir * fw_prep_words<N>(a.c.nS) + (a.c.nS + N) * ((N + 1) & ~1);
-        for (int e = threadIdx.x; e < N * N; e += blockDim.x) Hs[e] = hsrc[e];
-        if (threadIdx.x == 0) *ticket = 0u;
-        __syncthreads();
-    }
+    const int n_chunks = *a.c.n_chunks;
+    const int n_units = n_chunks * a.sub_per_chunk;
     const double tol = 1e-12, inf = __builtin_huge_val();
-    const int n_batches = (ck.count + 63) >> 6;
     // lane state
     const bool warm0 = amx_warm_start(a.c.lam2, a.c.flags);
-    const unsigned pfull = (1u << n_atoms) - 1u;
     bool active = false, warm = false;       // warm: still in the block-removal phase that starts from the full set
     int vox = 0, its = 0;
     unsigned P = 0u;
+    const double *Hl = Hs;                   // this lane's H table (slot of the sub-chunk its voxel came from)
     double c[N], x[N];
 #pragma unroll
     for (int j = 0; j < N; j++) { c[j] = 0.0; x[j] = 0.0; }
-    int buf_pos = 0, buf_cnt = 0;            // wave-uniform: next entry / entries left in Cb
-    bool more = true;                        // wave-uniform: the chunk may still have batches
+    // wave-uniform: buffer of projected voxels, current sub-chunk
+    int buf_pos = 0, buf_cnt = 0, buf_slot = 0;
+    int sub_pos = 0, sub_end = 0, cur_slot = 1;
+    bool more = true;                        // the global queue may still have sub-chunks
 
 #ifdef AMX_FW_PHASES
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long t_all = FWPH_T();
 #endif
-    for (int trip = 0; trip < (1 << 22); ++trip) {
+    for (int trip = 0; trip < (1 << 24); ++trip) {
         const unsigned long long freem = __ballot(!active);
         unsigned long long t0 = FWPH_T();
         // ------------------------------------------------------------ phase 1: refill the wavefront's buffer
         if (freem != 0ull && buf_cnt == 0 && more) {
-            const int b = next_ticket(ticket, lane);
-            if (b >= n_batches) {
-                more = false;
-            } else {
-                const int cnt = min(64, ck.count - (b << 6));
-                const int pos = ck.start + (b << 6) + lane;
+            if (sub_pos >= sub_end) {
+                // next sub-chunk, into the other slot -- once no lane works with that slot any more
+                const int ns = cur_slot ^ 1;
+                const double *slot_ptr = Hs + ns * kSlot;
+                if (__ballot(active && Hl == slot_ptr) == 0ull) {
+                    int u = 0;
+                    if (lane == 0) u = atomicAdd(a.queue, 1);
+                    u = __builtin_amdgcn_readfirstlane(u);
+                    if (u >= n_units) {
+                        more = false;
+                    } else {
+                        const Chunk ck = a.c.chunks[u / a.sub_per_chunk];
+                        const int k0 = (u % a.sub_per_chunk) * kSubChunk;
+                        if (k0 < ck.count) {
+                            const double *hsrc = a.prep + (size_t)ck.dir * fw_prep_words<N>(a.c.nS) + (a.c.nS + N) * ((N + 1) & ~1);
+                            for (int e = lane; e < N * N; e += 64) Hs[ns * kSlot + e] = hsrc[e];
+                            cur_slot = ns;
+                            sub_pos = ck.start + k0;
+                            sub_end = ck.start + min(ck.count, k0 + kSubChunk);
+                        }
+                    }
+                }
+            }
+            if (sub_pos < sub_end) {
+                const int cnt = min(64, sub_end - sub_pos);
+                const int pos = sub_pos + lane;
                 Vb[lane] = (lane < cnt) ? a.c.perm[pos] : -1;
                 Pb[lane] = (lane < cnt) ? a.p0[pos] : 0u;
 #pragma unroll
                 for (int j = 0; j < N; j++) Cb[j * 64 + lane] = (lane < cnt) ? a.cproj[(size_t)j * a.ldC + pos] : 0.0;
-                buf_pos = 0; buf_cnt = cnt;
+                buf_pos = 0; buf_cnt = cnt; buf_slot = cur_slot;
+                sub_pos += cnt;
             }
         }
         FWPH_ADD(0, t0); t0 = FWPH_T();
@@ -924,13 +944,13 @@ __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
             }
             // cold: empty passive set, pick an atom first; warm: all atoms, solve first (see lane_nnqp_rows)
             // warm: the full-set solve and the first block removal happened in k_fw_project (p0: the atoms that stayed)
-            if (take) { active = true; vox = nv; P = warm0 ? np0 : 0u; its = warm0 ? 1 : 0; warm = warm0 && np0 != 0u; }
+            if (take) { active = true; vox = nv; P = warm0 ? np0 : 0u; its = warm0 ? 1 : 0; warm = warm0 && np0 != 0u; Hl = Hs + buf_slot * kSlot; }
             const int taken = min(__builtin_popcountll(freem), buf_cnt);
             buf_pos += taken; buf_cnt -= taken;
         }
         FWPH_ADD(1, t0); t0 = FWPH_T();
         if (__ballot(active) == 0ull) {
-            if (!more) break;
+            if (!more && buf_cnt == 0 && sub_pos >= sub_end) break;
             continue;
         }
 #ifdef AMX_FW_PHASES
@@ -945,7 +965,7 @@ __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
         const bool slv = active && !done;
         {
             double z[N];
-            lane_solve<N>(Hs, c, P, z);                           // (an empty passive set gives z = 0: feasible)
+            lane_solve<N>(Hl, c, P, z);                           // (an empty passive set gives z = 0: feasible)
             bool feasible = true;
 #pragma unroll
             for (int j = 0; j < N; j++)
@@ -995,7 +1015,7 @@ __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
                 for (int j = 0; j < N; j++) {
                     double g = c[j];
 #pragma unroll
-                    for (int k = 0; k < N; k++) g -= Hs[j * N + k] * x[k];
+                    for (int k = 0; k < N; k++) g -= Hl[j * N + k] * x[k];
                     if (!((P >> j) & 1u) && g > best) { best = g; t = j; }
                 }
                 if (pick) {
@@ -1043,7 +1063,7 @@ __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
 #endif
 }
 
-static size_t refill_lds_bytes(int N, int nw) { return ((size_t)N * N + (size_t)nw * (N * 64 + 64)) * sizeof(double) + 16; }
+static size_t refill_lds_bytes(int N, int nw) { return (size_t)nw * (2 * ((N * N + 3) & ~1) + N * 64 + 64) * sizeof(double); }
 static size_t project_lds_bytes(int nS, int N, int nw)
 {
     const int NP = (N + 1) & ~1;
@@ -1080,10 +1100,12 @@ static int launch_refill(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s,
     const size_t lds_p = project_lds_bytes(a.c.nS, N, 4), lds = refill_lds_bytes(N, 4);
     if ((rc = set_lds(ctx, proj, lds_p)) || (rc = set_lds(ctx, kern, lds))) return rc;
     const dim3 grid(((pl.max_chunks + 7) / 8) * 8);
+    a.queue = pl.n_chunks + 60;                            // (misc word 60: zeroed with the plan counters)
+    a.sub_per_chunk = (amx_refill_chunk((long long)pl.n) + kSubChunk - 1) / kSubChunk;
     rec(ctx, 2, s);
     hipLaunchKernelGGL(proj, grid, dim3(256), lds_p, s, a);
     AMX_TRACE(ctx, s, "A'y of every voxel");
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(2 * ctx->n_cu), dim3(256), lds, s, a);
     AMX_TRACE(ctx, s, "lane-per-voxel solver with refill");
     rec(ctx, 3, s);
     HIPCHK(ctx, hipGetLastError());
