@@ -696,7 +696,7 @@ constexpr int kTileLd = 65;            // odd leading dimension (doubles) of the
 
 // per orientation, once per (dictionary, lambda2): the fp64 dictionary A [nS][NP], H^-1 [N][NP] and H = A'A + lambda2 I
 // [N][N] (NP = N rounded up to even).  One wavefront per orientation.
-template <int N> constexpr int fw_prep_words(int nS) { return nS * ((N + 1) & ~1) + N * ((N + 1) & ~1) + N * N; }
+template <int N> constexpr int fw_prep_words(int nS) { return (nS * ((N + 1) & ~1) + N * ((N + 1) & ~1) + N * N + 1) & ~1; }   // even: 16-byte aligned tables
 
 template <int N>
 __global__ void __launch_bounds__(64) k_fw_orient_prep(const float *__restrict__ tiles, int tile_stride, int ldA, int nS, int n_atoms,
@@ -735,9 +735,8 @@ __global__ void __launch_bounds__(64) k_fw_orient_prep(const float *__restrict__
     }
 }
 
-// phase 1 as its own launch: c = A'y - lambda1 for every voxel, in bucket order, [N][ldC] (atom-major: coalesced for the
-// lanes that write it here and for the lanes that draw from it in the solver), plus H = A'A + lambda2 I of every chunk's
-// orientation.  A streaming kernel (520 B in, 92 B out per voxel) at four wavefronts per SIMD: the signal loads of one
+// phase 1 as its own launch: c = A'y - lambda1 for every voxel, in bucket order, [ldC][NP] (voxel-major: a batch of 64
+// voxels is one contiguous 6 KB block that the solver streams into its LDS with direct global->LDS loads).  A streaming kernel (520 B in, 92 B out per voxel) at four wavefronts per SIMD: the signal loads of one
 // wavefront overlap the contractions of the others, which the solver's two wavefronts per SIMD could not do.
 //
 // It also takes the first step of the warm-started active-set method off the solver's hands: the unconstrained optimum on
@@ -829,9 +828,11 @@ __global__ void __launch_bounds__(256, AMX_FW_PROJ_OCC) k_fw_project(const FwArg
             unsigned p0 = 0u;
 #pragma unroll
             for (int j = 0; j < N; j++) cn[j] -= a.c.lam1;
+            double *crow = a.cproj + (size_t)pos * NP;            // voxel-major: the solver streams whole batches into LDS
+#pragma unroll
+            for (int j = 0; j < NP; j++) crow[j] = finite ? cn[j] : __builtin_nan("");
 #pragma unroll
             for (int j = 0; j < N; j++) {
-                a.cproj[(size_t)j * a.ldC + pos] = finite ? cn[j] : __builtin_nan("");
                 double z0 = 0.0;
 #pragma unroll
                 for (int k = 0; k < N; k++) z0 += Hi[j * NP + k] * cn[k];
@@ -861,13 +862,16 @@ __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
     const int n_atoms = a.c.n_atoms, n_perp = a.n_perp;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // LDS per wavefront: Hs f64 [2][kSlot] | Cb [N][64] | Vb int[64] | Pb unsigned[64]
-    constexpr int kSlot = (N * N + 3) & ~1;              // 16-byte aligned slots whose banks do not coincide
-    constexpr int kWaveWords = 2 * kSlot + N * 64 + 64;
+    constexpr int NP = (N + 1) & ~1;
+    // LDS per wavefront: Hs f64 [2][kSlot] | two voxel buffers, each Cb [64][NP], Vb int[64], Pb unsigned[64].
+    // Everything arrives by direct global->LDS loads (no staging registers, and the wavefront keeps iterating while
+    // they are in flight): 16 bytes per lane and instruction, destination = base + 16 * lane.
+    constexpr int kHPieces = (N * N + 127) / 128;        // 1 KB loads per H table
+    constexpr int kSlot = 128 * kHPieces + 2;            // banks shifted between the two slots
+    constexpr int kBufWords = 64 * NP + 64;              // doubles
+    constexpr int kWaveWords = 2 * kSlot + 2 + 2 * kBufWords;
     double *Hs = reinterpret_cast<double *>(smem_r) + (size_t)wave * kWaveWords;
-    double *Cb = Hs + 2 * kSlot;
-    int *Vb = reinterpret_cast<int *>(Cb + N * 64);
-    unsigned *Pb = reinterpret_cast<unsigned *>(Vb + 64);
+    double *buf0 = Hs + 2 * kSlot + 2;
     const int n_chunks = *a.c.n_chunks;
     const int n_units = n_chunks * a.sub_per_chunk;
     const double tol = 1e-12, inf = __builtin_huge_val();
@@ -880,8 +884,9 @@ __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
     double c[N], x[N];
 #pragma unroll
     for (int j = 0; j < N; j++) { c[j] = 0.0; x[j] = 0.0; }
-    // wave-uniform: buffer of projected voxels, current sub-chunk
-    int buf_pos = 0, buf_cnt = 0, buf_slot = 0;
+    // wave-uniform: the buffer being consumed, the buffer in flight, the current sub-chunk
+    int cur = 0, buf_pos = 0, buf_cnt = 0, buf_slot = 0;
+    int nxt_cnt = 0, nxt_slot = 0;
     int sub_pos = 0, sub_end = 0, cur_slot = 1;
     bool more = true;                        // the global queue may still have sub-chunks
 
@@ -890,15 +895,15 @@ __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
     const unsigned long long t_all = FWPH_T();
 #endif
     for (int trip = 0; trip < (1 << 24); ++trip) {
-        const unsigned long long freem = __ballot(!active);
         unsigned long long t0 = FWPH_T();
-        // ------------------------------------------------------------ phase 1: refill the wavefront's buffer
-        if (freem != 0ull && buf_cnt == 0 && more) {
+        // ------------------------------------------------------------ prefetch: the next batch into the idle buffer
+        if (nxt_cnt == 0 && (more || sub_pos < sub_end)) {
             if (sub_pos >= sub_end) {
-                // next sub-chunk, into the other slot -- once no lane works with that slot any more
+                // next sub-chunk, its H into the other slot -- once no lane works with that slot any more
                 const int ns = cur_slot ^ 1;
                 const double *slot_ptr = Hs + ns * kSlot;
-                if (__ballot(active && Hl == slot_ptr) == 0ull) {
+                const bool slot_busy = __ballot(active && Hl == slot_ptr) != 0ull || (buf_cnt > 0 && buf_slot == ns);
+                if (!slot_busy) {
                     int u = 0;
                     if (lane == 0) u = atomicAdd(a.queue, 1);
                     u = __builtin_amdgcn_readfirstlane(u);
@@ -908,8 +913,12 @@ __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
                         const Chunk ck = a.c.chunks[u / a.sub_per_chunk];
                         const int k0 = (u % a.sub_per_chunk) * kSubChunk;
                         if (k0 < ck.count) {
-                            const double *hsrc = a.prep + (size_t)ck.dir * fw_prep_words<N>(a.c.nS) + (a.c.nS + N) * ((N + 1) & ~1);
-                            for (int e = lane; e < N * N; e += 64) Hs[ns * kSlot + e] = hsrc[e];
+                            const double *hsrc = a.prep + (size_t)ck.dir * fw_prep_words<N>(a.c.nS) + (a.c.nS + N) * NP;
+#pragma unroll
+                            for (int i = 0; i < kHPieces; i++) {
+                                const int hoff = min(i * 128 + lane * 2, (N * N - 1) & ~1);   // (the tail lanes re-read the last piece)
+                                __builtin_amdgcn_global_load_lds(hsrc + hoff, (__attribute__((address_space(3))) void *)(Hs + ns * kSlot + i * 128), 16, 0, 0);
+                            }
                             cur_slot = ns;
                             sub_pos = ck.start + k0;
                             sub_end = ck.start + min(ck.count, k0 + kSubChunk);
@@ -919,18 +928,35 @@ __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
             }
             if (sub_pos < sub_end) {
                 const int cnt = min(64, sub_end - sub_pos);
-                const int pos = sub_pos + lane;
-                Vb[lane] = (lane < cnt) ? a.c.perm[pos] : -1;
-                Pb[lane] = (lane < cnt) ? a.p0[pos] : 0u;
+                double *nb = buf0 + (cur ^ 1) * kBufWords;
+                int *nVb = reinterpret_cast<int *>(nb + 64 * NP);
+                unsigned *nPb = reinterpret_cast<unsigned *>(nVb + 64);
+                const int pl = sub_pos + min(lane, cnt - 1);                              // lanes past the end repeat the last voxel
+                __builtin_amdgcn_global_load_lds(a.c.perm + pl, (__attribute__((address_space(3))) void *)nVb, 4, 0, 0);
+                __builtin_amdgcn_global_load_lds(a.p0 + pl, (__attribute__((address_space(3))) void *)nPb, 4, 0, 0);
+                const double *src = a.cproj + (size_t)sub_pos * NP;
+                const int last = cnt * NP - 2;                                            // last 16-byte piece of the batch
 #pragma unroll
-                for (int j = 0; j < N; j++) Cb[j * 64 + lane] = (lane < cnt) ? a.cproj[(size_t)j * a.ldC + pos] : 0.0;
-                buf_pos = 0; buf_cnt = cnt; buf_slot = cur_slot;
+                for (int i = 0; i < (64 * NP * 8) / 1024; i++) {
+                    const int off = min(i * 128 + lane * 2, last);
+                    __builtin_amdgcn_global_load_lds(src + off, (__attribute__((address_space(3))) void *)(nb + i * 128), 16, 0, 0);
+                }
+                nxt_cnt = cnt; nxt_slot = cur_slot;
                 sub_pos += cnt;
             }
+        }
+        const unsigned long long freem = __ballot(!active);
+        // ------------------------------------------------------------ the buffer ran dry: switch to the one in flight
+        if (freem != 0ull && buf_cnt == 0 && nxt_cnt > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            cur ^= 1; buf_pos = 0; buf_cnt = nxt_cnt; buf_slot = nxt_slot; nxt_cnt = 0;
         }
         FWPH_ADD(0, t0); t0 = FWPH_T();
         // ------------------------------------------------------------ free lanes take the next voxels of the buffer
         if (freem != 0ull && buf_cnt > 0) {
+            const double *Cb = buf0 + cur * kBufWords;
+            const int *Vb = reinterpret_cast<const int *>(Cb + 64 * NP);
+            const unsigned *Pb = reinterpret_cast<const unsigned *>(Vb + 64);
             const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(freem >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)freem, 0u));
             const bool take = !active && rank < buf_cnt;
             const int e = take ? buf_pos + rank : 0;
@@ -938,11 +964,11 @@ __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
             const unsigned np0 = Pb[e];
 #pragma unroll
             for (int j = 0; j < N; j++) {
-                const double cj = Cb[j * 64 + e];
+                const double cj = Cb[e * NP + j];
                 c[j] = take ? cj : c[j];
                 x[j] = take ? 0.0 : x[j];
             }
-            // cold: empty passive set, pick an atom first; warm: all atoms, solve first (see lane_nnqp_rows)
+            // cold: empty passive set, pick an atom first
             // warm: the full-set solve and the first block removal happened in k_fw_project (p0: the atoms that stayed)
             if (take) { active = true; vox = nv; P = warm0 ? np0 : 0u; its = warm0 ? 1 : 0; warm = warm0 && np0 != 0u; Hl = Hs + buf_slot * kSlot; }
             const int taken = min(__builtin_popcountll(freem), buf_cnt);
@@ -950,7 +976,7 @@ __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
         }
         FWPH_ADD(1, t0); t0 = FWPH_T();
         if (__ballot(active) == 0ull) {
-            if (!more && buf_cnt == 0 && sub_pos >= sub_end) break;
+            if (!more && buf_cnt == 0 && nxt_cnt == 0 && sub_pos >= sub_end) break;
             continue;
         }
 #ifdef AMX_FW_PHASES
@@ -1063,7 +1089,7 @@ __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
 #endif
 }
 
-static size_t refill_lds_bytes(int N, int nw) { return (size_t)nw * (2 * ((N * N + 3) & ~1) + N * 64 + 64) * sizeof(double); }
+static size_t refill_lds_bytes(int N, int nw) { return (size_t)nw * (2 * (128 * ((N * N + 127) / 128) + 2) + 2 + 2 * (64 * ((N + 1) & ~1) + 64)) * sizeof(double); }
 static size_t project_lds_bytes(int nS, int N, int nw)
 {
     const int NP = (N + 1) & ~1;
@@ -1091,9 +1117,9 @@ template <typename KP, typename K>
 static int launch_refill(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s, KP proj, K kern, int N)
 {
     int rc;
-    // workspace of the projection: c [N][ldC], p0 [ldC]
+    // workspace of the projection: c [ldC][NP], p0 [ldC]
     a.ldC = (int)((pl.n + 63) & ~(size_t)63);
-    const size_t cbytes = (size_t)N * a.ldC * sizeof(double);
+    const size_t cbytes = (size_t)((N + 1) & ~1) * a.ldC * sizeof(double);
     if ((rc = amx_ensure(ctx, ctx->cproj, cbytes + (size_t)a.ldC * sizeof(unsigned)))) return rc;
     a.cproj = (double *)ctx->cproj.p;
     a.p0 = (unsigned *)((char *)ctx->cproj.p + cbytes);
@@ -1122,7 +1148,7 @@ static int fw_prepare_n(amx_ctx *ctx, const amx_lut *lut, FwArgs &a, hipStream_t
         if (!lut->fw_prep || lut->fw_N != N) {
             if (lut->fw_prep) HIPCHK(ctx, hipFree(lut->fw_prep));
             lut->fw_prep = nullptr;
-            HIPCHK(ctx, hipMalloc((void **)&lut->fw_prep, words * lut->ndirs * sizeof(double)));
+            HIPCHK(ctx, hipMalloc((void **)&lut->fw_prep, words * lut->ndirs * sizeof(double) + 64));     // (+ slack: 16-byte reads of the last entries)
         }
         if (!lut->fw_ready) HIPCHK(ctx, hipEventCreateWithFlags(&lut->fw_ready, hipEventDisableTiming));
         const int NP = (N + 1) & ~1;
