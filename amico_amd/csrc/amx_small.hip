@@ -26,42 +26,44 @@ __device__ __forceinline__ constexpr int tri(int i, int j) { return i * (i + 1) 
 // across the fully unrolled passes (hundreds of VGPRs) and spills everything else
 #define AMX_RELOAD() asm volatile("" ::: "memory")
 
-// masked Cholesky of H restricted to P (identity elsewhere) and the two triangular solves: z = H_PP^-1 cc_P (0 elsewhere)
+// Cholesky of H restricted to P and the two triangular solves: z = H_PP^-1 cc_P (0 elsewhere).
+// The restriction costs ONE select per column: ivm_j = 1 / L_jj for j in P, 0 otherwise.  A zero ivm_j zeroes column j of
+// the factor (so no row of P ever sees atom j) and z_j in both substitutions.  Row j itself is then computed from whatever
+// the arithmetic gives (finite: sums of products of bounded entries; a negative pivot only feeds the discarded rsqrt) --
+// nothing reads it, because every use of row j is multiplied by ivm_j or by z_j = 0.
 template <int N>
 __device__ __forceinline__ void lane_solve(const double *__restrict__ Hs, const double (&cc)[N], unsigned P, double (&z)[N])
 {
-    double L[N * (N + 1) / 2], linv[N];
+    double L[N * (N + 1) / 2], ivm[N];
     AMX_RELOAD();
 #pragma unroll
     for (int j = 0; j < N; j++) {
-        const bool pj = (P >> j) & 1u;
         double s = Hs[j * N + j];
 #pragma unroll
         for (int k = 0; k < j; k++) s -= L[tri<N>(j, k)] * L[tri<N>(j, k)];
-        const double iv = pj ? rsqrt(s) : 1.0;
-        linv[j] = iv;
-        L[tri<N>(j, j)] = pj ? s * iv : 1.0;
+        const double iv = ((P >> j) & 1u) ? rsqrt(s) : 0.0;
+        ivm[j] = iv;
 #pragma unroll
         for (int i = j + 1; i < N; i++) {
             double tt = Hs[i * N + j];
 #pragma unroll
             for (int k = 0; k < j; k++) tt -= L[tri<N>(i, k)] * L[tri<N>(j, k)];
-            L[tri<N>(i, j)] = (pj && ((P >> i) & 1u)) ? tt * iv : 0.0;
+            L[tri<N>(i, j)] = tt * iv;
         }
     }
 #pragma unroll
     for (int j = 0; j < N; j++) {
-        double s = ((P >> j) & 1u) ? cc[j] : 0.0;
+        double s = cc[j];
 #pragma unroll
         for (int k = 0; k < j; k++) s -= L[tri<N>(j, k)] * z[k];
-        z[j] = s * linv[j];
+        z[j] = s * ivm[j];
     }
 #pragma unroll
     for (int j = N - 1; j >= 0; j--) {
         double s = z[j];
 #pragma unroll
         for (int i = j + 1; i < N; i++) s -= L[tri<N>(i, j)] * z[i];
-        z[j] = s * linv[j];
+        z[j] = s * ivm[j];
     }
 }
 
