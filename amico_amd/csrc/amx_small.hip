@@ -852,6 +852,136 @@ __global__ void __launch_bounds__(256, AMX_FW_PROJ_OCC) k_fw_project(const FwArg
 #endif
 }
 
+// The same projection on the matrix cores: C' [atoms x voxels] = A' [atoms x nS] * Y' [nS x voxels] is a tall-skinny fp64 GEMM
+// (v_mfma_f64_16x16x4_f64; 16 atoms x 16 voxels x 4 signal values per instruction, exact fp64 accumulation).
+//   * A' lives in registers (one f64 per lane and K-step, loaded once per workgroup: lane l holds A[4 ks + (l >> 4)][l & 15]);
+//   * the signal rows stream global -> LDS with direct loads, two 8 KB tiles of 64 voxels x 16 values per wavefront
+//     (the next tile is in flight while the current one is multiplied); 8 lanes fetch the 128 contiguous bytes of one voxel,
+//     and the 16-byte pieces of a voxel are XOR-swizzled by the voxel number so that the operand reads (16 voxels x one
+//     value per instruction) spread over the LDS banks;
+//   * z0 = H^-1 c is a second small GEMM on the accumulator registers (the D layout of the first product IS the B operand
+//     layout of the second: atom (l >> 4) + 4 r of voxel l & 15 sits in register r of lane l);
+//   * the values of a voxel end up in four lanes (l & 15 equal): the passive-set bits are OR-ed across them.
+// Rows beyond the last full tile of 16 (nS = 65: one row) go through ordinary loads, zero-padded to a K-step.
+typedef double v4d __attribute__((ext_vector_type(4)));
+constexpr int kProjKS = 24;                // K-steps of dictionary registers: nS <= 96
+
+template <int N>
+__global__ void __launch_bounds__(256, 2) k_fw_project_mfma(const FwArgs a)
+{
+    static_assert(N <= 16, "one 16-row MFMA tile of atoms");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_m[];
+    const int cid = xcd_chunk((int)blockIdx.x, *a.c.n_chunks);
+    if (cid < 0) return;
+    const Chunk ck = a.c.chunks[cid];
+    const int nS = a.c.nS, n_atoms = a.c.n_atoms;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
+    constexpr int NP = (N + 1) & ~1;
+    constexpr int kTile = 64 * 16;                       // doubles per tile
+    double *T = reinterpret_cast<double *>(smem_m) + (size_t)wave * (2 * kTile + 32);
+    int *Vb = reinterpret_cast<int *>(T + 2 * kTile);
+    const int q = lane >> 4, v16 = lane & 15;
+    const double *src = a.prep + (size_t)ck.dir * fw_prep_words<N>(nS);
+    const int KS = (nS + 3) >> 2;
+    double ad[kProjKS], hi[4];
+#pragma unroll
+    for (int ks = 0; ks < kProjKS; ks++) {
+        const int row = 4 * ks + q;
+        ad[ks] = (ks < KS && row < nS && v16 < NP) ? src[row * NP + v16] : 0.0;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+        const int k = 4 * ks + q;                        // H^-1 [i = l & 15][k], zero beyond N
+        hi[ks] = (v16 < N && k < N) ? src[(size_t)nS * NP + v16 * NP + k] : 0.0;
+    }
+    const int n_pass = nS >> 4;                          // full tiles of 16 signal values
+    const int n_batches = (ck.count + 63) >> 6;
+    const int seg = lane & 7, grp = lane >> 3;           // loader role: 8 lanes x 16 B = 128 B of one voxel
+    for (int b = wave; b < n_batches; b += nw) {
+        const int cnt = min(64, ck.count - (b << 6));
+        const int pos0 = ck.start + (b << 6);
+        Vb[lane] = a.c.perm[pos0 + min(lane, cnt - 1)];   // (lanes past the end repeat the last voxel; their results are dropped)
+        const double *yl[8];
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int vloc = it * 8 + grp;
+            yl[it] = a.c.y + (size_t)Vb[vloc] * nS + 2 * (seg ^ ((vloc >> 1) & 7));
+        }
+        auto issue = [&](int p) {
+            double *dst = T + (p & 1) * kTile;
+#pragma unroll
+            for (int it = 0; it < 8; it++)
+                __builtin_amdgcn_global_load_lds(yl[it] + 16 * p, (__attribute__((address_space(3))) void *)(dst + it * 128), 16, 0, 0);
+        };
+        v4d acc[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) acc[mt] = (v4d){0.0, 0.0, 0.0, 0.0};
+        if (n_pass > 0) issue(0);
+#pragma unroll
+        for (int p = 0; p < kProjKS / 4; p++) {              // (unrolled: the dictionary registers need compile-time indices)
+            if (p < n_pass) {
+                if (p + 1 < n_pass) {
+                    issue(p + 1);
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // tile p has landed, tile p + 1 (8 loads) may be in flight
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                const double *tile = T + (p & 1) * kTile;
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    const int k = 4 * kk + q, s2 = k >> 1, half = k & 1;
+#pragma unroll
+                    for (int mt = 0; mt < 4; mt++) {
+                        const int vloc = mt * 16 + v16;
+                        const double bv = tile[vloc * 16 + ((s2 ^ ((vloc >> 1) & 7)) << 1) + half];
+                        acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[4 * p + kk], bv, acc[mt], 0, 0, 0);
+                    }
+                }
+                asm volatile("" ::: "memory");
+            } else if (p == n_pass) {
+                // rows beyond the last full tile: ordinary loads, zero-padded to whole K-steps
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    const int row = 16 * p + 4 * kk + q;
+                    if (16 * p + 4 * kk < nS) {
+#pragma unroll
+                        for (int mt = 0; mt < 4; mt++) {
+                            const double bv = (row < nS) ? a.c.y[(size_t)Vb[mt * 16 + v16] * nS + row] : 0.0;
+                            acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[4 * p + kk], bv, acc[mt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        // c = A'y - lambda1; z0 = H^-1 c; passive set after the first block removal
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+            v4d cf = acc[mt], z = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < 4; r++) cf[r] = (q + 4 * r < n_atoms) ? cf[r] - a.c.lam1 : 0.0;
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) z = __builtin_amdgcn_mfma_f64_16x16x4f64(hi[ks], cf[ks], z, 0, 0, 0);
+            unsigned m = 0u;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                if (q + 4 * r < n_atoms && z[r] > 0.0) m |= 1u << (q + 4 * r);
+                if (!(fabs(cf[r]) <= 1.79769313486231570e308)) m |= 0x80000000u;       // non-finite signal
+            }
+            m |= __shfl_xor((int)m, 16);
+            m |= __shfl_xor((int)m, 32);
+            const int vloc = mt * 16 + v16;
+            if (vloc < cnt) {
+                const bool finite = !(m & 0x80000000u);
+                double *crow = a.cproj + (size_t)(pos0 + vloc) * NP;
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (q + 4 * r < NP) crow[q + 4 * r] = finite ? cf[r] : __builtin_nan("");
+                if (q == 0) a.p0[pos0 + vloc] = m & 0x7fffffffu;
+            }
+        }
+    }
+}
+
 // The solver is a set of PERSISTENT wavefronts: each draws sub-chunks of kSubChunk voxels (of one orientation) from a global
 // ticket and keeps TWO H tables in its LDS block -- lanes still iterating on voxels of the previous sub-chunk keep theirs
 // while the free lanes already take voxels of the next one, so lanes only idle at the very end of the launch (a
@@ -1115,8 +1245,8 @@ int launch_lane(amx_ctx *ctx, Args &a, const Plan &pl, hipStream_t s, K kern, si
 
 }  // namespace
 
-template <typename KP, typename K>
-static int launch_refill(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s, KP proj, K kern, int N)
+template <typename KP, typename KM, typename K>
+static int launch_refill(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s, KP proj, KM pmfma, K kern, int N)
 {
     int rc;
     // workspace of the projection: c [ldC][NP], p0 [ldC]
@@ -1125,13 +1255,15 @@ static int launch_refill(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s,
     if ((rc = amx_ensure(ctx, ctx->cproj, cbytes + (size_t)a.ldC * sizeof(unsigned)))) return rc;
     a.cproj = (double *)ctx->cproj.p;
     a.p0 = (unsigned *)((char *)ctx->cproj.p + cbytes);
-    const size_t lds_p = project_lds_bytes(a.c.nS, N, 4), lds = refill_lds_bytes(N, 4);
-    if ((rc = set_lds(ctx, proj, lds_p)) || (rc = set_lds(ctx, kern, lds))) return rc;
+    const bool mfma = a.c.nS <= 4 * kProjKS && !getenv("AMX_FW_PROJ_VALU");
+    const size_t lds_p = mfma ? (size_t)4 * (2 * 64 * 16 + 32) * sizeof(double) : project_lds_bytes(a.c.nS, N, 4), lds = refill_lds_bytes(N, 4);
+    if ((rc = set_lds(ctx, proj, lds_p)) || (rc = set_lds(ctx, pmfma, lds_p)) || (rc = set_lds(ctx, kern, lds))) return rc;
     const dim3 grid(((pl.max_chunks + 7) / 8) * 8);
     a.queue = pl.n_chunks + 60;                            // (misc word 60: zeroed with the plan counters)
     a.sub_per_chunk = (amx_refill_chunk((long long)pl.n) + kSubChunk - 1) / kSubChunk;
     rec(ctx, 2, s);
-    hipLaunchKernelGGL(proj, grid, dim3(256), lds_p, s, a);
+    if (mfma) hipLaunchKernelGGL(pmfma, grid, dim3(256), lds_p, s, a);
+    else hipLaunchKernelGGL(proj, grid, dim3(256), lds_p, s, a);
     AMX_TRACE(ctx, s, "A'y of every voxel");
     hipLaunchKernelGGL(kern, dim3(2 * ctx->n_cu), dim3(256), lds, s, a);
     AMX_TRACE(ctx, s, "lane-per-voxel solver with refill");
@@ -1178,8 +1310,8 @@ int amx_launch_fw_small(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s)
     // compile-time dictionary sizes: the reference's defaults (11 Human, 12 Mouse) exactly, 16 otherwise
     const int n = a.c.n_atoms;
     if (amx_fw_use_refill(n, a.c.nS, a.c.flags)) {
-        if (n <= 11) return launch_refill(ctx, a, pl, s, k_fw_project<11>, k_freewater_refill<11>, 11);
-        return launch_refill(ctx, a, pl, s, k_fw_project<12>, k_freewater_refill<12>, 12);
+        if (n <= 11) return launch_refill(ctx, a, pl, s, k_fw_project<11>, k_fw_project_mfma<11>, k_freewater_refill<11>, 11);
+        return launch_refill(ctx, a, pl, s, k_fw_project<12>, k_fw_project_mfma<12>, k_freewater_refill<12>, 12);
     }
     if (n <= 11) return launch_lane(ctx, a, pl, s, k_freewater_lane<11>, sizeof(float), 11);
     if (n == 12) return launch_lane(ctx, a, pl, s, k_freewater_lane<12>, sizeof(float), 12);
