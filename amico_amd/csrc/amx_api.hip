@@ -168,9 +168,10 @@ void amx_lut_destroy(amx_lut *lut)
     if (!lut) return;
     if (lut->ctx) hipSetDevice(lut->ctx->device);
     void *ps[] = {lut->gram, lut->gram_dwi, lut->tiles, lut->htable, lut->rowdwi, lut->colscale, lut->icvf, lut->kappa,
-                  lut->norms, lut->Rs, lut->d_in, lut->d_isos, lut->fw_prep};
+                  lut->norms, lut->Rs, lut->d_in, lut->d_isos, lut->fw_prep, lut->sandi_prep};
     for (void *p : ps) if (p) hipFree(p);
     if (lut->fw_ready) (void)hipEventDestroy(lut->fw_ready);
+    if (lut->sandi_ready) (void)hipEventDestroy(lut->sandi_ready);
     delete lut;
 }
 
@@ -564,6 +565,7 @@ int amx_sandi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, in
         a.c.xdbg = ctx->dbg_x + (size_t)ctx->vox_base * lut->n_atoms;
     }
     a.est = d_estimates; a.rmse = (flags & AMX_F_RMSE) ? d_rmse : nullptr; a.nrmse = (flags & AMX_F_NRMSE) ? d_nrmse : nullptr;
+    if ((rc = amx_sandi_prepare(ctx, lut, a, s))) return rc;
     rc = amx_launch_sandi(ctx, a, pl, s);
     hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, s, (const int *)ctx->misc.p, ctx->status_d);
     rec(ctx, 1, s);

@@ -71,6 +71,10 @@ struct amx_lut {
     mutable double fw_lam2 = -1.0;
     mutable int fw_N = 0;
     mutable hipEvent_t fw_ready = nullptr;
+    // SANDI row-space solver tables (k_sandi_tables) for one (lambda1, lambda2)
+    mutable double *sandi_prep = nullptr;
+    mutable double sandi_lam1 = -1.0, sandi_lam2 = -1.0;
+    mutable hipEvent_t sandi_ready = nullptr;
 };
 
 // principal-direction estimator of one acquisition scheme (amx_signal.hip)
@@ -160,7 +164,8 @@ int amx_launch_sandi(amx_ctx *ctx, amx::SandiArgs &a, const Plan &pl, hipStream_
 int amx_launch_czb(amx_ctx *ctx, amx::CzbArgs &a, const Plan &pl, hipStream_t s);
 // lane-per-voxel variants for dictionaries of <= 16 atoms (amx_small.hip)
 int amx_launch_fw_small(amx_ctx *ctx, amx::FwArgs &a, const Plan &pl, hipStream_t s);
-int amx_fw_prepare(amx_ctx *ctx, const amx_lut *lut, amx::FwArgs &a, hipStream_t s);   // before amx_launch_fw when the refill path runs
+int amx_fw_prepare(amx_ctx *ctx, const amx_lut *lut, amx::FwArgs &a, hipStream_t s);
+int amx_sandi_prepare(amx_ctx *ctx, const amx_lut *lut, amx::SandiArgs &a, hipStream_t s);   // before amx_launch_fw when the refill path runs
 int amx_launch_sandi_small(amx_ctx *ctx, amx::SandiArgs &a, const Plan &pl, hipStream_t s);
 // NODDI NNLS stages, two voxels per wavefront (amx_pair.hpp; protocols that fit 32-lane halves: 4 volumes, 5 atoms per
 // lane).  OPT-IN (AMX_PAIR=1): certified by the same KKT tests, but measured SLOWER than the wavefront-per-voxel

@@ -370,6 +370,7 @@ struct SandiArgs {
     const double *norms, *Rs, *d_in, *d_isos;
     int n_rs, n_in, n_iso;
     double *est, *rmse, *nrmse;
+    const double *tables;          // k_sandi_tables (row-space kernel): T | G | g0
 };
 
 template <int NR, int NQ, int MAXP>

@@ -22,6 +22,17 @@ namespace {
 template <int N>
 __device__ __forceinline__ constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
 
+// x / d for well-scaled operands (no denormal / overflow handling: v_rcp_f64, two Newton steps, one residual correction;
+// ~9 instructions against ~35 of the IEEE sequence, within 1 ulp)
+__device__ __forceinline__ double fast_div(double x, double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    const double q = x * r;
+    return __builtin_fma(__builtin_fma(-d, q, x), r, q);
+}
+
 // H / the dictionary are loop invariant: without these barriers the compiler keeps their entries in vector registers
 // across the fully unrolled passes (hundreds of VGPRs) and spills everything else
 #define AMX_RELOAD() asm volatile("" ::: "memory")
@@ -329,10 +340,10 @@ __global__ void __launch_bounds__(256) k_sandi_lane(const SandiArgs a)
             for (int j = 0; j < N; j++) if (j < n_atoms) a.c.xdbg[(size_t)vox * n_atoms + j] = x[j];
         }
         x_sum += 1e-16;
-        e[0] = xsph / x_sum; e[1] = xstk / x_sum; e[2] = xiso / x_sum;
-        e[3] = 1e6 * Rsoma / (xsph + 1e-16);
-        e[4] = 1e3 * Din / (xstk + 1e-16);
-        e[5] = 1e3 * De / (xiso + 1e-16);
+        e[0] = fast_div(xsph, x_sum); e[1] = fast_div(xstk, x_sum); e[2] = fast_div(xiso, x_sum);
+        e[3] = 1e6 * fast_div(Rsoma, xsph + 1e-16);
+        e[4] = 1e3 * fast_div(Din, xstk + 1e-16);
+        e[5] = 1e3 * fast_div(De, xiso + 1e-16);
         if (a.rmse || a.nrmse) {
             // quirk kept (models.pyx:1571 then 1615): errors use the RESCALED x with the NORMALISED A
             const double rss = lane_rss<N, double>(As, yv, nS, ldA, n_atoms, x);
@@ -343,256 +354,200 @@ __global__ void __launch_bounds__(256) k_sandi_lane(const SandiArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// SANDI after the directional average has M = 6 signal values and N = 15 atoms: the passive system
-//     (A_P' A_P + lambda2 I) x_P = c_P           (|P| x |P|, up to 15 x 15)
-// is solved in ROW space by the Woodbury identity
-//     x_P = (c_P - A_P' w) / lambda2,   (lambda2 I_M + A_P A_P') w = A_P c_P      (M x M, 6 x 6)
-// so a lane keeps one 6 x 6 matrix B = lambda2 I + sum_{j in P} a_j a_j' (updated by +- a a' when an atom enters or
-// leaves) and its Cholesky factor instead of a 15 x 15 masked factor: 21 + 21 doubles instead of 120, no register
-// spills, ~1/5 of the arithmetic.  The dictionary (M x N doubles, the same for every voxel) is read through
-// wave-uniform addresses.  cond(B) <= 1 + |P| / lambda2 (~3e3 for the defaults): harmless in fp64.
+// Row-space solver of the SANDI problem (M = 6 values per voxel after the directional average, N = 15 atoms, ONE dictionary
+// for all voxels):  min 1/2 ||y - A x||^2 + lambda1 sum(x) + lambda2/2 ||x||^2, x >= 0, lambda2 > 0.
+// On a passive set P the solution is x_P = (c_P - A_P' w) / lambda2 with w = B^-1 A_P c_P, B = lambda2 I + A_P A_P' (Woodbury:
+// a 6 x 6 Cholesky instead of a |P| x |P| one).  For j outside P the same expression is the dual value: A_P x_P = w exactly,
+// so g_j = c_j - a_j'w -- the KKT test and the choice of the entering atom cost nothing extra.
+// Tables of the dictionary (k_sandi_tables, once per (dictionary, lambda1, lambda2)), read from LDS with wave-uniform addresses:
+//   T [N][kRowsTs]  packed lower triangles of a_j a_j'          (B is summed from them: no +- drift, half the arithmetic)
+//   G [N][M], g0 [N]  z0 = G y + g0 = the unconstrained optimum on the FULL set (G = A' (lambda2 I + A A')^-1)
+// Warm start: SANDI's optimum is dense (12 of 15 atoms), so the method starts from P0 = {z0 > 0} -- the full-set solve and
+// the first block removal are one tabulated map -- keeps dropping the non-positive coefficients in blocks until the solve
+// is feasible, then continues as Lawson-Hanson (add the most violating atom, step back when infeasible).  With lambda2 > 0
+// the optimum is unique, so the path does not matter; the result satisfies the KKT conditions to 1e-12.
+constexpr int kRowsTs = 22;                // stride of T: 21 entries of the 6 x 6 triangle, padded for 16-byte reads
+
 template <int M, int N>
-__device__ __forceinline__ int lane_nnqp_rows(const double *__restrict__ A, int ldA, const double (&y)[M], double lam1,
-                                              double lam2, double (&x)[N], int n_atoms, bool warm)
+__device__ __forceinline__ int lane_nnqp_rows(const double *__restrict__ A, int ldA, const double *__restrict__ T,
+                                              const double *__restrict__ G, const double *__restrict__ g0, const double (&y)[M],
+                                              double lam1, double lam2, double (&x)[N], int n_atoms, bool warm)
 {
-    const double tol = 1e-12, inf = __builtin_huge_val(), il2 = 1.0 / lam2;
-    double c[N], B[M * (M + 1) / 2], L[M * (M + 1) / 2], li[M], w[M], z[N];
+    static_assert(M * (M + 1) / 2 <= kRowsTs, "triangle of a_j a_j' fits its table row");
+    constexpr int kTri = M * (M + 1) / 2;
+    const double tol = 1e-12, il2 = 1.0 / lam2;
+    double c[N], z[N];
     unsigned P = 0u;
-    int status = 0;
+    AMX_RELOAD();
 #pragma unroll
     for (int j = 0; j < N; j++) {
         x[j] = 0.0;
-        double s = -lam1;
+        double sc = -lam1, sz = g0[j];
 #pragma unroll
-        for (int i = 0; i < M; i++) s += A[i * ldA + j] * y[i];
-        c[j] = s;
+        for (int i = 0; i < M; i++) { sc += A[i * ldA + j] * y[i]; sz += G[j * M + i] * y[i]; }
+        c[j] = sc;
+        if (warm && j < n_atoms && sz > 0.0) P |= 1u << j;
     }
-#pragma unroll
-    for (int i = 0; i < M; i++)
-#pragma unroll
-        for (int k = 0; k <= i; k++) B[tri<M>(i, k)] = (i == k) ? lam2 : 0.0;
-    if (warm) {
-        // Start from the FULL set instead of the empty one.  With lambda2 > 0 the optimum is unique, so the path does not
-        // matter -- and SANDI's optimum is dense (12 of 15 atoms): solving on all atoms and dropping the negative ones,
-        // a few times, reaches it in 3-4 factorisations where Lawson-Hanson needs one per atom (13-15).  The loop below
-        // then verifies the KKT conditions and repairs what the block removals got wrong.
-        P = (n_atoms >= 32) ? ~0u : ((1u << n_atoms) - 1u);
+    bool blocks = warm && P != 0u;           // still in the block-removal phase
+    for (int it = 0;; ++it) {
+        if (it > 4 * N + 16) return 2;
+        double B[kTri], L[kTri], li[M], w[M];
         AMX_RELOAD();
+#pragma unroll
+        for (int t = 0; t < kTri; t++) B[t] = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; i++) { B[tri<M>(i, i)] = lam2; w[i] = 0.0; }
 #pragma unroll
         for (int j = 0; j < N; j++) {
-            if (j < n_atoms) {
+            const bool pj = (P >> j) & 1u;
+            const double mj = pj ? 1.0 : 0.0, cj = pj ? c[j] : 0.0;
 #pragma unroll
-                for (int i = 0; i < M; i++)
+            for (int t = 0; t < kTri; t++) B[t] += mj * T[j * kRowsTs + t];
 #pragma unroll
-                    for (int k = 0; k <= i; k++) B[tri<M>(i, k)] += A[i * ldA + j] * A[k * ldA + j];
+            for (int i = 0; i < M; i++) w[i] += A[i * ldA + j] * cj;
+        }
+#pragma unroll
+        for (int j = 0; j < M; j++) {
+            double d = B[tri<M>(j, j)];
+#pragma unroll
+            for (int k = 0; k < j; k++) d -= L[tri<M>(j, k)] * L[tri<M>(j, k)];
+            const double iv = rsqrt(d);
+            li[j] = iv;
+#pragma unroll
+            for (int i = j + 1; i < M; i++) {
+                double tt = B[tri<M>(i, j)];
+#pragma unroll
+                for (int k = 0; k < j; k++) tt -= L[tri<M>(i, k)] * L[tri<M>(j, k)];
+                L[tri<M>(i, j)] = tt * iv;
             }
         }
-        for (int round = 0; round < N && P != 0u; ++round) {
 #pragma unroll
-            for (int j = 0; j < M; j++) {
-                double d = B[tri<M>(j, j)];
+        for (int j = 0; j < M; j++) {
+            double sacc = w[j];
 #pragma unroll
-                for (int k = 0; k < j; k++) d -= L[tri<M>(j, k)] * L[tri<M>(j, k)];
-                const double iv = rsqrt(d);
-                li[j] = iv;
-                L[tri<M>(j, j)] = d * iv;
-#pragma unroll
-                for (int i = j + 1; i < M; i++) {
-                    double tt = B[tri<M>(i, j)];
-#pragma unroll
-                    for (int k = 0; k < j; k++) tt -= L[tri<M>(i, k)] * L[tri<M>(j, k)];
-                    L[tri<M>(i, j)] = tt * iv;
-                }
-            }
-            AMX_RELOAD();
-#pragma unroll
-            for (int i = 0; i < M; i++) w[i] = 0.0;
-#pragma unroll
-            for (int j = 0; j < N; j++) {
-                const double cj = ((P >> j) & 1u) ? c[j] : 0.0;
-#pragma unroll
-                for (int i = 0; i < M; i++) w[i] += A[i * ldA + j] * cj;
-            }
-#pragma unroll
-            for (int j = 0; j < M; j++) {
-                double sacc = w[j];
-#pragma unroll
-                for (int k = 0; k < j; k++) sacc -= L[tri<M>(j, k)] * w[k];
-                w[j] = sacc * li[j];
-            }
-#pragma unroll
-            for (int j = M - 1; j >= 0; j--) {
-                double sacc = w[j];
-#pragma unroll
-                for (int i = j + 1; i < M; i++) sacc -= L[tri<M>(i, j)] * w[i];
-                w[j] = sacc * li[j];
-            }
-            AMX_RELOAD();
-            unsigned negm = 0u;
-#pragma unroll
-            for (int j = 0; j < N; j++) {
-                double sacc = c[j];
-#pragma unroll
-                for (int i = 0; i < M; i++) sacc -= A[i * ldA + j] * w[i];
-                z[j] = sacc * il2;
-                if (((P >> j) & 1u) && !(z[j] > 0.0)) negm |= 1u << j;
-            }
-            if (negm == 0u) {
-#pragma unroll
-                for (int j = 0; j < N; j++) x[j] = ((P >> j) & 1u) ? z[j] : 0.0;
-                break;
-            }
-            P &= ~negm;
-            AMX_RELOAD();
-#pragma unroll
-            for (int j = 0; j < N; j++) {
-                if ((negm >> j) & 1u) {
-#pragma unroll
-                    for (int i = 0; i < M; i++)
-#pragma unroll
-                        for (int k = 0; k <= i; k++) B[tri<M>(i, k)] -= A[i * ldA + j] * A[k * ldA + j];
-                }
-            }
+            for (int k = 0; k < j; k++) sacc -= L[tri<M>(j, k)] * w[k];
+            w[j] = sacc * li[j];
         }
-        if (P == 0u) {
 #pragma unroll
-            for (int i = 0; i < M; i++)
+        for (int j = M - 1; j >= 0; j--) {
+            double sacc = w[j];
 #pragma unroll
-                for (int k = 0; k <= i; k++) B[tri<M>(i, k)] = (i == k) ? lam2 : 0.0;
+            for (int i = j + 1; i < M; i++) sacc -= L[tri<M>(i, j)] * w[i];
+            w[j] = sacc * li[j];
         }
-    }
-    for (int it = 0; status == 0; ++it) {
-        if (it > 3 * N + 8) { status = 2; break; }
         AMX_RELOAD();
-        // dual vector g_j = a_j'(y - A x) - lambda1 - lambda2 x_j = c_j - a_j' (A x) - lambda2 x_j; most violating atom
-        double ax[M];
-#pragma unroll
-        for (int i = 0; i < M; i++) ax[i] = 0.0;
+        unsigned negm = 0u;
+        double best = -__builtin_huge_val();
+        int t_in = -1;
 #pragma unroll
         for (int j = 0; j < N; j++) {
-            const double xj = x[j];                       // 0 outside the passive set
+            double g = c[j];
 #pragma unroll
-            for (int i = 0; i < M; i++) ax[i] += A[i * ldA + j] * xj;
+            for (int i = 0; i < M; i++) g -= A[i * ldA + j] * w[i];
+            const bool pj = (P >> j) & 1u;
+            z[j] = g * il2;
+            if (pj && !(g > 0.0)) negm |= 1u << j;
+            if (!pj && j < n_atoms && g > best) { best = g; t_in = j; }
         }
-        AMX_RELOAD();
-        double best = -inf;
-        int t = -1;
+        if (negm == 0u) {
+            // feasible: accept, then KKT test / next atom on the dual values that came with the solve
 #pragma unroll
-        for (int j = 0; j < N; j++) {
-            double g = c[j] - lam2 * x[j];
-#pragma unroll
-            for (int i = 0; i < M; i++) g -= A[i * ldA + j] * ax[i];
-            if (!((P >> j) & 1u) && g > best) { best = g; t = j; }
-        }
-        if (!(best > tol)) break;                         // KKT point
-        P |= 1u << t;
-        AMX_RELOAD();
-#pragma unroll
-        for (int j = 0; j < N; j++) {                     // B += a_t a_t'
-            if (j == t) {
-#pragma unroll
-                for (int i = 0; i < M; i++)
-#pragma unroll
-                    for (int k = 0; k <= i; k++) B[tri<M>(i, k)] += A[i * ldA + j] * A[k * ldA + j];
-            }
-        }
-        for (int in = 0;; ++in) {
-            if (in > N + 2) { status = 2; break; }
-            // Cholesky of B (M x M), w = B^-1 (A_P c_P), z_P = (c_P - A_P' w) / lambda2
-#pragma unroll
-            for (int j = 0; j < M; j++) {
-                double d = B[tri<M>(j, j)];
-#pragma unroll
-                for (int k = 0; k < j; k++) d -= L[tri<M>(j, k)] * L[tri<M>(j, k)];
-                const double iv = rsqrt(d);
-                li[j] = iv;
-                L[tri<M>(j, j)] = d * iv;
-#pragma unroll
-                for (int i = j + 1; i < M; i++) {
-                    double tt = B[tri<M>(i, j)];
-#pragma unroll
-                    for (int k = 0; k < j; k++) tt -= L[tri<M>(i, k)] * L[tri<M>(j, k)];
-                    L[tri<M>(i, j)] = tt * iv;
-                }
-            }
-            AMX_RELOAD();
-#pragma unroll
-            for (int i = 0; i < M; i++) w[i] = 0.0;
-#pragma unroll
-            for (int j = 0; j < N; j++) {
-                const double cj = ((P >> j) & 1u) ? c[j] : 0.0;
-#pragma unroll
-                for (int i = 0; i < M; i++) w[i] += A[i * ldA + j] * cj;
-            }
-#pragma unroll
-            for (int j = 0; j < M; j++) {
-                double sacc = w[j];
-#pragma unroll
-                for (int k = 0; k < j; k++) sacc -= L[tri<M>(j, k)] * w[k];
-                w[j] = sacc * li[j];
-            }
-#pragma unroll
-            for (int j = M - 1; j >= 0; j--) {
-                double sacc = w[j];
-#pragma unroll
-                for (int i = j + 1; i < M; i++) sacc -= L[tri<M>(i, j)] * w[i];
-                w[j] = sacc * li[j];
-            }
-            AMX_RELOAD();
-            bool feasible = true;
-#pragma unroll
-            for (int j = 0; j < N; j++) {
-                double sacc = c[j];
-#pragma unroll
-                for (int i = 0; i < M; i++) sacc -= A[i * ldA + j] * w[i];
-                z[j] = sacc * il2;
-                if (((P >> j) & 1u) && !(z[j] > 0.0)) feasible = false;
-            }
-            if (feasible) {
-#pragma unroll
-                for (int j = 0; j < N; j++) x[j] = ((P >> j) & 1u) ? z[j] : 0.0;
-                break;
-            }
-            AMX_RELOAD();
-            double alpha = inf;
+            for (int j = 0; j < N; j++) x[j] = ((P >> j) & 1u) ? z[j] : 0.0;
+            blocks = false;
+            if (!(best > tol)) return 0;
+            if (it > 3 * N + 8) return 2;
+            P |= 1u << t_in;
+        } else if (blocks) {
+            P &= ~negm;                                          // (x is still 0)
+            if (P == 0u) blocks = false;
+        } else {
+            // step back: alpha = min x_j / (x_j - z_j) over the non-positive z_j, by cross multiplication (one division)
+            double xb = 1.0, db = 0.0;
             int jm = -1;
 #pragma unroll
             for (int j = 0; j < N; j++) {
-                if (((P >> j) & 1u) && !(z[j] > 0.0)) {
+                if ((negm >> j) & 1u) {
                     const double den = x[j] - z[j];
-                    const double r = (den > 0.0) ? x[j] / den : 0.0;
-                    if (r < alpha) { alpha = r; jm = j; }
+                    const double xn = (den > 0.0) ? x[j] : 0.0, dn = (den > 0.0) ? den : 1.0;
+                    if (jm < 0 || xn * db < xb * dn) { xb = xn; db = dn; jm = j; }
                 }
             }
+            const double alpha = fast_div(xb, db);
 #pragma unroll
             for (int j = 0; j < N; j++) {
                 if ((P >> j) & 1u) {
                     x[j] += alpha * (z[j] - x[j]);
-                    if (j == jm || !(x[j] > 0.0)) {
-                        x[j] = 0.0;
-                        P &= ~(1u << j);
-#pragma unroll
-                        for (int i = 0; i < M; i++)      // B -= a_j a_j'
-#pragma unroll
-                            for (int k = 0; k <= i; k++) B[tri<M>(i, k)] -= A[i * ldA + j] * A[k * ldA + j];
-                    }
+                    if (j == jm || !(x[j] > 0.0)) { x[j] = 0.0; P &= ~(1u << j); }
                 }
-            }
-            if (P == 0u) {
-#pragma unroll
-                for (int i = 0; i < M; i++)               // exact reset: no drift left from the +- updates
-#pragma unroll
-                    for (int k = 0; k <= i; k++) B[tri<M>(i, k)] = (i == k) ? lam2 : 0.0;
-                break;
             }
         }
     }
-    return status;
 }
+
+// T, G, g0 of one dictionary and one (lambda1, lambda2): one workgroup, thread 0 inverts the 6 x 6 (Gauss-Jordan on the SPD
+// matrix, no pivoting needed).  out: T [N][kRowsTs] | G [N][M] | g0 [16]
+template <int M, int N>
+__global__ void __launch_bounds__(64) k_sandi_tables(const double *__restrict__ Ag, int ldA, int n_atoms, double lam1, double lam2,
+                                                     double *__restrict__ out)
+{
+    __shared__ double A[M * 16], W[M * M], Bm[M * 2 * M];
+    for (int e = threadIdx.x; e < M * 16; e += blockDim.x) A[e] = ((e % 16) < n_atoms) ? Ag[(e / 16) * ldA + (e % 16)] : 0.0;
+    __syncthreads();
+    double *T = out, *G = out + N * kRowsTs, *g0 = G + N * M;
+    for (int e = threadIdx.x; e < N * kRowsTs; e += blockDim.x) {
+        const int j = e / kRowsTs, t = e % kRowsTs;
+        int i = 0;
+        while ((i + 1) * (i + 2) / 2 <= t) i++;                 // t = i (i + 1) / 2 + k
+        const int k = t - i * (i + 1) / 2;
+        T[e] = (t < M * (M + 1) / 2) ? A[i * 16 + j] * A[k * 16 + j] : 0.0;
+    }
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < M; i++)
+            for (int k = 0; k < M; k++) {
+                double acc = (i == k) ? lam2 : 0.0;
+                for (int j = 0; j < N; j++) acc += A[i * 16 + j] * A[k * 16 + j];
+                Bm[i * 2 * M + k] = acc; Bm[i * 2 * M + M + k] = (i == k) ? 1.0 : 0.0;
+            }
+        for (int c0 = 0; c0 < M; c0++) {
+            const double pv = 1.0 / Bm[c0 * 2 * M + c0];
+            for (int k = 0; k < 2 * M; k++) Bm[c0 * 2 * M + k] *= pv;
+            for (int i = 0; i < M; i++)
+                if (i != c0) {
+                    const double f = Bm[i * 2 * M + c0];
+                    for (int k = 0; k < 2 * M; k++) Bm[i * 2 * M + k] -= f * Bm[c0 * 2 * M + k];
+                }
+        }
+        for (int i = 0; i < M; i++) for (int k = 0; k < M; k++) W[i * M + k] = Bm[i * 2 * M + M + k];
+    }
+    __syncthreads();
+    // z0 = (c - A' W A c) / lambda2 with c = A'y - lambda1 1 and A A' = W^-1 - lambda2 I:
+    //    = A' W y - (lambda1 / lambda2) (1 - A' W A 1)
+    for (int e = threadIdx.x; e < N * M; e += blockDim.x) {
+        const int j = e / M, i = e % M;
+        double acc = 0.0;
+        for (int k = 0; k < M; k++) acc += A[k * 16 + j] * W[k * M + i];
+        G[e] = acc;
+    }
+    for (int j = threadIdx.x; j < 16; j += blockDim.x) {
+        double acc = 0.0;
+        if (j < n_atoms) {
+            double awa = 0.0;
+            for (int i = 0; i < M; i++) {
+                double wi = 0.0;
+                for (int k = 0; k < M; k++) { double a1 = 0.0; for (int jj = 0; jj < n_atoms; jj++) a1 += A[k * 16 + jj]; wi += W[i * M + k] * a1; }
+                awa += A[i * 16 + j] * wi;
+            }
+            acc = -(lam1 / lam2) * (1.0 - awa);
+        }
+        g0[j] = acc;
+    }
+}
+constexpr int kSandiTableWords = 15 * kRowsTs + 15 * 6 + 16;
 
 #ifndef AMX_ROWS_OCC
 #define AMX_ROWS_OCC 2
 #endif
+
 // SANDI, nS == M (<= 8) values per voxel: row-space solver; the dictionary sits in LDS (wave-uniform reads), y comes
 // from the voxel's row.
 template <int M, int N>
@@ -603,13 +558,16 @@ __global__ void __launch_bounds__(256, AMX_ROWS_OCC) k_sandi_rows(const SandiArg
     const Chunk ck = a.c.chunks[cid];
     const int n_atoms = a.c.n_atoms, n_rs = a.n_rs, n_in = a.n_in;
     // the dictionary (M x N doubles, the same for every voxel) in LDS, read with wave-uniform addresses
-    __shared__ double A[M * N];
-    constexpr int ldA = N;
+    __shared__ __attribute__((aligned(16))) double A[M * 16];
+    __shared__ __attribute__((aligned(16))) double Tb[N * kRowsTs + N * M + 16];
+    constexpr int ldA = 16;
     {
         const double *__restrict__ Ag = reinterpret_cast<const double *>(a.c.tiles);
-        for (int e = threadIdx.x; e < M * N; e += blockDim.x) A[e] = ((e % N) < n_atoms) ? Ag[(e / N) * a.c.ldA + (e % N)] : 0.0;
+        for (int e = threadIdx.x; e < M * 16; e += blockDim.x) A[e] = ((e % 16) < n_atoms) ? Ag[(e / 16) * a.c.ldA + (e % 16)] : 0.0;
+        for (int e = threadIdx.x; e < N * kRowsTs + N * M + 16; e += blockDim.x) Tb[e] = a.tables[e];
         __syncthreads();
     }
+    const double *T = Tb, *G = Tb + N * kRowsTs, *g0 = G + N * M;
     const bool warm = amx_warm_start(a.c.lam2, a.c.flags);
     for (int v = threadIdx.x; v < ck.count; v += blockDim.x) {
         const int vox = a.c.perm[ck.start + v];
@@ -630,7 +588,7 @@ __global__ void __launch_bounds__(256, AMX_ROWS_OCC) k_sandi_rows(const SandiArg
             if (a.nrmse) a.nrmse[vox] = nan;
             continue;
         }
-        if (lane_nnqp_rows<M, N>(A, ldA, y, a.c.lam1, a.c.lam2, x, n_atoms, warm) != 0) atomicAdd(&a.c.status[ST_ITCAP], 1);
+        if (lane_nnqp_rows<M, N>(A, ldA, T, G, g0, y, a.c.lam1, a.c.lam2, x, n_atoms, warm) != 0) atomicAdd(&a.c.status[ST_ITCAP], 1);
         // models.pyx:1570-1612
         double x_sum = 0.0, xsph = 0.0, xstk = 0.0, xiso = 0.0, Rsoma = 0.0, Din = 0.0, De = 0.0;
 #pragma unroll
@@ -648,10 +606,10 @@ __global__ void __launch_bounds__(256, AMX_ROWS_OCC) k_sandi_rows(const SandiArg
             for (int j = 0; j < N; j++) if (j < n_atoms) a.c.xdbg[(size_t)vox * n_atoms + j] = x[j];
         }
         x_sum += 1e-16;
-        e[0] = xsph / x_sum; e[1] = xstk / x_sum; e[2] = xiso / x_sum;
-        e[3] = 1e6 * Rsoma / (xsph + 1e-16);
-        e[4] = 1e3 * Din / (xstk + 1e-16);
-        e[5] = 1e3 * De / (xiso + 1e-16);
+        e[0] = fast_div(xsph, x_sum); e[1] = fast_div(xstk, x_sum); e[2] = fast_div(xiso, x_sum);
+        e[3] = 1e6 * fast_div(Rsoma, xsph + 1e-16);
+        e[4] = 1e3 * fast_div(Din, xstk + 1e-16);
+        e[5] = 1e3 * fast_div(De, xiso + 1e-16);
         if (a.rmse || a.nrmse) {
             // quirk kept (models.pyx:1571 then 1615): errors use the RESCALED x with the NORMALISED A
             double rss = 0.0;
@@ -986,7 +944,10 @@ __global__ void __launch_bounds__(256, 2) k_fw_project_mfma(const FwArgs a)
 // ticket and keeps TWO H tables in its LDS block -- lanes still iterating on voxels of the previous sub-chunk keep theirs
 // while the free lanes already take voxels of the next one, so lanes only idle at the very end of the launch (a
 // workgroup-per-chunk version lost a third of its lane-trips to the tail of every chunk).
-constexpr int kSubChunk = 256;
+#ifndef AMX_FW_SUBCHUNK
+#define AMX_FW_SUBCHUNK 256      // (measured: 128 -> 534 us, 256 -> 527 us, 512 -> 540 us for the solver on 2 M voxels)
+#endif
+constexpr int kSubChunk = AMX_FW_SUBCHUNK;
 
 template <int N>
 __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
@@ -1318,6 +1279,26 @@ int amx_launch_fw_small(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s)
     return launch_lane(ctx, a, pl, s, k_freewater_lane<16>, sizeof(float), 16);
 }
 
+// tables of the row-space solver, cached in the dictionary handle for one (lambda1, lambda2)
+int amx_sandi_prepare(amx_ctx *ctx, const amx_lut *lut, SandiArgs &a, hipStream_t s)
+{
+    a.tables = nullptr;
+    if (!(lut->nS == 6 && lut->n_atoms == 15 && a.c.lam2 >= 1e-6)) return AMX_OK;          // other shapes: atom-space kernels
+    if (lut->sandi_lam1 != a.c.lam1 || lut->sandi_lam2 != a.c.lam2 || !lut->sandi_prep) {
+        if (lut->sandi_prep) HIPCHK(ctx, hipDeviceSynchronize());                              // (a fit with the old tables may still run)
+        if (!lut->sandi_prep) HIPCHK(ctx, hipMalloc((void **)&lut->sandi_prep, kSandiTableWords * sizeof(double)));
+        if (!lut->sandi_ready) HIPCHK(ctx, hipEventCreateWithFlags(&lut->sandi_ready, hipEventDisableTiming));
+        hipLaunchKernelGGL((k_sandi_tables<6, 15>), dim3(1), dim3(64), 0, s, reinterpret_cast<const double *>(lut->tiles), lut->ldA,
+                           lut->n_atoms, a.c.lam1, a.c.lam2, lut->sandi_prep);
+        AMX_TRACE(ctx, s, "SANDI dictionary tables");
+        HIPCHK(ctx, hipEventRecord(lut->sandi_ready, s));
+        lut->sandi_lam1 = a.c.lam1; lut->sandi_lam2 = a.c.lam2;
+    }
+    HIPCHK(ctx, hipStreamWaitEvent(s, lut->sandi_ready, 0));
+    a.tables = lut->sandi_prep;
+    return AMX_OK;
+}
+
 int amx_launch_sandi_small(amx_ctx *ctx, SandiArgs &a, const Plan &pl, hipStream_t s)
 {
     const int n = a.c.n_atoms;                // SANDI default: 5 + 5 + 5 = 15 atoms
@@ -1326,6 +1307,7 @@ int amx_launch_sandi_small(amx_ctx *ctx, SandiArgs &a, const Plan &pl, hipStream
     //  2.65 vs 2.29 ms per 1 M voxels: SANDI's optimum is dense, 12 of 15 atoms, so the lanes of a wavefront need
     //  nearly the same number of steps and there is no idle time to win back)
     if (a.c.nS == 6 && n == 15 && a.c.lam2 >= 1e-6 && !getenv("AMX_SANDI_ATOM_SPACE")) {
+        if (!a.tables) { ctx->err = "amx_launch_sandi_small: dictionary tables missing (amx_sandi_prepare)"; return AMX_E_BADARG; }
         rec(ctx, 2, s);
         hipLaunchKernelGGL((k_sandi_rows<6, 15>), dim3(((pl.max_chunks + 7) / 8) * 8), dim3(256), 0, s, a);
         AMX_TRACE(ctx, s, "row-space SANDI solver");
