@@ -79,7 +79,7 @@ def small_model(model, n, steps, warmup, cpu=True):
                                                  est.data_ptr(), None, None, None, None))
         ref = lambda m: oracle.freewater_fit(y_h[:m], d_h[:m], K, htable, nthreads=cores)['estimates']
         name = 'FreeWater fit, %d voxels, 65-volume single shell (1 b0 + 64@b1000), 11 atoms, ndirs=500' % n
-        kernel = 'k_freewater_refill<11>'
+        kernel = 'k_fw_project_mfma<11> + k_freewater_refill<11> (one launch pair per fit: projection c = A\'y on the fp64 matrix cores, then the active-set solver)'
     else:
         full = S.make_sandi_scheme()
         avg = S.directional_average_scheme(full)

@@ -31,7 +31,7 @@ for key, name, cmd in (('fw', 'freewater_2M', '--model freewater --voxels 200000
 out = ['# rocprofv3 --kernel-trace --pmc <set> --output-format csv -- python bench.py --model {freewater --voxels 2000000 | sandi --voxels 1000000 | lut} '
        '--steps 2 --warmup 1; separate passes (never combined with other trace domains); mean per launch',
        '# FETCH_SIZE / WRITE_SIZE in KiB (FETCH_SIZE under-reports wide coalesced reads 2x on gfx950); SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* in quad-cycles']
-for m, pats in (('freewater', ['k_freewater']), ('sandi', ['k_sandi']), ('lut', ['k_lut_resample'])):
+for m, pats in (('freewater', ['k_freewater', 'k_fw_project']), ('sandi', ['k_sandi']), ('lut', ['k_lut_resample'])):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for fn in glob.glob('%s/pmc_%s_*/*/*_counter_collection.csv' % (O, m)):
         for r in csv.DictReader(open(fn)):
@@ -46,16 +46,23 @@ open('profiles/%s_pmc_small.txt' % tag, 'w').write('\n'.join(out) + '\n')
 # per-voxel HBM traffic of the lane kernels -> profiles/pmc_traffic.json (read by bench.py for roofline.traffic)
 import json
 small = {}
-for m, pat, n in (('freewater', 'k_freewater', 2000000), ('sandi', 'k_sandi', 1000000)):
-    acc = collections.defaultdict(list)
+for m, pats, n in (('freewater', ('k_fw_project', 'k_freewater'), 2000000), ('sandi', ('k_sandi',), 1000000)):
+    # a fit may be several kernels (FreeWater: projection + solver): per-launch means per kernel, summed over the kernels
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
     for fn in glob.glob('%s/pmc_%s_*/*/*_counter_collection.csv' % (O, m)):
         for r in csv.DictReader(open(fn)):
-            if pat in r['Kernel_Name']:
-                acc[r['Counter_Name']].append(float(r['Counter_Value']))
-    if 'FETCH_SIZE' in acc and 'WRITE_SIZE' in acc:
-        mean = lambda v: sum(v) / len(v)
-        small[m] = {'voxels_per_launch': n, 'bytes_per_voxel_measured': (2 * mean(acc['FETCH_SIZE']) + mean(acc['WRITE_SIZE'])) * 1024 / n,
-                    'valu_insts_per_voxel': mean(acc['SQ_INSTS_VALU']) / n,
+            for pat in pats:
+                if pat in r['Kernel_Name']:
+                    per[pat][r['Counter_Name']].append(float(r['Counter_Value']))
+    mean = lambda v: sum(v) / len(v)
+    tot = collections.defaultdict(float)
+    for pat in per:
+        for c, v in per[pat].items():
+            tot[c] += mean(v)
+    if 'FETCH_SIZE' in tot and 'WRITE_SIZE' in tot:
+        small[m] = {'voxels_per_launch': n, 'bytes_per_voxel_measured': (2 * tot['FETCH_SIZE'] + tot['WRITE_SIZE']) * 1024 / n,
+                    'valu_insts_per_voxel': tot['SQ_INSTS_VALU'] / n, 'kernels': sorted(per),
+                    'mfma_busy_quad_cycles': tot.get('SQ_VALU_MFMA_BUSY_CYCLES'), 'mfma_f64_mops': tot.get('SQ_INSTS_VALU_MFMA_MOPS_F64'),
                     '_source': 'profiles/%s_pmc_small.txt; bytes = 2 * FETCH_SIZE + WRITE_SIZE (KiB), see _correction' % tag}
 try:
     t = json.load(open('profiles/pmc_traffic.json'))
