@@ -363,8 +363,7 @@ __global__ void __launch_bounds__(256) k_sandi_lane(const SandiArgs a)
 //   T [N][kRowsTs]  packed lower triangles of a_j a_j'          (B is summed from them: no +- drift, half the arithmetic)
 //   G [N][M], g0 [N]  z0 = G y + g0 = the unconstrained optimum on the FULL set (G = A' (lambda2 I + A A')^-1)
 // Warm start: SANDI's optimum is dense (12 of 15 atoms), so the method starts from P0 = {z0 > 0} -- the full-set solve and
-// the first block removal are one tabulated map -- keeps dropping the non-positive coefficients in blocks until the solve
-// is feasible, then continues as Lawson-Hanson (add the most violating atom, step back when infeasible).  With lambda2 > 0
+// the first block removal are one tabulated map -- and continues by block principal pivoting (below).  With lambda2 > 0
 // the optimum is unique, so the path does not matter; the result satisfies the KKT conditions to 1e-12.
 constexpr int kRowsTs = 22;                // stride of T: 21 entries of the 6 x 6 triangle, padded for 16-byte reads
 
@@ -376,7 +375,7 @@ __device__ __forceinline__ int lane_nnqp_rows(const double *__restrict__ A, int 
     static_assert(M * (M + 1) / 2 <= kRowsTs, "triangle of a_j a_j' fits its table row");
     constexpr int kTri = M * (M + 1) / 2;
     const double tol = 1e-12, il2 = 1.0 / lam2;
-    double c[N], z[N];
+    double c[N];
     unsigned P = 0u;
     AMX_RELOAD();
 #pragma unroll
@@ -388,7 +387,8 @@ __device__ __forceinline__ int lane_nnqp_rows(const double *__restrict__ A, int 
         c[j] = sc;
         if (warm && j < n_atoms && sz > 0.0) P |= 1u << j;
     }
-    bool blocks = warm && P != 0u;           // still in the block-removal phase
+    constexpr int kBackup = 3;               // block exchanges allowed without progress (Kim & Park)
+    int ninf = N + 1, backup = 0;
     for (int it = 0;; ++it) {
         if (it > 4 * N + 16) return 2;
         double B[kTri], L[kTri], li[M], w[M];
@@ -436,51 +436,27 @@ __device__ __forceinline__ int lane_nnqp_rows(const double *__restrict__ A, int 
             w[j] = sacc * li[j];
         }
         AMX_RELOAD();
-        unsigned negm = 0u;
-        double best = -__builtin_huge_val();
-        int t_in = -1;
+        // block principal pivoting: passive atoms with a non-positive coefficient leave, inactive atoms with a positive dual
+        // value enter, all at once while the number of infeasibilities keeps falling (then kBackup more times); otherwise only
+        // the infeasible atom with the largest index is exchanged (Murty's rule).  Cold start: single exchanges only.
+        unsigned v1 = 0u, v2 = 0u;
 #pragma unroll
         for (int j = 0; j < N; j++) {
             double g = c[j];
 #pragma unroll
             for (int i = 0; i < M; i++) g -= A[i * ldA + j] * w[i];
             const bool pj = (P >> j) & 1u;
-            z[j] = g * il2;
-            if (pj && !(g > 0.0)) negm |= 1u << j;
-            if (!pj && j < n_atoms && g > best) { best = g; t_in = j; }
+            x[j] = pj ? g * il2 : 0.0;
+            if (pj && !(g > 0.0)) v1 |= 1u << j;
+            if (!pj && j < n_atoms && g > tol) v2 |= 1u << j;
         }
-        if (negm == 0u) {
-            // feasible: accept, then KKT test / next atom on the dual values that came with the solve
-#pragma unroll
-            for (int j = 0; j < N; j++) x[j] = ((P >> j) & 1u) ? z[j] : 0.0;
-            blocks = false;
-            if (!(best > tol)) return 0;
-            if (it > 3 * N + 8) return 2;
-            P |= 1u << t_in;
-        } else if (blocks) {
-            P &= ~negm;                                          // (x is still 0)
-            if (P == 0u) blocks = false;
-        } else {
-            // step back: alpha = min x_j / (x_j - z_j) over the non-positive z_j, by cross multiplication (one division)
-            double xb = 1.0, db = 0.0;
-            int jm = -1;
-#pragma unroll
-            for (int j = 0; j < N; j++) {
-                if ((negm >> j) & 1u) {
-                    const double den = x[j] - z[j];
-                    const double xn = (den > 0.0) ? x[j] : 0.0, dn = (den > 0.0) ? den : 1.0;
-                    if (jm < 0 || xn * db < xb * dn) { xb = xn; db = dn; jm = j; }
-                }
-            }
-            const double alpha = fast_div(xb, db);
-#pragma unroll
-            for (int j = 0; j < N; j++) {
-                if ((P >> j) & 1u) {
-                    x[j] += alpha * (z[j] - x[j]);
-                    if (j == jm || !(x[j] > 0.0)) { x[j] = 0.0; P &= ~(1u << j); }
-                }
-            }
-        }
+        const unsigned bad = v1 | v2;
+        if (bad == 0u) return 0;                                   // KKT point: x holds the solution
+        const int nbad = __builtin_popcount(bad);
+        bool block = false;
+        if (nbad < ninf) { ninf = nbad; backup = warm ? kBackup : 0; block = warm; }
+        else if (backup > 0) { backup--; block = true; }
+        P ^= block ? bad : (1u << (31 - __builtin_clz(bad)));
     }
 }
 
