@@ -116,3 +116,50 @@ def test_device_wrappers_reject_mismatched_buffers(htable500):
     est, _, _, _ = _capi.noddi_fit_device(ctx, lut, yt, dt, 0.5, 1e-3, 3)
     ctx.sync()
     assert est.shape == (64, 3)
+
+
+def test_small_model_kernels_edge_shapes(htable500):
+    """the round-2 FreeWater / SANDI kernels (projection + persistent solver, table-driven row-space solver): tiny and ragged
+    voxel counts, one single orientation, a non-finite voxel, lambda1 > 0, lambda2 changed between calls on the same
+    dictionary (the cached per-orientation tables are rebuilt), Mouse (12 atoms: two table pieces)"""
+    from amico_amd import _capi, get_context, synthetic as S
+    from oracle import oracle
+    ctx = get_context()
+    ht = htable500['htable']
+    s1 = S.make_scheme(1, ((1000.0, 64),), seed=3)
+    Kf = S.freewater_kernels(s1, htable500['dirs'])
+    lf = _capi.upload_freewater(ctx, Kf, ht)
+    yf, df = S.freewater_signals(700, Kf, ht, s1, seed=12)
+    for n in (1, 63, 65, 257, 700):
+        for lam1, lam2 in ((0.0, 1e-3), (0.05, 2e-2), (0.0, 1e-3)):
+            got = _capi.freewater_fit(ctx, lf, yf[:n], df[:n], lam1, lam2, False)[0]
+            ref = oracle.freewater_fit(yf[:n], df[:n], Kf, ht, lambda1=lam1, lambda2=lam2)['estimates']
+            assert np.abs(got - ref).max() < 1e-8, (n, lam1, lam2)
+    same = np.repeat(df[:1], 300, axis=0)                      # one orientation: one bucket, several sub-chunks
+    got = _capi.freewater_fit(ctx, lf, yf[:300], same, 0.0, 1e-3, False)[0]
+    ref = oracle.freewater_fit(yf[:300], same, Kf, ht)['estimates']
+    assert np.abs(got - ref).max() < 1e-8
+    yb = yf[:130].copy()
+    yb[7, 3] = np.nan
+    yb[129, 64] = np.inf
+    got = _capi.freewater_fit(ctx, lf, yb, df[:130], 0.0, 1e-3, False)[0]
+    ref = oracle.freewater_fit(yf[:130], df[:130], Kf, ht)['estimates']
+    assert np.isnan(got[7]).all() and np.isnan(got[129]).all()
+    ok = np.ones(130, bool); ok[[7, 129]] = False
+    assert np.abs(got[ok] - ref[ok]).max() < 1e-8
+    Km = S.freewater_kernels(s1, htable500['dirs'], d_isos=(2.0e-3, 3.0e-3))
+    lm = _capi.upload_freewater(ctx, Km, ht)
+    ym, dm = S.freewater_signals(321, Km, ht, s1, seed=5)
+    got = _capi.freewater_fit(ctx, lm, ym, dm, 0.0, 1e-3, True)[0]
+    ref = oracle.freewater_fit(ym, dm, Km, ht, is_mouse=True)['estimates']
+    assert got.shape == (321, 4) and np.abs(got - ref).max() < 1e-8
+    avg = S.directional_average_scheme(S.make_sandi_scheme())
+    Ks, Rs, d_in, d_isos = S.sandi_kernels(avg)
+    ls = _capi.upload_sandi(ctx, Ks, Rs, d_in, d_isos)
+    ys = S.sandi_signals(600, Ks, avg, seed=6)
+    for n in (1, 65, 600):
+        for lam1, lam2 in ((0.0, 5e-3), (0.01, 5e-2), (0.0, 5e-3)):
+            got = _capi.sandi_fit(ctx, ls, ys[:n], lam1, lam2)[0]
+            ref = oracle.sandi_fit(ys[:n], Ks, Rs, d_in, d_isos, lambda1=lam1, lambda2=lam2)['estimates']
+            scale = np.maximum(np.abs(ref), 1.0)
+            assert (np.abs(got - ref) / scale).max() < 1e-7, (n, lam1, lam2)
