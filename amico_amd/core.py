@@ -141,6 +141,27 @@ class Evaluation:
         if self.model is not None:
             self.model.scheme = self.scheme
 
+    def generate_kernels(self, lut_dirs, out_path=None, lmax=12):
+        """core.py:328-372 `generate_kernels`: response functions of the model on the high-resolution scheme (500 directions
+        per shell) -> SH coefficients rotated to every LUT orientation.  Writes `A_###.npy` under `out_path` when given and
+        returns the list of arrays (what `load_kernels` takes as `in_path`).  `lut_dirs` [ndirs, 3]: the LUT orientations."""
+        from . import lut as _lut
+        if self.model is None:
+            raise RuntimeError('Model not set; call "set_model()" method first')
+        if self.scheme is None:
+            raise RuntimeError('Scheme not loaded; call "set_data()" first')
+        t = time.time()
+        self.model.scheme = self.scheme
+        lut_dirs = np.asarray(lut_dirs, dtype=np.float64)
+        aux = _lut.aux_matrices(lmax, lut_dirs)
+        idx_in, idx_out = _lut.aux_structures_generate(self.scheme, lmax)
+        if out_path is not None:
+            import os
+            os.makedirs(out_path, exist_ok=True)
+        lms = self.model.generate(out_path, aux, idx_in, idx_out, len(lut_dirs))
+        self.set_config('generate_kernels_time', time.time() - t)
+        return lms
+
     def load_kernels(self, in_path, lut_dirs, lmax=12):
         """core.py:374-404 `load_kernels`: resample the rotated SH coefficients (folder of A_###.npy files written by
         generate_kernels, or the list of arrays) to this subject's scheme -- one GEMM on the GPU -- and set KERNELS /

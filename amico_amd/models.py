@@ -43,9 +43,24 @@ class BaseModel(ABC):
     def set_solver(self):
         self.solver_params = {}
 
+    # ---- response functions on the high-resolution scheme -> rotated SH coefficients (models.pyx:444-477, 727-751, 1088-1110,
+    #      1414-1444).  `_atoms()` yields (signal on the high-resolution scheme, is_isotropic) in the order of the A_###.npy files.
+    def _atoms(self, scheme_high):
+        raise NotImplementedError
+
     def generate(self, out_path, aux, idx_in, idx_out, ndirs):
-        raise NotImplementedError('response-function synthesis is outside the MI355X path (one-off per protocol, '
-                                  'amico/synthesis.py); amico_amd.lut.rotate_kernel rotates a synthesised kernel')
+        """response functions (amico_amd.synthesis) -> lut.rotate_kernel -> `A_%03d.npy` under `out_path` (skipped when
+        out_path is None); returns the list of arrays, which `resample` / `Evaluation.load_kernels` accept directly"""
+        from . import lut as _lut
+        scheme_high = _lut.high_resolution_scheme(self.scheme, aux['grad'])
+        lms = []
+        for i, (signal, isotropic) in enumerate(self._atoms(scheme_high)):
+            lm = _lut.rotate_kernel(signal, aux, idx_in, idx_out, isotropic, ndirs)
+            if out_path is not None:
+                from os.path import join as pjoin
+                np.save(pjoin(out_path, f'A_{i + 1:03d}.npy'), lm)
+            lms.append(lm)
+        return lms
 
     # ---- resampling of the rotated SH coefficients to the subject's scheme (models.pyx:754-792, 1113-1144,
     #      1446-1486): `in_path` is the reference's folder of A_###.npy files or a list of the arrays themselves.
@@ -182,6 +197,19 @@ class CylinderZeppelinBall(BaseModel):
         self.solver_params['lambda1'] = lambda1
         self.solver_params['lambda2'] = lambda2
 
+    def _atoms(self, scheme_high):
+        """models.pyx:444-477"""
+        from . import synthesis as syn
+        if self.scheme.version != 1:
+            raise RuntimeError('This model requires a "VERSION: STEJSKALTANNER" scheme')
+        cylinder, zeppelin, ball = syn.CylinderGPD(scheme_high), syn.Zeppelin(scheme_high), syn.Ball(scheme_high)
+        for R in self.Rs:
+            yield cylinder.get_signal(self.d_par, R), False
+        for d in self.d_perps:
+            yield zeppelin.get_signal(self.d_par, d), False
+        for d in self.d_isos:
+            yield ball.get_signal(d), True
+
     def resample(self, in_path, idx_out, Ylm_out, doMergeB0, ndirs):
         """models.pyx:480-522"""
         n_r, n_p, n_i = len(self.Rs), len(self.d_perps), len(self.d_isos)
@@ -252,6 +280,17 @@ class NODDI(BaseModel):
         super().set_solver()
         self.solver_params['lambda1'] = lambda1
         self.solver_params['lambda2'] = lambda2
+
+    def _atoms(self, scheme_high):
+        """models.pyx:727-751: one atom per (kappa, v_ic) -- v_ic * intra-cellular + (1 - v_ic) * extra-cellular, the orientation
+        dispersion index mapped to the Watson concentration kappa = 1 / tan(OD pi / 2) -- then the isotropic atom"""
+        from . import synthesis as syn
+        ic, ec, iso = syn.NODDIIntraCellular(scheme_high), syn.NODDIExtraCellular(scheme_high), syn.NODDIIsotropic(scheme_high)
+        for kappa in 1.0 / np.tan(np.asarray(self.IC_ODs) * np.pi / 2.0):
+            signal_ic = ic.get_signal(self.dPar, kappa)
+            for v_ic in self.IC_VFs:
+                yield v_ic * signal_ic + (1.0 - v_ic) * ec.get_signal(self.dPar, kappa, v_ic), False
+        yield iso.get_signal(self.dIso), True
 
     def resample(self, in_path, idx_out, Ylm_out, doMergeB0, ndirs):
         """models.pyx:754-792"""
@@ -336,6 +375,15 @@ class FreeWater(BaseModel):
         # NB: the reference assigns lambda2 = 0.25 for Mouse to a dead local (models.pyx:1082-1085):
         # it has no effect there and therefore none here.
 
+    def _atoms(self, scheme_high):
+        """models.pyx:1088-1110"""
+        from . import synthesis as syn
+        zeppelin, ball = syn.Zeppelin(scheme_high), syn.Ball(scheme_high)
+        for d in self.d_perps:
+            yield zeppelin.get_signal(self.d_par, d), False
+        for d in self.d_isos:
+            yield ball.get_signal(d), True
+
     def resample(self, in_path, idx_out, Ylm_out, doMergeB0, ndirs):
         """models.pyx:1113-1144"""
         n_t, n_i = len(self.d_perps), len(self.d_isos)
@@ -405,6 +453,19 @@ class SANDI(BaseModel):
         super().set_solver()
         self.solver_params['lambda1'] = lambda1
         self.solver_params['lambda2'] = lambda2
+
+    def _atoms(self, scheme_high):
+        """models.pyx:1407-1444: all three compartments are isotropic (soma = sphere, neurites = astrosticks, extra-cellular = ball)"""
+        from . import synthesis as syn
+        if self.scheme.version != 1:
+            raise RuntimeError('This model requires a "VERSION: STEJSKALTANNER" scheme')
+        sphere, sticks, ball = syn.SphereGPD(scheme_high), syn.Astrosticks(scheme_high), syn.Ball(scheme_high)
+        for R in self.Rs:
+            yield sphere.get_signal(self.d_is, R), True
+        for d in self.d_in:
+            yield sticks.get_signal(d), True
+        for d in self.d_isos:
+            yield ball.get_signal(d), True
 
     def resample(self, in_path, idx_out, Ylm_out, doMergeB0, ndirs):
         """models.pyx:1446-1486: isotropic atoms, each scaled to unit norm"""

@@ -442,3 +442,46 @@ def test_evaluation_freewater_corrected_dwi(htable500):
     assert vol.shape == img.shape and not vol[:, :, 0].any()
     assert np.allclose(vol[sel], yc.astype(np.float32), rtol=1e-5, atol=1e-3)
     assert np.allclose(vol[sel][:, sch.b0_idx], img[sel][:, sch.b0_idx], rtol=1e-6)      # b0 volumes intact
+
+
+def test_whole_chain_generate_load_fit(htable500, tmp_path):
+    """the reference's user flow without the reference: set_data -> set_model -> generate_kernels (response functions, SH
+    rotation) -> load_kernels (GPU resampling) -> fit.  The data are synthesised from the generated dictionary itself (one atom
+    + free water per voxel, noise-free), so the fit must return the atom's own parameters"""
+    import amico_amd
+    from amico_amd import synthetic as S
+    lut_dirs = htable500['dirs']
+    sch = S.make_scheme(seed=0)
+    ae = amico_amd.Evaluation()
+    shape = (12, 10, 4)
+    n = int(np.prod(shape))
+    ae.set_data(np.ones(shape + (sch.nS,), dtype=np.float32), sch, np.ones(shape, dtype=np.uint8))
+    ae.set_model('NODDI')
+    lms = ae.generate_kernels(lut_dirs, out_path=str(tmp_path / 'kernels'))
+    assert len(lms) == 145 and (tmp_path / 'kernels' / 'A_145.npy').exists()
+    ae.load_kernels(str(tmp_path / 'kernels'), lut_dirs)                # from the files, like the reference
+    K = ae.KERNELS
+    assert K['wm'].shape == (144, len(lut_dirs), sch.nS) and K['iso'].shape == (sch.nS,)
+    ae2 = amico_amd.Evaluation()
+    ae2.set_data(np.ones(shape + (sch.nS,), dtype=np.float32), sch, np.ones(shape, dtype=np.uint8))
+    ae2.set_model('NODDI')
+    ae2.load_kernels(lms, lut_dirs)                                     # ... or from the arrays
+    assert np.array_equal(ae2.KERNELS['wm'], K['wm'])
+    rng = np.random.default_rng(5)
+    atom = rng.integers(0, 144, n)
+    ori = rng.integers(0, len(lut_dirs), n)
+    f_iso = rng.uniform(0.05, 0.4, n)
+    y = (1.0 - f_iso)[:, None] * K['wm'][atom, ori, :].astype(np.float64) + f_iso[:, None] * K['iso'][None, :].astype(np.float64)
+    peaks = lut_dirs[ori].reshape(shape + (3,))
+    ae.set_data((1000.0 * y).reshape(shape + (sch.nS,)).astype(np.float32), sch, np.ones(shape, dtype=np.uint8), directions=peaks)
+    ae.fit()
+    maps = ae.RESULTS['MAPs'].reshape(n, 3)
+    od = np.repeat(ae.model.IC_ODs, len(ae.model.IC_VFs))[atom]
+    vf = np.tile(ae.model.IC_VFs, len(ae.model.IC_ODs))[atom]
+    # (the LUT cell of a peak may belong to a neighbouring orientation: require the bulk, not every voxel)
+    good = (np.abs(maps[:, 0] - vf) < 2e-3) & (np.abs(maps[:, 2] - f_iso) < 2e-3)
+    assert good.mean() > 0.9, good.mean()
+    kappa = 1.0 / np.tan(od * np.pi / 2.0)
+    # (strongly dispersed atoms of equal volume fraction are nearly collinear: NNLS may mix two orientation dispersions there)
+    odi_ok = np.abs(maps[good, 1] - 2.0 / np.pi * np.arctan2(1.0, kappa[good])) < 5e-3
+    assert odi_ok.mean() > 0.9, odi_ok.mean()
