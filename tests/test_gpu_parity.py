@@ -292,6 +292,15 @@ def test_other_protocol_shapes(htable500):
     out3 = FreeWater().fit(Holder(y3, d3, ht, K3))
     ref3 = oracle.freewater_fit(y3, d3, K3, ht, nthreads=8)
     assert np.abs(out3['estimates'] - ref3['estimates']).max() < TOL
+    # (d) FreeWater protocol lengths around the tiling of the projection kernel: 16 values per LDS tile (17 = one tile + a
+    #     remainder row, 64 = whole tiles only, 81 = five tiles + one), 97 and 130 > 96 volumes (VALU projection / lane kernel)
+    for nd in (16, 63, 80, 96, 129):
+        schd = S.make_scheme(1, ((1000.0, nd),), seed=nd)
+        Kd = S.freewater_kernels(schd, dirs)
+        yd, dd = S.freewater_signals(900, Kd, ht, schd, seed=nd + 1)
+        outd = FreeWater().fit(Holder(yd, dd, ht, Kd))
+        refd = oracle.freewater_fit(yd, dd, Kd, ht, nthreads=8)
+        assert np.abs(outd['estimates'] - refd['estimates']).max() < TOL, nd
 
 
 def test_small_models_both_mappings(fw_fix, sandi_fix, htable500, monkeypatch):
