@@ -566,6 +566,120 @@ __global__ __launch_bounds__(256) void k_lut_resample(const float *__restrict__ 
     }
 }
 
+// The same GEMM with BOTH operands in LDS (plain `lm` input, K even, operator + four row tiles <= 160 KB): what limited
+// k_lut_resample was not the matrix pipe but its left operand -- every lane walking its own 728-byte row of L with 8-byte
+// loads (64 cache lines per load instruction: 59 % of the wavefronts' time, matrix pipe 18 % busy).  32 consecutive rows of L
+// are ONE contiguous 23 KB block, so a wavefront streams its tile global -> LDS with direct 16-byte loads (23 instructions,
+// all in flight at once) and reads the MFMA operand from there; the row stride K = 182 floats puts 32 consecutive rows into
+// 32 different even banks, for the tile and for the operator alike, so neither needs padding or a swizzle.  A row is read up
+// to 4 KH2 - K floats beyond its end (the next row: finite values); the left operand is forced to zero there.
+#ifdef AMX_LUT_PHASES
+__device__ unsigned long long g_lut_ph[8];
+#define LPH_T() __builtin_readcyclecounter()
+#define LPH_ADD(k, t0) ph[k] += __builtin_readcyclecounter() - (t0)
+#else
+#define LPH_T() 0ull
+#define LPH_ADD(k, t0) (void)(t0)
+#endif
+template <int KH2>
+__global__ __launch_bounds__(256) void k_lut_resample_tile(const float *__restrict__ L, const float *__restrict__ Y,
+                                                           const int *__restrict__ idx_out, long long M, int K, int N, int nS,
+                                                           float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_t[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, l32 = lane & 31;
+#ifdef AMX_LUT_PHASES
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_all = LPH_T();
+#endif
+    unsigned long long t0 = LPH_T();
+    // LDS: Ys [N][K] (+ a zeroed tail of 1056 B) | per wavefront: Lt [32][K]
+    float *Ys = reinterpret_cast<float *>(smem_t);
+    const long long ybytes = (long long)N * K * 4;
+    const long long yzone = ((ybytes + 1023) & ~1023LL) + 2048;      // the copy's last piece ends inside; rows N .. N + 31 start inside or behind
+    const long long tile_bytes = 32LL * K * 4, tile_stride = (tile_bytes + 1023) & ~1023LL;      // whole 1 KB pieces per wavefront
+    float *Lt = reinterpret_cast<float *>(smem_t + yzone + wave * tile_stride);
+    {
+        const int pieces = (int)((ybytes + 1023) >> 10);
+        for (int p = wave; p < pieces; p += 4) {
+            long long off = ((long long)p << 10) + lane * 16;
+            if (off > ybytes - 16) off = ybytes - 16;                 // (the tail lanes of the last piece repeat its last 16 bytes)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const char *>(Y) + off,
+                                             (__attribute__((address_space(3))) void *)(smem_t + ((long long)p << 10)), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // behind the last row of the operator: zeros (the over-read of row N - 1 and the rows N .. of the last column block)
+        for (long long pos = ybytes / 4 + threadIdx.x; pos < yzone / 4; pos += blockDim.x) Ys[pos] = 0.0f;
+        __syncthreads();
+    }
+    LPH_ADD(0, t0);
+    // the tile of rows m0 .. m0 + 31 -> this wavefront's LDS block (whole 1 KB pieces; the tail lanes of the last piece repeat
+    // its last 16 bytes, which land in the slack behind the tile)
+    auto load_tile = [&](long long m0) {
+        const long long rows = (M - m0) < 32 ? (M - m0) : 32;
+        const long long bytes = rows * K * 4;
+        const char *src = reinterpret_cast<const char *>(L + m0 * K);
+        const int pieces = (int)(tile_stride >> 10);
+#pragma unroll 4
+        for (int p = 0; p < pieces; p++) {
+            long long off = ((long long)p << 10) + lane * 16;
+            if (off > bytes - 16) off = bytes - 16;
+            __builtin_amdgcn_global_load_lds(src + off, (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(Lt) + ((long long)p << 10)),
+                                             16, 0, 0);
+        }
+    };
+    // (measured alternatives, both slower than this plain order at 0.053 ms: issuing the next tile's loads behind the last
+    //  block's MFMAs so that they overlap the stores -- 0.064 ms; advancing all column blocks together with one read of the left
+    //  operand per K-step -- 0.060 ms: the stores of a block then no longer overlap the MFMAs of the next one)
+    const long long m_first = ((long long)blockIdx.x * 4 + wave) * 32, m_step = (long long)gridDim.x * 128;
+    for (long long m0 = m_first; m0 < M; m0 += m_step) {
+        t0 = LPH_T();
+        load_tile(m0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (also: the previous tile's stores are out)
+        LPH_ADD(1, t0);
+        const float2 *arow = reinterpret_cast<const float2 *>(Lt + (size_t)l32 * K + 2 * half * KH2);
+        for (int n0 = 0; n0 < N; n0 += 32) {
+            t0 = LPH_T();
+            const float2 *yrow = reinterpret_cast<const float2 *>(Ys + (size_t)(n0 + l32) * K + 2 * half * KH2);
+            floatx16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < KH2; j++) {
+                const int k = 2 * half * KH2 + 2 * j;
+                float2 a2 = arow[j];
+                const float2 b2 = yrow[j];
+                if (2 * KH2 + 2 * j >= K) {                          // (compile-time position: only the last columns of the second half)
+                    a2.x = (k < K) ? a2.x : 0.0f;
+                    a2.y = (k + 1 < K) ? a2.y : 0.0f;
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, b2.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, b2.y, acc, 0, 0, 0);
+            }
+            LPH_ADD(2, t0); t0 = LPH_T();
+            const int n = n0 + l32;
+            if (n < N) {
+                const int col = idx_out[n];
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const long long r = m0 + 8 * (i / 4) + 4 * half + (i % 4);
+                    if (r < M) out[r * nS + col] = acc[i];
+                }
+            }
+            LPH_ADD(3, t0);
+        }
+#ifdef AMX_LUT_PHASES
+        ph[5] += 1;
+#endif
+    }
+#ifdef AMX_LUT_PHASES
+    ph[7] = LPH_T() - t_all;
+    if (lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_lut_ph[k], ph[k]);
+#endif
+}
+
 // Generic shapes (more than 256 reduction indices, or an SH -> signal operator beyond the LDS: SANDI's 5 shells x 91
 // coefficients x 300 volumes): one wavefront = 32 rows of L against 32 columns at a time, operands straight from L2.  The reduction
 // index is split in two halves, one per half-wavefront (lane l works on k = (l / 32) * Kh + j), so that every lane
@@ -616,6 +730,24 @@ static int lut_gemm(amx_ctx *ctx, const float *d_lm, const float *d_z, const flo
     const int kh2 = (n_sh + 3) / 4;
     const int kh2t = kh2 <= 23 ? 23 : (kh2 <= 46 ? 46 : 64);         // compile-time reduction lengths: 1 / 2 shells of lmax 12, <= 256
     const size_t lds = (size_t)((n_out + 31) & ~31) * (4 * kh2t + 2) * sizeof(float);
+    // both operands in LDS: plain input, even K, operator zone + four row tiles within the 160 KB of a CU
+    const size_t yzone = ((((size_t)n_out * n_sh * 4) + 1023) & ~(size_t)1023) + 2048;
+    const size_t lds_tile = yzone + 4 * ((((size_t)32 * n_sh * 4) + 1023) & ~(size_t)1023);
+    if (d_lm && (n_sh & 1) == 0 && n_sh <= 4 * amx::kLutKhMax && 4 * kh2t - n_sh <= 4 && lds_tile <= 160 * 1024 && !getenv("AMX_LUT_REGS")) {
+        auto launch = [&](auto kern) -> int {
+            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile));
+            long long blocks = (n_rows + 127) / 128;
+            if (blocks > ctx->n_cu) blocks = ctx->n_cu;              // persistent, one workgroup per CU: the operator is staged once
+            rec(ctx, 8, nullptr);
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_tile, nullptr, d_lm, d_ylm, d_idx, (long long)n_rows, n_sh,
+                               n_out, nS, (float *)ctx->hextra.p);
+            return AMX_OK;
+        };
+        if (kh2t == 23) rc = launch(amx::k_lut_resample_tile<23>);
+        else if (kh2t == 46) rc = launch(amx::k_lut_resample_tile<46>);
+        else rc = launch(amx::k_lut_resample_tile<64>);
+        if (rc) return rc;
+    } else
     if (n_sh > 4 * amx::kLutKhMax || lds > 80 * 1024) {              // generic shapes: operands from L2
         if (!d_lm) return amx_bad(ctx, "amx_lut_rotate_resample: shape beyond the fused kernel (K <= 256, operator <= 80 KB)");
         rec(ctx, 8, nullptr);
@@ -697,3 +829,12 @@ extern "C" int amx_lut_rotate_resample(amx_ctx *ctx, const float *zonal, int n_a
     HIPCHK(ctx, hipStreamSynchronize(nullptr));
     return AMX_OK;
 }
+
+#ifdef AMX_LUT_PHASES
+extern "C" int amx_debug_lut_phases(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(amx::g_lut_ph), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(amx::g_lut_ph), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
