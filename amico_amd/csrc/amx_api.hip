@@ -598,6 +598,7 @@ int amx_czb_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, cons
     a.c.lutidx = pl.lutidx; a.c.status = ctx->status_d; a.c.nS = lut->nS; a.c.ldA = lut->ldA;
     a.c.n_atoms = lut->n_atoms; a.c.tile_stride = lut->tile_stride; a.c.lam1 = lambda1; a.c.lam2 = lambda2; a.c.flags = flags;
     a.n_rs = lut->n_rs; a.n_perp = lut->n_perp; a.Rs = lut->Rs; a.gram = lut->gram; a.ldG = lut->ldG;
+    { const char *e = getenv("AMX_COLD_START"); if (e && *e && *e != '0') a.c.flags |= 0x80000000u; }
     if (flags & AMX_F_DEBUG_X) {
         if (!ctx->dbg_x) return bad(ctx, "amx_czb_fit: AMX_F_DEBUG_X without a buffer (amx_set_debug_x)");
         a.c.xdbg = ctx->dbg_x + (size_t)ctx->vox_base * lut->n_atoms;

@@ -88,6 +88,90 @@ struct GramSolver {
         refactor(lane);
     }
 
+    // append atom t (scale sct, s * A'y = uyt) as slot np: new row of H_PP and of its Cholesky factor; false if the atom is
+    // numerically dependent on the passive ones (cannot happen with lambda2 > 0: d2 >= lambda2)
+    __device__ __forceinline__ bool append(int t, double sct, double uyt, double lam1, double lam2, int lane, const double *__restrict__ G, int ldG)
+    {
+        const int ls = row(lane);
+        const double h = (lane < np) ? sc * sct * G[(size_t)idx * ldG + t] : 0.0;
+        const double htt = sct * sct * G[(size_t)t * ldG + t] + lam2;
+        double hh = h;
+        for (int k = 0; k < np; k++) {
+            const double lk_ = Ll[ls + k];
+            const double lk = bcast(hh * linv, k);
+            if (lane > k) hh -= lk_ * lk;
+        }
+        const double lrow = (lane < np) ? hh * linv : 0.0;           // lane k's hh is final after step k
+        const double d2 = htt - wave_sum(lrow * lrow);
+        if (!uni(d2 > 1e-13 * htt)) return false;
+        const int kn = np;
+        const double iv = inv_sqrt(d2);
+        if (lane < kn) { Hl[tri(kn, lane)] = h; Ll[tri(kn, lane)] = lrow; }
+        if (lane == kn) {
+            Hl[tri(kn, kn)] = htt; Ll[tri(kn, kn)] = d2 * iv; linv = iv;
+            x = 0.0; xprev = 0.0; sc = sct; idx = t; cs = sct * uyt - lam1;
+        }
+        np = kn + 1;
+        return true;
+    }
+
+    // Dense optima (strong ridge -- CylinderZeppelinBall: lambda2 = 4, 22 of 26 atoms): block principal pivoting from the FULL
+    // set instead of one Lawson-Hanson addition per atom.  n_atoms <= 64, one atom per lane in atom space (NQ == 1), unit column
+    // scales.  Every step rebuilds the factor by appending the atoms of P in ascending order (O(np^2) LDS steps in total), solves,
+    // forms the dual vector from the Gram columns and exchanges ALL infeasible atoms (passive with a non-positive coefficient,
+    // inactive with a positive dual value) while their number keeps falling, then `kBackup` more times, else only the one with
+    // the largest index (Murty's rule: finite for a positive definite H).  Leaves np / idx / x like solve().
+    __device__ __forceinline__ int solve_dense(const AT *As, int ldA, int nS, int n_atoms, const double (&yr)[NR], double lam1,
+                                               double lam2, double *rs, double *rl, int lane, const double *__restrict__ G, int ldG)
+    {
+        static_assert(NQ == 1, "one atom per lane");
+        Hl = rl;
+        Ll = rl + kTri;
+        const double tol = 1e-12;
+        constexpr int kBackup = 3;
+        iters = 0; n_exact = 1; n_gram = 0;
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) rs[lane + kWave * rr] = yr[rr];
+        double uy = 0.0;                                             // lane j: a_j'y (lanes >= n_atoms: unused)
+        if (lane < n_atoms)
+            for (int i = 0; i < nS; i++) uy += (double)As[i * ldA + lane] * rs[i];
+        const double cj = uy - lam1;
+        unsigned long long P = n_atoms >= 64 ? ~0ull : ((1ull << n_atoms) - 1ull);
+        int ninf = n_atoms + 1, backup = 0, status = kSolved;
+        for (int it = 0;; ++it) {
+            if (it > 4 * n_atoms + 16) { status = kIterCap; break; }
+            np = 0; x = 0.0; xprev = 0.0; sc = 1.0; cs = 0.0; linv = 0.0; idx = -1;
+            for (unsigned long long rem = P; rem != 0ull; rem &= rem - 1ull) {
+                const int t = __builtin_ctzll(rem);
+                if (np >= MAXP) return kOverflow;
+                if (!append(t, 1.0, bcast(uy, t), lam1, lam2, lane, G, ldG)) P &= ~(1ull << t);
+            }
+            const double z = solve_passive(lane);
+            iters++;
+            double g = cj;                                            // dual value of atom `lane`: c_j - sum_s G[j][atom_s] z_s
+            for (int s = 0; s < np; s++) {
+                const int as = bcast_i(idx, s);
+                const double zs = bcast(z, s);
+                g -= G[(size_t)as * ldG + lane] * zs;
+            }
+            n_gram++;
+            const bool in_p = (P >> lane) & 1ull;
+            const int rank = __builtin_popcountll(P & ((1ull << lane) - 1ull));       // slot of atom `lane`
+            const double za = __shfl(z, rank);
+            const bool v1 = in_p && !(za > 0.0);
+            const bool v2 = !in_p && lane < n_atoms && g > tol;
+            const unsigned long long bad = ballot64(v1 || v2);
+            x = z;
+            if (bad == 0ull) break;                                   // KKT point
+            const int nbad = __builtin_popcountll(bad);
+            bool block = false;
+            if (nbad < ninf) { ninf = nbad; backup = kBackup; block = true; }
+            else if (backup > 0) { backup--; block = true; }
+            P ^= block ? bad : (1ull << (63 - __builtin_clzll(bad)));
+        }
+        return status;
+    }
+
     // G: Gram matrix A'A of this orientation restricted to the rows in rowok (REQUIRED here)
     __device__ __forceinline__ int solve(const AT *As, int ldA, int nS, int n_atoms, const double (&yr)[NR],
                                          const bool (&rowok)[NR], const double (&scl)[NQ],

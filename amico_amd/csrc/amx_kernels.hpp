@@ -463,7 +463,7 @@ struct CzbArgs {
 };
 
 template <int NR, int NQ, int MAXP>
-__device__ __forceinline__ void czb_voxel(const CzbArgs &a, const float *As, double *rs, double *rl, int vox, int dir, int lane)
+__device__ __forceinline__ void czb_voxel(const CzbArgs &a, const float *As, double *rs, double *rl, int vox, const double *gdir, int lane)
 {
     const int nS = a.c.nS, ldA = a.c.ldA, n_atoms = a.c.n_atoms, n_rs = a.n_rs, n_perp = a.n_perp;
     double yr[NR];
@@ -486,9 +486,16 @@ __device__ __forceinline__ void czb_voxel(const CzbArgs &a, const float *As, dou
     }
     if (ok) {
     GramSolver<NR, NQ, MAXP, float> S;
-    const double *gdir = a.gram + (size_t)dir * n_atoms * a.ldG;
-    const int st = __builtin_amdgcn_readfirstlane(S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed, a.c.lam1, a.c.lam2,
-                                                          rs, rl, lane, gdir, a.ldG));
+    // strong ridge, dense optimum: block principal pivoting from the full set; otherwise (or AMX_COLD_START) Lawson-Hanson
+    const bool dense = NQ == 1 && n_atoms <= MAXP && a.c.lam2 >= 1e-2 && !(a.c.flags & 0x80000000u);
+    int st_;
+    if constexpr (NQ == 1) {
+        st_ = dense ? S.solve_dense(As, ldA, nS, n_atoms, yr, a.c.lam1, a.c.lam2, rs, rl, lane, gdir, a.ldG)
+                    : S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed, a.c.lam1, a.c.lam2, rs, rl, lane, gdir, a.ldG);
+    } else {
+        st_ = S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed, a.c.lam1, a.c.lam2, rs, rl, lane, gdir, a.ldG);
+    }
+    const int st = __builtin_amdgcn_readfirstlane(st_);
     if (st == kOverflow) {
         if (lane == 0) { const int k = atomicAdd(a.c.ovf_count, 1); a.c.ovf_list[k] = vox; }
     } else {
@@ -687,9 +694,14 @@ __global__ void __launch_bounds__(NW * 64) k_czb(const CzbArgs a)
         unsigned *ticket = reinterpret_cast<unsigned *>(wm_all + nw_ * 4);
         if (threadIdx.x == 0) *ticket = (unsigned)nw_;
         stage_tile<float>(As, tiles + (size_t)ck.dir * a.c.tile_stride, words, words_pad - words);
+        // the Gram matrix of the orientation (n_atoms x ldG doubles: 13 KB for 26 atoms) next to the tile: the solver reads a
+        // column per passive atom and step
+        double *Gs = reinterpret_cast<double *>(ticket + 4);
+        const double *gsrc = a.gram + (size_t)ck.dir * a.c.n_atoms * a.ldG;
+        for (int e = threadIdx.x; e < a.c.n_atoms * a.ldG; e += blockDim.x) Gs[e] = gsrc[e];
         __syncthreads();
         for (int k = wave; k < ck.count; k = next_ticket(ticket, lane)) {   // LDS voxel ticket, see k_noddi
-            czb_voxel<NR, NQ, MAXP>(a, As, rs, rl, a.c.perm[ck.start + k], ck.dir, lane);
+            czb_voxel<NR, NQ, MAXP>(a, As, rs, rl, a.c.perm[ck.start + k], Gs, lane);
         }
     } else {
         const int cnt = *a.c.list_count;
@@ -698,7 +710,7 @@ __global__ void __launch_bounds__(NW * 64) k_czb(const CzbArgs a)
             __syncthreads();
             stage_tile<float>(As, tiles + (size_t)a.c.lutidx[vox] * a.c.tile_stride, words, words_pad - words);
             __syncthreads();
-            czb_voxel<NR, NQ, MAXP>(a, As, rs, rl, vox, a.c.lutidx[vox], lane);
+            czb_voxel<NR, NQ, MAXP>(a, As, rs, rl, vox, a.gram + (size_t)a.c.lutidx[vox] * a.c.n_atoms * a.ldG, lane);
         }
     }
 }
