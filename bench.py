@@ -80,6 +80,33 @@ def small_model(model, n, steps, warmup, cpu=True):
         ref = lambda m: oracle.freewater_fit(y_h[:m], d_h[:m], K, htable, nthreads=cores)['estimates']
         name = 'FreeWater fit, %d voxels, 65-volume single shell (1 b0 + 64@b1000), 11 atoms, ndirs=500' % n
         kernel = 'k_fw_project_mfma<11> + k_freewater_refill<11> (one launch pair per fit: projection c = A\'y on the fp64 matrix cores, then the active-set solver)'
+    elif model == 'czb':
+        # CylinderZeppelinBall (SURVEY 8 row a-M; not a BASELINE config): dictionary generated + resampled by this repository
+        # (amico_amd.synthesis -> lut.rotate_kernel -> amx_lut_resample) on a 3-shell STEJSKALTANNER scheme
+        import amico_amd
+        scheme = S.make_sandi_scheme(bvals=(1000., 2500., 4000.), ndir_per_shell=30, n_b0=3)
+        ae = amico_amd.Evaluation()
+        ae.set_data(np.ones((2, 2, 2, scheme.nS), dtype=np.float32), scheme, np.ones((2, 2, 2), dtype=np.uint8))
+        ae.set_model('CylinderZeppelinBall')
+        ae.load_kernels(ae.generate_kernels(lut_dirs), lut_dirs)
+        K, Rs_ = ae.KERNELS, ae.model.Rs
+        rng = np.random.default_rng(1)
+        ori = rng.integers(0, len(lut_dirs), n)
+        a1, a2 = rng.integers(0, K['wmr'].shape[0], n), rng.integers(0, K['wmh'].shape[0], n)
+        f = rng.dirichlet([2, 2, 1], n)
+        y_h = (f[:, :1] * K['wmr'][a1, ori] + f[:, 1:2] * K['wmh'][a2, ori] + f[:, 2:] * K['iso'][0][None, :]).astype(np.float64)
+        y_h = np.sqrt((y_h + rng.normal(0, 1 / 30, y_h.shape)) ** 2 + rng.normal(0, 1 / 30, y_h.shape) ** 2)
+        d_h = np.ascontiguousarray(lut_dirs[ori])
+        lut = _capi.upload_czb(ctx, K, Rs_, htable)
+        y = torch.from_numpy(y_h).to(dev); d = torch.from_numpy(d_h).to(dev)
+        est = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+        bpv = 8 * scheme.nS + 24 + 24
+
+        def step():
+            ctx.check(L.amx_czb_fit_device(ctx._h, lut._h, y.data_ptr(), d.data_ptr(), n, 0.0, 4.0, 0, est.data_ptr(), None, None, None))
+        ref = lambda m: oracle.czb_fit(y_h[:m], d_h[:m], K, Rs_, htable, nthreads=cores)['estimates']
+        name = 'CylinderZeppelinBall fit, %d voxels, %d volumes (3 shells), 26 atoms, ndirs=500' % (n, scheme.nS)
+        kernel = 'k_czb<2, 1, 32, 8, false>'
     else:
         full = S.make_sandi_scheme()
         avg = S.directional_average_scheme(full)
@@ -456,8 +483,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--voxels', type=int, default=1_000_000, help='voxels per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-other-configs', action='store_true', help='headline only: skip configs 3 / 4 (FreeWater 2 M, SANDI 1 M) and the host-buffer legs of the default run')
-    ap.add_argument('--model', default='noddi', choices=['noddi', 'freewater', 'sandi', 'dti', 'prep', 'lut', 'pipeline'],
+    ap.add_argument('--no-other-configs', action='store_true', help='headline only: skip configs 3 / 4 (FreeWater 2 M, SANDI 1 M), CylinderZeppelinBall and the host-buffer legs of the default run')
+    ap.add_argument('--model', default='noddi', choices=['noddi', 'freewater', 'sandi', 'czb', 'dti', 'prep', 'lut', 'pipeline'],
                     help='noddi = the BASELINE.json headline; the others are extra measurements (configs 3, 4)')
     args = ap.parse_args()
     if args.model == 'dti':
@@ -615,6 +642,7 @@ def main():
                 torch.cuda.empty_cache()
                 other['freewater_2M'] = small_model('freewater', 2_000_000, 5, 2, cpu=not args.no_cpu_baseline)
                 other['sandi_1M'] = small_model('sandi', 1_000_000, 5, 2, cpu=not args.no_cpu_baseline)
+                other['czb_500k'] = small_model('czb', 500_000, 5, 2, cpu=not args.no_cpu_baseline)
             if other:
                 out['other_configs'] = other
         print(json.dumps(out))
