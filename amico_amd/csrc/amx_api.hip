@@ -508,7 +508,7 @@ int amx_freewater_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y
     Plan pl; int rc;
     if ((rc = make_plan(ctx, n_vox, lut->ndirs, pl))) return rc;
     rec(ctx, 0, s);
-    const bool refill = amx_use_lane_solver(lut->n_atoms, lambda2) && amx_fw_use_refill(lut->n_atoms, lut->nS, flags);
+    const bool refill = amx_use_lane_solver(lut->n_atoms, lambda2) && amx_fw_use_refill(lut->n_atoms, lut->nS, flags, lambda2);
     if ((rc = enqueue_bucketing(ctx, lut, d_dirs, n_vox, pl, s, refill ? amx_refill_chunk(n_vox) : kChunk))) return rc;
     FwArgs a;
     memset(&a, 0, sizeof a);

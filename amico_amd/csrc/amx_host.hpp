@@ -189,8 +189,13 @@ static inline int amx_refill_chunk(long long n_vox)
     const long long c = n_vox / 1536;
     return (int)(c < 512 ? 512 : (c > 2048 ? 2048 : c));
 }
-static inline bool amx_fw_use_refill(int n_atoms, int nS, unsigned flags)
+static inline bool amx_cold_start_env() { const char *e = getenv("AMX_COLD_START"); return e && *e && *e != '0'; }
+// (the projection + block-pivoting kernels assume the warm start: with lambda2 < 1e-5, or AMX_COLD_START=1, the fit goes to the
+//  Lawson-Hanson lane kernels -- single exchanges from the empty set, which is all block pivoting could do there, ran into
+//  the iteration cap on 15 % of the voxels at lambda2 = 1e-6)
+static inline bool amx_fw_use_refill(int n_atoms, int nS, unsigned flags, double lam2)
 {
+    if (!amx_warm_start(lam2, flags) || amx_cold_start_env()) return false;
     const char *e = getenv("AMX_NO_REFILL"), *w = getenv("AMX_WAVE_PER_VOXEL");
     if ((e && *e && *e != '0') || (w && *w && *w != '0')) return false;
     return n_atoms <= 12 && (flags & (AMX_F_RMSE | AMX_F_NRMSE | AMX_F_CORRECTED)) == 0 &&

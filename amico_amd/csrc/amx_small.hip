@@ -438,7 +438,8 @@ __device__ __forceinline__ int lane_nnqp_rows(const double *__restrict__ A, int 
         AMX_RELOAD();
         // block principal pivoting: passive atoms with a non-positive coefficient leave, inactive atoms with a positive dual
         // value enter, all at once while the number of infeasibilities keeps falling (then kBackup more times); otherwise only
-        // the infeasible atom with the largest index is exchanged (Murty's rule).  Cold start: single exchanges only.
+        // the infeasible atom with the largest index is exchanged (Murty's rule).  (Launched with the warm start only: smaller
+        // lambda2 / AMX_COLD_START=1 go to k_sandi_lane's Lawson-Hanson loop, amx_launch_sandi_small.)
         unsigned v1 = 0u, v2 = 0u;
 #pragma unroll
         for (int j = 0; j < N; j++) {
@@ -1058,7 +1059,8 @@ __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
         // infeasible atom with the largest index is exchanged (Murty's rule, which terminates on its own).  The unique
         // KKT point is reached in 2.9 solves per voxel from P0 (3.2 for block removals followed by Lawson-Hanson steps; the
         // longest voxel needs 7 instead of 14), and no coefficient vector has to survive from one trip to the next.
-        // Cold start (lambda2 < 1e-5: H may be nearly singular): single exchanges only.
+        // (The kernel is only launched with the warm start: for lambda2 < 1e-5, where H may be nearly singular, and for
+        // AMX_COLD_START=1 the fit goes to k_freewater_lane's Lawson-Hanson loop -- amx_fw_use_refill.)
         bool done = false;
         if (active && !(c[0] == c[0])) done = true;             // non-finite signal: NaN maps, never iterate
         const bool slv = active && !done;
@@ -1218,7 +1220,7 @@ int amx_launch_fw_small(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s)
 {
     // compile-time dictionary sizes: the reference's defaults (11 Human, 12 Mouse) exactly, 16 otherwise
     const int n = a.c.n_atoms;
-    if (amx_fw_use_refill(n, a.c.nS, a.c.flags)) {
+    if (amx_fw_use_refill(n, a.c.nS, a.c.flags, a.c.lam2)) {
         if (n <= 11) return launch_refill(ctx, a, pl, s, k_fw_project<11>, k_fw_project_mfma<11>, k_freewater_refill<11>, 11);
         return launch_refill(ctx, a, pl, s, k_fw_project<12>, k_fw_project_mfma<12>, k_freewater_refill<12>, 12);
     }
@@ -1231,7 +1233,7 @@ int amx_launch_fw_small(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s)
 int amx_sandi_prepare(amx_ctx *ctx, const amx_lut *lut, SandiArgs &a, hipStream_t s)
 {
     a.tables = nullptr;
-    if (!(lut->nS == 6 && lut->n_atoms == 15 && a.c.lam2 >= 1e-6)) return AMX_OK;          // other shapes: atom-space kernels
+    if (!(lut->nS == 6 && lut->n_atoms == 15 && amx_warm_start(a.c.lam2, a.c.flags))) return AMX_OK;   // other shapes / cold start: atom-space kernels
     if (lut->sandi_lam1 != a.c.lam1 || lut->sandi_lam2 != a.c.lam2 || !lut->sandi_prep) {
         if (lut->sandi_prep) HIPCHK(ctx, hipDeviceSynchronize());                              // (a fit with the old tables may still run)
         if (!lut->sandi_prep) HIPCHK(ctx, hipMalloc((void **)&lut->sandi_prep, kSandiTableWords * sizeof(double)));
@@ -1254,7 +1256,7 @@ int amx_launch_sandi_small(amx_ctx *ctx, SandiArgs &a, const Plan &pl, hipStream
     // (a refill variant of this kernel -- lanes drawing the next voxel from a global counter -- was measured SLOWER,
     //  2.65 vs 2.29 ms per 1 M voxels: SANDI's optimum is dense, 12 of 15 atoms, so the lanes of a wavefront need
     //  nearly the same number of steps and there is no idle time to win back)
-    if (a.c.nS == 6 && n == 15 && a.c.lam2 >= 1e-6 && !getenv("AMX_SANDI_ATOM_SPACE")) {
+    if (a.c.nS == 6 && n == 15 && amx_warm_start(a.c.lam2, a.c.flags) && !getenv("AMX_SANDI_ATOM_SPACE")) {
         if (!a.tables) { ctx->err = "amx_launch_sandi_small: dictionary tables missing (amx_sandi_prepare)"; return AMX_E_BADARG; }
         rec(ctx, 2, s);
         hipLaunchKernelGGL((k_sandi_rows<6, 15>), dim3(((pl.max_chunks + 7) / 8) * 8), dim3(256), 0, s, a);

@@ -131,7 +131,8 @@ def test_small_model_kernels_edge_shapes(htable500):
     lf = _capi.upload_freewater(ctx, Kf, ht)
     yf, df = S.freewater_signals(700, Kf, ht, s1, seed=12)
     for n in (1, 63, 65, 257, 700):
-        for lam1, lam2 in ((0.0, 1e-3), (0.05, 2e-2), (0.0, 1e-3)):
+        # (lambda2 = 1e-6 is below the warm-start threshold: Lawson-Hanson lane kernel instead of block pivoting)
+        for lam1, lam2 in ((0.0, 1e-3), (0.05, 2e-2), (0.0, 1e-6), (0.0, 1e-3)):
             got = _capi.freewater_fit(ctx, lf, yf[:n], df[:n], lam1, lam2, False)[0]
             ref = oracle.freewater_fit(yf[:n], df[:n], Kf, ht, lambda1=lam1, lambda2=lam2)['estimates']
             assert np.abs(got - ref).max() < 1e-8, (n, lam1, lam2)
@@ -158,7 +159,7 @@ def test_small_model_kernels_edge_shapes(htable500):
     ls = _capi.upload_sandi(ctx, Ks, Rs, d_in, d_isos)
     ys = S.sandi_signals(600, Ks, avg, seed=6)
     for n in (1, 65, 600):
-        for lam1, lam2 in ((0.0, 5e-3), (0.01, 5e-2), (0.0, 5e-3)):
+        for lam1, lam2 in ((0.0, 5e-3), (0.01, 5e-2), (0.0, 2e-6), (0.0, 5e-3)):
             got = _capi.sandi_fit(ctx, ls, ys[:n], lam1, lam2)[0]
             ref = oracle.sandi_fit(ys[:n], Ks, Rs, d_in, d_isos, lambda1=lam1, lambda2=lam2)['estimates']
             scale = np.maximum(np.abs(ref), 1.0)
