@@ -164,3 +164,29 @@ def test_small_model_kernels_edge_shapes(htable500):
             ref = oracle.sandi_fit(ys[:n], Ks, Rs, d_in, d_isos, lambda1=lam1, lambda2=lam2)['estimates']
             scale = np.maximum(np.abs(ref), 1.0)
             assert (np.abs(got - ref) / scale).max() < 1e-7, (n, lam1, lam2)
+
+
+def test_small_models_pipelined_host_path(htable500):
+    """>= 524 288 voxels from host buffers travel in batches on two streams with separate workspace sets (the FreeWater hand-over
+    buffers and the cached per-orientation tables included): the maps must be those of the one-launch device-resident call"""
+    import torch
+    from amico_amd import _capi, get_context, synthetic as S
+    ctx = get_context()
+    dev = torch.device('cuda', 0)
+    n = 600_000
+    s1 = S.make_scheme(1, ((1000.0, 64),), seed=3)
+    Kf = S.freewater_kernels(s1, htable500['dirs'])
+    yf, df = S.freewater_signals(n, Kf, htable500['htable'], s1, seed=21)
+    lf = _capi.upload_freewater(ctx, Kf, htable500['htable'])
+    host = _capi.freewater_fit(ctx, lf, yf, df, 0.0, 1e-3, False)[0]
+    devr = _capi.freewater_fit_device(ctx, lf, torch.from_numpy(yf).to(dev), torch.from_numpy(df).to(dev), 0.0, 1e-3, False)[0]
+    ctx.sync()
+    assert np.array_equal(host, devr.cpu().numpy())
+    avg = S.directional_average_scheme(S.make_sandi_scheme())
+    Ks, Rs, d_in, d_isos = S.sandi_kernels(avg)
+    ys = S.sandi_signals(n, Ks, avg, seed=22)
+    ls = _capi.upload_sandi(ctx, Ks, Rs, d_in, d_isos)
+    host = _capi.sandi_fit(ctx, ls, ys, 0.0, 5e-3)[0]
+    devr = _capi.sandi_fit_device(ctx, ls, torch.from_numpy(ys).to(dev), 0.0, 5e-3)[0]
+    ctx.sync()
+    assert np.array_equal(host, devr.cpu().numpy())
