@@ -11,7 +11,7 @@
  * status (0 = ok, negative = error, see AMX_E_*); the library never keeps host pointers
  * after a call returns; device memory is owned by amx_ctx / amx_lut handles.
  * Arrays use the reference's layouts and dtypes (C-order, float64 signals / maps).
- * Threading: calls on one amx_ctx (and on the amx_lut handles made from it) are serialised by the caller, like the
+ * Threading: the calls on one context, and on the dictionary handles made from it, are serialised by the caller, like the
  * reference's single `model.fit` call per Evaluation; the FreeWater / SANDI handles cache small per-dictionary tables for the
  * last (lambda1, lambda2) they were fitted with and rebuild them when the solver parameters change.
  */
