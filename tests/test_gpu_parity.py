@@ -494,3 +494,49 @@ def test_whole_chain_generate_load_fit(htable500, tmp_path):
     # (strongly dispersed atoms of equal volume fraction are nearly collinear: NNLS may mix two orientation dispersions there)
     odi_ok = np.abs(maps[good, 1] - 2.0 / np.pi * np.arctan2(1.0, kappa[good])) < 5e-3
     assert odi_ok.mean() > 0.9, odi_ok.mean()
+
+
+def test_whole_chain_freewater_and_sandi(htable500):
+    """generate_kernels -> load_kernels -> fit for the other two BASELINE models: the generated dictionaries must equal the
+    independently written signal-space dictionaries of amico_amd.synthetic to the lmax = 12 truncation, and the
+    fit on it must agree with the CPU oracle"""
+    import amico_amd
+    from amico_amd import synthetic as S
+    lut_dirs = htable500['dirs']
+    rng = np.random.default_rng(9)
+    # FreeWater: b-value scheme
+    sch = S.make_scheme(1, ((1000.0, 64),), seed=3)
+    shape = (10, 10, 4)
+    n = int(np.prod(shape))
+    ae = amico_amd.Evaluation()
+    ae.set_data(np.ones(shape + (sch.nS,), dtype=np.float32), sch, np.ones(shape, dtype=np.uint8))
+    ae.set_model('FreeWater')
+    ae.load_kernels(ae.generate_kernels(lut_dirs), lut_dirs)
+    K = ae.KERNELS
+    Kd = S.freewater_kernels(sch, lut_dirs)
+    assert np.abs(K['D'] - Kd['D']).max() < 2e-3 and np.abs(K['CSF'] - Kd['CSF']).max() < 1e-5
+    ori, atom, fw = rng.integers(0, len(lut_dirs), n), rng.integers(0, 10, n), rng.uniform(0.1, 0.6, n)
+    y = (1.0 - fw)[:, None] * K['D'][atom, ori].astype(np.float64) + fw[:, None] * K['CSF'][0][None, :].astype(np.float64)
+    ae.set_data((1000.0 * y).reshape(shape + (sch.nS,)).astype(np.float32), sch, np.ones(shape, dtype=np.uint8),
+                directions=lut_dirs[ori].reshape(shape + (3,)))
+    ae.fit()
+    got = ae.RESULTS['MAPs'].reshape(n, 2)
+    # (the mixing fraction itself is not identifiable -- the slowest zeppelin is a ball too: the fit is checked against the CPU
+    #  oracle on the same generated dictionary; float32 maps in RESULTS)
+    from oracle import oracle
+    ref = oracle.freewater_fit(ae.y, ae.DIRs, K, ae.htable, nthreads=8)['estimates']
+    assert np.abs(got - ref.astype(np.float32)).max() < 1e-5
+    assert np.abs(got[:, 0] + got[:, 1] - 1.0).max() < 1e-6 and (got[:, 1] > 0.02).mean() > 0.95
+    # SANDI: STEJSKALTANNER scheme, shell averages
+    full = S.make_sandi_scheme(ndir_per_shell=16, n_b0=2)
+    ae = amico_amd.Evaluation()
+    ae.set_config('doDirectionalAverage', True)
+    shape = (8, 8, 4)
+    n = int(np.prod(shape))
+    ae.set_data(np.ones(shape + (full.nS,), dtype=np.float32), full, np.ones(shape, dtype=np.uint8))
+    ae.set_model('SANDI')
+    ae.load_kernels(ae.generate_kernels(lut_dirs), lut_dirs)
+    Ks = ae.KERNELS
+    Kref = S.sandi_kernels(ae.scheme)[0]
+    assert np.abs(np.asarray(Ks['signal']) - np.asarray(Kref['signal'])).max() < 1e-5
+    assert np.abs(np.asarray(Ks['norms']) - np.asarray(Kref['norms'])).max() < 1e-4 * np.abs(np.asarray(Kref['norms'])).max()
