@@ -147,6 +147,20 @@ def small_model(model, n, steps, warmup, cpu=True):
                         'kernel': kernel, 'kernel_ms': kms, 'bytes_per_voxel': bpv},
            'parity': {'sample_voxels': m, 'max_abs_dmap': float(diff.max()), 'max_rel_dmap': float(rel.max())},
            'solver_stats': ctx.last_stats()}
+    if model in ('freewater', 'sandi'):
+        # host numpy in -> host numpy out (pageable memory; PCIe inclusive): the batches of the pipelined entry points hide the
+        # solver behind the copies here, so this is a PCIe figure, reported beside the kernels' rate, never as `value`
+        hb = {}
+        for tag, yy in (('f64', y_h), ('f32', y_h.astype(np.float32))):
+            call = (lambda: _capi.freewater_fit(ctx, lut, yy, d_h, 0.0, 1e-3, False)) if model == 'freewater' else \
+                   (lambda: _capi.sandi_fit(ctx, lut, yy, 0.0, 5e-3))
+            call()
+            ts = []
+            for _ in range(3):
+                t1 = time.perf_counter(); call(); ts.append(time.perf_counter() - t1)
+            hb[tag] = {'value': n / float(np.median(ts)), 'unit': 'voxels/s', 'ms_per_call': 1e3 * float(np.median(ts)),
+                       'GB_per_s_uploaded': yy.nbytes / float(np.median(ts)) / 1e9}
+        out['host_buffers'] = hb
     if cpu:
         oracle.use_fast_build(True)
         mc = n
