@@ -8,7 +8,7 @@ static int go(amx_ctx *ctx, CzbArgs &a, const Plan &pl, hipStream_t s)
     constexpr int NQ = 1, MP = 32, MB = 64;      // 26 atoms by default: the main kernel's passive set holds them all
     constexpr int NW = 8;
     return launch_pair<NW>(ctx, a, pl, s, k_czb<NR, NQ, MP, NW, false>, k_czb<NR, NQ, MB, 1, true>,
-                           [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MP, true) + (size_t)a.c.n_atoms * a.ldG * sizeof(double) + 16; },
+                           [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MP, true) + ((size_t)a.c.n_atoms * a.ldG + (size_t)(MP + 1) * (MP + 2) + MP + 1) * sizeof(double) + 16; },
                            fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, true), 0, 2);
 }
 

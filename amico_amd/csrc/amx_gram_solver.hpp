@@ -121,8 +121,20 @@ struct GramSolver {
     // forms the dual vector from the Gram columns and exchanges ALL infeasible atoms (passive with a non-positive coefficient,
     // inactive with a positive dual value) while their number keeps falling, then `kBackup` more times, else only the one with
     // the largest index (Murty's rule: finite for a positive definite H).  Leaves np / idx / x like solve().
+    // Cholesky factor of the FULL set -- the same for every voxel of an orientation: built once per workgroup by one wavefront
+    // into Lf [kTri] / lf_inv [MAXP] (Hf [kTri]: scratch), read by the first step of solve_dense
+    __device__ __forceinline__ void factor_full(int n_atoms, double lam2, double *Hf, double *Lf, double *lf_inv, int lane,
+                                                const double *__restrict__ G, int ldG)
+    {
+        Hl = Hf; Ll = Lf;
+        np = 0; x = 0.0; xprev = 0.0; sc = 1.0; cs = 0.0; linv = 0.0; idx = -1;
+        for (int t = 0; t < n_atoms && t < MAXP; t++) append(t, 1.0, 0.0, 0.0, lam2, lane, G, ldG);
+        if (lane < MAXP) lf_inv[lane] = (lane < np) ? linv : 0.0;
+    }
+
     __device__ __forceinline__ int solve_dense(const AT *As, int ldA, int nS, int n_atoms, const double (&yr)[NR], double lam1,
-                                               double lam2, double *rs, double *rl, int lane, const double *__restrict__ G, int ldG)
+                                               double lam2, double *rs, double *rl, int lane, const double *__restrict__ G, int ldG,
+                                               const double *Lf = nullptr, const double *lf_inv = nullptr)
     {
         static_assert(NQ == 1, "one atom per lane");
         Hl = rl;
@@ -140,11 +152,22 @@ struct GramSolver {
         int ninf = n_atoms + 1, backup = 0, status = kSolved;
         for (int it = 0;; ++it) {
             if (it > 4 * n_atoms + 16) { status = kIterCap; break; }
-            np = 0; x = 0.0; xprev = 0.0; sc = 1.0; cs = 0.0; linv = 0.0; idx = -1;
-            for (unsigned long long rem = P; rem != 0ull; rem &= rem - 1ull) {
-                const int t = __builtin_ctzll(rem);
-                if (np >= MAXP) return kOverflow;
-                if (!append(t, 1.0, bcast(uy, t), lam1, lam2, lane, G, ldG)) P &= ~(1ull << t);
+            if (it == 0 && Lf != nullptr) {
+                // the full set: slot s = atom s, factor shared by the workgroup (read-only)
+                Ll = const_cast<double *>(Lf);
+                np = n_atoms;
+                const bool act = lane < np;
+                idx = act ? lane : -1; sc = 1.0; x = 0.0; xprev = 0.0;
+                cs = act ? cj : 0.0;
+                linv = act ? lf_inv[lane] : 0.0;
+            } else {
+                Hl = rl; Ll = rl + kTri;
+                np = 0; x = 0.0; xprev = 0.0; sc = 1.0; cs = 0.0; linv = 0.0; idx = -1;
+                for (unsigned long long rem = P; rem != 0ull; rem &= rem - 1ull) {
+                    const int t = __builtin_ctzll(rem);
+                    if (np >= MAXP) return kOverflow;
+                    if (!append(t, 1.0, bcast(uy, t), lam1, lam2, lane, G, ldG)) P &= ~(1ull << t);
+                }
             }
             const double z = solve_passive(lane);
             iters++;

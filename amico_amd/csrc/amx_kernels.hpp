@@ -463,7 +463,8 @@ struct CzbArgs {
 };
 
 template <int NR, int NQ, int MAXP>
-__device__ __forceinline__ void czb_voxel(const CzbArgs &a, const float *As, double *rs, double *rl, int vox, const double *gdir, int lane)
+__device__ __forceinline__ void czb_voxel(const CzbArgs &a, const float *As, double *rs, double *rl, int vox, const double *gdir, int lane,
+                                          const double *Lf = nullptr, const double *lf_inv = nullptr)
 {
     const int nS = a.c.nS, ldA = a.c.ldA, n_atoms = a.c.n_atoms, n_rs = a.n_rs, n_perp = a.n_perp;
     double yr[NR];
@@ -490,7 +491,7 @@ __device__ __forceinline__ void czb_voxel(const CzbArgs &a, const float *As, dou
     const bool dense = NQ == 1 && n_atoms <= MAXP && a.c.lam2 >= 1e-2 && !(a.c.flags & 0x80000000u);
     int st_;
     if constexpr (NQ == 1) {
-        st_ = dense ? S.solve_dense(As, ldA, nS, n_atoms, yr, a.c.lam1, a.c.lam2, rs, rl, lane, gdir, a.ldG)
+        st_ = dense ? S.solve_dense(As, ldA, nS, n_atoms, yr, a.c.lam1, a.c.lam2, rs, rl, lane, gdir, a.ldG, Lf, lf_inv)
                     : S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed, a.c.lam1, a.c.lam2, rs, rl, lane, gdir, a.ldG);
     } else {
         st_ = S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed, a.c.lam1, a.c.lam2, rs, rl, lane, gdir, a.ldG);
@@ -700,8 +701,17 @@ __global__ void __launch_bounds__(NW * 64) k_czb(const CzbArgs a)
         const double *gsrc = a.gram + (size_t)ck.dir * a.c.n_atoms * a.ldG;
         for (int e = threadIdx.x; e < a.c.n_atoms * a.ldG; e += blockDim.x) Gs[e] = gsrc[e];
         __syncthreads();
+        // ... and the Cholesky factor of the full passive set (the first step of every voxel's block pivoting), by wavefront 0
+        constexpr int kTriF = (MAXP + 1) * (MAXP + 2) / 2;
+        double *Hf = Gs + (size_t)a.c.n_atoms * a.ldG, *Lf = Hf + kTriF, *lf_inv = Lf + kTriF;
+        const bool dense_ = a.c.n_atoms <= MAXP && a.c.lam2 >= 1e-2 && !(a.c.flags & 0x80000000u);
+        if (dense_ && wave == 0) {
+            GramSolver<NR, NQ, MAXP, float> F;
+            F.factor_full(a.c.n_atoms, a.c.lam2, Hf, Lf, lf_inv, lane, Gs, a.ldG);
+        }
+        __syncthreads();
         for (int k = wave; k < ck.count; k = next_ticket(ticket, lane)) {   // LDS voxel ticket, see k_noddi
-            czb_voxel<NR, NQ, MAXP>(a, As, rs, rl, a.c.perm[ck.start + k], Gs, lane);
+            czb_voxel<NR, NQ, MAXP>(a, As, rs, rl, a.c.perm[ck.start + k], Gs, lane, dense_ ? Lf : nullptr, lf_inv);
         }
     } else {
         const int cnt = *a.c.list_count;
