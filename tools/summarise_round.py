@@ -8,19 +8,29 @@ O = 'gpurun_out/prof_%s' % tag
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def head_stamp():
+    """git HEAD (+ 'dirty' when amico_amd/ or bench.py differ from it) of the tree the profile was taken from: the collection
+    and this summary run back to back on the same working tree, so a stale summary is visible"""
+    g = lambda *a: subprocess.run(['git', '-C', ROOT] + list(a), capture_output=True, text=True).stdout.strip()
+    dirty = g('status', '--porcelain', '--', 'amico_amd', 'bench.py')
+    return '# source tree: git %s%s\n' % (g('rev-parse', '--short', 'HEAD'), ' + uncommitted changes in: ' + ', '.join(l.split()[-1] for l in dirty.splitlines()) if dirty else '')
+
+
 def stats(db):
     return subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'rocpd_summary.py'), db], capture_output=True, text=True).stdout
 
 
 with open('profiles/%s_kernel_stats_noddi_1M.txt' % tag, 'w') as f:
+    f.write(head_stamp())
     f.write('# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline (NODDI 1 M voxels)\n')
     f.write(stats(O + '/noddi/noddi_results.db'))
 with open('profiles/%s_kernel_stats_dti_prep.txt' % tag, 'w') as f:
+    f.write(head_stamp())
     f.write('# rocprofv3 --kernel-trace --stats -- python bench.py --model dti --steps 5 --warmup 1\n')
     f.write(stats(O + '/dti/dti_results.db'))
     f.write('\n# rocprofv3 --kernel-trace --stats -- python bench.py --model prep --steps 5 --warmup 1 (F order first, then C order)\n')
     f.write(stats(O + '/prep/prep_results.db'))
-out = ['# rocprofv3 --kernel-trace --pmc <set> --output-format csv -- python bench.py [--model ...] --steps 3 --warmup 1; '
+out = [head_stamp().rstrip(), '# rocprofv3 --kernel-trace --pmc <set> --output-format csv -- python bench.py [--model ...] --steps 3 --warmup 1; '
        'separate passes; mean per launch']
 
 

@@ -8,6 +8,14 @@ O = 'gpurun_out/small_%s' % tag
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def head_stamp():
+    """git HEAD (+ 'dirty' when amico_amd/ or bench.py differ from it) of the tree the profile was taken from: the collection
+    and this summary run back to back on the same working tree, so a stale summary is visible"""
+    g = lambda *a: subprocess.run(['git', '-C', ROOT] + list(a), capture_output=True, text=True).stdout.strip()
+    dirty = g('status', '--porcelain', '--', 'amico_amd', 'bench.py')
+    return '# source tree: git %s%s\n' % (g('rev-parse', '--short', 'HEAD'), ' + uncommitted changes in: ' + ', '.join(l.split()[-1] for l in dirty.splitlines()) if dirty else '')
+
+
 def stats(db):
     return subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'rocpd_summary.py'), db], capture_output=True, text=True).stdout
 
@@ -25,10 +33,11 @@ for key, name, cmd in (('fw', 'freewater_2M', '--model freewater --voxels 200000
     if not os.path.exists(db):
         continue
     with open('profiles/%s_kernel_stats_%s.txt' % (tag, name), 'w') as f:
+        f.write(head_stamp())
         f.write('# rocprofv3 --kernel-trace --stats -- python bench.py %s --steps 5 --warmup 1\n' % cmd)
         f.write(stats(db))
         f.write('\n# bench.py line of the same run\n# ' + bench_line('%s/%s_bench.log' % (O, key)) + '\n')
-out = ['# rocprofv3 --kernel-trace --pmc <set> --output-format csv -- python bench.py --model {freewater --voxels 2000000 | sandi --voxels 1000000 | lut} '
+out = [head_stamp().rstrip(), '# rocprofv3 --kernel-trace --pmc <set> --output-format csv -- python bench.py --model {freewater --voxels 2000000 | sandi --voxels 1000000 | lut} '
        '--steps 2 --warmup 1; separate passes (never combined with other trace domains); mean per launch',
        '# FETCH_SIZE / WRITE_SIZE in KiB (FETCH_SIZE under-reports wide coalesced reads 2x on gfx950); SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* in quad-cycles']
 for m, pats in (('freewater', ['k_freewater', 'k_fw_project']), ('sandi', ['k_sandi']), ('lut', ['k_lut_resample'])):
