@@ -19,7 +19,7 @@ SYMBOLS = ['amx_version', 'amx_ctx_create', 'amx_ctx_destroy', 'amx_last_error',
            'amx_lut_upload_noddi', 'amx_lut_upload_freewater', 'amx_lut_upload_sandi', 'amx_lut_destroy',
            'amx_dir_to_lut_idx', 'amx_noddi_fit', 'amx_freewater_fit', 'amx_sandi_fit',
            'amx_noddi_fit_device', 'amx_freewater_fit_device', 'amx_sandi_fit_device', 'amx_sync_status',
-           'amx_set_debug_x', 'amx_lut_upload_czb', 'amx_czb_fit', 'amx_czb_fit_f32', 'amx_czb_fit_device', 'amx_noddi_fit_f32', 'amx_freewater_fit_f32', 'amx_sandi_fit_f32', 'amx_set_progress',
+           'amx_set_debug_x', 'amx_debug_fetch', 'amx_lut_upload_czb', 'amx_czb_fit', 'amx_czb_fit_f32', 'amx_czb_fit_device', 'amx_noddi_fit_f32', 'amx_freewater_fit_f32', 'amx_sandi_fit_f32', 'amx_set_progress',
            'amx_set_profiling', 'amx_last_kernel_ms', 'amx_last_stats', 'amx_selftest',
            'amx_dti_create', 'amx_dti_destroy', 'amx_dti_directions', 'amx_dti_directions_device',
            'amx_prep_create', 'amx_prep_destroy', 'amx_prep_gather', 'amx_prep_gather_device',
@@ -83,6 +83,7 @@ def lib():
                                        c_vp, c_vp, c_vp, c_vp]
     L.amx_sync_status.argtypes = [c_vp, c_vp]
     L.amx_set_debug_x.argtypes = [c_vp, c_vp]
+    L.amx_debug_fetch.argtypes = [c_vp, c_vp, C.c_int, c_vp, C.c_size_t]
     L.amx_noddi_fit_f32.argtypes = [c_vp, c_vp, c_fp, c_dp, C.c_int64, C.c_double, C.c_double, C.c_uint, c_dp, c_dp, c_dp, c_dp]
     L.amx_freewater_fit_f32.argtypes = [c_vp, c_vp, c_fp, c_dp, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_uint,
                                         c_dp, c_dp, c_dp, c_dp]
@@ -351,6 +352,13 @@ def czb_fit(ctx, lut, y, dirs, lambda1, lambda2, rmse=False, nrmse=False):
 
 # ---- the same three fits on DEVICE-resident inputs (torch tensors used as plain device buffers); outputs are torch
 #      tensors on the same device, enqueued on `stream`; the caller synchronises with ctx.sync(stream)
+def debug_fetch(ctx, lut, which, shape, dtype):
+    """workspace / dictionary tables of the support seeds (include/amico_amd.h: amx_debug_fetch) as a numpy array"""
+    out = np.empty(shape, dtype=dtype)
+    ctx.check(lib().amx_debug_fetch(ctx._h, lut._h if lut is not None else None, int(which), out.ctypes.data_as(c_vp), out.nbytes))
+    return out
+
+
 def _dptr(t):
     return c_vp(t.data_ptr()) if t is not None else None
 

@@ -24,10 +24,18 @@ int reset_status(amx_ctx *ctx, hipStream_t s)
     return AMX_OK;
 }
 
-int make_plan(amx_ctx *ctx, int64_t n, int ndirs, Plan &pl)
+int make_plan(amx_ctx *ctx, int64_t n, int ndirs, Plan &pl, bool seeds = false)
 {
     int rc;
     const int max_chunks = (int)(n / kChunk) + ndirs + 1;
+    if (seeds) {
+        const int sc = ctx->opt_seed_chunk;
+        pl.max_schunks = (int)(n / sc) + ndirs + 1;
+        if ((rc = ensure(ctx, ctx->schunks, (size_t)pl.max_schunks * sizeof(Chunk)))) return rc;
+        if ((rc = ensure(ctx, ctx->ytil, (size_t)n * amx::kSeedKD * sizeof(double)))) return rc;
+        if ((rc = ensure(ctx, ctx->seeds, (size_t)n * sizeof(unsigned long long)))) return rc;
+        pl.schunks = (Chunk *)ctx->schunks.p;
+    }
     if ((rc = ensure(ctx, ctx->lutidx, n * sizeof(int)))) return rc;
     if ((rc = ensure(ctx, ctx->perm, n * sizeof(int)))) return rc;
     if ((rc = ensure(ctx, ctx->counts, (size_t)(ndirs + 1) * sizeof(int)))) return rc;
@@ -55,7 +63,7 @@ int enqueue_bucketing(amx_ctx *ctx, const amx_lut *lut, const double *d_dirs, in
                        (int)n, lut->htable, lut->ndirs, pl.lutidx, pl.counts, ctx->status_d, use_lds, (int)ctx->vox_base);
     AMX_TRACE(ctx, s, "k_dir_to_lut");
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, pl.counts, lut->ndirs, chunk, pl.dir_start,
-                       pl.cursor, pl.chunks, pl.n_chunks);
+                       pl.cursor, pl.chunks, pl.n_chunks, pl.schunks ? ctx->opt_seed_chunk : 0, pl.schunks);
     AMX_TRACE(ctx, s, "k_plan");
     hipLaunchKernelGGL(k_bucket, dim3(nb), dim3(1024), use_lds ? (size_t)2 * lut->ndirs * sizeof(int) : 0, s, pl.lutidx,
                        (int)n, lut->ndirs, pl.dir_start, pl.cursor, pl.perm, use_lds);
@@ -138,6 +146,14 @@ int amx_ctx_create(int device, amx_ctx **out)
         return AMX_E_HIP;
     }
     for (int k = 0; k < kEv; k++) { hipEventCreate(&ctx->ev[k]); ctx->ev_valid[k] = false; }
+    {
+        const char *e = getenv("AMX_NO_SEED");
+        ctx->opt_no_seed = e && *e && *e != '0';
+        e = getenv("AMX_SEED_STAGES");
+        if (e && *e) ctx->opt_seed_stages = atoi(e) & 3;
+        e = getenv("AMX_SEED_CHUNK");
+        if (e && atoi(e) >= 64) ctx->opt_seed_chunk = atoi(e);
+    }
     reset_status(ctx, nullptr);
     hipStreamSynchronize(nullptr);
     *out = ctx;
@@ -151,7 +167,7 @@ void amx_ctx_destroy(amx_ctx *ctx)
     hipDeviceSynchronize();
     DevBuf *bufs[] = {&ctx->lutidx, &ctx->perm, &ctx->counts, &ctx->dir_start, &ctx->cursor, &ctx->chunks,
                       &ctx->misc, &ctx->xiso, &ctx->supp, &ctx->ovf, &ctx->cproj, &ctx->hy, &ctx->hdirs, &ctx->hest,
-                      &ctx->hrmse, &ctx->hnrmse, &ctx->hextra, &ctx->hy32};
+                      &ctx->hrmse, &ctx->hnrmse, &ctx->hextra, &ctx->hy32, &ctx->ytil, &ctx->seeds, &ctx->schunks};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     for (DevBuf &b : ctx->alt) if (b.p) hipFree(b.p);
     if (ctx->status_d) hipFree(ctx->status_d);
@@ -167,7 +183,7 @@ void amx_lut_destroy(amx_lut *lut)
 {
     if (!lut) return;
     if (lut->ctx) hipSetDevice(lut->ctx->device);
-    void *ps[] = {lut->gram, lut->gram_dwi, lut->tiles, lut->htable, lut->rowdwi, lut->colscale, lut->icvf, lut->kappa,
+    void *ps[] = {lut->basis_U, lut->basis_S, lut->gram, lut->gram_dwi, lut->tiles, lut->htable, lut->rowdwi, lut->colscale, lut->icvf, lut->kappa,
                   lut->norms, lut->Rs, lut->d_in, lut->d_isos, lut->fw_prep, lut->sandi_prep};
     for (void *p : ps) if (p) hipFree(p);
     if (lut->fw_ready) (void)hipEventDestroy(lut->fw_ready);
@@ -250,6 +266,8 @@ int amx_lut_upload_noddi(amx_ctx *ctx, const float *wm, const float *iso, const 
                                lut->tile_stride, nS, lut->ldA, n_atoms, (const unsigned char *)lut->rowdwi, lut->ldG, lut->gram_dwi);
             HIPCHK(ctx, hipGetLastError());
             HIPCHK(ctx, hipDeviceSynchronize());
+            // compressed basis of every orientation: support seeds of the NNLS stages (amx_seed.hpp)
+            if (!is_exvivo && (rc = amx_build_basis(ctx, lut))) { amx_lut_destroy(lut); return rc; }
         }
     }
     *out = lut;
@@ -375,6 +393,8 @@ int amx_sync_status(amx_ctx *ctx, void *hip_stream)
     ctx->stats[2] = st[ST_OVERFLOW];
     ctx->stats[3] = ((int64_t)st[ST_GUARD] << 32) | (unsigned)st[ST_GUARDVOX];
     if (amx_debug()) fprintf(stderr, "[amx] dual-vector evaluations per stage: exact %d %d %d  gram %d %d %d  inner iterations %d %d %d\n", st[ST_EXACT], st[ST_EXACT + 1], st[ST_EXACT + 2], st[ST_GRAM], st[ST_GRAM + 1], st[ST_GRAM + 2], st[ST_ITERS], st[ST_ITERS + 1], st[ST_ITERS + 2]);
+    if (amx_debug()) fprintf(stderr, "[amx] seeds: stage 1 tried %d certified %d, stage 3 tried %d certified %d; seed solver trips %d lane-trips used %d; stage-1 refusals: malformed %d pivot %d refinement %d x<=0 %d dual %d\n", st[ST_SEED], st[ST_SEED + 1], st[ST_SEED + 2], st[ST_SEED + 3], st[ST_SEED + 4], st[ST_SEED + 5], st[ST_SEED + 7], st[ST_SEED + 8], st[ST_SEED + 9], st[ST_SEED + 10], st[ST_SEED + 11]);
+    if (amx_debug()) fprintf(stderr, "[amx] seed solver kcycles (wave sums / 1024): take %d solve+drop %d residual %d scan %d append %d store %d\n", st[ST_SEED + 12], st[ST_SEED + 13], st[ST_SEED + 14], st[ST_SEED + 15], st[ST_SEED + 16], st[ST_SEED + 17]);
     if (st[ST_ERRVOX] != 0x7f7f7f7f) {
         char b[256];
         snprintf(b, sizeof b, "\"amico.lut.dir_to_lut_idx\" index out of bounds (%d, %d) [voxel %d]", st[ST_II1], st[ST_II2], st[ST_ERRVOX]);
@@ -395,6 +415,27 @@ int amx_set_progress(amx_ctx *ctx, void (*callback)(int64_t done, int64_t total,
     if (!ctx) return AMX_E_BADARG;
     ctx->progress = callback;
     ctx->progress_user = user;
+    return AMX_OK;
+}
+
+// diagnosis / tests: copy a workspace buffer of the LAST fit (0 perm int32[n], 1 y~ f64[n][12], 2 seeds u64[n]) or a
+// dictionary table (10 basis U f64[ndirs][nS][12], 11 compressed dictionary S f64[ndirs][n_atoms][12]) to the host
+int amx_debug_fetch(amx_ctx *ctx, const amx_lut *lut, int which, void *dst, size_t bytes)
+{
+    if (!ctx || !dst) return AMX_E_BADARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    const void *src = nullptr;
+    switch (which) {
+    case 0: src = ctx->perm.p; break;
+    case 1: src = ctx->ytil.p; break;
+    case 2: src = ctx->seeds.p; break;
+    case 10: src = lut ? lut->basis_U : nullptr; break;
+    case 11: src = lut ? lut->basis_S : nullptr; break;
+    default: break;
+    }
+    if (!src) return bad(ctx, "amx_debug_fetch: no such buffer");
+    HIPCHK(ctx, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     return AMX_OK;
 }
 
@@ -459,7 +500,8 @@ int amx_noddi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
     hipStream_t s = (hipStream_t)hip_stream;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     Plan pl; int rc;
-    if ((rc = make_plan(ctx, n_vox, lut->ndirs, pl))) return rc;
+    const bool seeds = lut->basis_S != nullptr && lut->gram != nullptr && !ctx->opt_no_seed;
+    if ((rc = make_plan(ctx, n_vox, lut->ndirs, pl, seeds))) return rc;
     if ((rc = ensure(ctx, ctx->xiso, (size_t)n_vox * 2 * sizeof(double)))) return rc;
     if ((rc = ensure(ctx, ctx->supp, (size_t)n_vox * 4 * sizeof(unsigned long long)))) return rc;
     rec(ctx, 0, s);
@@ -481,8 +523,22 @@ int amx_noddi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
     a.nrmse = (flags & AMX_F_NRMSE) ? d_nrmse : nullptr; a.mod = (flags & AMX_F_MODULATED) ? d_mod : nullptr;
     // voxels with an out-of-bounds direction are skipped: give them defined (zero) maps
     HIPCHK(ctx, hipMemsetAsync(d_estimates, 0, (size_t)n_vox * a.n_maps * sizeof(double), s));
-    if (!(rc = amx_launch_noddi_s1(ctx, a, pl, s)) && !(rc = amx_launch_noddi_s2(ctx, a, pl, s)))
-        rc = amx_launch_noddi_s3(ctx, a, pl, s);
+    if (seeds) {
+        // y~ = U'y once; the seed solver proposes the stage's support, the stage kernel certifies it (amx_seed.hpp)
+        if ((rc = amx_launch_noddi_project(ctx, lut, a, pl, s))) return rc;
+        if (ctx->opt_seed_stages & 1) {
+            a.seeds = (const unsigned long long *)ctx->seeds.p;
+            if ((rc = amx_launch_noddi_seed(ctx, lut, a, pl, s, 1))) return rc;
+        }
+    }
+    if (!(rc = amx_launch_noddi_s1(ctx, a, pl, s)) && !(rc = amx_launch_noddi_s2(ctx, a, pl, s))) {
+        a.seeds = nullptr;
+        if (seeds && (ctx->opt_seed_stages & 2)) {
+            a.seeds = (const unsigned long long *)ctx->seeds.p;
+            rc = amx_launch_noddi_seed(ctx, lut, a, pl, s, 3);
+        }
+        if (!rc) rc = amx_launch_noddi_s3(ctx, a, pl, s);
+    }
     hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, s, (const int *)ctx->misc.p, ctx->status_d);
     rec(ctx, 1, s);
     return rc;

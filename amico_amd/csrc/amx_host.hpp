@@ -25,7 +25,7 @@ struct amx_ctx {
     int n_cu = 256;                // compute units of the device (persistent-grid launches)
     std::string err;
     // stream-ordered workspace (grow-only)
-    DevBuf lutidx, perm, counts, dir_start, cursor, chunks, misc, xiso, supp, ovf, cproj;
+    DevBuf lutidx, perm, counts, dir_start, cursor, chunks, misc, xiso, supp, ovf, cproj, ytil, seeds, schunks;
     DevBuf hy, hdirs, hest, hrmse, hnrmse, hextra;   // staging for the host-pointer entry points
     int *status_d = nullptr;       // ST_WORDS ints
     int *status_h = nullptr;       // pinned mirror (+16 words: copy of the misc counters)
@@ -42,12 +42,16 @@ struct amx_ctx {
     hipStream_t hs2 = nullptr;     // between the two, so the tail of one batch's kernels is filled by the next batch's
     hipEvent_t hev[3] = {nullptr, nullptr, nullptr};
     // second workspace set for the batch in flight on the other stream (swap_work exchanges it with the named buffers)
-    DevBuf alt[11];
+    DevBuf alt[14];
     void swap_work()
     {
-        DevBuf *named[11] = {&lutidx, &perm, &counts, &dir_start, &cursor, &chunks, &misc, &xiso, &supp, &ovf, &cproj};
-        for (int i = 0; i < 11; i++) { DevBuf t = *named[i]; *named[i] = alt[i]; alt[i] = t; }
+        DevBuf *named[14] = {&lutidx, &perm, &counts, &dir_start, &cursor, &chunks, &misc, &xiso, &supp, &ovf, &cproj, &ytil, &seeds, &schunks};
+        for (int i = 0; i < 14; i++) { DevBuf t = *named[i]; *named[i] = alt[i]; alt[i] = t; }
     }
+    // switches read ONCE, at amx_ctx_create (environment): diagnosis / A-B only
+    bool opt_no_seed = false;      // AMX_NO_SEED=1: Lawson-Hanson from the empty set in the NNLS stages (the round-2 path)
+    int opt_seed_stages = 3;       // AMX_SEED_STAGES: bit 0 = seed stage 1, bit 1 = seed stage 3
+    int opt_seed_chunk = 2048;     // AMX_SEED_CHUNK: voxels of one orientation per workgroup of the seed solver
 };
 
 struct amx_lut {
@@ -59,6 +63,7 @@ struct amx_lut {
     int n_rs = 0, n_in = 0, n_isos = 0;   // SANDI
     void *tiles = nullptr;
     double *gram = nullptr, *gram_dwi = nullptr;   // per-orientation Gram matrices (NODDI)
+    double *basis_U = nullptr, *basis_S = nullptr; // per-orientation compressed basis and dictionary (amx_seed.hpp), NODDI
     int ldG = 0;
     short *htable = nullptr;
     unsigned char *rowdwi = nullptr;
@@ -137,6 +142,8 @@ struct Plan {
     amx::Chunk *chunks;
     int max_chunks;
     size_t n;
+    amx::Chunk *schunks = nullptr;  // larger chunks of the seed solver (count at n_chunks[1]); null: none
+    int max_schunks = 0;
 };
 
 // AMX_DEBUG=1: synchronise after every launch and trace progress on stderr
@@ -156,6 +163,9 @@ static inline void rec(amx_ctx *ctx, int k, hipStream_t s)
 }
 
 // defined in the per-model launch units (amx_noddi.hip, amx_fw.hip, amx_sandi.hip)
+int amx_build_basis(amx_ctx *ctx, amx_lut *lut);
+int amx_launch_noddi_project(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s);
+int amx_launch_noddi_seed(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, int stage);
 int amx_launch_noddi_s1(amx_ctx *ctx, amx::NoddiArgs &a, const Plan &pl, hipStream_t s);
 int amx_launch_noddi_s2(amx_ctx *ctx, amx::NoddiArgs &a, const Plan &pl, hipStream_t s);
 int amx_launch_noddi_s3(amx_ctx *ctx, amx::NoddiArgs &a, const Plan &pl, hipStream_t s);
@@ -167,11 +177,6 @@ int amx_launch_fw_small(amx_ctx *ctx, amx::FwArgs &a, const Plan &pl, hipStream_
 int amx_fw_prepare(amx_ctx *ctx, const amx_lut *lut, amx::FwArgs &a, hipStream_t s);
 int amx_sandi_prepare(amx_ctx *ctx, const amx_lut *lut, amx::SandiArgs &a, hipStream_t s);   // before amx_launch_fw when the refill path runs
 int amx_launch_sandi_small(amx_ctx *ctx, amx::SandiArgs &a, const Plan &pl, hipStream_t s);
-// NODDI NNLS stages, two voxels per wavefront (amx_pair.hpp; protocols that fit 32-lane halves: 4 volumes, 5 atoms per
-// lane).  OPT-IN (AMX_PAIR=1): certified by the same KKT tests, but measured SLOWER than the wavefront-per-voxel
-// kernels on MI355X (stage 1 17.9 vs 15.3 ms, stage 3 8.4 vs 7.8 ms per 1 M voxels; four voxels per wavefront 21.6 /
-// 9.4 ms) -- DESIGN.md section 5.
-static inline bool amx_use_pair(int nS, int n_atoms) { const char *e = getenv("AMX_PAIR"); return nS <= 128 && n_atoms <= 160 && e && *e && *e != '0'; }
 // Lane-per-voxel solvers: start the active set from ALL atoms and drop the non-positive ones in blocks (unique optimum
 // with lambda2 > 0, so the path is free; dense optima are reached in 3-4 factorisations).  AMX_COLD_START=1: the
 // Lawson-Hanson start from the empty set.  Needs a ridge that keeps the full system well conditioned.

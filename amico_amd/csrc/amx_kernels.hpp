@@ -16,8 +16,9 @@
 namespace amx {
 
 struct Chunk { int dir, start, count, pad; };
+constexpr int kSeedKD = 12;      // compressed dimensions of the support-seed problem (amx_seed.hpp)
 
-enum StatusSlot { ST_ERRVOX = 0, ST_II1 = 1, ST_II2 = 2, ST_OVERFLOW = 3, ST_ITCAP = 4, ST_RERUN = 5, ST_GUARD = 6, ST_GUARDVOX = 7, ST_EXACT = 8, ST_GRAM = 11, ST_ITERS = 14, ST_WORDS = 20 };
+enum StatusSlot { ST_ERRVOX = 0, ST_II1 = 1, ST_II2 = 2, ST_OVERFLOW = 3, ST_ITCAP = 4, ST_RERUN = 5, ST_GUARD = 6, ST_GUARDVOX = 7, ST_EXACT = 8, ST_GRAM = 11, ST_ITERS = 14, ST_SEED = 17, ST_WORDS = 40 };
 
 // ------------------------------------------------------------------ shared pieces
 struct FitCommon {
@@ -116,6 +117,7 @@ struct NoddiArgs {
     const double *gram;           // [ndirs][n_atoms][ldG] A'A of every orientation tile (all rows), or null
     const double *gram_dwi;       // same restricted to the stage-2 rows
     int ldG;
+    const unsigned long long *seeds;   // support seeds of the NNLS stage being run, bucket order (amx_seed.hpp), or null
     double *xiso;                 // [n_vox][2]  x_iso, x_dot after stage 1
     unsigned long long *supp;     // [n_vox][4]  stage-2 support bit set
     double *est, *rmse, *nrmse, *mod;
@@ -125,7 +127,7 @@ struct NoddiArgs {
 // (models.pyx:914-926), 3 = debias NNLS + maps (models.pyx:929-967)
 template <int STAGE, int NR, int NQ, int MAXP, typename AT = float>
 __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const AT *As, double *rs, double *rl,
-                                            unsigned long long *wmask, int vox, int dir, int lane)
+                                            unsigned long long *wmask, int vox, int dir, int lane, int pos = -1)
 {
     constexpr bool kLasso = (STAGE == 2 || STAGE == 4);
     const int nS = a.c.nS, ldA = a.c.ldA, n_atoms = a.c.n_atoms, n_wm = a.n_wm;
@@ -191,8 +193,14 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const AT *As, do
     const double *gm = kLasso ? a.gram_dwi : a.gram;
     const double *gdir = gm ? gm + (size_t)dir * n_atoms * a.ldG : nullptr;
     typename std::conditional<STAGE == 4, GramSolver<NR, NQ, MAXP, AT>, NNSolver<NR, NQ, MAXP, STAGE == 2, AT>>::type S;
-    const int st = __builtin_amdgcn_readfirstlane(S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed,
-                           kLasso ? a.c.lam1 : 0.0, kLasso ? a.c.lam2 : 0.0, rs, rl, lane, gdir, a.ldG));
+    unsigned long long seed = kSeedNone;
+    if constexpr (!kLasso) {
+        if (a.seeds != nullptr && pos >= 0) seed = a.seeds[pos];
+    }
+    int st_;
+    if constexpr (STAGE == 4) st_ = S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed, a.c.lam1, a.c.lam2, rs, rl, lane, gdir, a.ldG);
+    else st_ = S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed, kLasso ? a.c.lam1 : 0.0, kLasso ? a.c.lam2 : 0.0, rs, rl, lane, gdir, a.ldG, seed);
+    const int st = __builtin_amdgcn_readfirstlane(st_);
     if (st == kOverflow) {
         if (lane == 0) {
             const int k = atomicAdd(a.c.ovf_count, 1);
@@ -210,7 +218,8 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const AT *As, do
     }
 #endif
 #ifdef AMX_STATS
-    if (lane == 0) { constexpr int sx = kLasso ? 1 : STAGE - 1; atomicAdd(&a.c.status[ST_EXACT + sx], S.n_exact); atomicAdd(&a.c.status[ST_GRAM + sx], S.n_gram); atomicAdd(&a.c.status[ST_ITERS + sx], S.iters); }
+    if (lane == 0) { constexpr int sx = kLasso ? 1 : STAGE - 1; atomicAdd(&a.c.status[ST_EXACT + sx], S.n_exact); atomicAdd(&a.c.status[ST_GRAM + sx], S.n_gram); atomicAdd(&a.c.status[ST_ITERS + sx], S.iters);
+        if constexpr (!kLasso) { if (S.seeded >= 0) atomicAdd(&a.c.status[ST_SEED + (STAGE == 1 ? 0 : 2)], 1); if (S.seeded == 1) atomicAdd(&a.c.status[ST_SEED + (STAGE == 1 ? 1 : 3)], 1); if (S.seeded == 0 && STAGE == 1) atomicAdd(&a.c.status[ST_SEED + 6 + S.seed_why], 1); } }
 #endif
     const bool act = lane < S.np;
     if (a.c.xdbg) {
@@ -613,7 +622,7 @@ __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
         // voxels differ 2-3x in solver iterations: the wavefronts draw the next voxel of the chunk from an LDS ticket
         // (next_ticket keeps the control flow wave-uniform: every lane takes part in the atomic)
         for (int k = wave; k < ck.count; k = next_ticket(ticket, lane)) {
-            noddi_voxel<STAGE, NR, NQ, MAXP, AT>(a, As, rs, rl, wmask, a.c.perm[ck.start + k], ck.dir, lane);
+            noddi_voxel<STAGE, NR, NQ, MAXP, AT>(a, As, rs, rl, wmask, a.c.perm[ck.start + k], ck.dir, lane, ck.start + k);
         }
 #endif
     } else {

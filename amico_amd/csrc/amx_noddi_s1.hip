@@ -1,6 +1,5 @@
 // amx_noddi_s1.hip -- NODDI solver stage 1 (models.pyx:911)
 #include "amx_launch.hpp"
-#include "amx_pair.hpp"
 using namespace amx;
 
 template <int NR>
@@ -28,25 +27,7 @@ static int go(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
                        0, 2);
 }
 
-// four voxels per wavefront (amx_pair.hpp): protocols of <= 112 volumes and <= 160 atoms; the wavefront-per-voxel
-// kernel re-runs the voxels whose passive set outgrows 8 atoms
-#ifndef AMX_LPV
-#define AMX_LPV 32     // lanes per voxel of the NNLS stages: 32 (two voxels per wavefront) or 16 (four)
-#endif
-#ifndef AMX_PAIR_NW
-#define AMX_PAIR_NW 12
-#endif
-template <int NR>
-static int go_pair(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
-{
-    constexpr int LPV = AMX_LPV, QR = 128 / LPV, QQ = 160 / LPV, MP = 8, MB = 32, NW = AMX_PAIR_NW;
-    return launch_pair<NW>(ctx, a, pl, s, k_noddi_pair<1, LPV, QR, QQ, MP, NW>, k_noddi<1, NR, 3, MB, 1, true>,
-                           [&](int nw) { return pair_lds_bytes<LPV, QR, QQ, MP>(a.c.nS, a.c.ldA, nw); },
-                           fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, 3, 1, MB), 0, 2);
-}
-
 int amx_launch_noddi_s1(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
 {
-    if (amx_use_pair(a.c.nS, a.c.n_atoms)) return go_pair<2>(ctx, a, pl, s);
     return a.c.nS <= 128 ? go<2>(ctx, a, pl, s) : go<4>(ctx, a, pl, s);
 }

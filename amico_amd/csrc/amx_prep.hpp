@@ -60,30 +60,34 @@ __global__ __launch_bounds__(1024) void k_dir_to_lut(const double *__restrict__ 
 }
 
 // single block: dir_start = exclusive scan(counts); ceil(count / ch) equal chunks of <= ch voxels per orientation
+// (ch2 > 0: a second list of larger chunks for the seed solver, count at n_chunks[1])
 __global__ void k_plan(const int *__restrict__ counts, int ndirs, int ch, int *__restrict__ dir_start,
-                       int *__restrict__ cursor, Chunk *__restrict__ chunks, int *__restrict__ n_chunks)
+                       int *__restrict__ cursor, Chunk *__restrict__ chunks, int *__restrict__ n_chunks,
+                       int ch2 = 0, Chunk *__restrict__ chunks2 = nullptr)
 {
-    __shared__ int s_off, s_chk;
-    if (threadIdx.x == 0) { s_off = 0; s_chk = 0; }
+    __shared__ int s_off, s_chk, s_chk2;
+    if (threadIdx.x == 0) { s_off = 0; s_chk = 0; s_chk2 = 0; }
     __syncthreads();
     // ndirs is small (500..32761): a serial scan by one thread per 1024-wide tile is enough
     for (int base = 0; base < ndirs; base += blockDim.x) {
         const int dsel = base + threadIdx.x;
         const int c = (dsel < ndirs) ? counts[dsel] : 0;
         const int nc = (c + ch - 1) / ch;
-        // block-wide exclusive scans through shared memory (Hillis-Steele on 2 values)
-        __shared__ int sa[1024], sb[1024];
-        sa[threadIdx.x] = c; sb[threadIdx.x] = nc;
+        const int nc2 = ch2 > 0 ? (c + ch2 - 1) / ch2 : 0;
+        // block-wide exclusive scans through shared memory (Hillis-Steele on 3 values)
+        __shared__ int sa[1024], sb[1024], sc2[1024];
+        sa[threadIdx.x] = c; sb[threadIdx.x] = nc; sc2[threadIdx.x] = nc2;
         __syncthreads();
         for (int off = 1; off < (int)blockDim.x; off <<= 1) {
-            int ta = 0, tb = 0;
-            if ((int)threadIdx.x >= off) { ta = sa[threadIdx.x - off]; tb = sb[threadIdx.x - off]; }
+            int ta = 0, tb = 0, tc = 0;
+            if ((int)threadIdx.x >= off) { ta = sa[threadIdx.x - off]; tb = sb[threadIdx.x - off]; tc = sc2[threadIdx.x - off]; }
             __syncthreads();
-            sa[threadIdx.x] += ta; sb[threadIdx.x] += tb;
+            sa[threadIdx.x] += ta; sb[threadIdx.x] += tb; sc2[threadIdx.x] += tc;
             __syncthreads();
         }
         const int start = s_off + sa[threadIdx.x] - c;
         const int cstart = s_chk + sb[threadIdx.x] - nc;
+        const int cstart2 = s_chk2 + sc2[threadIdx.x] - nc2;
         if (dsel < ndirs) {
             dir_start[dsel] = start;
             cursor[dsel] = 0;
@@ -96,12 +100,19 @@ __global__ void k_plan(const int *__restrict__ counts, int ndirs, int ch, int *_
                 ck.count = base + (k < rem ? 1 : 0); ck.pad = 0;
                 chunks[cstart + k] = ck;
             }
+            const int base2 = nc2 ? c / nc2 : 0, rem2 = nc2 ? c - base2 * nc2 : 0;
+            for (int k = 0; k < nc2; k++) {
+                Chunk ck;
+                ck.dir = dsel; ck.start = start + k * base2 + (k < rem2 ? k : rem2);
+                ck.count = base2 + (k < rem2 ? 1 : 0); ck.pad = 0;
+                chunks2[cstart2 + k] = ck;
+            }
         }
         __syncthreads();
-        if (threadIdx.x == blockDim.x - 1) { s_off += sa[threadIdx.x]; s_chk += sb[threadIdx.x]; }
+        if (threadIdx.x == blockDim.x - 1) { s_off += sa[threadIdx.x]; s_chk += sb[threadIdx.x]; s_chk2 += sc2[threadIdx.x]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { dir_start[ndirs] = s_off; *n_chunks = s_chk; }
+    if (threadIdx.x == 0) { dir_start[ndirs] = s_off; n_chunks[0] = s_chk; if (ch2 > 0) n_chunks[1] = s_chk2; }
 }
 
 // scatter of the voxel ids into their orientation's range.  With LDS: the block reserves, per orientation, one range

@@ -1,0 +1,68 @@
+// amx_seed.hip -- support seeds of the NODDI NNLS stages (amx_seed.hpp): basis per orientation, projection, seed solver
+#include "amx_launch.hpp"
+#include "amx_seed.hpp"
+using namespace amx;
+
+// basis of the dominant column space of every orientation tile (once per dictionary upload)
+int amx_build_basis(amx_ctx *ctx, amx_lut *lut)
+{
+    const size_t ub = (size_t)lut->ndirs * lut->nS * kSeedKD * sizeof(double);
+    const size_t sb = (size_t)lut->ndirs * lut->n_atoms * kSeedKD * sizeof(double);
+    HIPCHK(ctx, hipMalloc((void **)&lut->basis_U, ub + 64));
+    HIPCHK(ctx, hipMalloc((void **)&lut->basis_S, sb + 64));
+    const size_t lds = ((size_t)lut->nS * lut->ldA + (size_t)kSeedKD * lut->nS + 256) * sizeof(double);
+    if (lds > kLdsPerCU) { hipFree(lut->basis_U); hipFree(lut->basis_S); lut->basis_U = lut->basis_S = nullptr; return AMX_OK; }   // no seeds for this shape
+    int rc;
+    if ((rc = set_lds(ctx, k_build_basis, lds))) return rc;
+    hipLaunchKernelGGL(k_build_basis, dim3(lut->ndirs), dim3(256), lds, nullptr, (const float *)lut->tiles, lut->tile_stride, lut->nS,
+                       lut->ldA, lut->n_atoms, (const unsigned char *)nullptr, (const double *)nullptr, lut->basis_U, lut->basis_S);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipDeviceSynchronize());
+    return AMX_OK;
+}
+
+static void fill(SeedArgs &sa, const amx_lut *lut, const NoddiArgs &a, const Plan &pl, amx_ctx *ctx)
+{
+    memset(&sa, 0, sizeof sa);
+    sa.y = a.c.y; sa.perm = pl.perm; sa.chunks = pl.chunks; sa.n_chunks = pl.n_chunks;
+    sa.schunks = pl.schunks; sa.n_schunks = pl.n_chunks + 1;
+    sa.Ub = lut->basis_U; sa.Sb = lut->basis_S;
+    sa.ytil = (double *)ctx->ytil.p; sa.seeds = (unsigned long long *)ctx->seeds.p;
+    sa.nS = lut->nS; sa.n_atoms = lut->n_atoms; sa.iso_atom = lut->n_atoms - 1;
+    sa.dot_atom = lut->is_exvivo ? lut->n_atoms - 2 : -1;
+#ifdef AMX_STATS
+    sa.stats = a.c.status + ST_SEED + 4;
+#endif
+}
+
+int amx_launch_noddi_project(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, const Plan &pl, hipStream_t s)
+{
+    SeedArgs sa; fill(sa, lut, a, pl, ctx);
+    const dim3 grid(((pl.max_chunks + 7) / 8) * 8);
+    if (lut->nS <= 128) hipLaunchKernelGGL(k_noddi_project<2>, grid, dim3(1024), 0, s, sa);
+    else hipLaunchKernelGGL(k_noddi_project<4>, grid, dim3(1024), 0, s, sa);
+    AMX_TRACE(ctx, s, "projection onto the orientation bases");
+    HIPCHK(ctx, hipGetLastError());
+    return AMX_OK;
+}
+
+int amx_launch_noddi_seed(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, const Plan &pl, hipStream_t s, int stage)
+{
+    SeedArgs sa; fill(sa, lut, a, pl, ctx);
+    sa.supp = stage == 3 ? a.supp : nullptr;
+    // S for the per-lane gathers + ticket; stage 1 adds S in MFMA operand order (10 x 3 x 64) and a residual block per wavefront
+    const size_t lds = (size_t)lut->n_atoms * kSeedLd * sizeof(double) + 64 +
+                       (stage == 1 ? ((size_t)10 * (kSeedKD / 4) * 64 + (size_t)4 * 64 * (kSeedKD + 1)) * sizeof(double) : 0);
+    const dim3 grid(((pl.max_schunks + 7) / 8) * 8);
+    int rc;
+    if (stage == 1) {
+        if ((rc = set_lds(ctx, (k_nnls_seed<1, 8>), lds))) return rc;
+        hipLaunchKernelGGL((k_nnls_seed<1, 8>), grid, dim3(256), lds, s, sa);
+    } else {
+        if ((rc = set_lds(ctx, (k_nnls_seed<3, 6>), lds))) return rc;
+        hipLaunchKernelGGL((k_nnls_seed<3, 6>), grid, dim3(256), lds, s, sa);
+    }
+    AMX_TRACE(ctx, s, "seed solver");
+    HIPCHK(ctx, hipGetLastError());
+    return AMX_OK;
+}

@@ -1,0 +1,649 @@
+// amx_seed.hpp -- support SEEDS for the NNLS stages of the NODDI fit (models.pyx:911, 940).
+//
+// Lawson-Hanson reaches the 4.3 atoms of a NODDI stage-1 optimum by ~10 column additions and ~5.6 removals -- the path
+// walks along the (kappa, v_ic) grid of nearly collinear atoms.  Two thirds of the solver's work is path, not destination
+// (DESIGN.md section 5).  But WHICH atoms end up in the support is decided by a dozen directions of signal space: the
+// dictionary of one orientation has singular values 1, .16, .11, .016, .009, .003, 6e-4, 1e-4, 2e-5, 2e-6, 7e-7, 4e-8 and
+// then the float32 rounding floor of its entries (4e-9); the NNLS problem projected onto a rank-12 basis has the SAME
+// support as the full problem in 97 % of the voxels (tools/lab/*.py).  So:
+//
+//   k_build_basis   once per dictionary and orientation: U [nS][KD] = an orthonormal basis of the dominant column space
+//                   (pivoted Gram-Schmidt with re-orthogonalisation), S = U'A [n_atoms][KD]
+//   k_noddi_project y~ = U'y of every voxel (bucket order), 12 doubles per voxel
+//   k_nnls_seed     ONE VOXEL PER LANE: Lawson-Hanson on min ||S x - y~||, x >= 0 -- 12 rows instead of 99, so a voxel's
+//                   whole state (y~, the passive set, the 8x8 Gram block of the passive columns) lives in the lane's
+//                   registers and nothing crosses lanes; the dual vector is one sweep over S with wave-uniform (scalar)
+//                   operands.  Output: the passive set, 8 bytes per voxel.
+//   NNSolver::solve (amx_solver.hpp) then only CERTIFIES the seed in the full 99-row problem: least squares on the seeded
+//                   columns (semi-normal equations with refinement on the true residual), one exact sweep of the dual
+//                   vector, strict KKT test.  A seed that fails ANY test falls through to the unchanged Lawson-Hanson
+//                   solver from the empty set, so the result is always the full problem's own KKT point: the compressed
+//                   problem only proposes, it never decides.
+#pragma once
+#include "amx_kernels.hpp"
+
+namespace amx {
+
+constexpr int kSeedMax = 8;      // passive-set capacity of the seed solver (= MAXP of the NNLS stage kernels)
+constexpr int kSeedLd = 13;      // LDS row stride of S (odd: per-lane column gathers spread over the banks)
+constexpr unsigned long long kNoSeed = kSeedNone;
+
+// ------------------------------------------------------------------ basis of one orientation
+// One workgroup per orientation.  tile: float [nS][ldA]; rowsel (optional): rows of the sub-problem (others zero);
+// colscale (optional): column scales.  Out: U f64 [nS][KD] (zero rows where rowsel == 0), S f64 [n_cols][KD].
+__global__ void __launch_bounds__(256) k_build_basis(const float *__restrict__ tiles, int tile_stride, int nS, int ldA, int n_cols,
+                                                     const unsigned char *__restrict__ rowsel, const double *__restrict__ colscale,
+                                                     double *__restrict__ Ub, double *__restrict__ Sb)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    constexpr int KD = kSeedKD;
+    double *R = reinterpret_cast<double *>(smem_b);            // [nS][ldA] deflated columns
+    double *Q = R + (size_t)nS * ldA;                          // [KD][nS]
+    double *red = Q + (size_t)KD * nS;                         // [256]
+    __shared__ int s_j;
+    __shared__ double s_n, s_coef[kSeedKD];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const float *g = tiles + (size_t)blockIdx.x * tile_stride;
+    for (int e = tid; e < nS * ldA; e += nt) {
+        const int i = e / ldA, j = e - i * ldA;
+        double v = (j < n_cols && (rowsel == nullptr || rowsel[i])) ? (double)g[e] : 0.0;
+        if (colscale != nullptr && j < n_cols) v *= colscale[j];
+        R[e] = v;
+    }
+    __syncthreads();
+    for (int d = 0; d < KD; d++) {
+        double nr = -1.0;
+        if (tid < n_cols) { nr = 0.0; for (int i = 0; i < nS; i++) { const double v = R[i * ldA + tid]; nr += v * v; } }
+        red[tid] = nr;
+        __syncthreads();
+        if (tid == 0) {
+            int bj = 0; double bn = red[0];
+            for (int j = 1; j < n_cols && j < nt; j++) if (red[j] > bn) { bn = red[j]; bj = j; }
+            s_j = bj; s_n = bn;
+        }
+        __syncthreads();
+        const double nn = s_n;
+        const bool live = nn > 1e-280;
+        for (int i = tid; i < nS; i += nt) Q[d * nS + i] = live ? R[i * ldA + s_j] / sqrt(nn) : 0.0;
+        __syncthreads();
+        // re-orthogonalise against the previous directions, twice, and renormalise
+        for (int pass = 0; pass < 2 && live; pass++) {
+            if (tid < d) { double c = 0.0; for (int i = 0; i < nS; i++) c += Q[tid * nS + i] * Q[d * nS + i]; s_coef[tid] = c; }
+            __syncthreads();
+            for (int i = tid; i < nS; i += nt) { double v = Q[d * nS + i]; for (int e = 0; e < d; e++) v -= s_coef[e] * Q[e * nS + i]; Q[d * nS + i] = v; }
+            __syncthreads();
+            if (tid == 0) { double c = 0.0; for (int i = 0; i < nS; i++) c += Q[d * nS + i] * Q[d * nS + i]; s_n = c; }
+            __syncthreads();
+            const double n2 = s_n;
+            for (int i = tid; i < nS; i += nt) Q[d * nS + i] = n2 > 0.0 ? Q[d * nS + i] / sqrt(n2) : 0.0;
+            __syncthreads();
+        }
+        if (tid < n_cols) {
+            double c = 0.0;
+            for (int i = 0; i < nS; i++) c += Q[d * nS + i] * R[i * ldA + tid];
+            for (int i = 0; i < nS; i++) R[i * ldA + tid] -= c * Q[d * nS + i];
+        }
+        __syncthreads();
+    }
+    double *U = Ub + (size_t)blockIdx.x * nS * KD;
+    for (int e = tid; e < nS * KD; e += nt) { const int i = e / KD, d = e - i * KD; U[e] = Q[d * nS + i]; }
+    // S = U'A from the ORIGINAL (scaled, row-selected) columns
+    double *S = Sb + (size_t)blockIdx.x * n_cols * KD;
+    for (int e = tid; e < n_cols * KD; e += nt) {
+        const int j = e / KD, d = e - j * KD;
+        double c = 0.0;
+        for (int i = 0; i < nS; i++) {
+            double v = (rowsel == nullptr || rowsel[i]) ? (double)g[i * ldA + j] : 0.0;
+            c += Q[d * nS + i] * v;
+        }
+        if (colscale != nullptr) c *= colscale[j];
+        S[e] = c;
+    }
+}
+
+// ------------------------------------------------------------------ y~ = U'y (wavefront per voxel, lane = signal rows)
+struct SeedArgs {
+    const double *y;              // [n_vox][nS]
+    const int *perm;
+    const Chunk *chunks;          // 256-voxel chunks of the solver kernels (projection)
+    const int *n_chunks;
+    const Chunk *schunks;         // larger chunks of the seed kernel
+    const int *n_schunks;
+    const double *Ub, *Sb;        // [ndirs][nS][KD], [ndirs][n_atoms][KD]
+    double *ytil;                 // [n_vox][KD], bucket order
+    unsigned long long *seeds;    // [n_vox], bucket order: up to 8 atom ids, one per byte, 0xff = empty; kNoSeed = none
+    const unsigned long long *supp;   // stage 3: [n_vox][4] stage-2 support bit set (voxel order), null for stage 1
+    int nS, n_atoms, iso_atom, dot_atom;
+    int *stats;                   // optional counters (AMX_STATS): [0] trips, [1] lane-trips in use, [2] voxels, [3] no-seed voxels
+};
+
+template <int NR>
+__global__ void __launch_bounds__(1024) k_noddi_project(const SeedArgs a)
+{
+    constexpr int KD = kSeedKD;
+    const int cid = xcd_chunk((int)blockIdx.x, *a.n_chunks);
+    if (cid < 0) return;
+    const Chunk ck = a.chunks[cid];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
+    const int nS = a.nS;
+    // this lane's rows of U stay in registers for the whole chunk
+    double ur[NR][KD];
+    const double *U = a.Ub + (size_t)ck.dir * nS * KD;
+#pragma unroll
+    for (int rr = 0; rr < NR; rr++) {
+        const int i = lane + kWave * rr;
+#pragma unroll
+        for (int d = 0; d < KD; d++) ur[rr][d] = (i < nS) ? U[i * KD + d] : 0.0;
+    }
+    for (int k = wave; k < ck.count; k += nw) {
+        const int pos = ck.start + k;
+        const double *yv = a.y + (size_t)a.perm[pos] * nS;
+        double yr[NR];
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) { const int i = lane + kWave * rr; yr[rr] = (i < nS) ? yv[i] : 0.0; }
+        double out = 0.0;
+#pragma unroll
+        for (int b = 0; b < KD; b += 4) {
+            double p[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                p[u] = 0.0;
+#pragma unroll
+                for (int rr = 0; rr < NR; rr++) p[u] += ur[rr][b + u] * yr[rr];
+            }
+            wave_sum4(p, lane);
+#pragma unroll
+            for (int u = 0; u < 4; u++) out = (lane == b + u) ? p[u] : out;
+        }
+        if (lane < KD) a.ytil[(size_t)pos * KD + lane] = out;
+    }
+}
+
+// ------------------------------------------------------------------ lane-per-voxel Lawson-Hanson in the compressed space
+__device__ __forceinline__ double seed_div(double x, double d)      // x / d, d > 0 normal: reciprocal + two Newton steps
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = r * (2.0 - d * r);
+    r = r * (2.0 - d * r);
+    const double q = x * r;
+    return q + r * (x - q * d);
+}
+
+template <int N> __device__ __forceinline__ constexpr int stri(int i, int j) { return i * (i + 1) / 2 + j; }
+
+
+// Dual vector of the compressed problem for the 64 voxels of a wavefront on the fp64 matrix cores:
+// W [atoms x voxels] = S' [atoms x KD] * R [KD x voxels], v_mfma_f64_16x16x4_f64 (exact fp64 products and sums).
+//   * A operand (S'): prepared once per chunk in LDS in operand order, Aop[(mt * KS + ks) * 64 + lane] = S[atom 16 mt +
+//     (lane & 15)][4 ks + (lane >> 4)] (zero beyond n_atoms);
+//   * B operand (R): every lane publishes the residual of ITS voxel in the wavefront's LDS block Rb [64][4 KS + 1] and
+//     reads back the element the operand layout asks of it -- r[4 ks + (lane >> 4)] of voxel 16 nt + (lane & 15);
+//   * D: register r of lane l holds the dual value of atom 16 mt + 4 r + (l >> 4) for voxel 16 nt + (l & 15).  The arg-max
+//     rides in the value itself: the low 8 mantissa bits are replaced by the candidate's code (mt * 4 + r, later the row
+//     l >> 4), so one v_max_f64 per value keeps both; the four rows that share a voxel are combined by the two row
+//     swaps, and the lane that owns voxel v finds its result in row v >> 4.  (2^-44 relative: far below what the choice
+//     of the entering atom, or the 1e-10 stopping test, can see.)
+typedef double seed_v4d __attribute__((ext_vector_type(4)));
+template <int KS, int MT>
+__device__ __forceinline__ void seed_scan_mfma(const double *Aop, double *Rb, const double (&r)[4 * KS], int lane, double &best, int &bj)
+{
+    constexpr int KDP = 4 * KS + 1;
+    const int q = lane >> 4, c16 = lane & 15;
+#pragma unroll
+    for (int d = 0; d < 4 * KS; d++) Rb[lane * KDP + d] = r[d];
+    double b[4][KS];
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) b[nt][ks] = Rb[(16 * nt + c16) * KDP + 4 * ks + q];
+    }
+    const double ninf = -__builtin_huge_val();
+    double bv[4] = {ninf, ninf, ninf, ninf};
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        double av[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) av[ks] = Aop[(mt * KS + ks) * 64 + lane];
+        seed_v4d acc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) acc[nt] = (seed_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], b[nt][ks], acc[nt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const double v = acc[nt][rr];
+                const unsigned lo = ((unsigned)__double2loint(v) & 0xffffff00u) | (unsigned)(mt * 4 + rr);
+                bv[nt] = fmax(bv[nt], __hiloint2double(__double2hiint(v), (int)lo));
+            }
+        }
+    }
+    double mine = ninf;
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) {
+        const double t = __hiloint2double(__double2hiint(bv[nt]), (int)((unsigned)__double2loint(bv[nt]) | (unsigned)(q << 6)));
+        const double m = rows_allmax(t);
+        mine = (q == nt) ? m : mine;
+    }
+    const unsigned code = (unsigned)__double2loint(mine) & 0xffu;
+    best = mine;
+    bj = 16 * (int)((code >> 2) & 15u) + 4 * (int)(code & 3u) + (int)(code >> 6);
+}
+
+// Per-lane state of one voxel: the passive atoms idx[], their coefficients x[], c = S_P' y~, and ONE packed triangle T that
+// holds the Cholesky factor of H_PP = S_P' S_P (slots >= np: zero rows, zero reciprocal pivots, so every loop runs over
+// all MS slots without predicates).  Removing a slot turns T back into H_PP in place (L L'), deletes the row and column
+// in place and factors again in place: no second triangle is ever live.
+template <int MS>
+struct SeedLane {
+    static constexpr int NT = MS * (MS + 1) / 2;
+    double T[NT], dinv[MS], c[MS], x[MS];
+    int idx[MS], np;
+
+    __device__ __forceinline__ void clear()
+    {
+        np = 0;
+#pragma unroll
+        for (int s = 0; s < MS; s++) { idx[s] = 0; x[s] = 0.0; c[s] = 0.0; dinv[s] = 0.0; }
+#pragma unroll
+        for (int e = 0; e < NT; e++) T[e] = 0.0;
+    }
+    // z = (L L')^-1 c
+    __device__ __forceinline__ void solve(double (&z)[MS]) const
+    {
+#pragma unroll
+        for (int j = 0; j < MS; j++) {
+            double f = c[j];
+#pragma unroll
+            for (int m = 0; m < j; m++) f -= T[stri<MS>(j, m)] * z[m];
+            z[j] = f * dinv[j];
+        }
+#pragma unroll
+        for (int j = MS - 1; j >= 0; j--) {
+            double f = z[j];
+#pragma unroll
+            for (int m = j + 1; m < MS; m++) f -= T[stri<MS>(m, j)] * z[m];
+            z[j] = f * dinv[j];
+        }
+    }
+    // in-place Cholesky of the matrix held in T (slots >= np are zero); false: a pivot of a live slot is not positive
+    __device__ __forceinline__ bool factor()
+    {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < MS; j++) {
+            double dj = T[stri<MS>(j, j)];
+            const double hjj = dj;
+#pragma unroll
+            for (int m = 0; m < j; m++) dj -= T[stri<MS>(j, m)] * T[stri<MS>(j, m)];
+            const bool good = dj > 1e-15 * hjj;
+            ok = ok && (j >= np || good);
+            dinv[j] = (j < np && good) ? inv_sqrt(dj) : 0.0;
+            T[stri<MS>(j, j)] = dj * dinv[j];
+#pragma unroll
+            for (int i = j + 1; i < MS; i++) {
+                double v = T[stri<MS>(i, j)];
+#pragma unroll
+                for (int m = 0; m < j; m++) v -= T[stri<MS>(i, m)] * T[stri<MS>(j, m)];
+                T[stri<MS>(i, j)] = v * dinv[j];
+            }
+        }
+        return ok;
+    }
+    // slot k leaves (per-lane k < np; k = MS: nothing happens, bit for bit -- the call is branch-free for the whole wavefront,
+    // a divergent branch around it made the compiler keep a second copy of the triangle).  Rows below k lose their
+    // entry of column k -- the vector l -- and move up one slot, columns right of k move left; the trailing block then takes
+    // the rank-one update L22 L22' + l l' (the textbook Cholesky update: one rotation per column, identity where l is
+    // zero, i.e. left of k and beyond the passive set).  Everything happens in place in the one triangle.
+    __device__ __forceinline__ void remove(int k)
+    {
+        double l[MS];
+#pragma unroll
+        for (int i = 0; i < MS - 1; i++) {                   // l[i] = old T[i + 1][k] for i >= k, else 0
+            double v = 0.0;
+#pragma unroll
+            for (int kk = 0; kk <= i; kk++) v = (k == kk) ? T[stri<MS>(i + 1, kk)] : v;
+            l[i] = v;
+        }
+        l[MS - 1] = 0.0;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MS - 1; i++) {                   // ascending: every entry is read before it is overwritten
+#pragma unroll
+            for (int j = 0; j <= i; j++) {
+                const double v00 = T[stri<MS>(i, j)], v10 = T[stri<MS>(i + 1, j)], v11 = T[stri<MS>(i + 1, j + 1)];
+                T[stri<MS>(i, j)] = (i < k) ? v00 : ((j < k) ? v10 : v11);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MS; m++) T[stri<MS>(MS - 1, m)] = (k < MS) ? 0.0 : T[stri<MS>(MS - 1, m)];
+#pragma unroll
+        for (int s = 0; s < MS - 1; s++) {
+            const bool mv = s >= k;
+            idx[s] = mv ? idx[s + 1] : idx[s]; x[s] = mv ? x[s + 1] : x[s]; c[s] = mv ? c[s + 1] : c[s]; dinv[s] = mv ? dinv[s + 1] : dinv[s];
+        }
+        if (k < MS) { idx[MS - 1] = 0; x[MS - 1] = 0.0; c[MS - 1] = 0.0; dinv[MS - 1] = 0.0; np -= 1; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < MS - 1; j++) {
+            const double a = T[stri<MS>(j, j)], b = l[j];
+            const bool rot = b != 0.0;
+            const double n2 = a * a + b * b;
+            const double ri = rot ? inv_sqrt(n2) : dinv[j];
+            const double ss = rot ? b * dinv[j] : 0.0;                   // sin / cos of the rotation
+            const double cc = rot ? n2 * ri * dinv[j] : 1.0;             // 1 / cos
+            const double ci = rot ? a * ri : 1.0;                        // cos
+            T[stri<MS>(j, j)] = rot ? n2 * ri : a;
+            dinv[j] = ri;
+#pragma unroll
+            for (int i = j + 1; i < MS - 1; i++) {
+                const double t = (T[stri<MS>(i, j)] + ss * l[i]) * ci;
+                l[i] = cc * l[i] - ss * t;
+                T[stri<MS>(i, j)] = t;
+            }
+        }
+    }
+    // step from x towards z: returns the slot that reaches zero first (-1: z is feasible and becomes x)
+    __device__ __forceinline__ int step(const double (&z)[MS])
+    {
+        const double inf = __builtin_huge_val();
+        double alpha = inf;
+        int kmin = -1;
+#pragma unroll
+        for (int s = 0; s < MS; s++) {
+            const bool neg = s < np && !(z[s] > 0.0);
+            const double den = x[s] - z[s];
+            const double ratio = neg ? ((den > 0.0) ? seed_div(x[s], den) : 0.0) : inf;
+            if (ratio < alpha) { alpha = ratio; kmin = s; }
+        }
+        if (kmin >= 0) {
+#pragma unroll
+            for (int s = 0; s < MS; s++) x[s] = (s < np) ? x[s] + alpha * (z[s] - x[s]) : 0.0;
+        } else {
+#pragma unroll
+            for (int s = 0; s < MS; s++) x[s] = z[s];
+        }
+        return kmin;
+    }
+};
+
+// STAGE 1: all atoms are candidates; STAGE 3: the atoms of the stage-2 support plus iso (dot)
+template <int STAGE, int MS>
+__global__ void __launch_bounds__(256, 2) k_nnls_seed(const SeedArgs a)
+{
+    constexpr int KD = kSeedKD, LD = kSeedLd;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
+    double *Sl = reinterpret_cast<double *>(smem_s);             // [n_atoms][LD]
+    const int n_atoms = a.n_atoms;
+    unsigned *ticket = reinterpret_cast<unsigned *>(Sl + (size_t)n_atoms * LD);
+    // STAGE 1: the compressed dictionary once more in MFMA operand order, and a block per wavefront for the residuals
+    constexpr int KS = KD / 4, MT = 10, KDP = KD + 1;
+    static_assert(KD % 4 == 0, "whole K-steps");
+    double *Aop = reinterpret_cast<double *>(ticket + 4);
+    double *Rb = Aop + (STAGE == 1 ? MT * KS * 64 : 0) + (threadIdx.x >> 6) * (64 * KDP);
+    const int cid = xcd_chunk((int)blockIdx.x, *a.n_schunks);
+    if (cid < 0) return;
+    const Chunk ck = a.schunks[cid];
+    const int lane = threadIdx.x & 63;
+    const double *__restrict__ Sg = a.Sb + (size_t)ck.dir * n_atoms * KD;
+    for (int e = threadIdx.x; e < n_atoms * KD; e += blockDim.x) { const int j = e / KD, d = e - j * KD; Sl[j * LD + d] = Sg[e]; }
+    if (STAGE == 1) {
+        for (int e = threadIdx.x; e < MT * KS * 64; e += blockDim.x) {
+            const int l = e & 63, ks = (e >> 6) % KS, mt = (e >> 6) / KS;
+            const int atom = 16 * mt + (l & 15), d = 4 * ks + (l >> 4);
+            Aop[e] = (atom < n_atoms) ? Sg[(size_t)atom * KD + d] : 0.0;
+        }
+    }
+    if (threadIdx.x == 0) *ticket = 0u;
+    __syncthreads();
+    const double tol = 1e-10, inf = __builtin_huge_val();
+    constexpr int trip_cap = 64;
+
+    bool active = false;
+    int pos = 0, trips = 0, last_added = -1, ban0 = -1, ban1 = -1;
+    SeedLane<MS> V;
+    V.clear();
+    unsigned long long allow[STAGE == 3 ? 4 : 1];
+    bool more = true;
+#ifdef AMX_STATS
+    int st_trips = 0, st_used = 0;
+    long long ph[6] = {0, 0, 0, 0, 0, 0}, pt = (long long)__builtin_readcyclecounter();
+#define SEED_PH(k) do { const long long t__ = (long long)__builtin_readcyclecounter(); ph[k] += t__ - pt; pt = t__; } while (0)
+#else
+#define SEED_PH(k) do { } while (0)
+#endif
+    for (int guard = 0; guard < (1 << 20); ++guard) {
+        // ------------------------------------------------------------ free lanes take the next voxels of the chunk
+        const unsigned long long freem = __ballot(!active);
+        if (freem != 0ull && more) {
+            const int nfree = __builtin_popcountll(freem);
+            unsigned base = 0u;
+            if (lane == 0) base = atomicAdd(ticket, (unsigned)nfree);
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            if ((int)base + nfree >= ck.count) more = false;
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(freem >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)freem, 0u));
+            const int k = (int)base + rank;
+            if (!active && k < ck.count) {
+                pos = ck.start + k;
+                const double *yp = a.ytil + (size_t)pos * KD;
+                bool finite = true;
+#pragma unroll
+                for (int d = 0; d < KD; d++) finite = finite && (fabs(yp[d]) <= 1.79769313486231570e308);
+                trips = 0; last_added = -1; ban0 = -1; ban1 = -1;
+                V.clear();
+                if (STAGE == 3) {
+                    const int vox = a.perm[pos];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) allow[q] = a.supp[(size_t)vox * 4 + q];
+                    allow[a.iso_atom >> 6] |= 1ull << (a.iso_atom & 63);
+                    if (a.dot_atom >= 0) allow[a.dot_atom >> 6] |= 1ull << (a.dot_atom & 63);
+                }
+                if (finite) active = true;
+                else a.seeds[pos] = kNoSeed;
+            }
+        }
+        if (__ballot(active) == 0ull) {
+            if (!more) break;
+            continue;
+        }
+#ifdef AMX_STATS
+        st_trips++; st_used += __builtin_popcountll(__ballot(active));
+#endif
+        trips++;
+        SEED_PH(0);
+        // ------------------------------------------------------------ least squares on the passive set; step back and drop
+        // one atom if it is infeasible, then solve again at once (a second removal waits for the next trip)
+        bool scan = active;
+        {
+            double z[MS];
+            V.solve(z);
+            int kmin = V.step(z);
+            if (__ballot(active && kmin >= 0) != 0ull) {
+                bool ok = true;
+                if (active && kmin >= 0) {
+                    int gone = 0;
+#pragma unroll
+                    for (int s = 0; s < MS; s++) gone = (s == kmin) ? V.idx[s] : gone;
+                    if (gone == last_added) { ban1 = ban0; ban0 = gone; }
+                }
+#ifndef SEED_NO_REMOVE
+                __builtin_amdgcn_sched_barrier(0);
+                V.remove((active && kmin >= 0) ? kmin : MS);
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                V.solve(z);
+                if (active && kmin >= 0) {
+                    if (!ok) scan = false;                     // (numerically dependent set: the next trip's step sorts it out)
+                    else if (V.step(z) >= 0) scan = false;     // still infeasible: the drop happens next trip (x already stepped)
+                }
+            } else if (active) {
+                ban0 = -1; ban1 = -1;                          // the last addition stood: forget the refused candidates
+            }
+        }
+        SEED_PH(1);
+        // ------------------------------------------------------------ dual vector in the compressed space, entering atom
+        bool done = false;
+        bool noseed = false;
+        if (__ballot(scan) != 0ull) {
+            // (the voxel's projected signal is read again in every trip -- 96 contiguous bytes, cache resident -- instead of
+            //  occupying 24 registers for the whole solve)
+            const double *yp = a.ytil + (size_t)pos * KD;
+            double r[KD];
+#pragma unroll
+            for (int d = 0; d < KD; d++) r[d] = yp[d];
+#pragma unroll
+            for (int s = 0; s < MS; s++) {         // (slots >= np: x = 0, idx = 0 -- no predicate needed)
+                const double *col = Sl + V.idx[s] * LD;
+                double cv[KD];
+#pragma unroll
+                for (int d = 0; d < KD; d++) cv[d] = col[d];
+#pragma unroll
+                for (int d = 0; d < KD; d++) r[d] -= V.x[s] * cv[d];
+            }
+            SEED_PH(2);
+            double best = -inf;
+            int bj = -1;
+            if (STAGE == 1) {
+                if (n_atoms <= 16 * MT) {
+#ifndef SEED_NO_MFMA
+                    seed_scan_mfma<KS, MT>(Aop, Rb, r, lane, best, bj);
+#else
+                    best = r[0] + r[5]; bj = (int)(r[1] * 100.0) & 127;
+#endif
+                } else {
+                    for (int j = 0; j < n_atoms; j++) {
+                        const double *sp = Sg + (size_t)j * KD;              // wave-uniform address: scalar loads
+                        double w = 0.0;
+#pragma unroll
+                        for (int d = 0; d < KD; d++) w += sp[d] * r[d];
+                        const bool ok = w > best;
+                        best = ok ? w : best; bj = ok ? j : bj;
+                    }
+                }
+                // a refused candidate may not come back before another atom has entered: look again without it (rare)
+                if (__ballot(scan && (bj == ban0 || bj == ban1)) != 0ull) {
+                    best = -inf; bj = -1;
+                    for (int j = 0; j < n_atoms; j++) {
+                        const double *sp = Sg + (size_t)j * KD;
+                        double w = 0.0;
+#pragma unroll
+                        for (int d = 0; d < KD; d++) w += sp[d] * r[d];
+                        const bool ok = (j != ban0) && (j != ban1) && (w > best);
+                        best = ok ? w : best; bj = ok ? j : bj;
+                    }
+                }
+            } else {
+                // candidates = set bits of the lane's own mask (<= ~20): per-lane gathers
+                unsigned long long rem[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) rem[q] = scan ? allow[q] : 0ull;
+                for (int it = 0; it < 256; it++) {
+                    int q = -1;
+#pragma unroll
+                    for (int qq = 3; qq >= 0; qq--) q = (rem[qq] != 0ull) ? qq : q;
+                    if (__ballot(q >= 0) == 0ull) break;
+                    unsigned long long word = 0ull;
+#pragma unroll
+                    for (int qq = 0; qq < 4; qq++) word = (q == qq) ? rem[qq] : word;
+                    const int b = (q >= 0) ? __builtin_ctzll(word) : 0;
+                    const int j = (q >= 0) ? q * 64 + b : 0;
+#pragma unroll
+                    for (int qq = 0; qq < 4; qq++) rem[qq] = (q == qq) ? (rem[qq] & (rem[qq] - 1ull)) : rem[qq];
+                    const double *col = Sl + j * LD;
+                    double cv[KD];
+#pragma unroll
+                    for (int d = 0; d < KD; d++) cv[d] = col[d];
+                    double w = 0.0;
+#pragma unroll
+                    for (int d = 0; d < KD; d++) w += cv[d] * r[d];
+                    const bool ok = (q >= 0) && (j != ban0) && (j != ban1) && (w > best);
+                    best = ok ? w : best; bj = ok ? j : bj;
+                }
+            }
+            SEED_PH(3);
+            if (scan) {
+                bool inp = false;
+#pragma unroll
+                for (int s = 0; s < MS; s++) inp = inp || (s < V.np && V.idx[s] == bj);
+                if (!(best > tol) || bj < 0 || inp) {
+                    done = true;                                         // KKT point of the compressed problem
+                } else if (V.np >= MS || trips > trip_cap) {
+                    done = true; noseed = true;                          // no usable seed
+                } else {
+                    // append atom bj as slot np: new row of the factor by one forward substitution
+                    const double *ct = Sl + bj * LD;
+                    double st[KD], cn = 0.0, htt = 0.0;
+#pragma unroll
+                    for (int d = 0; d < KD; d++) { st[d] = ct[d]; cn += st[d] * yp[d]; htt += st[d] * st[d]; }
+                    double h[MS];
+#pragma unroll
+                    for (int s = 0; s < MS; s++) {
+                        const double *col = Sl + V.idx[s] * LD;
+                        double cv[KD];
+#pragma unroll
+                        for (int d = 0; d < KD; d++) cv[d] = col[d];
+                        double v = 0.0;
+#pragma unroll
+                        for (int d = 0; d < KD; d++) v += cv[d] * st[d];
+                        h[s] = (s < V.np) ? v : 0.0;
+                    }
+                    double dd = htt;
+#pragma unroll
+                    for (int j = 0; j < MS; j++) {
+                        double f = h[j];
+#pragma unroll
+                        for (int m = 0; m < j; m++) f -= V.T[stri<MS>(j, m)] * h[m];
+                        h[j] = f * V.dinv[j];                                     // (slots >= np: dinv = 0)
+                        dd -= h[j] * h[j];
+                    }
+                    const bool good = dd > 1e-15 * htt;
+                    const double di = good ? inv_sqrt(dd) : 0.0;
+                    if (!good) {
+                        ban1 = ban0; ban0 = bj;                          // numerically inside the span of the passive atoms
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < MS; i++) {
+                            const bool here = (V.np == i);
+#pragma unroll
+                            for (int j = 0; j < i; j++) V.T[stri<MS>(i, j)] = here ? h[j] : V.T[stri<MS>(i, j)];
+                            V.T[stri<MS>(i, i)] = here ? dd * di : V.T[stri<MS>(i, i)];
+                            V.dinv[i] = here ? di : V.dinv[i];
+                            V.idx[i] = here ? bj : V.idx[i]; V.c[i] = here ? cn : V.c[i]; V.x[i] = here ? 0.0 : V.x[i];
+                        }
+                        last_added = bj;
+                        V.np += 1;
+                    }
+                }
+            }
+        }
+        SEED_PH(4);
+        if (active && !done && trips > 2 * trip_cap) { done = true; noseed = true; }
+        if (done) {
+            unsigned lo = 0xffffffffu, hi = 0xffffffffu;                 // one byte per slot, 0xff = empty
+            if (!noseed) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    if (s < V.np) lo = (lo & ~(0xffu << (8 * s))) | ((unsigned)(V.idx[s] & 0xff) << (8 * s));
+                    if (s + 4 < V.np && s + 4 < MS) hi = (hi & ~(0xffu << (8 * s))) | ((unsigned)(V.idx[s + 4 < MS ? s + 4 : 0] & 0xff) << (8 * s));
+                }
+                if (V.np == 0) lo = 0xfffffffeu;                          // certified-empty support: not the "no seed" pattern
+            }
+            a.seeds[pos] = ((unsigned long long)hi << 32) | (unsigned long long)lo;
+            active = false;
+        }
+        SEED_PH(5);
+    }
+#ifdef AMX_STATS
+    if (a.stats && lane == 0) {
+        atomicAdd(&a.stats[0], st_trips); atomicAdd(&a.stats[1], st_used);
+        if (STAGE == 1) for (int k = 0; k < 6; k++) atomicAdd(&a.stats[8 + k], (int)(ph[k] >> 10));
+    }
+#endif
+}
+
+}  // namespace amx

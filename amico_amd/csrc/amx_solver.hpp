@@ -40,6 +40,8 @@ constexpr int kWave = 64;
 #define AMX_PH(k) do { } while (0)
 #endif
 enum SolveStatus : int { kSolved = 0, kOverflow = 1, kIterCap = 2, kGuardSelect = 3, kGuardOuter = 4 };
+// support seed of a voxel (amx_seed.hpp): up to 8 atom ids, one per byte from the low end; bytes >= 0xf0 are empty
+constexpr unsigned long long kSeedNone = ~0ull;
 
 // ------------------------------------------------------------------ wavefront primitives
 __device__ __forceinline__ double bcast(double v, int l)   // l must be wave-uniform
@@ -107,6 +109,14 @@ __device__ __forceinline__ double wave_max(double v)
     return t;
 }
 __device__ __forceinline__ double wave_min(double v) { return -wave_max(-v); }
+// maximum over the four 16-lane rows, lane by lane, left in every row
+__device__ __forceinline__ double rows_allmax(double k)
+{
+    double a, b;
+    AMX_ROW_SWAP(__builtin_amdgcn_permlane16_swap, k, a, b); k = fmax(a, b);
+    AMX_ROW_SWAP(__builtin_amdgcn_permlane32_swap, k, a, b); k = fmax(a, b);
+    return k;
+}
 
 // Four wavefront sums at once (all lanes receive all four totals).  Instead of four 7-step
 // reductions the values are "transposed" while they are summed: after the two quad_perm
@@ -177,6 +187,8 @@ struct NNSolver {
     double r[NR];         // row space: residual y - A s x at exit
     int iters;
     int n_exact, n_gram;  // dual-vector evaluations: exact sweeps / Gram updates (statistics)
+    int seed_why;         // diagnosis: why certify_seed refused (1 malformed, 2 pivot, 3 refinement, 4 x <= 0, 5 dual value > 0)
+    int seeded;           // 1: the seed was certified (Q holds the raw passive columns, r the final residual), 0: not, -1: no seed
 #ifdef AMX_PHASES
     long long ph[8], pht; // 0 sweep, 1 gram update, 2 selection, 3 column + Gram-Schmidt, 4 commit, 5 triangular solve, 6 step/removal, 7 other
 #endif
@@ -269,6 +281,7 @@ struct NNSolver {
     // sweeps of solve(); callers that need it afterwards -- the error maps -- recompute it here)
     __device__ __forceinline__ void residual(const double (&yr)[NR], double lam1)
     {
+        if (seeded == 1) return;          // certify_seed() left the residual of the certified solution in r
 #pragma unroll
         for (int rr = 0; rr < NR; rr++) r[rr] = yr[rr];
         const double coef = d - lam1 * e;
@@ -282,12 +295,209 @@ struct NNSolver {
         }
     }
 
+
+    // u = A'v (atom space) by one sweep over the LDS tile; v is handed over through the per-wave scratch rs
+    __device__ __forceinline__ void sweep(const AT *As, int ldA, int nS, const double (&v)[NR], double *rs, int lane, double (&u)[NQ])
+    {
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) rs[lane + kWave * rr] = v[rr];
+        double w2[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) { u[q] = 0.0; w2[q] = 0.0; }
+        const AT *ap = As + lane;
+        int i = 0;
+        for (; i + 1 < nS; i += 2) {
+            const double r0 = rs[i], r1 = rs[i + 1];
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                u[q] += (double)ap[i * ldA + kWave * q] * r0;
+                w2[q] += (double)ap[(i + 1) * ldA + kWave * q] * r1;
+            }
+        }
+        if (i < nS) {
+            const double r0 = rs[i];
+#pragma unroll
+            for (int q = 0; q < NQ; q++) u[q] += (double)ap[i * ldA + kWave * q] * r0;
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; q++) u[q] += w2[q];
+    }
+
+    // lane s < np: sum over the rows of Q[s] * v (the raw passive columns while a seed is being certified)
+    __device__ __forceinline__ double slot_dots(const double (&v)[NR], int lane)
+    {
+        double out = 0.0;
+#pragma unroll
+        for (int kb = 0; kb < MAXP; kb += 4) {
+            if (kb < np) {
+                double p[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    p[u] = 0.0;
+                    if (kb + u < MAXP) {
+#pragma unroll
+                        for (int rr = 0; rr < NR; rr++) p[u] += Q[kb + u][rr] * v[rr];
+                    }
+                }
+                if (kb + 1 < np) wave_sum4(p, lane);
+                else { p[0] = bcast(wave_sum(p[0]), 0); p[1] = 0.0; p[2] = 0.0; p[3] = 0.0; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) out = (lane == kb + u) ? p[u] : out;
+            }
+        }
+        return out;
+    }
+
+    // two triangular solves with the Cholesky factor kept as a square in Rl (lane = row): returns (L L')^-1 rhs in slot space
+    __device__ __forceinline__ double chol_solve(double rhs, int lane)
+    {
+        const int li = (lane < MAXP ? lane : MAXP) * LDR;
+        double f = (lane < np) ? rhs : 0.0;
+        for (int k = 0; k < np; k++) {
+            const double lk = Rl[li + k];
+            const double wk = bcast(f * rinv, k);
+            if (lane > k) f -= lk * wk;
+        }
+        double b = f * rinv;
+        for (int k = np - 1; k >= 0; k--) {
+            const double lk = Rl[k * LDR + (lane < k ? lane : k)];
+            const double zk = bcast(b * rinv, k);
+            if (lane < k) b -= lk * zk;
+        }
+        return (lane < np) ? b * rinv : 0.0;
+    }
+
+    // Certify a support seed in the full problem (unregularised NNLS only): least squares on the seeded columns by the
+    // semi-normal equations -- Cholesky of the precomputed Gram block, refined on the TRUE residual until the passive dual
+    // values are at rounding level, which is what the thin QR of the Lawson-Hanson path delivers too --, then one exact
+    // sweep of the dual vector and the STRICT Kuhn-Tucker test of that path (x_P > 0, w_j <= 0 for every other admissible
+    // atom).  true: np / idx / x / r hold the solution (a KKT point of a problem whose minimiser is unique whenever the
+    // seeded columns are independent).  false: nothing is decided -- the caller starts Lawson-Hanson from the empty set.
+    __device__ __forceinline__ bool certify_seed(const AT *As, int ldA, int nS, const double (&yr)[NR], const bool (&rowok)[NR],
+                                                 unsigned fl, unsigned long long seed, double *rs, int lane,
+                                                 const double *__restrict__ G, int ldG)
+    {
+        // decode: slot s = byte s
+        const int my = (int)((seed >> (8 * (lane & 7))) & 0xffull);
+        const unsigned long long present = ballot64(lane < MAXP && lane < 8 && my < 0xf0);
+        const int n0 = __builtin_popcountll(present);
+        seed_why = 0;
+        if (present != ((1ull << n0) - 1ull)) { seed_why = 1; return false; }   // not a prefix: malformed
+        np = n0;
+        idx = (lane < np) ? my : -1;
+        // every seeded atom must be admissible and distinct
+        {
+            bool bad = false;
+            for (int s = 0; s < np; s++) {
+                const int t = bcast_i(idx, s);
+                const unsigned ft = (unsigned)bcast_i((int)fl, t & 63);
+                bad = bad || !((ft >> (t >> 6)) & 1u) || (t >= 64 * NQ);
+                if (lane > s && lane < np && idx == t) bad = true;
+            }
+            if (ballot64(bad) != 0ull) { np = 0; idx = -1; seed_why = 1; return false; }
+        }
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) r[rr] = yr[rr];
+        bool ok = true;
+        if (np > 0) {
+            // raw columns (row space) and the Gram block (lane = row of the triangle), factored in place
+#pragma unroll
+            for (int m = 0; m < MAXP; m++) {
+                if (m < np) {
+                    const int t = bcast_i(idx, m);
+#pragma unroll
+                    for (int rr = 0; rr < NR; rr++) {
+                        const int i = lane + kWave * rr;
+                        Q[m][rr] = (i < nS && rowok[rr]) ? (double)As[i * ldA + t] : 0.0;
+                    }
+                }
+            }
+            const int li = (lane < MAXP ? lane : MAXP) * LDR;
+            for (int k = 0; k < np; k++) {
+                const int tk = bcast_i(idx, k);
+                if (lane >= k && lane < np) Rl[li + k] = G[(size_t)idx * ldG + tk];
+            }
+            for (int k = 0; k < np; k++) {
+                double t = Rl[li + k];
+                const double hkk = bcast(t, k);
+                for (int m = 0; m < k; m++) t -= Rl[li + m] * Rl[k * LDR + m];
+                const double tk = bcast(t, k);
+                if (!uni(tk > 1e-14 * hkk)) { ok = false; seed_why = 2; break; }
+                const double iv = inv_sqrt(tk);
+                if (lane >= k && lane < np) Rl[li + k] = t * iv;
+                if (lane == k) rinv = iv;
+            }
+            if (ok) {
+                x = chol_solve(slot_dots(yr, lane), lane);
+#pragma unroll
+                for (int m = 0; m < MAXP; m++) {
+                    if (m < np) {
+                        const double xs = bcast(x, m);
+#pragma unroll
+                        for (int rr = 0; rr < NR; rr++) r[rr] -= Q[m][rr] * xs;
+                    }
+                }
+                // refinement on the true residual: g = A_P' r -> 0
+                double gprev = __builtin_huge_val();
+                for (int it = 0; it < 5; it++) {
+                    const double g = slot_dots(r, lane);
+                    const double gmax = wave_max((lane < np) ? fabs(g) : 0.0);
+                    if (uni(gmax < 2e-15)) break;
+                    if (uni(!(gmax < 0.25 * gprev))) { ok = uni(gmax < 1e-12); if (!ok) seed_why = 3; break; }      // stagnation: rounding level reached (or ill-conditioned)
+                    gprev = gmax;
+                    const double dx = chol_solve(g, lane);
+                    x += dx;
+#pragma unroll
+                    for (int m = 0; m < MAXP; m++) {
+                        if (m < np) {
+                            const double ds = bcast(dx, m);
+#pragma unroll
+                            for (int rr = 0; rr < NR; rr++) r[rr] -= Q[m][rr] * ds;
+                        }
+                    }
+                    if (it == 4) { ok = false; seed_why = 3; }
+                }
+                if (ok && ballot64(lane < np && !(x > 0.0)) != 0ull) { ok = false; seed_why = 4; }
+            }
+        }
+        if (ok) {
+            // exact dual vector of the candidate solution; strict test over the admissible atoms outside the seed
+            double u[NQ];
+            sweep(As, ldA, nS, r, rs, lane, u);
+            n_exact++;
+            unsigned pm = 0u;                                    // bit q: atom lane + 64 q is seeded
+            for (int s = 0; s < np; s++) {
+                const int t = bcast_i(idx, s);
+                if (lane == (t & 63)) pm |= 1u << (t >> 6);
+            }
+            bool viol = false;
+#pragma unroll
+            for (int q = 0; q < NQ; q++) viol = viol || (((fl & ~pm) >> q) & 1u && u[q] > 0.0);
+            ok = ballot64(viol) == 0ull;
+            if (!ok) seed_why = 5;
+        }
+        if (!ok) {
+            // leave the state as solve() initialised it
+            np = 0; idx = -1; x = 0.0; rinv = 0.0;
+#pragma unroll
+            for (int m = 0; m < MAXP; m++) {
+#pragma unroll
+                for (int rr = 0; rr < NR; rr++) Q[m][rr] = 0.0;
+            }
+            return false;
+        }
+        sc = 1.0; xprev = x; d = 0.0; e = 0.0;
+        if (lane >= np) { x = 0.0; xprev = 0.0; idx = -1; }
+        return true;
+    }
+
     __device__ __forceinline__ int solve(const AT *As, int ldA, int nS, int n_atoms,
                                          const double (&yr)[NR], const bool (&rowok)[NR],
                                          const double (&scl)[NQ],
                                          const unsigned long long (&allowed)[NQ],
                                          double lam1, double lam2, double *rs, double *rl, int lane,
-                                         const double *__restrict__ G = nullptr, int ldG = 0)
+                                         const double *__restrict__ G = nullptr, int ldG = 0,
+                                         unsigned long long seed = kSeedNone)
     {
         Rl = rl;
         Ql = rl + (MAXP + 1) * LDR;
@@ -323,6 +533,11 @@ struct NNSolver {
         int last_added = -1, second_looks = 0;
         bool cyc_banned = false;
         n_exact = 0; n_gram = 0;
+        seeded = -1;
+        if (!RIDGE && G != nullptr && seed != kSeedNone && lam1 == 0.0) {
+            seeded = certify_seed(As, ldA, nS, yr, rowok, fl, seed, rs, lane, G, ldG) ? 1 : 0;
+            if (seeded == 1) return kSolved;
+        }
 #ifdef AMX_PHASES
         for (int k = 0; k < 8; k++) ph[k] = 0;
         pht = (long long)__builtin_readcyclecounter();

@@ -17,6 +17,7 @@
  */
 #ifndef AMICO_AMD_H
 #define AMICO_AMD_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -154,6 +155,13 @@ int amx_sync_status(amx_ctx *ctx, void *hip_stream);
  *   FreeWater  f64[n_vox][n_atoms]    the lasso solution (models.pyx:1238)
  *   SANDI      f64[n_vox][n_atoms]    the lasso solution rescaled by KERNELS['norms'] (models.pyx:1570-1571)   */
 int amx_set_debug_x(amx_ctx *ctx, double *d_x);
+
+/* ---- diagnosis / tests of the support seeds (csrc/amx_seed.hpp; no counterpart in the reference): copies a workspace
+ * buffer of the LAST NODDI fit of this ctx -- which = 0: voxel permutation int32[n] (bucket order), 1: projected signals
+ * f64[n][12] (bucket order), 2: support seeds uint64[n] (bucket order; up to 8 atom ids, one per byte, >= 0xf0 = empty;
+ * all ones = no seed) -- or a table of the dictionary `lut` -- 10: orientation bases U f64[ndirs][nS][12], 11: compressed
+ * dictionaries S = U'A f64[ndirs][n_atoms][12] -- into the HOST buffer dst (synchronises the device).                     */
+int amx_debug_fetch(amx_ctx *ctx, const amx_lut *lut, int which, void *dst, size_t bytes);
 
 /* ---- next rows of the hot-path table (SURVEY.md section 8 f): the steps either side of model.fit ---- */
 
