@@ -34,6 +34,8 @@ int make_plan(amx_ctx *ctx, int64_t n, int ndirs, Plan &pl, bool seeds = false)
         if ((rc = ensure(ctx, ctx->schunks, (size_t)pl.max_schunks * sizeof(Chunk)))) return rc;
         if ((rc = ensure(ctx, ctx->ytil, (size_t)n * amx::kSeedKD * sizeof(double)))) return rc;
         if ((rc = ensure(ctx, ctx->seeds, (size_t)n * sizeof(unsigned long long)))) return rc;
+        if ((rc = ensure(ctx, ctx->ytil2, (size_t)n * 8 * sizeof(double)))) return rc;
+        if ((rc = ensure(ctx, ctx->seeds2, (size_t)n * 4 * sizeof(unsigned long long)))) return rc;
         pl.schunks = (Chunk *)ctx->schunks.p;
     }
     if ((rc = ensure(ctx, ctx->lutidx, n * sizeof(int)))) return rc;
@@ -150,7 +152,7 @@ int amx_ctx_create(int device, amx_ctx **out)
         const char *e = getenv("AMX_NO_SEED");
         ctx->opt_no_seed = e && *e && *e != '0';
         e = getenv("AMX_SEED_STAGES");
-        if (e && *e) ctx->opt_seed_stages = atoi(e) & 3;
+        if (e && *e) ctx->opt_seed_stages = atoi(e) & 7;
         e = getenv("AMX_SEED_CHUNK");
         if (e && atoi(e) >= 64) ctx->opt_seed_chunk = atoi(e);
     }
@@ -167,7 +169,7 @@ void amx_ctx_destroy(amx_ctx *ctx)
     hipDeviceSynchronize();
     DevBuf *bufs[] = {&ctx->lutidx, &ctx->perm, &ctx->counts, &ctx->dir_start, &ctx->cursor, &ctx->chunks,
                       &ctx->misc, &ctx->xiso, &ctx->supp, &ctx->ovf, &ctx->cproj, &ctx->hy, &ctx->hdirs, &ctx->hest,
-                      &ctx->hrmse, &ctx->hnrmse, &ctx->hextra, &ctx->hy32, &ctx->ytil, &ctx->seeds, &ctx->schunks};
+                      &ctx->hrmse, &ctx->hnrmse, &ctx->hextra, &ctx->hy32, &ctx->ytil, &ctx->seeds, &ctx->schunks, &ctx->ytil2, &ctx->seeds2};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     for (DevBuf &b : ctx->alt) if (b.p) hipFree(b.p);
     if (ctx->status_d) hipFree(ctx->status_d);
@@ -183,7 +185,7 @@ void amx_lut_destroy(amx_lut *lut)
 {
     if (!lut) return;
     if (lut->ctx) hipSetDevice(lut->ctx->device);
-    void *ps[] = {lut->basis_U, lut->basis_S, lut->gram, lut->gram_dwi, lut->tiles, lut->htable, lut->rowdwi, lut->colscale, lut->icvf, lut->kappa,
+    void *ps[] = {lut->basis_U, lut->basis_S, lut->basis2_U, lut->basis2_S, lut->gram, lut->gram_dwi, lut->tiles, lut->htable, lut->rowdwi, lut->colscale, lut->icvf, lut->kappa,
                   lut->norms, lut->Rs, lut->d_in, lut->d_isos, lut->fw_prep, lut->sandi_prep};
     for (void *p : ps) if (p) hipFree(p);
     if (lut->fw_ready) (void)hipEventDestroy(lut->fw_ready);
@@ -394,6 +396,7 @@ int amx_sync_status(amx_ctx *ctx, void *hip_stream)
     ctx->stats[3] = ((int64_t)st[ST_GUARD] << 32) | (unsigned)st[ST_GUARDVOX];
     if (amx_debug()) fprintf(stderr, "[amx] dual-vector evaluations per stage: exact %d %d %d  gram %d %d %d  inner iterations %d %d %d\n", st[ST_EXACT], st[ST_EXACT + 1], st[ST_EXACT + 2], st[ST_GRAM], st[ST_GRAM + 1], st[ST_GRAM + 2], st[ST_ITERS], st[ST_ITERS + 1], st[ST_ITERS + 2]);
     if (amx_debug()) fprintf(stderr, "[amx] seeds: stage 1 tried %d certified %d, stage 3 tried %d certified %d; seed solver trips %d lane-trips used %d; stage-1 refusals: malformed %d pivot %d refinement %d x<=0 %d dual %d\n", st[ST_SEED], st[ST_SEED + 1], st[ST_SEED + 2], st[ST_SEED + 3], st[ST_SEED + 4], st[ST_SEED + 5], st[ST_SEED + 7], st[ST_SEED + 8], st[ST_SEED + 9], st[ST_SEED + 10], st[ST_SEED + 11]);
+    if (amx_debug()) fprintf(stderr, "[amx] LASSO seeds: tried %d certified %d; seed solver trips %d lane-trips used %d\n", st[ST_SEED + 18], st[ST_SEED + 19], st[ST_SEED + 20], st[ST_SEED + 21]);
     if (amx_debug()) fprintf(stderr, "[amx] seed solver kcycles (wave sums / 1024): take %d solve+drop %d residual %d scan %d append %d store %d\n", st[ST_SEED + 12], st[ST_SEED + 13], st[ST_SEED + 14], st[ST_SEED + 15], st[ST_SEED + 16], st[ST_SEED + 17]);
     if (st[ST_ERRVOX] != 0x7f7f7f7f) {
         char b[256];
@@ -430,8 +433,12 @@ int amx_debug_fetch(amx_ctx *ctx, const amx_lut *lut, int which, void *dst, size
     case 0: src = ctx->perm.p; break;
     case 1: src = ctx->ytil.p; break;
     case 2: src = ctx->seeds.p; break;
+    case 3: src = ctx->ytil2.p; break;
+    case 4: src = ctx->seeds2.p; break;
     case 10: src = lut ? lut->basis_U : nullptr; break;
     case 11: src = lut ? lut->basis_S : nullptr; break;
+    case 12: src = lut ? lut->basis2_U : nullptr; break;
+    case 13: src = lut ? lut->basis2_S : nullptr; break;
     default: break;
     }
     if (!src) return bad(ctx, "amx_debug_fetch: no such buffer");
@@ -531,7 +538,13 @@ int amx_noddi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
             if ((rc = amx_launch_noddi_seed(ctx, lut, a, pl, s, 1))) return rc;
         }
     }
-    if (!(rc = amx_launch_noddi_s1(ctx, a, pl, s)) && !(rc = amx_launch_noddi_s2(ctx, a, pl, s))) {
+    if ((rc = amx_launch_noddi_s1(ctx, a, pl, s))) return rc;
+    // the LASSO seeds need x_iso: Gram-space solver only (lambda2 >= 1e-5), with the default dictionary shape
+    if (seeds && (ctx->opt_seed_stages & 4) && lut->basis2_S != nullptr && lambda2 >= 1e-5 && lut->nS <= 128 && !getenv("AMX_LASSO_QR")) {
+        if ((rc = amx_launch_noddi_seed2(ctx, lut, a, pl, s))) return rc;
+        a.seeds2 = (const unsigned long long *)ctx->seeds2.p;
+    }
+    if (!(rc = amx_launch_noddi_s2(ctx, a, pl, s))) {
         a.seeds = nullptr;
         if (seeds && (ctx->opt_seed_stages & 2)) {
             a.seeds = (const unsigned long long *)ctx->seeds.p;

@@ -27,6 +27,7 @@ struct GramSolver {
     int idx, np;
     double r[NR];         // row space: residual y - A s x at exit
     int iters, n_exact, n_gram;
+    int seeded;           // 1: the seed was certified, 0: refused, -1: none given
 
     __device__ __forceinline__ static int tri(int i, int j) { return i * (i + 1) / 2 + j; }
     __device__ __forceinline__ static int row(int lane) { const int i = lane < MAXP ? lane : MAXP; return i * (i + 1) / 2; }
@@ -195,11 +196,133 @@ struct GramSolver {
         return status;
     }
 
+
+    // Certify a passive-set seed (bit mask over the atoms, amx_seed.hpp: k_lasso_seed) in the full problem: Cholesky solve on
+    // H_PP = (S A'A S + lambda2 I)_PP from the Gram table -- exactly what the Lawson-Hanson path below does for its last
+    // passive set --, then the exact dual vector by one sweep of the tile and the Kuhn-Tucker test of that path (x_P > 0,
+    // g_j = s_j a_j'(y - A s x) - lambda1 <= tol for every other admissible atom).  With lambda2 > 0 the problem is strictly
+    // convex: a point that passes IS the unique optimum.  false: nothing decided, the caller starts from the empty set.
+    __device__ __forceinline__ bool certify_seed(const AT *As, int ldA, int nS, int n_atoms, const double (&yr)[NR], const bool (&rowok)[NR],
+                                                 const double (&scl)[NQ], unsigned fl, const unsigned long long (&mask)[4],
+                                                 double lam1, double lam2, double tol, double *rs, int lane,
+                                                 const double *__restrict__ G, int ldG)
+    {
+        const int n0 = __builtin_popcountll(mask[0]) + __builtin_popcountll(mask[1]) + __builtin_popcountll(mask[2]);
+        if (mask[3] != 0ull || n0 > MAXP) return false;
+        np = n0; idx = -1; sc = 1.0;
+        {
+            // slot s = the s-th set bit (ascending atom index), its column scale from atom space
+            int s = 0;
+#pragma unroll
+            for (int w3 = 0; w3 < 3; w3++) {
+                for (unsigned long long rem = mask[w3]; rem != 0ull; rem &= rem - 1ull) {
+                    const int t = w3 * 64 + __builtin_ctzll(rem);
+                    double sct = 1.0;
+#pragma unroll
+                    for (int q = 0; q < NQ; q++)
+                        if (q == (t >> 6)) sct = bcast(scl[q], t & 63);
+                    if (lane == s) { idx = t; sc = sct; }
+                    s++;
+                }
+            }
+        }
+        {
+            bool bad = false;
+            for (int s = 0; s < np; s++) {
+                const int t = bcast_i(idx, s);
+                const unsigned ft = (unsigned)bcast_i((int)fl, t & 63);
+                bad = bad || !((ft >> (t >> 6)) & 1u) || t >= n_atoms;
+            }
+            if (bad) { np = 0; idx = -1; return false; }
+        }
+        x = 0.0; xprev = 0.0; cs = 0.0; linv = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) r[rr] = yr[rr];
+        if (np > 0) {
+            for (int t = 0; t < np; t++) {
+                const int it = bcast_i(idx, t);
+                const double sct = bcast(sc, t);
+                if (lane >= t && lane < np) Hl[tri(lane, t)] = sc * sct * G[(size_t)idx * ldG + it] + ((lane == t) ? lam2 : 0.0);
+            }
+            refactor(lane);
+            // c_P = s a_p'y - lambda1: four columns per batched reduction
+            for (int s0 = 0; s0 < np; s0 += 4) {
+                double p[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int t = bcast_i(idx, (s0 + u < np) ? s0 + u : np - 1);
+                    p[u] = 0.0;
+#pragma unroll
+                    for (int rr = 0; rr < NR; rr++) {
+                        const int i = lane + kWave * rr;
+                        if (i < nS && rowok[rr]) p[u] += (double)As[i * ldA + t] * yr[rr];
+                    }
+                }
+                wave_sum4(p, lane);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (lane == s0 + u) cs = sc * p[u] - lam1;
+            }
+            if (lane >= np) cs = 0.0;
+            x = solve_passive(lane);
+            if (ballot64(lane < np && !(x > 0.0)) != 0ull) { np = 0; idx = -1; x = 0.0; cs = 0.0; linv = 0.0; return false; }
+            for (int s = 0; s < np; s++) {
+                const int t = bcast_i(idx, s);
+                const double cx = bcast(sc * x, s);
+#pragma unroll
+                for (int rr = 0; rr < NR; rr++) {
+                    const int i = lane + kWave * rr;
+                    if (i < nS && rowok[rr]) r[rr] -= (double)As[i * ldA + t] * cx;
+                }
+            }
+        }
+        // exact dual vector
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) rs[lane + kWave * rr] = r[rr];
+        double u[NQ], w2[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) { u[q] = 0.0; w2[q] = 0.0; }
+        {
+            const AT *ap = As + lane;
+            int i = 0;
+            for (; i + 1 < nS; i += 2) {
+                const double r0 = rs[i], r1 = rs[i + 1];
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    u[q] += (double)ap[i * ldA + kWave * q] * r0;
+                    w2[q] += (double)ap[(i + 1) * ldA + kWave * q] * r1;
+                }
+            }
+            if (i < nS) {
+                const double r0 = rs[i];
+#pragma unroll
+                for (int q = 0; q < NQ; q++) u[q] += (double)ap[i * ldA + kWave * q] * r0;
+            }
+        }
+        n_exact++;
+        unsigned pm = 0u;
+        for (int s = 0; s < np; s++) {
+            const int t = bcast_i(idx, s);
+            if (lane == (t & 63)) pm |= 1u << (t >> 6);
+        }
+        bool viol = false;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const double gq = scl[q] * (u[q] + w2[q]) - lam1;
+            viol = viol || ((((fl & ~pm) >> q) & 1u) && gq > tol);
+        }
+        if (ballot64(viol) != 0ull) { np = 0; idx = -1; x = 0.0; cs = 0.0; linv = 0.0; return false; }
+        xprev = x;
+        if (lane >= np) { x = 0.0; xprev = 0.0; idx = -1; }
+        return true;
+    }
+
     // G: Gram matrix A'A of this orientation restricted to the rows in rowok (REQUIRED here)
     __device__ __forceinline__ int solve(const AT *As, int ldA, int nS, int n_atoms, const double (&yr)[NR],
                                          const bool (&rowok)[NR], const double (&scl)[NQ],
                                          const unsigned long long (&allowed)[NQ], double lam1, double lam2,
-                                         double *rs, double *rl, int lane, const double *__restrict__ G, int ldG)
+                                         double *rs, double *rl, int lane, const double *__restrict__ G, int ldG,
+                                         const unsigned long long *seedmask = nullptr)
     {
         Hl = rl;
         Ll = rl + kTri;
@@ -211,6 +334,13 @@ struct GramSolver {
 #pragma unroll
         for (int q = 0; q < NQ; q++) fl |= (unsigned)((allowed[q] >> lane) & 1ull) << q;
         np = 0; x = 0.0; xprev = 0.0; sc = 1.0; cs = 0.0; linv = 0.0; idx = -1; iters = 0; n_exact = 0; n_gram = 0;
+        seeded = -1;
+        if (seedmask != nullptr) {
+            const unsigned long long m4[4] = {seedmask[0], seedmask[1], seedmask[2], seedmask[3]};
+            seeded = certify_seed(As, ldA, nS, n_atoms, yr, rowok, scl, fl, m4, lam1, lam2, tol, rs, lane, G, ldG) ? 1 : 0;
+            if (seeded == 1) return kSolved;
+            sc = 1.0;
+        }
         int status = kSolved, last_added = -1, gram_steps = 0, second_looks = 0;
         bool cyc_banned = false;
         bool have_u = false, force_exact = false;

@@ -18,7 +18,7 @@ namespace amx {
 struct Chunk { int dir, start, count, pad; };
 constexpr int kSeedKD = 12;      // compressed dimensions of the support-seed problem (amx_seed.hpp)
 
-enum StatusSlot { ST_ERRVOX = 0, ST_II1 = 1, ST_II2 = 2, ST_OVERFLOW = 3, ST_ITCAP = 4, ST_RERUN = 5, ST_GUARD = 6, ST_GUARDVOX = 7, ST_EXACT = 8, ST_GRAM = 11, ST_ITERS = 14, ST_SEED = 17, ST_WORDS = 40 };
+enum StatusSlot { ST_ERRVOX = 0, ST_II1 = 1, ST_II2 = 2, ST_OVERFLOW = 3, ST_ITCAP = 4, ST_RERUN = 5, ST_GUARD = 6, ST_GUARDVOX = 7, ST_EXACT = 8, ST_GRAM = 11, ST_ITERS = 14, ST_SEED = 17, ST_WORDS = 44 };
 
 // ------------------------------------------------------------------ shared pieces
 struct FitCommon {
@@ -118,6 +118,7 @@ struct NoddiArgs {
     const double *gram_dwi;       // same restricted to the stage-2 rows
     int ldG;
     const unsigned long long *seeds;   // support seeds of the NNLS stage being run, bucket order (amx_seed.hpp), or null
+    const unsigned long long *seeds2;  // passive-set seeds of the LASSO stage [n_vox][4], bucket order, or null
     double *xiso;                 // [n_vox][2]  x_iso, x_dot after stage 1
     unsigned long long *supp;     // [n_vox][4]  stage-2 support bit set
     double *est, *rmse, *nrmse, *mod;
@@ -198,7 +199,8 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const AT *As, do
         if (a.seeds != nullptr && pos >= 0) seed = a.seeds[pos];
     }
     int st_;
-    if constexpr (STAGE == 4) st_ = S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed, a.c.lam1, a.c.lam2, rs, rl, lane, gdir, a.ldG);
+    if constexpr (STAGE == 4) st_ = S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed, a.c.lam1, a.c.lam2, rs, rl, lane, gdir, a.ldG,
+                                            (a.seeds2 != nullptr && pos >= 0) ? a.seeds2 + (size_t)pos * 4 : nullptr);
     else st_ = S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed, kLasso ? a.c.lam1 : 0.0, kLasso ? a.c.lam2 : 0.0, rs, rl, lane, gdir, a.ldG, seed);
     const int st = __builtin_amdgcn_readfirstlane(st_);
     if (st == kOverflow) {
@@ -219,6 +221,7 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const AT *As, do
 #endif
 #ifdef AMX_STATS
     if (lane == 0) { constexpr int sx = kLasso ? 1 : STAGE - 1; atomicAdd(&a.c.status[ST_EXACT + sx], S.n_exact); atomicAdd(&a.c.status[ST_GRAM + sx], S.n_gram); atomicAdd(&a.c.status[ST_ITERS + sx], S.iters);
+        if constexpr (STAGE == 4) { if (S.seeded >= 0) atomicAdd(&a.c.status[ST_SEED + 18], 1); if (S.seeded == 1) atomicAdd(&a.c.status[ST_SEED + 19], 1); }
         if constexpr (!kLasso) { if (S.seeded >= 0) atomicAdd(&a.c.status[ST_SEED + (STAGE == 1 ? 0 : 2)], 1); if (S.seeded == 1) atomicAdd(&a.c.status[ST_SEED + (STAGE == 1 ? 1 : 3)], 1); if (S.seeded == 0 && STAGE == 1) atomicAdd(&a.c.status[ST_SEED + 6 + S.seed_why], 1); } }
 #endif
     const bool act = lane < S.np;

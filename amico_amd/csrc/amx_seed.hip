@@ -6,18 +6,56 @@ using namespace amx;
 // basis of the dominant column space of every orientation tile (once per dictionary upload)
 int amx_build_basis(amx_ctx *ctx, amx_lut *lut)
 {
+    const size_t lds = ((size_t)lut->nS * lut->ldA + (size_t)kSeedKD * lut->nS + 256) * sizeof(double);
+    if (lds > kLdsPerCU || lut->n_atoms > 160 || lut->n_wm > 144) return AMX_OK;          // no seeds for this shape
     const size_t ub = (size_t)lut->ndirs * lut->nS * kSeedKD * sizeof(double);
     const size_t sb = (size_t)lut->ndirs * lut->n_atoms * kSeedKD * sizeof(double);
     HIPCHK(ctx, hipMalloc((void **)&lut->basis_U, ub + 64));
     HIPCHK(ctx, hipMalloc((void **)&lut->basis_S, sb + 64));
-    const size_t lds = ((size_t)lut->nS * lut->ldA + (size_t)kSeedKD * lut->nS + 256) * sizeof(double);
-    if (lds > kLdsPerCU) { hipFree(lut->basis_U); hipFree(lut->basis_S); lut->basis_U = lut->basis_S = nullptr; return AMX_OK; }   // no seeds for this shape
     int rc;
     if ((rc = set_lds(ctx, k_build_basis, lds))) return rc;
     hipLaunchKernelGGL(k_build_basis, dim3(lut->ndirs), dim3(256), lds, nullptr, (const float *)lut->tiles, lut->tile_stride, lut->nS,
-                       lut->ldA, lut->n_atoms, (const unsigned char *)nullptr, (const double *)nullptr, lut->basis_U, lut->basis_S);
+                       lut->ldA, lut->n_atoms, (const unsigned char *)nullptr, (const double *)nullptr, lut->basis_U, lut->basis_S, kSeedKD);
+    // the LASSO stage's dictionary: DWI rows, column-normalised wm atoms (models.pyx:917-921), rank 8
+    if (lut->gram_dwi) {
+        HIPCHK(ctx, hipMalloc((void **)&lut->basis2_U, (size_t)lut->ndirs * lut->nS * kSeed2KD * sizeof(double) + 64));
+        HIPCHK(ctx, hipMalloc((void **)&lut->basis2_S, (size_t)lut->ndirs * lut->n_wm * kSeed2KD * sizeof(double) + 64));
+        hipLaunchKernelGGL(k_build_basis, dim3(lut->ndirs), dim3(256), lds, nullptr, (const float *)lut->tiles, lut->tile_stride, lut->nS,
+                           lut->ldA, lut->n_wm, (const unsigned char *)lut->rowdwi, (const double *)lut->colscale, lut->basis2_U, lut->basis2_S, kSeed2KD);
+    }
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipDeviceSynchronize());
+    return AMX_OK;
+}
+
+// LASSO stage: y2~ = U2'y2 and the passive-set seeds (after stage 1: y2 needs x_iso)
+int amx_launch_noddi_seed2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, const Plan &pl, hipStream_t s)
+{
+    Seed2Args sa;
+    memset(&sa, 0, sizeof sa);
+    sa.y = a.c.y; sa.perm = pl.perm; sa.chunks = pl.chunks; sa.n_chunks = pl.n_chunks;
+    sa.schunks = pl.schunks; sa.n_schunks = pl.n_chunks + 1;
+    sa.tiles = (const float *)lut->tiles; sa.tile_stride = lut->tile_stride; sa.ldA = lut->ldA;
+    sa.rowdwi = lut->rowdwi; sa.xiso = a.xiso; sa.Ub = lut->basis2_U; sa.Sb = lut->basis2_S;
+    sa.ytil = (double *)ctx->ytil2.p; sa.seeds = (unsigned long long *)ctx->seeds2.p;
+    sa.nS = lut->nS; sa.n_wm = lut->n_wm; sa.iso_atom = lut->n_atoms - 1; sa.is_exvivo = lut->is_exvivo;
+    sa.lam1 = a.c.lam1; sa.lam2 = a.c.lam2;
+#ifdef AMX_STATS
+    sa.stats = a.c.status + ST_SEED + 20;
+#endif
+#ifdef SEED2_TRACE
+    sa.trace = (double *)ctx->seeds.p; hipMemsetAsync(ctx->seeds.p, 0, 8 * 8 * 80, s);
+#endif
+    const dim3 grid(((pl.max_chunks + 7) / 8) * 8);
+    if (lut->nS <= 128) hipLaunchKernelGGL(k_noddi_project2<2>, grid, dim3(1024), 0, s, sa);
+    else hipLaunchKernelGGL(k_noddi_project2<4>, grid, dim3(1024), 0, s, sa);
+    AMX_TRACE(ctx, s, "projection of the clipped signals");
+    const size_t lds = ((size_t)lut->n_wm * (kSeed2KD + 1) + 8 + (size_t)9 * (kSeed2KD / 4) * 64 + (size_t)4 * (64 * (kSeed2KD + 1) + 64 * 3)) * sizeof(double);
+    int rc;
+    if ((rc = set_lds(ctx, k_lasso_seed, lds))) return rc;
+    hipLaunchKernelGGL(k_lasso_seed, dim3(((pl.max_schunks + 7) / 8) * 8), dim3(256), lds, s, sa);
+    AMX_TRACE(ctx, s, "LASSO seed solver");
+    HIPCHK(ctx, hipGetLastError());
     return AMX_OK;
 }
 

@@ -33,10 +33,9 @@ constexpr unsigned long long kNoSeed = kSeedNone;
 // colscale (optional): column scales.  Out: U f64 [nS][KD] (zero rows where rowsel == 0), S f64 [n_cols][KD].
 __global__ void __launch_bounds__(256) k_build_basis(const float *__restrict__ tiles, int tile_stride, int nS, int ldA, int n_cols,
                                                      const unsigned char *__restrict__ rowsel, const double *__restrict__ colscale,
-                                                     double *__restrict__ Ub, double *__restrict__ Sb)
+                                                     double *__restrict__ Ub, double *__restrict__ Sb, int KD)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    constexpr int KD = kSeedKD;
     double *R = reinterpret_cast<double *>(smem_b);            // [nS][ldA] deflated columns
     double *Q = R + (size_t)nS * ldA;                          // [KD][nS]
     double *red = Q + (size_t)KD * nS;                         // [256]
@@ -643,6 +642,340 @@ __global__ void __launch_bounds__(256, 2) k_nnls_seed(const SeedArgs a)
         atomicAdd(&a.stats[0], st_trips); atomicAdd(&a.stats[1], st_used);
         if (STAGE == 1) for (int k = 0; k < 6; k++) atomicAdd(&a.stats[8 + k], (int)(ph[k] >> 10));
     }
+#endif
+}
+
+// ================================================================== LASSO stage (models.pyx:914-926): seeds in Woodbury form
+// The stage-2 problem  min 1/2 ||y2 - A2 x||^2 + lambda1 sum(x) + lambda2/2 ||x||^2, x >= 0  (column-normalised atoms, DWI rows,
+// clipped signal) has a ridge, so on a passive set P
+//     x_P = (c_P - S_P' w) / lambda2,   (lambda2 I_k + S_P S_P') w = S_P c_P,   c_j = s_j' y~ - lambda1,
+// in the rank-k compressed space (k = 8: the support of the compressed problem equals the full problem's in tools/lab/s2_lab.py
+// on every voxel tried): the passive system is k x k WHATEVER the size of P.  With t_j = s_j' (y~ - w) - lambda1:
+// passive atoms have x_j = t_j / lambda2, all others have the dual value t_j -- one product S'(y~ - w) serves both.
+// A lane therefore carries no per-atom state at all: the passive set as a bit mask, the Cholesky factor of
+// M = lambda2 I + S_P S_P' (8 x 8) and g = S_P c_P.  One trip = solve, scan (fp64 MFMA for all 64 voxels of the wavefront),
+// then ONE rank-one change of the factor: the most negative passive atom leaves (down-date), or, if none is negative, the
+// atom with the largest dual value enters (update).  Greedy, no step back -- it is a proposal, certified afterwards by
+// GramSolver::certify_seed in the full problem.
+constexpr int kSeed2KD = 8;
+struct Seed2Args {
+    const double *y;              // [n_vox][nS]
+    const int *perm;
+    const Chunk *chunks;
+    const int *n_chunks;
+    const Chunk *schunks;
+    const int *n_schunks;
+    const float *tiles;           // dictionary tiles (the iso column of the orientation)
+    int tile_stride, ldA;
+    const unsigned char *rowdwi;
+    const double *xiso;           // [n_vox][2] stage-1 x_iso, x_dot
+    const double *Ub, *Sb;        // [ndirs][nS][8], [ndirs][n_wm][8]
+    double *ytil;                 // [n_vox][8], bucket order
+    unsigned long long *seeds;    // [n_vox][4], bucket order: passive-set bits; word 3 = all ones: no seed
+    int nS, n_wm, iso_atom, is_exvivo;
+    double lam1, lam2;
+    int *stats;
+    double *trace;                // SEED2_TRACE: per-trip records of the voxel at bucket position 0
+};
+
+template <int NR>
+__global__ void __launch_bounds__(1024) k_noddi_project2(const Seed2Args a)
+{
+    constexpr int KD = kSeed2KD;
+    const int cid = xcd_chunk((int)blockIdx.x, *a.n_chunks);
+    if (cid < 0) return;
+    const Chunk ck = a.chunks[cid];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
+    const int nS = a.nS;
+    double ur[NR][KD], isov[NR];
+    bool rowok[NR];
+    const double *U = a.Ub + (size_t)ck.dir * nS * KD;
+    const float *tile = a.tiles + (size_t)ck.dir * a.tile_stride;
+#pragma unroll
+    for (int rr = 0; rr < NR; rr++) {
+        const int i = lane + kWave * rr;
+        rowok[rr] = (i < nS) && a.rowdwi[i];
+        isov[rr] = (i < nS) ? (double)tile[i * a.ldA + a.iso_atom] : 0.0;
+#pragma unroll
+        for (int d = 0; d < KD; d++) ur[rr][d] = (i < nS) ? U[i * KD + d] : 0.0;
+    }
+    for (int k = wave; k < ck.count; k += nw) {
+        const int pos = ck.start + k;
+        const int vox = a.perm[pos];
+        const double *yv = a.y + (size_t)vox * nS;
+        const double xi = a.xiso[(size_t)vox * 2], xd = a.xiso[(size_t)vox * 2 + 1];
+        double yr[NR];
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) {
+            const int i = lane + kWave * rr;
+            double t = 0.0;
+            if (rowok[rr]) {                      // models.pyx:917-925
+                t = yv[i] - xi * isov[rr];
+                if (a.is_exvivo) t -= xd * 1.0;
+                if (t < 0.0) t = 0.0;
+            }
+            yr[rr] = t;
+        }
+        double out = 0.0;
+#pragma unroll
+        for (int b = 0; b < KD; b += 4) {
+            double p[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                p[u] = 0.0;
+#pragma unroll
+                for (int rr = 0; rr < NR; rr++) p[u] += ur[rr][b + u] * yr[rr];
+            }
+            wave_sum4(p, lane);
+#pragma unroll
+            for (int u = 0; u < 4; u++) out = (lane == b + u) ? p[u] : out;
+        }
+        if (lane < KD) a.ytil[(size_t)pos * KD + lane] = out;
+    }
+}
+
+__device__ __forceinline__ double seed_max(double a, double b)     // plain v_max_f64 (no canonicalisation of the operands)
+{
+    double d;
+    asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+__global__ void __launch_bounds__(256, 2) k_lasso_seed(const Seed2Args a)
+{
+    constexpr int KD = kSeed2KD, KS = KD / 4, MT = 9, KDP = KD + 1, NT = KD * (KD + 1) / 2, LD = KD + 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_l[];
+    double *Sl = reinterpret_cast<double *>(smem_l);             // [n_wm][LD] for the per-lane gathers
+    const int n_wm = a.n_wm;
+    unsigned *ticket = reinterpret_cast<unsigned *>(Sl + (size_t)n_wm * LD);
+    double *Aop = reinterpret_cast<double *>(ticket + 4);         // [MT][KS][64] in MFMA operand order
+    double *Rb = Aop + MT * KS * 64 + (threadIdx.x >> 6) * (64 * KDP + 64 * 3);
+    unsigned long long *Pb = reinterpret_cast<unsigned long long *>(Rb + 64 * KDP);      // [64][3] passive-set bits of the lanes' voxels
+    const int cid = xcd_chunk((int)blockIdx.x, *a.n_schunks);
+    if (cid < 0) return;
+    const Chunk ck = a.schunks[cid];
+    const int lane = threadIdx.x & 63, q = lane >> 4, c16 = lane & 15;
+    const double *__restrict__ Sg = a.Sb + (size_t)ck.dir * n_wm * KD;
+    for (int e = threadIdx.x; e < n_wm * KD; e += blockDim.x) { const int j = e / KD, d = e - j * KD; Sl[j * LD + d] = Sg[e]; }
+    for (int e = threadIdx.x; e < MT * KS * 64; e += blockDim.x) {
+        const int l = e & 63, ks = (e >> 6) % KS, mt = (e >> 6) / KS;
+        const int atom = 16 * mt + (l & 15), d = 4 * ks + (l >> 4);
+        Aop[e] = (atom < n_wm) ? Sg[(size_t)atom * KD + d] : 0.0;
+    }
+    if (threadIdx.x == 0) *ticket = 0u;
+    __syncthreads();
+    const double lam1 = a.lam1, lam2 = a.lam2, tol = 1e-9, inf = __builtin_huge_val();
+    const double sl2 = sqrt(lam2), isl2 = 1.0 / sl2;
+    constexpr int trip_cap = 64;
+
+    bool active = false;
+    int pos = 0, trips = 0;
+    double T[NT], dinv[KD], g[KD];
+    unsigned long long P[3] = {0ull, 0ull, 0ull};
+#pragma unroll
+    for (int e = 0; e < NT; e++) T[e] = 0.0;
+#pragma unroll
+    for (int d = 0; d < KD; d++) { dinv[d] = 0.0; g[d] = 0.0; }
+    bool more = true;
+#ifdef AMX_STATS
+    int st_trips = 0, st_used = 0;
+#endif
+    for (int guard = 0; guard < (1 << 20); ++guard) {
+        const unsigned long long freem = __ballot(!active);
+        if (freem != 0ull && more) {
+            const int nfree = __builtin_popcountll(freem);
+            unsigned base = 0u;
+            if (lane == 0) base = atomicAdd(ticket, (unsigned)nfree);
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            if ((int)base + nfree >= ck.count) more = false;
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(freem >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)freem, 0u));
+            const int k = (int)base + rank;
+            if (!active && k < ck.count) {
+                pos = ck.start + k;
+                const double *yp = a.ytil + (size_t)pos * KD;
+                bool finite = true;
+#pragma unroll
+                for (int d = 0; d < KD; d++) finite = finite && (fabs(yp[d]) <= 1.79769313486231570e308);
+                trips = 0;
+                P[0] = 0ull; P[1] = 0ull; P[2] = 0ull;
+#pragma unroll
+                for (int i = 0; i < KD; i++) {                 // M = lambda2 I
+#pragma unroll
+                    for (int j = 0; j <= i; j++) T[stri<KD>(i, j)] = (i == j) ? sl2 : 0.0;
+                    dinv[i] = isl2; g[i] = 0.0;
+                }
+                if (finite) active = true;
+                else { a.seeds[(size_t)pos * 4 + 3] = ~0ull; }
+            }
+        }
+        if (__ballot(active) == 0ull) {
+            if (!more) break;
+            continue;
+        }
+#ifdef AMX_STATS
+        st_trips++; st_used += __builtin_popcountll(__ballot(active));
+#endif
+        trips++;
+        // ------------------------------------------------------------ w = M^-1 g, r = y~ - w
+        double r[KD];
+        {
+            double w[KD];
+#pragma unroll
+            for (int j = 0; j < KD; j++) {
+                double f = g[j];
+#pragma unroll
+                for (int m = 0; m < j; m++) f -= T[stri<KD>(j, m)] * w[m];
+                w[j] = f * dinv[j];
+            }
+#pragma unroll
+            for (int j = KD - 1; j >= 0; j--) {
+                double f = w[j];
+#pragma unroll
+                for (int m = j + 1; m < KD; m++) f -= T[stri<KD>(m, j)] * w[m];
+                w[j] = f * dinv[j];
+            }
+            const double *yp = a.ytil + (size_t)pos * KD;
+#pragma unroll
+            for (int d = 0; d < KD; d++) r[d] = yp[d] - w[d];
+        }
+        // ------------------------------------------------------------ passive atoms of the own voxel: the most negative one
+        // (x_j = t_j / lambda2 <= 0) leaves
+        int dj = -1;
+        {
+            double worst = 0.0;
+            unsigned long long rem[3] = {active ? P[0] : 0ull, active ? P[1] : 0ull, active ? P[2] : 0ull};
+            for (int it = 0; it < 192; it++) {
+                int wq = -1;
+#pragma unroll
+                for (int qq = 2; qq >= 0; qq--) wq = (rem[qq] != 0ull) ? qq : wq;
+                if (__ballot(wq >= 0) == 0ull) break;
+                unsigned long long word = 0ull;
+#pragma unroll
+                for (int qq = 0; qq < 3; qq++) word = (wq == qq) ? rem[qq] : word;
+                const int j = (wq >= 0) ? wq * 64 + __builtin_ctzll(word) : 0;
+#pragma unroll
+                for (int qq = 0; qq < 3; qq++) rem[qq] = (wq == qq) ? (rem[qq] & (rem[qq] - 1ull)) : rem[qq];
+                const double *col = Sl + j * LD;
+                double t = -lam1;
+#pragma unroll
+                for (int d = 0; d < KD; d++) t += col[d] * r[d];
+                const bool ok = (wq >= 0) && (t <= worst);
+                worst = ok ? t : worst; dj = ok ? j : dj;
+            }
+        }
+        // ------------------------------------------------------------ dual values of all atoms for the 64 voxels (fp64 MFMA),
+        // passive atoms masked out, arg-max in the low mantissa bits (see seed_scan_mfma)
+        double best = -inf;
+        int bj = -1;
+        {
+#pragma unroll
+            for (int d = 0; d < KD; d++) Rb[lane * KDP + d] = r[d];
+#pragma unroll
+            for (int w3 = 0; w3 < 3; w3++) Pb[lane * 3 + w3] = active ? P[w3] : ~0ull;
+            double b[4][KS];
+            unsigned pq[4][6];                               // passive bits of voxel 16 nt + c16, shifted by this lane's row
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) b[nt][ks] = Rb[(16 * nt + c16) * KDP + 4 * ks + q];
+#pragma unroll
+                for (int w3 = 0; w3 < 3; w3++) {
+                    const unsigned long long m = Pb[(16 * nt + c16) * 3 + w3] >> q;
+                    pq[nt][2 * w3] = (unsigned)m; pq[nt][2 * w3 + 1] = (unsigned)(m >> 32);
+                }
+            }
+            const double ninf = -inf;
+            double bv[4] = {ninf, ninf, ninf, ninf};
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                double av[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) av[ks] = Aop[(mt * KS + ks) * 64 + lane];
+                seed_v4d acc[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) acc[nt] = (seed_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], b[nt][ks], acc[nt], 0, 0, 0);
+                }
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++) {
+                        constexpr int dummy = 0; (void)dummy;
+                        const int bit = 16 * mt + 4 * rr;        // position of this atom in the row-shifted mask
+                        const bool pas = (pq[nt][bit >> 5] >> (bit & 31)) & 1u;
+                        const double v = acc[nt][rr];
+                        const unsigned lo = ((unsigned)__double2loint(v) & 0xffffff00u) | (unsigned)(mt * 4 + rr);
+                        const int hi = pas ? (int)0xffe00000 : __double2hiint(v);     // passive: -9e307 (finite whatever the low word is; 0xfff... would be a NaN)
+                        bv[nt] = seed_max(bv[nt], __hiloint2double(hi, (int)lo));
+                    }
+                }
+            }
+            double mine = ninf;
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) {
+                const double t = __hiloint2double(__double2hiint(bv[nt]), (int)((unsigned)__double2loint(bv[nt]) | (unsigned)(q << 6)));
+                const double m = rows_allmax(t);
+                mine = (q == nt) ? m : mine;
+            }
+            const unsigned code = (unsigned)__double2loint(mine) & 0xffu;
+            best = mine - lam1;
+            bj = 16 * (int)((code >> 2) & 15u) + 4 * (int)(code & 3u) + (int)(code >> 6);
+        }
+        // ------------------------------------------------------------ one rank-one change of the factor per trip
+        bool done = false, noseed = false;
+        int jj = -1;
+        double sigma = 0.0;
+        if (active) {
+            if (dj >= 0) { jj = dj; sigma = -1.0; }
+            else if (best > tol && bj < n_wm) { jj = bj; sigma = 1.0; }
+            else done = true;
+            const int cnt = __builtin_popcountll(P[0]) + __builtin_popcountll(P[1]) + __builtin_popcountll(P[2]);
+            if (!done && (trips > trip_cap || (sigma > 0.0 && cnt >= 20))) { done = true; noseed = true; jj = -1; sigma = 0.0; }
+        }
+        {
+            // v = s_jj (zero for the lanes without a change: every rotation is then the identity, bit for bit)
+            double v[KD];
+            const double *col = Sl + (jj >= 0 ? jj : 0) * LD;
+            const double *yp = a.ytil + (size_t)pos * KD;
+            double cj = -lam1;
+#pragma unroll
+            for (int d = 0; d < KD; d++) { v[d] = (jj >= 0) ? col[d] : 0.0; cj += v[d] * yp[d]; }
+#pragma unroll
+            for (int d = 0; d < KD; d++) g[d] += sigma * cj * v[d];
+            if (jj >= 0) P[jj >> 6] ^= 1ull << (jj & 63);
+#pragma unroll
+            for (int j = 0; j < KD; j++) {
+                const double al = T[stri<KD>(j, j)], bl = v[j];
+                const bool rot = bl != 0.0;
+                const double n2 = al * al + sigma * bl * bl;
+                const double ri = rot ? ((n2 > 0.0) ? inv_sqrt(n2) : 0.0) : dinv[j];
+                const double ss = rot ? bl * dinv[j] : 0.0;
+                const double cc = rot ? n2 * ri * dinv[j] : 1.0;       // cos
+                const double ci = rot ? al * ri : 1.0;                  // 1 / cos
+                T[stri<KD>(j, j)] = rot ? n2 * ri : al;
+                dinv[j] = ri;
+#pragma unroll
+                for (int i = j + 1; i < KD; i++) {
+                    const double t = (T[stri<KD>(i, j)] + sigma * ss * v[i]) * ci;
+                    v[i] = cc * v[i] - ss * t;
+                    T[stri<KD>(i, j)] = t;
+                }
+            }
+        }
+#ifdef SEED2_TRACE
+        if (active && pos == 0 && a.trace) { double *tr = a.trace + 8 * trips; tr[0] = trips; tr[1] = jj; tr[2] = sigma; tr[3] = best; tr[4] = bj; tr[5] = dj; tr[6] = r[0]; tr[7] = g[0]; }
+#endif
+        if (done) {
+            unsigned long long *sd = a.seeds + (size_t)pos * 4;
+            sd[0] = P[0]; sd[1] = P[1]; sd[2] = P[2]; sd[3] = noseed ? ~0ull : 0ull;
+            active = false;
+        }
+    }
+#ifdef AMX_STATS
+    if (a.stats && lane == 0) { atomicAdd(&a.stats[0], st_trips); atomicAdd(&a.stats[1], st_used); }
 #endif
 }
 

@@ -40,3 +40,16 @@ for p in range(0, n, max(1, n // 2000)):
     if ids != ref and shown < 8:
         shown += 1; print('  pos', p, 'vox', v, 'seed', ids, 'exact', ref, hex(sd))
 print('seed == exact support: %d / %d' % (same, tot))
+# ---- LASSO stage seeds vs the exact stage-2 supports
+if os.environ.get('AMX_SEED_STAGES', '7') in ('7', '4', '5', '6'):
+    s2 = _capi.debug_fetch(ctx, None, 4, (n, 4), np.uint64)
+    same = 0; tot = 0; shown = 0; nos = 0
+    for p in range(0, n, max(1, n // 2000)):
+        v = perm[p]
+        if int(s2[p, 3]) != 0: nos += 1; tot += 1; continue
+        ids = [j for j in range(144) if (int(s2[p, j >> 6]) >> (j & 63)) & 1]
+        ref = np.nonzero(X[v, 1, :144] > 0)[0].tolist()
+        tot += 1; same += ids == ref
+        if ids != ref and shown < 6:
+            shown += 1; print('  pos', p, 'vox', v, 'seed', ids, 'exact', ref)
+    print('LASSO seed == exact support: %d / %d (no seed: %d)' % (same, tot, nos))
