@@ -49,6 +49,7 @@ struct amx_ctx {
         for (int i = 0; i < 16; i++) { DevBuf t = *named[i]; *named[i] = alt[i]; alt[i] = t; }
     }
     // switches read ONCE, at amx_ctx_create (environment): diagnosis / A-B only
+    bool opt_no_screen = false;    // AMX_NO_SCREEN=1: certify seeds with the full exact sweep of the dual vector
     bool opt_no_seed = false;      // AMX_NO_SEED=1: Lawson-Hanson from the empty set in the NNLS stages (the round-2 path)
     int opt_seed_stages = 7;       // AMX_SEED_STAGES: bit 0 = seed stage 1, bit 1 = seed stage 3, bit 2 = seed the LASSO stage
     int opt_seed_chunk = 2048;     // AMX_SEED_CHUNK: voxels of one orientation per workgroup of the seed solver
@@ -64,6 +65,7 @@ struct amx_lut {
     void *tiles = nullptr;
     double *gram = nullptr, *gram_dwi = nullptr;   // per-orientation Gram matrices (NODDI)
     double *basis_U = nullptr, *basis_S = nullptr; // per-orientation compressed basis and dictionary (amx_seed.hpp), NODDI
+    float *screen_S = nullptr; double *screen_kappa = nullptr;   // float32 S [ndirs][12][192] + kappa [ndirs]: dual-value screening
     double *basis2_U = nullptr, *basis2_S = nullptr;   // the same for the LASSO stage's dictionary (DWI rows, normalised atoms)
     int ldG = 0;
     short *htable = nullptr;

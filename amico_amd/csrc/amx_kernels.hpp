@@ -17,8 +17,9 @@ namespace amx {
 
 struct Chunk { int dir, start, count, pad; };
 constexpr int kSeedKD = 12;      // compressed dimensions of the support-seed problem (amx_seed.hpp)
+constexpr int kScreenLd = 192;   // atoms per row of the float32 screening table [KD][kScreenLd]
 
-enum StatusSlot { ST_ERRVOX = 0, ST_II1 = 1, ST_II2 = 2, ST_OVERFLOW = 3, ST_ITCAP = 4, ST_RERUN = 5, ST_GUARD = 6, ST_GUARDVOX = 7, ST_EXACT = 8, ST_GRAM = 11, ST_ITERS = 14, ST_SEED = 17, ST_WORDS = 44 };
+enum StatusSlot { ST_ERRVOX = 0, ST_II1 = 1, ST_II2 = 2, ST_OVERFLOW = 3, ST_ITCAP = 4, ST_RERUN = 5, ST_GUARD = 6, ST_GUARDVOX = 7, ST_EXACT = 8, ST_GRAM = 11, ST_ITERS = 14, ST_SEED = 17, ST_WORDS = 48 };
 
 // ------------------------------------------------------------------ shared pieces
 struct FitCommon {
@@ -119,6 +120,9 @@ struct NoddiArgs {
     int ldG;
     const unsigned long long *seeds;   // support seeds of the NNLS stage being run, bucket order (amx_seed.hpp), or null
     const unsigned long long *seeds2;  // passive-set seeds of the LASSO stage [n_vox][4], bucket order, or null
+    // dual-value screening of certify_seed (NNLS stages): float32 S [ndirs][12][192], kappa [ndirs], y~ [n_vox][12] (bucket
+    // order), fp64 S [ndirs][n_atoms][12]; all null: exact sweep
+    const float *scr_S; const double *scr_kappa, *scr_ytil, *scr_Sg;
     double *xiso;                 // [n_vox][2]  x_iso, x_dot after stage 1
     unsigned long long *supp;     // [n_vox][4]  stage-2 support bit set
     double *est, *rmse, *nrmse, *mod;
@@ -128,7 +132,7 @@ struct NoddiArgs {
 // (models.pyx:914-926), 3 = debias NNLS + maps (models.pyx:929-967)
 template <int STAGE, int NR, int NQ, int MAXP, typename AT = float>
 __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const AT *As, double *rs, double *rl,
-                                            unsigned long long *wmask, int vox, int dir, int lane, int pos = -1)
+                                            unsigned long long *wmask, int vox, int dir, int lane, int pos = -1, const float *Sf = nullptr)
 {
     constexpr bool kLasso = (STAGE == 2 || STAGE == 4);
     const int nS = a.c.nS, ldA = a.c.ldA, n_atoms = a.c.n_atoms, n_wm = a.n_wm;
@@ -201,7 +205,17 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const AT *As, do
     int st_;
     if constexpr (STAGE == 4) st_ = S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed, a.c.lam1, a.c.lam2, rs, rl, lane, gdir, a.ldG,
                                             (a.seeds2 != nullptr && pos >= 0) ? a.seeds2 + (size_t)pos * 4 : nullptr);
-    else st_ = S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed, kLasso ? a.c.lam1 : 0.0, kLasso ? a.c.lam2 : 0.0, rs, rl, lane, gdir, a.ldG, seed);
+    else {
+        SeedScreen scr;
+        if (Sf != nullptr && pos >= 0 && seed != kSeedNone) {
+            scr.Sf = Sf; scr.ld = kScreenLd; scr.kappa = a.scr_kappa[dir];
+            scr.ytil = a.scr_ytil + (size_t)pos * kSeedKD; scr.Sg = a.scr_Sg + (size_t)dir * n_atoms * kSeedKD;
+#ifdef AMX_STATS
+            scr.count = a.c.status + ST_SEED + 22;
+#endif
+        }
+        st_ = S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed, kLasso ? a.c.lam1 : 0.0, kLasso ? a.c.lam2 : 0.0, rs, rl, lane, gdir, a.ldG, seed, scr);
+    }
     const int st = __builtin_amdgcn_readfirstlane(st_);
     if (st == kOverflow) {
         if (lane == 0) {
@@ -616,6 +630,13 @@ __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
         unsigned *ticket = reinterpret_cast<unsigned *>(wm_all + nw_ * 4);     // the 16 spare bytes of fit_lds_bytes
         if (threadIdx.x == 0) *ticket = (unsigned)nw_;
         stage_noddi_tile<AT>(As, tiles + (size_t)ck.dir * a.c.tile_stride, words, words_pad - words);
+        // NNLS stages with seeds: the float32 compressed dictionary of the orientation for the dual-value screening
+        float *Sf = nullptr;
+        if ((STAGE == 1 || STAGE == 3) && a.scr_S != nullptr && a.seeds != nullptr) {
+            Sf = reinterpret_cast<float *>(ticket + 4);
+            const float *src = a.scr_S + (size_t)ck.dir * kSeedKD * kScreenLd;
+            for (int e = threadIdx.x; e < kSeedKD * kScreenLd; e += blockDim.x) Sf[e] = src[e];
+        }
         __syncthreads();
 #ifdef AMX_STATIC_VOXELS
         for (int k = wave; k < ck.count; k += nw_) {
@@ -625,7 +646,7 @@ __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
         // voxels differ 2-3x in solver iterations: the wavefronts draw the next voxel of the chunk from an LDS ticket
         // (next_ticket keeps the control flow wave-uniform: every lane takes part in the atomic)
         for (int k = wave; k < ck.count; k = next_ticket(ticket, lane)) {
-            noddi_voxel<STAGE, NR, NQ, MAXP, AT>(a, As, rs, rl, wmask, a.c.perm[ck.start + k], ck.dir, lane, ck.start + k);
+            noddi_voxel<STAGE, NR, NQ, MAXP, AT>(a, As, rs, rl, wmask, a.c.perm[ck.start + k], ck.dir, lane, ck.start + k, Sf);
         }
 #endif
     } else {

@@ -10,20 +10,21 @@ static int go(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
 #endif
     constexpr int NQ = 3, MP = AMX_S3_MP, MB = 32;
 #ifndef AMX_S3_NW
-#define AMX_S3_NW 16
+#define AMX_S3_NW 12      // (measured with the seeded path: 16 wavefronts -> 128 VGPRs and 223 spilled registers, 5.9 ms; 12 -> 168 VGPRs, 3.7 ms)
 #endif
     constexpr int NW = AMX_S3_NW; // wavefronts per workgroup: as many as the register budget of this stage allows
+    const size_t scr = (a.scr_S && a.seeds) ? (size_t)kSeedKD * kScreenLd * sizeof(float) : 0;   // screening table (amx_solver.hpp)
     // fp64 tile in LDS when it fits next to the per-wavefront blocks (99 x 145: 115 KB + 16 x 2.3 KB of 160 KB): the
     // fp32 -> fp64 conversions of the tile reads are then paid once per chunk.  AMX_TILE_F32=1: the fp32 tile.
     {
         const char *e = getenv("AMX_TILE_F32");
-        if (fit_lds_bytes<double>(a.c.nS, a.c.ldA, NR, NQ, NW, MP, false, false) <= kLdsPerCU && !(e && *e && *e != '0'))
+        if (fit_lds_bytes<double>(a.c.nS, a.c.ldA, NR, NQ, NW, MP, false, false) + scr <= kLdsPerCU && !(e && *e && *e != '0'))
             return launch_pair<NW>(ctx, a, pl, s, k_noddi<3, NR, NQ, MP, NW, false, double>, k_noddi<3, NR, NQ, MB, 1, true>,
-                                   [&](int nw) { return fit_lds_bytes<double>(a.c.nS, a.c.ldA, NR, NQ, nw, MP, false, false); },
+                                   [&](int nw) { return fit_lds_bytes<double>(a.c.nS, a.c.ldA, NR, NQ, nw, MP, false, false) + scr; },
                                    fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, false), 2, 6);
     }
     return launch_pair<NW>(ctx, a, pl, s, k_noddi<3, NR, NQ, MP, NW, false>, k_noddi<3, NR, NQ, MB, 1, true>,
-                       [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MP, false, false); }, fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, false),
+                       [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MP, false, false) + scr; }, fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, false),
                        2, 6);
 }
 

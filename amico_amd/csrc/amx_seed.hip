@@ -12,10 +12,14 @@ int amx_build_basis(amx_ctx *ctx, amx_lut *lut)
     const size_t sb = (size_t)lut->ndirs * lut->n_atoms * kSeedKD * sizeof(double);
     HIPCHK(ctx, hipMalloc((void **)&lut->basis_U, ub + 64));
     HIPCHK(ctx, hipMalloc((void **)&lut->basis_S, sb + 64));
+    HIPCHK(ctx, hipMalloc((void **)&lut->screen_S, (size_t)lut->ndirs * kSeedKD * kScreenLd * sizeof(float) + 64));
+    HIPCHK(ctx, hipMemset(lut->screen_S, 0, (size_t)lut->ndirs * kSeedKD * kScreenLd * sizeof(float)));
+    HIPCHK(ctx, hipMalloc((void **)&lut->screen_kappa, (size_t)lut->ndirs * sizeof(double) + 64));
     int rc;
     if ((rc = set_lds(ctx, k_build_basis, lds))) return rc;
     hipLaunchKernelGGL(k_build_basis, dim3(lut->ndirs), dim3(256), lds, nullptr, (const float *)lut->tiles, lut->tile_stride, lut->nS,
-                       lut->ldA, lut->n_atoms, (const unsigned char *)nullptr, (const double *)nullptr, lut->basis_U, lut->basis_S, kSeedKD);
+                       lut->ldA, lut->n_atoms, (const unsigned char *)nullptr, (const double *)nullptr, lut->basis_U, lut->basis_S, kSeedKD,
+                       lut->screen_S, lut->screen_kappa);
     // the LASSO stage's dictionary: DWI rows, column-normalised wm atoms (models.pyx:917-921), rank 8
     if (lut->gram_dwi) {
         HIPCHK(ctx, hipMalloc((void **)&lut->basis2_U, (size_t)lut->ndirs * lut->nS * kSeed2KD * sizeof(double) + 64));

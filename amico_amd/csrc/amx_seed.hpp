@@ -33,7 +33,8 @@ constexpr unsigned long long kNoSeed = kSeedNone;
 // colscale (optional): column scales.  Out: U f64 [nS][KD] (zero rows where rowsel == 0), S f64 [n_cols][KD].
 __global__ void __launch_bounds__(256) k_build_basis(const float *__restrict__ tiles, int tile_stride, int nS, int ldA, int n_cols,
                                                      const unsigned char *__restrict__ rowsel, const double *__restrict__ colscale,
-                                                     double *__restrict__ Ub, double *__restrict__ Sb, int KD)
+                                                     double *__restrict__ Ub, double *__restrict__ Sb, int KD,
+                                                     float *__restrict__ Sf = nullptr, double *__restrict__ kap = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     double *R = reinterpret_cast<double *>(smem_b);            // [nS][ldA] deflated columns
@@ -84,6 +85,30 @@ __global__ void __launch_bounds__(256) k_build_basis(const float *__restrict__ t
         }
         __syncthreads();
     }
+    // what the basis leaves out: the deflated columns ARE e_j = (I - U U') a_j.  kappa bounds, per unit of ||r||, how far the
+    // compressed dual value s_j'(U'r) (evaluated from the float32 copy Sf of S) can be from a_j'r: max ||e_j|| plus the
+    // rounding of the float32 table and products, 2e-6 max ||a_j||  (NNSolver::certify_seed screens with it)
+    if (kap != nullptr) {
+        double en = 0.0, an = 0.0;
+        if (tid < n_cols) {
+            for (int i = 0; i < nS; i++) {
+                const double v = R[i * ldA + tid]; en += v * v;
+                double o = (rowsel == nullptr || rowsel[i]) ? (double)g[i * ldA + tid] : 0.0;
+                if (colscale != nullptr) o *= colscale[tid];
+                an += o * o;
+            }
+        }
+        red[tid] = en;
+        __syncthreads();
+        if (tid == 0) { double m = 0.0; for (int j = 0; j < n_cols && j < nt; j++) m = red[j] > m ? red[j] : m; s_n = m; }
+        __syncthreads();
+        const double emax = sqrt(s_n);
+        __syncthreads();
+        red[tid] = an;
+        __syncthreads();
+        if (tid == 0) { double m = 0.0; for (int j = 0; j < n_cols && j < nt; j++) m = red[j] > m ? red[j] : m; kap[blockIdx.x] = emax + 2e-6 * sqrt(m); }
+        __syncthreads();
+    }
     double *U = Ub + (size_t)blockIdx.x * nS * KD;
     for (int e = tid; e < nS * KD; e += nt) { const int i = e / KD, d = e - i * KD; U[e] = Q[d * nS + i]; }
     // S = U'A from the ORIGINAL (scaled, row-selected) columns
@@ -97,6 +122,7 @@ __global__ void __launch_bounds__(256) k_build_basis(const float *__restrict__ t
         }
         if (colscale != nullptr) c *= colscale[j];
         S[e] = c;
+        if (Sf != nullptr) Sf[(size_t)blockIdx.x * KD * kScreenLd + d * kScreenLd + j] = (float)c;      // [d][atom], zero padded
     }
 }
 

@@ -40,6 +40,15 @@ constexpr int kWave = 64;
 #define AMX_PH(k) do { } while (0)
 #endif
 enum SolveStatus : int { kSolved = 0, kOverflow = 1, kIterCap = 2, kGuardSelect = 3, kGuardOuter = 4 };
+// inputs of the dual-value screening in certify_seed (all of one voxel / orientation; Sf == nullptr: exact sweep instead)
+struct SeedScreen {
+    const float *Sf = nullptr;        // LDS: float32 compressed dictionary [KD][ld]
+    int ld = 0;
+    double kappa = 0.0;               // |a_j'r - s_j'(U'r)| <= kappa ||r|| for every atom of the orientation
+    const double *ytil = nullptr;     // global: U'y of the voxel [KD]
+    const double *Sg = nullptr;       // global: fp64 compressed dictionary of the orientation [n_atoms][KD]
+    int *count = nullptr;             // statistics (AMX_STATS): atoms that needed the exact dot product
+};
 // support seed of a voxel (amx_seed.hpp): up to 8 atom ids, one per byte from the low end; bytes >= 0xf0 are empty
 constexpr unsigned long long kSeedNone = ~0ull;
 
@@ -375,7 +384,7 @@ struct NNSolver {
     // seeded columns are independent).  false: nothing is decided -- the caller starts Lawson-Hanson from the empty set.
     __device__ __forceinline__ bool certify_seed(const AT *As, int ldA, int nS, const double (&yr)[NR], const bool (&rowok)[NR],
                                                  unsigned fl, unsigned long long seed, double *rs, int lane,
-                                                 const double *__restrict__ G, int ldG)
+                                                 const double *__restrict__ G, int ldG, const SeedScreen &scr)
     {
         // decode: slot s = byte s
         const int my = (int)((seed >> (8 * (lane & 7))) & 0xffull);
@@ -461,19 +470,80 @@ struct NNSolver {
             }
         }
         if (ok) {
-            // exact dual vector of the candidate solution; strict test over the admissible atoms outside the seed
-            double u[NQ];
-            sweep(As, ldA, nS, r, rs, lane, u);
-            n_exact++;
             unsigned pm = 0u;                                    // bit q: atom lane + 64 q is seeded
             for (int s = 0; s < np; s++) {
                 const int t = bcast_i(idx, s);
                 if (lane == (t & 63)) pm |= 1u << (t >> 6);
             }
-            bool viol = false;
+            if (scr.Sf == nullptr) {
+                // exact dual vector of the candidate solution; strict test over the admissible atoms outside the seed
+                double u[NQ];
+                sweep(As, ldA, nS, r, rs, lane, u);
+                n_exact++;
+                bool viol = false;
 #pragma unroll
-            for (int q = 0; q < NQ; q++) viol = viol || (((fl & ~pm) >> q) & 1u && u[q] > 0.0);
-            ok = ballot64(viol) == 0ull;
+                for (int q = 0; q < NQ; q++) viol = viol || (((fl & ~pm) >> q) & 1u && u[q] > 0.0);
+                ok = ballot64(viol) == 0ull;
+            } else {
+                // SCREENED test.  a_j = U s_j + e_j with ||e_j|| tiny (the basis spans the dictionary to float32 rounding), so
+                // a_j'r = s_j'(U'r) + e_j'r and |e_j'r| <= ||e_j|| ||r||: an atom whose compressed dual value is below
+                // -kappa ||r|| cannot violate.  U'r = y~ - S_P x needs no reduction (lane d < KD owns component d); the
+                // compressed dual values are KD float32 products per atom from an LDS table.  Only the atoms inside the
+                // margin get their exact fp64 dual value (a column dot product), and the strict test of the sweep.
+                constexpr int KDs = 12;
+                // few admissible atoms outside the seed (stage 3: the LASSO support): all of them get the exact value at once
+                int n_out = 0;
+#pragma unroll
+                for (int q = 0; q < NQ; q++) n_out += __builtin_popcountll(ballot64(((fl & ~pm) >> q) & 1u));
+                const bool direct = n_out <= 12;
+                float ut[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; q++) ut[q] = 0.0f;
+                double rho2 = 0.0;
+                if (!direct) {
+#pragma unroll
+                    for (int rr = 0; rr < NR; rr++) rho2 += r[rr] * r[rr];
+                    rho2 = wave_sum(rho2);
+                    double rt = (lane < KDs) ? scr.ytil[lane] : 0.0;
+#pragma unroll
+                    for (int m = 0; m < MAXP; m++) {
+                        if (m < np) {
+                            const int t = bcast_i(idx, m);
+                            const double xs = bcast(x, m);
+                            if (lane < KDs) rt -= scr.Sg[(size_t)t * KDs + lane] * xs;
+                        }
+                    }
+#pragma unroll
+                    for (int dd = 0; dd < KDs; dd++) {
+                        const float rd = (float)bcast(rt, dd);
+#pragma unroll
+                        for (int q = 0; q < NQ; q++) ut[q] += scr.Sf[dd * scr.ld + lane + kWave * q] * rd;
+                    }
+                }
+                const float margin = direct ? __builtin_huge_valf() : (float)(1.0625 * scr.kappa * sqrt(rho2));
+                bool viol = false;
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    unsigned long long todo = ballot64((((fl & ~pm) >> q) & 1u) && !(ut[q] < -margin));
+                    while (todo != 0ull) {
+                        const int t = kWave * q + __builtin_ctzll(todo);
+                        todo &= todo - 1ull;
+                        double p = 0.0;
+#pragma unroll
+                        for (int rr = 0; rr < NR; rr++) {
+                            const int i = lane + kWave * rr;
+                            if (i < nS && rowok[rr]) p += (double)As[i * ldA + t] * r[rr];
+                        }
+                        p = wave_sum(p);
+                        viol = viol || (p > 0.0);
+#ifdef AMX_STATS
+                        if (scr.count && lane == 0) atomicAdd(scr.count, 1);
+#endif
+                    }
+                }
+                n_exact++;
+                ok = !viol;
+            }
             if (!ok) seed_why = 5;
         }
         if (!ok) {
@@ -497,7 +567,7 @@ struct NNSolver {
                                          const unsigned long long (&allowed)[NQ],
                                          double lam1, double lam2, double *rs, double *rl, int lane,
                                          const double *__restrict__ G = nullptr, int ldG = 0,
-                                         unsigned long long seed = kSeedNone)
+                                         unsigned long long seed = kSeedNone, const SeedScreen &scr = SeedScreen())
     {
         Rl = rl;
         Ql = rl + (MAXP + 1) * LDR;
@@ -535,7 +605,7 @@ struct NNSolver {
         n_exact = 0; n_gram = 0;
         seeded = -1;
         if (!RIDGE && G != nullptr && seed != kSeedNone && lam1 == 0.0) {
-            seeded = certify_seed(As, ldA, nS, yr, rowok, fl, seed, rs, lane, G, ldG) ? 1 : 0;
+            seeded = certify_seed(As, ldA, nS, yr, rowok, fl, seed, rs, lane, G, ldG, scr) ? 1 : 0;
             if (seeded == 1) return kSolved;
         }
 #ifdef AMX_PHASES
