@@ -34,7 +34,7 @@ int make_plan(amx_ctx *ctx, int64_t n, int ndirs, Plan &pl, bool seeds = false)
         if ((rc = ensure(ctx, ctx->schunks, (size_t)pl.max_schunks * sizeof(Chunk)))) return rc;
         if ((rc = ensure(ctx, ctx->ytil, (size_t)n * amx::kSeedKD * sizeof(double)))) return rc;
         if ((rc = ensure(ctx, ctx->seeds, (size_t)n * sizeof(unsigned long long)))) return rc;
-        if ((rc = ensure(ctx, ctx->ytil2, (size_t)n * 8 * sizeof(double)))) return rc;
+        if ((rc = ensure(ctx, ctx->ytil2, (size_t)n * amx::kSeedKD * sizeof(double)))) return rc;
         if ((rc = ensure(ctx, ctx->seeds2, (size_t)n * 4 * sizeof(unsigned long long)))) return rc;
         pl.schunks = (Chunk *)ctx->schunks.p;
     }
@@ -187,7 +187,7 @@ void amx_lut_destroy(amx_lut *lut)
 {
     if (!lut) return;
     if (lut->ctx) hipSetDevice(lut->ctx->device);
-    void *ps[] = {lut->screen_S, lut->screen_kappa, lut->basis_U, lut->basis_S, lut->basis2_U, lut->basis2_S, lut->gram, lut->gram_dwi, lut->tiles, lut->htable, lut->rowdwi, lut->colscale, lut->icvf, lut->kappa,
+    void *ps[] = {lut->screen2_S, lut->screen2_kappa, lut->screen_S, lut->screen_kappa, lut->basis_U, lut->basis_S, lut->basis2_U, lut->basis2_S, lut->gram, lut->gram_dwi, lut->tiles, lut->htable, lut->rowdwi, lut->colscale, lut->icvf, lut->kappa,
                   lut->norms, lut->Rs, lut->d_in, lut->d_isos, lut->fw_prep, lut->sandi_prep};
     for (void *p : ps) if (p) hipFree(p);
     if (lut->fw_ready) (void)hipEventDestroy(lut->fw_ready);
@@ -398,7 +398,7 @@ int amx_sync_status(amx_ctx *ctx, void *hip_stream)
     ctx->stats[3] = ((int64_t)st[ST_GUARD] << 32) | (unsigned)st[ST_GUARDVOX];
     if (amx_debug()) fprintf(stderr, "[amx] dual-vector evaluations per stage: exact %d %d %d  gram %d %d %d  inner iterations %d %d %d\n", st[ST_EXACT], st[ST_EXACT + 1], st[ST_EXACT + 2], st[ST_GRAM], st[ST_GRAM + 1], st[ST_GRAM + 2], st[ST_ITERS], st[ST_ITERS + 1], st[ST_ITERS + 2]);
     if (amx_debug()) fprintf(stderr, "[amx] seeds: stage 1 tried %d certified %d, stage 3 tried %d certified %d; seed solver trips %d lane-trips used %d; stage-1 refusals: malformed %d pivot %d refinement %d x<=0 %d dual %d\n", st[ST_SEED], st[ST_SEED + 1], st[ST_SEED + 2], st[ST_SEED + 3], st[ST_SEED + 4], st[ST_SEED + 5], st[ST_SEED + 7], st[ST_SEED + 8], st[ST_SEED + 9], st[ST_SEED + 10], st[ST_SEED + 11]);
-    if (amx_debug()) fprintf(stderr, "[amx] screened certificates: %d exact dot products\n", st[ST_SEED + 22]);
+    if (amx_debug()) fprintf(stderr, "[amx] screened certificates: %d exact dot products (NNLS stages), %d (LASSO stage)\n", st[ST_SEED + 22], st[ST_SEED + 23]);
     if (amx_debug()) fprintf(stderr, "[amx] LASSO seeds: tried %d certified %d; seed solver trips %d lane-trips used %d\n", st[ST_SEED + 18], st[ST_SEED + 19], st[ST_SEED + 20], st[ST_SEED + 21]);
     if (amx_debug()) fprintf(stderr, "[amx] seed solver kcycles (wave sums / 1024): take %d solve+drop %d residual %d scan %d append %d store %d\n", st[ST_SEED + 12], st[ST_SEED + 13], st[ST_SEED + 14], st[ST_SEED + 15], st[ST_SEED + 16], st[ST_SEED + 17]);
     if (st[ST_ERRVOX] != 0x7f7f7f7f) {
@@ -547,6 +547,7 @@ int amx_noddi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
     if (seeds && (ctx->opt_seed_stages & 4) && lut->basis2_S != nullptr && lambda2 >= 1e-5 && lut->nS <= 128 && !getenv("AMX_LASSO_QR")) {
         if ((rc = amx_launch_noddi_seed2(ctx, lut, a, pl, s))) return rc;
         a.seeds2 = (const unsigned long long *)ctx->seeds2.p;
+        if (!ctx->opt_no_screen && lut->screen2_S) { a.scr2_S = lut->screen2_S; a.scr2_kappa = lut->screen2_kappa; a.scr2_ytil = (const double *)ctx->ytil2.p; a.scr2_Sg = lut->basis2_S; }
     }
     if (!(rc = amx_launch_noddi_s2(ctx, a, pl, s))) {
         a.seeds = nullptr;

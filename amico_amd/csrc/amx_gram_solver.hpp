@@ -205,7 +205,7 @@ struct GramSolver {
     __device__ __forceinline__ bool certify_seed(const AT *As, int ldA, int nS, int n_atoms, const double (&yr)[NR], const bool (&rowok)[NR],
                                                  const double (&scl)[NQ], unsigned fl, const unsigned long long (&mask)[4],
                                                  double lam1, double lam2, double tol, double *rs, int lane,
-                                                 const double *__restrict__ G, int ldG)
+                                                 const double *__restrict__ G, int ldG, const SeedScreen &scr)
     {
         const int n0 = __builtin_popcountll(mask[0]) + __builtin_popcountll(mask[1]) + __builtin_popcountll(mask[2]);
         if (mask[3] != 0ull || n0 > MAXP) return false;
@@ -276,41 +276,88 @@ struct GramSolver {
                 }
             }
         }
-        // exact dual vector
-#pragma unroll
-        for (int rr = 0; rr < NR; rr++) rs[lane + kWave * rr] = r[rr];
-        double u[NQ], w2[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; q++) { u[q] = 0.0; w2[q] = 0.0; }
-        {
-            const AT *ap = As + lane;
-            int i = 0;
-            for (; i + 1 < nS; i += 2) {
-                const double r0 = rs[i], r1 = rs[i + 1];
-#pragma unroll
-                for (int q = 0; q < NQ; q++) {
-                    u[q] += (double)ap[i * ldA + kWave * q] * r0;
-                    w2[q] += (double)ap[(i + 1) * ldA + kWave * q] * r1;
-                }
-            }
-            if (i < nS) {
-                const double r0 = rs[i];
-#pragma unroll
-                for (int q = 0; q < NQ; q++) u[q] += (double)ap[i * ldA + kWave * q] * r0;
-            }
-        }
-        n_exact++;
         unsigned pm = 0u;
         for (int s = 0; s < np; s++) {
             const int t = bcast_i(idx, s);
             if (lane == (t & 63)) pm |= 1u << (t >> 6);
         }
         bool viol = false;
+        if (scr.Sf == nullptr) {
+            // exact dual vector
 #pragma unroll
-        for (int q = 0; q < NQ; q++) {
-            const double gq = scl[q] * (u[q] + w2[q]) - lam1;
-            viol = viol || ((((fl & ~pm) >> q) & 1u) && gq > tol);
+            for (int rr = 0; rr < NR; rr++) rs[lane + kWave * rr] = r[rr];
+            double u[NQ], w2[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; q++) { u[q] = 0.0; w2[q] = 0.0; }
+            {
+                const AT *ap = As + lane;
+                int i = 0;
+                for (; i + 1 < nS; i += 2) {
+                    const double r0 = rs[i], r1 = rs[i + 1];
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) {
+                        u[q] += (double)ap[i * ldA + kWave * q] * r0;
+                        w2[q] += (double)ap[(i + 1) * ldA + kWave * q] * r1;
+                    }
+                }
+                if (i < nS) {
+                    const double r0 = rs[i];
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) u[q] += (double)ap[i * ldA + kWave * q] * r0;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                const double gq = scl[q] * (u[q] + w2[q]) - lam1;
+                viol = viol || ((((fl & ~pm) >> q) & 1u) && gq > tol);
+            }
+        } else {
+            // screened test (see NNSolver::certify_seed): s a_j'r = s2_j'(U2'r) + e_j'r, U2'r = y2~ - S2_P x; atoms whose
+            // compressed dual value is below -kappa ||r|| cannot violate, the others get the exact dot product
+            constexpr int KDs = 12;
+            double rho2 = 0.0;
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++) rho2 += r[rr] * r[rr];
+            rho2 = wave_sum(rho2);
+            double rt = (lane < KDs) ? scr.ytil[lane] : 0.0;
+            for (int s = 0; s < np; s++) {
+                const int t = bcast_i(idx, s);
+                const double xs = bcast(x, s);
+                if (lane < KDs) rt -= scr.Sg[(size_t)t * KDs + lane] * xs;
+            }
+            float ut[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; q++) ut[q] = 0.0f;
+#pragma unroll
+            for (int dd = 0; dd < KDs; dd++) {
+                const float rd = (float)bcast(rt, dd);
+#pragma unroll
+                for (int q = 0; q < NQ; q++) ut[q] += scr.Sf[dd * scr.ld + lane + kWave * q] * rd;
+            }
+            const float margin = (float)(1.0625 * scr.kappa * sqrt(rho2)), l1f = (float)lam1;
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                unsigned long long todo = ballot64((((fl & ~pm) >> q) & 1u) && !(ut[q] - l1f < -margin));
+                while (todo != 0ull) {
+                    const int tl = __builtin_ctzll(todo);
+                    const int t = kWave * q + tl;
+                    todo &= todo - 1ull;
+                    double p = 0.0;
+#pragma unroll
+                    for (int rr = 0; rr < NR; rr++) {
+                        const int i = lane + kWave * rr;
+                        if (i < nS && rowok[rr]) p += (double)As[i * ldA + t] * r[rr];
+                    }
+                    p = wave_sum(p);
+                    const double gt = bcast(scl[q], tl) * p - lam1;
+                    viol = viol || (gt > tol);
+#ifdef AMX_STATS
+                    if (scr.count && lane == 0) atomicAdd(scr.count, 1);
+#endif
+                }
+            }
         }
+        n_exact++;
         if (ballot64(viol) != 0ull) { np = 0; idx = -1; x = 0.0; cs = 0.0; linv = 0.0; return false; }
         xprev = x;
         if (lane >= np) { x = 0.0; xprev = 0.0; idx = -1; }
@@ -322,7 +369,7 @@ struct GramSolver {
                                          const bool (&rowok)[NR], const double (&scl)[NQ],
                                          const unsigned long long (&allowed)[NQ], double lam1, double lam2,
                                          double *rs, double *rl, int lane, const double *__restrict__ G, int ldG,
-                                         const unsigned long long *seedmask = nullptr)
+                                         const unsigned long long *seedmask = nullptr, const SeedScreen &scr = SeedScreen())
     {
         Hl = rl;
         Ll = rl + kTri;
@@ -337,7 +384,7 @@ struct GramSolver {
         seeded = -1;
         if (seedmask != nullptr) {
             const unsigned long long m4[4] = {seedmask[0], seedmask[1], seedmask[2], seedmask[3]};
-            seeded = certify_seed(As, ldA, nS, n_atoms, yr, rowok, scl, fl, m4, lam1, lam2, tol, rs, lane, G, ldG) ? 1 : 0;
+            seeded = certify_seed(As, ldA, nS, n_atoms, yr, rowok, scl, fl, m4, lam1, lam2, tol, rs, lane, G, ldG, scr) ? 1 : 0;
             if (seeded == 1) return kSolved;
             sc = 1.0;
         }

@@ -65,6 +65,7 @@ struct amx_lut {
     void *tiles = nullptr;
     double *gram = nullptr, *gram_dwi = nullptr;   // per-orientation Gram matrices (NODDI)
     double *basis_U = nullptr, *basis_S = nullptr; // per-orientation compressed basis and dictionary (amx_seed.hpp), NODDI
+    float *screen2_S = nullptr; double *screen2_kappa = nullptr; // the same for the LASSO stage's dictionary
     float *screen_S = nullptr; double *screen_kappa = nullptr;   // float32 S [ndirs][12][192] + kappa [ndirs]: dual-value screening
     double *basis2_U = nullptr, *basis2_S = nullptr;   // the same for the LASSO stage's dictionary (DWI rows, normalised atoms)
     int ldG = 0;

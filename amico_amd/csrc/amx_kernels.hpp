@@ -123,6 +123,7 @@ struct NoddiArgs {
     // dual-value screening of certify_seed (NNLS stages): float32 S [ndirs][12][192], kappa [ndirs], y~ [n_vox][12] (bucket
     // order), fp64 S [ndirs][n_atoms][12]; all null: exact sweep
     const float *scr_S; const double *scr_kappa, *scr_ytil, *scr_Sg;
+    const float *scr2_S; const double *scr2_kappa, *scr2_ytil, *scr2_Sg;   // the same for the LASSO stage (n_wm atoms, stage-2 rows)
     double *xiso;                 // [n_vox][2]  x_iso, x_dot after stage 1
     unsigned long long *supp;     // [n_vox][4]  stage-2 support bit set
     double *est, *rmse, *nrmse, *mod;
@@ -203,8 +204,18 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const AT *As, do
         if (a.seeds != nullptr && pos >= 0) seed = a.seeds[pos];
     }
     int st_;
-    if constexpr (STAGE == 4) st_ = S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed, a.c.lam1, a.c.lam2, rs, rl, lane, gdir, a.ldG,
-                                            (a.seeds2 != nullptr && pos >= 0) ? a.seeds2 + (size_t)pos * 4 : nullptr);
+    if constexpr (STAGE == 4) {
+        SeedScreen scr;
+        if (Sf != nullptr && pos >= 0 && a.seeds2 != nullptr) {
+            scr.Sf = Sf; scr.ld = kScreenLd; scr.kappa = a.scr2_kappa[dir];
+            scr.ytil = a.scr2_ytil + (size_t)pos * kSeedKD; scr.Sg = a.scr2_Sg + (size_t)dir * n_wm * kSeedKD;
+#ifdef AMX_STATS
+            scr.count = a.c.status + ST_SEED + 23;
+#endif
+        }
+        st_ = S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed, a.c.lam1, a.c.lam2, rs, rl, lane, gdir, a.ldG,
+                      (a.seeds2 != nullptr && pos >= 0) ? a.seeds2 + (size_t)pos * 4 : nullptr, scr);
+    }
     else {
         SeedScreen scr;
         if (Sf != nullptr && pos >= 0 && seed != kSeedNone) {
@@ -635,6 +646,11 @@ __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
         if ((STAGE == 1 || STAGE == 3) && a.scr_S != nullptr && a.seeds != nullptr) {
             Sf = reinterpret_cast<float *>(ticket + 4);
             const float *src = a.scr_S + (size_t)ck.dir * kSeedKD * kScreenLd;
+            for (int e = threadIdx.x; e < kSeedKD * kScreenLd; e += blockDim.x) Sf[e] = src[e];
+        }
+        if (STAGE == 4 && a.scr2_S != nullptr && a.seeds2 != nullptr) {
+            Sf = reinterpret_cast<float *>(ticket + 4);
+            const float *src = a.scr2_S + (size_t)ck.dir * kSeedKD * kScreenLd;
             for (int e = threadIdx.x; e < kSeedKD * kScreenLd; e += blockDim.x) Sf[e] = src[e];
         }
         __syncthreads();

@@ -22,10 +22,14 @@ int amx_build_basis(amx_ctx *ctx, amx_lut *lut)
                        lut->screen_S, lut->screen_kappa);
     // the LASSO stage's dictionary: DWI rows, column-normalised wm atoms (models.pyx:917-921), rank 8
     if (lut->gram_dwi) {
-        HIPCHK(ctx, hipMalloc((void **)&lut->basis2_U, (size_t)lut->ndirs * lut->nS * kSeed2KD * sizeof(double) + 64));
-        HIPCHK(ctx, hipMalloc((void **)&lut->basis2_S, (size_t)lut->ndirs * lut->n_wm * kSeed2KD * sizeof(double) + 64));
+        HIPCHK(ctx, hipMalloc((void **)&lut->basis2_U, (size_t)lut->ndirs * lut->nS * kSeed2Ld * sizeof(double) + 64));
+        HIPCHK(ctx, hipMalloc((void **)&lut->basis2_S, (size_t)lut->ndirs * lut->n_wm * kSeed2Ld * sizeof(double) + 64));
+        HIPCHK(ctx, hipMalloc((void **)&lut->screen2_S, (size_t)lut->ndirs * kSeedKD * kScreenLd * sizeof(float) + 64));
+        HIPCHK(ctx, hipMemset(lut->screen2_S, 0, (size_t)lut->ndirs * kSeedKD * kScreenLd * sizeof(float)));
+        HIPCHK(ctx, hipMalloc((void **)&lut->screen2_kappa, (size_t)lut->ndirs * sizeof(double) + 64));
         hipLaunchKernelGGL(k_build_basis, dim3(lut->ndirs), dim3(256), lds, nullptr, (const float *)lut->tiles, lut->tile_stride, lut->nS,
-                           lut->ldA, lut->n_wm, (const unsigned char *)lut->rowdwi, (const double *)lut->colscale, lut->basis2_U, lut->basis2_S, kSeed2KD);
+                           lut->ldA, lut->n_wm, (const unsigned char *)lut->rowdwi, (const double *)lut->colscale, lut->basis2_U, lut->basis2_S, kSeed2Ld,
+                           lut->screen2_S, lut->screen2_kappa);
     }
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipDeviceSynchronize());

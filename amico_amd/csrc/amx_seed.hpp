@@ -683,7 +683,8 @@ __global__ void __launch_bounds__(256, 2) k_nnls_seed(const SeedArgs a)
 // then ONE rank-one change of the factor: the most negative passive atom leaves (down-date), or, if none is negative, the
 // atom with the largest dual value enters (update).  Greedy, no step back -- it is a proposal, certified afterwards by
 // GramSolver::certify_seed in the full problem.
-constexpr int kSeed2KD = 8;
+constexpr int kSeed2KD = 8;       // components the LASSO seed solver works with (the first 8 of the 12 stored: the pivoted basis is nested)
+constexpr int kSeed2Ld = kSeedKD; // stride of U2 / S2 / y2~ rows
 struct Seed2Args {
     const double *y;              // [n_vox][nS]
     const int *perm;
@@ -707,7 +708,7 @@ struct Seed2Args {
 template <int NR>
 __global__ void __launch_bounds__(1024) k_noddi_project2(const Seed2Args a)
 {
-    constexpr int KD = kSeed2KD;
+    constexpr int KD = kSeed2Ld;
     const int cid = xcd_chunk((int)blockIdx.x, *a.n_chunks);
     if (cid < 0) return;
     const Chunk ck = a.chunks[cid];
@@ -781,12 +782,13 @@ __global__ void __launch_bounds__(256, 2) k_lasso_seed(const Seed2Args a)
     if (cid < 0) return;
     const Chunk ck = a.schunks[cid];
     const int lane = threadIdx.x & 63, q = lane >> 4, c16 = lane & 15;
-    const double *__restrict__ Sg = a.Sb + (size_t)ck.dir * n_wm * KD;
-    for (int e = threadIdx.x; e < n_wm * KD; e += blockDim.x) { const int j = e / KD, d = e - j * KD; Sl[j * LD + d] = Sg[e]; }
+    constexpr int SLD = kSeed2Ld;
+    const double *__restrict__ Sg = a.Sb + (size_t)ck.dir * n_wm * SLD;
+    for (int e = threadIdx.x; e < n_wm * KD; e += blockDim.x) { const int j = e / KD, d = e - j * KD; Sl[j * LD + d] = Sg[(size_t)j * SLD + d]; }
     for (int e = threadIdx.x; e < MT * KS * 64; e += blockDim.x) {
         const int l = e & 63, ks = (e >> 6) % KS, mt = (e >> 6) / KS;
         const int atom = 16 * mt + (l & 15), d = 4 * ks + (l >> 4);
-        Aop[e] = (atom < n_wm) ? Sg[(size_t)atom * KD + d] : 0.0;
+        Aop[e] = (atom < n_wm) ? Sg[(size_t)atom * SLD + d] : 0.0;
     }
     if (threadIdx.x == 0) *ticket = 0u;
     __syncthreads();
@@ -818,7 +820,7 @@ __global__ void __launch_bounds__(256, 2) k_lasso_seed(const Seed2Args a)
             const int k = (int)base + rank;
             if (!active && k < ck.count) {
                 pos = ck.start + k;
-                const double *yp = a.ytil + (size_t)pos * KD;
+                const double *yp = a.ytil + (size_t)pos * SLD;
                 bool finite = true;
 #pragma unroll
                 for (int d = 0; d < KD; d++) finite = finite && (fabs(yp[d]) <= 1.79769313486231570e308);
@@ -860,7 +862,7 @@ __global__ void __launch_bounds__(256, 2) k_lasso_seed(const Seed2Args a)
                 for (int m = j + 1; m < KD; m++) f -= T[stri<KD>(m, j)] * w[m];
                 w[j] = f * dinv[j];
             }
-            const double *yp = a.ytil + (size_t)pos * KD;
+            const double *yp = a.ytil + (size_t)pos * SLD;
 #pragma unroll
             for (int d = 0; d < KD; d++) r[d] = yp[d] - w[d];
         }
@@ -965,7 +967,7 @@ __global__ void __launch_bounds__(256, 2) k_lasso_seed(const Seed2Args a)
             // v = s_jj (zero for the lanes without a change: every rotation is then the identity, bit for bit)
             double v[KD];
             const double *col = Sl + (jj >= 0 ? jj : 0) * LD;
-            const double *yp = a.ytil + (size_t)pos * KD;
+            const double *yp = a.ytil + (size_t)pos * SLD;
             double cj = -lam1;
 #pragma unroll
             for (int d = 0; d < KD; d++) { v[d] = (jj >= 0) ? col[d] : 0.0; cj += v[d] * yp[d]; }

@@ -159,10 +159,10 @@ int amx_set_debug_x(amx_ctx *ctx, double *d_x);
 /* ---- diagnosis / tests of the support seeds (csrc/amx_seed.hpp; no counterpart in the reference): copies a workspace
  * buffer of the LAST NODDI fit of this ctx -- which = 0: voxel permutation int32[n] (bucket order), 1: projected signals
  * f64[n][12] (bucket order), 2: support seeds uint64[n] (bucket order; up to 8 atom ids, one per byte, >= 0xf0 = empty;
- * all ones = no seed), 3: projected clipped signals of the LASSO stage f64[n][8], 4: LASSO passive-set seeds uint64[n][4]
+ * all ones = no seed), 3: projected clipped signals of the LASSO stage f64[n][12], 4: LASSO passive-set seeds uint64[n][4]
  * (bit j = atom j; word 3 all ones = no seed) -- or a table of the dictionary `lut` -- 10: orientation bases U
  * f64[ndirs][nS][12], 11: compressed dictionaries S = U'A f64[ndirs][n_atoms][12], 12 / 13: the same for the LASSO stage's
- * dictionary, f64[ndirs][nS][8] / f64[ndirs][n_wm][8] -- into the HOST buffer dst (synchronises the device).              */
+ * dictionary, f64[ndirs][nS][12] / f64[ndirs][n_wm][12] (the seed solver reads the first 8 components) -- into the HOST buffer dst (synchronises the device).              */
 int amx_debug_fetch(amx_ctx *ctx, const amx_lut *lut, int which, void *dst, size_t bytes);
 
 /* ---- next rows of the hot-path table (SURVEY.md section 8 f): the steps either side of model.fit ---- */

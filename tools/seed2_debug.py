@@ -15,10 +15,10 @@ yt = torch.from_numpy(y).cuda(); dt = torch.from_numpy(d).cuda()
 res = _capi.noddi_fit_device(ctx, lut, yt, dt, 0.5, 1e-3, 3, return_x=True); ctx.sync()
 X = res[-1].cpu().numpy()
 perm = _capi.debug_fetch(ctx, None, 0, (n,), np.int32)
-y2t = _capi.debug_fetch(ctx, None, 3, (n, 8), np.float64)
+y2t = _capi.debug_fetch(ctx, None, 3, (n, 12), np.float64)[:, :8]
 s2 = _capi.debug_fetch(ctx, None, 4, (n, 4), np.uint64)
-U2 = _capi.debug_fetch(ctx, lut, 12, (500, 99, 8), np.float64)
-S2 = _capi.debug_fetch(ctx, lut, 13, (500, 144, 8), np.float64)
+U2 = _capi.debug_fetch(ctx, lut, 12, (500, 99, 12), np.float64)[:, :, :8]
+S2 = _capi.debug_fetch(ctx, lut, 13, (500, 144, 12), np.float64)[:, :, :8]
 li = S.lut_indices(d, ht); dwi = np.asarray(sch.dwi_idx); norms = K['norms'][0]; iso = K['iso'].astype(np.float64)
 lam1, lam2 = 0.5, 1e-3
 # basis / projection checks on voxel perm[0]
