@@ -478,7 +478,7 @@ int amx_set_profiling(amx_ctx *ctx, int enable)
 
 int amx_last_kernel_ms(amx_ctx *ctx, int which, float *out_ms)
 {
-    if (!ctx || !out_ms || which < 0 || which > 4) return AMX_E_BADARG;
+    if (!ctx || !out_ms || which < 0 || which > 7) return AMX_E_BADARG;
     const int a = which == 0 ? 0 : 2 * which, b = which == 0 ? 1 : 2 * which + 1;
     if (!ctx->ev_valid[a] || !ctx->ev_valid[b]) return bad(ctx, "amx_last_kernel_ms: no profiled call");
     HIPCHK(ctx, hipEventSynchronize(ctx->ev[b]));
@@ -535,17 +535,21 @@ int amx_noddi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
     HIPCHK(ctx, hipMemsetAsync(d_estimates, 0, (size_t)n_vox * a.n_maps * sizeof(double), s));
     if (seeds) {
         // y~ = U'y once; the seed solver proposes the stage's support, the stage kernel certifies it (amx_seed.hpp)
+        rec(ctx, 10, s);
         if ((rc = amx_launch_noddi_project(ctx, lut, a, pl, s))) return rc;
         if (!ctx->opt_no_screen) { a.scr_S = lut->screen_S; a.scr_kappa = lut->screen_kappa; a.scr_ytil = (const double *)ctx->ytil.p; a.scr_Sg = lut->basis_S; }
         if (ctx->opt_seed_stages & 1) {
             a.seeds = (const unsigned long long *)ctx->seeds.p;
             if ((rc = amx_launch_noddi_seed(ctx, lut, a, pl, s, 1))) return rc;
         }
+        rec(ctx, 11, s);
     }
     if ((rc = amx_launch_noddi_s1(ctx, a, pl, s))) return rc;
     // the LASSO seeds need x_iso: Gram-space solver only (lambda2 >= 1e-5), with the default dictionary shape
     if (seeds && (ctx->opt_seed_stages & 4) && lut->basis2_S != nullptr && lambda2 >= 1e-5 && lut->nS <= 128 && !getenv("AMX_LASSO_QR")) {
+        rec(ctx, 12, s);
         if ((rc = amx_launch_noddi_seed2(ctx, lut, a, pl, s))) return rc;
+        rec(ctx, 13, s);
         a.seeds2 = (const unsigned long long *)ctx->seeds2.p;
         if (!ctx->opt_no_screen && lut->screen2_S) { a.scr2_S = lut->screen2_S; a.scr2_kappa = lut->screen2_kappa; a.scr2_ytil = (const double *)ctx->ytil2.p; a.scr2_Sg = lut->basis2_S; }
     }
@@ -553,7 +557,9 @@ int amx_noddi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
         a.seeds = nullptr;
         if (seeds && (ctx->opt_seed_stages & 2)) {
             a.seeds = (const unsigned long long *)ctx->seeds.p;
+            rec(ctx, 14, s);
             rc = amx_launch_noddi_seed(ctx, lut, a, pl, s, 3);
+            rec(ctx, 15, s);
         }
         if (!rc) rc = amx_launch_noddi_s3(ctx, a, pl, s);
     }

@@ -39,8 +39,8 @@ def gather_packed(blocks, n_total, group=None):
     i, j = shard_range(n_total, dist.get_rank(group), world)
     if n_local != j - i:
         raise ValueError(f'rank {dist.get_rank(group)} holds {n_local} voxels, its shard of {n_total} has {j - i}')
-    flat = [blocks[k].reshape(n_local, -1) for k in names]
-    widths = [t.shape[1] for t in flat]
+    widths = [int(np.prod(blocks[k].shape[1:])) for k in names]          # (explicit: reshape(0, -1) is ambiguous for an empty shard)
+    flat = [blocks[k].reshape(n_local, w) for k, w in zip(names, widths)]
     longest = n_total - (world - 1) * (n_total // world)
     buf = torch.zeros((longest, sum(widths)), dtype=first.dtype, device=first.device)
     col = 0
@@ -87,6 +87,8 @@ def fit_sharded(model, evaluation, group=None, directions=None, n_total=None, to
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     ev = copy.copy(evaluation)
+    if getattr(evaluation, '_dev', None) is not None:
+        ev._dev = dict(evaluation._dev)          # the shard's device state must not leak into the caller's evaluation
     if n_total is None:
         n_total = evaluation.y.shape[0]
         i, j = shard_range(n_total, rank, world)

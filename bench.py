@@ -461,7 +461,7 @@ def sharded_step(fit, est, gathered, world):
 
     def step():
         fit()
-        if world > 1:
+        if gathered is not None:             # (world == 1 runs allocate no gather buffer; a test may: RCCL with one rank)
             gather_equal(est, gathered)
     return step
 
@@ -488,6 +488,23 @@ def timed_steps(step, step_sync, steps, warmup, world, dev, per_step=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed
+
+
+def self_launch(n_gpus):
+    """re-run this command line under torch.distributed.run: N ranks on this node, rendezvous on 127.0.0.1 (the
+    container hostname may not resolve); the ranks inherit stdout, rank 0 prints the one JSON line"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        raise SystemExit(rc)
 
 
 def main():
@@ -519,9 +536,13 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, RCCL over xGMI)
+        return self_launch(args.gpus)
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if torch.cuda.is_available() and torch.cuda.device_count() < world and world > 1:
+        raise SystemExit('bench.py: %d GPUs requested, %d visible' % (world, torch.cuda.device_count()))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the fit path has no CPU fallback')
     torch.cuda.set_device(local_rank)
@@ -553,10 +574,14 @@ def main():
                                          est.data_ptr(), None, None, None, stream))
 
     step = sharded_step(fit, est, gathered, world)          # fit + the single collective of the path
-    kms = np.zeros(4)
+    kms = np.zeros(8)
 
     def per_step():
-        kms[:] += [ctx.last_kernel_ms(w) for w in range(4)]    # HIP events on the launch stream
+        for w in (0, 1, 2, 3, 5, 6, 7):                          # HIP events on the launch stream
+            try:
+                kms[w] += ctx.last_kernel_ms(w)
+            except Exception:                                   # seed kernels absent (AMX_NO_SEED=1)
+                pass
 
     # ctx.sync: status of the step (raises on error)
     elapsed = timed_steps(step, lambda: ctx.sync(stream), args.steps, args.warmup, world, dev, per_step)
@@ -565,7 +590,10 @@ def main():
 
     if rank == 0:
         value = world * n * args.steps / elapsed
-        stage = int(np.argmax(kms[1:4])) + 1
+        names = {1: 'k_noddi<1> (NNLS over all atoms: certificate of the seed)', 2: 'k_noddi<4> (LASSO certificate)', 3: 'k_noddi<3> (debias NNLS certificate + maps)',
+                 5: 'k_noddi_project + k_nnls_seed<1> (seed solver, stage 1)', 6: 'k_noddi_project2 + k_lasso_seed (seed solver, LASSO stage)',
+                 7: 'k_nnls_seed<3> (seed solver, stage 3)'}
+        stage = max(names, key=lambda w: kms[w])
         dom_ms = float(kms[stage])
         achieved = BYTES_PER_VOXEL * n / (dom_ms * 1e-3) / 1e9
         traffic = pmc_traffic(stage, n)
@@ -582,8 +610,8 @@ def main():
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'traffic_source': 'profiles/pmc_traffic.json (rocprofv3 --pmc, bytes per launch)'
                                            if traffic is not None else None,
-                         'kernel': 'k_noddi<stage %d>' % stage, 'kernel_ms': dom_ms,
-                         'stage_ms': [float(v) for v in kms[1:4]], 'all_kernels_ms': float(kms[0]),
+                         'kernel': names[stage], 'kernel_ms': dom_ms,
+                         'stage_ms': [float(v) for v in kms[1:4]], 'seed_ms': [float(v) for v in kms[5:8]], 'all_kernels_ms': float(kms[0]),
                          'note': 'path is fp64-VALU issue bound, not HBM bound (DESIGN.md section 5): see compute_side'},
             'compute_side': pmc_valu(stage, n, dom_ms),
             'solver_stats': stats,

@@ -1,0 +1,80 @@
+"""The N-GPU path on the one GPU a test box has: RCCL ("nccl") with a single rank exercises init_process_group, the packed
+all_gather_into_tensor on device memory and bench.py's step / timing helpers; `bench.py --gpus 2` must start its own ranks
+and fail with a clear message when the GPUs are not there."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _nccl_world1(port):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    return dist
+
+
+def test_sharded_step_and_fit_sharded_under_rccl_world1():
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from amico_amd import _capi, get_context, synthetic as S
+    from amico_amd.parallel import fit_sharded, gather_maps
+    dist = _nccl_world1(36500 + os.getpid() % 2000)
+    try:
+        dev = torch.device('cuda', 0)
+        ctx = get_context()
+        dirs = S.fibonacci_hemisphere(500); ht = S.build_htable(dirs)
+        sch = S.make_scheme(seed=0); K = S.noddi_kernels(sch, dirs)
+        n = 4096
+        y_h, d_h = S.noddi_signals(n, K, ht, sch, seed=11)
+        lut = _capi.upload_noddi(ctx, K, ht, sch.dwi_idx)
+        y = torch.from_numpy(y_h).to(dev); d = torch.from_numpy(d_h).to(dev)
+        est = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+        gathered = torch.full((n, 3), -1.0, dtype=torch.float64, device=dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        L = _capi.lib()
+
+        def fit():
+            ctx.check(L.amx_noddi_fit_device(ctx._h, lut._h, y.data_ptr(), d.data_ptr(), n, 0.5, 1e-3, 0, est.data_ptr(), None, None, None, stream))
+        step = bench.sharded_step(fit, est, gathered, 1)                 # fit + the one collective, on device memory
+        el = bench.timed_steps(step, lambda: ctx.sync(stream), 2, 1, 1, dev)
+        assert el > 0
+        assert torch.equal(gathered, est)
+        ref = _capi.noddi_fit(ctx, lut, y_h, d_h, 0.5, 1e-3, 3)[0]
+        assert np.abs(gathered.cpu().numpy() - ref).max() < 1e-12
+        # the packed gather of fit_sharded (unequal-shard code path, here one shard)
+        got = gather_maps(est, n)
+        assert got.is_cuda and torch.equal(got, est)
+
+        class Model:
+            def fit(self, ev):
+                return {'estimates': _capi.noddi_fit(ctx, lut, ev.y, ev.DIRs, 0.5, 1e-3, 3)[0]}
+
+        class Ev:
+            pass
+        ev = Ev(); ev.y = y_h; ev.DIRs = d_h
+        out = fit_sharded(Model(), ev, n_total=n)
+        assert np.abs(out['estimates'] - ref).max() < 1e-12
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_gpus2_starts_its_own_ranks():
+    """one visible GPU: the command form of the driver's scaling run must get as far as the ranks and say what is missing"""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('needs a box with fewer than 2 GPUs')
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--voxels', '4096',
+                        '--no-cpu-baseline', '--no-other-configs'], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode != 0
+    assert '2 GPUs requested, 1 visible' in (p.stdout + p.stderr)
