@@ -488,6 +488,7 @@ __global__ void __launch_bounds__(256, 2) k_nnls_seed(const SeedArgs a)
             double z[MS];
             V.solve(z);
             int kmin = V.step(z);
+            if (active && kmin < 0) { ban0 = -1; ban1 = -1; }     // the last addition stood: forget the refused candidates
             if (__ballot(active && kmin >= 0) != 0ull) {
                 bool ok = true;
                 if (active && kmin >= 0) {
@@ -506,8 +507,6 @@ __global__ void __launch_bounds__(256, 2) k_nnls_seed(const SeedArgs a)
                     if (!ok) scan = false;                     // (numerically dependent set: the next trip's step sorts it out)
                     else if (V.step(z) >= 0) scan = false;     // still infeasible: the drop happens next trip (x already stepped)
                 }
-            } else if (active) {
-                ban0 = -1; ban1 = -1;                          // the last addition stood: forget the refused candidates
             }
         }
         SEED_PH(1);

@@ -475,7 +475,16 @@ struct NNSolver {
                 const int t = bcast_i(idx, s);
                 if (lane == (t & 63)) pm |= 1u << (t >> 6);
             }
-            if (scr.Sf == nullptr) {
+            // ||r||^2 and ||y||^2 together; a residual at rounding level is a Kuhn-Tucker point whatever the signs of the
+            // dual values (see the zero-residual exit of solve())
+            double nrm[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++) { nrm[0] += r[rr] * r[rr]; nrm[1] += yr[rr] * yr[rr]; }
+            wave_sum4(nrm, lane);
+            const bool zero_res = np > 0 && nrm[0] <= 1e-28 * nrm[1];
+            if (zero_res) {
+                n_exact++;
+            } else if (scr.Sf == nullptr) {
                 // exact dual vector of the candidate solution; strict test over the admissible atoms outside the seed
                 double u[NQ];
                 sweep(As, ldA, nS, r, rs, lane, u);
@@ -499,11 +508,8 @@ struct NNSolver {
                 float ut[NQ];
 #pragma unroll
                 for (int q = 0; q < NQ; q++) ut[q] = 0.0f;
-                double rho2 = 0.0;
+                const double rho2 = nrm[0];
                 if (!direct) {
-#pragma unroll
-                    for (int rr = 0; rr < NR; rr++) rho2 += r[rr] * r[rr];
-                    rho2 = wave_sum(rho2);
                     double rt = (lane < KDs) ? scr.ytil[lane] : 0.0;
 #pragma unroll
                     for (int m = 0; m < MAXP; m++) {
@@ -627,6 +633,16 @@ struct NNSolver {
 #pragma unroll
         for (int q = 0; q < NQ; q++) u[q] = 0.0;
 
+        // Zero-residual exit (unregularised NNLS): once ||r|| <= 1e-14 ||y|| every dual value a_j'r is rounding noise of
+        // either sign, and Lawson-Hanson's strict `w > 0` rule would keep admitting atoms with coefficients ~1e-17 until
+        // the iteration cap (a voxel whose signal IS an atom: golden fixture voxel 0).  The point is a Kuhn-Tucker point to
+        // working precision: stop there.
+        double ysq = 0.0;
+        if (lam1 == 0.0 && !RIDGE) {
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++) ysq += yr[rr] * yr[rr];
+            ysq = wave_sum(ysq);
+        }
         for (int outer = 0; status == kSolved; ++outer) {
             if (outer > 2 * itmax) { status = kGuardOuter; break; }   // never spin
             double w[NQ];
@@ -645,6 +661,13 @@ struct NNSolver {
                             for (int rr = 0; rr < NR; rr++) r[rr] -= Q[k][rr] * ck;
                         }
                     }
+                }
+                if (lam1 == 0.0 && !RIDGE && np > 0) {
+                    double rsq = 0.0;
+#pragma unroll
+                    for (int rr = 0; rr < NR; rr++) rsq += r[rr] * r[rr];
+                    rsq = wave_sum(rsq);
+                    if (uni(rsq <= 1e-28 * ysq)) break;
                 }
                 // ---- u = A' r (atom space): one sweep over the LDS tile
 #pragma unroll

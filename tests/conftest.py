@@ -11,6 +11,9 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # a voxel that stops at the iteration cap of an active-set solver is a test failure, not a warning (round-2 verdict:
+    # the exact-atom voxel of the NODDI fixture used to end there; the solver now leaves at a zero residual)
+    config.addinivalue_line('filterwarnings', 'error:amico_amd.*iteration cap:RuntimeWarning')
 
 
 def load_npz(name):

@@ -78,3 +78,29 @@ def test_bench_gpus2_starts_its_own_ranks():
                         '--no-cpu-baseline', '--no-other-configs'], capture_output=True, text=True, env=env, timeout=600)
     assert p.returncode != 0
     assert '2 GPUs requested, 1 visible' in (p.stdout + p.stderr)
+
+
+def test_noddi_fit_is_bitwise_repeatable():
+    """The seed solvers run one voxel per lane next to 63 others drawn from a ticket: which voxels share a wavefront changes
+    from call to call, the result of a voxel must not (a neighbour-dependent branch once made ~20 of 900 000 seeds differ
+    between calls).  Coefficient vectors of all three stages, bit for bit, over repeated calls."""
+    import torch
+    sys.path.insert(0, ROOT)
+    from amico_amd import _capi, get_context, synthetic as S
+    ctx = get_context()
+    dirs = S.fibonacci_hemisphere(500); ht = S.build_htable(dirs)
+    sch = S.make_scheme(seed=0); K = S.noddi_kernels(sch, dirs)
+    n = 300_000
+    y_h, d_h = S.noddi_signals(n, K, ht, sch, seed=21)
+    lut = _capi.upload_noddi(ctx, K, ht, sch.dwi_idx)
+    y = torch.from_numpy(y_h).cuda(); d = torch.from_numpy(d_h).cuda()
+    ref = None
+    for rep in range(4):
+        out = _capi.noddi_fit_device(ctx, lut, y, d, 0.5, 1e-3, 3, rmse=True, return_x=True)
+        ctx.sync()
+        cur = [out[0].clone(), out[1].clone(), out[-1].clone()]
+        if ref is None:
+            ref = cur
+            continue
+        for a, b in zip(ref, cur):
+            assert torch.equal(a, b)
