@@ -208,6 +208,13 @@ template <int N> __device__ __forceinline__ constexpr int stri(int i, int j) { r
 //     l >> 4), so one v_max_f64 per value keeps both; the four rows that share a voxel are combined by the two row
 //     swaps, and the lane that owns voxel v finds its result in row v >> 4.  (2^-44 relative: far below what the choice
 //     of the entering atom, or the 1e-10 stopping test, can see.)
+__device__ __forceinline__ double seed_max(double a, double b)     // plain v_max_f64 (no canonicalisation of the operands)
+{
+    double d;
+    asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 typedef double seed_v4d __attribute__((ext_vector_type(4)));
 template <int KS, int MT>
 __device__ __forceinline__ void seed_scan_mfma(const double *Aop, double *Rb, const double (&r)[4 * KS], int lane, double &best, int &bj)
@@ -243,7 +250,7 @@ __device__ __forceinline__ void seed_scan_mfma(const double *Aop, double *Rb, co
             for (int rr = 0; rr < 4; rr++) {
                 const double v = acc[nt][rr];
                 const unsigned lo = ((unsigned)__double2loint(v) & 0xffffff00u) | (unsigned)(mt * 4 + rr);
-                bv[nt] = fmax(bv[nt], __hiloint2double(__double2hiint(v), (int)lo));
+                bv[nt] = seed_max(bv[nt], __hiloint2double(__double2hiint(v), (int)lo));
             }
         }
     }
@@ -373,26 +380,24 @@ struct SeedLane {
             }
         }
     }
-    // step from x towards z: returns the slot that reaches zero first (-1: z is feasible and becomes x)
+    // step from x towards z: returns the slot that reaches zero first (-1: z is feasible and becomes x).  The smallest ratio
+    // x_s / (x_s - z_s) over the infeasible slots is found by cross-multiplication (denominators are positive): one
+    // division per call instead of one per slot
     __device__ __forceinline__ int step(const double (&z)[MS])
     {
-        const double inf = __builtin_huge_val();
-        double alpha = inf;
+        double nb = 0.0, db = 1.0;
         int kmin = -1;
 #pragma unroll
         for (int s = 0; s < MS; s++) {
             const bool neg = s < np && !(z[s] > 0.0);
             const double den = x[s] - z[s];
-            const double ratio = neg ? ((den > 0.0) ? seed_div(x[s], den) : 0.0) : inf;
-            if (ratio < alpha) { alpha = ratio; kmin = s; }
+            const double num = (den > 0.0) ? x[s] : 0.0, dd = (den > 0.0) ? den : 1.0;
+            const bool better = neg && (kmin < 0 || num * db < nb * dd);
+            nb = better ? num : nb; db = better ? dd : db; kmin = better ? s : kmin;
         }
-        if (kmin >= 0) {
+        const double alpha = seed_div(nb, db);                 // (0 / 1 when nothing is infeasible: unused)
 #pragma unroll
-            for (int s = 0; s < MS; s++) x[s] = (s < np) ? x[s] + alpha * (z[s] - x[s]) : 0.0;
-        } else {
-#pragma unroll
-            for (int s = 0; s < MS; s++) x[s] = z[s];
-        }
+        for (int s = 0; s < MS; s++) x[s] = (kmin < 0) ? z[s] : ((s < np) ? x[s] + alpha * (z[s] - x[s]) : 0.0);
         return kmin;
     }
 };
@@ -758,13 +763,6 @@ __global__ void __launch_bounds__(1024) k_noddi_project2(const Seed2Args a)
         }
         if (lane < KD) a.ytil[(size_t)pos * KD + lane] = out;
     }
-}
-
-__device__ __forceinline__ double seed_max(double a, double b)     // plain v_max_f64 (no canonicalisation of the operands)
-{
-    double d;
-    asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
 }
 
 __global__ void __launch_bounds__(256, 2) k_lasso_seed(const Seed2Args a)
