@@ -381,12 +381,12 @@ int amx_sync_status(amx_ctx *ctx, void *hip_stream)
     HIPCHK(ctx, hipStreamSynchronize(s));
 #ifdef AMX_PHASES
     if (ctx->misc.p) {
-        static const char *nm[8] = {"sweep", "gram-update", "selection", "column+CGS", "commit", "tri-solve", "step/removal", "other"};
+        static const char *nm[8] = {"decode", "columns+gram", "cholesky", "solve+residual", "refinement", "norms", "screening", "exact-dots"};   // certified voxels: phases of certify_seed
         for (int st_ = 0; st_ < 2; st_++) {
             unsigned long long tot = 0;
             for (int k = 0; k < 8; k++) tot += ph_[st_ * 8 + k];
             fprintf(stderr, "[amx] NNLS stage %d phases:", st_ == 0 ? 1 : 3);
-            for (int k = 0; k < 7; k++) fprintf(stderr, " %s %.1f%%", nm[k], tot ? 100.0 * ph_[st_ * 8 + k] / tot : 0.0);
+            for (int k = 0; k < 8; k++) fprintf(stderr, " %s %.1f%%", nm[k], tot ? 100.0 * ph_[st_ * 8 + k] / tot : 0.0);
             fprintf(stderr, "\n");
         }
     }

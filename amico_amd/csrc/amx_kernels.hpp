@@ -238,7 +238,7 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const AT *As, do
     if (st > kIterCap && lane == 0) { atomicAdd(&a.c.status[ST_GUARD], 1); a.c.status[ST_GUARDVOX] = vox * 8 + st; }
 #ifdef AMX_PHASES
     if constexpr (STAGE == 1 || STAGE == 3) {
-        if (lane == 0) {
+        if (lane == 0 && S.seeded == 1) {       // (certified voxels only: phases of certify_seed)
             unsigned long long *acc = reinterpret_cast<unsigned long long *>(const_cast<int *>(a.c.n_chunks) + 16) + (STAGE == 1 ? 0 : 8);
             for (int k = 0; k < 8; k++) atomicAdd(&acc[k], (unsigned long long)S.ph[k]);
         }
@@ -264,8 +264,10 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const AT *As, do
     }
 
     if constexpr (STAGE == 1) {
-        const double xi = wave_sum((act && S.idx == iso_atom) ? S.x : 0.0);
-        const double xd = wave_sum((act && S.idx == dot_atom) ? S.x : 0.0);
+        // (the coefficient of the slot that holds the atom, if any: a ballot and a broadcast instead of a wavefront sum)
+        const unsigned long long mi = ballot64(act && S.idx == iso_atom), md = ballot64(act && S.idx == dot_atom);
+        const double xi = mi ? bcast(S.x, __builtin_ctzll(mi)) : 0.0;
+        const double xd = md ? bcast(S.x, __builtin_ctzll(md)) : 0.0;
         if (lane == 0) { a.xiso[(size_t)vox * 2] = xi; a.xiso[(size_t)vox * 2 + 1] = xd; }
     } else if constexpr (kLasso) {
         if (lane < 4) wmask[lane] = 0ull;

@@ -386,6 +386,10 @@ struct NNSolver {
                                                  unsigned fl, unsigned long long seed, double *rs, int lane,
                                                  const double *__restrict__ G, int ldG, const SeedScreen &scr)
     {
+#ifdef AMX_PHASES
+        for (int k = 0; k < 8; k++) ph[k] = 0;
+        pht = (long long)__builtin_readcyclecounter();
+#endif
         // decode: slot s = byte s
         const int my = (int)((seed >> (8 * (lane & 7))) & 0xffull);
         const unsigned long long present = ballot64(lane < MAXP && lane < 8 && my < 0xf0);
@@ -408,8 +412,20 @@ struct NNSolver {
 #pragma unroll
         for (int rr = 0; rr < NR; rr++) r[rr] = yr[rr];
         bool ok = true;
+        AMX_PH(0);
         if (np > 0) {
-            // raw columns (row space) and the Gram block (lane = row of the triangle), factored in place
+            // the Gram block first (lane = row of the triangle): ALL its loads are in flight at once, and behind them the column
+            // fetch and the first set of dot products (a loop that loaded and stored entry by entry waited np round trips)
+            double gk[MAXP];
+#pragma unroll
+            for (int k = 0; k < MAXP; k++) {
+                gk[k] = 0.0;
+                if (k < np) {
+                    const int tk = bcast_i(idx, k);
+                    if (lane >= k && lane < np) gk[k] = G[(size_t)idx * ldG + tk];
+                }
+            }
+            // raw columns (row space)
 #pragma unroll
             for (int m = 0; m < MAXP; m++) {
                 if (m < np) {
@@ -422,10 +438,12 @@ struct NNSolver {
                 }
             }
             const int li = (lane < MAXP ? lane : MAXP) * LDR;
-            for (int k = 0; k < np; k++) {
-                const int tk = bcast_i(idx, k);
-                if (lane >= k && lane < np) Rl[li + k] = G[(size_t)idx * ldG + tk];
+            const double c0 = slot_dots(yr, lane);                        // A_P'y (independent of the factor)
+#pragma unroll
+            for (int k = 0; k < MAXP; k++) {
+                if (k < np && lane >= k && lane < np) Rl[li + k] = gk[k];
             }
+            AMX_PH(1);
             for (int k = 0; k < np; k++) {
                 double t = Rl[li + k];
                 const double hkk = bcast(t, k);
@@ -436,8 +454,9 @@ struct NNSolver {
                 if (lane >= k && lane < np) Rl[li + k] = t * iv;
                 if (lane == k) rinv = iv;
             }
+            AMX_PH(2);
             if (ok) {
-                x = chol_solve(slot_dots(yr, lane), lane);
+                x = chol_solve(c0, lane);
 #pragma unroll
                 for (int m = 0; m < MAXP; m++) {
                     if (m < np) {
@@ -446,6 +465,7 @@ struct NNSolver {
                         for (int rr = 0; rr < NR; rr++) r[rr] -= Q[m][rr] * xs;
                     }
                 }
+                AMX_PH(3);
                 // refinement on the true residual: g = A_P' r -> 0
                 double gprev = __builtin_huge_val();
                 for (int it = 0; it < 5; it++) {
@@ -467,6 +487,7 @@ struct NNSolver {
                     if (it == 4) { ok = false; seed_why = 3; }
                 }
                 if (ok && ballot64(lane < np && !(x > 0.0)) != 0ull) { ok = false; seed_why = 4; }
+                AMX_PH(4);
             }
         }
         if (ok) {
@@ -482,6 +503,7 @@ struct NNSolver {
             for (int rr = 0; rr < NR; rr++) { nrm[0] += r[rr] * r[rr]; nrm[1] += yr[rr] * yr[rr]; }
             wave_sum4(nrm, lane);
             const bool zero_res = np > 0 && nrm[0] <= 1e-28 * nrm[1];
+            AMX_PH(5);
             if (zero_res) {
                 n_exact++;
             } else if (scr.Sf == nullptr) {
@@ -527,28 +549,44 @@ struct NNSolver {
                     }
                 }
                 const float margin = direct ? __builtin_huge_valf() : (float)(1.0625 * scr.kappa * sqrt(rho2));
+                AMX_PH(6);
                 bool viol = false;
+                // the atoms inside the margin, four exact dot products per batched reduction
+                unsigned long long todo[NQ];
 #pragma unroll
-                for (int q = 0; q < NQ; q++) {
-                    unsigned long long todo = ballot64((((fl & ~pm) >> q) & 1u) && !(ut[q] < -margin));
-                    while (todo != 0ull) {
-                        const int t = kWave * q + __builtin_ctzll(todo);
-                        todo &= todo - 1ull;
-                        double p = 0.0;
+                for (int q = 0; q < NQ; q++) todo[q] = ballot64((((fl & ~pm) >> q) & 1u) && !(ut[q] < -margin));
+                for (int guard = 0; guard < kWave * NQ; guard++) {
+                    int t4[4] = {-1, -1, -1, -1};
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+#pragma unroll
+                        for (int q = 0; q < NQ; q++) {
+                            if (t4[u] < 0 && todo[q] != 0ull) { t4[u] = kWave * q + __builtin_ctzll(todo[q]); todo[q] &= todo[q] - 1ull; }
+                        }
+                    }
+                    if (t4[0] < 0) break;
+                    double p[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        p[u] = 0.0;
+                        const int t = t4[u] < 0 ? t4[0] : t4[u];
 #pragma unroll
                         for (int rr = 0; rr < NR; rr++) {
                             const int i = lane + kWave * rr;
-                            if (i < nS && rowok[rr]) p += (double)As[i * ldA + t] * r[rr];
+                            if (i < nS && rowok[rr]) p[u] += (double)As[i * ldA + t] * r[rr];
                         }
-                        p = wave_sum(p);
-                        viol = viol || (p > 0.0);
-#ifdef AMX_STATS
-                        if (scr.count && lane == 0) atomicAdd(scr.count, 1);
-#endif
                     }
+                    if (t4[1] >= 0) wave_sum4(p, lane);
+                    else { p[0] = bcast(wave_sum(p[0]), 0); p[1] = 0.0; p[2] = 0.0; p[3] = 0.0; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) viol = viol || (t4[u] >= 0 && p[u] > 0.0);
+#ifdef AMX_STATS
+                    if (scr.count && lane == 0) atomicAdd(scr.count, (t4[0] >= 0) + (t4[1] >= 0) + (t4[2] >= 0) + (t4[3] >= 0));
+#endif
                 }
                 n_exact++;
                 ok = !viol;
+                AMX_PH(7);
             }
             if (!ok) seed_why = 5;
         }
@@ -615,7 +653,7 @@ struct NNSolver {
             if (seeded == 1) return kSolved;
         }
 #ifdef AMX_PHASES
-        for (int k = 0; k < 8; k++) ph[k] = 0;
+        if (seeded != 1) { for (int k = 0; k < 8; k++) ph[k] = 0; }
         pht = (long long)__builtin_readcyclecounter();
 #endif
 #ifndef AMX_GRAM_COLS
