@@ -19,7 +19,7 @@ struct Chunk { int dir, start, count, pad; };
 constexpr int kSeedKD = 12;      // compressed dimensions of the support-seed problem (amx_seed.hpp)
 constexpr int kScreenLd = 192;   // atoms per row of the float32 screening table [KD][kScreenLd]
 
-enum StatusSlot { ST_ERRVOX = 0, ST_II1 = 1, ST_II2 = 2, ST_OVERFLOW = 3, ST_ITCAP = 4, ST_RERUN = 5, ST_GUARD = 6, ST_GUARDVOX = 7, ST_EXACT = 8, ST_GRAM = 11, ST_ITERS = 14, ST_SEED = 17, ST_WORDS = 48 };
+enum StatusSlot { ST_ERRVOX = 0, ST_II1 = 1, ST_II2 = 2, ST_OVERFLOW = 3, ST_ITCAP = 4, ST_RERUN = 5, ST_GUARD = 6, ST_GUARDVOX = 7, ST_EXACT = 8, ST_GRAM = 11, ST_ITERS = 14, ST_SEED = 17, ST_WORDS = 60 };
 
 // ------------------------------------------------------------------ shared pieces
 struct FitCommon {
@@ -120,6 +120,9 @@ struct NoddiArgs {
     int ldG;
     const unsigned long long *seeds;   // support seeds of the NNLS stage being run, bucket order (amx_seed.hpp), or null
     const unsigned long long *seeds2;  // passive-set seeds of the LASSO stage [n_vox][4], bucket order, or null
+    const unsigned char *done;         // NNLS stages: [n_vox] bucket order, 1 = settled by k_nnls_gcert (skipped here), or null
+    const int *rlist, *rcount;         // NNLS stages after k_nnls_gcert: the chunk list is the second plan's, chunk c works on the
+                                       // rcount[c] bucket positions rlist[chunk start ...] (the voxels the Gram certificate left over)
     // dual-value screening of certify_seed (NNLS stages): float32 S [ndirs][12][192], kappa [ndirs], y~ [n_vox][12] (bucket
     // order), fp64 S [ndirs][n_atoms][12]; all null: exact sweep
     const float *scr_S; const double *scr_kappa, *scr_ytil, *scr_Sg;
@@ -641,6 +644,7 @@ __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
         if (cid < 0) return;
         const Chunk ck = a.c.chunks[cid];
         unsigned *ticket = reinterpret_cast<unsigned *>(wm_all + nw_ * 4);     // the 16 spare bytes of fit_lds_bytes
+        if ((STAGE == 1 || STAGE == 3) && a.rlist != nullptr && a.rcount[cid] == 0) return;      // nothing left over in this chunk
         if (threadIdx.x == 0) *ticket = (unsigned)nw_;
         stage_noddi_tile<AT>(As, tiles + (size_t)ck.dir * a.c.tile_stride, words, words_pad - words);
         // NNLS stages with seeds: the float32 compressed dictionary of the orientation for the dual-value screening
@@ -663,8 +667,16 @@ __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
 #else
         // voxels differ 2-3x in solver iterations: the wavefronts draw the next voxel of the chunk from an LDS ticket
         // (next_ticket keeps the control flow wave-uniform: every lane takes part in the atomic)
-        for (int k = wave; k < ck.count; k = next_ticket(ticket, lane)) {
-            noddi_voxel<STAGE, NR, NQ, MAXP, AT>(a, As, rs, rl, wmask, a.c.perm[ck.start + k], ck.dir, lane, ck.start + k, Sf);
+        if ((STAGE == 1 || STAGE == 3) && a.rlist != nullptr) {
+            const int cnt = a.rcount[cid];
+            for (int k = wave; k < cnt; k = next_ticket(ticket, lane)) {
+                const int pos = a.rlist[ck.start + k];
+                noddi_voxel<STAGE, NR, NQ, MAXP, AT>(a, As, rs, rl, wmask, a.c.perm[pos], ck.dir, lane, pos, Sf);
+            }
+        } else {
+            for (int k = wave; k < ck.count; k = next_ticket(ticket, lane)) {
+                noddi_voxel<STAGE, NR, NQ, MAXP, AT>(a, As, rs, rl, wmask, a.c.perm[ck.start + k], ck.dir, lane, ck.start + k, Sf);
+            }
         }
 #endif
     } else {

@@ -60,13 +60,15 @@ __global__ __launch_bounds__(1024) void k_dir_to_lut(const double *__restrict__ 
 }
 
 // single block: dir_start = exclusive scan(counts); ceil(count / ch) equal chunks of <= ch voxels per orientation
-// (ch2 > 0: a second list of larger chunks for the seed solver, count at n_chunks[1])
+// (ch2 > 0, a multiple of 64: a second list of chunks of exactly ch2 voxels (the last one of an orientation shorter) for the
+//  lane-per-voxel kernels, count at n_chunks[1]; Chunk::pad = index of the chunk's first 64-voxel block in the block-wise
+//  tables of amx_seed.hpp (blocks never straddle orientations), total number of blocks at n_chunks[2])
 __global__ void k_plan(const int *__restrict__ counts, int ndirs, int ch, int *__restrict__ dir_start,
                        int *__restrict__ cursor, Chunk *__restrict__ chunks, int *__restrict__ n_chunks,
                        int ch2 = 0, Chunk *__restrict__ chunks2 = nullptr)
 {
-    __shared__ int s_off, s_chk, s_chk2;
-    if (threadIdx.x == 0) { s_off = 0; s_chk = 0; s_chk2 = 0; }
+    __shared__ int s_off, s_chk, s_chk2, s_blk;
+    if (threadIdx.x == 0) { s_off = 0; s_chk = 0; s_chk2 = 0; s_blk = 0; }
     __syncthreads();
     // ndirs is small (500..32761): a serial scan by one thread per 1024-wide tile is enough
     for (int base = 0; base < ndirs; base += blockDim.x) {
@@ -75,19 +77,21 @@ __global__ void k_plan(const int *__restrict__ counts, int ndirs, int ch, int *_
         const int nc = (c + ch - 1) / ch;
         const int nc2 = ch2 > 0 ? (c + ch2 - 1) / ch2 : 0;
         // block-wide exclusive scans through shared memory (Hillis-Steele on 3 values)
-        __shared__ int sa[1024], sb[1024], sc2[1024];
-        sa[threadIdx.x] = c; sb[threadIdx.x] = nc; sc2[threadIdx.x] = nc2;
+        const int nblk = ch2 > 0 ? (c + 63) / 64 : 0;
+        __shared__ int sa[1024], sb[1024], sc2[1024], sd[1024];
+        sa[threadIdx.x] = c; sb[threadIdx.x] = nc; sc2[threadIdx.x] = nc2; sd[threadIdx.x] = nblk;
         __syncthreads();
         for (int off = 1; off < (int)blockDim.x; off <<= 1) {
-            int ta = 0, tb = 0, tc = 0;
-            if ((int)threadIdx.x >= off) { ta = sa[threadIdx.x - off]; tb = sb[threadIdx.x - off]; tc = sc2[threadIdx.x - off]; }
+            int ta = 0, tb = 0, tc = 0, td = 0;
+            if ((int)threadIdx.x >= off) { ta = sa[threadIdx.x - off]; tb = sb[threadIdx.x - off]; tc = sc2[threadIdx.x - off]; td = sd[threadIdx.x - off]; }
             __syncthreads();
-            sa[threadIdx.x] += ta; sb[threadIdx.x] += tb; sc2[threadIdx.x] += tc;
+            sa[threadIdx.x] += ta; sb[threadIdx.x] += tb; sc2[threadIdx.x] += tc; sd[threadIdx.x] += td;
             __syncthreads();
         }
         const int start = s_off + sa[threadIdx.x] - c;
         const int cstart = s_chk + sb[threadIdx.x] - nc;
         const int cstart2 = s_chk2 + sc2[threadIdx.x] - nc2;
+        const int bstart = s_blk + sd[threadIdx.x] - nblk;
         if (dsel < ndirs) {
             dir_start[dsel] = start;
             cursor[dsel] = 0;
@@ -100,19 +104,18 @@ __global__ void k_plan(const int *__restrict__ counts, int ndirs, int ch, int *_
                 ck.count = base + (k < rem ? 1 : 0); ck.pad = 0;
                 chunks[cstart + k] = ck;
             }
-            const int base2 = nc2 ? c / nc2 : 0, rem2 = nc2 ? c - base2 * nc2 : 0;
             for (int k = 0; k < nc2; k++) {
                 Chunk ck;
-                ck.dir = dsel; ck.start = start + k * base2 + (k < rem2 ? k : rem2);
-                ck.count = base2 + (k < rem2 ? 1 : 0); ck.pad = 0;
+                ck.dir = dsel; ck.start = start + k * ch2;
+                ck.count = (c - k * ch2 < ch2) ? c - k * ch2 : ch2; ck.pad = bstart + k * (ch2 / 64);
                 chunks2[cstart2 + k] = ck;
             }
         }
         __syncthreads();
-        if (threadIdx.x == blockDim.x - 1) { s_off += sa[threadIdx.x]; s_chk += sb[threadIdx.x]; s_chk2 += sc2[threadIdx.x]; }
+        if (threadIdx.x == blockDim.x - 1) { s_off += sa[threadIdx.x]; s_chk += sb[threadIdx.x]; s_chk2 += sc2[threadIdx.x]; s_blk += sd[threadIdx.x]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { dir_start[ndirs] = s_off; n_chunks[0] = s_chk; if (ch2 > 0) n_chunks[1] = s_chk2; }
+    if (threadIdx.x == 0) { dir_start[ndirs] = s_off; n_chunks[0] = s_chk; if (ch2 > 0) { n_chunks[1] = s_chk2; n_chunks[2] = s_blk; } }
 }
 
 // scatter of the voxel ids into their orientation's range.  With LDS: the block reserves, per orientation, one range

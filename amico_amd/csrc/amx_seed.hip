@@ -15,11 +15,12 @@ int amx_build_basis(amx_ctx *ctx, amx_lut *lut)
     HIPCHK(ctx, hipMalloc((void **)&lut->screen_S, (size_t)lut->ndirs * kSeedKD * kScreenLd * sizeof(float) + 64));
     HIPCHK(ctx, hipMemset(lut->screen_S, 0, (size_t)lut->ndirs * kSeedKD * kScreenLd * sizeof(float)));
     HIPCHK(ctx, hipMalloc((void **)&lut->screen_kappa, (size_t)lut->ndirs * sizeof(double) + 64));
+    HIPCHK(ctx, hipMalloc((void **)&lut->screen_kappa0, (size_t)lut->ndirs * sizeof(double) + 64));
     int rc;
     if ((rc = set_lds(ctx, k_build_basis, lds))) return rc;
     hipLaunchKernelGGL(k_build_basis, dim3(lut->ndirs), dim3(256), lds, nullptr, (const float *)lut->tiles, lut->tile_stride, lut->nS,
                        lut->ldA, lut->n_atoms, (const unsigned char *)nullptr, (const double *)nullptr, lut->basis_U, lut->basis_S, kSeedKD,
-                       lut->screen_S, lut->screen_kappa);
+                       lut->screen_S, lut->screen_kappa, lut->screen_kappa0);
     // the LASSO stage's dictionary: DWI rows, column-normalised wm atoms (models.pyx:917-921), rank 8
     if (lut->gram_dwi) {
         HIPCHK(ctx, hipMalloc((void **)&lut->basis2_U, (size_t)lut->ndirs * lut->nS * kSeed2Ld * sizeof(double) + 64));
@@ -79,6 +80,55 @@ static void fill(SeedArgs &sa, const amx_lut *lut, const NoddiArgs &a, const Pla
 #ifdef AMX_STATS
     sa.stats = a.c.status + ST_SEED + 4;
 #endif
+}
+
+// C = [A | U]'Y of every voxel (k_noddi_gemm): block-wise table in ctx->cgemm
+int amx_launch_noddi_gemm(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, const Plan &pl, hipStream_t s)
+{
+    GemmArgs ga;
+    memset(&ga, 0, sizeof ga);
+    ga.y = a.c.y; ga.perm = pl.perm; ga.schunks = pl.schunks; ga.n_schunks = pl.n_chunks + 1;
+    ga.tiles = (const float *)lut->tiles; ga.tile_stride = lut->tile_stride; ga.ldA = lut->ldA; ga.nS = lut->nS; ga.n_atoms = lut->n_atoms;
+    ga.Ub = lut->basis_U; ga.Cb = (double *)ctx->cgemm.p; ga.ytil = (double *)ctx->ytil.p;
+    const size_t lds = (size_t)9 * 25 * 64 * sizeof(float) + ((size_t)25 * 64 + (size_t)4 * 16 * 101) * sizeof(double);
+    int rc;
+    if ((rc = set_lds(ctx, k_noddi_gemm, lds))) return rc;
+    hipLaunchKernelGGL(k_noddi_gemm, dim3(((pl.max_schunks + 7) / 8) * 8), dim3(256), lds, s, ga);
+    AMX_TRACE(ctx, s, "A'y of every voxel on the matrix cores");
+    HIPCHK(ctx, hipGetLastError());
+    return AMX_OK;
+}
+
+// Gram-space certificates of the NNLS seeds, one voxel per lane (k_nnls_gcert): done[pos] = 1 for the voxels it settles
+int amx_launch_noddi_gcert(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, const Plan &pl, hipStream_t s, int stage)
+{
+    GcertArgs g;
+    memset(&g, 0, sizeof g);
+    g.perm = pl.perm; g.schunks = pl.schunks; g.n_schunks = pl.n_chunks + 1;
+    g.seeds = (const unsigned long long *)ctx->seeds.p; g.Cb = (const double *)ctx->cgemm.p;
+    g.gram = lut->gram; g.ldG = lut->ldG; g.n_atoms = lut->n_atoms; g.n_wm = lut->n_wm; g.nS = lut->nS;
+    g.iso_atom = lut->n_atoms - 1; g.dot_atom = lut->is_exvivo ? lut->n_atoms - 2 : -1; g.n_maps = a.n_maps;
+    g.Sb = lut->basis_S; g.kappa0 = lut->screen_kappa0; g.supp = a.supp; g.icvf = lut->icvf; g.kappa = lut->kappa;
+    g.done = (unsigned char *)ctx->done.p; g.rlist = (int *)ctx->rlist.p; g.rcount = (int *)ctx->rlist.p + pl.n;
+    HIPCHK(ctx, hipMemsetAsync(g.rcount, 0, (size_t)pl.max_schunks * sizeof(int), s));
+    g.xiso = a.xiso; g.est = a.est; g.rmse = a.rmse; g.nrmse = a.nrmse; g.mod = a.mod;
+    if (a.c.xdbg) g.xdbg = a.c.xdbg;
+#ifdef AMX_STATS
+    g.stats = a.c.status + ST_SEED + 24 + (stage == 1 ? 0 : 6);
+#endif
+    const size_t lds = ((size_t)lut->n_atoms * kSeedLd + 2 + (stage == 1 ? (size_t)10 * (kSeedKD / 4) * 64 : 0) + (size_t)4 * 64 * 16) * sizeof(double);
+    const dim3 grid(((pl.max_schunks + 7) / 8) * 8);
+    int rc;
+    if (stage == 1) {
+        if ((rc = set_lds(ctx, k_nnls_gcert<1>, lds))) return rc;
+        hipLaunchKernelGGL(k_nnls_gcert<1>, grid, dim3(256), lds, s, g);
+    } else {
+        if ((rc = set_lds(ctx, k_nnls_gcert<3>, lds))) return rc;
+        hipLaunchKernelGGL(k_nnls_gcert<3>, grid, dim3(256), lds, s, g);
+    }
+    AMX_TRACE(ctx, s, "Gram-space certificates");
+    HIPCHK(ctx, hipGetLastError());
+    return AMX_OK;
 }
 
 int amx_launch_noddi_project(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, const Plan &pl, hipStream_t s)

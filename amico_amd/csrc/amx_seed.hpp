@@ -34,7 +34,8 @@ constexpr unsigned long long kNoSeed = kSeedNone;
 __global__ void __launch_bounds__(256) k_build_basis(const float *__restrict__ tiles, int tile_stride, int nS, int ldA, int n_cols,
                                                      const unsigned char *__restrict__ rowsel, const double *__restrict__ colscale,
                                                      double *__restrict__ Ub, double *__restrict__ Sb, int KD,
-                                                     float *__restrict__ Sf = nullptr, double *__restrict__ kap = nullptr)
+                                                     float *__restrict__ Sf = nullptr, double *__restrict__ kap = nullptr,
+                                                     double *__restrict__ kap0 = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     double *R = reinterpret_cast<double *>(smem_b);            // [nS][ldA] deflated columns
@@ -106,7 +107,7 @@ __global__ void __launch_bounds__(256) k_build_basis(const float *__restrict__ t
         __syncthreads();
         red[tid] = an;
         __syncthreads();
-        if (tid == 0) { double m = 0.0; for (int j = 0; j < n_cols && j < nt; j++) m = red[j] > m ? red[j] : m; kap[blockIdx.x] = emax + 2e-6 * sqrt(m); }
+        if (tid == 0) { double m = 0.0; for (int j = 0; j < n_cols && j < nt; j++) m = red[j] > m ? red[j] : m; kap[blockIdx.x] = emax + 2e-6 * sqrt(m); if (kap0) kap0[blockIdx.x] = emax; }
         __syncthreads();
     }
     double *U = Ub + (size_t)blockIdx.x * nS * KD;
@@ -135,7 +136,7 @@ struct SeedArgs {
     const Chunk *schunks;         // larger chunks of the seed kernel
     const int *n_schunks;
     const double *Ub, *Sb;        // [ndirs][nS][KD], [ndirs][n_atoms][KD]
-    double *ytil;                 // [n_vox][KD], bucket order
+    double *ytil;                 // [n_vox][KD], bucket order (k_noddi_project), or
     unsigned long long *seeds;    // [n_vox], bucket order: up to 8 atom ids, one per byte, 0xff = empty; kNoSeed = none
     const unsigned long long *supp;   // stage 3: [n_vox][4] stage-2 support bit set (voxel order), null for stage 1
     int nS, n_atoms, iso_atom, dot_atom;
@@ -673,6 +674,443 @@ __global__ void __launch_bounds__(256, 2) k_nnls_seed(const SeedArgs a)
         if (STAGE == 1) for (int k = 0; k < 6; k++) atomicAdd(&a.stats[8 + k], (int)(ph[k] >> 10));
     }
 #endif
+}
+
+// ================================================================== C = [A | U]' Y on the fp64 matrix cores
+// The one genuinely GEMM-shaped piece of the NODDI fit: c_j = a_j'y for every atom and voxel, plus the 12
+// projections u_d'y and ||y||^2 -- everything the Gram-space certificates of the NNLS stages (k_nnls_gcert) and the seed
+// solvers need from the signal, so that neither has to touch y (792 bytes per voxel) again.  v_mfma_f64_16x16x4_f64; one
+// workgroup per chunk of the second plan (one orientation), a wavefront takes 16 voxels at a time:
+//   * A' operand: the orientation's dictionary once per workgroup in LDS in operand order, float32 for the atom tiles (the
+//     dictionary IS float32: exact), fp64 for the last tile (iso atom + the basis U);
+//   * B operand: the 16 signal rows land in LDS by one fully coalesced 16-byte-per-lane load per voxel (792 contiguous
+//     bytes), every lane then keeps its 25 operand values in registers for all 10 atom tiles;
+//   * output in blocks of 64 voxels, atom-major: Cb[block][160][64] -- a D tile stores four 128-byte row pieces.
+// Rows 146 .. 157 of a block hold the projections y~ = U'y, row 158 holds ||y||^2, whatever the number of atoms.
+constexpr int kGemmRows = 160, kGemmU = 146, kGemmYY = 158;     // rows: atoms (n_atoms <= 146) | y~ at 146 .. 157 | ||y||^2 at 158
+struct GemmArgs {
+    const double *y;              // [n_vox][nS]
+    const int *perm;
+    const Chunk *schunks;         // pad = first block of the chunk
+    const int *n_schunks;
+    const float *tiles;           // [ndirs][nS][ldA]
+    int tile_stride, ldA, nS, n_atoms;
+    const double *Ub;             // [ndirs][nS][12]
+    double *Cb;                   // [n_blocks][160][64]
+    double *ytil;                 // [n][12] bucket order (copy of rows n_atoms .. n_atoms + 11), or null
+};
+
+__global__ void __launch_bounds__(256) k_noddi_gemm(const GemmArgs a)
+{
+    constexpr int MT = 10, KS = 25, YLD = 101;     // nS <= 100
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
+    float *A32 = reinterpret_cast<float *>(smem_g);                       // [9][KS][64]
+    double *A64 = reinterpret_cast<double *>(A32 + (MT - 1) * KS * 64);   // [KS][64]: atoms 144 .. 159
+    double *Yt = A64 + KS * 64 + (threadIdx.x >> 6) * (16 * YLD);         // per wavefront [16][YLD]
+    const int cid = xcd_chunk((int)blockIdx.x, *a.n_schunks);
+    if (cid < 0) return;
+    const Chunk ck = a.schunks[cid];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
+    const int q = lane >> 4, c16 = lane & 15;
+    const int nS = a.nS, n_atoms = a.n_atoms, ldA = a.ldA;
+    const float *tile = a.tiles + (size_t)ck.dir * a.tile_stride;
+    const double *U = a.Ub + (size_t)ck.dir * nS * kSeedKD;
+    for (int e = threadIdx.x; e < (MT - 1) * KS * 64; e += blockDim.x) {
+        const int l = e & 63, ks = (e >> 6) % KS, mt = (e >> 6) / KS;
+        const int atom = 16 * mt + (l & 15), row = 4 * ks + (l >> 4);
+        A32[e] = (row < nS && atom < n_atoms) ? tile[row * ldA + atom] : 0.0f;
+    }
+    for (int e = threadIdx.x; e < KS * 64; e += blockDim.x) {
+        const int l = e & 63, ks = e >> 6;
+        const int atom = 16 * (MT - 1) + (l & 15), row = 4 * ks + (l >> 4);
+        double v = 0.0;
+        if (row < nS) {
+            if (atom < n_atoms) v = (double)tile[row * ldA + atom];
+            else if (atom >= kGemmU && atom < kGemmU + kSeedKD) v = U[row * kSeedKD + (atom - kGemmU)];
+        }
+        A64[e] = v;
+    }
+    __syncthreads();
+    const int n_groups = (ck.count + 15) >> 4;
+    // the 16 signal rows of a group: one coalesced load per voxel (lane l takes bytes 16 l .. 16 l + 15 of the row); the loads
+    // of group g + nw are issued before the products of group g, so they are long done when their turn comes
+    double ya[16], yb[16];
+    auto issue = [&](int g) {
+#pragma unroll
+        for (int v = 0; v < 16; v++) {
+            const int k = 16 * g + v;
+            const int vox = a.perm[ck.start + (k < ck.count ? k : ck.count - 1)];
+            const double *yv = a.y + (size_t)vox * nS;
+            ya[v] = (2 * lane < nS && k < ck.count) ? yv[2 * lane] : 0.0;
+            yb[v] = (2 * lane + 1 < nS && k < ck.count) ? yv[2 * lane + 1] : 0.0;
+        }
+    };
+    if (wave < n_groups) issue(wave);
+    for (int g = wave; g < n_groups; g += nw) {
+        if (2 * lane < YLD - 1) {
+#pragma unroll
+            for (int v = 0; v < 16; v++) { Yt[v * YLD + 2 * lane] = ya[v]; Yt[v * YLD + 2 * lane + 1] = yb[v]; }
+        }
+        double b[KS], yy = 0.0;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) { b[ks] = Yt[c16 * YLD + 4 * ks + q]; yy += b[ks] * b[ks]; }
+        yy = rows_allreduce(yy);
+        if (g + nw < n_groups) issue(g + nw);
+        const int blk = ck.pad + (g >> 2), col = 16 * (g & 3) + c16;
+        double *out = a.Cb + (size_t)blk * kGemmRows * 64 + col;
+        const bool live = 16 * g + c16 < ck.count;
+#pragma unroll 1
+        for (int mt = 0; mt < MT - 1; mt += 3) {
+            // the operands of three atom tiles first (75 LDS reads in flight together), then 75 products back to back: with one
+            // wavefront per SIMD nothing else hides an LDS round trip in front of every matrix instruction
+            float af[3][KS];
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) af[u][ks] = A32[((mt + u) * KS + ks) * 64 + lane];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            seed_v4d acc[3];
+#pragma unroll
+            for (int u = 0; u < 3; u++) acc[u] = (seed_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+#pragma unroll
+                for (int u = 0; u < 3; u++)
+                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)af[u][ks], b[ks], acc[u], 0, 0, 0);
+            }
+            if (live) {
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++) out[(size_t)(16 * (mt + u) + 4 * rr + q) * 64] = acc[u][rr];
+                }
+            }
+        }
+        {
+            seed_v4d acc = (seed_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A64[ks * 64 + lane], b[ks], acc, 0, 0, 0);
+            if (live) {
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) {
+                    const int row = 16 * (MT - 1) + 4 * rr + q;
+                    out[(size_t)row * 64] = (row == kGemmYY) ? yy : acc[rr];
+                    // the projections once more in voxel-major order for the kernels that walk the 256-voxel chunks
+                    if (a.ytil != nullptr && row >= kGemmU && row < kGemmU + kSeedKD) a.ytil[(size_t)(ck.start + 16 * g + c16) * kSeedKD + (row - kGemmU)] = acc[rr];
+                }
+            }
+        }
+    }
+}
+
+// ================================================================== Gram-space certificates of the NNLS seeds, one voxel per lane
+// With c = A'y (k_noddi_gemm) and the orientation's Gram matrix G = A'A the Kuhn-Tucker conditions of a seeded support P
+// need neither the signal nor the dictionary:  x_P = G_PP^-1 c_P (Cholesky in the lane's registers),  dual value of atom t:
+// u_t = c_t - G_tP x_P,  ||r||^2 = ||y||^2 - x_P'c_P.  Normal equations square the condition number, so a lane only
+// certifies what they can certify: the pivot ratio min L_ii / max L_ii (a lower bound of 1 / cond(A_P)) must exceed
+// kGcertPivot{1,3} (tools/lab/gram_certify_lab.py: at 3e-3 x agrees with the QR solution to 2.5e-8 relative at worst, 2e-12
+// in the median, for 94 % of the voxels; at 1e-3: 5.5e-8, 98 %), every coefficient must be positive and every examined dual value below -1e-10
+// (the Gram-form value is exact to ~1e-11).  Which atoms are examined: stage 3 -- all admissible ones (the LASSO support,
+// a handful); stage 1 -- those whose compressed dual value s_t'(y~ - S_P x) is within kappa ||r|| of zero or above, found
+// for the 64 voxels of the wavefront by one fp64 MFMA product (see seed_scan_mfma).  Everything else -- refused seeds,
+// ill-conditioned supports, ambiguous signs, non-finite signals -- is left to the wavefront-per-voxel kernel (k_noddi with
+// the done[] flags: it skips the certified voxels), whose certificate works on the true residual.
+constexpr double kGcertPivot1 = 1e-3, kGcertPivot3 = 3e-3;   // stage 1 only hands x_iso to the LASSO stage; stage 3's x becomes the maps
+struct GcertArgs {
+    const int *perm;
+    const Chunk *schunks;
+    const int *n_schunks;
+    const unsigned long long *seeds;   // [n], bucket order
+    const double *Cb;                  // [n_blocks][160][64]
+    const double *gram;                // [ndirs][n_atoms][ldG]
+    int ldG, n_atoms, n_wm, nS, iso_atom, dot_atom, n_maps;
+    const double *Sb;                  // [ndirs][n_atoms][12]
+    const double *kappa0;              // [ndirs] max ||(I - U U') a_j||
+    const unsigned long long *supp;    // stage 3: [n_vox][4]
+    const float *icvf, *kappa;         // stage 3: maps
+    unsigned char *done;               // [n], bucket order: 1 = certified here
+    int *rlist, *rcount;               // refused voxels: positions, compact from the chunk's own start; count per chunk
+    double *xiso;                      // stage 1 out: [n_vox][2]
+    double *est, *rmse, *nrmse, *mod;  // stage 3 out
+    double *xdbg;                      // AMX_F_DEBUG_X: [n_vox][3][n_atoms]
+    int *stats;
+};
+
+template <int STAGE>
+__global__ void __launch_bounds__(256, 2) k_nnls_gcert(const GcertArgs a)
+{
+    constexpr int KD = kSeedKD, KS = KD / 4, MT = 10, MS = 8, LD = kSeedLd, RBW = 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_c[];
+    double *Sl = reinterpret_cast<double *>(smem_c);             // [n_atoms][LD]
+    const int n_atoms = a.n_atoms;
+    double *Aop = Sl + (size_t)n_atoms * LD + 2;                  // stage 1: [MT][KS][64]
+    double *Rb = Aop + (STAGE == 1 ? MT * KS * 64 : 0) + (threadIdx.x >> 6) * (64 * RBW);   // per wavefront [64][16]: r~ | margin | masks
+    const int cid = xcd_chunk((int)blockIdx.x, *a.n_schunks);
+    if (cid < 0) return;
+    const Chunk ck = a.schunks[cid];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
+    const int q = lane >> 4, c16 = lane & 15;
+    const double *__restrict__ Sg = a.Sb + (size_t)ck.dir * n_atoms * KD;
+    const double *__restrict__ Gd = a.gram + (size_t)ck.dir * n_atoms * a.ldG;
+    for (int e = threadIdx.x; e < n_atoms * KD; e += blockDim.x) { const int j = e / KD, d = e - j * KD; Sl[j * LD + d] = Sg[e]; }
+    if (STAGE == 1) {
+        for (int e = threadIdx.x; e < MT * KS * 64; e += blockDim.x) {
+            const int l = e & 63, ks = (e >> 6) % KS, mt = (e >> 6) / KS;
+            const int atom = 16 * mt + (l & 15), d = 4 * ks + (l >> 4);
+            Aop[e] = (atom < n_atoms) ? Sg[(size_t)atom * KD + d] : 0.0;
+        }
+    }
+    __syncthreads();
+    const double kap = a.kappa0[ck.dir];
+    const int n_blocks = (ck.count + 63) >> 6;
+    for (int bl = wave; bl < n_blocks; bl += nw) {
+        const int k = 64 * bl + lane;
+        const bool valid = k < ck.count;
+        const int pos = ck.start + (valid ? k : ck.count - 1);
+        const double *Crow = a.Cb + (size_t)(ck.pad + bl) * kGemmRows * 64 + lane;
+        const unsigned long long seed = a.seeds[pos];
+        const int vox = a.perm[pos];
+        SeedLane<MS> V;
+        V.clear();
+        bool okv = valid && seed != kNoSeed;
+        // ---- decode (bytes from the low end; >= 0xf0: empty)
+        {
+            int n0 = 0; bool tail = false;
+#pragma unroll
+            for (int s = 0; s < MS; s++) {
+                const int b = (int)((seed >> (8 * s)) & 0xffull);
+                const bool on = b < 0xf0;
+                if (on && tail) okv = false;                      // not a prefix
+                if (!on) tail = true;
+                if (on && b >= n_atoms) okv = false;
+                V.idx[s] = (on && b < n_atoms) ? b : 0;
+                n0 += on ? 1 : 0;
+            }
+            V.np = okv ? n0 : 0;
+        }
+        unsigned long long cand[3] = {~0ull, ~0ull, ~0ull};          // admissible atoms outside the seed
+        if (STAGE == 3) {
+#pragma unroll
+            for (int w3 = 0; w3 < 3; w3++) cand[w3] = a.supp[(size_t)vox * 4 + w3];
+            cand[a.iso_atom >> 6] |= 1ull << (a.iso_atom & 63);
+            if (a.dot_atom >= 0) cand[a.dot_atom >> 6] |= 1ull << (a.dot_atom & 63);
+        } else {
+#pragma unroll
+            for (int w3 = 0; w3 < 3; w3++) {
+                const int cnt = n_atoms - 64 * w3;
+                cand[w3] = cnt >= 64 ? ~0ull : (cnt > 0 ? ((1ull << cnt) - 1ull) : 0ull);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < MS; s++) {
+            if (s < V.np) {
+                const int t = V.idx[s];
+                unsigned long long wsel = 0ull;
+#pragma unroll
+                for (int w3 = 0; w3 < 3; w3++) wsel = ((t >> 6) == w3) ? cand[w3] : wsel;
+                if (!((wsel >> (t & 63)) & 1ull)) okv = false;      // seeded atom not admissible (or twice in the seed)
+#pragma unroll
+                for (int w3 = 0; w3 < 3; w3++) cand[w3] = ((t >> 6) == w3) ? (cand[w3] & ~(1ull << (t & 63))) : cand[w3];
+            }
+        }
+        if (!okv) V.np = 0;
+        // ---- Gram block, c_P, ||y||^2
+#pragma unroll
+        for (int s = 0; s < MS; s++) {
+#pragma unroll
+            for (int t = 0; t <= s; t++) V.T[stri<MS>(s, t)] = (s < V.np) ? Gd[(size_t)V.idx[s] * a.ldG + V.idx[t]] : 0.0;
+            V.c[s] = (s < V.np) ? Crow[(size_t)V.idx[s] * 64] : 0.0;
+        }
+        const double yy = Crow[(size_t)kGemmYY * 64];
+        double pmax = 0.0, pmin = __builtin_huge_val();
+        bool piv = V.factor();
+#pragma unroll
+        for (int s = 0; s < MS; s++) {
+            const double di = V.T[stri<MS>(s, s)];
+            if (s < V.np) { pmax = di > pmax ? di : pmax; pmin = di < pmin ? di : pmin; }
+        }
+        if (V.np > 0 && !(pmin > (STAGE == 1 ? kGcertPivot1 : kGcertPivot3) * pmax)) piv = false;
+        double z[MS];
+        V.solve(z);
+        bool feas = true;
+        double rho2 = yy;
+#pragma unroll
+        for (int s = 0; s < MS; s++) { V.x[s] = z[s]; if (s < V.np && !(z[s] > 0.0)) feas = false; rho2 -= z[s] * V.c[s]; }
+        rho2 = rho2 > 0.0 ? rho2 : 0.0;
+        bool good = okv && piv && feas && (yy <= 1.79769313486231570e308);
+        // ---- which atoms need their exact dual value
+        unsigned long long ex[3] = {cand[0], cand[1], cand[2]};
+        if (STAGE == 1) {
+            double rt[KD];
+#pragma unroll
+            for (int d = 0; d < KD; d++) rt[d] = Crow[(size_t)(kGemmU + d) * 64];
+#pragma unroll
+            for (int s = 0; s < MS; s++) {
+                const double *col = Sl + V.idx[s] * LD;
+#pragma unroll
+                for (int d = 0; d < KD; d++) rt[d] -= V.x[s] * col[d];
+            }
+            // publish: r~ [12] | margin | candidate mask (3 words)
+#pragma unroll
+            for (int d = 0; d < KD; d++) Rb[lane * RBW + d] = good ? rt[d] : 0.0;
+            Rb[lane * RBW + 12] = good ? -1.0625 * kap * sqrt(rho2) - 1e-12 : __builtin_huge_val();      // flag when dual > this
+            unsigned long long *Mb = reinterpret_cast<unsigned long long *>(Rb + lane * RBW + 13);
+#pragma unroll
+            for (int w3 = 0; w3 < 3; w3++) Mb[w3] = good ? cand[w3] : 0ull;
+            double b[4][KS], thr[4];
+            unsigned cq[4][6];
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) {
+                const int src = 16 * nt + c16;
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) b[nt][ks] = Rb[src * RBW + 4 * ks + q];
+                thr[nt] = Rb[src * RBW + 12];
+                const unsigned long long *Ms = reinterpret_cast<const unsigned long long *>(Rb + src * RBW + 13);
+#pragma unroll
+                for (int w3 = 0; w3 < 3; w3++) { const unsigned long long m = Ms[w3] >> q; cq[nt][2 * w3] = (unsigned)m; cq[nt][2 * w3 + 1] = (unsigned)(m >> 32); }
+            }
+            unsigned fq[4][6];
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) {
+#pragma unroll
+                for (int w6 = 0; w6 < 6; w6++) fq[nt][w6] = 0u;
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                double av[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) av[ks] = Aop[(mt * KS + ks) * 64 + lane];
+                seed_v4d acc[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) acc[nt] = (seed_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], b[nt][ks], acc[nt], 0, 0, 0);
+                }
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++) {
+                        const int bit = 16 * mt + 4 * rr;            // position in the row-shifted masks
+                        const bool hit = ((cq[nt][bit >> 5] >> (bit & 31)) & 1u) && (acc[nt][rr] > thr[nt]);
+                        fq[nt][bit >> 5] |= hit ? (1u << (bit & 31)) : 0u;
+                    }
+                }
+            }
+            // the four rows that share a voxel: OR of their flag words (shifted back by the row), owner = row of the voxel
+#pragma unroll
+            for (int w3 = 0; w3 < 3; w3++) {
+                unsigned long long mine = 0ull;
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) {
+                    unsigned long long f = (((unsigned long long)fq[nt][2 * w3 + 1] << 32) | (unsigned long long)fq[nt][2 * w3]) << q;
+                    unsigned lo = (unsigned)f, hi = (unsigned)(f >> 32);
+                    {
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false); lo = s1[0] | s1[1];
+                        const auto s2 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false); lo = s2[0] | s2[1];
+                        const auto s3 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false); hi = s3[0] | s3[1];
+                        const auto s4 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false); hi = s4[0] | s4[1];
+                    }
+                    const unsigned long long m = ((unsigned long long)hi << 32) | (unsigned long long)lo;
+                    mine = (q == nt) ? m : mine;
+                }
+                ex[w3] = mine;
+            }
+        }
+        // ---- exact (Gram-form) dual values of the flagged atoms: u_t = c_t - G_tP x
+        bool viol = false;
+        int n_ex = 0;
+        {
+            unsigned long long rem[3] = {good ? ex[0] : 0ull, good ? ex[1] : 0ull, good ? ex[2] : 0ull};
+            for (int it = 0; it < 192; it++) {
+                int wq = -1;
+#pragma unroll
+                for (int qq = 2; qq >= 0; qq--) wq = (rem[qq] != 0ull) ? qq : wq;
+                if (__ballot(wq >= 0) == 0ull) break;
+                unsigned long long word = 0ull;
+#pragma unroll
+                for (int qq = 0; qq < 3; qq++) word = (wq == qq) ? rem[qq] : word;
+                const int t = (wq >= 0) ? wq * 64 + __builtin_ctzll(word) : 0;
+#pragma unroll
+                for (int qq = 0; qq < 3; qq++) rem[qq] = (wq == qq) ? (rem[qq] & (rem[qq] - 1ull)) : rem[qq];
+                const bool on = wq >= 0 && t < n_atoms;
+                double u = on ? Crow[(size_t)t * 64] : 0.0;
+                const double *gt = Gd + (size_t)t * a.ldG;
+#pragma unroll
+                for (int s = 0; s < MS; s++) { if (s < V.np && on) u -= gt[V.idx[s]] * V.x[s]; }
+                if (on && !(u < -1e-10)) viol = true;                 // positive, or too close to zero for the Gram form to call
+                n_ex += on ? 1 : 0;
+            }
+        }
+        const bool cert = good && !viol;
+        if (valid) a.done[pos] = cert ? 1 : 0;
+        {
+            // the voxels left to the wavefront-per-voxel kernel, compacted per chunk (that kernel then shares out real work only)
+            const unsigned long long rm = __ballot(valid && !cert);
+            if (rm != 0ull) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&a.rcount[cid], __builtin_popcountll(rm));
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(rm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)rm, 0u));
+                if (valid && !cert) a.rlist[ck.start + base + rank] = pos;
+            }
+        }
+#ifdef AMX_STATS
+        if (a.stats) {
+            const int nc = __builtin_popcountll(__ballot(cert)), nv = __builtin_popcountll(__ballot(valid));
+            const int npv = __builtin_popcountll(__ballot(valid && okv && !piv)), nfe = __builtin_popcountll(__ballot(valid && okv && piv && !feas)), nvi = __builtin_popcountll(__ballot(valid && good && viol));
+            if (lane == 0) { atomicAdd(&a.stats[0], nv); atomicAdd(&a.stats[1], nc); atomicAdd(&a.stats[2], npv); atomicAdd(&a.stats[3], nfe); atomicAdd(&a.stats[4], nvi); }
+            int ne = n_ex;
+            for (int o = 32; o > 0; o >>= 1) ne += __shfl_xor(ne, o);
+            if (lane == 0) atomicAdd(&a.stats[5], ne);
+        }
+#endif
+        if (cert) {
+            double xi = 0.0, xd = 0.0;
+#pragma unroll
+            for (int s = 0; s < MS; s++) { if (s < V.np && V.idx[s] == a.iso_atom) xi = V.x[s]; if (s < V.np && V.idx[s] == a.dot_atom) xd = V.x[s]; }
+            if (STAGE == 1) {
+                a.xiso[(size_t)vox * 2] = xi; a.xiso[(size_t)vox * 2 + 1] = xd;
+            } else {
+                // models.pyx:945-967
+                double sum_atoms = 1e-16;
+#pragma unroll
+                for (int s = 0; s < MS; s++) sum_atoms += (s < V.np) ? V.x[s] : 0.0;
+                double sum_wm = 0.0;
+#pragma unroll
+                for (int s = 0; s < MS; s++) sum_wm += (s < V.np && V.idx[s] < a.n_wm) ? V.x[s] / sum_atoms : 0.0;
+                sum_wm += 1e-16;
+                double f1 = 0.0, f2 = 0.0, k1 = 0.0;
+#pragma unroll
+                for (int s = 0; s < MS; s++) {
+                    if (s < V.np && V.idx[s] < a.n_wm) {
+                        const float ic = a.icvf[V.idx[s]];
+                        const double t = V.x[s] / sum_atoms / sum_wm;
+                        f1 += (double)ic * t;
+                        f2 += (double)((float)(1.0 - (double)ic)) * t;
+                        k1 += (double)a.kappa[V.idx[s]] * t;
+                    }
+                }
+                const double ndi = f1 / (f1 + f2 + 1e-16);
+                const double odi = odi_from_kappa(k1);
+                const double fwf = xi / sum_atoms;
+                double *e = a.est + (size_t)vox * a.n_maps;
+                e[0] = ndi; e[1] = odi; e[2] = fwf;
+                if (a.dot_atom >= 0) e[3] = xd / sum_atoms;
+                if (a.rmse) a.rmse[vox] = sqrt(rho2 / (double)a.nS);
+                if (a.nrmse) a.nrmse[vox] = (yy > 1e-16) ? sqrt(rho2 / yy) : 0.0;
+                if (a.mod) { const double tf = 1.0 - fwf; a.mod[(size_t)vox * 2] = ndi * tf; a.mod[(size_t)vox * 2 + 1] = odi * tf; }
+            }
+            if (a.xdbg) {
+                double *dst = a.xdbg + ((size_t)vox * 3 + (STAGE == 1 ? 0 : 2)) * n_atoms;
+                for (int j = 0; j < n_atoms; j++) dst[j] = 0.0;
+#pragma unroll
+                for (int s = 0; s < MS; s++) if (s < V.np) dst[V.idx[s]] = V.x[s];
+            }
+        }
+    }
 }
 
 // ================================================================== LASSO stage (models.pyx:914-926): seeds in Woodbury form
