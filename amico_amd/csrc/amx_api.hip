@@ -35,6 +35,7 @@ int make_plan(amx_ctx *ctx, int64_t n, int ndirs, Plan &pl, bool seeds = false)
         if ((rc = ensure(ctx, ctx->ytil, (size_t)n * amx::kSeedKD * sizeof(double)))) return rc;
         if ((rc = ensure(ctx, ctx->seeds, (size_t)n * sizeof(unsigned long long)))) return rc;
         if ((rc = ensure(ctx, ctx->cgemm, ((size_t)n / 64 + ndirs + 1) * 160 * 64 * sizeof(double)))) return rc;
+        if ((rc = ensure(ctx, ctx->cgemm2, ((size_t)n / 64 + ndirs + 1) * 160 * 64 * sizeof(double)))) return rc;
         if ((rc = ensure(ctx, ctx->done, (size_t)n + 64))) return rc;
         if ((rc = ensure(ctx, ctx->rlist, ((size_t)n + pl.max_schunks + 64) * sizeof(int)))) return rc;
         if ((rc = ensure(ctx, ctx->ytil2, (size_t)n * amx::kSeedKD * sizeof(double)))) return rc;
@@ -176,7 +177,7 @@ void amx_ctx_destroy(amx_ctx *ctx)
     hipDeviceSynchronize();
     DevBuf *bufs[] = {&ctx->lutidx, &ctx->perm, &ctx->counts, &ctx->dir_start, &ctx->cursor, &ctx->chunks,
                       &ctx->misc, &ctx->xiso, &ctx->supp, &ctx->ovf, &ctx->cproj, &ctx->hy, &ctx->hdirs, &ctx->hest,
-                      &ctx->hrmse, &ctx->hnrmse, &ctx->hextra, &ctx->hy32, &ctx->ytil, &ctx->seeds, &ctx->schunks, &ctx->ytil2, &ctx->seeds2, &ctx->cgemm, &ctx->done, &ctx->rlist};
+                      &ctx->hrmse, &ctx->hnrmse, &ctx->hextra, &ctx->hy32, &ctx->ytil, &ctx->seeds, &ctx->schunks, &ctx->ytil2, &ctx->seeds2, &ctx->cgemm, &ctx->done, &ctx->rlist, &ctx->cgemm2};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     for (DevBuf &b : ctx->alt) if (b.p) hipFree(b.p);
     if (ctx->status_d) hipFree(ctx->status_d);
@@ -192,7 +193,7 @@ void amx_lut_destroy(amx_lut *lut)
 {
     if (!lut) return;
     if (lut->ctx) hipSetDevice(lut->ctx->device);
-    void *ps[] = {lut->screen_kappa0, lut->screen2_S, lut->screen2_kappa, lut->screen_S, lut->screen_kappa, lut->basis_U, lut->basis_S, lut->basis2_U, lut->basis2_S, lut->gram, lut->gram_dwi, lut->tiles, lut->htable, lut->rowdwi, lut->colscale, lut->icvf, lut->kappa,
+    void *ps[] = {lut->screen2_kappa0, lut->screen_kappa0, lut->screen2_S, lut->screen2_kappa, lut->screen_S, lut->screen_kappa, lut->basis_U, lut->basis_S, lut->basis2_U, lut->basis2_S, lut->gram, lut->gram_dwi, lut->tiles, lut->htable, lut->rowdwi, lut->colscale, lut->icvf, lut->kappa,
                   lut->norms, lut->Rs, lut->d_in, lut->d_isos, lut->fw_prep, lut->sandi_prep};
     for (void *p : ps) if (p) hipFree(p);
     if (lut->fw_ready) (void)hipEventDestroy(lut->fw_ready);
@@ -406,6 +407,8 @@ int amx_sync_status(amx_ctx *ctx, void *hip_stream)
     if (amx_debug()) fprintf(stderr, "[amx] screened certificates: %d exact dot products (NNLS stages), %d (LASSO stage)\n", st[ST_SEED + 22], st[ST_SEED + 23]);
     if (amx_debug()) fprintf(stderr, "[amx] Gram certificates stage 1: %d voxels, %d certified (pivot ratio %d, x <= 0 %d, dual %d), %d dual values; stage 3: %d voxels, %d certified (pivot %d, x <= 0 %d, dual %d), %d dual values\n",
                              st[ST_SEED + 24], st[ST_SEED + 25], st[ST_SEED + 26], st[ST_SEED + 27], st[ST_SEED + 28], st[ST_SEED + 29], st[ST_SEED + 30], st[ST_SEED + 31], st[ST_SEED + 32], st[ST_SEED + 33], st[ST_SEED + 34], st[ST_SEED + 35]);
+    if (amx_debug()) fprintf(stderr, "[amx] Gram certificates LASSO: %d voxels, %d certified (more than 12 atoms %d, x <= 0 %d, dual %d), %d dual values\n",
+                             st[ST_SEED + 36], st[ST_SEED + 37], st[ST_SEED + 38], st[ST_SEED + 39], st[ST_SEED + 40], st[ST_SEED + 41]);
     if (amx_debug()) fprintf(stderr, "[amx] LASSO seeds: tried %d certified %d; seed solver trips %d lane-trips used %d\n", st[ST_SEED + 18], st[ST_SEED + 19], st[ST_SEED + 20], st[ST_SEED + 21]);
     if (amx_debug()) fprintf(stderr, "[amx] seed solver kcycles (wave sums / 1024): take %d solve+drop %d residual %d scan %d append %d store %d\n", st[ST_SEED + 12], st[ST_SEED + 13], st[ST_SEED + 14], st[ST_SEED + 15], st[ST_SEED + 16], st[ST_SEED + 17]);
     if (st[ST_ERRVOX] != 0x7f7f7f7f) {
@@ -547,7 +550,7 @@ int amx_noddi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
         // y~ = U'y once; the seed solver proposes the stage's support, the stage kernel certifies it (amx_seed.hpp)
         rec(ctx, 10, s);
         const bool gcert = !ctx->opt_no_gcert && lut->nS <= 100 && lut->n_atoms <= 146;
-        if (gcert && (rc = amx_launch_noddi_gemm(ctx, lut, a, pl, s))) return rc;
+        if (gcert && (rc = amx_launch_noddi_gemm(ctx, lut, a, pl, s, false))) return rc;
         if (!gcert && (rc = amx_launch_noddi_project(ctx, lut, a, pl, s))) return rc;      // (the GEMM writes y~ as well)
         if (!ctx->opt_no_screen) { a.scr_S = lut->screen_S; a.scr_kappa = lut->screen_kappa; a.scr_ytil = (const double *)ctx->ytil.p; a.scr_Sg = lut->basis_S; }
         if (ctx->opt_seed_stages & 1) {
@@ -566,14 +569,22 @@ int amx_noddi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
     a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks; a.rlist = nullptr; a.rcount = nullptr; a.done = nullptr;
     // the LASSO seeds need x_iso: Gram-space solver only (lambda2 >= 1e-5), with the default dictionary shape
     if (seeds && (ctx->opt_seed_stages & 4) && lut->basis2_S != nullptr && lambda2 >= 1e-5 && lut->nS <= 128 && !getenv("AMX_LASSO_QR")) {
+        const bool gcert2 = !ctx->opt_no_gcert && lut->nS <= 100 && lut->n_atoms <= 146 && lut->n_wm <= 144 && lut->screen2_kappa0 != nullptr;
         rec(ctx, 12, s);
-        if ((rc = amx_launch_noddi_seed2(ctx, lut, a, pl, s))) return rc;
-        rec(ctx, 13, s);
+        if (gcert2 && (rc = amx_launch_noddi_gemm(ctx, lut, a, pl, s, true))) return rc;        // c2 = A2'y2, y2~, ||y2||^2
+        if ((rc = amx_launch_noddi_seed2(ctx, lut, a, pl, s, gcert2))) return rc;
         a.seeds2 = (const unsigned long long *)ctx->seeds2.p;
         if (!ctx->opt_no_screen && lut->screen2_S) { a.scr2_S = lut->screen2_S; a.scr2_kappa = lut->screen2_kappa; a.scr2_ytil = (const double *)ctx->ytil2.p; a.scr2_Sg = lut->basis2_S; }
+        if (gcert2) {
+            if ((rc = amx_launch_noddi_gcert2(ctx, lut, a, pl, s))) return rc;
+            a.rlist = (const int *)ctx->rlist.p; a.rcount = a.rlist + pl.n;
+            a.c.chunks = pl.schunks; a.c.n_chunks = pl.n_chunks + 1;
+        }
+        rec(ctx, 13, s);
     }
     if (!(rc = amx_launch_noddi_s2(ctx, a, pl, s))) {
         a.seeds = nullptr; a.done = nullptr; a.rlist = nullptr; a.rcount = nullptr;
+        a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks;
         if (seeds && (ctx->opt_seed_stages & 2)) {
             a.seeds = (const unsigned long long *)ctx->seeds.p;
             rec(ctx, 14, s);

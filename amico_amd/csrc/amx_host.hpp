@@ -25,7 +25,7 @@ struct amx_ctx {
     int n_cu = 256;                // compute units of the device (persistent-grid launches)
     std::string err;
     // stream-ordered workspace (grow-only)
-    DevBuf lutidx, perm, counts, dir_start, cursor, chunks, misc, xiso, supp, ovf, cproj, ytil, seeds, schunks, ytil2, seeds2, cgemm, done, rlist;
+    DevBuf lutidx, perm, counts, dir_start, cursor, chunks, misc, xiso, supp, ovf, cproj, ytil, seeds, schunks, ytil2, seeds2, cgemm, done, rlist, cgemm2;
     DevBuf hy, hdirs, hest, hrmse, hnrmse, hextra;   // staging for the host-pointer entry points
     int *status_d = nullptr;       // ST_WORDS ints
     int *status_h = nullptr;       // pinned mirror (+16 words: copy of the misc counters)
@@ -42,11 +42,11 @@ struct amx_ctx {
     hipStream_t hs2 = nullptr;     // between the two, so the tail of one batch's kernels is filled by the next batch's
     hipEvent_t hev[3] = {nullptr, nullptr, nullptr};
     // second workspace set for the batch in flight on the other stream (swap_work exchanges it with the named buffers)
-    DevBuf alt[19];
+    DevBuf alt[20];
     void swap_work()
     {
-        DevBuf *named[19] = {&lutidx, &perm, &counts, &dir_start, &cursor, &chunks, &misc, &xiso, &supp, &ovf, &cproj, &ytil, &seeds, &schunks, &ytil2, &seeds2, &cgemm, &done, &rlist};
-        for (int i = 0; i < 19; i++) { DevBuf t = *named[i]; *named[i] = alt[i]; alt[i] = t; }
+        DevBuf *named[20] = {&lutidx, &perm, &counts, &dir_start, &cursor, &chunks, &misc, &xiso, &supp, &ovf, &cproj, &ytil, &seeds, &schunks, &ytil2, &seeds2, &cgemm, &done, &rlist, &cgemm2};
+        for (int i = 0; i < 20; i++) { DevBuf t = *named[i]; *named[i] = alt[i]; alt[i] = t; }
     }
     // switches read ONCE, at amx_ctx_create (environment): diagnosis / A-B only
     bool opt_no_gcert = false;     // AMX_NO_GCERT=1: every seed is certified by the wavefront-per-voxel kernels (true residual)
@@ -66,6 +66,7 @@ struct amx_lut {
     void *tiles = nullptr;
     double *gram = nullptr, *gram_dwi = nullptr;   // per-orientation Gram matrices (NODDI)
     double *basis_U = nullptr, *basis_S = nullptr; // per-orientation compressed basis and dictionary (amx_seed.hpp), NODDI
+    double *screen2_kappa0 = nullptr;
     float *screen2_S = nullptr; double *screen2_kappa = nullptr; // the same for the LASSO stage's dictionary
     double *screen_kappa0 = nullptr;                             // max ||(I - U U') a_j|| per orientation (k_nnls_gcert)
     float *screen_S = nullptr; double *screen_kappa = nullptr;   // float32 S [ndirs][12][192] + kappa [ndirs]: dual-value screening
@@ -173,8 +174,9 @@ int amx_build_basis(amx_ctx *ctx, amx_lut *lut);
 int amx_launch_noddi_project(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s);
 int amx_launch_noddi_seed(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, int stage);
 int amx_launch_noddi_gcert(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, int stage);
-int amx_launch_noddi_gemm(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s);
-int amx_launch_noddi_seed2(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s);
+int amx_launch_noddi_gemm(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, bool lasso);
+int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s);
+int amx_launch_noddi_seed2(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, bool have_ytil2);
 int amx_launch_noddi_s1(amx_ctx *ctx, amx::NoddiArgs &a, const Plan &pl, hipStream_t s);
 int amx_launch_noddi_s2(amx_ctx *ctx, amx::NoddiArgs &a, const Plan &pl, hipStream_t s);
 int amx_launch_noddi_s3(amx_ctx *ctx, amx::NoddiArgs &a, const Plan &pl, hipStream_t s);

@@ -19,7 +19,7 @@ struct Chunk { int dir, start, count, pad; };
 constexpr int kSeedKD = 12;      // compressed dimensions of the support-seed problem (amx_seed.hpp)
 constexpr int kScreenLd = 192;   // atoms per row of the float32 screening table [KD][kScreenLd]
 
-enum StatusSlot { ST_ERRVOX = 0, ST_II1 = 1, ST_II2 = 2, ST_OVERFLOW = 3, ST_ITCAP = 4, ST_RERUN = 5, ST_GUARD = 6, ST_GUARDVOX = 7, ST_EXACT = 8, ST_GRAM = 11, ST_ITERS = 14, ST_SEED = 17, ST_WORDS = 60 };
+enum StatusSlot { ST_ERRVOX = 0, ST_II1 = 1, ST_II2 = 2, ST_OVERFLOW = 3, ST_ITCAP = 4, ST_RERUN = 5, ST_GUARD = 6, ST_GUARDVOX = 7, ST_EXACT = 8, ST_GRAM = 11, ST_ITERS = 14, ST_SEED = 17, ST_WORDS = 64 };
 
 // ------------------------------------------------------------------ shared pieces
 struct FitCommon {
@@ -644,7 +644,7 @@ __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
         if (cid < 0) return;
         const Chunk ck = a.c.chunks[cid];
         unsigned *ticket = reinterpret_cast<unsigned *>(wm_all + nw_ * 4);     // the 16 spare bytes of fit_lds_bytes
-        if ((STAGE == 1 || STAGE == 3) && a.rlist != nullptr && a.rcount[cid] == 0) return;      // nothing left over in this chunk
+        if ((STAGE == 1 || STAGE == 3 || STAGE == 4) && a.rlist != nullptr && a.rcount[cid] == 0) return;      // nothing left over in this chunk
         if (threadIdx.x == 0) *ticket = (unsigned)nw_;
         stage_noddi_tile<AT>(As, tiles + (size_t)ck.dir * a.c.tile_stride, words, words_pad - words);
         // NNLS stages with seeds: the float32 compressed dictionary of the orientation for the dual-value screening
@@ -667,7 +667,7 @@ __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
 #else
         // voxels differ 2-3x in solver iterations: the wavefronts draw the next voxel of the chunk from an LDS ticket
         // (next_ticket keeps the control flow wave-uniform: every lane takes part in the atomic)
-        if ((STAGE == 1 || STAGE == 3) && a.rlist != nullptr) {
+        if ((STAGE == 1 || STAGE == 3 || STAGE == 4) && a.rlist != nullptr) {
             const int cnt = a.rcount[cid];
             for (int k = wave; k < cnt; k = next_ticket(ticket, lane)) {
                 const int pos = a.rlist[ck.start + k];

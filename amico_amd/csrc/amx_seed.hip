@@ -28,9 +28,10 @@ int amx_build_basis(amx_ctx *ctx, amx_lut *lut)
         HIPCHK(ctx, hipMalloc((void **)&lut->screen2_S, (size_t)lut->ndirs * kSeedKD * kScreenLd * sizeof(float) + 64));
         HIPCHK(ctx, hipMemset(lut->screen2_S, 0, (size_t)lut->ndirs * kSeedKD * kScreenLd * sizeof(float)));
         HIPCHK(ctx, hipMalloc((void **)&lut->screen2_kappa, (size_t)lut->ndirs * sizeof(double) + 64));
+        HIPCHK(ctx, hipMalloc((void **)&lut->screen2_kappa0, (size_t)lut->ndirs * sizeof(double) + 64));
         hipLaunchKernelGGL(k_build_basis, dim3(lut->ndirs), dim3(256), lds, nullptr, (const float *)lut->tiles, lut->tile_stride, lut->nS,
                            lut->ldA, lut->n_wm, (const unsigned char *)lut->rowdwi, (const double *)lut->colscale, lut->basis2_U, lut->basis2_S, kSeed2Ld,
-                           lut->screen2_S, lut->screen2_kappa);
+                           lut->screen2_S, lut->screen2_kappa, lut->screen2_kappa0);
     }
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipDeviceSynchronize());
@@ -38,7 +39,7 @@ int amx_build_basis(amx_ctx *ctx, amx_lut *lut)
 }
 
 // LASSO stage: y2~ = U2'y2 and the passive-set seeds (after stage 1: y2 needs x_iso)
-int amx_launch_noddi_seed2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, const Plan &pl, hipStream_t s)
+int amx_launch_noddi_seed2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, const Plan &pl, hipStream_t s, bool have_ytil2)
 {
     Seed2Args sa;
     memset(&sa, 0, sizeof sa);
@@ -56,9 +57,11 @@ int amx_launch_noddi_seed2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a,
     sa.trace = (double *)ctx->seeds.p; hipMemsetAsync(ctx->seeds.p, 0, 8 * 8 * 80, s);
 #endif
     const dim3 grid(((pl.max_chunks + 7) / 8) * 8);
-    if (lut->nS <= 128) hipLaunchKernelGGL(k_noddi_project2<2>, grid, dim3(1024), 0, s, sa);
-    else hipLaunchKernelGGL(k_noddi_project2<4>, grid, dim3(1024), 0, s, sa);
-    AMX_TRACE(ctx, s, "projection of the clipped signals");
+    if (!have_ytil2) {
+        if (lut->nS <= 128) hipLaunchKernelGGL(k_noddi_project2<2>, grid, dim3(1024), 0, s, sa);
+        else hipLaunchKernelGGL(k_noddi_project2<4>, grid, dim3(1024), 0, s, sa);
+        AMX_TRACE(ctx, s, "projection of the clipped signals");
+    }
     const size_t lds = ((size_t)lut->n_wm * (kSeed2KD + 1) + 8 + (size_t)9 * (kSeed2KD / 4) * 64 + (size_t)4 * (64 * (kSeed2KD + 1) + 64 * 3)) * sizeof(double);
     int rc;
     if ((rc = set_lds(ctx, k_lasso_seed, lds))) return rc;
@@ -82,19 +85,52 @@ static void fill(SeedArgs &sa, const amx_lut *lut, const NoddiArgs &a, const Pla
 #endif
 }
 
-// C = [A | U]'Y of every voxel (k_noddi_gemm): block-wise table in ctx->cgemm
-int amx_launch_noddi_gemm(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, const Plan &pl, hipStream_t s)
+// C = [A | U]'Y of every voxel (k_noddi_gemm): block-wise table in ctx->cgemm; lasso: the stage-2 problem (y2, U2, scaled rows)
+int amx_launch_noddi_gemm(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, const Plan &pl, hipStream_t s, bool lasso)
 {
     GemmArgs ga;
     memset(&ga, 0, sizeof ga);
     ga.y = a.c.y; ga.perm = pl.perm; ga.schunks = pl.schunks; ga.n_schunks = pl.n_chunks + 1;
     ga.tiles = (const float *)lut->tiles; ga.tile_stride = lut->tile_stride; ga.ldA = lut->ldA; ga.nS = lut->nS; ga.n_atoms = lut->n_atoms;
-    ga.Ub = lut->basis_U; ga.Cb = (double *)ctx->cgemm.p; ga.ytil = (double *)ctx->ytil.p;
+    ga.Ub = lasso ? lut->basis2_U : lut->basis_U; ga.Cb = (double *)(lasso ? ctx->cgemm2.p : ctx->cgemm.p); ga.ytil = (double *)(lasso ? ctx->ytil2.p : ctx->ytil.p);
+    ga.xiso = a.xiso; ga.rowdwi = lut->rowdwi; ga.colscale = lut->colscale; ga.iso_atom = lut->n_atoms - 1; ga.is_exvivo = lut->is_exvivo; ga.n_wm = lut->n_wm;
     const size_t lds = (size_t)9 * 25 * 64 * sizeof(float) + ((size_t)25 * 64 + (size_t)4 * 16 * 101) * sizeof(double);
     int rc;
-    if ((rc = set_lds(ctx, k_noddi_gemm, lds))) return rc;
-    hipLaunchKernelGGL(k_noddi_gemm, dim3(((pl.max_schunks + 7) / 8) * 8), dim3(256), lds, s, ga);
+    const dim3 grid(((pl.max_schunks + 7) / 8) * 8);
+    if (lasso) {
+        if ((rc = set_lds(ctx, k_noddi_gemm<true>, lds))) return rc;
+        hipLaunchKernelGGL(k_noddi_gemm<true>, grid, dim3(256), lds, s, ga);
+    } else {
+        if ((rc = set_lds(ctx, k_noddi_gemm<false>, lds))) return rc;
+        hipLaunchKernelGGL(k_noddi_gemm<false>, grid, dim3(256), lds, s, ga);
+    }
     AMX_TRACE(ctx, s, "A'y of every voxel on the matrix cores");
+    HIPCHK(ctx, hipGetLastError());
+    return AMX_OK;
+}
+
+// Gram-space certificates of the LASSO seeds (k_lasso_gcert): support bits of the voxels it settles, left-over lists for k_noddi<4>
+int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, const Plan &pl, hipStream_t s)
+{
+    Gcert2Args g;
+    memset(&g, 0, sizeof g);
+    g.perm = pl.perm; g.schunks = pl.schunks; g.n_schunks = pl.n_chunks + 1;
+    g.seeds2 = (const unsigned long long *)ctx->seeds2.p; g.Cb = (const double *)ctx->cgemm2.p;
+    g.gram = lut->gram_dwi; g.colscale = lut->colscale; g.ldG = lut->ldG; g.n_atoms = lut->n_atoms; g.n_wm = lut->n_wm;
+    g.iso_atom = lut->n_atoms - 1; g.dot_atom = lut->is_exvivo ? lut->n_atoms - 2 : -1;
+    g.Sb = lut->basis2_S; g.kappa0 = lut->screen2_kappa0; g.lam1 = a.c.lam1; g.lam2 = a.c.lam2;
+    g.supp = a.supp; g.xiso = a.xiso; g.done = (unsigned char *)ctx->done.p;
+    g.rlist = (int *)ctx->rlist.p; g.rcount = (int *)ctx->rlist.p + pl.n;
+    HIPCHK(ctx, hipMemsetAsync(g.rcount, 0, (size_t)pl.max_schunks * sizeof(int), s));
+    if (a.c.xdbg) g.xdbg = a.c.xdbg;
+#ifdef AMX_STATS
+    g.stats = a.c.status + ST_SEED + 36;
+#endif
+    const size_t lds = ((size_t)lut->n_wm * kSeedLd + 2 + ((lut->n_wm + 1) & ~1) + (size_t)9 * (kSeedKD / 4) * 64 + (size_t)4 * 64 * 16) * sizeof(double);
+    int rc;
+    if ((rc = set_lds(ctx, k_lasso_gcert, lds))) return rc;
+    hipLaunchKernelGGL(k_lasso_gcert, dim3(((pl.max_schunks + 7) / 8) * 8), dim3(256), lds, s, g);
+    AMX_TRACE(ctx, s, "Gram-space certificates of the LASSO seeds");
     HIPCHK(ctx, hipGetLastError());
     return AMX_OK;
 }

@@ -689,6 +689,12 @@ __global__ void __launch_bounds__(256, 2) k_nnls_seed(const SeedArgs a)
 // Rows 146 .. 157 of a block hold the projections y~ = U'y, row 158 holds ||y||^2, whatever the number of atoms.
 constexpr int kGemmRows = 160, kGemmU = 146, kGemmYY = 158;     // rows: atoms (n_atoms <= 146) | y~ at 146 .. 157 | ||y||^2 at 158
 struct GemmArgs {
+    // LASSO variant (k_noddi_gemm<true>): the signal is y2 = max(0, y - x_iso iso (- x_dot)) on the stage-2 rows, 0 elsewhere
+    // (models.pyx:917-925), the basis is U2, and row j of the output is scaled by colscale[j] (column-normalised atoms)
+    const double *xiso;           // [n_vox][2]
+    const unsigned char *rowdwi;  // [nS]
+    const double *colscale;       // [n_atoms]
+    int iso_atom, is_exvivo, n_wm;
     const double *y;              // [n_vox][nS]
     const int *perm;
     const Chunk *schunks;         // pad = first block of the chunk
@@ -700,6 +706,7 @@ struct GemmArgs {
     double *ytil;                 // [n][12] bucket order (copy of rows n_atoms .. n_atoms + 11), or null
 };
 
+template <bool LASSO>
 __global__ void __launch_bounds__(256) k_noddi_gemm(const GemmArgs a)
 {
     constexpr int MT = 10, KS = 25, YLD = 101;     // nS <= 100
@@ -718,14 +725,14 @@ __global__ void __launch_bounds__(256) k_noddi_gemm(const GemmArgs a)
     for (int e = threadIdx.x; e < (MT - 1) * KS * 64; e += blockDim.x) {
         const int l = e & 63, ks = (e >> 6) % KS, mt = (e >> 6) / KS;
         const int atom = 16 * mt + (l & 15), row = 4 * ks + (l >> 4);
-        A32[e] = (row < nS && atom < n_atoms) ? tile[row * ldA + atom] : 0.0f;
+        A32[e] = (row < nS && atom < (LASSO ? a.n_wm : n_atoms)) ? tile[row * ldA + atom] : 0.0f;
     }
     for (int e = threadIdx.x; e < KS * 64; e += blockDim.x) {
         const int l = e & 63, ks = e >> 6;
         const int atom = 16 * (MT - 1) + (l & 15), row = 4 * ks + (l >> 4);
         double v = 0.0;
         if (row < nS) {
-            if (atom < n_atoms) v = (double)tile[row * ldA + atom];
+            if (atom < (LASSO ? a.n_wm : n_atoms)) v = (double)tile[row * ldA + atom];
             else if (atom >= kGemmU && atom < kGemmU + kSeedKD) v = U[row * kSeedKD + (atom - kGemmU)];
         }
         A64[e] = v;
@@ -735,6 +742,12 @@ __global__ void __launch_bounds__(256) k_noddi_gemm(const GemmArgs a)
     // the 16 signal rows of a group: one coalesced load per voxel (lane l takes bytes 16 l .. 16 l + 15 of the row); the loads
     // of group g + nw are issued before the products of group g, so they are long done when their turn comes
     double ya[16], yb[16];
+    double iso0 = 0.0, iso1 = 0.0;
+    bool rw0 = false, rw1 = false;
+    if (LASSO) {
+        if (2 * lane < nS) { iso0 = (double)tile[(2 * lane) * ldA + a.iso_atom]; rw0 = a.rowdwi[2 * lane] != 0; }
+        if (2 * lane + 1 < nS) { iso1 = (double)tile[(2 * lane + 1) * ldA + a.iso_atom]; rw1 = a.rowdwi[2 * lane + 1] != 0; }
+    }
     auto issue = [&](int g) {
 #pragma unroll
         for (int v = 0; v < 16; v++) {
@@ -743,6 +756,12 @@ __global__ void __launch_bounds__(256) k_noddi_gemm(const GemmArgs a)
             const double *yv = a.y + (size_t)vox * nS;
             ya[v] = (2 * lane < nS && k < ck.count) ? yv[2 * lane] : 0.0;
             yb[v] = (2 * lane + 1 < nS && k < ck.count) ? yv[2 * lane + 1] : 0.0;
+            if (LASSO) {
+                const double xi = a.xiso[(size_t)vox * 2], xd = a.is_exvivo ? a.xiso[(size_t)vox * 2 + 1] : 0.0;
+                double t0 = ya[v] - xi * iso0 - xd, t1 = yb[v] - xi * iso1 - xd;
+                t0 = t0 < 0.0 ? 0.0 : t0; t1 = t1 < 0.0 ? 0.0 : t1;       // (NaN stays NaN: comparisons with NaN are false)
+                ya[v] = (rw0 && k < ck.count) ? t0 : 0.0; yb[v] = (rw1 && k < ck.count) ? t1 : 0.0;
+            }
         }
     };
     if (wave < n_groups) issue(wave);
@@ -783,7 +802,10 @@ __global__ void __launch_bounds__(256) k_noddi_gemm(const GemmArgs a)
 #pragma unroll
                 for (int u = 0; u < 3; u++) {
 #pragma unroll
-                    for (int rr = 0; rr < 4; rr++) out[(size_t)(16 * (mt + u) + 4 * rr + q) * 64] = acc[u][rr];
+                    for (int rr = 0; rr < 4; rr++) {
+                        const int row = 16 * (mt + u) + 4 * rr + q;
+                        out[(size_t)row * 64] = LASSO ? ((row < a.n_wm) ? a.colscale[row] * acc[u][rr] : 0.0) : acc[u][rr];
+                    }
                 }
             }
         }
@@ -795,12 +817,90 @@ __global__ void __launch_bounds__(256) k_noddi_gemm(const GemmArgs a)
 #pragma unroll
                 for (int rr = 0; rr < 4; rr++) {
                     const int row = 16 * (MT - 1) + 4 * rr + q;
-                    out[(size_t)row * 64] = (row == kGemmYY) ? yy : acc[rr];
+                    out[(size_t)row * 64] = (row == kGemmYY) ? yy : ((LASSO && row < a.n_wm) ? a.colscale[row] * acc[rr] : acc[rr]);
                     // the projections once more in voxel-major order for the kernels that walk the 256-voxel chunks
                     if (a.ytil != nullptr && row >= kGemmU && row < kGemmU + kSeedKD) a.ytil[(size_t)(ck.start + 16 * g + c16) * kSeedKD + (row - kGemmU)] = acc[rr];
                 }
             }
         }
+    }
+}
+
+// Which atoms of which voxel have a compressed dual value above the voxel's threshold?  One fp64 MFMA product for the 64 voxels
+// of the wavefront (operands as in seed_scan_mfma); every lane publishes its residual r~, its threshold and the mask of the
+// atoms it wants examined in the wavefront's LDS block Rb [64][16], the lanes that hold the D tiles test "candidate and
+// value > threshold" and the flag words travel back to the owner through the two row swaps.  ex[3]: flagged atoms of the own voxel.
+template <int KS, int MT>
+__device__ __forceinline__ void seed_flags_mfma(const double *Aop, double *Rb, int lane, const double (&rt)[4 * KS], bool good, double thr_own,
+                                                const unsigned long long (&cand)[3], unsigned long long (&ex)[3])
+{
+    constexpr int RBW = 16;
+    const int q = lane >> 4, c16 = lane & 15;
+#pragma unroll
+    for (int d = 0; d < 4 * KS; d++) Rb[lane * RBW + d] = good ? rt[d] : 0.0;
+    Rb[lane * RBW + 12] = thr_own;                                     // flag when the compressed dual value exceeds this
+    unsigned long long *Mb = reinterpret_cast<unsigned long long *>(Rb + lane * RBW + 13);
+#pragma unroll
+    for (int w3 = 0; w3 < 3; w3++) Mb[w3] = good ? cand[w3] : 0ull;
+    double b[4][KS], thr[4];
+    unsigned cq[4][6];
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) {
+        const int src = 16 * nt + c16;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) b[nt][ks] = Rb[src * RBW + 4 * ks + q];
+        thr[nt] = Rb[src * RBW + 12];
+        const unsigned long long *Ms = reinterpret_cast<const unsigned long long *>(Rb + src * RBW + 13);
+#pragma unroll
+        for (int w3 = 0; w3 < 3; w3++) { const unsigned long long m = Ms[w3] >> q; cq[nt][2 * w3] = (unsigned)m; cq[nt][2 * w3 + 1] = (unsigned)(m >> 32); }
+    }
+    unsigned fq[4][6];
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) {
+#pragma unroll
+        for (int w6 = 0; w6 < 6; w6++) fq[nt][w6] = 0u;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        double av[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) av[ks] = Aop[(mt * KS + ks) * 64 + lane];
+        seed_v4d acc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) acc[nt] = (seed_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], b[nt][ks], acc[nt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const int bit = 16 * mt + 4 * rr;            // position in the row-shifted masks
+                const bool hit = ((cq[nt][bit >> 5] >> (bit & 31)) & 1u) && (acc[nt][rr] > thr[nt]);
+                fq[nt][bit >> 5] |= hit ? (1u << (bit & 31)) : 0u;
+            }
+        }
+    }
+    // the four rows that share a voxel: OR of their flag words (shifted back by the row), owner = row of the voxel
+#pragma unroll
+    for (int w3 = 0; w3 < 3; w3++) {
+        unsigned long long mine = 0ull;
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+            const unsigned long long f = (((unsigned long long)fq[nt][2 * w3 + 1] << 32) | (unsigned long long)fq[nt][2 * w3]) << q;
+            unsigned lo = (unsigned)f, hi = (unsigned)(f >> 32);
+            {
+                const auto s1 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false); lo = s1[0] | s1[1];
+                const auto s2 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false); lo = s2[0] | s2[1];
+                const auto s3 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false); hi = s3[0] | s3[1];
+                const auto s4 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false); hi = s4[0] | s4[1];
+            }
+            const unsigned long long m = ((unsigned long long)hi << 32) | (unsigned long long)lo;
+            mine = (q == nt) ? m : mine;
+        }
+        ex[w3] = mine;
     }
 }
 
@@ -951,73 +1051,7 @@ __global__ void __launch_bounds__(256, 2) k_nnls_gcert(const GcertArgs a)
 #pragma unroll
                 for (int d = 0; d < KD; d++) rt[d] -= V.x[s] * col[d];
             }
-            // publish: r~ [12] | margin | candidate mask (3 words)
-#pragma unroll
-            for (int d = 0; d < KD; d++) Rb[lane * RBW + d] = good ? rt[d] : 0.0;
-            Rb[lane * RBW + 12] = good ? -1.0625 * kap * sqrt(rho2) - 1e-12 : __builtin_huge_val();      // flag when dual > this
-            unsigned long long *Mb = reinterpret_cast<unsigned long long *>(Rb + lane * RBW + 13);
-#pragma unroll
-            for (int w3 = 0; w3 < 3; w3++) Mb[w3] = good ? cand[w3] : 0ull;
-            double b[4][KS], thr[4];
-            unsigned cq[4][6];
-#pragma unroll
-            for (int nt = 0; nt < 4; nt++) {
-                const int src = 16 * nt + c16;
-#pragma unroll
-                for (int ks = 0; ks < KS; ks++) b[nt][ks] = Rb[src * RBW + 4 * ks + q];
-                thr[nt] = Rb[src * RBW + 12];
-                const unsigned long long *Ms = reinterpret_cast<const unsigned long long *>(Rb + src * RBW + 13);
-#pragma unroll
-                for (int w3 = 0; w3 < 3; w3++) { const unsigned long long m = Ms[w3] >> q; cq[nt][2 * w3] = (unsigned)m; cq[nt][2 * w3 + 1] = (unsigned)(m >> 32); }
-            }
-            unsigned fq[4][6];
-#pragma unroll
-            for (int nt = 0; nt < 4; nt++) {
-#pragma unroll
-                for (int w6 = 0; w6 < 6; w6++) fq[nt][w6] = 0u;
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++) {
-                double av[KS];
-#pragma unroll
-                for (int ks = 0; ks < KS; ks++) av[ks] = Aop[(mt * KS + ks) * 64 + lane];
-                seed_v4d acc[4];
-#pragma unroll
-                for (int nt = 0; nt < 4; nt++) acc[nt] = (seed_v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int ks = 0; ks < KS; ks++) {
-#pragma unroll
-                    for (int nt = 0; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], b[nt][ks], acc[nt], 0, 0, 0);
-                }
-#pragma unroll
-                for (int nt = 0; nt < 4; nt++) {
-#pragma unroll
-                    for (int rr = 0; rr < 4; rr++) {
-                        const int bit = 16 * mt + 4 * rr;            // position in the row-shifted masks
-                        const bool hit = ((cq[nt][bit >> 5] >> (bit & 31)) & 1u) && (acc[nt][rr] > thr[nt]);
-                        fq[nt][bit >> 5] |= hit ? (1u << (bit & 31)) : 0u;
-                    }
-                }
-            }
-            // the four rows that share a voxel: OR of their flag words (shifted back by the row), owner = row of the voxel
-#pragma unroll
-            for (int w3 = 0; w3 < 3; w3++) {
-                unsigned long long mine = 0ull;
-#pragma unroll
-                for (int nt = 0; nt < 4; nt++) {
-                    unsigned long long f = (((unsigned long long)fq[nt][2 * w3 + 1] << 32) | (unsigned long long)fq[nt][2 * w3]) << q;
-                    unsigned lo = (unsigned)f, hi = (unsigned)(f >> 32);
-                    {
-                        const auto s1 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false); lo = s1[0] | s1[1];
-                        const auto s2 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false); lo = s2[0] | s2[1];
-                        const auto s3 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false); hi = s3[0] | s3[1];
-                        const auto s4 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false); hi = s4[0] | s4[1];
-                    }
-                    const unsigned long long m = ((unsigned long long)hi << 32) | (unsigned long long)lo;
-                    mine = (q == nt) ? m : mine;
-                }
-                ex[w3] = mine;
-            }
+            seed_flags_mfma<KS, MT>(Aop, Rb, lane, rt, good, good ? -1.0625 * kap * sqrt(rho2) - 1e-12 : __builtin_huge_val(), cand, ex);
         }
         // ---- exact (Gram-form) dual values of the flagged atoms: u_t = c_t - G_tP x
         bool viol = false;
@@ -1108,6 +1142,199 @@ __global__ void __launch_bounds__(256, 2) k_nnls_gcert(const GcertArgs a)
                 for (int j = 0; j < n_atoms; j++) dst[j] = 0.0;
 #pragma unroll
                 for (int s = 0; s < MS; s++) if (s < V.np) dst[V.idx[s]] = V.x[s];
+            }
+        }
+    }
+}
+
+// ================================================================== Gram-space certificate of the LASSO seeds, one voxel per lane
+// Same idea as k_nnls_gcert for  min 1/2 ||y2 - A2 x||^2 + lambda1 sum(x) + lambda2/2 ||x||^2, x >= 0:  with c2 = A2'y2
+// (k_noddi_gemm<true>) and the stage-2 Gram matrix,  H_PP x_P = c2_P - lambda1,  H = S G2 S + lambda2 I  (S = column scales),
+// dual value of atom t: g_t = c2_t - (S G2 S)_tP x_P - lambda1.  The ridge bounds cond(H), so no pivot guard is needed
+// -- this is the arithmetic GramSolver::certify_seed performs too.  A lane holds the factor of up to 12 passive atoms
+// (87 % of the voxels; the rest, and everything refused, goes to k_noddi<4> through the left-over lists).
+constexpr int kGcert2Max = 12;
+struct Gcert2Args {
+    const int *perm;
+    const Chunk *schunks;
+    const int *n_schunks;
+    const unsigned long long *seeds2;  // [n][4], bucket order
+    const double *Cb;                  // [n_blocks][160][64] of k_noddi_gemm<true>
+    const double *gram;                // [ndirs][n_atoms][ldG] stage-2 rows
+    const double *colscale;            // [n_atoms]
+    int ldG, n_atoms, n_wm, iso_atom, dot_atom;
+    const double *Sb;                  // [ndirs][n_wm][12]
+    const double *kappa0;              // [ndirs]
+    double lam1, lam2;
+    unsigned long long *supp;          // out: [n_vox][4]
+    const double *xiso;                // [n_vox][2] (AMX_F_DEBUG_X only)
+    unsigned char *done;
+    int *rlist, *rcount;
+    double *xdbg;
+    int *stats;
+};
+
+__global__ void __launch_bounds__(256, 2) k_lasso_gcert(const Gcert2Args a)
+{
+    constexpr int KD = kSeedKD, KS = KD / 4, MT = 9, MS = kGcert2Max, LD = kSeedLd, RBW = 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_c2[];
+    double *Sl = reinterpret_cast<double *>(smem_c2);             // [n_wm][LD]
+    const int n_wm = a.n_wm;
+    double *scl = Sl + (size_t)n_wm * LD + 2;                      // [n_wm]
+    double *Aop = scl + ((n_wm + 1) & ~1);                         // [MT][KS][64]
+    double *Rb = Aop + MT * KS * 64 + (threadIdx.x >> 6) * (64 * RBW);
+    const int cid = xcd_chunk((int)blockIdx.x, *a.n_schunks);
+    if (cid < 0) return;
+    const Chunk ck = a.schunks[cid];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
+    const double *__restrict__ Sg = a.Sb + (size_t)ck.dir * n_wm * KD;
+    const double *__restrict__ Gd = a.gram + (size_t)ck.dir * a.n_atoms * a.ldG;
+    for (int e = threadIdx.x; e < n_wm * KD; e += blockDim.x) { const int j = e / KD, d = e - j * KD; Sl[j * LD + d] = Sg[e]; }
+    for (int e = threadIdx.x; e < n_wm; e += blockDim.x) scl[e] = a.colscale[e];
+    for (int e = threadIdx.x; e < MT * KS * 64; e += blockDim.x) {
+        const int l = e & 63, ks = (e >> 6) % KS, mt = (e >> 6) / KS;
+        const int atom = 16 * mt + (l & 15), d = 4 * ks + (l >> 4);
+        Aop[e] = (atom < n_wm) ? Sg[(size_t)atom * KD + d] : 0.0;
+    }
+    __syncthreads();
+    const double kap = a.kappa0[ck.dir], lam1 = a.lam1, lam2 = a.lam2;
+    const int n_blocks = (ck.count + 63) >> 6;
+    for (int bl = wave; bl < n_blocks; bl += nw) {
+        const int k = 64 * bl + lane;
+        const bool valid = k < ck.count;
+        const int pos = ck.start + (valid ? k : ck.count - 1);
+        const double *Crow = a.Cb + (size_t)(ck.pad + bl) * kGemmRows * 64 + lane;
+        const unsigned long long *sd = a.seeds2 + (size_t)pos * 4;
+        unsigned long long P[3] = {sd[0], sd[1], sd[2]};
+        const unsigned long long flag = sd[3];
+        const int vox = a.perm[pos];
+        const int cnt = __builtin_popcountll(P[0]) + __builtin_popcountll(P[1]) + __builtin_popcountll(P[2]);
+        bool okv = valid && flag == 0ull && cnt <= MS;
+        SeedLane<MS> V;
+        V.clear();
+        {
+            // slots = set bits in ascending order
+            unsigned long long rem[3] = {okv ? P[0] : 0ull, okv ? P[1] : 0ull, okv ? P[2] : 0ull};
+            int n0 = 0;
+#pragma unroll
+            for (int s = 0; s < MS; s++) {
+                int wq = -1;
+#pragma unroll
+                for (int qq = 2; qq >= 0; qq--) wq = (rem[qq] != 0ull) ? qq : wq;
+                unsigned long long word = 0ull;
+#pragma unroll
+                for (int qq = 0; qq < 3; qq++) word = (wq == qq) ? rem[qq] : word;
+                const int t = (wq >= 0) ? wq * 64 + __builtin_ctzll(word) : 0;
+#pragma unroll
+                for (int qq = 0; qq < 3; qq++) rem[qq] = (wq == qq) ? (rem[qq] & (rem[qq] - 1ull)) : rem[qq];
+                if (wq >= 0 && t >= n_wm) okv = false;
+                V.idx[s] = (wq >= 0 && t < n_wm) ? t : 0;
+                n0 += (wq >= 0) ? 1 : 0;
+            }
+            V.np = okv ? n0 : 0;
+        }
+        unsigned long long cand[3];
+#pragma unroll
+        for (int w3 = 0; w3 < 3; w3++) {
+            const int c = n_wm - 64 * w3;
+            const unsigned long long all = c >= 64 ? ~0ull : (c > 0 ? ((1ull << c) - 1ull) : 0ull);
+            cand[w3] = all & ~P[w3];
+        }
+        double sc[MS];
+#pragma unroll
+        for (int s = 0; s < MS; s++) sc[s] = scl[V.idx[s]];
+#pragma unroll
+        for (int s = 0; s < MS; s++) {
+#pragma unroll
+            for (int t = 0; t <= s; t++)
+                V.T[stri<MS>(s, t)] = (s < V.np) ? sc[s] * sc[t] * Gd[(size_t)V.idx[s] * a.ldG + V.idx[t]] + ((s == t) ? lam2 : 0.0) : 0.0;
+            V.c[s] = (s < V.np) ? Crow[(size_t)V.idx[s] * 64] - lam1 : 0.0;
+        }
+        const double yy = Crow[(size_t)kGemmYY * 64];
+        const bool piv = V.factor();
+        double z[MS];
+        V.solve(z);
+        bool feas = true;
+        double rho2 = yy;
+#pragma unroll
+        for (int s = 0; s < MS; s++) {
+            V.x[s] = z[s];
+            if (s < V.np && !(z[s] > 0.0)) feas = false;
+            rho2 -= z[s] * (V.c[s] + ((s < V.np) ? lam1 : 0.0)) + lam1 * z[s] + lam2 * z[s] * z[s];
+        }
+        rho2 = rho2 > 0.0 ? rho2 : 0.0;
+        const bool good = okv && piv && feas && (yy <= 1.79769313486231570e308);
+        unsigned long long ex[3] = {0ull, 0ull, 0ull};
+        {
+            double rt[KD];
+#pragma unroll
+            for (int d = 0; d < KD; d++) rt[d] = Crow[(size_t)(kGemmU + d) * 64];
+#pragma unroll
+            for (int s = 0; s < MS; s++) {
+                const double *col = Sl + V.idx[s] * LD;
+#pragma unroll
+                for (int d = 0; d < KD; d++) rt[d] -= V.x[s] * col[d];
+            }
+            // compressed dual value s2_t'r~ - lambda1 > -kappa ||r||  <=>  s2_t'r~ > lambda1 - kappa ||r||
+            seed_flags_mfma<KS, MT>(Aop, Rb, lane, rt, good, good ? lam1 - 1.0625 * kap * sqrt(rho2) - 1e-12 : __builtin_huge_val(), cand, ex);
+        }
+        bool viol = false;
+        int n_ex = 0;
+        {
+            unsigned long long rem[3] = {good ? ex[0] : 0ull, good ? ex[1] : 0ull, good ? ex[2] : 0ull};
+            for (int it = 0; it < 192; it++) {
+                int wq = -1;
+#pragma unroll
+                for (int qq = 2; qq >= 0; qq--) wq = (rem[qq] != 0ull) ? qq : wq;
+                if (__ballot(wq >= 0) == 0ull) break;
+                unsigned long long word = 0ull;
+#pragma unroll
+                for (int qq = 0; qq < 3; qq++) word = (wq == qq) ? rem[qq] : word;
+                const int t = (wq >= 0) ? wq * 64 + __builtin_ctzll(word) : 0;
+#pragma unroll
+                for (int qq = 0; qq < 3; qq++) rem[qq] = (wq == qq) ? (rem[qq] & (rem[qq] - 1ull)) : rem[qq];
+                const bool on = wq >= 0 && t < n_wm;
+                double g = on ? Crow[(size_t)t * 64] - lam1 : -1.0;
+                const double *gt = Gd + (size_t)t * a.ldG;
+                const double st = on ? scl[t] : 0.0;
+#pragma unroll
+                for (int s = 0; s < MS; s++) { if (s < V.np && on) g -= st * sc[s] * gt[V.idx[s]] * V.x[s]; }
+                if (on && !(g < -1e-10)) viol = true;
+                n_ex += on ? 1 : 0;
+            }
+        }
+        const bool cert = good && !viol;
+        if (valid) a.done[pos] = cert ? 1 : 0;
+        {
+            const unsigned long long rm = __ballot(valid && !cert);
+            if (rm != 0ull) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&a.rcount[cid], __builtin_popcountll(rm));
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(rm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)rm, 0u));
+                if (valid && !cert) a.rlist[ck.start + base + rank] = pos;
+            }
+        }
+#ifdef AMX_STATS
+        if (a.stats) {
+            const int nc = __builtin_popcountll(__ballot(cert)), nv = __builtin_popcountll(__ballot(valid));
+            const int nbig = __builtin_popcountll(__ballot(valid && flag == 0ull && cnt > MS)), nfe = __builtin_popcountll(__ballot(valid && okv && piv && !feas)), nvi = __builtin_popcountll(__ballot(valid && good && viol));
+            if (lane == 0) { atomicAdd(&a.stats[0], nv); atomicAdd(&a.stats[1], nc); atomicAdd(&a.stats[2], nbig); atomicAdd(&a.stats[3], nfe); atomicAdd(&a.stats[4], nvi); }
+            int ne = n_ex;
+            for (int o = 32; o > 0; o >>= 1) ne += __shfl_xor(ne, o);
+            if (lane == 0) atomicAdd(&a.stats[5], ne);
+        }
+#endif
+        if (cert) {
+            unsigned long long *sp = a.supp + (size_t)vox * 4;
+            sp[0] = P[0]; sp[1] = P[1]; sp[2] = P[2]; sp[3] = 0ull;
+            if (a.xdbg) {
+                double *dst = a.xdbg + ((size_t)vox * 3 + 1) * a.n_atoms;
+                for (int j = 0; j < a.n_atoms; j++) dst[j] = 0.0;
+#pragma unroll
+                for (int s = 0; s < MS; s++) if (s < V.np) dst[V.idx[s]] = V.x[s];
+                dst[a.iso_atom] = a.xiso[(size_t)vox * 2];
+                if (a.dot_atom >= 0) dst[a.dot_atom] = a.xiso[(size_t)vox * 2 + 1];
             }
         }
     }
