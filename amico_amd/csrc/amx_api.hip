@@ -743,7 +743,8 @@ int amx_czb_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, cons
 // callback (amx_set_progress; models.pyx:28-43, 981 keep a per-thread counter for the same purpose) is called as
 // batches complete.
 // (largest batch; measured on 1 M NODDI voxels: 131072 -> 38.3 ms, 262144 -> 37.2 ms, 393216 -> 36.3 ms per call)
-static int64_t host_batch() { const char *e = getenv("AMX_HOST_BATCH"); const long v = e ? atol(e) : 0; return v >= 4096 ? (int64_t)v : 393216; }
+// (a multiple of 4: k_widen reads float4; at least the largest ramp batch, 131072: the ramp batches are written into slots of this size)
+static int64_t host_batch() { const char *e = getenv("AMX_HOST_BATCH"); const long v = e ? atol(e) : 0; return v >= 131072 ? ((int64_t)v + 3) & ~(int64_t)3 : 393216; }
 constexpr int64_t kPipelineFrom = 524288;      // smaller inputs go in one shot
 
 struct HostOut { void *dst; DevBuf *buf; size_t cols; bool on; };
@@ -788,6 +789,9 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
             progress(ctx, done_before[b], n_vox);                    // batches 0 .. c-3 are complete
         }
         if (two_streams) { s = (c & 1) ? ctx->hs2 : ctx->hs; if (c) ctx->swap_work(); }
+        // (the uploads below are blocking hipMemcpy calls from pageable memory on the null stream; the consumers run on the
+        //  non-blocking streams hs / hs2 without an event in between: this relies on hipMemcpy returning only after the data
+        //  has landed in device memory, which holds for pageable host-to-device copies on ROCm)
         double *yb = (double *)ctx->hy.p + (size_t)b * kHostBatch * nS;
         double *db = dirs ? (double *)ctx->hdirs.p + (size_t)b * kHostBatch * 3 : nullptr;
         if (kF32) {

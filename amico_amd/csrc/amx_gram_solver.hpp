@@ -152,7 +152,7 @@ struct GramSolver {
         unsigned long long P = n_atoms >= 64 ? ~0ull : ((1ull << n_atoms) - 1ull);
         int ninf = n_atoms + 1, backup = 0, status = kSolved;
         for (int it = 0;; ++it) {
-            if (it > 4 * n_atoms + 16) { status = kIterCap; break; }
+            if (it > 4 * n_atoms + 16) { status = kIterCap; x = (x > 0.0) ? x : 0.0; break; }      // (the last iterate may be infeasible: the maps get a feasible one; ST_ITCAP reports it)
             if (it == 0 && Lf != nullptr) {
                 // the full set: slot s = atom s, factor shared by the workgroup (read-only)
                 Ll = const_cast<double *>(Lf);

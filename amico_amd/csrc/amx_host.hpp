@@ -201,7 +201,7 @@ static inline int amx_refill_chunk(long long n_vox)
 {
     const char *e = getenv("AMX_REFILL_CHUNK");
     const int v = e ? atoi(e) : 0;
-    if (v >= 64) return v;
+    if (v >= AMX_CHUNK) return v;                       // (make_plan sizes the chunk list for kChunk: smaller chunks would overrun it)
     const long long c = n_vox / 1536;
     return (int)(c < 512 ? 512 : (c > 2048 ? 2048 : c));
 }

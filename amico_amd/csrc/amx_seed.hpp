@@ -351,6 +351,7 @@ struct SeedLane {
                 const double v00 = T[stri<MS>(i, j)], v10 = T[stri<MS>(i + 1, j)], v11 = T[stri<MS>(i + 1, j + 1)];
                 T[stri<MS>(i, j)] = (i < k) ? v00 : ((j < k) ? v10 : v11);
             }
+            __builtin_amdgcn_sched_barrier(0);               // row by row: a reordered schedule needs a second copy of the triangle
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -379,6 +380,7 @@ struct SeedLane {
                 l[i] = cc * l[i] - ss * t;
                 T[stri<MS>(i, j)] = t;
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // step from x towards z: returns the slot that reaches zero first (-1: z is feasible and becomes x).  The smallest ratio
@@ -404,8 +406,14 @@ struct SeedLane {
 };
 
 // STAGE 1: all atoms are candidates; STAGE 3: the atoms of the stage-2 support plus iso (dot)
+// (MS = 8: the compiler needs ~540 registers for this kernel; at two wavefronts per SIMD it spilled 290 of them and the kernel moved
+//  27 GB + 9 GB of scratch per 1 M voxels (rocprofv3 FETCH_SIZE / WRITE_SIZE) -- at one wavefront per SIMD, with the accumulation
+//  registers as overflow, none: 5.1 -> 3.4 ms)
+#ifndef AMX_SEED1_OCC
+#define AMX_SEED1_OCC 1
+#endif
 template <int STAGE, int MS>
-__global__ void __launch_bounds__(256, 2) k_nnls_seed(const SeedArgs a)
+__global__ void __launch_bounds__(256, (MS > 6 ? AMX_SEED1_OCC : 2)) k_nnls_seed(const SeedArgs a)
 {
     constexpr int KD = kSeedKD, LD = kSeedLd;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
@@ -1430,7 +1438,10 @@ __global__ void __launch_bounds__(1024) k_noddi_project2(const Seed2Args a)
     }
 }
 
-__global__ void __launch_bounds__(256, 2) k_lasso_seed(const Seed2Args a)
+#ifndef AMX_SEED2_OCC
+#define AMX_SEED2_OCC 2
+#endif
+__global__ void __launch_bounds__(256, AMX_SEED2_OCC) k_lasso_seed(const Seed2Args a)
 {
     constexpr int KD = kSeed2KD, KS = KD / 4, MT = 9, KDP = KD + 1, NT = KD * (KD + 1) / 2, LD = KD + 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_l[];
@@ -1563,24 +1574,25 @@ __global__ void __launch_bounds__(256, 2) k_lasso_seed(const Seed2Args a)
 #pragma unroll
             for (int w3 = 0; w3 < 3; w3++) Pb[lane * 3 + w3] = active ? P[w3] : ~0ull;
             double b[4][KS];
-            unsigned pq[4][6];                               // passive bits of voxel 16 nt + c16, shifted by this lane's row
 #pragma unroll
             for (int nt = 0; nt < 4; nt++) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) b[nt][ks] = Rb[(16 * nt + c16) * KDP + 4 * ks + q];
-#pragma unroll
-                for (int w3 = 0; w3 < 3; w3++) {
-                    const unsigned long long m = Pb[(16 * nt + c16) * 3 + w3] >> q;
-                    pq[nt][2 * w3] = (unsigned)m; pq[nt][2 * w3 + 1] = (unsigned)(m >> 32);
-                }
             }
             const double ninf = -inf;
             double bv[4] = {ninf, ninf, ninf, ninf};
-#pragma unroll
+            // (rolled: unrolled, the scheduler overlaps the nine tiles and spills; the mask word of a tile is picked by a
+            //  wave-uniform index, so nothing is indexed dynamically in registers)
+#pragma unroll 1
             for (int mt = 0; mt < MT; mt++) {
                 double av[KS];
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) av[ks] = Aop[(mt * KS + ks) * 64 + lane];
+                // passive bits of the voxels 16 nt + c16 for this tile's atoms (row-shifted), read back per tile instead of
+                // living in 24 registers for the whole scan
+                unsigned long long pw[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) pw[nt] = Pb[(16 * nt + c16) * 3 + ((16 * mt) >> 6)] >> q;
                 seed_v4d acc[4];
 #pragma unroll
                 for (int nt = 0; nt < 4; nt++) acc[nt] = (seed_v4d){0.0, 0.0, 0.0, 0.0};
@@ -1595,7 +1607,7 @@ __global__ void __launch_bounds__(256, 2) k_lasso_seed(const Seed2Args a)
                     for (int rr = 0; rr < 4; rr++) {
                         constexpr int dummy = 0; (void)dummy;
                         const int bit = 16 * mt + 4 * rr;        // position of this atom in the row-shifted mask
-                        const bool pas = (pq[nt][bit >> 5] >> (bit & 31)) & 1u;
+                        const bool pas = (pw[nt] >> (bit & 63)) & 1ull;
                         const double v = acc[nt][rr];
                         const unsigned lo = ((unsigned)__double2loint(v) & 0xffffff00u) | (unsigned)(mt * 4 + rr);
                         const int hi = pas ? (int)0xffe00000 : __double2hiint(v);     // passive: -9e307 (finite whatever the low word is; 0xfff... would be a NaN)

@@ -1102,7 +1102,11 @@ __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
                     const double nan = __builtin_nan("");
                     for (int m = 0; m < a.n_maps; m++) e[m] = nan;
                 } else {
-                    if (its > 4 * N + 16) atomicAdd(&a.c.status[ST_ITCAP], 1);
+                    if (its > 4 * N + 16) {          // (the last block-pivoting iterate may be infeasible: the maps get a feasible one)
+                        atomicAdd(&a.c.status[ST_ITCAP], 1);
+#pragma unroll
+                        for (int j = 0; j < N; j++) x[j] = (x[j] > 0.0) ? x[j] : 0.0;
+                    }
                     if (a.c.xdbg) {
 #pragma unroll
                         for (int j = 0; j < N; j++) if (j < n_atoms) a.c.xdbg[(size_t)vox * n_atoms + j] = x[j];

@@ -1,9 +1,9 @@
 """Model plug-ins with the surface of ``amico.models`` (amico/models.pyx:75-217, 655-991,
 995-1286, 1344-1627): same names, constructor defaults, ``set`` / ``get_params`` /
 ``set_solver`` and ``fit(evaluation) -> dict``; the per-voxel work is done by the HIP library
-through the C ABI (``amico_amd._capi``).  LUT generation / resampling (``generate``,
-``resample``) is out of scope of this path: dictionaries arrive as the reference's
-``KERNELS`` dict (``amico_amd.synthetic`` builds realistic ones for tests and benchmarks).
+through the C ABI (``amico_amd._capi``).  ``generate`` (response functions, ``amico_amd.synthesis``) and ``resample`` (the
+GPU GEMM of ``amico_amd.lut``) produce the reference's ``KERNELS`` dict; ``amico_amd.synthetic`` builds realistic
+dictionaries directly in signal space for tests and benchmarks.
 """
 from abc import ABC, abstractmethod
 import numpy as np

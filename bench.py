@@ -427,7 +427,7 @@ def pmc_valu(stage, n, kernel_ms):
     except (OSError, KeyError, ValueError):
         return None
     busy = insts * n * 4.0 / 1024.0 / (kernel_ms * 1e-3 * 2.4e9)
-    return {'bound': 'fp64 VALU issue', 'valu_wave_insts_per_voxel': insts, 'issue_cycles_filled': busy,
+    return {'bound': 'dependent latency (VALU issue slots mostly idle)', 'valu_wave_insts_per_voxel': insts, 'issue_cycles_filled': busy,
             'source': 'profiles/pmc_traffic.json (SQ_INSTS_VALU) x live kernel time'}
 
 
@@ -590,9 +590,9 @@ def main():
 
     if rank == 0:
         value = world * n * args.steps / elapsed
-        names = {1: 'k_noddi<1> (NNLS over all atoms: certificate of the seed)', 2: 'k_noddi<4> (LASSO certificate)', 3: 'k_noddi<3> (debias NNLS certificate + maps)',
-                 5: 'k_noddi_project + k_nnls_seed<1> (seed solver, stage 1)', 6: 'k_noddi_project2 + k_lasso_seed (seed solver, LASSO stage)',
-                 7: 'k_nnls_seed<3> (seed solver, stage 3)'}
+        names = {1: 'k_noddi<1> (stage 1: voxels the Gram certificate left over)', 2: 'k_noddi<4> (LASSO: left-over voxels)', 3: 'k_noddi<3> (stage 3: left-over voxels)',
+                 5: 'k_noddi_gemm + k_nnls_seed<1> + k_nnls_gcert<1> (A\'y on the matrix cores, seed solver, Gram certificate of stage 1)',
+                 6: 'k_noddi_gemm<lasso> + k_lasso_seed + k_lasso_gcert (LASSO stage)', 7: 'k_nnls_seed<3> + k_nnls_gcert<3> (stage 3)'}
         stage = max(names, key=lambda w: kms[w])
         dom_ms = float(kms[stage])
         achieved = BYTES_PER_VOXEL * n / (dom_ms * 1e-3) / 1e9
@@ -612,7 +612,7 @@ def main():
                                            if traffic is not None else None,
                          'kernel': names[stage], 'kernel_ms': dom_ms,
                          'stage_ms': [float(v) for v in kms[1:4]], 'seed_ms': [float(v) for v in kms[5:8]], 'all_kernels_ms': float(kms[0]),
-                         'note': 'path is fp64-VALU issue bound, not HBM bound (DESIGN.md section 5): see compute_side'},
+                         'note': 'the path is bound by dependent latencies inside the per-voxel active-set solvers, not by HBM (DESIGN.md section 5): see compute_side'},
             'compute_side': pmc_valu(stage, n, dom_ms),
             'solver_stats': stats,
         }
