@@ -691,8 +691,8 @@ __global__ void __launch_bounds__(256, (MS > 6 ? AMX_SEED1_OCC : 2)) k_nnls_seed
 // workgroup per chunk of the second plan (one orientation), a wavefront takes 16 voxels at a time:
 //   * A' operand: the orientation's dictionary once per workgroup in LDS in operand order, float32 for the atom tiles (the
 //     dictionary IS float32: exact), fp64 for the last tile (iso atom + the basis U);
-//   * B operand: the 16 signal rows land in LDS by one fully coalesced 16-byte-per-lane load per voxel (792 contiguous
-//     bytes), every lane then keeps its 25 operand values in registers for all 10 atom tiles;
+//   * B operand: loaded from HBM straight in operand order (lane (q, c16): samples q, 4 + q, ... of voxel c16), one group
+//     ahead; every lane keeps its 25 operand values in registers for all 10 atom tiles;
 //   * output in blocks of 64 voxels, atom-major: Cb[block][160][64] -- a D tile stores four 128-byte row pieces.
 // Rows 146 .. 157 of a block hold the projections y~ = U'y, row 158 holds ||y||^2, whatever the number of atoms.
 constexpr int kGemmRows = 160, kGemmU = 146, kGemmYY = 158;     // rows: atoms (n_atoms <= 146) | y~ at 146 .. 157 | ||y||^2 at 158
@@ -715,13 +715,14 @@ struct GemmArgs {
 };
 
 template <bool LASSO>
-__global__ void __launch_bounds__(256) k_noddi_gemm(const GemmArgs a)
+__global__ void __launch_bounds__(256, 2) k_noddi_gemm(const GemmArgs a)
 {
-    constexpr int MT = 10, KS = 25, YLD = 101;     // nS <= 100
+    constexpr int MT = 10, KS = 25;                // nS <= 100
+    constexpr int NB = 3;                          // atom tiles in flight together
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
     float *A32 = reinterpret_cast<float *>(smem_g);                       // [9][KS][64]
     double *A64 = reinterpret_cast<double *>(A32 + (MT - 1) * KS * 64);   // [KS][64]: atoms 144 .. 159
-    double *Yt = A64 + KS * 64 + (threadIdx.x >> 6) * (16 * YLD);         // per wavefront [16][YLD]
+    double *IsoT = A64 + KS * 64;                                         // [4 KS] iso atom by signal row (LASSO)
     const int cid = xcd_chunk((int)blockIdx.x, *a.n_schunks);
     if (cid < 0) return;
     const Chunk ck = a.schunks[cid];
@@ -745,74 +746,78 @@ __global__ void __launch_bounds__(256) k_noddi_gemm(const GemmArgs a)
         }
         A64[e] = v;
     }
+    if (LASSO) {
+        for (int e = threadIdx.x; e < 4 * KS; e += blockDim.x) IsoT[e] = e < nS ? (double)tile[e * ldA + a.iso_atom] : 0.0;
+    }
     __syncthreads();
     const int n_groups = (ck.count + 15) >> 4;
-    // the 16 signal rows of a group: one coalesced load per voxel (lane l takes bytes 16 l .. 16 l + 15 of the row); the loads
-    // of group g + nw are issued before the products of group g, so they are long done when their turn comes
-    double ya[16], yb[16];
-    double iso0 = 0.0, iso1 = 0.0;
-    bool rw0 = false, rw1 = false;
-    if (LASSO) {
-        if (2 * lane < nS) { iso0 = (double)tile[(2 * lane) * ldA + a.iso_atom]; rw0 = a.rowdwi[2 * lane] != 0; }
-        if (2 * lane + 1 < nS) { iso1 = (double)tile[(2 * lane + 1) * ldA + a.iso_atom]; rw1 = a.rowdwi[2 * lane + 1] != 0; }
-    }
-    auto issue = [&](int g) {
+    // the signals of a group of 16 voxels straight in operand order: lane (q, c16) reads samples q, 4 + q, 8 + q, ... of voxel c16
+    // (four lanes share every 32-byte sector; all 800 bytes of a row are used by the 25 loads).  The loads of group g + nw are
+    // issued before the products of group g, so they are long done when their turn comes; no LDS staging: the kernel keeps
+    // two workgroups per CU (two wavefronts per SIMD), one computes while the other waits for its stores.
+    unsigned rowmask = 0u;                 // bit ks: sample 4 ks + q is a stage-2 row (LASSO) / exists (NNLS)
 #pragma unroll
-        for (int v = 0; v < 16; v++) {
-            const int k = 16 * g + v;
-            const int vox = a.perm[ck.start + (k < ck.count ? k : ck.count - 1)];
-            const double *yv = a.y + (size_t)vox * nS;
-            ya[v] = (2 * lane < nS && k < ck.count) ? yv[2 * lane] : 0.0;
-            yb[v] = (2 * lane + 1 < nS && k < ck.count) ? yv[2 * lane + 1] : 0.0;
-            if (LASSO) {
-                const double xi = a.xiso[(size_t)vox * 2], xd = a.is_exvivo ? a.xiso[(size_t)vox * 2 + 1] : 0.0;
-                double t0 = ya[v] - xi * iso0 - xd, t1 = yb[v] - xi * iso1 - xd;
-                t0 = t0 < 0.0 ? 0.0 : t0; t1 = t1 < 0.0 ? 0.0 : t1;       // (NaN stays NaN: comparisons with NaN are false)
-                ya[v] = (rw0 && k < ck.count) ? t0 : 0.0; yb[v] = (rw1 && k < ck.count) ? t1 : 0.0;
-            }
-        }
+    for (int ks = 0; ks < KS; ks++) {
+        const int row = 4 * ks + q;
+        if (row < nS && (!LASSO || a.rowdwi[row] != 0)) rowmask |= 1u << ks;
+    }
+    double bn[KS], xi_n = 0.0, xd_n = 0.0;
+    auto issue = [&](int g) {
+        const int k = 16 * g + c16;
+        const int vox = a.perm[ck.start + (k < ck.count ? k : ck.count - 1)];
+        const double *yv = a.y + (size_t)vox * nS + q;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) bn[ks] = (4 * ks + q < nS) ? yv[4 * ks] : 0.0;
+        if (LASSO) { xi_n = a.xiso[(size_t)vox * 2]; xd_n = a.is_exvivo ? a.xiso[(size_t)vox * 2 + 1] : 0.0; }
     };
     if (wave < n_groups) issue(wave);
     for (int g = wave; g < n_groups; g += nw) {
-        if (2 * lane < YLD - 1) {
-#pragma unroll
-            for (int v = 0; v < 16; v++) { Yt[v * YLD + 2 * lane] = ya[v]; Yt[v * YLD + 2 * lane + 1] = yb[v]; }
-        }
+        const bool live = 16 * g + c16 < ck.count;
         double b[KS], yy = 0.0;
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) { b[ks] = Yt[c16 * YLD + 4 * ks + q]; yy += b[ks] * b[ks]; }
+        for (int ks = 0; ks < KS; ks++) {
+            double t = bn[ks];
+            if (LASSO) {
+                t = t - xi_n * IsoT[4 * ks + q] - xd_n;
+                t = t < 0.0 ? 0.0 : t;                                   // (NaN stays NaN: comparisons with NaN are false)
+            }
+            b[ks] = (live && ((rowmask >> ks) & 1u)) ? t : 0.0;
+            yy += b[ks] * b[ks];
+        }
         yy = rows_allreduce(yy);
         if (g + nw < n_groups) issue(g + nw);
         const int blk = ck.pad + (g >> 2), col = 16 * (g & 3) + c16;
         double *out = a.Cb + (size_t)blk * kGemmRows * 64 + col;
-        const bool live = 16 * g + c16 < ck.count;
-#pragma unroll 1
-        for (int mt = 0; mt < MT - 1; mt += 3) {
-            // the operands of three atom tiles first (75 LDS reads in flight together), then 75 products back to back: with one
-            // wavefront per SIMD nothing else hides an LDS round trip in front of every matrix instruction
-            float af[3][KS];
+#pragma unroll (LASSO ? 1 : 3)
+        for (int mt = 0; mt < MT - 1; mt += NB) {
+            // the operands of NB atom tiles first (all their LDS reads in flight together), then the products back to back
+            float af[NB][KS];
 #pragma unroll
-            for (int u = 0; u < 3; u++) {
+            for (int u = 0; u < NB; u++) {
+                if (mt + u < MT - 1) {
 #pragma unroll
-                for (int ks = 0; ks < KS; ks++) af[u][ks] = A32[((mt + u) * KS + ks) * 64 + lane];
+                    for (int ks = 0; ks < KS; ks++) af[u][ks] = A32[((mt + u) * KS + ks) * 64 + lane];
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
-            seed_v4d acc[3];
+            seed_v4d acc[NB];
 #pragma unroll
-            for (int u = 0; u < 3; u++) acc[u] = (seed_v4d){0.0, 0.0, 0.0, 0.0};
+            for (int u = 0; u < NB; u++) acc[u] = (seed_v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
 #pragma unroll
-                for (int u = 0; u < 3; u++)
-                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)af[u][ks], b[ks], acc[u], 0, 0, 0);
+                for (int u = 0; u < NB; u++)
+                    if (mt + u < MT - 1) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)af[u][ks], b[ks], acc[u], 0, 0, 0);
             }
             if (live) {
 #pragma unroll
-                for (int u = 0; u < 3; u++) {
+                for (int u = 0; u < NB; u++) {
+                    if (mt + u < MT - 1) {
 #pragma unroll
-                    for (int rr = 0; rr < 4; rr++) {
-                        const int row = 16 * (mt + u) + 4 * rr + q;
-                        out[(size_t)row * 64] = LASSO ? ((row < a.n_wm) ? a.colscale[row] * acc[u][rr] : 0.0) : acc[u][rr];
+                        for (int rr = 0; rr < 4; rr++) {
+                            const int row = 16 * (mt + u) + 4 * rr + q;
+                            out[(size_t)row * 64] = LASSO ? ((row < a.n_wm) ? a.colscale[row] * acc[u][rr] : 0.0) : acc[u][rr];
+                        }
                     }
                 }
             }
