@@ -28,6 +28,7 @@ int make_plan(amx_ctx *ctx, int64_t n, int ndirs, Plan &pl, bool seeds = false)
 {
     int rc;
     const int max_chunks = (int)(n / kChunk) + ndirs + 1;
+    pl.n = (size_t)n;
     if (seeds) {
         const int sc = ctx->opt_seed_chunk;
         pl.max_schunks = (int)(n / sc) + ndirs + 1;
@@ -37,7 +38,7 @@ int make_plan(amx_ctx *ctx, int64_t n, int ndirs, Plan &pl, bool seeds = false)
         if ((rc = ensure(ctx, ctx->cgemm, ((size_t)n / 64 + ndirs + 1) * 160 * 64 * sizeof(double)))) return rc;
         if ((rc = ensure(ctx, ctx->cgemm2, ((size_t)n / 64 + ndirs + 1) * 160 * 64 * sizeof(double)))) return rc;
         if ((rc = ensure(ctx, ctx->done, (size_t)n + 64))) return rc;
-        if ((rc = ensure(ctx, ctx->rlist, ((size_t)n + pl.max_schunks + 64) * sizeof(int)))) return rc;
+        if ((rc = ensure(ctx, ctx->rlist, 2 * amx_rlist_half(pl) * sizeof(int)))) return rc;
         if ((rc = ensure(ctx, ctx->ytil2, (size_t)n * amx::kSeedKD * sizeof(double)))) return rc;
         if ((rc = ensure(ctx, ctx->seeds2, (size_t)n * 4 * sizeof(unsigned long long)))) return rc;
         pl.schunks = (Chunk *)ctx->schunks.p;
@@ -157,6 +158,8 @@ int amx_ctx_create(int device, amx_ctx **out)
         ctx->opt_no_seed = e && *e && *e != '0';
         e = getenv("AMX_NO_GCERT");
         ctx->opt_no_gcert = e && *e && *e != '0';
+        e = getenv("AMX_NO_GCERT_WIDE");
+        ctx->opt_no_gcert_wide = e && *e && *e != '0';
         e = getenv("AMX_NO_SCREEN");
         ctx->opt_no_screen = e && *e && *e != '0';
         e = getenv("AMX_SEED_STAGES");
@@ -574,10 +577,12 @@ int amx_noddi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
         if (gcert2 && (rc = amx_launch_noddi_gemm(ctx, lut, a, pl, s, true))) return rc;        // c2 = A2'y2, y2~, ||y2||^2
         if ((rc = amx_launch_noddi_seed2(ctx, lut, a, pl, s, gcert2))) return rc;
         a.seeds2 = (const unsigned long long *)ctx->seeds2.p;
+        a.list_is_pos = 1;
         if (!ctx->opt_no_screen && lut->screen2_S) { a.scr2_S = lut->screen2_S; a.scr2_kappa = lut->screen2_kappa; a.scr2_ytil = (const double *)ctx->ytil2.p; a.scr2_Sg = lut->basis2_S; }
         if (gcert2) {
-            if ((rc = amx_launch_noddi_gcert2(ctx, lut, a, pl, s))) return rc;
-            a.rlist = (const int *)ctx->rlist.p; a.rcount = a.rlist + pl.n;
+            const bool wide = !ctx->opt_no_gcert_wide;
+            if ((rc = amx_launch_noddi_gcert2(ctx, lut, a, pl, s, wide))) return rc;
+            a.rlist = (const int *)ctx->rlist.p + (wide ? amx_rlist_half(pl) : 0); a.rcount = a.rlist + pl.n;
             a.c.chunks = pl.schunks; a.c.n_chunks = pl.n_chunks + 1;
         }
         rec(ctx, 13, s);

@@ -49,6 +49,7 @@ struct amx_ctx {
         for (int i = 0; i < 20; i++) { DevBuf t = *named[i]; *named[i] = alt[i]; alt[i] = t; }
     }
     // switches read ONCE, at amx_ctx_create (environment): diagnosis / A-B only
+    bool opt_no_gcert_wide = false; // AMX_NO_GCERT_WIDE=1: no second Gram-certificate pass for LASSO supports of 13 .. 16 atoms
     bool opt_no_gcert = false;     // AMX_NO_GCERT=1: every seed is certified by the wavefront-per-voxel kernels (true residual)
     bool opt_no_screen = false;    // AMX_NO_SCREEN=1: certify seeds with the full exact sweep of the dual vector
     bool opt_no_seed = false;      // AMX_NO_SEED=1: Lawson-Hanson from the empty set in the NNLS stages (the round-2 path)
@@ -175,7 +176,8 @@ int amx_launch_noddi_project(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiA
 int amx_launch_noddi_seed(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, int stage);
 int amx_launch_noddi_gcert(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, int stage);
 int amx_launch_noddi_gemm(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, bool lasso);
-int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s);
+int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, bool wide);
+static inline size_t amx_rlist_half(const Plan &pl) { return (size_t)pl.n + pl.max_schunks + 64; }   // ints per left-over list + counts
 int amx_launch_noddi_seed2(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, bool have_ytil2);
 int amx_launch_noddi_s1(amx_ctx *ctx, amx::NoddiArgs &a, const Plan &pl, hipStream_t s);
 int amx_launch_noddi_s2(amx_ctx *ctx, amx::NoddiArgs &a, const Plan &pl, hipStream_t s);

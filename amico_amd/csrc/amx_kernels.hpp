@@ -19,7 +19,7 @@ struct Chunk { int dir, start, count, pad; };
 constexpr int kSeedKD = 12;      // compressed dimensions of the support-seed problem (amx_seed.hpp)
 constexpr int kScreenLd = 192;   // atoms per row of the float32 screening table [KD][kScreenLd]
 
-enum StatusSlot { ST_ERRVOX = 0, ST_II1 = 1, ST_II2 = 2, ST_OVERFLOW = 3, ST_ITCAP = 4, ST_RERUN = 5, ST_GUARD = 6, ST_GUARDVOX = 7, ST_EXACT = 8, ST_GRAM = 11, ST_ITERS = 14, ST_SEED = 17, ST_WORDS = 64 };
+enum StatusSlot { ST_ERRVOX = 0, ST_II1 = 1, ST_II2 = 2, ST_OVERFLOW = 3, ST_ITCAP = 4, ST_RERUN = 5, ST_GUARD = 6, ST_GUARDVOX = 7, ST_EXACT = 8, ST_GRAM = 11, ST_ITERS = 14, ST_SEED = 17, ST_WORDS = 96 };
 
 // ------------------------------------------------------------------ shared pieces
 struct FitCommon {
@@ -130,6 +130,7 @@ struct NoddiArgs {
     double *xiso;                 // [n_vox][2]  x_iso, x_dot after stage 1
     unsigned long long *supp;     // [n_vox][4]  stage-2 support bit set
     double *est, *rmse, *nrmse, *mod;
+    int list_is_pos;              // stage 4: the overflow list holds bucket positions (seeded fit), not voxel numbers
 };
 
 // STAGE 1 = NNLS (models.pyx:911), 2 = LASSO by the QR solver, 4 = LASSO by the Gram solver
@@ -234,7 +235,7 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const AT *As, do
     if (st == kOverflow) {
         if (lane == 0) {
             const int k = atomicAdd(a.c.ovf_count, 1);
-            a.c.ovf_list[k] = vox;
+            a.c.ovf_list[k] = (STAGE == 4 && a.list_is_pos) ? pos : vox;      // (the re-run kernel wants the seed as well)
         }
     } else {
     if (st == kIterCap && lane == 0) atomicAdd(&a.c.status[ST_ITCAP], 1);
@@ -682,11 +683,15 @@ __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
     } else {
         const int cnt = *a.c.list_count;
         for (int it = blockIdx.x; it < cnt; it += gridDim.x) {
-            const int vox = a.c.list[it];
+            // LASSO stage with seeds: the list holds bucket positions, the seed (more atoms than the main pass can hold) is
+            // certified here instead of solving from scratch
+            const int e = a.c.list[it];
+            const int pos = (STAGE == 4 && a.list_is_pos) ? e : -1;
+            const int vox = (STAGE == 4 && a.list_is_pos) ? a.c.perm[e] : e;
             __syncthreads();
             stage_noddi_tile<AT>(As, tiles + (size_t)a.c.lutidx[vox] * a.c.tile_stride, words, words_pad - words);
             __syncthreads();
-            noddi_voxel<STAGE, NR, NQ, MAXP, AT>(a, As, rs, rl, wmask, vox, a.c.lutidx[vox], lane);
+            noddi_voxel<STAGE, NR, NQ, MAXP, AT>(a, As, rs, rl, wmask, vox, a.c.lutidx[vox], lane, pos);
         }
     }
 }

@@ -20,6 +20,14 @@ static int go_gram(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
     constexpr int NQ = 3, MP = 20, MB = 64;
     constexpr int NW = AMX_S2_NW;
     const size_t scr = (a.scr2_S && a.seeds2) ? (size_t)kSeedKD * kScreenLd * sizeof(float) : 0;   // screening table (amx_gram_solver.hpp)
+    if (a.rlist != nullptr && a.seeds2 != nullptr) {
+        // left-over lists of the Gram certificates: few voxels, mostly seeds of more than 16 atoms -- half the wavefronts with
+        // room for 32 atoms each, so that practically nothing is left for the (slow, one wavefront per voxel) re-run kernel
+        constexpr int MPL = 32, NWL = AMX_S2_NW / 2;
+        return launch_pair<NWL>(ctx, a, pl, s, k_noddi<4, NR, NQ, MPL, NWL, false>, k_noddi<4, NR, NQ, MB, 1, true>,
+                           [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MPL, true) + scr; }, fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, true),
+                           1, 4);
+    }
     return launch_pair<NW>(ctx, a, pl, s, k_noddi<4, NR, NQ, MP, NW, false>, k_noddi<4, NR, NQ, MB, 1, true>,
                        [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MP, true) + scr; }, fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, true),
                        1, 4);

@@ -110,7 +110,7 @@ int amx_launch_noddi_gemm(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, 
 }
 
 // Gram-space certificates of the LASSO seeds (k_lasso_gcert): support bits of the voxels it settles, left-over lists for k_noddi<4>
-int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, const Plan &pl, hipStream_t s)
+int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, const Plan &pl, hipStream_t s, bool wide)
 {
     Gcert2Args g;
     memset(&g, 0, sizeof g);
@@ -128,10 +128,23 @@ int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a
 #endif
     const size_t lds = ((size_t)lut->n_wm * kSeedLd + 2 + ((lut->n_wm + 1) & ~1) + (size_t)9 * (kSeedKD / 4) * 64 + (size_t)4 * 64 * 16) * sizeof(double);
     int rc;
-    if ((rc = set_lds(ctx, k_lasso_gcert, lds))) return rc;
-    hipLaunchKernelGGL(k_lasso_gcert, dim3(((pl.max_schunks + 7) / 8) * 8), dim3(256), lds, s, g);
+    if ((rc = set_lds(ctx, (k_lasso_gcert<kGcert2Max, false>), lds))) return rc;
+    hipLaunchKernelGGL((k_lasso_gcert<kGcert2Max, false>), dim3(((pl.max_schunks + 7) / 8) * 8), dim3(256), lds, s, g);
     AMX_TRACE(ctx, s, "Gram-space certificates of the LASSO seeds");
     HIPCHK(ctx, hipGetLastError());
+    if (wide) {
+        // second pass: supports of 13 .. 16 atoms from the left-over lists; its own left-overs in the second half of the buffer
+        g.rlist_in = g.rlist; g.rcount_in = g.rcount;
+        g.rlist = (int *)ctx->rlist.p + amx_rlist_half(pl); g.rcount = g.rlist + pl.n;
+        HIPCHK(ctx, hipMemsetAsync(g.rcount, 0, (size_t)pl.max_schunks * sizeof(int), s));
+#ifdef AMX_STATS
+        g.stats = a.c.status + ST_SEED + 48;
+#endif
+        if ((rc = set_lds(ctx, (k_lasso_gcert<kGcert2Wide, true>), lds))) return rc;
+        hipLaunchKernelGGL((k_lasso_gcert<kGcert2Wide, true>), dim3(((pl.max_schunks + 7) / 8) * 8), dim3(256), lds, s, g);
+        AMX_TRACE(ctx, s, "Gram-space certificates of the LASSO seeds, supports of 13 .. 16 atoms");
+        HIPCHK(ctx, hipGetLastError());
+    }
     return AMX_OK;
 }
 

@@ -1167,6 +1167,10 @@ __global__ void __launch_bounds__(256, 2) k_nnls_gcert(const GcertArgs a)
 // -- this is the arithmetic GramSolver::certify_seed performs too.  A lane holds the factor of up to 12 passive atoms
 // (87 % of the voxels; the rest, and everything refused, goes to k_noddi<4> through the left-over lists).
 constexpr int kGcert2Max = 12;
+#ifndef AMX_GCERT2_WIDE
+#define AMX_GCERT2_WIDE 16
+#endif
+constexpr int kGcert2Wide = AMX_GCERT2_WIDE;   // second pass (k_lasso_gcert<.., true>)
 struct Gcert2Args {
     const int *perm;
     const Chunk *schunks;
@@ -1183,13 +1187,18 @@ struct Gcert2Args {
     const double *xiso;                // [n_vox][2] (AMX_F_DEBUG_X only)
     unsigned char *done;
     int *rlist, *rcount;
+    const int *rlist_in, *rcount_in;   // WIDE pass: the left-over lists of the first pass
     double *xdbg;
     int *stats;
 };
 
-__global__ void __launch_bounds__(256, 2) k_lasso_gcert(const Gcert2Args a)
+// WIDE = false: every voxel of the chunk, supports of up to 12 atoms, two wavefronts per SIMD.  WIDE = true: second pass over the
+// left-over lists of the first for the supports of 13 .. 16 atoms (another 13 % of the voxels at the default lambdas), one
+// wavefront per SIMD -- the 16 x 16 triangle lives in the whole register file; what it cannot settle goes on to k_noddi<4>.
+template <int MS, bool WIDE>
+__global__ void __launch_bounds__(256, WIDE ? 1 : 2) k_lasso_gcert(const Gcert2Args a)
 {
-    constexpr int KD = kSeedKD, KS = KD / 4, MT = 9, MS = kGcert2Max, LD = kSeedLd, RBW = 16;
+    constexpr int KD = kSeedKD, KS = KD / 4, MT = 9, LD = kSeedLd, RBW = 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_c2[];
     double *Sl = reinterpret_cast<double *>(smem_c2);             // [n_wm][LD]
     const int n_wm = a.n_wm;
@@ -1199,6 +1208,8 @@ __global__ void __launch_bounds__(256, 2) k_lasso_gcert(const Gcert2Args a)
     const int cid = xcd_chunk((int)blockIdx.x, *a.n_schunks);
     if (cid < 0) return;
     const Chunk ck = a.schunks[cid];
+    const int n_items = WIDE ? a.rcount_in[cid] : ck.count;
+    if (WIDE && n_items == 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
     const double *__restrict__ Sg = a.Sb + (size_t)ck.dir * n_wm * KD;
     const double *__restrict__ Gd = a.gram + (size_t)ck.dir * a.n_atoms * a.ldG;
@@ -1211,18 +1222,19 @@ __global__ void __launch_bounds__(256, 2) k_lasso_gcert(const Gcert2Args a)
     }
     __syncthreads();
     const double kap = a.kappa0[ck.dir], lam1 = a.lam1, lam2 = a.lam2;
-    const int n_blocks = (ck.count + 63) >> 6;
+    const int n_blocks = (n_items + 63) >> 6;
     for (int bl = wave; bl < n_blocks; bl += nw) {
         const int k = 64 * bl + lane;
-        const bool valid = k < ck.count;
-        const int pos = ck.start + (valid ? k : ck.count - 1);
-        const double *Crow = a.Cb + (size_t)(ck.pad + bl) * kGemmRows * 64 + lane;
+        const bool valid = k < n_items;
+        const int pos = WIDE ? a.rlist_in[ck.start + (valid ? k : n_items - 1)] : ck.start + (valid ? k : n_items - 1);
+        const int kk = pos - ck.start;                    // the voxel's place in the chunk: GEMM block and column
+        const double *Crow = a.Cb + (size_t)(ck.pad + (kk >> 6)) * kGemmRows * 64 + (kk & 63);
         const unsigned long long *sd = a.seeds2 + (size_t)pos * 4;
         unsigned long long P[3] = {sd[0], sd[1], sd[2]};
         const unsigned long long flag = sd[3];
         const int vox = a.perm[pos];
         const int cnt = __builtin_popcountll(P[0]) + __builtin_popcountll(P[1]) + __builtin_popcountll(P[2]);
-        bool okv = valid && flag == 0ull && cnt <= MS;
+        bool okv = valid && flag == 0ull && cnt <= MS && (!WIDE || cnt > kGcert2Max);
         SeedLane<MS> V;
         V.clear();
         {
