@@ -231,7 +231,17 @@ class Evaluation:
         self.mean_b0s = d_mb0.cpu().numpy() if self._prep.do_normalize else None
         self.set_config('dirs_precomputing_time', time.time() - t)
         t = time.time()
-        results = self.model.fit(self)                                # reads self._dev in place
+        # models.pyx:28-43, 981 feed a ProgressBar while the chunks are fitted; here the whole fit is enqueued at once and
+        # the library reports from the stream (amx_set_progress: after each NODDI stage / at the end of the other models)
+        cb = self.get_config('progress_callback')
+        if callable(cb):
+            ctx.set_progress(cb)
+        try:
+            results = self.model.fit(self)                            # reads self._dev in place
+        finally:
+            if callable(cb):
+                ctx.sync()
+                ctx.set_progress(None)
         self.set_config('fit_time', time.time() - t)
         out = self._dev.get('out', {})
 

@@ -125,6 +125,22 @@ void progress(amx_ctx *ctx, int64_t done, int64_t total)
     if (ctx->progress) ctx->progress(done, total, ctx->progress_user);
 }
 
+// Device-pointer entry points: the fit is only ENQUEUED when the call returns, so the callback is a host function on the
+// stream (hipLaunchHostFunc) -- it runs on a runtime thread once everything enqueued before it has finished.
+struct ProgressTick { amx_ctx *ctx; int64_t done, total; };
+void progress_host_fn(void *p)
+{
+    ProgressTick *t = static_cast<ProgressTick *>(p);
+    if (t->ctx->progress) t->ctx->progress(t->done, t->total, t->ctx->progress_user);
+    delete t;
+}
+void progress_tick(amx_ctx *ctx, hipStream_t s, int64_t done, int64_t total)
+{
+    if (!ctx->progress || ctx->in_host_fit) return;
+    ProgressTick *t = new ProgressTick{ctx, done, total};
+    if (hipLaunchHostFunc(s, progress_host_fn, t) != hipSuccess) { (void)hipGetLastError(); delete t; }
+}
+
 }  // namespace
 
 // =================================================================== C ABI
@@ -158,6 +174,17 @@ int amx_ctx_create(int device, amx_ctx **out)
         ctx->opt_no_seed = e && *e && *e != '0';
         e = getenv("AMX_NO_GCERT");
         ctx->opt_no_gcert = e && *e && *e != '0';
+        auto on = [](const char *name) { const char *v = getenv(name); return v && *v && *v != '0'; };
+        ctx->opt_no_gram = on("AMX_NO_GRAM"); ctx->opt_lasso_qr = on("AMX_LASSO_QR"); ctx->opt_cold_start = on("AMX_COLD_START");
+        ctx->opt_host_one_shot = on("AMX_HOST_ONE_SHOT"); ctx->opt_host_one_stream = on("AMX_HOST_ONE_STREAM");
+        ctx->opt_tile_f32 = on("AMX_TILE_F32"); ctx->opt_fw_proj_valu = on("AMX_FW_PROJ_VALU"); ctx->opt_sandi_atom_space = on("AMX_SANDI_ATOM_SPACE");
+        ctx->opt_prep_tile = on("AMX_PREP_TILE"); ctx->opt_lut_regs = on("AMX_LUT_REGS"); ctx->opt_no_refill = on("AMX_NO_REFILL");
+        ctx->opt_wave_per_voxel = on("AMX_WAVE_PER_VOXEL");
+        e = getenv("AMX_REFILL_CHUNK");
+        if (e) ctx->opt_refill_chunk = atoi(e);
+        e = getenv("AMX_HOST_BATCH");
+        // (a multiple of 4: k_widen reads float4; at least the largest ramp batch, 131072: the ramp batches are written into slots of this size)
+        if (e && atol(e) >= 131072) ctx->opt_host_batch = ((long long)atol(e) + 3) & ~3LL;
         e = getenv("AMX_NO_GCERT_WIDE");
         ctx->opt_no_gcert_wide = e && *e && *e != '0';
         e = getenv("AMX_NO_SCREEN");
@@ -264,8 +291,7 @@ int amx_lut_upload_noddi(amx_ctx *ctx, const float *wm, const float *iso, const 
     // Gram matrices of every orientation (all rows for the NNLS stages, stage-2 rows for the LASSO):
     // they let the solver update the dual vector without sweeping the tile (amx_solver.hpp)
     {
-        const char *env = getenv("AMX_NO_GRAM");
-        if (!(env && *env && *env != '0')) {
+        if (!ctx->opt_no_gram) {
             lut->ldG = 192;
             const size_t gbytes = (size_t)ndirs * n_atoms * lut->ldG * sizeof(double);
             const size_t lds = (size_t)nS * lut->ldA * sizeof(float);
@@ -569,9 +595,10 @@ int amx_noddi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
         rec(ctx, 11, s);
     }
     if ((rc = amx_launch_noddi_s1(ctx, a, pl, s))) return rc;
+    progress_tick(ctx, s, n_vox / 3, n_vox);                       // (three stages: a third of the work each, roughly)
     a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks; a.rlist = nullptr; a.rcount = nullptr; a.done = nullptr;
     // the LASSO seeds need x_iso: Gram-space solver only (lambda2 >= 1e-5), with the default dictionary shape
-    if (seeds && (ctx->opt_seed_stages & 4) && lut->basis2_S != nullptr && lambda2 >= 1e-5 && lut->nS <= 128 && !getenv("AMX_LASSO_QR")) {
+    if (seeds && (ctx->opt_seed_stages & 4) && lut->basis2_S != nullptr && lambda2 >= 1e-5 && lut->nS <= 128 && !ctx->opt_lasso_qr) {
         const bool gcert2 = !ctx->opt_no_gcert && lut->nS <= 100 && lut->n_atoms <= 146 && lut->n_wm <= 144 && lut->screen2_kappa0 != nullptr;
         rec(ctx, 12, s);
         if (gcert2 && (rc = amx_launch_noddi_gemm(ctx, lut, a, pl, s, true))) return rc;        // c2 = A2'y2, y2~, ||y2||^2
@@ -588,6 +615,7 @@ int amx_noddi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
         rec(ctx, 13, s);
     }
     if (!(rc = amx_launch_noddi_s2(ctx, a, pl, s))) {
+        progress_tick(ctx, s, 2 * (n_vox / 3), n_vox);
         a.seeds = nullptr; a.done = nullptr; a.rlist = nullptr; a.rcount = nullptr;
         a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks;
         if (seeds && (ctx->opt_seed_stages & 2)) {
@@ -606,6 +634,7 @@ int amx_noddi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
     }
     hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, s, (const int *)ctx->misc.p, ctx->status_d);
     rec(ctx, 1, s);
+    if (!rc) progress_tick(ctx, s, n_vox, n_vox);
     return rc;
 }
 
@@ -629,15 +658,15 @@ int amx_freewater_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y
     Plan pl; int rc;
     if ((rc = make_plan(ctx, n_vox, lut->ndirs, pl))) return rc;
     rec(ctx, 0, s);
-    const bool refill = amx_use_lane_solver(lut->n_atoms, lambda2) && amx_fw_use_refill(lut->n_atoms, lut->nS, flags, lambda2);
-    if ((rc = enqueue_bucketing(ctx, lut, d_dirs, n_vox, pl, s, refill ? amx_refill_chunk(n_vox) : kChunk))) return rc;
+    const bool refill = amx_use_lane_solver(ctx, lut->n_atoms, lambda2) && amx_fw_use_refill(ctx, lut->n_atoms, lut->nS, flags, lambda2);
+    if ((rc = enqueue_bucketing(ctx, lut, d_dirs, n_vox, pl, s, refill ? amx_refill_chunk(ctx, n_vox) : kChunk))) return rc;
     FwArgs a;
     memset(&a, 0, sizeof a);
     a.c.tiles = lut->tiles; a.c.y = d_y; a.c.perm = pl.perm; a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks;
     a.c.lutidx = pl.lutidx; a.c.status = ctx->status_d; a.c.nS = lut->nS; a.c.ldA = lut->ldA;
     a.c.n_atoms = lut->n_atoms; a.c.tile_stride = lut->tile_stride; a.c.lam1 = lambda1; a.c.lam2 = lambda2; a.c.flags = flags;
     a.n_perp = lut->n_perp; a.n_iso = lut->n_iso; a.is_mouse = is_mouse; a.n_maps = is_mouse ? 4 : 2;
-    { const char *e = getenv("AMX_COLD_START"); if (e && *e && *e != '0') a.c.flags |= 0x80000000u; }
+    if (ctx->opt_cold_start) a.c.flags |= 0x80000000u;
     if (flags & AMX_F_DEBUG_X) {
         if (!ctx->dbg_x) return bad(ctx, "amx_freewater_fit: AMX_F_DEBUG_X without a buffer (amx_set_debug_x)");
         a.c.xdbg = ctx->dbg_x + (size_t)ctx->vox_base * lut->n_atoms;
@@ -649,6 +678,7 @@ int amx_freewater_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y
     rc = amx_launch_fw(ctx, a, pl, s);
     hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, s, (const int *)ctx->misc.p, ctx->status_d);
     rec(ctx, 1, s);
+    if (!rc) progress_tick(ctx, s, n_vox, n_vox);
     return rc;
 }
 
@@ -680,7 +710,7 @@ int amx_sandi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, in
     a.c.n_atoms = lut->n_atoms; a.c.tile_stride = lut->tile_stride; a.c.lam1 = lambda1; a.c.lam2 = lambda2; a.c.flags = flags;
     a.norms = lut->norms; a.Rs = lut->Rs; a.d_in = lut->d_in; a.d_isos = lut->d_isos;
     a.n_rs = lut->n_rs; a.n_in = lut->n_in; a.n_iso = lut->n_isos;
-    { const char *e = getenv("AMX_COLD_START"); if (e && *e && *e != '0') a.c.flags |= 0x80000000u; }
+    if (ctx->opt_cold_start) a.c.flags |= 0x80000000u;
     if (flags & AMX_F_DEBUG_X) {
         if (!ctx->dbg_x) return bad(ctx, "amx_sandi_fit: AMX_F_DEBUG_X without a buffer (amx_set_debug_x)");
         a.c.xdbg = ctx->dbg_x + (size_t)ctx->vox_base * lut->n_atoms;
@@ -690,6 +720,7 @@ int amx_sandi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, in
     rc = amx_launch_sandi(ctx, a, pl, s);
     hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, s, (const int *)ctx->misc.p, ctx->status_d);
     rec(ctx, 1, s);
+    if (!rc) progress_tick(ctx, s, n_vox, n_vox);
     return rc;
 }
 
@@ -719,7 +750,7 @@ int amx_czb_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, cons
     a.c.lutidx = pl.lutidx; a.c.status = ctx->status_d; a.c.nS = lut->nS; a.c.ldA = lut->ldA;
     a.c.n_atoms = lut->n_atoms; a.c.tile_stride = lut->tile_stride; a.c.lam1 = lambda1; a.c.lam2 = lambda2; a.c.flags = flags;
     a.n_rs = lut->n_rs; a.n_perp = lut->n_perp; a.Rs = lut->Rs; a.gram = lut->gram; a.ldG = lut->ldG;
-    { const char *e = getenv("AMX_COLD_START"); if (e && *e && *e != '0') a.c.flags |= 0x80000000u; }
+    if (ctx->opt_cold_start) a.c.flags |= 0x80000000u;
     if (flags & AMX_F_DEBUG_X) {
         if (!ctx->dbg_x) return bad(ctx, "amx_czb_fit: AMX_F_DEBUG_X without a buffer (amx_set_debug_x)");
         a.c.xdbg = ctx->dbg_x + (size_t)ctx->vox_base * lut->n_atoms;
@@ -729,6 +760,7 @@ int amx_czb_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, cons
     rc = amx_launch_czb(ctx, a, pl, s);
     hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, s, (const int *)ctx->misc.p, ctx->status_d);
     rec(ctx, 1, s);
+    if (!rc) progress_tick(ctx, s, n_vox, n_vox);
     return rc;
 }
 
@@ -748,8 +780,6 @@ int amx_czb_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, cons
 // callback (amx_set_progress; models.pyx:28-43, 981 keep a per-thread counter for the same purpose) is called as
 // batches complete.
 // (largest batch; measured on 1 M NODDI voxels: 131072 -> 38.3 ms, 262144 -> 37.2 ms, 393216 -> 36.3 ms per call)
-// (a multiple of 4: k_widen reads float4; at least the largest ramp batch, 131072: the ramp batches are written into slots of this size)
-static int64_t host_batch() { const char *e = getenv("AMX_HOST_BATCH"); const long v = e ? atol(e) : 0; return v >= 131072 ? ((int64_t)v + 3) & ~(int64_t)3 : 393216; }
 constexpr int64_t kPipelineFrom = 524288;      // smaller inputs go in one shot
 
 struct HostOut { void *dst; DevBuf *buf; size_t cols; bool on; };
@@ -759,9 +789,9 @@ template <typename T, typename Enqueue>
 static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox, int nS, HostOut (&outs)[4], Enqueue enqueue)
 {
     int rc;
-    const int64_t kHostBatch = host_batch();
+    const int64_t kHostBatch = ctx->opt_host_batch;
     constexpr bool kF32 = sizeof(T) == 4;
-    const bool pipelined = n_vox >= kPipelineFrom && !getenv("AMX_HOST_ONE_SHOT");
+    const bool pipelined = n_vox >= kPipelineFrom && !ctx->opt_host_one_shot;
     constexpr int kBufs = 3;                      // staging buffers: batch c uploads while c-1 and c-2 are being solved
     const int64_t cap = pipelined ? kBufs * kHostBatch : n_vox;
     if ((rc = ensure(ctx, ctx->hy, (size_t)cap * nS * sizeof(double)))) return rc;
@@ -777,9 +807,11 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
     HIPCHK(ctx, hipStreamSynchronize(nullptr));                      // earlier default-stream work on these buffers
     const bool was_profiling = ctx->profiling;
     if (pipelined) ctx->profiling = false;
+    ctx->in_host_fit = true;
+    struct HostFitScope { amx_ctx *c; ~HostFitScope() { c->in_host_fit = false; } } host_scope{ctx};
     // Batch c runs on stream c & 1 with workspace set c & 1: the kernels of consecutive batches overlap, so the idle tail
     // of every launch (and the one-wavefront re-run kernels) is filled by the other batch instead of adding up six times.
-    const bool two_streams = pipelined && !getenv("AMX_HOST_ONE_STREAM");
+    const bool two_streams = pipelined && !ctx->opt_host_one_stream;
     hipStream_t s = pipelined ? ctx->hs : nullptr;
     int64_t off = 0, done_before[kBufs] = {0, 0, 0};         // voxels complete once the event of that buffer has fired
     for (int c = 0; off < n_vox; c++) {

@@ -13,6 +13,6 @@ static int go(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s)
 
 int amx_launch_fw(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s)
 {
-    if (amx_use_lane_solver(a.c.n_atoms, a.c.lam2)) return amx_launch_fw_small(ctx, a, pl, s);
+    if (amx_use_lane_solver(ctx, a.c.n_atoms, a.c.lam2)) return amx_launch_fw_small(ctx, a, pl, s);
     return a.c.nS <= 128 ? go<2>(ctx, a, pl, s) : go<4>(ctx, a, pl, s);
 }

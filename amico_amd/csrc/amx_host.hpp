@@ -30,6 +30,7 @@ struct amx_ctx {
     int *status_d = nullptr;       // ST_WORDS ints
     int *status_h = nullptr;       // pinned mirror (+16 words: copy of the misc counters)
     bool profiling = false;
+    bool in_host_fit = false;      // the host-buffer entry points report progress per batch themselves
     hipEvent_t ev[kEv];
     bool ev_valid[kEv];
     int64_t stats[4] = {0, 0, 0, 0};
@@ -49,6 +50,21 @@ struct amx_ctx {
         for (int i = 0; i < 20; i++) { DevBuf t = *named[i]; *named[i] = alt[i]; alt[i] = t; }
     }
     // switches read ONCE, at amx_ctx_create (environment): diagnosis / A-B only
+    // switches below: environment variables read ONCE, at amx_ctx_create (diagnosis / A-B tools; the defaults are the product path)
+    bool opt_no_gram = false;          // AMX_NO_GRAM=1: no Gram matrices at upload (the solvers sweep the tile instead)
+    bool opt_lasso_qr = false;         // AMX_LASSO_QR=1: NODDI stage 2 by the A-space QR solver whatever lambda2
+    bool opt_cold_start = false;       // AMX_COLD_START=1: FreeWater / SANDI / CZB start from the empty passive set
+    bool opt_host_one_shot = false;    // AMX_HOST_ONE_SHOT=1: host-buffer entry points upload everything, then fit
+    bool opt_host_one_stream = false;  // AMX_HOST_ONE_STREAM=1: pipelined host path on one stream
+    long long opt_host_batch = 393216; // AMX_HOST_BATCH: voxels per pipelined batch (>= 131072, multiple of 4)
+    bool opt_tile_f32 = false;         // AMX_TILE_F32=1: NNLS stages keep the float32 tile in LDS
+    bool opt_fw_proj_valu = false;     // AMX_FW_PROJ_VALU=1: FreeWater projection without the matrix cores
+    bool opt_sandi_atom_space = false; // AMX_SANDI_ATOM_SPACE=1: SANDI 6 x 15 by the atom-space lane kernel
+    bool opt_prep_tile = false;        // AMX_PREP_TILE=1: signal preparation always through the transposition tile
+    bool opt_lut_regs = false;         // AMX_LUT_REGS=1: LUT resampling with register operands
+    bool opt_no_refill = false;        // AMX_NO_REFILL=1: FreeWater by k_freewater_lane (one solve per lane and pass)
+    bool opt_wave_per_voxel = false;   // AMX_WAVE_PER_VOXEL=1: small models by the wavefront-per-voxel kernels
+    int opt_refill_chunk = 0;          // AMX_REFILL_CHUNK: voxels per workgroup of k_freewater_refill (0 = by problem size)
     bool opt_no_gcert_wide = false; // AMX_NO_GCERT_WIDE=1: no second Gram-certificate pass for LASSO supports of 13 .. 16 atoms
     bool opt_no_gcert = false;     // AMX_NO_GCERT=1: every seed is certified by the wavefront-per-voxel kernels (true residual)
     bool opt_no_screen = false;    // AMX_NO_SCREEN=1: certify seeds with the full exact sweep of the dual vector
@@ -199,27 +215,24 @@ __host__ __device__ static inline bool amx_warm_start(double lam2, unsigned flag
 // voxels of one orientation per workgroup of the refill kernel: large enough to keep the lanes fed (the buffer needs a
 // pool to draw from), small enough for ~3 rounds of workgroups over the chip (measured on 2 M voxels: 512 -> 1.83 ms,
 // 1024 -> 1.79, 2048 -> 1.93, 4096 -> 2.54)
-static inline int amx_refill_chunk(long long n_vox)
+static inline int amx_refill_chunk(const amx_ctx *ctx, long long n_vox)
 {
-    const char *e = getenv("AMX_REFILL_CHUNK");
-    const int v = e ? atoi(e) : 0;
+    const int v = ctx->opt_refill_chunk;
     if (v >= AMX_CHUNK) return v;                       // (make_plan sizes the chunk list for kChunk: smaller chunks would overrun it)
     const long long c = n_vox / 1536;
     return (int)(c < 512 ? 512 : (c > 2048 ? 2048 : c));
 }
-static inline bool amx_cold_start_env() { const char *e = getenv("AMX_COLD_START"); return e && *e && *e != '0'; }
 // (the projection + block-pivoting kernels assume the warm start: with lambda2 < 1e-5, or AMX_COLD_START=1, the fit goes to the
 //  Lawson-Hanson lane kernels -- single exchanges from the empty set, which is all block pivoting could do there, ran into
 //  the iteration cap on 15 % of the voxels at lambda2 = 1e-6)
-static inline bool amx_fw_use_refill(int n_atoms, int nS, unsigned flags, double lam2)
+static inline bool amx_fw_use_refill(const amx_ctx *ctx, int n_atoms, int nS, unsigned flags, double lam2)
 {
-    if (!amx_warm_start(lam2, flags) || amx_cold_start_env()) return false;
-    const char *e = getenv("AMX_NO_REFILL"), *w = getenv("AMX_WAVE_PER_VOXEL");
-    if ((e && *e && *e != '0') || (w && *w && *w != '0')) return false;
+    if (!amx_warm_start(lam2, flags) || ctx->opt_cold_start) return false;
+    if (ctx->opt_no_refill || ctx->opt_wave_per_voxel) return false;
     return n_atoms <= 12 && (flags & (AMX_F_RMSE | AMX_F_NRMSE | AMX_F_CORRECTED)) == 0 &&
            ((size_t)nS * 12 + 144 + 4 * (16 * 65 + 12 * 64 + 32)) * sizeof(double) + 16 <= 80 * 1024;
 }
 // lane-per-voxel solvers work on H = A'A + lambda2 I (Gram space): they need the ridge to bound cond(H); with
 // lambda2 (nearly) 0 the problem goes to the QR solver in A-space (wavefront per voxel), like the reference's lasso,
 // which accepts any lambda2 >= 0
-static inline bool amx_use_lane_solver(int n_atoms, double lam2) { const char *e = getenv("AMX_WAVE_PER_VOXEL"); return n_atoms <= 16 && lam2 >= 1e-9 && !(e && *e && *e != '0'); }
+static inline bool amx_use_lane_solver(const amx_ctx *ctx, int n_atoms, double lam2) { return n_atoms <= 16 && lam2 >= 1e-9 && !ctx->opt_wave_per_voxel; }

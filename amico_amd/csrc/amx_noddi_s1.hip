@@ -17,8 +17,7 @@ static int go(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
     // fp64 tile in LDS when it fits next to the per-wavefront blocks (99 x 145: 115 KB + 16 x 2.3 KB of 160 KB): the
     // fp32 -> fp64 conversions of the tile reads are then paid once per chunk.  AMX_TILE_F32=1: the fp32 tile.
     {
-        const char *e = getenv("AMX_TILE_F32");
-        if (fit_lds_bytes<double>(a.c.nS, a.c.ldA, NR, NQ, NW, MP, false, false) + scr <= kLdsPerCU && !(e && *e && *e != '0'))
+        if (fit_lds_bytes<double>(a.c.nS, a.c.ldA, NR, NQ, NW, MP, false, false) + scr <= kLdsPerCU && !ctx->opt_tile_f32)
             return launch_pair<NW>(ctx, a, pl, s, k_noddi<1, NR, NQ, MP, NW, false, double>, k_noddi<1, NR, NQ, MB, 1, true>,
                                    [&](int nw) { return fit_lds_bytes<double>(a.c.nS, a.c.ldA, NR, NQ, nw, MP, false, false) + scr; },
                                    fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, false), 0, 2);

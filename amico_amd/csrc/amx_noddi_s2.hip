@@ -35,8 +35,7 @@ static int go_gram(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
 
 int amx_launch_noddi_s2(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
 {
-    const char *e = getenv("AMX_LASSO_QR");
-    const bool gram = a.gram_dwi != nullptr && a.c.lam2 >= 1e-5 && !(e && *e && *e != '0');
+    const bool gram = a.gram_dwi != nullptr && a.c.lam2 >= 1e-5 && !ctx->opt_lasso_qr;
     if (gram) return a.c.nS <= 128 ? go_gram<2>(ctx, a, pl, s) : go_gram<4>(ctx, a, pl, s);
     return a.c.nS <= 128 ? go_qr<2>(ctx, a, pl, s) : go_qr<4>(ctx, a, pl, s);
 }

@@ -13,6 +13,6 @@ static int go(amx_ctx *ctx, SandiArgs &a, const Plan &pl, hipStream_t s)
 
 int amx_launch_sandi(amx_ctx *ctx, SandiArgs &a, const Plan &pl, hipStream_t s)
 {
-    if (amx_use_lane_solver(a.c.n_atoms, a.c.lam2)) return amx_launch_sandi_small(ctx, a, pl, s);
+    if (amx_use_lane_solver(ctx, a.c.n_atoms, a.c.lam2)) return amx_launch_sandi_small(ctx, a, pl, s);
     return a.c.nS <= 64 ? go<1>(ctx, a, pl, s) : go<2>(ctx, a, pl, s);
 }

@@ -1170,12 +1170,12 @@ static int launch_refill(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s,
     if ((rc = amx_ensure(ctx, ctx->cproj, cbytes + (size_t)a.ldC * sizeof(unsigned)))) return rc;
     a.cproj = (double *)ctx->cproj.p;
     a.p0 = (unsigned *)((char *)ctx->cproj.p + cbytes);
-    const bool mfma = a.c.nS <= 4 * kProjKS && !getenv("AMX_FW_PROJ_VALU");
+    const bool mfma = a.c.nS <= 4 * kProjKS && !ctx->opt_fw_proj_valu;
     const size_t lds_p = mfma ? (size_t)4 * (2 * 64 * 16 + 32) * sizeof(double) : project_lds_bytes(a.c.nS, N, 4), lds = refill_lds_bytes(N, 4);
     if ((rc = set_lds(ctx, proj, lds_p)) || (rc = set_lds(ctx, pmfma, lds_p)) || (rc = set_lds(ctx, kern, lds))) return rc;
     const dim3 grid(((pl.max_chunks + 7) / 8) * 8);
     a.queue = pl.n_chunks + 60;                            // (misc word 60: zeroed with the plan counters)
-    a.sub_per_chunk = (amx_refill_chunk((long long)pl.n) + kSubChunk - 1) / kSubChunk;
+    a.sub_per_chunk = (amx_refill_chunk(ctx, (long long)pl.n) + kSubChunk - 1) / kSubChunk;
     rec(ctx, 2, s);
     if (mfma) hipLaunchKernelGGL(pmfma, grid, dim3(256), lds_p, s, a);
     else hipLaunchKernelGGL(proj, grid, dim3(256), lds_p, s, a);
@@ -1224,7 +1224,7 @@ int amx_launch_fw_small(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s)
 {
     // compile-time dictionary sizes: the reference's defaults (11 Human, 12 Mouse) exactly, 16 otherwise
     const int n = a.c.n_atoms;
-    if (amx_fw_use_refill(n, a.c.nS, a.c.flags, a.c.lam2)) {
+    if (amx_fw_use_refill(ctx, n, a.c.nS, a.c.flags, a.c.lam2)) {
         if (n <= 11) return launch_refill(ctx, a, pl, s, k_fw_project<11>, k_fw_project_mfma<11>, k_freewater_refill<11>, 11);
         return launch_refill(ctx, a, pl, s, k_fw_project<12>, k_fw_project_mfma<12>, k_freewater_refill<12>, 12);
     }
@@ -1260,7 +1260,7 @@ int amx_launch_sandi_small(amx_ctx *ctx, SandiArgs &a, const Plan &pl, hipStream
     // (a refill variant of this kernel -- lanes drawing the next voxel from a global counter -- was measured SLOWER,
     //  2.65 vs 2.29 ms per 1 M voxels: SANDI's optimum is dense, 12 of 15 atoms, so the lanes of a wavefront need
     //  nearly the same number of steps and there is no idle time to win back)
-    if (a.c.nS == 6 && n == 15 && amx_warm_start(a.c.lam2, a.c.flags) && !getenv("AMX_SANDI_ATOM_SPACE")) {
+    if (a.c.nS == 6 && n == 15 && amx_warm_start(a.c.lam2, a.c.flags) && !ctx->opt_sandi_atom_space) {
         if (!a.tables) { ctx->err = "amx_launch_sandi_small: dictionary tables missing (amx_sandi_prepare)"; return AMX_E_BADARG; }
         rec(ctx, 2, s);
         hipLaunchKernelGGL((k_sandi_rows<6, 15>), dim3(((pl.max_chunks + 7) / 8) * 8), dim3(256), 0, s, a);

@@ -348,7 +348,7 @@ int amx_prep_gather_device(amx_ctx *ctx, const amx_prep *p, const float *d_img, 
     long long grid = 256LL * per_cu * 2;
     const long long need = (a.n_tiles + kPrepWaves - 1) / kPrepWaves;
     if (grid > need) grid = need;
-    if (!identity && !p->hazard && p->layout == 1 && !getenv("AMX_PREP_TILE")) {
+    if (!identity && !p->hazard && p->layout == 1 && !ctx->opt_prep_tile) {
         // grouped outputs on a planar image: streaming kernel, no transposition tile
         const size_t lds_s = ((size_t)p->n_b0 + p->n_out + 1 + p->n_gidx) * sizeof(int);
         long long g2 = (a.n_tiles + 3) / 4;
@@ -740,7 +740,7 @@ static int lut_gemm(amx_ctx *ctx, const float *d_lm, const float *d_z, const flo
     // both operands in LDS: plain input, even K, operator zone + four row tiles within the 160 KB of a CU
     const size_t yzone = ((((size_t)n_out * n_sh * 4) + 1023) & ~(size_t)1023) + 2048;
     const size_t lds_tile = yzone + 4 * ((((size_t)32 * n_sh * 4) + 1023) & ~(size_t)1023);
-    if (d_lm && (n_sh & 1) == 0 && n_sh <= 4 * amx::kLutKhMax && 4 * kh2t - n_sh <= 4 && lds_tile <= 160 * 1024 && !getenv("AMX_LUT_REGS")) {
+    if (d_lm && (n_sh & 1) == 0 && n_sh <= 4 * amx::kLutKhMax && 4 * kh2t - n_sh <= 4 && lds_tile <= 160 * 1024 && !ctx->opt_lut_regs) {
         auto launch = [&](auto kern) -> int {
             HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile));
             long long blocks = (n_rows + 127) / 128;

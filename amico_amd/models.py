@@ -20,6 +20,13 @@ def get_context():
     return _CTX
 
 
+def reset_context():
+    """forget the process-wide context: the next get_context() creates a new one (the library reads its AMX_* environment
+    switches once, when a context is created -- tools and tests that flip a switch call this afterwards)"""
+    global _CTX
+    _CTX = None
+
+
 class BaseModel(ABC):
     """models.pyx:75-217"""
 

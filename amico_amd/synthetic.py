@@ -37,8 +37,13 @@ def build_htable(dirs):
     th = np.deg2rad(np.arange(181.0))[:, None]
     ph = np.deg2rad(np.arange(181.0))[None, :]
     v = np.stack([np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th) * np.ones_like(ph)], axis=-1)
-    dots = np.abs(v.reshape(-1, 3) @ np.asarray(dirs, dtype=np.float64).T)
-    return np.argmax(dots, axis=1).astype(np.int16)
+    v = v.reshape(-1, 3)
+    dt = np.asarray(dirs, dtype=np.float64).T
+    out = np.empty(v.shape[0], dtype=np.int16)
+    step = max(1, (1 << 24) // max(1, dt.shape[1]))          # (32 761 grid points x 32 761 directions would not fit at once)
+    for s in range(0, v.shape[0], step):
+        out[s:s + step] = np.argmax(np.abs(v[s:s + step] @ dt), axis=1)
+    return out
 
 
 def random_unit_vectors(n, rng):

@@ -20,6 +20,24 @@ def load_npz(name):
     return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
 
 
+@pytest.fixture
+def amx_env(monkeypatch):
+    """amx_env(AMX_X='1', AMX_Y=None): set / unset library switches for ONE test.  The library reads its environment once per
+    context (amx_ctx_create), so the process-wide context is replaced now and again when the test is over."""
+    from amico_amd import reset_context
+
+    def setter(**kv):
+        for k, v in kv.items():
+            if v is None:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, v)
+        reset_context()
+    yield setter
+    monkeypatch.undo()
+    reset_context()
+
+
 @pytest.fixture(scope='session')
 def htable500():
     return load_npz('htable500.npz')

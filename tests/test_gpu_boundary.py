@@ -190,3 +190,32 @@ def test_small_models_pipelined_host_path(htable500):
     devr = _capi.sandi_fit_device(ctx, ls, torch.from_numpy(ys).to(dev), 0.0, 5e-3)[0]
     ctx.sync()
     assert np.array_equal(host, devr.cpu().numpy())
+
+
+def test_progress_from_the_device_pointer_calls(htable500):
+    """amx_set_progress also fires for fits on buffers that are already in HBM (models.pyx:28-43, 981: the reference's fit
+    reports while it runs): a host function on the stream after each NODDI stage, and at the end of the other models"""
+    import torch
+    from amico_amd import _capi, synthetic as S
+    n = 50_000
+    ctx, lut, K, ht, sch, y, d = _noddi(htable500, n)
+    dev = torch.device('cuda', 0)
+    yt, dt = torch.from_numpy(y).to(dev), torch.from_numpy(d).to(dev)
+    seen = []
+    ctx.set_progress(lambda done, total: seen.append((done, total)))
+    est = _capi.noddi_fit_device(ctx, lut, yt, dt, 0.5, 1e-3, 3)[0]
+    ctx.sync()
+    assert seen == [(n // 3, n), (2 * (n // 3), n), (n, n)]
+    del seen[:]
+    s1 = S.make_scheme(1, ((1000.0, 64),), seed=3)
+    Kf = S.freewater_kernels(s1, htable500['dirs'])
+    yf, df = S.freewater_signals(5000, Kf, ht, s1, seed=2)
+    lf = _capi.upload_freewater(ctx, Kf, ht)
+    _capi.freewater_fit_device(ctx, lf, torch.from_numpy(yf).to(dev), torch.from_numpy(df).to(dev), 0.0, 1e-3, False)
+    ctx.sync()
+    assert seen == [(5000, 5000)]
+    ctx.set_progress(None)
+    del seen[:]
+    est2 = _capi.noddi_fit_device(ctx, lut, yt, dt, 0.5, 1e-3, 3)[0]
+    ctx.sync()
+    assert not seen and torch.equal(est, est2)

@@ -65,3 +65,34 @@ def test_freewater_two_million_and_sandi_one_million_voxels_against_the_oracle(h
     _report('SANDI 1M (relative for Rsoma / Din / De)', rel)
     assert rel.max() < 1e-7
     assert ctx.last_stats()['itercap_voxels'] == 0
+
+
+def test_noddi_with_the_largest_direction_set_of_the_reference():
+    """ndirs = 32761 (the finest of the 22 sets of lut.pyx:18-25): upload (tiles, Gram matrices, orientation bases: ~20 GB of
+    HBM) and a fit whose voxels spread over all orientations, against the oracle on a sample."""
+    import torch
+    from amico_amd import _capi, get_context, synthetic as S
+    from oracle import oracle
+    ndirs, n = 32761, 300_000
+    dirs = S.fibonacci_hemisphere(ndirs)
+    ht = S.build_htable(dirs)
+    sch = S.make_scheme(seed=0)
+    K = S.noddi_kernels(sch, dirs)
+    y, d = S.noddi_signals(n, K, ht, sch, seed=11)
+    assert len(np.unique(S.lut_indices(d, ht))) > 20000            # (1-degree table: not every direction is reachable)
+    ctx = get_context()
+    free0 = torch.cuda.mem_get_info()[0]
+    lut = _capi.upload_noddi(ctx, K, ht, sch.dwi_idx)
+    dev = torch.device('cuda', 0)
+    est = _capi.noddi_fit_device(ctx, lut, torch.from_numpy(y).to(dev), torch.from_numpy(d).to(dev), 0.5, 1e-3, 3)[0]
+    ctx.sync()
+    print('ndirs 32761: dictionary + work buffers %.1f GB of HBM' % ((free0 - torch.cuda.mem_get_info()[0]) / 1e9))
+    st = ctx.last_stats()
+    assert st['itercap_voxels'] == 0 and st['overflow_voxels'] == 0 and st['guard_trips'] == 0
+    m = 4000
+    ref = oracle.noddi_fit(y[:m], d[:m], K, ht, sch.dwi_idx, nthreads=os.cpu_count() or 1)['estimates']
+    diff = np.abs(est[:m].cpu().numpy() - ref).max(axis=1)
+    _report('NODDI ndirs=32761', diff)
+    assert diff.max() < 1e-4 and (diff > 1e-6).sum() <= 2
+    assert bool(torch.isfinite(est).all())
+    del lut

@@ -69,12 +69,13 @@ def _noddi_certificates(K, sch, ht, y, d, x, lam1, lam2):
     return out
 
 
-@pytest.mark.parametrize('snr,mapping', [(30.0, 'wave'), (10.0, 'wave'), (10.0, 'pair')])
-def test_noddi_kkt_certificates_and_supports(htable500, snr, mapping, monkeypatch):
-    """mapping: 'wave' = one wavefront per voxel (default), 'pair' = two voxels per wavefront in the NNLS stages (opt-in)"""
+@pytest.mark.parametrize('snr,mapping', [(30.0, 'seeded'), (10.0, 'seeded'), (10.0, 'cold')])
+def test_noddi_kkt_certificates_and_supports(htable500, snr, mapping, amx_env):
+    """mapping: 'seeded' = seed solvers + Gram-space certificates + left-over kernels (default), 'cold' = the wavefront-per-voxel
+    active-set solvers from the empty set for every voxel (AMX_NO_SEED=1)"""
     import torch
-    if mapping == 'pair':
-        monkeypatch.setenv('AMX_PAIR', '1')
+    if mapping == 'cold':
+        amx_env(AMX_NO_SEED='1')
     from amico_amd import _capi, get_context, synthetic as S
     from oracle import oracle
     dirs, ht = htable500['dirs'], htable500['htable']
@@ -135,16 +136,16 @@ def _lasso_certificate(A, Y, X, lam1, lam2):
 
 @pytest.mark.parametrize('snr', [30.0, 10.0])
 @pytest.mark.parametrize('mapping', ['refill', 'lane', 'wave'])
-def test_freewater_kkt_certificates(htable500, snr, mapping, monkeypatch):
+def test_freewater_kkt_certificates(htable500, snr, mapping, amx_env):
     """mapping: 'refill' = lane per voxel, lanes refilled from a buffer (default), 'lane' = one solve per lane and pass,
     'wave' = one wavefront per voxel"""
     import torch
     from amico_amd import _capi, get_context, synthetic as S
     from oracle import oracle
     if mapping == 'wave':
-        monkeypatch.setenv('AMX_WAVE_PER_VOXEL', '1')
+        amx_env(AMX_WAVE_PER_VOXEL='1')
     if mapping == 'lane':
-        monkeypatch.setenv('AMX_NO_REFILL', '1')
+        amx_env(AMX_NO_REFILL='1')
     n = 20_000 if mapping == 'wave' else N_VOX
     dirs, ht = htable500['dirs'], htable500['htable']
     sch = S.make_scheme(1, ((1000.0, 64),), seed=3)
@@ -173,14 +174,14 @@ def test_freewater_kkt_certificates(htable500, snr, mapping, monkeypatch):
 
 @pytest.mark.parametrize('snr', [30.0, 10.0])
 @pytest.mark.parametrize('mapping', ['rows', 'lane', 'wave'])
-def test_sandi_kkt_certificates(snr, mapping, monkeypatch):
+def test_sandi_kkt_certificates(snr, mapping, amx_env):
     import torch
     from amico_amd import _capi, get_context, synthetic as S
     from oracle import oracle
     if mapping == 'wave':
-        monkeypatch.setenv('AMX_WAVE_PER_VOXEL', '1')
+        amx_env(AMX_WAVE_PER_VOXEL='1')
     if mapping == 'lane':
-        monkeypatch.setenv('AMX_SANDI_ATOM_SPACE', '1')
+        amx_env(AMX_SANDI_ATOM_SPACE='1')
     n = N_VOX if mapping == 'rows' else 20_000
     avg = S.directional_average_scheme(S.make_sandi_scheme())
     K, Rs, d_in, d_isos = S.sandi_kernels(avg)

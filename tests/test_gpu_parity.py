@@ -219,8 +219,11 @@ def test_evaluation_end_to_end_from_raw_volume(htable500):
     ae.set_data(img, sch, mask)
     ae.set_model('NODDI')
     ae.set_kernels(K, ht)
+    ticks = []
+    ae.set_config('progress_callback', lambda done, total: ticks.append((done, total)))      # models.pyx:981
     ae.fit()
     sel = mask == 1
+    assert ticks and ticks[-1] == (int(sel.sum()), int(sel.sum())) and len(ticks) == 3
     y_ref, _ = signal_np.prepare_signal(img, mask, sch.b0_idx, sch.dwi_idx)
     assert np.array_equal(ae.y, y_ref)
     d_ref, ev = signal_np.dti_directions(y_ref, sch.b, sch.raw[:, :3], return_evals=True)
@@ -303,13 +306,13 @@ def test_other_protocol_shapes(htable500):
         assert np.abs(outd['estimates'] - refd['estimates']).max() < TOL, nd
 
 
-def test_small_models_both_mappings(fw_fix, sandi_fix, htable500, monkeypatch):
+def test_small_models_both_mappings(fw_fix, sandi_fix, htable500, amx_env):
     """FreeWater / SANDI have two device mappings (one voxel per lane for <= 16 atoms, one voxel
     per wavefront otherwise); both must reproduce the golden maps."""
     from amico_amd import FreeWater, SANDI
     res = {}
     for mode in ('0', '1'):
-        monkeypatch.setenv('AMX_WAVE_PER_VOXEL', mode)
+        amx_env(AMX_WAVE_PER_VOXEL=mode)
         f = fw_fix
         out = FreeWater().fit(Holder(f['y'], f['dirs'], htable500['htable'], f['kernels'], doSaveCorrectedDWI=True,
                                      doComputeRMSE=True, doComputeNRMSE=True))
@@ -323,8 +326,7 @@ def test_small_models_both_mappings(fw_fix, sandi_fix, htable500, monkeypatch):
     assert np.abs(res['0'][0]['nrmse'] - res['1'][0]['nrmse']).max() < 1e-9
     assert np.abs(res['0'][1]['rmse'] - res['1'][1]['rmse']).max() < 1e-9
     # SANDI's third mapping: one voxel per lane in ATOM space (the default 6 x 15 problem runs in row space)
-    monkeypatch.setenv('AMX_WAVE_PER_VOXEL', '0')
-    monkeypatch.setenv('AMX_SANDI_ATOM_SPACE', '1')
+    amx_env(AMX_WAVE_PER_VOXEL='0', AMX_SANDI_ATOM_SPACE='1')
     s = sandi_fix
     outa = SANDI().fit(Holder(s['y'], None, None, s['kernels'], doComputeRMSE=True))
     assert np.abs(outa['estimates'][:, :3] - s['estimates'][:, :3]).max() < TOL
@@ -356,7 +358,7 @@ def test_device_resident_volume_pipeline(htable500):
     assert np.array_equal(dirs.cpu().numpy(), ae.RESULTS['DIRs'])
 
 
-def test_large_host_batches_are_pipelined_identically(htable500, monkeypatch):
+def test_large_host_batches_are_pipelined_identically(htable500, amx_env):
     """amx_noddi_fit with >= 524 288 voxels copies and fits in batches (PCIe hidden behind the solver): same maps as
     the one-shot path bit for bit, statistics accumulated over the batches, error voxel reported in caller indices"""
     from amico_amd import _capi, get_context, synthetic as S
@@ -369,12 +371,14 @@ def test_large_host_batches_are_pipelined_identically(htable500, monkeypatch):
     lut = _capi.upload_noddi(ctx, K, ht, sch.dwi_idx)
     est, rmse, _, mod = _capi.noddi_fit(ctx, lut, y, d, 0.5, 1e-3, 3, rmse=True, mod=True)
     stats = ctx.last_stats()
-    monkeypatch.setenv('AMX_HOST_ONE_SHOT', '1')
-    est1, rmse1, _, mod1 = _capi.noddi_fit(ctx, lut, y, d, 0.5, 1e-3, 3, rmse=True, mod=True)
-    stats1 = ctx.last_stats()
-    monkeypatch.delenv('AMX_HOST_ONE_SHOT')
+    amx_env(AMX_HOST_ONE_SHOT='1')                          # (read when a context is created: a second context)
+    ctx1 = get_context()
+    assert ctx1 is not ctx
+    lut1 = _capi.upload_noddi(ctx1, K, ht, sch.dwi_idx)
+    est1, rmse1, _, mod1 = _capi.noddi_fit(ctx1, lut1, y, d, 0.5, 1e-3, 3, rmse=True, mod=True)
+    stats1 = ctx1.last_stats()
     assert np.array_equal(est, est1) and np.array_equal(rmse, rmse1) and np.array_equal(mod, mod1)
-    assert stats['rerun_voxels'] == stats1['rerun_voxels'] > 0
+    assert stats['rerun_voxels'] == stats1['rerun_voxels'] and stats['itercap_voxels'] == stats1['itercap_voxels'] == 0
     d_bad = d.copy()
     d_bad[400000] = np.nan
     with pytest.raises(RuntimeError, match=r'voxel 400000\]'):
