@@ -520,7 +520,7 @@ int amx_set_profiling(amx_ctx *ctx, int enable)
 
 int amx_last_kernel_ms(amx_ctx *ctx, int which, float *out_ms)
 {
-    if (!ctx || !out_ms || which < 0 || which > 7) return AMX_E_BADARG;
+    if (!ctx || !out_ms || which < 0 || which > 9) return AMX_E_BADARG;
     const int a = which == 0 ? 0 : 2 * which, b = which == 0 ? 1 : 2 * which + 1;
     if (!ctx->ev_valid[a] || !ctx->ev_valid[b]) return bad(ctx, "amx_last_kernel_ms: no profiled call");
     HIPCHK(ctx, hipEventSynchronize(ctx->ev[b]));
@@ -584,7 +584,9 @@ int amx_noddi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
         if (!ctx->opt_no_screen) { a.scr_S = lut->screen_S; a.scr_kappa = lut->screen_kappa; a.scr_ytil = (const double *)ctx->ytil.p; a.scr_Sg = lut->basis_S; }
         if (ctx->opt_seed_stages & 1) {
             a.seeds = (const unsigned long long *)ctx->seeds.p;
+            rec(ctx, 16, s);
             if ((rc = amx_launch_noddi_seed(ctx, lut, a, pl, s, 1))) return rc;
+            rec(ctx, 17, s);
             if (gcert) {
                 if ((rc = amx_launch_noddi_gcert(ctx, lut, a, pl, s, 1))) return rc;
                 a.done = (const unsigned char *)ctx->done.p;
@@ -602,7 +604,9 @@ int amx_noddi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
         const bool gcert2 = !ctx->opt_no_gcert && lut->nS <= 100 && lut->n_atoms <= 146 && lut->n_wm <= 144 && lut->screen2_kappa0 != nullptr;
         rec(ctx, 12, s);
         if (gcert2 && (rc = amx_launch_noddi_gemm(ctx, lut, a, pl, s, true))) return rc;        // c2 = A2'y2, y2~, ||y2||^2
+        rec(ctx, 18, s);
         if ((rc = amx_launch_noddi_seed2(ctx, lut, a, pl, s, gcert2))) return rc;
+        rec(ctx, 19, s);
         a.seeds2 = (const unsigned long long *)ctx->seeds2.p;
         a.list_is_pos = 1;
         if (!ctx->opt_no_screen && lut->screen2_S) { a.scr2_S = lut->screen2_S; a.scr2_kappa = lut->screen2_kappa; a.scr2_ytil = (const double *)ctx->ytil2.p; a.scr2_Sg = lut->basis2_S; }

@@ -14,7 +14,7 @@
 #endif
 constexpr int kChunk = AMX_CHUNK;        // voxels of one orientation per workgroup
 constexpr int kListGrid = 512;     // workgroups of the large-MAXP re-run pass
-constexpr int kEv = 16;           // event pairs: 0 whole call, 1-3 NODDI stage kernels, 4 small-model solver, 5-7 NODDI seed kernels of stages 1 / 2 / 3
+constexpr int kEv = 20;           // event pairs: 0 whole call, 1-3 NODDI stage kernels, 4 small-model solver, 5-7 NODDI GEMM + seed + certificate kernels of stages 1 / 2 / 3, 8 k_nnls_seed<1> alone, 9 k_lasso_seed alone
 
 struct DevBuf {
     void *p = nullptr; size_t cap = 0;

@@ -54,7 +54,7 @@ def pmc_small(model, key):
         return None
 
 
-def small_model(model, n, steps, warmup, cpu=True):
+def small_model(model, n, steps, warmup, cpu=True, host_legs=True):
     """FreeWater (config 3) / SANDI (config 4) on one GPU: same timing protocol as the headline, returns the record"""
     import torch
     from amico_amd import _capi, synthetic as S
@@ -147,7 +147,7 @@ def small_model(model, n, steps, warmup, cpu=True):
                         'kernel': kernel, 'kernel_ms': kms, 'bytes_per_voxel': bpv},
            'parity': {'sample_voxels': m, 'max_abs_dmap': float(diff.max()), 'max_rel_dmap': float(rel.max())},
            'solver_stats': ctx.last_stats()}
-    if model in ('freewater', 'sandi'):
+    if model in ('freewater', 'sandi') and host_legs:
         # host numpy in -> host numpy out (pageable memory; PCIe inclusive): the batches of the pipelined entry points hide the
         # solver behind the copies here, so this is a PCIe figure, reported beside the kernels' rate, never as `value`
         hb = {}
@@ -174,7 +174,8 @@ def small_model(model, n, steps, warmup, cpu=True):
 
 
 def other_models(args):
-    print(json.dumps(small_model(args.model, args.voxels, args.steps, args.warmup)))
+    # (--no-cpu-baseline here also skips the host-buffer legs: profiling runs want the device-resident launches only)
+    print(json.dumps(small_model(args.model, args.voxels, args.steps, args.warmup, cpu=not args.no_cpu_baseline, host_legs=not args.no_cpu_baseline)))
 
 
 def dti_directions(args):
@@ -574,10 +575,10 @@ def main():
                                          est.data_ptr(), None, None, None, stream))
 
     step = sharded_step(fit, est, gathered, world)          # fit + the single collective of the path
-    kms = np.zeros(8)
+    kms = np.zeros(10)
 
     def per_step():
-        for w in (0, 1, 2, 3, 5, 6, 7):                          # HIP events on the launch stream
+        for w in (0, 1, 2, 3, 5, 6, 7, 8, 9):                    # HIP events on the launch stream
             try:
                 kms[w] += ctx.last_kernel_ms(w)
             except Exception:                                   # seed kernels absent (AMX_NO_SEED=1)
@@ -590,10 +591,17 @@ def main():
 
     if rank == 0:
         value = world * n * args.steps / elapsed
-        names = {1: 'k_noddi<1> (stage 1: voxels the Gram certificate left over)', 2: 'k_noddi<4> (LASSO: left-over voxels)', 3: 'k_noddi<3> (stage 3: left-over voxels)',
-                 5: 'k_noddi_gemm + k_nnls_seed<1> + k_nnls_gcert<1> (A\'y on the matrix cores, seed solver, Gram certificate of stage 1)',
-                 6: 'k_noddi_gemm<lasso> + k_lasso_seed + k_lasso_gcert (LASSO stage)', 7: 'k_nnls_seed<3> + k_nnls_gcert<3> (stage 3)'}
-        stage = max(names, key=lambda w: kms[w])
+        groups = {1: 'k_noddi<1> (stage 1: voxels the Gram certificate left over) + re-run kernel', 2: 'k_noddi<4> (LASSO: left-over voxels) + re-run kernel',
+                  3: 'k_noddi<3> (stage 3: left-over voxels) + re-run kernel',
+                  5: "k_noddi_gemm + k_nnls_seed<1> + k_nnls_gcert<1> (A'y on the matrix cores, seed solver, Gram certificate of stage 1)",
+                  6: 'k_noddi_gemm<lasso> + k_lasso_seed + k_lasso_gcert x2 (LASSO stage)', 7: 'k_nnls_seed<3> + k_nnls_gcert<3> (stage 3)'}
+        # the dominant SINGLE kernel: the stage-1 seed solver (its own event pair), else the slowest of the other launches
+        singles = {8: 'k_nnls_seed<1, 8> (stage-1 NNLS seed solver, one voxel per lane, fp64 MFMA dual scan)',
+                   9: 'k_lasso_seed (LASSO seed solver, one voxel per lane, Woodbury form)', 1: groups[1], 2: groups[2], 3: groups[3]}
+        stage = max(singles, key=lambda w: kms[w])
+        if kms[8] == 0.0 and kms[9] == 0.0:                        # seeds off: the three stage kernels are the whole fit
+            stage = max((1, 2, 3), key=lambda w: kms[w])
+        names = singles
         dom_ms = float(kms[stage])
         achieved = BYTES_PER_VOXEL * n / (dom_ms * 1e-3) / 1e9
         traffic = pmc_traffic(stage, n)
@@ -611,7 +619,8 @@ def main():
                          'traffic_source': 'profiles/pmc_traffic.json (rocprofv3 --pmc, bytes per launch)'
                                            if traffic is not None else None,
                          'kernel': names[stage], 'kernel_ms': dom_ms,
-                         'stage_ms': [float(v) for v in kms[1:4]], 'seed_ms': [float(v) for v in kms[5:8]], 'all_kernels_ms': float(kms[0]),
+                         'stage_ms': [float(v) for v in kms[1:4]], 'seed_ms': [float(v) for v in kms[5:8]], 'seed_solver_ms': [float(kms[8]), float(kms[9])],
+                         'groups': {str(k): {'kernels': v, 'ms': float(kms[k])} for k, v in groups.items()}, 'all_kernels_ms': float(kms[0]),
                          'note': 'the path is bound by dependent latencies inside the per-voxel active-set solvers, not by HBM (DESIGN.md section 5): see compute_side'},
             'compute_side': pmc_valu(stage, n, dom_ms),
             'solver_stats': stats,

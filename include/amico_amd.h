@@ -250,9 +250,11 @@ int amx_lut_rotate_resample(amx_ctx *ctx, const float *zonal, int n_atoms, const
 
 /* ---- measurement hooks (bench.py): HIP-event time of the solver kernels of the LAST
  * *_fit_device call on this ctx, measured on the stream they were launched on.
- * which: 0 = all kernels of the call, 1..3 = solver stage kernels (NODDI: NNLS-1, LASSO,
- * NNLS-3; FreeWater/SANDI: 1 = the single solver kernel), 4 = the last amx_dti_directions_device / amx_prep_gather_device kernel,
- * 5..7 = NODDI support-seed kernels ahead of stage 1 / 2 / 3 (projection + seed solver, csrc/amx_seed.hpp; an error if seeds are off).
+ * which: 0 = all kernels of the call, 1..3 = solver stage kernels (NODDI: the wavefront-per-voxel kernels of NNLS-1, LASSO,
+ * NNLS-3 incl. their re-run kernels -- with seeds on they see only the voxels the Gram-space certificates left over;
+ * FreeWater/SANDI: 1 = the single solver kernel), 4 = the last amx_dti_directions_device / amx_prep_gather_device kernel,
+ * 5..7 = NODDI kernels ahead of stage 1 / 2 / 3 (A'y on the matrix cores + seed solver + Gram-space certificate,
+ * csrc/amx_seed.hpp; an error if seeds are off), 8 = k_nnls_seed<1> alone, 9 = k_lasso_seed alone.
  * Requires amx_set_profiling(1). */
 int amx_set_profiling(amx_ctx *ctx, int enable);
 int amx_last_kernel_ms(amx_ctx *ctx, int which, float *out_ms);

@@ -6,20 +6,21 @@ cd $GRAFT_REPO_ROOT
 TAG=${1:-rXX}
 O=gpurun_out/small_$TAG
 mkdir -p $O
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/fw -o fw -- python bench.py --model freewater --voxels 2000000 --steps 5 --warmup 1 > $O/fw_bench.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/sandi -o sandi -- python bench.py --model sandi --voxels 1000000 --steps 5 --warmup 1 > $O/sandi_bench.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/lut -o lut -- python bench.py --model lut --steps 5 --warmup 1 > $O/lut_bench.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/prep -o prep -- python bench.py --model prep --steps 5 --warmup 1 > $O/prep_bench.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/fw -o fw -- python bench.py --model freewater --voxels 2000000 --steps 5 --warmup 1 --no-cpu-baseline > $O/fw_bench.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/sandi -o sandi -- python bench.py --model sandi --voxels 1000000 --steps 5 --warmup 1 --no-cpu-baseline > $O/sandi_bench.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/czb -o czb -- python bench.py --model czb --voxels 500000 --steps 5 --warmup 1 --no-cpu-baseline > $O/czb_bench.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/lut -o lut -- python bench.py --model lut --steps 5 --warmup 1 --no-cpu-baseline > $O/lut_bench.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/prep -o prep -- python bench.py --model prep --steps 5 --warmup 1 --no-cpu-baseline > $O/prep_bench.log 2>&1
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  for m in freewater sandi; do
-    v=1000000; [ $m = freewater ] && v=2000000
-    timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_${m}_$i -- python bench.py --model $m --voxels $v --steps 2 --warmup 1 > $O/pmc_${m}_$i.log 2>&1
+  for m in freewater sandi czb; do
+    v=1000000; [ $m = freewater ] && v=2000000; [ $m = czb ] && v=500000
+    timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_${m}_$i -- python bench.py --model $m --voxels $v --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_${m}_$i.log 2>&1
   done
-  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_lut_$i -- python bench.py --model lut --steps 2 --warmup 1 > $O/pmc_lut_$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_lut_$i -- python bench.py --model lut --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_lut_$i.log 2>&1
 done
-for f in fw sandi lut prep; do tail -1 $O/${f}_bench.log | cut -c1-600; done
+for f in fw sandi czb lut prep; do tail -1 $O/${f}_bench.log | cut -c1-600; done

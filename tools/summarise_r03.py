@@ -33,7 +33,8 @@ open('profiles/%s_pmc.txt' % tag, 'w').write('\n'.join(out) + '\n')
 # groups = the HIP-event pairs of bench.py (amx_last_kernel_ms)
 groups = {'1': ['k_noddi<1,'], '2': ['k_noddi<4,', 'k_noddi<2,'], '3': ['k_noddi<3,'],
           '5': ['k_noddi_gemm<false>', 'k_noddi_project<', 'k_nnls_seed<1', 'k_nnls_gcert<1'],
-          '6': ['k_noddi_gemm<true>', 'k_noddi_project2', 'k_lasso_seed', 'k_lasso_gcert'], '7': ['k_nnls_seed<3', 'k_nnls_gcert<3']}
+          '6': ['k_noddi_gemm<true>', 'k_noddi_project2', 'k_lasso_seed', 'k_lasso_gcert'], '7': ['k_nnls_seed<3', 'k_nnls_gcert<3'],
+          '8': ['k_nnls_seed<1'], '9': ['k_lasso_seed']}
 tr, valu, per_kernel = {}, {}, {}
 for k, c in acc.items():
     per_kernel[k] = {'bytes': int(2 * mean(c['FETCH_SIZE']) * 1024 + mean(c['WRITE_SIZE']) * 1024), 'valu_insts': mean(c['SQ_INSTS_VALU']),
@@ -50,8 +51,8 @@ except (OSError, ValueError):
     t = {}
 t.update({'_source': 'profiles/%s_pmc.txt (rocprofv3 --pmc, separate passes, NODDI 1 M voxels, mean per launch); git %s' % (tag, g('rev-parse', '--short', 'HEAD')),
           '_correction': 'bytes = 2 * FETCH_SIZE[KiB] * 1024 (gfx950 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md HBM section) + WRITE_SIZE[KiB] * 1024 (uncalibrated)',
-          '_groups': 'keys = which of amx_last_kernel_ms: 1-3 stage kernels (incl. their re-run kernels), 5-7 GEMM + seed solver + Gram certificate ahead of stage 1 / 2 / 3',
+          '_groups': 'keys = which of amx_last_kernel_ms: 1-3 stage kernels (incl. their re-run kernels), 5-7 GEMM + seed solver + Gram certificate ahead of stage 1 / 2 / 3, 8 / 9 = k_nnls_seed<1> / k_lasso_seed alone (already contained in 5 / 6)',
           'voxels_per_launch': 1000000, 'stage_bytes_per_launch': tr, 'stage_valu_insts_per_launch': valu, 'kernels': per_kernel})
 json.dump(t, open('profiles/pmc_traffic.json', 'w'), indent=2)
-print('bytes per fit %.3f GB' % (sum(tr.values()) / 1e9), {k: round(v / 1e9, 3) for k, v in tr.items()})
+print('bytes per fit %.3f GB' % (sum(v for k, v in tr.items() if k not in ('8', '9')) / 1e9), {k: round(v / 1e9, 3) for k, v in tr.items()})
 print('VALU wave-instructions per voxel', {k: round(v / 1e6) for k, v in valu.items()})

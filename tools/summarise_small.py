@@ -27,7 +27,7 @@ def bench_line(log):
     return ''
 
 
-for key, name, cmd in (('fw', 'freewater_2M', '--model freewater --voxels 2000000'), ('sandi', 'sandi_1M', '--model sandi --voxels 1000000'),
+for key, name, cmd in (('fw', 'freewater_2M', '--model freewater --voxels 2000000'), ('sandi', 'sandi_1M', '--model sandi --voxels 1000000'), ('czb', 'czb_500k', '--model czb --voxels 500000'),
                        ('lut', 'lut', '--model lut'), ('prep', 'prep', '--model prep')):
     db = '%s/%s/%s_results.db' % (O, key, key)
     if not os.path.exists(db):
@@ -37,10 +37,10 @@ for key, name, cmd in (('fw', 'freewater_2M', '--model freewater --voxels 200000
         f.write('# rocprofv3 --kernel-trace --stats -- python bench.py %s --steps 5 --warmup 1\n' % cmd)
         f.write(stats(db))
         f.write('\n# bench.py line of the same run\n# ' + bench_line('%s/%s_bench.log' % (O, key)) + '\n')
-out = [head_stamp().rstrip(), '# rocprofv3 --kernel-trace --pmc <set> --output-format csv -- python bench.py --model {freewater --voxels 2000000 | sandi --voxels 1000000 | lut} '
+out = [head_stamp().rstrip(), '# rocprofv3 --kernel-trace --pmc <set> --output-format csv -- python bench.py --model {freewater --voxels 2000000 | sandi --voxels 1000000 | czb --voxels 500000 | lut} '
        '--steps 2 --warmup 1; separate passes (never combined with other trace domains); mean per launch',
        '# FETCH_SIZE / WRITE_SIZE in KiB (FETCH_SIZE under-reports wide coalesced reads 2x on gfx950); SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* in quad-cycles']
-for m, pats in (('freewater', ['k_freewater', 'k_fw_project']), ('sandi', ['k_sandi']), ('lut', ['k_lut_resample'])):
+for m, pats in (('freewater', ['k_freewater', 'k_fw_project']), ('sandi', ['k_sandi']), ('czb', ['k_czb']), ('lut', ['k_lut_resample'])):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for fn in glob.glob('%s/pmc_%s_*/*/*_counter_collection.csv' % (O, m)):
         for r in csv.DictReader(open(fn)):
@@ -55,7 +55,7 @@ open('profiles/%s_pmc_small.txt' % tag, 'w').write('\n'.join(out) + '\n')
 # per-voxel HBM traffic of the lane kernels -> profiles/pmc_traffic.json (read by bench.py for roofline.traffic)
 import json
 small = {}
-for m, pats, n in (('freewater', ('k_fw_project', 'k_freewater'), 2000000), ('sandi', ('k_sandi',), 1000000)):
+for m, pats, n in (('freewater', ('k_fw_project', 'k_freewater'), 2000000), ('sandi', ('k_sandi',), 1000000), ('czb', ('k_czb',), 500000)):
     # a fit may be several kernels (FreeWater: projection + solver): per-launch means per kernel, summed over the kernels
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     for fn in glob.glob('%s/pmc_%s_*/*/*_counter_collection.csv' % (O, m)):
