@@ -185,6 +185,8 @@ int amx_ctx_create(int device, amx_ctx **out)
         e = getenv("AMX_HOST_BATCH");
         // (a multiple of 4: k_widen reads float4; at least the largest ramp batch, 131072: the ramp batches are written into slots of this size)
         if (e && atol(e) >= 131072) ctx->opt_host_batch = ((long long)atol(e) + 3) & ~3LL;
+        e = getenv("AMX_SEED_MIN_VOXELS");
+        if (e && *e) ctx->opt_seed_min_voxels = atoll(e);
         e = getenv("AMX_NO_GCERT_WIDE");
         ctx->opt_no_gcert_wide = e && *e && *e != '0';
         e = getenv("AMX_NO_SCREEN");
@@ -552,7 +554,8 @@ int amx_noddi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
     hipStream_t s = (hipStream_t)hip_stream;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     Plan pl; int rc;
-    const bool seeds = lut->basis_S != nullptr && lut->gram != nullptr && !ctx->opt_no_seed;
+    const bool seeds = lut->basis_S != nullptr && lut->gram != nullptr && !ctx->opt_no_seed &&
+                       (ctx->in_host_fit ? ctx->host_total_vox : n_vox) >= ctx->opt_seed_min_voxels;   // (batches of one host call all take the same path: bit-identical to the one-shot call)
     if ((rc = make_plan(ctx, n_vox, lut->ndirs, pl, seeds))) return rc;
     if ((rc = ensure(ctx, ctx->xiso, (size_t)n_vox * 2 * sizeof(double)))) return rc;
     if ((rc = ensure(ctx, ctx->supp, (size_t)n_vox * 4 * sizeof(unsigned long long)))) return rc;
@@ -811,7 +814,7 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
     HIPCHK(ctx, hipStreamSynchronize(nullptr));                      // earlier default-stream work on these buffers
     const bool was_profiling = ctx->profiling;
     if (pipelined) ctx->profiling = false;
-    ctx->in_host_fit = true;
+    ctx->in_host_fit = true; ctx->host_total_vox = n_vox;
     struct HostFitScope { amx_ctx *c; ~HostFitScope() { c->in_host_fit = false; } } host_scope{ctx};
     // Batch c runs on stream c & 1 with workspace set c & 1: the kernels of consecutive batches overlap, so the idle tail
     // of every launch (and the one-wavefront re-run kernels) is filled by the other batch instead of adding up six times.

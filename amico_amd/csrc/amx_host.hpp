@@ -30,6 +30,7 @@ struct amx_ctx {
     int *status_d = nullptr;       // ST_WORDS ints
     int *status_h = nullptr;       // pinned mirror (+16 words: copy of the misc counters)
     bool profiling = false;
+    int64_t host_total_vox = 0;    // voxels of the whole host-buffer call while its batches are enqueued
     bool in_host_fit = false;      // the host-buffer entry points report progress per batch themselves
     hipEvent_t ev[kEv];
     bool ev_valid[kEv];
@@ -69,6 +70,7 @@ struct amx_ctx {
     bool opt_no_gcert = false;     // AMX_NO_GCERT=1: every seed is certified by the wavefront-per-voxel kernels (true residual)
     bool opt_no_screen = false;    // AMX_NO_SCREEN=1: certify seeds with the full exact sweep of the dual vector
     bool opt_no_seed = false;      // AMX_NO_SEED=1: Lawson-Hanson from the empty set in the NNLS stages (the round-2 path)
+    long long opt_seed_min_voxels = 65536; // AMX_SEED_MIN_VOXELS: smaller calls run the wavefront-per-voxel kernels on all voxels (the seeded chain of ~16 kernels has a floor of ~2.4 ms; measured crossover 50 000 .. 100 000 voxels: 16.0 vs 19.3 and 28.0 vs 22.2 M voxels/s)
     int opt_seed_stages = 7;       // AMX_SEED_STAGES: bit 0 = seed stage 1, bit 1 = seed stage 3, bit 2 = seed the LASSO stage
     int opt_seed_chunk = 4096;     // AMX_SEED_CHUNK: voxels of one orientation per workgroup of the seed solvers (lanes refill from the chunk: the more voxels per lane, the smaller the share of the tail; 1 M voxels: 1024 -> 7.2 ms, 2048 -> 7.3, 4096 -> 5.5 for stage 1)
 };
