@@ -182,6 +182,8 @@ int amx_ctx_create(int device, amx_ctx **out)
         ctx->opt_wave_per_voxel = on("AMX_WAVE_PER_VOXEL");
         e = getenv("AMX_REFILL_CHUNK");
         if (e) ctx->opt_refill_chunk = atoi(e);
+        e = getenv("AMX_HOST_RAMP");
+        if (e && *e) { const long long v = atoll(e); ctx->opt_host_ramp = v <= 0 ? 0 : (v > 131072 ? 131072 : ((v + 3) & ~3LL)); }
         e = getenv("AMX_HOST_BATCH");
         // (a multiple of 4: k_widen reads float4; at least the largest ramp batch, 131072: the ramp batches are written into slots of this size)
         if (e && atol(e) >= 131072) ctx->opt_host_batch = ((long long)atol(e) + 3) & ~3LL;
@@ -822,11 +824,11 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
     hipStream_t s = pipelined ? ctx->hs : nullptr;
     int64_t off = 0, done_before[kBufs] = {0, 0, 0};         // voxels complete once the event of that buffer has fired
     for (int c = 0; off < n_vox; c++) {
-        // the first copy is the only one the solver cannot hide: three short doubling batches, then the rest in equal
-        // batches of at most kHostBatch voxels
-        const int64_t rem = n_vox - off, ramp = (int64_t)32768 << (c < 3 ? c : 3);
+        // the first copy is the only one the solver cannot hide: one short batch (131 072 voxels; shorter ones cost more in the
+        // ~2.4 ms floor of the seeded kernel chain than their copy saves), then the rest in equal batches of <= kHostBatch voxels
+        const int64_t rem = n_vox - off, ramp = ctx->opt_host_ramp;
         const int64_t parts = (rem + kHostBatch - 1) / kHostBatch;
-        const int64_t cnt = !pipelined ? n_vox : ((c < 3 && rem > 4 * ramp) ? ramp : (rem + parts - 1) / parts);
+        const int64_t cnt = !pipelined ? n_vox : ((c < 1 && ramp > 0 && rem > 3 * ramp) ? ramp : (rem + parts - 1) / parts);
         int b = c % kBufs;
         if (pipelined && c >= kBufs) {
             HIPCHK(ctx, hipEventSynchronize(ctx->hev[b]));           // batch c-3 has released this buffer

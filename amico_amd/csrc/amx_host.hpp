@@ -57,6 +57,7 @@ struct amx_ctx {
     bool opt_cold_start = false;       // AMX_COLD_START=1: FreeWater / SANDI / CZB start from the empty passive set
     bool opt_host_one_shot = false;    // AMX_HOST_ONE_SHOT=1: host-buffer entry points upload everything, then fit
     bool opt_host_one_stream = false;  // AMX_HOST_ONE_STREAM=1: pipelined host path on one stream
+    long long opt_host_ramp = 131072;  // AMX_HOST_RAMP: voxels of the first pipelined batch (its copy is the only one nothing hides; 0 = equal batches)
     long long opt_host_batch = 393216; // AMX_HOST_BATCH: voxels per pipelined batch (>= 131072, multiple of 4)
     bool opt_tile_f32 = false;         // AMX_TILE_F32=1: NNLS stages keep the float32 tile in LDS
     bool opt_fw_proj_valu = false;     // AMX_FW_PROJ_VALU=1: FreeWater projection without the matrix cores

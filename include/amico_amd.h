@@ -124,7 +124,7 @@ int amx_sandi_fit_f32(amx_ctx *ctx, const amx_lut *lut, const float *y, int64_t 
 
 /* Progress of the host-buffer calls: models.pyx:28-43, 981 keep a per-thread voxel counter that ProgressBar polls
  * (util.py); here `callback(done, total, user)` is called from the calling thread as batches of voxels complete (large
- * inputs are fitted in batches: three short doubling ones, then equal parts of at most 393 216 voxels) and once with done == total at the end.  NULL unregisters.
+ * inputs are fitted in batches: a first one of 131 072 voxels, then equal parts of at most 393 216 voxels) and once with done == total at the end.  NULL unregisters.
  * The device-pointer calls below only ENQUEUE the fit: there the callback is a host function on the stream (hipLaunchHostFunc),
  * i.e. it is called from a HIP runtime thread when the work before it has finished -- after each of NODDI's three stages
  * (done = n/3, 2n/3, n) and at the end of a FreeWater / SANDI / CylinderZeppelinBall fit (done = n).  It must not call back
