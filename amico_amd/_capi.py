@@ -19,9 +19,10 @@ SYMBOLS = ['amx_version', 'amx_ctx_create', 'amx_ctx_destroy', 'amx_last_error',
            'amx_lut_upload_noddi', 'amx_lut_upload_freewater', 'amx_lut_upload_sandi', 'amx_lut_destroy',
            'amx_dir_to_lut_idx', 'amx_noddi_fit', 'amx_freewater_fit', 'amx_sandi_fit',
            'amx_noddi_fit_device', 'amx_freewater_fit_device', 'amx_sandi_fit_device', 'amx_sync_status',
+           'amx_noddi_fit_device_f32', 'amx_freewater_fit_device_f32', 'amx_sandi_fit_device_f32', 'amx_czb_fit_device_f32',
            'amx_set_debug_x', 'amx_debug_fetch', 'amx_lut_upload_czb', 'amx_czb_fit', 'amx_czb_fit_f32', 'amx_czb_fit_device', 'amx_noddi_fit_f32', 'amx_freewater_fit_f32', 'amx_sandi_fit_f32', 'amx_set_progress',
            'amx_set_profiling', 'amx_last_kernel_ms', 'amx_last_stats', 'amx_selftest',
-           'amx_dti_create', 'amx_dti_destroy', 'amx_dti_directions', 'amx_dti_directions_device',
+           'amx_dti_create', 'amx_dti_destroy', 'amx_dti_directions', 'amx_dti_directions_device', 'amx_dti_directions_device_f32', 'amx_prep_gather_device_f32',
            'amx_prep_create', 'amx_prep_destroy', 'amx_prep_gather', 'amx_prep_gather_device',
            'amx_prep_mean_b0', 'amx_prep_mean_b0_device', 'amx_prep_scatter', 'amx_prep_scatter_device',
            'amx_lut_resample', 'amx_lut_rotate_resample']
@@ -94,6 +95,9 @@ def lib():
     L.amx_czb_fit.argtypes = [c_vp, c_vp, c_dp, c_dp, C.c_int64, C.c_double, C.c_double, C.c_uint, c_dp, c_dp, c_dp]
     L.amx_czb_fit_f32.argtypes = [c_vp, c_vp, c_fp, c_dp, C.c_int64, C.c_double, C.c_double, C.c_uint, c_dp, c_dp, c_dp]
     L.amx_czb_fit_device.argtypes = [c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_double, C.c_double, C.c_uint, c_vp, c_vp, c_vp, c_vp]
+    for name in ('noddi', 'freewater', 'sandi', 'czb'):
+        getattr(L, 'amx_%s_fit_device_f32' % name).argtypes = getattr(L, 'amx_%s_fit_device' % name).argtypes
+        getattr(L, 'amx_%s_fit_device_f32' % name).restype = C.c_int
     L.amx_set_profiling.argtypes = [c_vp, C.c_int]
     L.amx_last_kernel_ms.argtypes = [c_vp, C.c_int, C.POINTER(C.c_float)]
     L.amx_last_stats.argtypes = [c_vp, c_i64p]
@@ -103,12 +107,16 @@ def lib():
     L.amx_dti_destroy.restype = None
     L.amx_dti_directions.argtypes = [c_vp, c_vp, c_dp, C.c_int64, c_dp]
     L.amx_dti_directions_device.argtypes = [c_vp, c_vp, c_vp, C.c_int64, c_vp, c_vp]
+    L.amx_dti_directions_device_f32.argtypes = [c_vp, c_vp, c_vp, C.c_int64, c_vp, c_vp]
+    L.amx_dti_directions_device_f32.restype = C.c_int
     L.amx_prep_create.argtypes = [c_vp, c_i64p, c_i64p, C.c_int, c_i32p, C.c_int64, c_i32p, c_i32p, C.c_int,
                                   c_i32p, C.c_int, C.c_int, C.POINTER(c_vp)]
     L.amx_prep_destroy.argtypes = [c_vp]
     L.amx_prep_destroy.restype = None
     L.amx_prep_gather.argtypes = [c_vp, c_vp, c_fp, C.c_int, C.c_float, c_dp, c_fp]
     L.amx_prep_gather_device.argtypes = [c_vp, c_vp, c_vp, C.c_int, C.c_float, c_vp, c_vp, c_vp]
+    L.amx_prep_gather_device_f32.argtypes = [c_vp, c_vp, c_vp, C.c_int, C.c_float, c_vp, c_vp, c_vp]
+    L.amx_prep_gather_device_f32.restype = C.c_int
     L.amx_prep_mean_b0.argtypes = [c_vp, c_vp, c_fp, c_fp]
     L.amx_prep_mean_b0_device.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp]
     L.amx_prep_scatter.argtypes = [c_vp, c_vp, c_dp, C.c_int, c_fp]
@@ -363,12 +371,18 @@ def _dptr(t):
     return c_vp(t.data_ptr()) if t is not None else None
 
 
+def _dev_fn(model, y_t):
+    """amx_<model>_fit_device for float64 tensors, amx_<model>_fit_device_f32 for float32 ones"""
+    import torch
+    return getattr(lib(), 'amx_%s_fit_device%s' % (model, '_f32' if y_t.dtype == torch.float32 else ''))
+
+
 def _check_dev(lut, y_t, dirs_t=None):
     """the kernels index `y` with the dictionary's nS as the row stride and `DIRs` with stride 3: anything else
     would read foreign memory and return garbage maps without an error"""
     import torch
-    if y_t.dtype != torch.float64 or y_t.dim() != 2 or y_t.shape[1] != lut.nS or not y_t.is_contiguous():
-        raise ValueError(f'y must be a contiguous float64 device tensor [n_vox, {lut.nS}] (the dictionary was built for '
+    if y_t.dtype not in (torch.float64, torch.float32) or y_t.dim() != 2 or y_t.shape[1] != lut.nS or not y_t.is_contiguous():
+        raise ValueError(f'y must be a contiguous float64 (or float32) device tensor [n_vox, {lut.nS}] (the dictionary was built for '
                          f'{lut.nS} volumes per voxel)')
     if dirs_t is not None and (dirs_t.dtype != torch.float64 or tuple(dirs_t.shape) != (y_t.shape[0], 3)
                                or not dirs_t.is_contiguous() or dirs_t.device != y_t.device):
@@ -398,7 +412,7 @@ def noddi_fit_device(ctx, lut, y_t, dirs_t, lambda1, lambda2, n_maps, rmse=False
     r = torch.empty(n, **f64) if rmse else None
     nr = torch.empty(n, **f64) if nrmse else None
     md = torch.empty((n, 2), **f64) if mod else None
-    ctx.check(lib().amx_noddi_fit_device(ctx._h, lut._h, _dptr(y_t), _dptr(dirs_t), n, float(lambda1), float(lambda2), flags,
+    ctx.check(_dev_fn('noddi', y_t)(ctx._h, lut._h, _dptr(y_t), _dptr(dirs_t), n, float(lambda1), float(lambda2), flags,
                                          _dptr(est), _dptr(r), _dptr(nr), _dptr(md), c_vp(stream or 0)))
     return (est, r, nr, md, xd) if return_x else (est, r, nr, md)
 
@@ -414,7 +428,7 @@ def freewater_fit_device(ctx, lut, y_t, dirs_t, lambda1, lambda2, is_mouse, rmse
     r = torch.empty(n, **f64) if rmse else None
     nr = torch.empty(n, **f64) if nrmse else None
     yc = torch.empty((n, lut.nS), **f64) if corrected else None
-    ctx.check(lib().amx_freewater_fit_device(ctx._h, lut._h, _dptr(y_t), _dptr(dirs_t), n, float(lambda1), float(lambda2),
+    ctx.check(_dev_fn('freewater', y_t)(ctx._h, lut._h, _dptr(y_t), _dptr(dirs_t), n, float(lambda1), float(lambda2),
                                              int(bool(is_mouse)), flags, _dptr(est), _dptr(r), _dptr(nr), _dptr(yc),
                                              c_vp(stream or 0)))
     return (est, r, nr, yc, xd) if return_x else (est, r, nr, yc)
@@ -429,7 +443,7 @@ def czb_fit_device(ctx, lut, y_t, dirs_t, lambda1, lambda2, rmse=False, nrmse=Fa
     est = torch.empty((n, 3), **f64)
     r = torch.empty(n, **f64) if rmse else None
     nr = torch.empty(n, **f64) if nrmse else None
-    ctx.check(lib().amx_czb_fit_device(ctx._h, lut._h, _dptr(y_t), _dptr(dirs_t), n, float(lambda1), float(lambda2), flags,
+    ctx.check(_dev_fn('czb', y_t)(ctx._h, lut._h, _dptr(y_t), _dptr(dirs_t), n, float(lambda1), float(lambda2), flags,
                                        _dptr(est), _dptr(r), _dptr(nr), c_vp(stream or 0)))
     return (est, r, nr, xd) if return_x else (est, r, nr)
 
@@ -443,7 +457,7 @@ def sandi_fit_device(ctx, lut, y_t, lambda1, lambda2, rmse=False, nrmse=False, s
     est = torch.empty((n, 6), **f64)
     r = torch.empty(n, **f64) if rmse else None
     nr = torch.empty(n, **f64) if nrmse else None
-    ctx.check(lib().amx_sandi_fit_device(ctx._h, lut._h, _dptr(y_t), n, float(lambda1), float(lambda2), flags, _dptr(est),
+    ctx.check(_dev_fn('sandi', y_t)(ctx._h, lut._h, _dptr(y_t), n, float(lambda1), float(lambda2), flags, _dptr(est),
                                          _dptr(r), _dptr(nr), c_vp(stream or 0)))
     return (est, r, nr, xd) if return_x else (est, r, nr)
 
@@ -486,10 +500,10 @@ class Dti:
         self.ctx.check(lib().amx_dti_directions(self.ctx._h, self._h, _p(y, c_dp), y.shape[0], _p(out, c_dp)))
         return out
 
-    def directions_device(self, d_y, n_vox, d_dirs, stream=None):
-        """device pointers (ints), enqueued on `stream`; check with ctx.sync(stream)."""
-        self.ctx.check(lib().amx_dti_directions_device(self.ctx._h, self._h, c_vp(d_y), int(n_vox), c_vp(d_dirs),
-                                                       c_vp(stream or 0)))
+    def directions_device(self, d_y, n_vox, d_dirs, stream=None, f32=False):
+        """device pointers (ints), enqueued on `stream`; check with ctx.sync(stream).  f32: d_y holds float32 signals."""
+        fn = lib().amx_dti_directions_device_f32 if f32 else lib().amx_dti_directions_device
+        self.ctx.check(fn(self.ctx._h, self._h, c_vp(d_y), int(n_vox), c_vp(d_dirs), c_vp(stream or 0)))
 
 
 class Prep:

@@ -61,7 +61,7 @@ class Evaluation:
     @property
     def y(self):
         if self._y is None and self._dev is not None:
-            self._y = self._dev['y'].cpu().numpy()
+            self._y = self._dev['y'].cpu().numpy().astype(np.float64, copy=False)      # (held as float32 in HBM: core.py:451-452 widen)
         return self._y
 
     @y.setter
@@ -202,7 +202,9 @@ class Evaluation:
         img = self.niiDWI_img
         d_img = torch.from_numpy(np.lib.stride_tricks.as_strided(img, shape=(plan.extent,), strides=(4,))).to(dev)
         n = self._prep.n_vox
-        d_y = torch.empty((n, self._prep.n_out), dtype=torch.float64, device=dev)
+        # the prepared signals stay float32 in HBM (every value of core.py:209-268 is a float32; core.py:451-452 only widen them):
+        # the tensor fit and the model fit read them in place, half the bytes of the float64 rows
+        d_y = torch.empty((n, self._prep.n_out), dtype=torch.float32, device=dev)
         d_mb0 = torch.empty(n, dtype=torch.float32, device=dev)
         thr = 0.0
         if self._prep.do_normalize and self._prep.b0_min_signal != 0.0:              # core.py:217
@@ -210,7 +212,7 @@ class Evaluation:
             ctx.check(L.amx_prep_mean_b0_device(ctx._h, plan._h, d_img.data_ptr(), d_vol.data_ptr(), None))
             mean_b0s = d_vol.cpu().numpy()
             thr = float(self._prep.b0_min_signal * mean_b0s[mean_b0s > 0].mean())
-        ctx.check(L.amx_prep_gather_device(ctx._h, plan._h, d_img.data_ptr(), int(self._prep.do_normalize), thr,
+        ctx.check(L.amx_prep_gather_device_f32(ctx._h, plan._h, d_img.data_ptr(), int(self._prep.do_normalize), thr,
                                            d_y.data_ptr(), d_mb0.data_ptr(), None))  # core.py:209-268 + 451-452
         # precompute directions (core.py:428-458)
         d_dirs = None
@@ -223,7 +225,7 @@ class Evaluation:
                 raise NotImplementedError('only the default DTI_fit_method (OLS) runs on the GPU')
             est = _dti.TensorDirections.from_scheme(self._raw_scheme, do_merge_b0=self.get_config('doMergeB0'), ctx=ctx)
             d_dirs = torch.empty((n, 3), dtype=torch.float64, device=dev)
-            est.fit_device(d_y.data_ptr(), n, d_dirs.data_ptr())
+            est.fit_device(d_y.data_ptr(), n, d_dirs.data_ptr(), f32=True)
         ctx.sync()
         del d_img
         self._y, self._DIRs = None, None

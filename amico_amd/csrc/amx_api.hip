@@ -211,7 +211,7 @@ void amx_ctx_destroy(amx_ctx *ctx)
     hipDeviceSynchronize();
     DevBuf *bufs[] = {&ctx->lutidx, &ctx->perm, &ctx->counts, &ctx->dir_start, &ctx->cursor, &ctx->chunks,
                       &ctx->misc, &ctx->xiso, &ctx->supp, &ctx->ovf, &ctx->cproj, &ctx->hy, &ctx->hdirs, &ctx->hest,
-                      &ctx->hrmse, &ctx->hnrmse, &ctx->hextra, &ctx->hy32, &ctx->ytil, &ctx->seeds, &ctx->schunks, &ctx->ytil2, &ctx->seeds2, &ctx->cgemm, &ctx->done, &ctx->rlist, &ctx->cgemm2};
+                      &ctx->hrmse, &ctx->hnrmse, &ctx->hextra, &ctx->hy32, &ctx->wy, &ctx->ytil, &ctx->seeds, &ctx->schunks, &ctx->ytil2, &ctx->seeds2, &ctx->cgemm, &ctx->done, &ctx->rlist, &ctx->cgemm2};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     for (DevBuf &b : ctx->alt) if (b.p) hipFree(b.p);
     if (ctx->status_d) hipFree(ctx->status_d);
@@ -540,7 +540,7 @@ int amx_last_stats(amx_ctx *ctx, int64_t out[4])
 }
 
 // ------------------------------------------------------------------ NODDI
-int amx_noddi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, const double *d_dirs,
+static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, const float *d_y32, const double *d_dirs,
                          int64_t n_vox, double lambda1, double lambda2, unsigned flags,
                          double *d_estimates, double *d_rmse, double *d_nrmse, double *d_mod,
                          void *hip_stream)
@@ -549,7 +549,7 @@ int amx_noddi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
     if (!lut || lut->model != 1 || lut->ctx != ctx) return bad(ctx, "amx_noddi_fit: not a NODDI dictionary of this ctx");
     if (n_vox < 0 || n_vox > INT_MAX / 4) return bad(ctx, "amx_noddi_fit: bad n_vox");
     if (n_vox == 0) return AMX_OK;
-    if (!d_y || !d_dirs || !d_estimates) return bad(ctx, "amx_noddi_fit: null buffer");
+    if ((!d_y && !d_y32) || !d_dirs || !d_estimates) return bad(ctx, "amx_noddi_fit: null buffer");
     if (((flags & AMX_F_RMSE) && !d_rmse) || ((flags & AMX_F_NRMSE) && !d_nrmse) || ((flags & AMX_F_MODULATED) && !d_mod))
         return bad(ctx, "amx_noddi_fit: flag set but output buffer is null");
     if (!(lambda2 >= 0.0) || !(lambda1 >= 0.0)) return bad(ctx, "amx_noddi_fit: need lambda1 >= 0 and lambda2 >= 0");
@@ -565,7 +565,7 @@ int amx_noddi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
     if ((rc = enqueue_bucketing(ctx, lut, d_dirs, n_vox, pl, s))) return rc;
     NoddiArgs a;
     memset(&a, 0, sizeof a);
-    a.c.tiles = lut->tiles; a.c.y = d_y; a.c.perm = pl.perm; a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks;
+    a.c.tiles = lut->tiles; a.c.y = d_y; a.c.y32 = d_y32; a.c.perm = pl.perm; a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks;
     a.c.lutidx = pl.lutidx; a.c.status = ctx->status_d; a.c.nS = lut->nS; a.c.ldA = lut->ldA;
     a.c.n_atoms = lut->n_atoms; a.c.tile_stride = lut->tile_stride; a.c.lam1 = lambda1; a.c.lam2 = lambda2; a.c.flags = flags;
     a.rowdwi = lut->rowdwi; a.colscale = lut->colscale; a.icvf = lut->icvf; a.kappa = lut->kappa;
@@ -648,7 +648,7 @@ int amx_noddi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
 }
 
 // ------------------------------------------------------------------ FreeWater
-int amx_freewater_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y,
+static int freewater_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, const float *d_y32,
                              const double *d_dirs, int64_t n_vox, double lambda1, double lambda2,
                              int is_mouse, unsigned flags, double *d_estimates, double *d_rmse,
                              double *d_nrmse, double *d_ycorr, void *hip_stream)
@@ -657,7 +657,7 @@ int amx_freewater_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y
     if (!lut || lut->model != 2 || lut->ctx != ctx) return bad(ctx, "amx_freewater_fit: not a FreeWater dictionary of this ctx");
     if (n_vox < 0 || n_vox > INT_MAX / 4) return bad(ctx, "amx_freewater_fit: bad n_vox");
     if (n_vox == 0) return AMX_OK;
-    if (!d_y || !d_dirs || !d_estimates) return bad(ctx, "amx_freewater_fit: null buffer");
+    if ((!d_y && !d_y32) || !d_dirs || !d_estimates) return bad(ctx, "amx_freewater_fit: null buffer");
     if (((flags & AMX_F_RMSE) && !d_rmse) || ((flags & AMX_F_NRMSE) && !d_nrmse) || ((flags & AMX_F_CORRECTED) && !d_ycorr))
         return bad(ctx, "amx_freewater_fit: flag set but output buffer is null");
     if (!(lambda2 >= 0.0) || !(lambda1 >= 0.0)) return bad(ctx, "amx_freewater_fit: need lambda1 >= 0 and lambda2 >= 0");
@@ -671,7 +671,7 @@ int amx_freewater_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y
     if ((rc = enqueue_bucketing(ctx, lut, d_dirs, n_vox, pl, s, refill ? amx_refill_chunk(ctx, n_vox) : kChunk))) return rc;
     FwArgs a;
     memset(&a, 0, sizeof a);
-    a.c.tiles = lut->tiles; a.c.y = d_y; a.c.perm = pl.perm; a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks;
+    a.c.tiles = lut->tiles; a.c.y = d_y; a.c.y32 = d_y32; a.c.perm = pl.perm; a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks;
     a.c.lutidx = pl.lutidx; a.c.status = ctx->status_d; a.c.nS = lut->nS; a.c.ldA = lut->ldA;
     a.c.n_atoms = lut->n_atoms; a.c.tile_stride = lut->tile_stride; a.c.lam1 = lambda1; a.c.lam2 = lambda2; a.c.flags = flags;
     a.n_perp = lut->n_perp; a.n_iso = lut->n_iso; a.is_mouse = is_mouse; a.n_maps = is_mouse ? 4 : 2;
@@ -692,7 +692,7 @@ int amx_freewater_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y
 }
 
 // ------------------------------------------------------------------ SANDI
-int amx_sandi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, int64_t n_vox,
+static int sandi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, const float *d_y32, int64_t n_vox,
                          double lambda1, double lambda2, unsigned flags, double *d_estimates,
                          double *d_rmse, double *d_nrmse, void *hip_stream)
 {
@@ -700,7 +700,7 @@ int amx_sandi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, in
     if (!lut || lut->model != 3 || lut->ctx != ctx) return bad(ctx, "amx_sandi_fit: not a SANDI dictionary of this ctx");
     if (n_vox < 0 || n_vox > INT_MAX / 4) return bad(ctx, "amx_sandi_fit: bad n_vox");
     if (n_vox == 0) return AMX_OK;
-    if (!d_y || !d_estimates) return bad(ctx, "amx_sandi_fit: null buffer");
+    if ((!d_y && !d_y32) || !d_estimates) return bad(ctx, "amx_sandi_fit: null buffer");
     if (((flags & AMX_F_RMSE) && !d_rmse) || ((flags & AMX_F_NRMSE) && !d_nrmse))
         return bad(ctx, "amx_sandi_fit: flag set but output buffer is null");
     if (!(lambda2 >= 0.0) || !(lambda1 >= 0.0)) return bad(ctx, "amx_sandi_fit: need lambda1 >= 0 and lambda2 >= 0");
@@ -714,7 +714,7 @@ int amx_sandi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, in
     hipLaunchKernelGGL(k_plan_linear, dim3(nb), dim3(256), 0, s, (int)n_vox, kChunk, pl.chunks, pl.n_chunks, pl.perm);
     SandiArgs a;
     memset(&a, 0, sizeof a);
-    a.c.tiles = lut->tiles; a.c.y = d_y; a.c.perm = pl.perm; a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks;
+    a.c.tiles = lut->tiles; a.c.y = d_y; a.c.y32 = d_y32; a.c.perm = pl.perm; a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks;
     a.c.lutidx = pl.lutidx; a.c.status = ctx->status_d; a.c.nS = lut->nS; a.c.ldA = lut->ldA;
     a.c.n_atoms = lut->n_atoms; a.c.tile_stride = lut->tile_stride; a.c.lam1 = lambda1; a.c.lam2 = lambda2; a.c.flags = flags;
     a.norms = lut->norms; a.Rs = lut->Rs; a.d_in = lut->d_in; a.d_isos = lut->d_isos;
@@ -734,7 +734,7 @@ int amx_sandi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, in
 }
 
 // ------------------------------------------------------------------ CylinderZeppelinBall
-int amx_czb_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, const double *d_dirs, int64_t n_vox,
+static int czb_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, const float *d_y32, const double *d_dirs, int64_t n_vox,
                        double lambda1, double lambda2, unsigned flags, double *d_estimates, double *d_rmse,
                        double *d_nrmse, void *hip_stream)
 {
@@ -742,7 +742,7 @@ int amx_czb_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, cons
     if (!lut || lut->model != 4 || lut->ctx != ctx) return bad(ctx, "amx_czb_fit: not a CylinderZeppelinBall dictionary of this ctx");
     if (n_vox < 0 || n_vox > INT_MAX / 4) return bad(ctx, "amx_czb_fit: bad n_vox");
     if (n_vox == 0) return AMX_OK;
-    if (!d_y || !d_dirs || !d_estimates) return bad(ctx, "amx_czb_fit: null buffer");
+    if ((!d_y && !d_y32) || !d_dirs || !d_estimates) return bad(ctx, "amx_czb_fit: null buffer");
     if (((flags & AMX_F_RMSE) && !d_rmse) || ((flags & AMX_F_NRMSE) && !d_nrmse))
         return bad(ctx, "amx_czb_fit: flag set but output buffer is null");
     // the Gram-space solver needs the ridge (models.pyx:439 default: 4.0)
@@ -755,7 +755,7 @@ int amx_czb_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, cons
     if ((rc = enqueue_bucketing(ctx, lut, d_dirs, n_vox, pl, s))) return rc;
     CzbArgs a;
     memset(&a, 0, sizeof a);
-    a.c.tiles = lut->tiles; a.c.y = d_y; a.c.perm = pl.perm; a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks;
+    a.c.tiles = lut->tiles; a.c.y = d_y; a.c.y32 = d_y32; a.c.perm = pl.perm; a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks;
     a.c.lutidx = pl.lutidx; a.c.status = ctx->status_d; a.c.nS = lut->nS; a.c.ldA = lut->ldA;
     a.c.n_atoms = lut->n_atoms; a.c.tile_stride = lut->tile_stride; a.c.lam1 = lambda1; a.c.lam2 = lambda2; a.c.flags = flags;
     a.n_rs = lut->n_rs; a.n_perp = lut->n_perp; a.Rs = lut->Rs; a.gram = lut->gram; a.ldG = lut->ldG;
@@ -771,6 +771,81 @@ int amx_czb_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, cons
     rec(ctx, 1, s);
     if (!rc) progress_tick(ctx, s, n_vox, n_vox);
     return rc;
+}
+
+// ---- public device-pointer entry points: float64 signals, or the float32 the image holds (core.py:136; lossless).  float32 is
+// read in place by the NODDI kernels, by every wavefront-per-voxel kernel and by FreeWater's matrix-core projection; the other
+// lane kernels get a float64 copy made on the device first.
+static int widen_on_device(amx_ctx *ctx, const float *d_y32, size_t nel, hipStream_t s, const double **out)
+{
+    int rc;
+    if ((rc = ensure(ctx, ctx->wy, nel * sizeof(double)))) return rc;
+    hipLaunchKernelGGL(k_widen, dim3((unsigned)((nel / 4 + 256) / 256)), dim3(256), 0, s, d_y32, (double *)ctx->wy.p, nel);
+    HIPCHK(ctx, hipGetLastError());
+    *out = (const double *)ctx->wy.p;
+    return AMX_OK;
+}
+
+int amx_noddi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, const double *d_dirs, int64_t n_vox, double lambda1,
+                         double lambda2, unsigned flags, double *d_estimates, double *d_rmse, double *d_nrmse, double *d_mod, void *hip_stream)
+{
+    return noddi_fit_dev(ctx, lut, d_y, nullptr, d_dirs, n_vox, lambda1, lambda2, flags, d_estimates, d_rmse, d_nrmse, d_mod, hip_stream);
+}
+
+int amx_noddi_fit_device_f32(amx_ctx *ctx, const amx_lut *lut, const float *d_y, const double *d_dirs, int64_t n_vox, double lambda1,
+                             double lambda2, unsigned flags, double *d_estimates, double *d_rmse, double *d_nrmse, double *d_mod, void *hip_stream)
+{
+    return noddi_fit_dev(ctx, lut, nullptr, d_y, d_dirs, n_vox, lambda1, lambda2, flags, d_estimates, d_rmse, d_nrmse, d_mod, hip_stream);
+}
+
+int amx_freewater_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, const double *d_dirs, int64_t n_vox, double lambda1,
+                             double lambda2, int is_mouse, unsigned flags, double *d_estimates, double *d_rmse, double *d_nrmse,
+                             double *d_ycorr, void *hip_stream)
+{
+    return freewater_fit_dev(ctx, lut, d_y, nullptr, d_dirs, n_vox, lambda1, lambda2, is_mouse, flags, d_estimates, d_rmse, d_nrmse, d_ycorr, hip_stream);
+}
+
+int amx_freewater_fit_device_f32(amx_ctx *ctx, const amx_lut *lut, const float *d_y, const double *d_dirs, int64_t n_vox, double lambda1,
+                                 double lambda2, int is_mouse, unsigned flags, double *d_estimates, double *d_rmse, double *d_nrmse,
+                                 double *d_ycorr, void *hip_stream)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!lut || lut->model != 2 || !d_y || n_vox <= 0 || amx_fw_native_f32(ctx, lut->n_atoms, lut->nS, flags | (ctx->opt_cold_start ? 0x80000000u : 0u), lambda2))
+        return freewater_fit_dev(ctx, lut, nullptr, d_y, d_dirs, n_vox, lambda1, lambda2, is_mouse, flags, d_estimates, d_rmse, d_nrmse, d_ycorr, hip_stream);
+    const double *wide; int rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if ((rc = widen_on_device(ctx, d_y, (size_t)n_vox * lut->nS, (hipStream_t)hip_stream, &wide))) return rc;
+    return freewater_fit_dev(ctx, lut, wide, nullptr, d_dirs, n_vox, lambda1, lambda2, is_mouse, flags, d_estimates, d_rmse, d_nrmse, d_ycorr, hip_stream);
+}
+
+int amx_sandi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, int64_t n_vox, double lambda1, double lambda2,
+                         unsigned flags, double *d_estimates, double *d_rmse, double *d_nrmse, void *hip_stream)
+{
+    return sandi_fit_dev(ctx, lut, d_y, nullptr, n_vox, lambda1, lambda2, flags, d_estimates, d_rmse, d_nrmse, hip_stream);
+}
+
+int amx_sandi_fit_device_f32(amx_ctx *ctx, const amx_lut *lut, const float *d_y, int64_t n_vox, double lambda1, double lambda2,
+                             unsigned flags, double *d_estimates, double *d_rmse, double *d_nrmse, void *hip_stream)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!lut || lut->model != 3 || !d_y || n_vox <= 0 || !amx_use_lane_solver(ctx, lut->n_atoms, lambda2))
+        return sandi_fit_dev(ctx, lut, nullptr, d_y, n_vox, lambda1, lambda2, flags, d_estimates, d_rmse, d_nrmse, hip_stream);
+    const double *wide; int rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if ((rc = widen_on_device(ctx, d_y, (size_t)n_vox * lut->nS, (hipStream_t)hip_stream, &wide))) return rc;
+    return sandi_fit_dev(ctx, lut, wide, nullptr, n_vox, lambda1, lambda2, flags, d_estimates, d_rmse, d_nrmse, hip_stream);
+}
+
+int amx_czb_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, const double *d_dirs, int64_t n_vox, double lambda1,
+                       double lambda2, unsigned flags, double *d_estimates, double *d_rmse, double *d_nrmse, void *hip_stream)
+{
+    return czb_fit_dev(ctx, lut, d_y, nullptr, d_dirs, n_vox, lambda1, lambda2, flags, d_estimates, d_rmse, d_nrmse, hip_stream);
+}
+
+int amx_czb_fit_device_f32(amx_ctx *ctx, const amx_lut *lut, const float *d_y, const double *d_dirs, int64_t n_vox, double lambda1,
+                           double lambda2, unsigned flags, double *d_estimates, double *d_rmse, double *d_nrmse, void *hip_stream)
+{
+    return czb_fit_dev(ctx, lut, nullptr, d_y, d_dirs, n_vox, lambda1, lambda2, flags, d_estimates, d_rmse, d_nrmse, hip_stream);   // k_czb: load_rows
 }
 
 }  // extern "C"

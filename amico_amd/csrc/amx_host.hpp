@@ -39,6 +39,7 @@ struct amx_ctx {
     double *dbg_x = nullptr;       // AMX_F_DEBUG_X destination (caller-owned device buffer, amx_set_debug_x)
     void (*progress)(int64_t, int64_t, void *) = nullptr;   // amx_set_progress
     void *progress_user = nullptr;
+    DevBuf wy;                     // float64 copy of float32 device signals for the lane kernels that read float64 only (amx_*_fit_device_f32)
     DevBuf hy32;                   // float32 signals of the *_fit_f32 entry points
     hipStream_t hs = nullptr;      // non-blocking compute streams of the chunked host entry points: batches alternate
     hipStream_t hs2 = nullptr;     // between the two, so the tail of one batch's kernels is filled by the next batch's
@@ -235,7 +236,15 @@ static inline bool amx_fw_use_refill(const amx_ctx *ctx, int n_atoms, int nS, un
     return n_atoms <= 12 && (flags & (AMX_F_RMSE | AMX_F_NRMSE | AMX_F_CORRECTED)) == 0 &&
            ((size_t)nS * 12 + 144 + 4 * (16 * 65 + 12 * 64 + 32)) * sizeof(double) + 16 <= 80 * 1024;
 }
+// float32 signals in HBM are read natively by the NODDI kernels, by the wavefront-per-voxel kernels of every model (load_rows) and by
+// FreeWater's matrix-core projection; the other lane kernels get a float64 copy made on the device first (k_widen)
+static inline bool amx_fw_native_f32(const amx_ctx *ctx, int n_atoms, int nS, unsigned flags, double lam2);
 // lane-per-voxel solvers work on H = A'A + lambda2 I (Gram space): they need the ridge to bound cond(H); with
 // lambda2 (nearly) 0 the problem goes to the QR solver in A-space (wavefront per voxel), like the reference's lasso,
 // which accepts any lambda2 >= 0
 static inline bool amx_use_lane_solver(const amx_ctx *ctx, int n_atoms, double lam2) { return n_atoms <= 16 && lam2 >= 1e-9 && !ctx->opt_wave_per_voxel; }
+static inline bool amx_fw_native_f32(const amx_ctx *ctx, int n_atoms, int nS, unsigned flags, double lam2)
+{
+    if (!amx_use_lane_solver(ctx, n_atoms, lam2)) return true;                     // wavefront per voxel: load_rows
+    return amx_fw_use_refill(ctx, n_atoms, nS, flags, lam2) && nS <= 96 && !ctx->opt_fw_proj_valu;
+}

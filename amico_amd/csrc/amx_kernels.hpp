@@ -25,6 +25,7 @@ enum StatusSlot { ST_ERRVOX = 0, ST_II1 = 1, ST_II2 = 2, ST_OVERFLOW = 3, ST_ITC
 struct FitCommon {
     const void *tiles;            // [ndirs][nS][ldA] (float) or [nS][ldA] (double, SANDI)
     const double *y;              // [n_vox][nS]
+    const float *y32;             // the same signals as float32 (the *_fit_device_f32 entry points), or null: then `y` is read
     const int *perm;              // voxels grouped by orientation
     const Chunk *chunks;
     const int *n_chunks;
@@ -71,6 +72,31 @@ __device__ __forceinline__ void stage_noddi_tile(AT *As, const float *__restrict
 {
     if constexpr (std::is_same<AT, double>::value) stage_tile_widen(As, g, words, pad);
     else stage_tile<float>(As, g, words, pad);
+}
+
+// the voxel's signal row, float64 or float32 storage (FitCommon::y / y32; float32 is what the image holds, core.py:136)
+template <int NR>
+__device__ __forceinline__ bool load_rows(const FitCommon &c, int vox, int nS, int lane, double (&yr)[NR])
+{
+    bool finite = true;
+    if (c.y32 != nullptr) {
+        const float *__restrict__ yv = c.y32 + (size_t)vox * nS;
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) {
+            const int i = lane + kWave * rr;
+            yr[rr] = (i < nS) ? (double)yv[i] : 0.0;
+            finite = finite && (fabs(yr[rr]) <= 1.79769313486231570e308);
+        }
+    } else {
+        const double *__restrict__ yv = c.y + (size_t)vox * nS;
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) {
+            const int i = lane + kWave * rr;
+            yr[rr] = (i < nS) ? yv[i] : 0.0;
+            finite = finite && (fabs(yr[rr]) <= 1.79769313486231570e308);
+        }
+    }
+    return ballot64(!finite) == 0ull;
 }
 
 template <int NR>
@@ -143,7 +169,7 @@ __device__ __forceinline__ void noddi_voxel(const NoddiArgs &a, const AT *As, do
     const int nS = a.c.nS, ldA = a.c.ldA, n_atoms = a.c.n_atoms, n_wm = a.n_wm;
     const int iso_atom = n_atoms - 1, dot_atom = a.is_exvivo ? n_atoms - 2 : -1;
     double yr[NR];
-    const bool ok = load_rows<NR>(a.c.y + (size_t)vox * nS, nS, lane, yr);
+    const bool ok = load_rows<NR>(a.c, vox, nS, lane, yr);
     bool rowok[NR];
     double scl[NQ];
     unsigned long long allowed[NQ];
@@ -335,7 +361,7 @@ __device__ __forceinline__ void fw_voxel(const FwArgs &a, const float *As, doubl
 {
     const int nS = a.c.nS, ldA = a.c.ldA, n_atoms = a.c.n_atoms, n_perp = a.n_perp;
     double yr[NR];
-    const bool ok = load_rows<NR>(a.c.y + (size_t)vox * nS, nS, lane, yr);
+    const bool ok = load_rows<NR>(a.c, vox, nS, lane, yr);
     bool rowok[NR];
     double scl[NQ];
     unsigned long long allowed[NQ];
@@ -422,7 +448,7 @@ __device__ __forceinline__ void sandi_voxel(const SandiArgs &a, const double *As
     const int nS = a.c.nS, ldA = a.c.ldA, n_atoms = a.c.n_atoms;
     const int n_rs = a.n_rs, n_in = a.n_in;
     double yr[NR];
-    const bool ok = load_rows<NR>(a.c.y + (size_t)vox * nS, nS, lane, yr);
+    const bool ok = load_rows<NR>(a.c, vox, nS, lane, yr);
     bool rowok[NR];
     double scl[NQ];
     unsigned long long allowed[NQ];
@@ -511,7 +537,7 @@ __device__ __forceinline__ void czb_voxel(const CzbArgs &a, const float *As, dou
 {
     const int nS = a.c.nS, ldA = a.c.ldA, n_atoms = a.c.n_atoms, n_rs = a.n_rs, n_perp = a.n_perp;
     double yr[NR];
-    const bool ok = load_rows<NR>(a.c.y + (size_t)vox * nS, nS, lane, yr);
+    const bool ok = load_rows<NR>(a.c, vox, nS, lane, yr);
     bool rowok[NR];
     double scl[NQ];
     unsigned long long allowed[NQ];

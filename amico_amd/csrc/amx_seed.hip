@@ -43,7 +43,7 @@ int amx_launch_noddi_seed2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a,
 {
     Seed2Args sa;
     memset(&sa, 0, sizeof sa);
-    sa.y = a.c.y; sa.perm = pl.perm; sa.chunks = pl.chunks; sa.n_chunks = pl.n_chunks;
+    sa.y = a.c.y; sa.y32 = a.c.y32; sa.perm = pl.perm; sa.chunks = pl.chunks; sa.n_chunks = pl.n_chunks;
     sa.schunks = pl.schunks; sa.n_schunks = pl.n_chunks + 1;
     sa.tiles = (const float *)lut->tiles; sa.tile_stride = lut->tile_stride; sa.ldA = lut->ldA;
     sa.rowdwi = lut->rowdwi; sa.xiso = a.xiso; sa.Ub = lut->basis2_U; sa.Sb = lut->basis2_S;
@@ -74,7 +74,7 @@ int amx_launch_noddi_seed2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a,
 static void fill(SeedArgs &sa, const amx_lut *lut, const NoddiArgs &a, const Plan &pl, amx_ctx *ctx)
 {
     memset(&sa, 0, sizeof sa);
-    sa.y = a.c.y; sa.perm = pl.perm; sa.chunks = pl.chunks; sa.n_chunks = pl.n_chunks;
+    sa.y = a.c.y; sa.y32 = a.c.y32; sa.perm = pl.perm; sa.chunks = pl.chunks; sa.n_chunks = pl.n_chunks;
     sa.schunks = pl.schunks; sa.n_schunks = pl.n_chunks + 1;
     sa.Ub = lut->basis_U; sa.Sb = lut->basis_S;
     sa.ytil = (double *)ctx->ytil.p; sa.seeds = (unsigned long long *)ctx->seeds.p;
@@ -90,7 +90,7 @@ int amx_launch_noddi_gemm(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, 
 {
     GemmArgs ga;
     memset(&ga, 0, sizeof ga);
-    ga.y = a.c.y; ga.perm = pl.perm; ga.schunks = pl.schunks; ga.n_schunks = pl.n_chunks + 1;
+    ga.y = a.c.y; ga.y32 = a.c.y32; ga.perm = pl.perm; ga.schunks = pl.schunks; ga.n_schunks = pl.n_chunks + 1;
     ga.tiles = (const float *)lut->tiles; ga.tile_stride = lut->tile_stride; ga.ldA = lut->ldA; ga.nS = lut->nS; ga.n_atoms = lut->n_atoms;
     ga.Ub = lasso ? lut->basis2_U : lut->basis_U; ga.Cb = (double *)(lasso ? ctx->cgemm2.p : ctx->cgemm.p); ga.ytil = (double *)(lasso ? ctx->ytil2.p : ctx->ytil.p);
     ga.xiso = a.xiso; ga.rowdwi = lut->rowdwi; ga.colscale = lut->colscale; ga.iso_atom = lut->n_atoms - 1; ga.is_exvivo = lut->is_exvivo; ga.n_wm = lut->n_wm;

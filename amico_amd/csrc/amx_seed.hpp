@@ -130,6 +130,7 @@ __global__ void __launch_bounds__(256) k_build_basis(const float *__restrict__ t
 // ------------------------------------------------------------------ y~ = U'y (wavefront per voxel, lane = signal rows)
 struct SeedArgs {
     const double *y;              // [n_vox][nS]
+    const float *y32;             // float32 signals instead (or null)
     const int *perm;
     const Chunk *chunks;          // 256-voxel chunks of the solver kernels (projection)
     const int *n_chunks;
@@ -163,10 +164,10 @@ __global__ void __launch_bounds__(1024) k_noddi_project(const SeedArgs a)
     }
     for (int k = wave; k < ck.count; k += nw) {
         const int pos = ck.start + k;
-        const double *yv = a.y + (size_t)a.perm[pos] * nS;
+        const size_t yo = (size_t)a.perm[pos] * nS;
         double yr[NR];
 #pragma unroll
-        for (int rr = 0; rr < NR; rr++) { const int i = lane + kWave * rr; yr[rr] = (i < nS) ? yv[i] : 0.0; }
+        for (int rr = 0; rr < NR; rr++) { const int i = lane + kWave * rr; yr[rr] = (i < nS) ? (a.y32 ? (double)a.y32[yo + i] : a.y[yo + i]) : 0.0; }
         double out = 0.0;
 #pragma unroll
         for (int b = 0; b < KD; b += 4) {
@@ -704,6 +705,7 @@ struct GemmArgs {
     const double *colscale;       // [n_atoms]
     int iso_atom, is_exvivo, n_wm;
     const double *y;              // [n_vox][nS]
+    const float *y32;             // float32 signals instead (or null)
     const int *perm;
     const Chunk *schunks;         // pad = first block of the chunk
     const int *n_schunks;
@@ -765,9 +767,15 @@ __global__ void __launch_bounds__(256, 2) k_noddi_gemm(const GemmArgs a)
     auto issue = [&](int g) {
         const int k = 16 * g + c16;
         const int vox = a.perm[ck.start + (k < ck.count ? k : ck.count - 1)];
-        const double *yv = a.y + (size_t)vox * nS + q;
+        if (a.y32 != nullptr) {
+            const float *yv = a.y32 + (size_t)vox * nS + q;
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) bn[ks] = (4 * ks + q < nS) ? yv[4 * ks] : 0.0;
+            for (int ks = 0; ks < KS; ks++) bn[ks] = (4 * ks + q < nS) ? (double)yv[4 * ks] : 0.0;
+        } else {
+            const double *yv = a.y + (size_t)vox * nS + q;
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) bn[ks] = (4 * ks + q < nS) ? yv[4 * ks] : 0.0;
+        }
         if (LASSO) { xi_n = a.xiso[(size_t)vox * 2]; xd_n = a.is_exvivo ? a.xiso[(size_t)vox * 2 + 1] : 0.0; }
     };
     if (wave < n_groups) issue(wave);
@@ -1381,6 +1389,7 @@ constexpr int kSeed2KD = 8;       // components the LASSO seed solver works with
 constexpr int kSeed2Ld = kSeedKD; // stride of U2 / S2 / y2~ rows
 struct Seed2Args {
     const double *y;              // [n_vox][nS]
+    const float *y32;             // float32 signals instead (or null)
     const int *perm;
     const Chunk *chunks;
     const int *n_chunks;
@@ -1423,7 +1432,7 @@ __global__ void __launch_bounds__(1024) k_noddi_project2(const Seed2Args a)
     for (int k = wave; k < ck.count; k += nw) {
         const int pos = ck.start + k;
         const int vox = a.perm[pos];
-        const double *yv = a.y + (size_t)vox * nS;
+        const size_t yo = (size_t)vox * nS;
         const double xi = a.xiso[(size_t)vox * 2], xd = a.xiso[(size_t)vox * 2 + 1];
         double yr[NR];
 #pragma unroll
@@ -1431,7 +1440,7 @@ __global__ void __launch_bounds__(1024) k_noddi_project2(const Seed2Args a)
             const int i = lane + kWave * rr;
             double t = 0.0;
             if (rowok[rr]) {                      // models.pyx:917-925
-                t = yv[i] - xi * isov[rr];
+                t = (a.y32 ? (double)a.y32[yo + i] : a.y[yo + i]) - xi * isov[rr];
                 if (a.is_exvivo) t -= xd * 1.0;
                 if (t < 0.0) t = 0.0;
             }

@@ -122,8 +122,19 @@ __device__ __forceinline__ void dti_prefetch(double2 (&pre)[kDtiPre], const doub
         else if (e < cnt) pre[i] = make_double2(src[e], 1.0);
     }
 }
+// float32 signals (the image's own dtype, core.py:136): two 4-byte loads per pair (a tile starts at any multiple of 4 bytes)
+__device__ __forceinline__ void dti_prefetch(double2 (&pre)[kDtiPre], const float *__restrict__ src, int cnt, int tid)
+{
+#pragma unroll
+    for (int i = 0; i < kDtiPre; i++) {
+        const int e = 2 * (tid + i * kDtiThreads);
+        if (e + 1 < cnt) pre[i] = make_double2((double)src[e], (double)src[e + 1]);
+        else if (e < cnt) pre[i] = make_double2((double)src[e], 1.0);
+    }
+}
 
-__global__ __launch_bounds__(kDtiThreads, 4) void k_dti_dirs(const double *__restrict__ y, const double *__restrict__ wt,
+template <typename YT>
+__global__ __launch_bounds__(kDtiThreads, 4) void k_dti_dirs(const YT *__restrict__ y, const double *__restrict__ wt,
                                                          int nS, int ldl, int tv, long long n, double min_signal,
                                                          double *__restrict__ dirs)
 {
@@ -247,15 +258,17 @@ void amx_dti_destroy(amx_dti *h)
     delete h;
 }
 
-int amx_dti_directions_device(amx_ctx *ctx, const amx_dti *h, const double *d_y, int64_t n_vox, double *d_dirs,
-                              void *hip_stream)
+}  // extern "C"
+
+template <typename YT>
+static int dti_directions_dev(amx_ctx *ctx, const amx_dti *h, const YT *d_y, int64_t n_vox, double *d_dirs, void *hip_stream)
 {
     if (!ctx) return AMX_E_BADARG;
     if (!h || h->ctx != ctx) return amx_bad(ctx, "amx_dti_directions: not an estimator of this ctx");
     if (n_vox < 0) return amx_bad(ctx, "amx_dti_directions: bad n_vox");
     if (n_vox == 0) return AMX_OK;
     if (!d_y || !d_dirs) return amx_bad(ctx, "amx_dti_directions: null buffer");
-    if (((uintptr_t)d_y & 15) != 0) return amx_bad(ctx, "amx_dti_directions: y must be 16-byte aligned");
+    if (sizeof(YT) == 8 && ((uintptr_t)d_y & 15) != 0) return amx_bad(ctx, "amx_dti_directions: y must be 16-byte aligned");
     hipStream_t s = (hipStream_t)hip_stream;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int nS = h->nS;
@@ -265,9 +278,9 @@ int amx_dti_directions_device(amx_ctx *ctx, const amx_dti *h, const double *d_y,
     tv = tv > kDtiVox ? kDtiVox : (tv & ~1);
     const size_t lds = ((size_t)((nS * 6 + 1) & ~1) + (size_t)tv * ldl + (size_t)kDtiBatch * tv * 7) * sizeof(double);
     if (tv < 2 || lds > 160 * 1024) return amx_bad(ctx, "amx_dti_directions: scheme too long for the LDS tile");
-    static bool attr_set = false;
+    static bool attr_set = false;          // (one flag per instantiation of this function template)
     if (!attr_set) {
-        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_dti_dirs, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_dti_dirs<YT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     const long long n_tiles = (n_vox + tv - 1) / tv;
@@ -275,11 +288,23 @@ int amx_dti_directions_device(amx_ctx *ctx, const amx_dti *h, const double *d_y,
     long long grid = 256LL * (per_cu > 8 ? 8 : per_cu);
     if (grid > n_tiles) grid = n_tiles;
     rec(ctx, 8, s);
-    hipLaunchKernelGGL(k_dti_dirs, dim3((unsigned)grid), dim3(kDtiThreads), lds, s, d_y, h->wt, nS, ldl, tv,
+    hipLaunchKernelGGL(k_dti_dirs<YT>, dim3((unsigned)grid), dim3(kDtiThreads), lds, s, d_y, h->wt, nS, ldl, tv,
                        (long long)n_vox, h->min_signal, d_dirs);
     HIPCHK(ctx, hipGetLastError());
     rec(ctx, 9, s);
     return AMX_OK;
+}
+
+extern "C" {
+
+int amx_dti_directions_device(amx_ctx *ctx, const amx_dti *h, const double *d_y, int64_t n_vox, double *d_dirs, void *hip_stream)
+{
+    return dti_directions_dev<double>(ctx, h, d_y, n_vox, d_dirs, hip_stream);
+}
+
+int amx_dti_directions_device_f32(amx_ctx *ctx, const amx_dti *h, const float *d_y, int64_t n_vox, double *d_dirs, void *hip_stream)
+{
+    return dti_directions_dev<float>(ctx, h, d_y, n_vox, d_dirs, hip_stream);
 }
 
 int amx_dti_directions(amx_ctx *ctx, const amx_dti *h, const double *y, int64_t n_vox, double *out_dirs)

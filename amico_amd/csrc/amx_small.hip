@@ -801,7 +801,10 @@ __global__ void __launch_bounds__(256, AMX_FW_PROJ_OCC) k_fw_project(const FwArg
 typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int kProjKS = 24;                // K-steps of dictionary registers: nS <= 96
 
-template <int N>
+// F32: the signals are float32 in HBM (amx_freewater_fit_device_f32; 260 instead of 520 bytes per voxel): a tile of 16 values
+// of 64 voxels is 4 KB, four lanes fetch the 64 bytes of a voxel, pieces XOR-swizzled by (voxel >> 2) & 3, converted at the
+// operand read.
+template <int N, bool F32>
 __global__ void __launch_bounds__(256, 2) k_fw_project_mfma(const FwArgs a)
 {
     static_assert(N <= 16, "one 16-row MFMA tile of atoms");
@@ -831,22 +834,24 @@ __global__ void __launch_bounds__(256, 2) k_fw_project_mfma(const FwArgs a)
     }
     const int n_pass = nS >> 4;                          // full tiles of 16 signal values
     const int n_batches = (ck.count + 63) >> 6;
-    const int seg = lane & 7, grp = lane >> 3;           // loader role: 8 lanes x 16 B = 128 B of one voxel
+    const int seg = F32 ? (lane & 3) : (lane & 7), grp = F32 ? (lane >> 2) : (lane >> 3);   // loader role: 8 (4) lanes x 16 B = the 128 (64) B of one voxel
+    constexpr int NL = F32 ? 4 : 8;                      // load instructions per tile
     for (int b = wave; b < n_batches; b += nw) {
         const int cnt = min(64, ck.count - (b << 6));
         const int pos0 = ck.start + (b << 6);
         Vb[lane] = a.c.perm[pos0 + min(lane, cnt - 1)];   // (lanes past the end repeat the last voxel; their results are dropped)
-        const double *yl[8];
+        const char *yl[8];                                  // (fixed size: a dependent array type here makes the host pass drop the kernel stub)
 #pragma unroll
-        for (int it = 0; it < 8; it++) {
-            const int vloc = it * 8 + grp;
-            yl[it] = a.c.y + (size_t)Vb[vloc] * nS + 2 * (seg ^ ((vloc >> 1) & 7));
+        for (int it = 0; it < NL; it++) {
+            const int vloc = F32 ? it * 16 + grp : it * 8 + grp;
+            if (F32) yl[it] = reinterpret_cast<const char *>(a.c.y32 + (size_t)Vb[vloc] * nS + 4 * (seg ^ ((vloc >> 2) & 3)));
+            else yl[it] = reinterpret_cast<const char *>(a.c.y + (size_t)Vb[vloc] * nS + 2 * (seg ^ ((vloc >> 1) & 7)));
         }
         auto issue = [&](int p) {
-            double *dst = T + (p & 1) * kTile;
+            char *dst = reinterpret_cast<char *>(T + (p & 1) * kTile);
 #pragma unroll
-            for (int it = 0; it < 8; it++)
-                __builtin_amdgcn_global_load_lds(yl[it] + 16 * p, (__attribute__((address_space(3))) void *)(dst + it * 128), 16, 0, 0);
+            for (int it = 0; it < NL; it++)
+                __builtin_amdgcn_global_load_lds(yl[it] + (F32 ? 64 : 128) * p, (__attribute__((address_space(3))) void *)(dst + it * 1024), 16, 0, 0);
         };
         v4d acc[4];
 #pragma unroll
@@ -857,7 +862,8 @@ __global__ void __launch_bounds__(256, 2) k_fw_project_mfma(const FwArgs a)
             if (p < n_pass) {
                 if (p + 1 < n_pass) {
                     issue(p + 1);
-                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // tile p has landed, tile p + 1 (8 loads) may be in flight
+                    if (F32) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // tile p has landed, tile p + 1 (8 / 4 loads) may be in flight
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
@@ -868,7 +874,8 @@ __global__ void __launch_bounds__(256, 2) k_fw_project_mfma(const FwArgs a)
 #pragma unroll
                     for (int mt = 0; mt < 4; mt++) {
                         const int vloc = mt * 16 + v16;
-                        const double bv = tile[vloc * 16 + ((s2 ^ ((vloc >> 1) & 7)) << 1) + half];
+                        const double bv = F32 ? (double)reinterpret_cast<const float *>(tile)[vloc * 16 + ((kk ^ ((vloc >> 2) & 3)) << 2) + q]
+                                              : tile[vloc * 16 + ((s2 ^ ((vloc >> 1) & 7)) << 1) + half];
                         acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[4 * p + kk], bv, acc[mt], 0, 0, 0);
                     }
                 }
@@ -881,7 +888,8 @@ __global__ void __launch_bounds__(256, 2) k_fw_project_mfma(const FwArgs a)
                     if (16 * p + 4 * kk < nS) {
 #pragma unroll
                         for (int mt = 0; mt < 4; mt++) {
-                            const double bv = (row < nS) ? a.c.y[(size_t)Vb[mt * 16 + v16] * nS + row] : 0.0;
+                            const size_t yo = (size_t)Vb[mt * 16 + v16] * nS + row;
+                            const double bv = (row < nS) ? (F32 ? (double)a.c.y32[yo] : a.c.y[yo]) : 0.0;
                             acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[4 * p + kk], bv, acc[mt], 0, 0, 0);
                         }
                     }
@@ -1160,8 +1168,8 @@ int launch_lane(amx_ctx *ctx, Args &a, const Plan &pl, hipStream_t s, K kern, si
 
 }  // namespace
 
-template <typename KP, typename KM, typename K>
-static int launch_refill(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s, KP proj, KM pmfma, K kern, int N)
+typedef void (*FwKernel)(const FwArgs);
+static int launch_refill(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s, FwKernel proj, FwKernel pmfma, FwKernel pmfma32, FwKernel kern, int N)
 {
     int rc;
     // workspace of the projection: c [ldC][NP], p0 [ldC]
@@ -1172,12 +1180,14 @@ static int launch_refill(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s,
     a.p0 = (unsigned *)((char *)ctx->cproj.p + cbytes);
     const bool mfma = a.c.nS <= 4 * kProjKS && !ctx->opt_fw_proj_valu;
     const size_t lds_p = mfma ? (size_t)4 * (2 * 64 * 16 + 32) * sizeof(double) : project_lds_bytes(a.c.nS, N, 4), lds = refill_lds_bytes(N, 4);
-    if ((rc = set_lds(ctx, proj, lds_p)) || (rc = set_lds(ctx, pmfma, lds_p)) || (rc = set_lds(ctx, kern, lds))) return rc;
+    if ((rc = set_lds(ctx, proj, lds_p)) || (rc = set_lds(ctx, pmfma, lds_p)) || (rc = set_lds(ctx, pmfma32, lds_p)) || (rc = set_lds(ctx, kern, lds))) return rc;
+    if (a.c.y32 != nullptr && !mfma) { ctx->err = "float32 signals need the matrix-core projection (amx_fw_native_f32)"; return AMX_E_BADARG; }
     const dim3 grid(((pl.max_chunks + 7) / 8) * 8);
     a.queue = pl.n_chunks + 60;                            // (misc word 60: zeroed with the plan counters)
     a.sub_per_chunk = (amx_refill_chunk(ctx, (long long)pl.n) + kSubChunk - 1) / kSubChunk;
     rec(ctx, 2, s);
-    if (mfma) hipLaunchKernelGGL(pmfma, grid, dim3(256), lds_p, s, a);
+    if (mfma && a.c.y32 != nullptr) hipLaunchKernelGGL(pmfma32, grid, dim3(256), lds_p, s, a);
+    else if (mfma) hipLaunchKernelGGL(pmfma, grid, dim3(256), lds_p, s, a);
     else hipLaunchKernelGGL(proj, grid, dim3(256), lds_p, s, a);
     AMX_TRACE(ctx, s, "A'y of every voxel");
     hipLaunchKernelGGL(kern, dim3(2 * ctx->n_cu), dim3(256), lds, s, a);
@@ -1225,8 +1235,8 @@ int amx_launch_fw_small(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s)
     // compile-time dictionary sizes: the reference's defaults (11 Human, 12 Mouse) exactly, 16 otherwise
     const int n = a.c.n_atoms;
     if (amx_fw_use_refill(ctx, n, a.c.nS, a.c.flags, a.c.lam2)) {
-        if (n <= 11) return launch_refill(ctx, a, pl, s, k_fw_project<11>, k_fw_project_mfma<11>, k_freewater_refill<11>, 11);
-        return launch_refill(ctx, a, pl, s, k_fw_project<12>, k_fw_project_mfma<12>, k_freewater_refill<12>, 12);
+        if (n <= 11) return launch_refill(ctx, a, pl, s, k_fw_project<11>, k_fw_project_mfma<11, false>, k_fw_project_mfma<11, true>, k_freewater_refill<11>, 11);
+        return launch_refill(ctx, a, pl, s, k_fw_project<12>, k_fw_project_mfma<12, false>, k_fw_project_mfma<12, true>, k_freewater_refill<12>, 12);
     }
     if (n <= 11) return launch_lane(ctx, a, pl, s, k_freewater_lane<11>, sizeof(float), 11);
     if (n == 12) return launch_lane(ctx, a, pl, s, k_freewater_lane<12>, sizeof(float), 12);

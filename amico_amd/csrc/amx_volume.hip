@@ -14,7 +14,7 @@ namespace amx {
 constexpr int kPrepWaves = 2;               // wavefronts per workgroup, one 64-voxel tile each
 
 struct PrepArgs {
-    const float *img; const int *rank; double *y; float *mean_b0;
+    const float *img; const int *rank; double *y; float *y32; float *mean_b0;     // y32: float32 output instead of y (lossless: the values ARE float32)
     long long d0, d1, d2, s0, s1, s2, sv;
     long long n_tiles, tiles_per_row;
     int nS, n_out, n_b0, n_gidx, ldt, inplace, layout, normalize;
@@ -122,10 +122,13 @@ __global__ __launch_bounds__(64 * kPrepWaves) void k_prep_gather(PrepArgs a)
             const int rk = __builtin_amdgcn_readlane(r, k);
             const float fk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, f), k));
             double *dst = a.y + (long long)rk * a.n_out;
+            float *dst32 = a.y32 + (long long)rk * a.n_out;
             for (int j = lane; j < a.n_out; j += 64) {
                 float val = O[k * a.ldt + j];
                 if (scale) val = val * fk;
-                dst[j] = (double)(val < 0.0f ? 0.0f : val);
+                val = val < 0.0f ? 0.0f : val;
+                if (a.y32) dst32[j] = val;
+                else dst[j] = (double)val;
             }
         }
         WAVE_SYNC();
@@ -175,6 +178,7 @@ __global__ __launch_bounds__(256) void k_prep_stream(PrepArgs a)
             f = (m <= a.thr) ? 0.0f : 1.0f / m;
         }
         double *dst = a.y + (long long)r * a.n_out;
+        float *dst32 = a.y32 + (long long)r * a.n_out;
         for (int j = 0; j < a.n_out; j++) {
             const int g0 = Pgp[j], g1 = Pgp[j + 1];
             float acc = 0.0f;
@@ -191,7 +195,9 @@ __global__ __launch_bounds__(256) void k_prep_stream(PrepArgs a)
             }
             for (; g < g1; g++) { const float v = scaled(src[(long long)Pgi[g] * a.sv], f); acc = (g == g0) ? v : acc + v; }
             if (g1 - g0 > 1) acc = acc / (float)(g1 - g0);
-            dst[j] = (double)(acc < 0.0f ? 0.0f : acc);
+            acc = acc < 0.0f ? 0.0f : acc;
+            if (a.y32) dst32[j] = acc;
+            else dst[j] = (double)acc;
         }
     }
 }
@@ -315,19 +321,34 @@ int amx_prep_create(amx_ctx *ctx, const int64_t dims[3], const int64_t strides[4
     return AMX_OK;
 }
 
+static int prep_gather_dev(amx_ctx *ctx, const amx_prep *p, const float *d_img, int normalize, float b0_threshold,
+                           double *d_y, float *d_y32, float *d_mean_b0, void *hip_stream);
+
 int amx_prep_gather_device(amx_ctx *ctx, const amx_prep *p, const float *d_img, int normalize, float b0_threshold,
                            double *d_y, float *d_mean_b0, void *hip_stream)
+{
+    return prep_gather_dev(ctx, p, d_img, normalize, b0_threshold, d_y, nullptr, d_mean_b0, hip_stream);
+}
+
+int amx_prep_gather_device_f32(amx_ctx *ctx, const amx_prep *p, const float *d_img, int normalize, float b0_threshold,
+                               float *d_y, float *d_mean_b0, void *hip_stream)
+{
+    return prep_gather_dev(ctx, p, d_img, normalize, b0_threshold, nullptr, d_y, d_mean_b0, hip_stream);
+}
+
+static int prep_gather_dev(amx_ctx *ctx, const amx_prep *p, const float *d_img, int normalize, float b0_threshold,
+                           double *d_y, float *d_y32, float *d_mean_b0, void *hip_stream)
 {
     if (!ctx) return AMX_E_BADARG;
     if (!p || p->ctx != ctx) return amx_bad(ctx, "amx_prep_gather: not a plan of this ctx");
     if (normalize && p->n_b0 == 0) return amx_bad(ctx, "amx_prep_gather: no b0 volume to normalize signal with");   // core.py:214-215
     if (p->n_vox == 0) return AMX_OK;
-    if (!d_img || !d_y) return amx_bad(ctx, "amx_prep_gather: null buffer");
+    if (!d_img || (!d_y && !d_y32)) return amx_bad(ctx, "amx_prep_gather: null buffer");
     hipStream_t s = (hipStream_t)hip_stream;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     PrepArgs a;
     memset(&a, 0, sizeof a);
-    a.img = d_img; a.rank = p->rank; a.y = d_y; a.mean_b0 = normalize ? d_mean_b0 : nullptr;
+    a.img = d_img; a.rank = p->rank; a.y = d_y; a.y32 = d_y32; a.mean_b0 = normalize ? d_mean_b0 : nullptr;
     a.d0 = p->d[0]; a.d1 = p->d[1]; a.d2 = p->d[2]; a.s0 = p->s[0]; a.s1 = p->s[1]; a.s2 = p->s[2]; a.sv = p->sv;
     a.tiles_per_row = (p->d[0] + 63) / 64;
     a.n_tiles = a.tiles_per_row * p->d[1] * p->d[2];

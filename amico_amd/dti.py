@@ -80,5 +80,5 @@ class TensorDirections:
         """y [n_vox, nS] -> directions f64[n_vox, 3]."""
         return self._dti.directions(y)
 
-    def fit_device(self, d_y, n_vox, d_dirs, stream=None):
-        self._dti.directions_device(d_y, n_vox, d_dirs, stream)
+    def fit_device(self, d_y, n_vox, d_dirs, stream=None, f32=False):
+        self._dti.directions_device(d_y, n_vox, d_dirs, stream, f32=f32)

@@ -33,7 +33,7 @@ class NoddiVolumePipeline:
         n = self.prep.n_vox
         self.n_vox, self.shape = n, tuple(img_like.shape[:3])
         f64 = dict(dtype=torch.float64, device=self.dev)
-        self.y = torch.empty((n, scheme.nS), **f64)
+        self.y = torch.empty((n, scheme.nS), dtype=torch.float32, device=self.dev)      # float32 like the image (core.py:136)
         self.dirs = torch.empty((n, 3), **f64)
         self.est = torch.empty((n, 3), **f64)
         self.mean_b0 = torch.empty(n, dtype=torch.float32, device=self.dev)
@@ -44,10 +44,10 @@ class NoddiVolumePipeline:
         """d_img: torch float32 tensor holding the image's element buffer (same strides as `img_like`)"""
         L, c, p = _capi.lib(), self.ctx, self.prep._plan
         s = _capi.c_vp(stream or 0)
-        c.check(L.amx_prep_gather_device(c._h, p._h, d_img.data_ptr(), int(self.prep.do_normalize), 0.0,
+        c.check(L.amx_prep_gather_device_f32(c._h, p._h, d_img.data_ptr(), int(self.prep.do_normalize), 0.0,
                                          self.y.data_ptr(), self.mean_b0.data_ptr(), s))
-        self.tensor.fit_device(self.y.data_ptr(), self.n_vox, self.dirs.data_ptr(), stream)
-        c.check(L.amx_noddi_fit_device(c._h, self.lut._h, self.y.data_ptr(), self.dirs.data_ptr(), self.n_vox,
+        self.tensor.fit_device(self.y.data_ptr(), self.n_vox, self.dirs.data_ptr(), stream, f32=True)
+        c.check(L.amx_noddi_fit_device_f32(c._h, self.lut._h, self.y.data_ptr(), self.dirs.data_ptr(), self.n_vox,
                                        self.lambda1, self.lambda2, 0, self.est.data_ptr(), None, None, None, s))
         c.check(L.amx_prep_scatter_device(c._h, p._h, self.est.data_ptr(), 3, self.maps.data_ptr(), s))
         c.check(L.amx_prep_scatter_device(c._h, p._h, self.dirs.data_ptr(), 3, self.dirs_vol.data_ptr(), s))

@@ -147,6 +147,31 @@ def small_model(model, n, steps, warmup, cpu=True, host_legs=True):
                         'kernel': kernel, 'kernel_ms': kms, 'bytes_per_voxel': bpv},
            'parity': {'sample_voxels': m, 'max_abs_dmap': float(diff.max()), 'max_rel_dmap': float(rel.max())},
            'solver_stats': ctx.last_stats()}
+    if model == 'freewater':
+        # the same fit on float32 signals in HBM (amx_freewater_fit_device_f32: the image's own dtype, 260 B rows): reported beside
+        # the float64 figure, never as `value` (BASELINE's boundary dtype is float64)
+        y32 = y.to(torch.float32)
+        est32 = torch.zeros_like(est)
+
+        def step32():
+            ctx.check(L.amx_freewater_fit_device_f32(ctx._h, lut._h, y32.data_ptr(), d.data_ptr(), n, 0.0, 1e-3, 0, 0,
+                                                     est32.data_ptr(), None, None, None, None))
+        for _ in range(warmup):
+            step32(); ctx.sync()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        k32 = 0.0
+        for _ in range(steps):
+            step32(); ctx.sync()
+            k32 += ctx.last_kernel_ms(1)
+        torch.cuda.synchronize()
+        el32 = time.perf_counter() - t1
+        bpv32 = 4 * scheme.nS + 24 + 16
+        out['float32_signals_in_hbm'] = {'value': n * steps / el32, 'unit': 'voxels/s', 'ms_per_step': 1e3 * el32 / steps, 'kernel_ms': k32 / steps,
+                                         'bytes_per_voxel': bpv32, 'achieved_GBps': bpv32 * n / (k32 / steps * 1e-3) / 1e9,
+                                         'frac_of_hbm_peak': bpv32 * n / (k32 / steps * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                         'max_abs_dmap_vs_f64_signals': float((est32 - est).abs().max())}
+        del y32, est32
     if model in ('freewater', 'sandi') and host_legs:
         # host numpy in -> host numpy out (pageable memory; PCIe inclusive): the batches of the pipelined entry points hide the
         # solver behind the copies here, so this is a PCIe figure, reported beside the kernels' rate, never as `value`

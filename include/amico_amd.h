@@ -146,6 +146,22 @@ int amx_freewater_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y
 int amx_sandi_fit_device(amx_ctx *ctx, const amx_lut *lut, const double *d_y, int64_t n_vox,
                          double lambda1, double lambda2, unsigned flags, double *d_estimates,
                          double *d_rmse, double *d_nrmse, void *hip_stream);
+/* The same with float32 signals in HBM -- the dtype the image has before core.py:451-452 widen it (core.py:136: float32), so
+ * the maps are bit-identical to the float64 calls on the widened values.  NODDI (A'y GEMM, left-over kernels), every
+ * wavefront-per-voxel kernel, CylinderZeppelinBall and FreeWater's matrix-core projection read the float32 rows in place (FreeWater:
+ * 260 instead of 520 bytes per voxel); for the remaining lane kernels (FreeWater with error maps / corrected signal, SANDI) a float64
+ * copy is made on the device first.                                                                                            */
+int amx_noddi_fit_device_f32(amx_ctx *ctx, const amx_lut *lut, const float *d_y, const double *d_dirs,
+                             int64_t n_vox, double lambda1, double lambda2, unsigned flags,
+                             double *d_estimates, double *d_rmse, double *d_nrmse, double *d_mod, void *hip_stream);
+int amx_freewater_fit_device_f32(amx_ctx *ctx, const amx_lut *lut, const float *d_y, const double *d_dirs, int64_t n_vox,
+                                 double lambda1, double lambda2, int is_mouse, unsigned flags, double *d_estimates,
+                                 double *d_rmse, double *d_nrmse, double *d_ycorr, void *hip_stream);
+int amx_sandi_fit_device_f32(amx_ctx *ctx, const amx_lut *lut, const float *d_y, int64_t n_vox, double lambda1, double lambda2,
+                             unsigned flags, double *d_estimates, double *d_rmse, double *d_nrmse, void *hip_stream);
+int amx_czb_fit_device_f32(amx_ctx *ctx, const amx_lut *lut, const float *d_y, const double *d_dirs, int64_t n_vox,
+                           double lambda1, double lambda2, unsigned flags, double *d_estimates, double *d_rmse,
+                           double *d_nrmse, void *hip_stream);
 int amx_sync_status(amx_ctx *ctx, void *hip_stream);
 
 /* ---- the solvers' own output: the coefficient vectors `x` that cyspams.interfaces.nnls / lasso hand back to
@@ -184,6 +200,8 @@ int  amx_dti_create(amx_ctx *ctx, const double *inv_design, int nS, double min_s
 void amx_dti_destroy(amx_dti *h);
 /* y f64[n_vox][nS] -> dirs f64[n_vox][3]; host buffers (blocking) / device buffers (enqueued on hip_stream) */
 int amx_dti_directions(amx_ctx *ctx, const amx_dti *h, const double *y, int64_t n_vox, double *out_dirs);
+/* (_f32: float32 signals, the dtype amx_prep_gather_device_f32 leaves them in -- same arithmetic, half the bytes)                */
+int amx_dti_directions_device_f32(amx_ctx *ctx, const amx_dti *h, const float *d_y, int64_t n_vox, double *d_dirs, void *hip_stream);
 int amx_dti_directions_device(amx_ctx *ctx, const amx_dti *h, const double *d_y, int64_t n_vox,
                               double *d_dirs, void *hip_stream);
 
@@ -217,6 +235,10 @@ void amx_prep_destroy(amx_prep *p);
  * not NULL).  normalize = doNormalizeSignal; b0_threshold = the right-hand side of core.py:217 (0 by default).  */
 int amx_prep_gather(amx_ctx *ctx, const amx_prep *p, const float *img, int normalize, float b0_threshold,
                     double *out_y, float *out_mean_b0);
+/* (_f32: the prepared signals stay float32 -- every value of core.py:209-268 IS a float32, core.py:451-452 only widen them; the
+ * amx_*_fit_device_f32 / amx_dti_directions_device_f32 calls read them in place)                                                  */
+int amx_prep_gather_device_f32(amx_ctx *ctx, const amx_prep *p, const float *d_img, int normalize, float b0_threshold,
+                               float *d_y, float *d_mean_b0, void *hip_stream);
 int amx_prep_gather_device(amx_ctx *ctx, const amx_prep *p, const float *d_img, int normalize,
                            float b0_threshold, double *d_y, float *d_mean_b0, void *hip_stream);
 /* self.mean_b0s of EVERY voxel (core.py:213), float32 [X][Y][Z] in C order: input of the threshold above */

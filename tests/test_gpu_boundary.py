@@ -108,7 +108,7 @@ def test_device_wrappers_reject_mismatched_buffers(htable500):
     with pytest.raises(ValueError):
         _capi.noddi_fit_device(ctx, lut, yt[:, :90].contiguous(), dt, 0.5, 1e-3, 3)
     with pytest.raises(ValueError):
-        _capi.noddi_fit_device(ctx, lut, yt.float(), dt, 0.5, 1e-3, 3)
+        _capi.noddi_fit_device(ctx, lut, yt.half(), dt, 0.5, 1e-3, 3)      # (float32 is a supported signal dtype, float16 is not)
     with pytest.raises(ValueError):
         _capi.noddi_fit_device(ctx, lut, yt, dt[:, :2].contiguous(), 0.5, 1e-3, 3)
     with pytest.raises(ValueError):
@@ -219,3 +219,62 @@ def test_progress_from_the_device_pointer_calls(htable500):
     est2 = _capi.noddi_fit_device(ctx, lut, yt, dt, 0.5, 1e-3, 3)[0]
     ctx.sync()
     assert not seen and torch.equal(est, est2)
+
+
+def test_float32_signals_in_device_memory(htable500, czb_fix):
+    """amx_*_fit_device_f32 (VERDICT r02 missing 4): the image is float32 (core.py:136) and only core.py:451-452 widen it, so
+    a float32 signal buffer in HBM must give the float64 call's maps bit for bit -- NODDI below and above the size where the
+    seeded chain takes over, FreeWater maps-only (matrix-core projection reads float32) and with error maps / corrected signal
+    (float64 copy on the device), Mouse, SANDI, CylinderZeppelinBall"""
+    import torch
+    from amico_amd import _capi, synthetic as S
+    dev = torch.device('cuda', 0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    for n in (3000, 90_000):
+        ctx, lut, K, ht, sch, y, d = _noddi(htable500, n, seed=21)
+        y32 = y.astype(np.float32)
+        a = _capi.noddi_fit_device(ctx, lut, up(y32), up(d), 0.5, 1e-3, 3, rmse=True, nrmse=True, mod=True)
+        b = _capi.noddi_fit_device(ctx, lut, up(y32.astype(np.float64)), up(d), 0.5, 1e-3, 3, rmse=True, nrmse=True, mod=True)
+        ctx.sync()
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+        assert ctx.last_stats()['itercap_voxels'] == 0
+    s1 = S.make_scheme(1, ((1000.0, 64),), seed=3)
+    Kf = S.freewater_kernels(s1, htable500['dirs'])
+    yf, df = S.freewater_signals(40_000, Kf, ht, s1, seed=2)
+    yf32 = yf.astype(np.float32)
+    lf = _capi.upload_freewater(ctx, Kf, ht)
+    for kw in (dict(), dict(rmse=True, nrmse=True, corrected=True)):
+        a = _capi.freewater_fit_device(ctx, lf, up(yf32), up(df), 0.0, 1e-3, False, **kw)
+        b = _capi.freewater_fit_device(ctx, lf, up(yf32.astype(np.float64)), up(df), 0.0, 1e-3, False, **kw)
+        ctx.sync()
+        for u, v in zip(a, b):
+            assert (u is None and v is None) or torch.equal(u, v)
+    Km = S.freewater_kernels(s1, htable500['dirs'], d_isos=(2.0e-3, 3.0e-3))
+    lm = _capi.upload_freewater(ctx, Km, ht)
+    a = _capi.freewater_fit_device(ctx, lm, up(yf32), up(df), 0.0, 1e-3, True)[0]
+    b = _capi.freewater_fit_device(ctx, lm, up(yf32.astype(np.float64)), up(df), 0.0, 1e-3, True)[0]
+    ctx.sync()
+    assert torch.equal(a, b) and a.shape[1] == 4
+    avg = S.directional_average_scheme(S.make_sandi_scheme())
+    Ks, Rs, d_in, d_isos = S.sandi_kernels(avg)
+    ys = S.sandi_signals(30_000, Ks, avg, seed=4).astype(np.float32)
+    ls = _capi.upload_sandi(ctx, Ks, Rs, d_in, d_isos)
+    a = _capi.sandi_fit_device(ctx, ls, up(ys), 0.0, 5e-3, rmse=True)
+    b = _capi.sandi_fit_device(ctx, ls, up(ys.astype(np.float64)), 0.0, 5e-3, rmse=True)
+    ctx.sync()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    f = czb_fix
+    Kc, ids = f['kernels'], f['lut_ids']
+    rng = np.random.default_rng(9)
+    dc = S.random_unit_vectors(200_000, rng)
+    dc = dc[np.isin(S.lut_indices(dc, ht), ids)][:5000]
+    li = S.lut_indices(dc, ht)
+    yc = (0.6 * Kc['wmr'][0, li] + 0.3 * Kc['wmh'][1, li] + 0.1 * Kc['iso'][0] + 0.02 * rng.standard_normal((len(dc), Kc['wmr'].shape[2]))).astype(np.float32)
+    lc = _capi.upload_czb(ctx, Kc, f['Rs'], ht)
+    a = _capi.czb_fit_device(ctx, lc, up(np.abs(yc)), up(dc), 0.0, 4.0, rmse=True)
+    b = _capi.czb_fit_device(ctx, lc, up(np.abs(yc).astype(np.float64)), up(dc), 0.0, 4.0, rmse=True)
+    ctx.sync()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    with pytest.raises(ValueError):
+        _capi.noddi_fit_device(ctx, lut, up(y32).to(torch.float16), up(d), 0.5, 1e-3, 3)
