@@ -457,8 +457,48 @@ __global__ void __launch_bounds__(256, (MS > 6 ? AMX_SEED1_OCC : 2)) k_nnls_seed
 #else
 #define SEED_PH(k) do { } while (0)
 #endif
+    // Stage 1 (one wavefront per SIMD, registers to spare): the voxel's y~ stays in registers, and a lane RESERVES its next voxel
+    // while it works on the current one -- the 12 loads of the next y~ are in flight for a whole solve instead of being waited
+    // for in every trip in which some lane of the wavefront refills (measured: 15 % of the kernel).
+    constexpr bool PREF = (MS > 6);
+    static_assert(!(PREF && STAGE == 3), "the reservation path does not load the stage-3 candidate masks");
+    double yv[PREF ? KD : 1], ynext[PREF ? KD : 1];
+    int next_pos = -1;
+    bool have_next = false;
     for (int guard = 0; guard < (1 << 20); ++guard) {
         // ------------------------------------------------------------ free lanes take the next voxels of the chunk
+        if (PREF) {
+            if (!active && have_next) {
+                pos = next_pos; have_next = false;
+                bool finite = true;
+#pragma unroll
+                for (int d = 0; d < KD; d++) { yv[PREF ? d : 0] = ynext[PREF ? d : 0]; finite = finite && (fabs(yv[PREF ? d : 0]) <= 1.79769313486231570e308); }
+                trips = 0; last_added = -1; ban0 = -1; ban1 = -1;
+                V.clear();
+                if (finite) active = true;
+                else a.seeds[pos] = kNoSeed;
+            }
+            const unsigned long long needm = __ballot(!have_next);
+            if (needm != 0ull && more) {
+                const int nneed = __builtin_popcountll(needm);
+                unsigned base = 0u;
+                if (lane == 0) base = atomicAdd(ticket, (unsigned)nneed);
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                if ((int)base + nneed >= ck.count) more = false;
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(needm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)needm, 0u));
+                const int k = (int)base + rank;
+                if (!have_next && k < ck.count) {
+                    next_pos = ck.start + k; have_next = true;
+                    const double *yp = a.ytil + (size_t)next_pos * KD;
+#pragma unroll
+                    for (int d = 0; d < KD; d++) ynext[PREF ? d : 0] = yp[d];
+                }
+            }
+            if (__ballot(active) == 0ull) {
+                if (!more && __ballot(have_next) == 0ull) break;
+                continue;
+            }
+        } else {
         const unsigned long long freem = __ballot(!active);
         if (freem != 0ull && more) {
             const int nfree = __builtin_popcountll(freem);
@@ -490,6 +530,7 @@ __global__ void __launch_bounds__(256, (MS > 6 ? AMX_SEED1_OCC : 2)) k_nnls_seed
         if (__ballot(active) == 0ull) {
             if (!more) break;
             continue;
+        }
         }
 #ifdef AMX_STATS
         st_trips++; st_used += __builtin_popcountll(__ballot(active));
@@ -534,7 +575,7 @@ __global__ void __launch_bounds__(256, (MS > 6 ? AMX_SEED1_OCC : 2)) k_nnls_seed
             const double *yp = a.ytil + (size_t)pos * KD;
             double r[KD];
 #pragma unroll
-            for (int d = 0; d < KD; d++) r[d] = yp[d];
+            for (int d = 0; d < KD; d++) r[d] = PREF ? yv[PREF ? d : 0] : yp[d];
 #pragma unroll
             for (int s = 0; s < MS; s++) {         // (slots >= np: x = 0, idx = 0 -- no predicate needed)
                 const double *col = Sl + V.idx[s] * LD;
@@ -618,7 +659,7 @@ __global__ void __launch_bounds__(256, (MS > 6 ? AMX_SEED1_OCC : 2)) k_nnls_seed
                     const double *ct = Sl + bj * LD;
                     double st[KD], cn = 0.0, htt = 0.0;
 #pragma unroll
-                    for (int d = 0; d < KD; d++) { st[d] = ct[d]; cn += st[d] * yp[d]; htt += st[d] * st[d]; }
+                    for (int d = 0; d < KD; d++) { st[d] = ct[d]; cn += st[d] * (PREF ? yv[PREF ? d : 0] : yp[d]); htt += st[d] * st[d]; }
                     double h[MS];
 #pragma unroll
                     for (int s = 0; s < MS; s++) {
