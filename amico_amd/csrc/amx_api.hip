@@ -32,6 +32,10 @@ int make_plan(amx_ctx *ctx, int64_t n, int ndirs, Plan &pl, bool seeds = false)
     if (seeds) {
         const int sc = ctx->opt_seed_chunk;
         pl.max_schunks = (int)(n / sc) + ndirs + 1;
+        pl.seed_waves = ctx->opt_seed_waves ? ctx->opt_seed_waves : 4;
+        // (measured, ndirs = 500: 100 000 / 200 000 / 400 000 / 1 M voxels -> stage-1 group 1.11 / 1.55 / 2.31 / 4.66 ms with two
+        //  wavefronts per workgroup against 1.33 / 1.80 / 2.39 / 4.14 ms with four; every other lane kernel is best with four)
+        pl.seed1_waves = ctx->opt_seed_waves ? ctx->opt_seed_waves : ((double)n / (double)pl.max_schunks < 640.0 ? 2 : 4);
         if ((rc = ensure(ctx, ctx->schunks, (size_t)pl.max_schunks * sizeof(Chunk)))) return rc;
         if ((rc = ensure(ctx, ctx->ytil, (size_t)n * amx::kSeedKD * sizeof(double)))) return rc;
         if ((rc = ensure(ctx, ctx->seeds, (size_t)n * sizeof(unsigned long long)))) return rc;
@@ -187,6 +191,8 @@ int amx_ctx_create(int device, amx_ctx **out)
         e = getenv("AMX_HOST_BATCH");
         // (a multiple of 4: k_widen reads float4; at least the largest ramp batch, 131072: the ramp batches are written into slots of this size)
         if (e && atol(e) >= 131072) ctx->opt_host_batch = ((long long)atol(e) + 3) & ~3LL;
+        e = getenv("AMX_SEED_WAVES");
+        if (e && *e) { const int v = atoi(e); ctx->opt_seed_waves = (v == 1 || v == 2 || v == 4) ? v : 0; }
         e = getenv("AMX_SEED_MIN_VOXELS");
         if (e && *e) ctx->opt_seed_min_voxels = atoll(e);
         e = getenv("AMX_NO_GCERT_WIDE");

@@ -65,7 +65,7 @@ int amx_launch_noddi_seed2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a,
     const size_t lds = ((size_t)lut->n_wm * (kSeed2KD + 1) + 8 + (size_t)9 * (kSeed2KD / 4) * 64 + (size_t)4 * (64 * (kSeed2KD + 1) + 64 * 3)) * sizeof(double);
     int rc;
     if ((rc = set_lds(ctx, k_lasso_seed, lds))) return rc;
-    hipLaunchKernelGGL(k_lasso_seed, dim3(((pl.max_schunks + 7) / 8) * 8), dim3(256), lds, s, sa);
+    hipLaunchKernelGGL(k_lasso_seed, dim3(((pl.max_schunks + 7) / 8) * 8), dim3(64 * pl.seed_waves), lds, s, sa);
     AMX_TRACE(ctx, s, "LASSO seed solver");
     HIPCHK(ctx, hipGetLastError());
     return AMX_OK;
@@ -99,10 +99,10 @@ int amx_launch_noddi_gemm(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, 
     const dim3 grid(((pl.max_schunks + 7) / 8) * 8);
     if (lasso) {
         if ((rc = set_lds(ctx, k_noddi_gemm<true>, lds))) return rc;
-        hipLaunchKernelGGL(k_noddi_gemm<true>, grid, dim3(256), lds, s, ga);
+        hipLaunchKernelGGL(k_noddi_gemm<true>, grid, dim3(64 * pl.seed_waves), lds, s, ga);
     } else {
         if ((rc = set_lds(ctx, k_noddi_gemm<false>, lds))) return rc;
-        hipLaunchKernelGGL(k_noddi_gemm<false>, grid, dim3(256), lds, s, ga);
+        hipLaunchKernelGGL(k_noddi_gemm<false>, grid, dim3(64 * pl.seed_waves), lds, s, ga);
     }
     AMX_TRACE(ctx, s, "A'y of every voxel on the matrix cores");
     HIPCHK(ctx, hipGetLastError());
@@ -129,7 +129,7 @@ int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a
     const size_t lds = ((size_t)lut->n_wm * kSeedLd + 2 + ((lut->n_wm + 1) & ~1) + (size_t)9 * (kSeedKD / 4) * 64 + (size_t)4 * 64 * 16) * sizeof(double);
     int rc;
     if ((rc = set_lds(ctx, (k_lasso_gcert<kGcert2Max, false>), lds))) return rc;
-    hipLaunchKernelGGL((k_lasso_gcert<kGcert2Max, false>), dim3(((pl.max_schunks + 7) / 8) * 8), dim3(256), lds, s, g);
+    hipLaunchKernelGGL((k_lasso_gcert<kGcert2Max, false>), dim3(((pl.max_schunks + 7) / 8) * 8), dim3(64 * pl.seed_waves), lds, s, g);
     AMX_TRACE(ctx, s, "Gram-space certificates of the LASSO seeds");
     HIPCHK(ctx, hipGetLastError());
     if (wide) {
@@ -141,7 +141,7 @@ int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a
         g.stats = a.c.status + ST_SEED + 48;
 #endif
         if ((rc = set_lds(ctx, (k_lasso_gcert<kGcert2Wide, true>), lds))) return rc;
-        hipLaunchKernelGGL((k_lasso_gcert<kGcert2Wide, true>), dim3(((pl.max_schunks + 7) / 8) * 8), dim3(256), lds, s, g);
+        hipLaunchKernelGGL((k_lasso_gcert<kGcert2Wide, true>), dim3(((pl.max_schunks + 7) / 8) * 8), dim3(64 * pl.seed_waves), lds, s, g);
         AMX_TRACE(ctx, s, "Gram-space certificates of the LASSO seeds, supports of 13 .. 16 atoms");
         HIPCHK(ctx, hipGetLastError());
     }
@@ -170,10 +170,10 @@ int amx_launch_noddi_gcert(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a,
     int rc;
     if (stage == 1) {
         if ((rc = set_lds(ctx, k_nnls_gcert<1>, lds))) return rc;
-        hipLaunchKernelGGL(k_nnls_gcert<1>, grid, dim3(256), lds, s, g);
+        hipLaunchKernelGGL(k_nnls_gcert<1>, grid, dim3(64 * pl.seed_waves), lds, s, g);
     } else {
         if ((rc = set_lds(ctx, k_nnls_gcert<3>, lds))) return rc;
-        hipLaunchKernelGGL(k_nnls_gcert<3>, grid, dim3(256), lds, s, g);
+        hipLaunchKernelGGL(k_nnls_gcert<3>, grid, dim3(64 * pl.seed_waves), lds, s, g);
     }
     AMX_TRACE(ctx, s, "Gram-space certificates");
     HIPCHK(ctx, hipGetLastError());
@@ -202,10 +202,10 @@ int amx_launch_noddi_seed(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, 
     int rc;
     if (stage == 1) {
         if ((rc = set_lds(ctx, (k_nnls_seed<1, 8>), lds))) return rc;
-        hipLaunchKernelGGL((k_nnls_seed<1, 8>), grid, dim3(256), lds, s, sa);
+        hipLaunchKernelGGL((k_nnls_seed<1, 8>), grid, dim3(64 * pl.seed1_waves), lds, s, sa);
     } else {
         if ((rc = set_lds(ctx, (k_nnls_seed<3, 6>), lds))) return rc;
-        hipLaunchKernelGGL((k_nnls_seed<3, 6>), grid, dim3(256), lds, s, sa);
+        hipLaunchKernelGGL((k_nnls_seed<3, 6>), grid, dim3(64 * pl.seed_waves), lds, s, sa);
     }
     AMX_TRACE(ctx, s, "seed solver");
     HIPCHK(ctx, hipGetLastError());
