@@ -238,6 +238,20 @@ def dti_directions(args):
     g = d[:m].cpu().numpy()
     err = np.linalg.norm(np.cross(g[ok], ref[ok]), axis=1)
     bpv = 8 * scheme.nS + 24
+    # the same on float32 signals (what amx_prep_gather_device_f32 leaves in HBM; Evaluation.fit runs this variant)
+    y32 = y.to(torch.float32)
+    d32 = torch.zeros_like(d)
+    for _ in range(args.warmup):
+        est.fit_device(y32.data_ptr(), n, d32.data_ptr(), f32=True); ctx.sync()
+    k32 = 0.0
+    for _ in range(args.steps):
+        est.fit_device(y32.data_ptr(), n, d32.data_ptr(), f32=True); ctx.sync()
+        k32 += ctx.last_kernel_ms(4)
+    k32 /= args.steps
+    y32w = y32.to(torch.float64)
+    est.fit_device(y32w.data_ptr(), n, d.data_ptr()); ctx.sync()
+    f32 = {'kernel_ms': k32, 'bytes_per_voxel': 4 * scheme.nS + 24, 'achieved_GBs': (4 * scheme.nS + 24) * n / (k32 * 1e-3) / 1e9,
+           'bit_identical_to_f64_input': bool(torch.equal(d, d32))}
     print(json.dumps({'metric': 'voxels/sec, principal directions (log-linear tensor fit)', 'value': n * args.steps / el,
                       'unit': 'voxels/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
                       'ms_per_step': 1e3 * el / args.steps, 'dtype': 'f64', 'data': 'synthetic',
@@ -245,6 +259,7 @@ def dti_directions(args):
                       'roofline': {'bound': 'hbm', 'achieved': bpv * n / (kms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
                                    'unit': 'GB/s', 'frac': bpv * n / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
                                    'kernel': 'k_dti_dirs', 'kernel_ms': kms, 'bytes_per_voxel': bpv},
+                      'float32_signals_in_hbm': f32,
                       'parity': {'sample_voxels': int(ok.sum()), 'max_sin_angle': float(err.max())},
                       'cpu_baseline': {'value': cpu, 'unit': 'voxels/s', 'cores': 1, 'kind': 'port',
                                        'sample': '%d voxels, numpy restatement of dipy OLS (pinv + log + batched eigh)' % m}}))

@@ -92,23 +92,32 @@ def test_noddi_vs_oracle_synthetic(htable500, seed_path, amx_env):
     assert np.median(diff) < 1e-10
 
 
-def test_noddi_exvivo_and_lambdas(htable500):
+@pytest.mark.parametrize('seed_path', ['default', 'seeded'])
+def test_noddi_exvivo_and_lambdas(htable500, seed_path, amx_env):
+    """ex-vivo model (dot compartment: 146 atoms, four maps) with other regularisation weights, error maps and modulated maps;
+    'seeded': 20 000 voxels forced through the seed / certificate chain"""
+    if seed_path == 'seeded':
+        amx_env(AMX_SEED_MIN_VOXELS='0')
     from amico_amd import NODDI, synthetic as S
     from oracle import oracle
     ht = htable500['htable']
     sch = S.make_scheme(seed=5)
     K = S.noddi_kernels(sch, htable500['dirs'])
-    y, d = S.noddi_signals(1500, K, ht, sch, seed=10)
+    n = 20000 if seed_path == 'seeded' else 1500
+    y, d = S.noddi_signals(n, K, ht, sch, seed=10)
     m = NODDI()
     m.set(isExvivo=True)
     m.set_solver(lambda1=0.2, lambda2=5e-3)
     m.scheme = sch
-    out = m.fit(Holder(y, d, ht, K))
-    ref = oracle.noddi_fit(y, d, K, ht, sch.dwi_idx, 0.2, 5e-3, is_exvivo=True, nthreads=8)
-    assert out['estimates'].shape == (1500, 4)
+    out = m.fit(Holder(y, d, ht, K, doComputeRMSE=True, doComputeNRMSE=True, doSaveModulatedMaps=True))
+    ref = oracle.noddi_fit(y, d, K, ht, sch.dwi_idx, 0.2, 5e-3, is_exvivo=True, rmse=True, nrmse=True, nthreads=8)
+    assert out['estimates'].shape == (n, 4)
     diff = np.abs(out['estimates'] - ref['estimates']).max(axis=1)
     assert (diff < TOL).mean() > 0.998
     assert diff.max() < CAP, diff.max()
+    assert np.abs(out['rmse'] - ref['rmse']).max() < 1e-6 and np.abs(out['nrmse'] - ref['nrmse']).max() < 1e-6
+    tf = 1 - out['estimates'][:, 2]
+    assert np.allclose(out['estimates_mod'], out['estimates'][:, :2] * tf[:, None], atol=1e-12)
 
 
 def test_freewater_golden_and_oracle(fw_fix, htable500):
