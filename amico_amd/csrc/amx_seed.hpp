@@ -25,6 +25,9 @@
 namespace amx {
 
 constexpr int kSeedMax = 8;      // passive-set capacity of the seed solver (= MAXP of the NNLS stage kernels)
+#ifndef SEED3_SCAN_MAX
+#define SEED3_SCAN_MAX 32      // (diagnosis: a smaller value truncates the stage-3 candidate scan)
+#endif
 constexpr int kSeedLd = 13;      // LDS row stride of S (odd: per-lane column gathers spread over the banks)
 constexpr unsigned long long kNoSeed = kSeedNone;
 
@@ -449,6 +452,8 @@ __global__ void __launch_bounds__(256, (MS > 6 ? AMX_SEED1_OCC : 2)) k_nnls_seed
     SeedLane<MS> V;
     V.clear();
     unsigned long long allow[STAGE == 3 ? 4 : 1];
+    unsigned long long cand[STAGE == 3 ? 4 : 1];      // stage 3: the voxel's admissible atoms as a byte list (<= 32), made once per voxel
+    int ncand = 0;
     bool more = true;
 #ifdef AMX_STATS
     int st_trips = 0, st_used = 0;
@@ -525,12 +530,47 @@ __global__ void __launch_bounds__(256, (MS > 6 ? AMX_SEED1_OCC : 2)) k_nnls_seed
                 }
                 if (finite) active = true;
                 else a.seeds[pos] = kNoSeed;
+                ncand = -1;                                     // (byte list below)
             }
         }
         if (__ballot(active) == 0ull) {
             if (!more) break;
             continue;
         }
+        }
+        if (STAGE == 3) {
+            // new voxels: set bits of the candidate mask -> byte list, once per voxel instead of once per trip
+            if (__ballot(ncand < 0) != 0ull) {
+                const bool fresh = ncand < 0;
+                unsigned long long rem[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) rem[q] = fresh ? allow[q] : 0ull;
+                unsigned long long cl[4] = {0ull, 0ull, 0ull, 0ull};
+                int nc = 0;
+                for (int it = 0; it < 33; it++) {
+                    int q = -1;
+#pragma unroll
+                    for (int qq = 3; qq >= 0; qq--) q = (rem[qq] != 0ull) ? qq : q;
+                    if (__ballot(q >= 0) == 0ull) break;
+                    unsigned long long word = 0ull;
+#pragma unroll
+                    for (int qq = 0; qq < 4; qq++) word = (q == qq) ? rem[qq] : word;
+                    const unsigned long long j = (q >= 0) ? (unsigned long long)(q * 64 + __builtin_ctzll(word)) : 0ull;
+#pragma unroll
+                    for (int qq = 0; qq < 4; qq++) rem[qq] = (q == qq) ? (rem[qq] & (rem[qq] - 1ull)) : rem[qq];
+                    if (q >= 0 && nc < 32) {
+#pragma unroll
+                        for (int w4 = 0; w4 < 4; w4++) cl[w4] |= ((nc >> 3) == w4) ? (j << (8 * (nc & 7))) : 0ull;
+                    }
+                    nc += (q >= 0) ? 1 : 0;
+                }
+                if (fresh) {
+#pragma unroll
+                    for (int w4 = 0; w4 < 4; w4++) cand[STAGE == 3 ? w4 : 0] = cl[w4];
+                    ncand = nc;
+                    if (nc > 32 && active) { a.seeds[pos] = kNoSeed; active = false; }      // (never seen: LASSO supports end at 23 atoms)
+                }
+            }
         }
 #ifdef AMX_STATS
         st_trips++; st_used += __builtin_popcountll(__ballot(active));
@@ -618,31 +658,25 @@ __global__ void __launch_bounds__(256, (MS > 6 ? AMX_SEED1_OCC : 2)) k_nnls_seed
                     }
                 }
             } else {
-                // candidates = set bits of the lane's own mask (<= ~20): per-lane gathers
-                unsigned long long rem[4];
+                // candidates = the lane's byte list (<= 32 atoms): per-lane gathers of their columns, two per step (two
+                // independent chains: the loop is a chain of LDS latencies and dependent FMAs otherwise)
 #pragma unroll
-                for (int q = 0; q < 4; q++) rem[q] = scan ? allow[q] : 0ull;
-                for (int it = 0; it < 256; it++) {
-                    int q = -1;
+                for (int it = 0; it < SEED3_SCAN_MAX; it += 2) {
+                    if (__ballot(scan && it < ncand) == 0ull) break;
+                    const int j0 = (int)((cand[STAGE == 3 ? (it >> 3) : 0] >> (8 * (it & 7))) & 0xffull);
+                    const int j1 = (int)((cand[STAGE == 3 ? ((it + 1) >> 3) : 0] >> (8 * ((it + 1) & 7))) & 0xffull);
+                    const double *c0 = Sl + j0 * LD, *c1 = Sl + j1 * LD;
+                    double u0[KD], u1[KD];
 #pragma unroll
-                    for (int qq = 3; qq >= 0; qq--) q = (rem[qq] != 0ull) ? qq : q;
-                    if (__ballot(q >= 0) == 0ull) break;
-                    unsigned long long word = 0ull;
+                    for (int d = 0; d < KD; d++) { u0[d] = c0[d]; u1[d] = c1[d]; }
+                    double w0a = 0.0, w0b = 0.0, w1a = 0.0, w1b = 0.0;
 #pragma unroll
-                    for (int qq = 0; qq < 4; qq++) word = (q == qq) ? rem[qq] : word;
-                    const int b = (q >= 0) ? __builtin_ctzll(word) : 0;
-                    const int j = (q >= 0) ? q * 64 + b : 0;
-#pragma unroll
-                    for (int qq = 0; qq < 4; qq++) rem[qq] = (q == qq) ? (rem[qq] & (rem[qq] - 1ull)) : rem[qq];
-                    const double *col = Sl + j * LD;
-                    double cv[KD];
-#pragma unroll
-                    for (int d = 0; d < KD; d++) cv[d] = col[d];
-                    double w = 0.0;
-#pragma unroll
-                    for (int d = 0; d < KD; d++) w += cv[d] * r[d];
-                    const bool ok = (q >= 0) && (j != ban0) && (j != ban1) && (w > best);
-                    best = ok ? w : best; bj = ok ? j : bj;
+                    for (int d = 0; d < KD; d += 2) { w0a += u0[d] * r[d]; w0b += u0[d + 1] * r[d + 1]; w1a += u1[d] * r[d]; w1b += u1[d + 1] * r[d + 1]; }
+                    const double w0 = w0a + w0b, w1 = w1a + w1b;
+                    const bool ok0 = scan && (it < ncand) && (j0 != ban0) && (j0 != ban1) && (w0 > best);
+                    best = ok0 ? w0 : best; bj = ok0 ? j0 : bj;
+                    const bool ok1 = scan && (it + 1 < ncand) && (j1 != ban0) && (j1 != ban1) && (w1 > best);
+                    best = ok1 ? w1 : best; bj = ok1 ? j1 : bj;
                 }
             }
             SEED_PH(3);
@@ -722,6 +756,7 @@ __global__ void __launch_bounds__(256, (MS > 6 ? AMX_SEED1_OCC : 2)) k_nnls_seed
     if (a.stats && lane == 0) {
         atomicAdd(&a.stats[0], st_trips); atomicAdd(&a.stats[1], st_used);
         if (STAGE == 1) for (int k = 0; k < 6; k++) atomicAdd(&a.stats[8 + k], (int)(ph[k] >> 10));
+        if (STAGE == 3) for (int k = 0; k < 6; k++) atomicAdd(&a.stats[50 + k], (int)(ph[k] >> 10));
     }
 #endif
 }
