@@ -1641,31 +1641,7 @@ __global__ void __launch_bounds__(256, AMX_SEED2_OCC) k_lasso_seed(const Seed2Ar
 #pragma unroll
             for (int d = 0; d < KD; d++) r[d] = yp[d] - w[d];
         }
-        // ------------------------------------------------------------ passive atoms of the own voxel: the most negative one
-        // (x_j = t_j / lambda2 <= 0) leaves
-        int dj = -1;
-        {
-            double worst = 0.0;
-            unsigned long long rem[3] = {active ? P[0] : 0ull, active ? P[1] : 0ull, active ? P[2] : 0ull};
-            for (int it = 0; it < 192; it++) {
-                int wq = -1;
-#pragma unroll
-                for (int qq = 2; qq >= 0; qq--) wq = (rem[qq] != 0ull) ? qq : wq;
-                if (__ballot(wq >= 0) == 0ull) break;
-                unsigned long long word = 0ull;
-#pragma unroll
-                for (int qq = 0; qq < 3; qq++) word = (wq == qq) ? rem[qq] : word;
-                const int j = (wq >= 0) ? wq * 64 + __builtin_ctzll(word) : 0;
-#pragma unroll
-                for (int qq = 0; qq < 3; qq++) rem[qq] = (wq == qq) ? (rem[qq] & (rem[qq] - 1ull)) : rem[qq];
-                const double *col = Sl + j * LD;
-                double t = -lam1;
-#pragma unroll
-                for (int d = 0; d < KD; d++) t += col[d] * r[d];
-                const bool ok = (wq >= 0) && (t <= worst);
-                worst = ok ? t : worst; dj = ok ? j : dj;
-            }
-        }
+        int dj = -1;                  // the most negative passive atom (x_j = t_j / lambda2 <= 0): it leaves
         // ------------------------------------------------------------ dual values of all atoms for the 64 voxels (fp64 MFMA),
         // passive atoms masked out, arg-max in the low mantissa bits (see seed_scan_mfma)
         double best = -inf;
@@ -1683,6 +1659,9 @@ __global__ void __launch_bounds__(256, AMX_SEED2_OCC) k_lasso_seed(const Seed2Ar
             }
             const double ninf = -inf;
             double bv[4] = {ninf, ninf, ninf, ninf};
+            // the SAME product holds t_j + lambda1 of the passive atoms: their minimum (kept as the maximum of the negated values, same
+            // tag trick) names the atom that leaves -- no second pass over the passive set with per-lane gathers
+            double wv[4] = {ninf, ninf, ninf, ninf};
             // (rolled: unrolled, the scheduler overlaps the nine tiles and spills; the mask word of a tile is picked by a
             //  wave-uniform index, so nothing is indexed dynamically in registers)
 #pragma unroll 1
@@ -1714,6 +1693,8 @@ __global__ void __launch_bounds__(256, AMX_SEED2_OCC) k_lasso_seed(const Seed2Ar
                         const unsigned lo = ((unsigned)__double2loint(v) & 0xffffff00u) | (unsigned)(mt * 4 + rr);
                         const int hi = pas ? (int)0xffe00000 : __double2hiint(v);     // passive: -9e307 (finite whatever the low word is; 0xfff... would be a NaN)
                         bv[nt] = seed_max(bv[nt], __hiloint2double(hi, (int)lo));
+                        const int hn = pas ? (__double2hiint(v) ^ (int)0x80000000) : (int)0xffe00000;
+                        wv[nt] = seed_max(wv[nt], __hiloint2double(hn, (int)lo));
                     }
                 }
             }
@@ -1727,6 +1708,17 @@ __global__ void __launch_bounds__(256, AMX_SEED2_OCC) k_lasso_seed(const Seed2Ar
             const unsigned code = (unsigned)__double2loint(mine) & 0xffu;
             best = mine - lam1;
             bj = 16 * (int)((code >> 2) & 15u) + 4 * (int)(code & 3u) + (int)(code >> 6);
+            double mine2 = ninf;
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) {
+                const double t = __hiloint2double(__double2hiint(wv[nt]), (int)((unsigned)__double2loint(wv[nt]) | (unsigned)(q << 6)));
+                const double m = rows_allmax(t);
+                mine2 = (q == nt) ? m : mine2;
+            }
+            const unsigned code2 = (unsigned)__double2loint(mine2) & 0xffu;
+            // mine2 = -(smallest passive s_j'r): t_j = -mine2 - lambda1 <= 0 ?  (no passive atom: mine2 = -9e307)
+            if (active && mine2 > -1e300 && -mine2 - lam1 <= 0.0)
+                dj = 16 * (int)((code2 >> 2) & 15u) + 4 * (int)(code2 & 3u) + (int)(code2 >> 6);
         }
         // ------------------------------------------------------------ one rank-one change of the factor per trip
         bool done = false, noseed = false;
