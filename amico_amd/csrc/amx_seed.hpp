@@ -220,6 +220,13 @@ __device__ __forceinline__ double seed_max(double a, double b)     // plain v_ma
     return d;
 }
 
+__device__ __forceinline__ double seed_min(double a, double b)
+{
+    double d;
+    asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 typedef double seed_v4d __attribute__((ext_vector_type(4)));
 template <int KS, int MT>
 __device__ __forceinline__ void seed_scan_mfma(const double *Aop, double *Rb, const double (&r)[4 * KS], int lane, double &best, int &bj)
@@ -1541,7 +1548,7 @@ __global__ void __launch_bounds__(1024) k_noddi_project2(const Seed2Args a)
 }
 
 #ifndef AMX_SEED2_OCC
-#define AMX_SEED2_OCC 2
+#define AMX_SEED2_OCC 1
 #endif
 __global__ void __launch_bounds__(256, AMX_SEED2_OCC) k_lasso_seed(const Seed2Args a)
 {
@@ -1583,36 +1590,48 @@ __global__ void __launch_bounds__(256, AMX_SEED2_OCC) k_lasso_seed(const Seed2Ar
 #ifdef AMX_STATS
     int st_trips = 0, st_used = 0;
 #endif
+    // (one wavefront per SIMD: y~ of the voxel in registers, the next voxel reserved -- and its y~ loading -- one solve ahead, as in
+    //  k_nnls_seed<1>)
+    double yv[KD], ynext[KD];
+    int next_pos = -1;
+    bool have_next = false;
     for (int guard = 0; guard < (1 << 20); ++guard) {
-        const unsigned long long freem = __ballot(!active);
-        if (freem != 0ull && more) {
-            const int nfree = __builtin_popcountll(freem);
-            unsigned base = 0u;
-            if (lane == 0) base = atomicAdd(ticket, (unsigned)nfree);
-            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-            if ((int)base + nfree >= ck.count) more = false;
-            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(freem >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)freem, 0u));
-            const int k = (int)base + rank;
-            if (!active && k < ck.count) {
-                pos = ck.start + k;
-                const double *yp = a.ytil + (size_t)pos * SLD;
-                bool finite = true;
+        if (!active && have_next) {
+            pos = next_pos; have_next = false;
+            bool finite = true;
 #pragma unroll
-                for (int d = 0; d < KD; d++) finite = finite && (fabs(yp[d]) <= 1.79769313486231570e308);
-                trips = 0;
-                P[0] = 0ull; P[1] = 0ull; P[2] = 0ull;
+            for (int d = 0; d < KD; d++) { yv[d] = ynext[d]; finite = finite && (fabs(yv[d]) <= 1.79769313486231570e308); }
+            trips = 0;
+            P[0] = 0ull; P[1] = 0ull; P[2] = 0ull;
 #pragma unroll
-                for (int i = 0; i < KD; i++) {                 // M = lambda2 I
+            for (int i = 0; i < KD; i++) {                 // M = lambda2 I
 #pragma unroll
-                    for (int j = 0; j <= i; j++) T[stri<KD>(i, j)] = (i == j) ? sl2 : 0.0;
-                    dinv[i] = isl2; g[i] = 0.0;
+                for (int j = 0; j <= i; j++) T[stri<KD>(i, j)] = (i == j) ? sl2 : 0.0;
+                dinv[i] = isl2; g[i] = 0.0;
+            }
+            if (finite) active = true;
+            else { a.seeds[(size_t)pos * 4 + 3] = ~0ull; }
+        }
+        {
+            const unsigned long long needm = __ballot(!have_next);
+            if (needm != 0ull && more) {
+                const int nneed = __builtin_popcountll(needm);
+                unsigned base = 0u;
+                if (lane == 0) base = atomicAdd(ticket, (unsigned)nneed);
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                if ((int)base + nneed >= ck.count) more = false;
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(needm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)needm, 0u));
+                const int k = (int)base + rank;
+                if (!have_next && k < ck.count) {
+                    next_pos = ck.start + k; have_next = true;
+                    const double *yp = a.ytil + (size_t)next_pos * SLD;
+#pragma unroll
+                    for (int d = 0; d < KD; d++) ynext[d] = yp[d];
                 }
-                if (finite) active = true;
-                else { a.seeds[(size_t)pos * 4 + 3] = ~0ull; }
             }
         }
         if (__ballot(active) == 0ull) {
-            if (!more) break;
+            if (!more && __ballot(have_next) == 0ull) break;
             continue;
         }
 #ifdef AMX_STATS
@@ -1637,15 +1656,14 @@ __global__ void __launch_bounds__(256, AMX_SEED2_OCC) k_lasso_seed(const Seed2Ar
                 for (int m = j + 1; m < KD; m++) f -= T[stri<KD>(m, j)] * w[m];
                 w[j] = f * dinv[j];
             }
-            const double *yp = a.ytil + (size_t)pos * SLD;
 #pragma unroll
-            for (int d = 0; d < KD; d++) r[d] = yp[d] - w[d];
+            for (int d = 0; d < KD; d++) r[d] = yv[d] - w[d];
         }
         int dj = -1;                  // the most negative passive atom (x_j = t_j / lambda2 <= 0): it leaves
         // ------------------------------------------------------------ dual values of all atoms for the 64 voxels (fp64 MFMA),
         // passive atoms masked out, arg-max in the low mantissa bits (see seed_scan_mfma)
-        double best = -inf;
-        int bj = -1;
+        double best = -inf, best2 = -inf;
+        int bj = -1, bj2 = -1;
         {
 #pragma unroll
             for (int d = 0; d < KD; d++) Rb[lane * KDP + d] = r[d];
@@ -1662,6 +1680,7 @@ __global__ void __launch_bounds__(256, AMX_SEED2_OCC) k_lasso_seed(const Seed2Ar
             // the SAME product holds t_j + lambda1 of the passive atoms: their minimum (kept as the maximum of the negated values, same
             // tag trick) names the atom that leaves -- no second pass over the passive set with per-lane gathers
             double wv[4] = {ninf, ninf, ninf, ninf};
+            double b2[4] = {ninf, ninf, ninf, ninf};           // runner-up of bv (two atoms may enter in one trip)
             // (rolled: unrolled, the scheduler overlaps the nine tiles and spills; the mask word of a tile is picked by a
             //  wave-uniform index, so nothing is indexed dynamically in registers)
 #pragma unroll 1
@@ -1692,7 +1711,9 @@ __global__ void __launch_bounds__(256, AMX_SEED2_OCC) k_lasso_seed(const Seed2Ar
                         const double v = acc[nt][rr];
                         const unsigned lo = ((unsigned)__double2loint(v) & 0xffffff00u) | (unsigned)(mt * 4 + rr);
                         const int hi = pas ? (int)0xffe00000 : __double2hiint(v);     // passive: -9e307 (finite whatever the low word is; 0xfff... would be a NaN)
-                        bv[nt] = seed_max(bv[nt], __hiloint2double(hi, (int)lo));
+                        const double val = __hiloint2double(hi, (int)lo);
+                        b2[nt] = seed_max(b2[nt], seed_min(bv[nt], val));
+                        bv[nt] = seed_max(bv[nt], val);
                         const int hn = pas ? (__double2hiint(v) ^ (int)0x80000000) : (int)0xffe00000;
                         wv[nt] = seed_max(wv[nt], __hiloint2double(hn, (int)lo));
                     }
@@ -1708,6 +1729,20 @@ __global__ void __launch_bounds__(256, AMX_SEED2_OCC) k_lasso_seed(const Seed2Ar
             const unsigned code = (unsigned)__double2loint(mine) & 0xffu;
             best = mine - lam1;
             bj = 16 * (int)((code >> 2) & 15u) + 4 * (int)(code & 3u) + (int)(code >> 6);
+            // runner-up of the voxel: the row that holds the winner contributes its own runner-up, the other rows their best
+            // (the tags make all values distinct, so equality identifies the winner's row)
+            double second = ninf;
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) {
+                const double t1 = __hiloint2double(__double2hiint(bv[nt]), (int)((unsigned)__double2loint(bv[nt]) | (unsigned)(q << 6)));
+                const double t2 = __hiloint2double(__double2hiint(b2[nt]), (int)((unsigned)__double2loint(b2[nt]) | (unsigned)(q << 6)));
+                const double mall = rows_allmax(t1);
+                const double m = rows_allmax((t1 == mall) ? t2 : t1);
+                second = (q == nt) ? m : second;
+            }
+            const unsigned codes = (unsigned)__double2loint(second) & 0xffu;
+            best2 = second - lam1;
+            bj2 = 16 * (int)((codes >> 2) & 15u) + 4 * (int)(codes & 3u) + (int)(codes >> 6);
             double mine2 = ninf;
 #pragma unroll
             for (int nt = 0; nt < 4; nt++) {
@@ -1720,33 +1755,39 @@ __global__ void __launch_bounds__(256, AMX_SEED2_OCC) k_lasso_seed(const Seed2Ar
             if (active && mine2 > -1e300 && -mine2 - lam1 <= 0.0)
                 dj = 16 * (int)((code2 >> 2) & 15u) + 4 * (int)(code2 & 3u) + (int)(code2 >> 6);
         }
-        // ------------------------------------------------------------ one rank-one change of the factor per trip
+        // ------------------------------------------------------------ up to TWO rank-one changes of the factor per trip: the most
+        // negative passive atom leaves and the best atom enters, or -- nothing to remove -- the two best atoms enter (11.9 -> 8.1 trips
+        // per voxel in tools/lab/s2_lab.py's emulation, same final supports: the ridge keeps M positive definite whatever enters)
         bool done = false, noseed = false;
-        int jj = -1;
-        double sigma = 0.0;
+        int jj = -1, jj2 = -1;
+        double sigma = 0.0, sigma2 = 0.0;
         if (active) {
-            if (dj >= 0) { jj = dj; sigma = -1.0; }
-            else if (best > tol && bj < n_wm) { jj = bj; sigma = 1.0; }
-            else done = true;
             const int cnt = __builtin_popcountll(P[0]) + __builtin_popcountll(P[1]) + __builtin_popcountll(P[2]);
-            if (!done && (trips > trip_cap || (sigma > 0.0 && cnt >= 20))) { done = true; noseed = true; jj = -1; sigma = 0.0; }
+            const bool add1 = best > tol && bj < n_wm, add2 = best2 > tol && bj2 < n_wm;
+            if (dj >= 0) { jj = dj; sigma = -1.0; if (add1 && cnt < 20) { jj2 = bj; sigma2 = 1.0; } }
+            else if (add1) { jj = bj; sigma = 1.0; if (add2 && cnt < 19) { jj2 = bj2; sigma2 = 1.0; } }
+            else done = true;
+            if (!done && (trips > trip_cap || (sigma > 0.0 && cnt >= 20))) { done = true; noseed = true; jj = -1; sigma = 0.0; jj2 = -1; sigma2 = 0.0; }
         }
-        {
-            // v = s_jj (zero for the lanes without a change: every rotation is then the identity, bit for bit)
+#pragma unroll 1
+        for (int ch = 0; ch < 2; ch++) {
+            const int jc = ch == 0 ? jj : jj2;
+            const double sg = ch == 0 ? sigma : sigma2;
+            if (ch == 1 && __ballot(jc >= 0) == 0ull) break;
+            // v = s_jc (zero for the lanes without a change: every rotation is then the identity, bit for bit)
             double v[KD];
-            const double *col = Sl + (jj >= 0 ? jj : 0) * LD;
-            const double *yp = a.ytil + (size_t)pos * SLD;
+            const double *col = Sl + (jc >= 0 ? jc : 0) * LD;
             double cj = -lam1;
 #pragma unroll
-            for (int d = 0; d < KD; d++) { v[d] = (jj >= 0) ? col[d] : 0.0; cj += v[d] * yp[d]; }
+            for (int d = 0; d < KD; d++) { v[d] = (jc >= 0) ? col[d] : 0.0; cj += v[d] * yv[d]; }
 #pragma unroll
-            for (int d = 0; d < KD; d++) g[d] += sigma * cj * v[d];
-            if (jj >= 0) P[jj >> 6] ^= 1ull << (jj & 63);
+            for (int d = 0; d < KD; d++) g[d] += sg * cj * v[d];
+            if (jc >= 0) P[jc >> 6] ^= 1ull << (jc & 63);
 #pragma unroll
             for (int j = 0; j < KD; j++) {
                 const double al = T[stri<KD>(j, j)], bl = v[j];
                 const bool rot = bl != 0.0;
-                const double n2 = al * al + sigma * bl * bl;
+                const double n2 = al * al + sg * bl * bl;
                 const double ri = rot ? ((n2 > 0.0) ? inv_sqrt(n2) : 0.0) : dinv[j];
                 const double ss = rot ? bl * dinv[j] : 0.0;
                 const double cc = rot ? n2 * ri * dinv[j] : 1.0;       // cos
@@ -1755,7 +1796,7 @@ __global__ void __launch_bounds__(256, AMX_SEED2_OCC) k_lasso_seed(const Seed2Ar
                 dinv[j] = ri;
 #pragma unroll
                 for (int i = j + 1; i < KD; i++) {
-                    const double t = (T[stri<KD>(i, j)] + sigma * ss * v[i]) * ci;
+                    const double t = (T[stri<KD>(i, j)] + sg * ss * v[i]) * ci;
                     v[i] = cc * v[i] - ss * t;
                     T[stri<KD>(i, j)] = t;
                 }
