@@ -65,7 +65,7 @@ int amx_launch_noddi_seed2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a,
     const size_t lds = ((size_t)lut->n_wm * (kSeed2KD + 1) + 8 + (size_t)9 * (kSeed2KD / 4) * 64 + (size_t)4 * (64 * (kSeed2KD + 1) + 64 * 3)) * sizeof(double);
     int rc;
     if ((rc = set_lds(ctx, k_lasso_seed, lds))) return rc;
-    hipLaunchKernelGGL(k_lasso_seed, dim3(((pl.max_schunks + 7) / 8) * 8), dim3(64 * pl.seed_waves), lds, s, sa);
+    hipLaunchKernelGGL(k_lasso_seed, dim3(((pl.max_schunks + 7) / 8) * 8), dim3(64 * pl.seed1_waves), lds, s, sa);
     AMX_TRACE(ctx, s, "LASSO seed solver");
     HIPCHK(ctx, hipGetLastError());
     return AMX_OK;
