@@ -310,8 +310,21 @@ def signal_preparation(args):
         cpu = n / (time.perf_counter() - t1)
         exact = bool(np.array_equal(d_y.cpu().numpy(), ref))
         bpv = 4 * scheme.nS + 8 * scheme.nS + 4
+        # float32 rows out (amx_prep_gather_device_f32: what Evaluation.fit and the volume pipeline use)
+        d_y32 = torch.zeros((n, scheme.nS), dtype=torch.float32, device=dev)
+        k32 = 0.0
+        for it in range(args.warmup + args.steps):
+            ctx.check(L.amx_prep_gather_device_f32(ctx._h, sp._plan._h, d_img.data_ptr(), 1, 0.0, d_y32.data_ptr(), d_m.data_ptr(), None))
+            ctx.sync()
+            if it >= args.warmup:
+                k32 += ctx.last_kernel_ms(4)
+        k32 /= args.steps
+        bpv32 = 4 * scheme.nS + 4 * scheme.nS + 4
         out[order] = {'voxels': n, 'voxels_per_s': n * args.steps / el, 'kernel_ms': kms,
-                      'achieved_GBs': bpv * n / (kms * 1e-3) / 1e9, 'bit_exact_vs_numpy': exact, 'numpy_voxels_per_s': cpu}
+                      'achieved_GBs': bpv * n / (kms * 1e-3) / 1e9, 'bit_exact_vs_numpy': exact, 'numpy_voxels_per_s': cpu,
+                      'float32_rows': {'kernel_ms': k32, 'bytes_per_voxel': bpv32, 'achieved_GBs': bpv32 * n / (k32 * 1e-3) / 1e9,
+                                       'bit_exact_vs_numpy': bool(np.array_equal(d_y32.cpu().numpy().astype(np.float64), ref))}}
+        del d_y32
     if os.environ.get('PREP_DIRAVG', '1') != '0':
         # SANDI preprocessing: 306 volumes (6 b0 + 5 shells x 60) -> b0 mean + 5 shell means per masked voxel (core.py:229-252)
         full = S.make_sandi_scheme()
