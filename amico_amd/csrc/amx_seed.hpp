@@ -28,7 +28,17 @@ constexpr int kSeedMax = 8;      // passive-set capacity of the seed solver (= M
 #ifndef SEED3_SCAN_MAX
 #define SEED3_SCAN_MAX 32      // (diagnosis: a smaller value truncates the stage-3 candidate scan)
 #endif
-constexpr int kSeedLd = 13;      // LDS row stride of S (odd: per-lane column gathers spread over the banks)
+// one column of S for THIS lane from the LDS copy (row stride kSeedLd doubles = 112 bytes: 16-byte aligned rows): 16-byte reads --
+// the per-lane gathers are bound by the NUMBER of LDS instructions (a float32 copy with half the bytes changed nothing, reads of
+// twice the width took 9 % off the stage-3 seed solver)
+template <int KD>
+__device__ __forceinline__ void seed_col(const double *col, double (&cv)[KD])
+{
+    const double2 *c2 = reinterpret_cast<const double2 *>(col);
+#pragma unroll
+    for (int d = 0; d < KD; d += 2) { const double2 p = c2[d >> 1]; cv[d] = p.x; cv[d + 1] = p.y; }
+}
+constexpr int kSeedLd = 14;      // LDS row stride of S (odd: per-lane column gathers spread over the banks)
 constexpr unsigned long long kNoSeed = kSeedNone;
 
 // ------------------------------------------------------------------ basis of one orientation
@@ -627,8 +637,7 @@ __global__ void __launch_bounds__(256, (MS > 6 ? AMX_SEED1_OCC : 2)) k_nnls_seed
             for (int s = 0; s < MS; s++) {         // (slots >= np: x = 0, idx = 0 -- no predicate needed)
                 const double *col = Sl + V.idx[s] * LD;
                 double cv[KD];
-#pragma unroll
-                for (int d = 0; d < KD; d++) cv[d] = col[d];
+                seed_col<KD>(col, cv);
 #pragma unroll
                 for (int d = 0; d < KD; d++) r[d] -= V.x[s] * cv[d];
             }
@@ -672,10 +681,13 @@ __global__ void __launch_bounds__(256, (MS > 6 ? AMX_SEED1_OCC : 2)) k_nnls_seed
                     if (__ballot(scan && it < ncand) == 0ull) break;
                     const int j0 = (int)((cand[STAGE == 3 ? (it >> 3) : 0] >> (8 * (it & 7))) & 0xffull);
                     const int j1 = (int)((cand[STAGE == 3 ? ((it + 1) >> 3) : 0] >> (8 * ((it + 1) & 7))) & 0xffull);
-                    const double *c0 = Sl + j0 * LD, *c1 = Sl + j1 * LD;
+                    const double2 *c0 = reinterpret_cast<const double2 *>(Sl + j0 * LD), *c1 = reinterpret_cast<const double2 *>(Sl + j1 * LD);
                     double u0[KD], u1[KD];
 #pragma unroll
-                    for (int d = 0; d < KD; d++) { u0[d] = c0[d]; u1[d] = c1[d]; }
+                    for (int d = 0; d < KD; d += 2) {           // 16-byte LDS reads (row stride 14 doubles: 16-byte aligned rows)
+                        const double2 p0 = c0[d >> 1], p1 = c1[d >> 1];
+                        u0[d] = p0.x; u0[d + 1] = p0.y; u1[d] = p1.x; u1[d + 1] = p1.y;
+                    }
                     double w0a = 0.0, w0b = 0.0, w1a = 0.0, w1b = 0.0;
 #pragma unroll
                     for (int d = 0; d < KD; d += 2) { w0a += u0[d] * r[d]; w0b += u0[d + 1] * r[d + 1]; w1a += u1[d] * r[d]; w1b += u1[d + 1] * r[d + 1]; }
@@ -699,15 +711,15 @@ __global__ void __launch_bounds__(256, (MS > 6 ? AMX_SEED1_OCC : 2)) k_nnls_seed
                     // append atom bj as slot np: new row of the factor by one forward substitution
                     const double *ct = Sl + bj * LD;
                     double st[KD], cn = 0.0, htt = 0.0;
+                    seed_col<KD>(ct, st);
 #pragma unroll
-                    for (int d = 0; d < KD; d++) { st[d] = ct[d]; cn += st[d] * (PREF ? yv[PREF ? d : 0] : yp[d]); htt += st[d] * st[d]; }
+                    for (int d = 0; d < KD; d++) { cn += st[d] * (PREF ? yv[PREF ? d : 0] : yp[d]); htt += st[d] * st[d]; }
                     double h[MS];
 #pragma unroll
                     for (int s = 0; s < MS; s++) {
                         const double *col = Sl + V.idx[s] * LD;
                         double cv[KD];
-#pragma unroll
-                        for (int d = 0; d < KD; d++) cv[d] = col[d];
+                        seed_col<KD>(col, cv);
                         double v = 0.0;
 #pragma unroll
                         for (int d = 0; d < KD; d++) v += cv[d] * st[d];
@@ -1152,8 +1164,10 @@ __global__ void __launch_bounds__(256, 2) k_nnls_gcert(const GcertArgs a)
 #pragma unroll
             for (int s = 0; s < MS; s++) {
                 const double *col = Sl + V.idx[s] * LD;
+                double cv[KD];
+                seed_col<KD>(col, cv);
 #pragma unroll
-                for (int d = 0; d < KD; d++) rt[d] -= V.x[s] * col[d];
+                for (int d = 0; d < KD; d++) rt[d] -= V.x[s] * cv[d];
             }
             seed_flags_mfma<KS, MT>(Aop, Rb, lane, rt, good, good ? -1.0625 * kap * sqrt(rho2) - 1e-12 : __builtin_huge_val(), cand, ex);
         }
@@ -1388,8 +1402,10 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : 2) k_lasso_gcert(const Gcert2A
 #pragma unroll
             for (int s = 0; s < MS; s++) {
                 const double *col = Sl + V.idx[s] * LD;
+                double cv[KD];
+                seed_col<KD>(col, cv);
 #pragma unroll
-                for (int d = 0; d < KD; d++) rt[d] -= V.x[s] * col[d];
+                for (int d = 0; d < KD; d++) rt[d] -= V.x[s] * cv[d];
             }
             // compressed dual value s2_t'r~ - lambda1 > -kappa ||r||  <=>  s2_t'r~ > lambda1 - kappa ||r||
             seed_flags_mfma<KS, MT>(Aop, Rb, lane, rt, good, good ? lam1 - 1.0625 * kap * sqrt(rho2) - 1e-12 : __builtin_huge_val(), cand, ex);
