@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', '..'))
 from amico_amd import synthetic as S
 from scipy.optimize import nnls as sp_nnls
 n_vox = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-KD, MS, tol, cap = 12, 8, 1e-10, 96
+KD, MS, tol, cap = 12, int(sys.argv[2]) if len(sys.argv) > 2 else 8, 1e-10, 96
 dirs = S.fibonacci_hemisphere(500); ht = S.build_htable(dirs); sch = S.make_scheme(seed=0)
 K = S.noddi_kernels(sch, dirs)
 y, d = S.noddi_signals(n_vox, K, ht, sch, seed=5)
