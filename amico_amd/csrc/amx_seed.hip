@@ -165,7 +165,7 @@ int amx_launch_noddi_gcert(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a,
 #ifdef AMX_STATS
     g.stats = a.c.status + ST_SEED + 24 + (stage == 1 ? 0 : 6);
 #endif
-    const size_t lds = ((size_t)lut->n_atoms * kSeedLd + 2 + (stage == 1 ? (size_t)10 * (kSeedKD / 4) * 64 : 0) + (size_t)4 * 64 * 16) * sizeof(double);
+    const size_t lds = ((size_t)lut->n_atoms * kSeedLd + 2 + (size_t)10 * (kSeedKD / 4) * 64 + (size_t)4 * 64 * 16) * sizeof(double);
     const dim3 grid(((pl.max_schunks + 7) / 8) * 8);
     int rc;
     if (stage == 1) {

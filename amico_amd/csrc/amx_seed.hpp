@@ -1060,8 +1060,8 @@ __global__ void __launch_bounds__(256, 2) k_nnls_gcert(const GcertArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_c[];
     double *Sl = reinterpret_cast<double *>(smem_c);             // [n_atoms][LD]
     const int n_atoms = a.n_atoms;
-    double *Aop = Sl + (size_t)n_atoms * LD + 2;                  // stage 1: [MT][KS][64]
-    double *Rb = Aop + (STAGE == 1 ? MT * KS * 64 : 0) + (threadIdx.x >> 6) * (64 * RBW);   // per wavefront [64][16]: r~ | margin | masks
+    double *Aop = Sl + (size_t)n_atoms * LD + 2;                  // [MT][KS][64]
+    double *Rb = Aop + MT * KS * 64 + (threadIdx.x >> 6) * (64 * RBW);   // per wavefront [64][16]: r~ | margin | masks
     const int cid = xcd_chunk((int)blockIdx.x, *a.n_schunks);
     if (cid < 0) return;
     const Chunk ck = a.schunks[cid];
@@ -1070,7 +1070,7 @@ __global__ void __launch_bounds__(256, 2) k_nnls_gcert(const GcertArgs a)
     const double *__restrict__ Sg = a.Sb + (size_t)ck.dir * n_atoms * KD;
     const double *__restrict__ Gd = a.gram + (size_t)ck.dir * n_atoms * a.ldG;
     for (int e = threadIdx.x; e < n_atoms * KD; e += blockDim.x) { const int j = e / KD, d = e - j * KD; Sl[j * LD + d] = Sg[e]; }
-    if (STAGE == 1) {
+    {
         for (int e = threadIdx.x; e < MT * KS * 64; e += blockDim.x) {
             const int l = e & 63, ks = (e >> 6) % KS, mt = (e >> 6) / KS;
             const int atom = 16 * mt + (l & 15), d = 4 * ks + (l >> 4);
@@ -1079,6 +1079,12 @@ __global__ void __launch_bounds__(256, 2) k_nnls_gcert(const GcertArgs a)
     }
     __syncthreads();
     const double kap = a.kappa0[ck.dir];
+#ifdef AMX_STATS
+    long long gph[5] = {0, 0, 0, 0, 0}, gpt = (long long)__builtin_readcyclecounter();
+#define GC_PH(k) do { const long long t__ = (long long)__builtin_readcyclecounter(); gph[k] += t__ - gpt; gpt = t__; } while (0)
+#else
+#define GC_PH(k) do { } while (0)
+#endif
     const int n_blocks = (ck.count + 63) >> 6;
     for (int bl = wave; bl < n_blocks; bl += nw) {
         const int k = 64 * bl + lane;
@@ -1131,6 +1137,7 @@ __global__ void __launch_bounds__(256, 2) k_nnls_gcert(const GcertArgs a)
             }
         }
         if (!okv) V.np = 0;
+        GC_PH(0);
         // ---- Gram block, c_P, ||y||^2
 #pragma unroll
         for (int s = 0; s < MS; s++) {
@@ -1155,9 +1162,12 @@ __global__ void __launch_bounds__(256, 2) k_nnls_gcert(const GcertArgs a)
         for (int s = 0; s < MS; s++) { V.x[s] = z[s]; if (s < V.np && !(z[s] > 0.0)) feas = false; rho2 -= z[s] * V.c[s]; }
         rho2 = rho2 > 0.0 ? rho2 : 0.0;
         bool good = okv && piv && feas && (yy <= 1.79769313486231570e308);
+        GC_PH(1);
         // ---- which atoms need their exact dual value
+        // (stage 3 as well: its <= 25 admissible atoms used to be examined one by one -- 9 scattered loads each, the texture path of
+        //  the CU was the bottleneck; the MFMA screening clears all but ~1 of them)
         unsigned long long ex[3] = {cand[0], cand[1], cand[2]};
-        if (STAGE == 1) {
+        {
             double rt[KD];
 #pragma unroll
             for (int d = 0; d < KD; d++) rt[d] = Crow[(size_t)(kGemmU + d) * 64];
@@ -1171,31 +1181,52 @@ __global__ void __launch_bounds__(256, 2) k_nnls_gcert(const GcertArgs a)
             }
             seed_flags_mfma<KS, MT>(Aop, Rb, lane, rt, good, good ? -1.0625 * kap * sqrt(rho2) - 1e-12 : __builtin_huge_val(), cand, ex);
         }
+        GC_PH(2);
         // ---- exact (Gram-form) dual values of the flagged atoms: u_t = c_t - G_tP x
         bool viol = false;
         int n_ex = 0;
         {
+            // (UN flagged atoms per step: their 1 + np loads are independent and in flight together -- one atom per step made this loop,
+            //  a chain of L2 round trips as long as the wavefront's LONGEST list, 72 % of the kernel)
+            constexpr int UN = 2;
             unsigned long long rem[3] = {good ? ex[0] : 0ull, good ? ex[1] : 0ull, good ? ex[2] : 0ull};
-            for (int it = 0; it < 192; it++) {
-                int wq = -1;
+            for (int it = 0; it < 192; it += UN) {
+                if (__ballot((rem[0] | rem[1] | rem[2]) != 0ull) == 0ull) break;
+                int tt[UN];
+                bool on[UN];
 #pragma unroll
-                for (int qq = 2; qq >= 0; qq--) wq = (rem[qq] != 0ull) ? qq : wq;
-                if (__ballot(wq >= 0) == 0ull) break;
-                unsigned long long word = 0ull;
+                for (int u4 = 0; u4 < UN; u4++) {
+                    int wq = -1;
 #pragma unroll
-                for (int qq = 0; qq < 3; qq++) word = (wq == qq) ? rem[qq] : word;
-                const int t = (wq >= 0) ? wq * 64 + __builtin_ctzll(word) : 0;
+                    for (int qq = 2; qq >= 0; qq--) wq = (rem[qq] != 0ull) ? qq : wq;
+                    unsigned long long word = 0ull;
 #pragma unroll
-                for (int qq = 0; qq < 3; qq++) rem[qq] = (wq == qq) ? (rem[qq] & (rem[qq] - 1ull)) : rem[qq];
-                const bool on = wq >= 0 && t < n_atoms;
-                double u = on ? Crow[(size_t)t * 64] : 0.0;
-                const double *gt = Gd + (size_t)t * a.ldG;
+                    for (int qq = 0; qq < 3; qq++) word = (wq == qq) ? rem[qq] : word;
+                    const int t = (wq >= 0) ? wq * 64 + __builtin_ctzll(word) : 0;
 #pragma unroll
-                for (int s = 0; s < MS; s++) { if (s < V.np && on) u -= gt[V.idx[s]] * V.x[s]; }
-                if (on && !(u < -1e-10)) viol = true;                 // positive, or too close to zero for the Gram form to call
-                n_ex += on ? 1 : 0;
+                    for (int qq = 0; qq < 3; qq++) rem[qq] = (wq == qq) ? (rem[qq] & (rem[qq] - 1ull)) : rem[qq];
+                    on[u4] = wq >= 0 && t < n_atoms;
+                    tt[u4] = on[u4] ? t : 0;
+                }
+                double uu[UN], gg[UN][MS];
+#pragma unroll
+                for (int u4 = 0; u4 < UN; u4++) {
+                    uu[u4] = Crow[(size_t)tt[u4] * 64];
+                    const double *gt = Gd + (size_t)tt[u4] * a.ldG;
+#pragma unroll
+                    for (int s = 0; s < MS; s++) gg[u4][s] = gt[V.idx[s]];          // (slots >= np: idx = 0, x = 0)
+                }
+#pragma unroll
+                for (int u4 = 0; u4 < UN; u4++) {
+                    double u = uu[u4];
+#pragma unroll
+                    for (int s = 0; s < MS; s++) u -= gg[u4][s] * V.x[s];
+                    if (on[u4] && !(u < -1e-10)) viol = true;             // positive, or too close to zero for the Gram form to call
+                    n_ex += on[u4] ? 1 : 0;
+                }
             }
         }
+        GC_PH(3);
         const bool cert = good && !viol;
         if (valid) a.done[pos] = cert ? 1 : 0;
         {
@@ -1262,7 +1293,11 @@ __global__ void __launch_bounds__(256, 2) k_nnls_gcert(const GcertArgs a)
                 for (int s = 0; s < MS; s++) if (s < V.np) dst[V.idx[s]] = V.x[s];
             }
         }
+        GC_PH(4);
     }
+#ifdef AMX_STATS
+    if (a.stats && lane == 0) for (int q5 = 0; q5 < 5; q5++) atomicAdd(&a.stats[(STAGE == 1 ? 36 : 35) + q5], (int)(gph[q5] >> 10));
+#endif
 }
 
 // ================================================================== Gram-space certificate of the LASSO seeds, one voxel per lane
