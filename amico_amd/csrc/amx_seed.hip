@@ -94,7 +94,7 @@ int amx_launch_noddi_gemm(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, 
     ga.tiles = (const float *)lut->tiles; ga.tile_stride = lut->tile_stride; ga.ldA = lut->ldA; ga.nS = lut->nS; ga.n_atoms = lut->n_atoms;
     ga.Ub = lasso ? lut->basis2_U : lut->basis_U; ga.Cb = (double *)(lasso ? ctx->cgemm2.p : ctx->cgemm.p); ga.ytil = (double *)(lasso ? ctx->ytil2.p : ctx->ytil.p);
     ga.xiso = a.xiso; ga.rowdwi = lut->rowdwi; ga.colscale = lut->colscale; ga.iso_atom = lut->n_atoms - 1; ga.is_exvivo = lut->is_exvivo; ga.n_wm = lut->n_wm;
-    const size_t lds = (size_t)9 * 25 * 64 * sizeof(float) + ((size_t)25 * 64 + 100) * sizeof(double);
+    const size_t lds = (size_t)9 * 25 * 64 * sizeof(float) + ((size_t)25 * 64 + 100 + 160) * sizeof(double);
     int rc;
     const dim3 grid(((pl.max_schunks + 7) / 8) * 8);
     if (lasso) {

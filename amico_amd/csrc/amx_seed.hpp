@@ -820,6 +820,7 @@ __global__ void __launch_bounds__(256, 2) k_noddi_gemm(const GemmArgs a)
     float *A32 = reinterpret_cast<float *>(smem_g);                       // [9][KS][64]
     double *A64 = reinterpret_cast<double *>(A32 + (MT - 1) * KS * 64);   // [KS][64]: atoms 144 .. 159
     double *IsoT = A64 + KS * 64;                                         // [4 KS] iso atom by signal row (LASSO)
+    double *ScT = IsoT + 4 * KS;                                          // [160] column scale by output row, 0 beyond n_wm (LASSO)
     const int cid = xcd_chunk((int)blockIdx.x, *a.n_schunks);
     if (cid < 0) return;
     const Chunk ck = a.schunks[cid];
@@ -845,6 +846,7 @@ __global__ void __launch_bounds__(256, 2) k_noddi_gemm(const GemmArgs a)
     }
     if (LASSO) {
         for (int e = threadIdx.x; e < 4 * KS; e += blockDim.x) IsoT[e] = e < nS ? (double)tile[e * ldA + a.iso_atom] : 0.0;
+        for (int e = threadIdx.x; e < kGemmRows; e += blockDim.x) ScT[e] = e < a.n_wm ? a.colscale[e] : 0.0;
     }
     __syncthreads();
     const int n_groups = (ck.count + 15) >> 4;
@@ -919,7 +921,7 @@ __global__ void __launch_bounds__(256, 2) k_noddi_gemm(const GemmArgs a)
 #pragma unroll
                         for (int rr = 0; rr < 4; rr++) {
                             const int row = 16 * (mt + u) + 4 * rr + q;
-                            out[(size_t)row * 64] = LASSO ? ((row < a.n_wm) ? a.colscale[row] * acc[u][rr] : 0.0) : acc[u][rr];
+                            out[(size_t)row * 64] = LASSO ? ScT[row] * acc[u][rr] : acc[u][rr];
                         }
                     }
                 }
@@ -933,7 +935,7 @@ __global__ void __launch_bounds__(256, 2) k_noddi_gemm(const GemmArgs a)
 #pragma unroll
                 for (int rr = 0; rr < 4; rr++) {
                     const int row = 16 * (MT - 1) + 4 * rr + q;
-                    out[(size_t)row * 64] = (row == kGemmYY) ? yy : ((LASSO && row < a.n_wm) ? a.colscale[row] * acc[rr] : acc[rr]);
+                    out[(size_t)row * 64] = (row == kGemmYY) ? yy : ((LASSO && row < a.n_wm) ? ScT[row] * acc[rr] : acc[rr]);
                     // the projections once more in voxel-major order for the kernels that walk the 256-voxel chunks
                     if (a.ytil != nullptr && row >= kGemmU && row < kGemmU + kSeedKD) a.ytil[(size_t)(ck.start + 16 * g + c16) * kSeedKD + (row - kGemmU)] = acc[rr];
                 }
