@@ -452,6 +452,8 @@ int amx_sync_status(amx_ctx *ctx, void *hip_stream)
     if (amx_debug()) fprintf(stderr, "[amx] seed solver kcycles (wave sums / 1024): take %d solve+drop %d residual %d scan %d append %d store %d\n", st[ST_SEED + 12], st[ST_SEED + 13], st[ST_SEED + 14], st[ST_SEED + 15], st[ST_SEED + 16], st[ST_SEED + 17]);
     if (amx_debug()) fprintf(stderr, "[amx] Gram certificate kcycles (decode | gather+factor+solve | screening | exact duals | output): stage 1 %d %d %d %d %d, stage 3 %d %d %d %d %d\n",
                              st[ST_SEED + 60], st[ST_SEED + 61], st[ST_SEED + 62], st[ST_SEED + 63], st[ST_SEED + 64], st[ST_SEED + 65], st[ST_SEED + 66], st[ST_SEED + 67], st[ST_SEED + 68], st[ST_SEED + 69]);
+    if (amx_debug()) fprintf(stderr, "[amx] LASSO Gram certificate kcycles (decode | gather+factor+solve | screening | exact duals | output): %d %d %d %d %d\n",
+                             st[ST_SEED + 70], st[ST_SEED + 71], st[ST_SEED + 72], st[ST_SEED + 73], st[ST_SEED + 74]);
     if (amx_debug()) fprintf(stderr, "[amx] stage-3 seed solver kcycles: take %d solve+drop %d residual %d scan %d append %d store %d\n", st[ST_SEED + 54], st[ST_SEED + 55], st[ST_SEED + 56], st[ST_SEED + 57], st[ST_SEED + 58], st[ST_SEED + 59]);
     if (st[ST_ERRVOX] != 0x7f7f7f7f) {
         char b[256];

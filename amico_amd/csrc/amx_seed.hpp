@@ -1337,8 +1337,11 @@ struct Gcert2Args {
 // WIDE = false: every voxel of the chunk, supports of up to 12 atoms, two wavefronts per SIMD.  WIDE = true: second pass over the
 // left-over lists of the first for the supports of 13 .. 16 atoms (another 13 % of the voxels at the default lambdas), one
 // wavefront per SIMD -- the 16 x 16 triangle lives in the whole register file; what it cannot settle goes on to k_noddi<4>.
+#ifndef AMX_GCERT2_OCC
+#define AMX_GCERT2_OCC 2
+#endif
 template <int MS, bool WIDE>
-__global__ void __launch_bounds__(256, WIDE ? 1 : 2) k_lasso_gcert(const Gcert2Args a)
+__global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(const Gcert2Args a)
 {
     constexpr int KD = kSeedKD, KS = KD / 4, MT = 9, LD = kSeedLd, RBW = 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_c2[];
@@ -1364,6 +1367,9 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : 2) k_lasso_gcert(const Gcert2A
     }
     __syncthreads();
     const double kap = a.kappa0[ck.dir], lam1 = a.lam1, lam2 = a.lam2;
+#ifdef AMX_STATS
+    long long gph[5] = {0, 0, 0, 0, 0}, gpt = (long long)__builtin_readcyclecounter();
+#endif
     const int n_blocks = (n_items + 63) >> 6;
     for (int bl = wave; bl < n_blocks; bl += nw) {
         const int k = 64 * bl + lane;
@@ -1407,6 +1413,7 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : 2) k_lasso_gcert(const Gcert2A
             const unsigned long long all = c >= 64 ? ~0ull : (c > 0 ? ((1ull << c) - 1ull) : 0ull);
             cand[w3] = all & ~P[w3];
         }
+        GC_PH(0);
         double sc[MS];
 #pragma unroll
         for (int s = 0; s < MS; s++) sc[s] = scl[V.idx[s]];
@@ -1431,6 +1438,7 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : 2) k_lasso_gcert(const Gcert2A
         }
         rho2 = rho2 > 0.0 ? rho2 : 0.0;
         const bool good = okv && piv && feas && (yy <= 1.79769313486231570e308);
+        GC_PH(1);
         unsigned long long ex[3] = {0ull, 0ull, 0ull};
         {
             double rt[KD];
@@ -1447,6 +1455,7 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : 2) k_lasso_gcert(const Gcert2A
             // compressed dual value s2_t'r~ - lambda1 > -kappa ||r||  <=>  s2_t'r~ > lambda1 - kappa ||r||
             seed_flags_mfma<KS, MT>(Aop, Rb, lane, rt, good, good ? lam1 - 1.0625 * kap * sqrt(rho2) - 1e-12 : __builtin_huge_val(), cand, ex);
         }
+        GC_PH(2);
         bool viol = false;
         int n_ex = 0;
         {
@@ -1472,6 +1481,7 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : 2) k_lasso_gcert(const Gcert2A
                 n_ex += on ? 1 : 0;
             }
         }
+        GC_PH(3);
         const bool cert = good && !viol;
         if (valid) a.done[pos] = cert ? 1 : 0;
         {
@@ -1506,7 +1516,11 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : 2) k_lasso_gcert(const Gcert2A
                 if (a.dot_atom >= 0) dst[a.dot_atom] = a.xiso[(size_t)vox * 2 + 1];
             }
         }
+        GC_PH(4);
     }
+#ifdef AMX_STATS
+    if (!WIDE && a.stats && lane == 0) for (int q5 = 0; q5 < 5; q5++) atomicAdd(&a.stats[34 + q5], (int)(gph[q5] >> 10));
+#endif
 }
 
 // ================================================================== LASSO stage (models.pyx:914-926): seeds in Woodbury form
