@@ -629,7 +629,7 @@ static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
         if (gcert2) {
             const bool wide = !ctx->opt_no_gcert_wide;
             if ((rc = amx_launch_noddi_gcert2(ctx, lut, a, pl, s, wide))) return rc;
-            a.rlist = (const int *)ctx->rlist.p + (wide ? amx_rlist_half(pl) : 0); a.rcount = a.rlist + pl.n;
+            a.rlist = (const int *)ctx->rlist.p + amx_gcert2_leftover_offset(pl, wide); a.rcount = a.rlist + pl.n;   // (two wide passes end in the first half again)
             a.c.chunks = pl.schunks; a.c.n_chunks = pl.n_chunks + 1;
         }
         rec(ctx, 13, s);

@@ -200,6 +200,7 @@ int amx_launch_noddi_seed(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs
 int amx_launch_noddi_gcert(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, int stage);
 int amx_launch_noddi_gemm(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, bool lasso);
 int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, bool wide);
+size_t amx_gcert2_leftover_offset(const Plan &pl, bool wide);      // which half of ctx->rlist the LASSO certificate passes end in (amx_seed.hip)
 static inline size_t amx_rlist_half(const Plan &pl) { return (size_t)pl.n + pl.max_schunks + 64; }   // ints per left-over list + counts
 int amx_launch_noddi_seed2(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, bool have_ytil2);
 int amx_launch_noddi_s1(amx_ctx *ctx, amx::NoddiArgs &a, const Plan &pl, hipStream_t s);

@@ -1310,9 +1310,15 @@ __global__ void __launch_bounds__(256, 2) k_nnls_gcert(const GcertArgs a)
 // (87 % of the voxels; the rest, and everything refused, goes to k_noddi<4> through the left-over lists).
 constexpr int kGcert2Max = 12;
 #ifndef AMX_GCERT2_WIDE
-#define AMX_GCERT2_WIDE 16
+#define AMX_GCERT2_WIDE 18
 #endif
 constexpr int kGcert2Wide = AMX_GCERT2_WIDE;   // second pass (k_lasso_gcert<.., true>)
+#ifndef AMX_GCERT2_WIDE3
+#define AMX_GCERT2_WIDE3 18
+#endif
+constexpr int kGcert2Wide3 = AMX_GCERT2_WIDE3; // optional third pass over what the second left (> kGcert2Wide enables it).  Measured, 1 M voxels, fit ms:
+                                               // 12 / 16: 10.46; 12 / 18: 10.33 (121 spilled registers, but the left-over kernel sees 1.0 % instead of 2.3 %
+                                               // of the voxels); 12 / 19: 10.35; 12 / 20: 10.42; 12 / 16 / 18: 10.34; 12 / 16 / 20: 10.42
 struct Gcert2Args {
     const int *perm;
     const Chunk *schunks;
@@ -1335,12 +1341,12 @@ struct Gcert2Args {
 };
 
 // WIDE = false: every voxel of the chunk, supports of up to 12 atoms, two wavefronts per SIMD.  WIDE = true: second pass over the
-// left-over lists of the first for the supports of 13 .. 16 atoms (another 13 % of the voxels at the default lambdas), one
-// wavefront per SIMD -- the 16 x 16 triangle lives in the whole register file; what it cannot settle goes on to k_noddi<4>.
+// left-over lists of the first for the supports of 13 .. 18 atoms (another 15 % of the voxels at the default lambdas), one
+// wavefront per SIMD -- the triangle lives in the whole register file (18: 121 spilled registers); what it cannot settle goes on to k_noddi<4>.
 #ifndef AMX_GCERT2_OCC
 #define AMX_GCERT2_OCC 2
 #endif
-template <int MS, bool WIDE>
+template <int MS, bool WIDE, int LOW = kGcert2Max>
 __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(const Gcert2Args a)
 {
     constexpr int KD = kSeedKD, KS = KD / 4, MT = 9, LD = kSeedLd, RBW = 16;
@@ -1382,7 +1388,7 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
         const unsigned long long flag = sd[3];
         const int vox = a.perm[pos];
         const int cnt = __builtin_popcountll(P[0]) + __builtin_popcountll(P[1]) + __builtin_popcountll(P[2]);
-        bool okv = valid && flag == 0ull && cnt <= MS && (!WIDE || cnt > kGcert2Max);
+        bool okv = valid && flag == 0ull && cnt <= MS && (!WIDE || cnt > LOW);
         SeedLane<MS> V;
         V.clear();
         {
