@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """k_noddi_gemm against numpy: C = [A | U]'y per voxel, block-wise layout, ||y||^2"""
 import os, sys
+os.environ.setdefault('AMX_SEED_MIN_VOXELS', '0')      # (small inputs would take the unseeded kernels: read at context creation)
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

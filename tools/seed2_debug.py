@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """LASSO seed solver: check the device's final passive sets against the compressed problem's own KKT conditions (numpy)."""
 import os, sys
+os.environ.setdefault('AMX_SEED_MIN_VOXELS', '0')      # (small inputs would take the unseeded kernels: read at context creation)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
