@@ -565,3 +565,32 @@ def test_whole_chain_freewater_and_sandi(htable500):
     Kref = S.sandi_kernels(ae.scheme)[0]
     assert np.abs(np.asarray(Ks['signal']) - np.asarray(Kref['signal'])).max() < 1e-5
     assert np.abs(np.asarray(Ks['norms']) - np.asarray(Kref['norms'])).max() < 1e-4 * np.abs(np.asarray(Kref['norms'])).max()
+
+
+@pytest.mark.parametrize('switch', ['AMX_NO_GCERT', 'AMX_NO_GCERT_WIDE', 'AMX_NO_SCREEN', 'AMX_SEED_STAGES=1', 'AMX_SEED_STAGES=6',
+                                    'AMX_SEED_CHUNK=1024', 'AMX_SEED_WAVES=2', 'AMX_NO_SEED'])
+def test_noddi_diagnosis_switches_keep_the_maps(htable500, switch, amx_env):
+    """every A/B switch of the seeded chain (certificates off, second certificate pass off, screening off, seeds for some stages
+    only, other chunk / workgroup sizes, no seeds at all) must end at the same maps: 70 000 voxels, a sample against the oracle and
+    all of them against the default chain"""
+    from amico_amd import _capi, get_context, synthetic as S
+    from oracle import oracle
+    ht = htable500['htable']
+    sch = S.make_scheme(seed=0)
+    K = S.noddi_kernels(sch, htable500['dirs'])
+    y, d = S.noddi_signals(70_000, K, ht, sch, seed=31)
+    ctx = get_context()
+    lut = _capi.upload_noddi(ctx, K, ht, sch.dwi_idx)
+    base = _capi.noddi_fit(ctx, lut, y, d, 0.5, 1e-3, 3, rmse=True)
+    name, _, val = switch.partition('=')
+    amx_env(**{name: val or '1'})
+    ctx2 = get_context()
+    assert ctx2 is not ctx
+    lut2 = _capi.upload_noddi(ctx2, K, ht, sch.dwi_idx)
+    got = _capi.noddi_fit(ctx2, lut2, y, d, 0.5, 1e-3, 3, rmse=True)
+    assert np.abs(got[0] - base[0]).max() < 1e-8 and np.abs(got[1] - base[1]).max() < 1e-8
+    st = ctx2.last_stats()
+    assert st['itercap_voxels'] == 0 and st['guard_trips'] == 0
+    m = 3000
+    ref = oracle.noddi_fit(y[:m], d[:m], K, ht, sch.dwi_idx, nthreads=8)['estimates']
+    assert np.abs(got[0][:m] - ref).max() < TOL
