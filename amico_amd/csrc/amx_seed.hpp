@@ -253,12 +253,12 @@ __device__ __forceinline__ void seed_scan_mfma(const double *Aop, double *Rb, co
     }
     const double ninf = -__builtin_huge_val();
     double bv[4] = {ninf, ninf, ninf, ninf};
-#pragma unroll
-    for (int mt = 0; mt < MT; mt++) {
+    // software pipeline: the 12 products of tile mt + 1 are issued BEFORE the tag / max work on tile mt's results, so the matrix
+    // pipe runs while the vector pipe reduces (one wavefront per SIMD: nothing else would overlap the two)
+    auto products = [&](int mt, seed_v4d (&acc)[4]) {
         double av[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) av[ks] = Aop[(mt * KS + ks) * 64 + lane];
-        seed_v4d acc[4];
 #pragma unroll
         for (int nt = 0; nt < 4; nt++) acc[nt] = (seed_v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -266,15 +266,25 @@ __device__ __forceinline__ void seed_scan_mfma(const double *Aop, double *Rb, co
 #pragma unroll
             for (int nt = 0; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], b[nt][ks], acc[nt], 0, 0, 0);
         }
+    };
+    seed_v4d cur[4], nxt[4];
+    products(0, cur);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        if (mt + 1 < MT) products(mt + 1, nxt);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int nt = 0; nt < 4; nt++) {
 #pragma unroll
             for (int rr = 0; rr < 4; rr++) {
-                const double v = acc[nt][rr];
+                const double v = cur[nt][rr];
                 const unsigned lo = ((unsigned)__double2loint(v) & 0xffffff00u) | (unsigned)(mt * 4 + rr);
                 bv[nt] = seed_max(bv[nt], __hiloint2double(__double2hiint(v), (int)lo));
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) cur[nt] = nxt[nt];
     }
     double mine = ninf;
 #pragma unroll
