@@ -1764,19 +1764,12 @@ __global__ void __launch_bounds__(256, AMX_SEED2_OCC) k_lasso_seed(const Seed2Ar
             // tag trick) names the atom that leaves -- no second pass over the passive set with per-lane gathers
             double wv[4] = {ninf, ninf, ninf, ninf};
             double b2[4] = {ninf, ninf, ninf, ninf};           // runner-up of bv (two atoms may enter in one trip)
-            // (rolled: unrolled, the scheduler overlaps the nine tiles and spills; the mask word of a tile is picked by a
-            //  wave-uniform index, so nothing is indexed dynamically in registers)
-#pragma unroll 1
-            for (int mt = 0; mt < MT; mt++) {
+            // (one wavefront per SIMD: unrolled and software-pipelined like seed_scan_mfma -- the products of tile mt + 1 are issued
+            //  before the mask / tag / max work on tile mt)
+            auto products = [&](int mt, seed_v4d (&acc)[4]) {
                 double av[KS];
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) av[ks] = Aop[(mt * KS + ks) * 64 + lane];
-                // passive bits of the voxels 16 nt + c16 for this tile's atoms (row-shifted), read back per tile instead of
-                // living in 24 registers for the whole scan
-                unsigned long long pw[4];
-#pragma unroll
-                for (int nt = 0; nt < 4; nt++) pw[nt] = Pb[(16 * nt + c16) * 3 + ((16 * mt) >> 6)] >> q;
-                seed_v4d acc[4];
 #pragma unroll
                 for (int nt = 0; nt < 4; nt++) acc[nt] = (seed_v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -1784,14 +1777,25 @@ __global__ void __launch_bounds__(256, AMX_SEED2_OCC) k_lasso_seed(const Seed2Ar
 #pragma unroll
                     for (int nt = 0; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], b[nt][ks], acc[nt], 0, 0, 0);
                 }
+            };
+            seed_v4d cur[4], nxt[4];
+            products(0, cur);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                if (mt + 1 < MT) products(mt + 1, nxt);
+                // passive bits of the voxels 16 nt + c16 for this tile's atoms (row-shifted), read back per tile instead of
+                // living in 24 registers for the whole scan
+                unsigned long long pw[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) pw[nt] = Pb[(16 * nt + c16) * 3 + ((16 * mt) >> 6)] >> q;
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int nt = 0; nt < 4; nt++) {
 #pragma unroll
                     for (int rr = 0; rr < 4; rr++) {
-                        constexpr int dummy = 0; (void)dummy;
                         const int bit = 16 * mt + 4 * rr;        // position of this atom in the row-shifted mask
                         const bool pas = (pw[nt] >> (bit & 63)) & 1ull;
-                        const double v = acc[nt][rr];
+                        const double v = cur[nt][rr];
                         const unsigned lo = ((unsigned)__double2loint(v) & 0xffffff00u) | (unsigned)(mt * 4 + rr);
                         const int hi = pas ? (int)0xffe00000 : __double2hiint(v);     // passive: -9e307 (finite whatever the low word is; 0xfff... would be a NaN)
                         const double val = __hiloint2double(hi, (int)lo);
@@ -1801,6 +1805,9 @@ __global__ void __launch_bounds__(256, AMX_SEED2_OCC) k_lasso_seed(const Seed2Ar
                         wv[nt] = seed_max(wv[nt], __hiloint2double(hn, (int)lo));
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) cur[nt] = nxt[nt];
             }
             double mine = ninf;
 #pragma unroll
