@@ -138,7 +138,7 @@ int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a
     AMX_TRACE(ctx, s, "Gram-space certificates of the LASSO seeds");
     HIPCHK(ctx, hipGetLastError());
     if (wide) {
-        // second pass: supports of 13 .. 18 atoms from the left-over lists; its own left-overs in the second half of the buffer
+        // second pass: supports of 12 .. 18 atoms from the left-over lists; its own left-overs in the second half of the buffer
         g.rlist_in = g.rlist; g.rcount_in = g.rcount;
         g.rlist = (int *)ctx->rlist.p + amx_rlist_half(pl); g.rcount = g.rlist + pl.n;
         HIPCHK(ctx, hipMemsetAsync(g.rcount, 0, (size_t)pl.max_schunks * sizeof(int), s));
@@ -147,7 +147,7 @@ int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a
 #endif
         if ((rc = set_lds(ctx, (k_lasso_gcert<kGcert2Wide, true>), lds))) return rc;
         hipLaunchKernelGGL((k_lasso_gcert<kGcert2Wide, true>), dim3(((pl.max_schunks + 7) / 8) * 8), dim3(64 * pl.seed_waves), lds, s, g);
-        AMX_TRACE(ctx, s, "Gram-space certificates of the LASSO seeds, supports of 13 .. 18 atoms");
+        AMX_TRACE(ctx, s, "Gram-space certificates of the LASSO seeds, supports of 12 .. 18 atoms");
         HIPCHK(ctx, hipGetLastError());
         if (kGcert2Wide3 > kGcert2Wide) {
             // third pass: supports beyond the second pass from the second pass's left-overs, back into the first half of the buffer

@@ -1318,7 +1318,10 @@ __global__ void __launch_bounds__(256, 2) k_nnls_gcert(const GcertArgs a)
 // dual value of atom t: g_t = c2_t - (S G2 S)_tP x_P - lambda1.  The ridge bounds cond(H), so no pivot guard is needed
 // -- this is the arithmetic GramSolver::certify_seed performs too.  A lane holds the factor of up to 12 passive atoms
 // (87 % of the voxels; the rest, and everything refused, goes to k_noddi<4> through the left-over lists).
-constexpr int kGcert2Max = 12;
+#ifndef AMX_GCERT2_MAX
+#define AMX_GCERT2_MAX 11      // (12: 37 spilled registers in the first pass, LASSO group 3.44 ms; 11: none, 3.37 ms; 10: 3.48 ms)
+#endif
+constexpr int kGcert2Max = AMX_GCERT2_MAX;
 #ifndef AMX_GCERT2_WIDE
 #define AMX_GCERT2_WIDE 18
 #endif
@@ -1350,8 +1353,8 @@ struct Gcert2Args {
     int *stats;
 };
 
-// WIDE = false: every voxel of the chunk, supports of up to 12 atoms, two wavefronts per SIMD.  WIDE = true: second pass over the
-// left-over lists of the first for the supports of 13 .. 18 atoms (another 15 % of the voxels at the default lambdas), one
+// WIDE = false: every voxel of the chunk, supports of up to 11 atoms, two wavefronts per SIMD.  WIDE = true: second pass over the
+// left-over lists of the first for the supports of 12 .. 18 atoms (another 22 % of the voxels at the default lambdas), one
 // wavefront per SIMD -- the triangle lives in the whole register file (18: 121 spilled registers); what it cannot settle goes on to k_noddi<4>.
 #ifndef AMX_GCERT2_OCC
 #define AMX_GCERT2_OCC 2
