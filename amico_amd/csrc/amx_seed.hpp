@@ -443,8 +443,11 @@ struct SeedLane {
 #ifndef AMX_SEED1_OCC
 #define AMX_SEED1_OCC 1
 #endif
+#ifndef AMX_SEED3_OCC
+#define AMX_SEED3_OCC 1
+#endif
 template <int STAGE, int MS>
-__global__ void __launch_bounds__(256, (MS > 6 ? AMX_SEED1_OCC : 2)) k_nnls_seed(const SeedArgs a)
+__global__ void __launch_bounds__(256, (MS > 6 ? AMX_SEED1_OCC : AMX_SEED3_OCC)) k_nnls_seed(const SeedArgs a)
 {
     constexpr int KD = kSeedKD, LD = kSeedLd;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
@@ -492,9 +495,11 @@ __global__ void __launch_bounds__(256, (MS > 6 ? AMX_SEED1_OCC : 2)) k_nnls_seed
     // Stage 1 (one wavefront per SIMD, registers to spare): the voxel's y~ stays in registers, and a lane RESERVES its next voxel
     // while it works on the current one -- the 12 loads of the next y~ are in flight for a whole solve instead of being waited
     // for in every trip in which some lane of the wavefront refills (measured: 15 % of the kernel).
-    constexpr bool PREF = (MS > 6);
-    static_assert(!(PREF && STAGE == 3), "the reservation path does not load the stage-3 candidate masks");
+    // (stage 3 as well, at one wavefront per SIMD -- which by itself costs it nothing: 1.10 ms either way -- with the admissible-atom
+    //  mask of the next voxel prefetched next to its y~)
+    constexpr bool PREF = (MS > 6) || (STAGE == 3 && AMX_SEED3_OCC == 1);
     double yv[PREF ? KD : 1], ynext[PREF ? KD : 1];
+    unsigned long long nallow[(PREF && STAGE == 3) ? 4 : 1];
     int next_pos = -1;
     bool have_next = false;
     for (int guard = 0; guard < (1 << 20); ++guard) {
@@ -507,6 +512,11 @@ __global__ void __launch_bounds__(256, (MS > 6 ? AMX_SEED1_OCC : 2)) k_nnls_seed
                 for (int d = 0; d < KD; d++) { yv[PREF ? d : 0] = ynext[PREF ? d : 0]; finite = finite && (fabs(yv[PREF ? d : 0]) <= 1.79769313486231570e308); }
                 trips = 0; last_added = -1; ban0 = -1; ban1 = -1;
                 V.clear();
+                if (STAGE == 3) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; q4++) allow[STAGE == 3 ? q4 : 0] = nallow[(PREF && STAGE == 3) ? q4 : 0];
+                    ncand = -1;                                 // (byte list below)
+                }
                 if (finite) active = true;
                 else a.seeds[pos] = kNoSeed;
             }
@@ -524,6 +534,13 @@ __global__ void __launch_bounds__(256, (MS > 6 ? AMX_SEED1_OCC : 2)) k_nnls_seed
                     const double *yp = a.ytil + (size_t)next_pos * KD;
 #pragma unroll
                     for (int d = 0; d < KD; d++) ynext[PREF ? d : 0] = yp[d];
+                    if (STAGE == 3) {
+                        const int vox = a.perm[next_pos];
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; q4++) nallow[(PREF && STAGE == 3) ? q4 : 0] = a.supp[(size_t)vox * 4 + q4];
+                        nallow[(PREF && STAGE == 3) ? (a.iso_atom >> 6) : 0] |= 1ull << (a.iso_atom & 63);
+                        if (a.dot_atom >= 0) nallow[(PREF && STAGE == 3) ? (a.dot_atom >> 6) : 0] |= 1ull << (a.dot_atom & 63);
+                    }
                 }
             }
             if (__ballot(active) == 0ull) {
