@@ -30,7 +30,15 @@ int make_plan(amx_ctx *ctx, int64_t n, int ndirs, Plan &pl, bool seeds = false)
     const int max_chunks = (int)(n / kChunk) + ndirs + 1;
     pl.n = (size_t)n;
     if (seeds) {
-        const int sc = ctx->opt_seed_chunk;
+        // Chunk of the second plan: whole orientations wherever possible (a lane then walks many voxels and the tail of the chunk
+        // is a small share), i.e. about twice the mean population -- 4 M voxels, ndirs 500: 4096 -> 103 M voxels/s (every
+        // orientation cut in two or three), 8192 -> 83 M, 16384 -> 123 M; never below 4096 (1 M voxels: 2048 -> 72 M, 4096 -> 99 M).
+        int sc = ctx->opt_seed_chunk;
+        if (sc <= 0) {
+            const long long want = 2 * (long long)n / (ndirs > 512 ? ndirs : 512);
+            sc = (int)(want < 4096 ? 4096 : (want > 65536 ? 65536 : ((want + 63) & ~63LL)));
+        }
+        pl.seed_chunk = sc;
         pl.max_schunks = (int)(n / sc) + ndirs + 1;
         pl.seed_waves = ctx->opt_seed_waves ? ctx->opt_seed_waves : 4;
         // (measured, ndirs = 500: 100 000 / 200 000 / 400 000 / 1 M voxels -> stage-1 group 1.11 / 1.55 / 2.31 / 4.66 ms with two
@@ -74,7 +82,7 @@ int enqueue_bucketing(amx_ctx *ctx, const amx_lut *lut, const double *d_dirs, in
                        (int)n, lut->htable, lut->ndirs, pl.lutidx, pl.counts, ctx->status_d, use_lds, (int)ctx->vox_base);
     AMX_TRACE(ctx, s, "k_dir_to_lut");
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, pl.counts, lut->ndirs, chunk, pl.dir_start,
-                       pl.cursor, pl.chunks, pl.n_chunks, pl.schunks ? ctx->opt_seed_chunk : 0, pl.schunks);
+                       pl.cursor, pl.chunks, pl.n_chunks, pl.schunks ? pl.seed_chunk : 0, pl.schunks);
     AMX_TRACE(ctx, s, "k_plan");
     hipLaunchKernelGGL(k_bucket, dim3(nb), dim3(1024), use_lds ? (size_t)2 * lut->ndirs * sizeof(int) : 0, s, pl.lutidx,
                        (int)n, lut->ndirs, pl.dir_start, pl.cursor, pl.perm, use_lds);
