@@ -84,6 +84,10 @@ int enqueue_bucketing(amx_ctx *ctx, const amx_lut *lut, const double *d_dirs, in
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, pl.counts, lut->ndirs, chunk, pl.dir_start,
                        pl.cursor, pl.chunks, pl.n_chunks, pl.schunks ? pl.seed_chunk : 0, pl.schunks);
     AMX_TRACE(ctx, s, "k_plan");
+    if (pl.schunks && !ctx->opt_no_chunk_order) {
+        hipLaunchKernelGGL(k_order_schunks, dim3(1), dim3(1024), 0, s, pl.schunks, pl.n_chunks);
+        AMX_TRACE(ctx, s, "k_order_schunks");
+    }
     hipLaunchKernelGGL(k_bucket, dim3(nb), dim3(1024), use_lds ? (size_t)2 * lut->ndirs * sizeof(int) : 0, s, pl.lutidx,
                        (int)n, lut->ndirs, pl.dir_start, pl.cursor, pl.perm, use_lds);
     AMX_TRACE(ctx, s, "k_bucket");
@@ -203,6 +207,7 @@ int amx_ctx_create(int device, amx_ctx **out)
         if (e && *e) { const int v = atoi(e); ctx->opt_seed_waves = (v == 1 || v == 2 || v == 4) ? v : 0; }
         e = getenv("AMX_SEED_MIN_VOXELS");
         if (e && *e) ctx->opt_seed_min_voxels = atoll(e);
+        ctx->opt_no_chunk_order = on("AMX_NO_CHUNK_ORDER");
         e = getenv("AMX_NO_GCERT_WIDE");
         ctx->opt_no_gcert_wide = e && *e && *e != '0';
         e = getenv("AMX_NO_SCREEN");

@@ -68,6 +68,7 @@ struct amx_ctx {
     bool opt_no_refill = false;        // AMX_NO_REFILL=1: FreeWater by k_freewater_lane (one solve per lane and pass)
     bool opt_wave_per_voxel = false;   // AMX_WAVE_PER_VOXEL=1: small models by the wavefront-per-voxel kernels
     int opt_refill_chunk = 0;          // AMX_REFILL_CHUNK: voxels per workgroup of k_freewater_refill (0 = by problem size)
+    bool opt_no_chunk_order = false; // AMX_NO_CHUNK_ORDER=1: the chunks of the second plan stay in orientation order (default: longest first)
     bool opt_no_gcert_wide = false; // AMX_NO_GCERT_WIDE=1: no second Gram-certificate pass for LASSO supports of 13 .. 16 atoms
     bool opt_no_gcert = false;     // AMX_NO_GCERT=1: every seed is certified by the wavefront-per-voxel kernels (true residual)
     bool opt_no_screen = false;    // AMX_NO_SCREEN=1: certify seeds with the full exact sweep of the dual vector

@@ -212,4 +212,45 @@ __global__ void k_build_gram(const float *__restrict__ tiles, int tile_stride, i
     }
 }
 
+// Longest chunks first for the lane kernels of the second plan: a kernel with one workgroup per chunk and one or two workgroups per
+// CU runs two or three "rounds" of workgroups over the chip, and the populations of the orientations differ by +-30 %; started in
+// order of decreasing size (LPT) the last round ends together instead of waiting for its largest member.  The kernels map
+// blockIdx -> chunk through xcd_chunk(): the p-th largest chunk is stored where the p-th dispatched workgroup looks.
+__global__ void __launch_bounds__(1024) k_order_schunks(Chunk *__restrict__ chunks2, const int *__restrict__ n_chunks)
+{
+    constexpr int CAP = 2048;
+    __shared__ unsigned long long key[CAP];
+    __shared__ Chunk tmp[CAP];
+    __shared__ int map[CAP];
+    const int n = n_chunks[1];
+    if (n < 2 || n > CAP) return;
+    for (int i = threadIdx.x; i < CAP; i += blockDim.x) {
+        key[i] = i < n ? (((unsigned long long)(unsigned)chunks2[i].count << 32) | (unsigned)(CAP - 1 - i)) : 0ull;   // ties: list order
+        if (i < n) tmp[i] = chunks2[i];
+    }
+    if (threadIdx.x == 0) {
+        const int per = (n + 7) >> 3;
+        int r = 0;
+        for (int b = 0; b < 8 * per; b++) {
+            const int cid = (b & 7) * per + (b >> 3);
+            if (cid < n) map[r++] = cid;
+        }
+    }
+    __syncthreads();
+    for (int k = 2; k <= CAP; k <<= 1) {                     // bitonic sort, descending
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < CAP; i += blockDim.x) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const unsigned long long a = key[i], b = key[l];
+                    if (up ? (a < b) : (a > b)) { key[i] = b; key[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int p = threadIdx.x; p < n; p += blockDim.x) chunks2[map[p]] = tmp[CAP - 1 - (int)(unsigned)(key[p] & 0xffffffffull)];
+}
+
 }  // namespace amx
