@@ -359,7 +359,7 @@ __global__ void __launch_bounds__(256) k_sandi_lane(const SandiArgs a)
 // On a passive set P the solution is x_P = (c_P - A_P' w) / lambda2 with w = B^-1 A_P c_P, B = lambda2 I + A_P A_P' (Woodbury:
 // a 6 x 6 Cholesky instead of a |P| x |P| one).  For j outside P the same expression is the dual value: A_P x_P = w exactly,
 // so g_j = c_j - a_j'w -- the KKT test and the choice of the entering atom cost nothing extra.
-// Tables of the dictionary (k_sandi_tables, once per (dictionary, lambda1, lambda2)), read from LDS with wave-uniform addresses:
+// Tables of the dictionary (k_sandi_tables, once per (dictionary, lambda1, lambda2)), read with wave-uniform addresses (scalar loads):
 //   T [N][kRowsTs]  packed lower triangles of a_j a_j'          (B is summed from them: no +- drift, half the arithmetic)
 //   G [N][M], g0 [N]  z0 = G y + g0 = the unconstrained optimum on the FULL set (G = A' (lambda2 I + A A')^-1)
 // Warm start: SANDI's optimum is dense (12 of 15 atoms), so the method starts from P0 = {z0 > 0} -- the full-set solve and
@@ -367,24 +367,24 @@ __global__ void __launch_bounds__(256) k_sandi_lane(const SandiArgs a)
 // the optimum is unique, so the path does not matter; the result satisfies the KKT conditions to 1e-12.
 constexpr int kRowsTs = 22;                // stride of T: 21 entries of the 6 x 6 triangle, padded for 16-byte reads
 
-template <int M, int N>
-__device__ __forceinline__ int lane_nnqp_rows(const double *__restrict__ A, int ldA, const double *__restrict__ T,
-                                              const double *__restrict__ G, const double *__restrict__ g0, const double (&y)[M],
+template <int M, int N, typename TP>
+__device__ __forceinline__ int lane_nnqp_rows(TP A, int ldA, TP T, TP G, TP g0, const double (&y)[M],
                                               double lam1, double lam2, double (&x)[N], int n_atoms, bool warm)
 {
     static_assert(M * (M + 1) / 2 <= kRowsTs, "triangle of a_j a_j' fits its table row");
     constexpr int kTri = M * (M + 1) / 2;
     const double tol = 1e-12, il2 = 1.0 / lam2;
-    double c[N];
+    // c = A'y - lambda1 is never stored (15 doubles = 30 registers the Cholesky would have to live with): the right-hand side
+    // A_P c_P = (B - lambda2 I) y - lambda1 sum_P a_j comes from the B that is summed anyway, the dual values from
+    // g_j = a_j'(y - w) - lambda1.
     unsigned P = 0u;
     AMX_RELOAD();
 #pragma unroll
     for (int j = 0; j < N; j++) {
         x[j] = 0.0;
-        double sc = -lam1, sz = g0[j];
+        double sz = g0[j];
 #pragma unroll
-        for (int i = 0; i < M; i++) { sc += A[i * ldA + j] * y[i]; sz += G[j * M + i] * y[i]; }
-        c[j] = sc;
+        for (int i = 0; i < M; i++) sz += G[j * M + i] * y[i];
         if (warm && j < n_atoms && sz > 0.0) P |= 1u << j;
     }
     constexpr int kBackup = 3;               // block exchanges allowed without progress (Kim & Park)
@@ -396,16 +396,24 @@ __device__ __forceinline__ int lane_nnqp_rows(const double *__restrict__ A, int 
 #pragma unroll
         for (int t = 0; t < kTri; t++) B[t] = 0.0;
 #pragma unroll
-        for (int i = 0; i < M; i++) { B[tri<M>(i, i)] = lam2; w[i] = 0.0; }
+        for (int i = 0; i < M; i++) w[i] = 0.0;
 #pragma unroll
         for (int j = 0; j < N; j++) {
-            const bool pj = (P >> j) & 1u;
-            const double mj = pj ? 1.0 : 0.0, cj = pj ? c[j] : 0.0;
+            const double mj = ((P >> j) & 1u) ? 1.0 : 0.0;
 #pragma unroll
             for (int t = 0; t < kTri; t++) B[t] += mj * T[j * kRowsTs + t];
 #pragma unroll
-            for (int i = 0; i < M; i++) w[i] += A[i * ldA + j] * cj;
+            for (int i = 0; i < M; i++) w[i] += mj * A[i * ldA + j];
         }
+#pragma unroll
+        for (int i = 0; i < M; i++) {                      // w = (A_P A_P') y - lambda1 sum_P a_j, then B = lambda2 I + A_P A_P'
+            double acc = -lam1 * w[i];
+#pragma unroll
+            for (int k = 0; k < M; k++) acc += B[i >= k ? tri<M>(i, k) : tri<M>(k, i)] * y[k];
+            w[i] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < M; i++) B[tri<M>(i, i)] += lam2;
 #pragma unroll
         for (int j = 0; j < M; j++) {
             double d = B[tri<M>(j, j)];
@@ -442,10 +450,12 @@ __device__ __forceinline__ int lane_nnqp_rows(const double *__restrict__ A, int 
         // lambda2 / AMX_COLD_START=1 go to k_sandi_lane's Lawson-Hanson loop, amx_launch_sandi_small.)
         unsigned v1 = 0u, v2 = 0u;
 #pragma unroll
-        for (int j = 0; j < N; j++) {
-            double g = c[j];
+        for (int i = 0; i < M; i++) w[i] = y[i] - w[i];
 #pragma unroll
-            for (int i = 0; i < M; i++) g -= A[i * ldA + j] * w[i];
+        for (int j = 0; j < N; j++) {
+            double g = -lam1;
+#pragma unroll
+            for (int i = 0; i < M; i++) g += A[i * ldA + j] * w[i];
             const bool pj = (P >> j) & 1u;
             x[j] = pj ? g * il2 : 0.0;
             if (pj && !(g > 0.0)) v1 |= 1u << j;
@@ -462,7 +472,7 @@ __device__ __forceinline__ int lane_nnqp_rows(const double *__restrict__ A, int 
 }
 
 // T, G, g0 of one dictionary and one (lambda1, lambda2): one workgroup, thread 0 inverts the 6 x 6 (Gauss-Jordan on the SPD
-// matrix, no pivoting needed).  out: T [N][kRowsTs] | G [N][M] | g0 [16]
+// matrix, no pivoting needed).  out: T [N][kRowsTs] | G [N][M] | g0 [16] | A [M][16] (zero-padded rows)
 template <int M, int N>
 __global__ void __launch_bounds__(64) k_sandi_tables(const double *__restrict__ Ag, int ldA, int n_atoms, double lam1, double lam2,
                                                      double *__restrict__ out)
@@ -471,6 +481,7 @@ __global__ void __launch_bounds__(64) k_sandi_tables(const double *__restrict__ 
     for (int e = threadIdx.x; e < M * 16; e += blockDim.x) A[e] = ((e % 16) < n_atoms) ? Ag[(e / 16) * ldA + (e % 16)] : 0.0;
     __syncthreads();
     double *T = out, *G = out + N * kRowsTs, *g0 = G + N * M;
+    for (int e = threadIdx.x; e < M * 16; e += blockDim.x) g0[16 + e] = A[e];                // the dictionary, rows padded to 16
     for (int e = threadIdx.x; e < N * kRowsTs; e += blockDim.x) {
         const int j = e / kRowsTs, t = e % kRowsTs;
         int i = 0;
@@ -519,14 +530,14 @@ __global__ void __launch_bounds__(64) k_sandi_tables(const double *__restrict__ 
         g0[j] = acc;
     }
 }
-constexpr int kSandiTableWords = 15 * kRowsTs + 15 * 6 + 16;
+constexpr int kSandiTableWords = 15 * kRowsTs + 15 * 6 + 16 + 8 * 16;
 
 #ifndef AMX_ROWS_OCC
-#define AMX_ROWS_OCC 2
+#define AMX_ROWS_OCC 3
 #endif
 
-// SANDI, nS == M (<= 8) values per voxel: row-space solver; the dictionary sits in LDS (wave-uniform reads), y comes
-// from the voxel's row.
+// SANDI, nS == M (<= 8) values per voxel: row-space solver; the dictionary and its tables come through the scalar cache
+// (wave-uniform addresses), y from the voxel's row.
 template <int M, int N>
 __global__ void __launch_bounds__(256, AMX_ROWS_OCC) k_sandi_rows(const SandiArgs a)
 {
@@ -534,17 +545,13 @@ __global__ void __launch_bounds__(256, AMX_ROWS_OCC) k_sandi_rows(const SandiArg
     if (cid < 0) return;
     const Chunk ck = a.c.chunks[cid];
     const int n_atoms = a.c.n_atoms, n_rs = a.n_rs, n_in = a.n_in;
-    // the dictionary (M x N doubles, the same for every voxel) in LDS, read with wave-uniform addresses
-    __shared__ __attribute__((aligned(16))) double A[M * 16];
-    __shared__ __attribute__((aligned(16))) double Tb[N * kRowsTs + N * M + 16];
+    // the dictionary and its tables (4.6 KB, the same for every voxel) are read through the SCALAR cache: every address is
+    // wave-uniform, so the loads are s_load_dwordx8/x16 into SGPRs and the fused multiply-adds take them as their scalar
+    // operand -- no LDS instruction in the solver (from LDS the ~210 16-byte broadcast reads per trip cost as much of the
+    // CU's time as the ~650 fp64 instructions they feed).
+    using CD = const __attribute__((address_space(4))) double;
     constexpr int ldA = 16;
-    {
-        const double *__restrict__ Ag = reinterpret_cast<const double *>(a.c.tiles);
-        for (int e = threadIdx.x; e < M * 16; e += blockDim.x) A[e] = ((e % 16) < n_atoms) ? Ag[(e / 16) * a.c.ldA + (e % 16)] : 0.0;
-        for (int e = threadIdx.x; e < N * kRowsTs + N * M + 16; e += blockDim.x) Tb[e] = a.tables[e];
-        __syncthreads();
-    }
-    const double *T = Tb, *G = Tb + N * kRowsTs, *g0 = G + N * M;
+    CD *T = (CD *)a.tables, *G = T + N * kRowsTs, *g0 = G + N * M, *A = g0 + 16;
     const bool warm = amx_warm_start(a.c.lam2, a.c.flags);
     for (int v = threadIdx.x; v < ck.count; v += blockDim.x) {
         const int vox = a.c.perm[ck.start + v];
