@@ -224,22 +224,32 @@ __global__ void __launch_bounds__(1024) k_order_schunks(Chunk *__restrict__ chun
     __shared__ int map[CAP];
     const int n = n_chunks[1];
     if (n < 2 || n > CAP) return;
-    for (int i = threadIdx.x; i < CAP; i += blockDim.x) {
+    int cap = 2;
+    while (cap < n) cap <<= 1;                               // sort size: the next power of two
+    for (int i = threadIdx.x; i < cap; i += blockDim.x) {
         key[i] = i < n ? (((unsigned long long)(unsigned)chunks2[i].count << 32) | (unsigned)(CAP - 1 - i)) : 0ull;   // ties: list order
         if (i < n) tmp[i] = chunks2[i];
     }
-    if (threadIdx.x == 0) {
-        const int per = (n + 7) >> 3;
-        int r = 0;
-        for (int b = 0; b < 8 * per; b++) {
-            const int cid = (b & 7) * per + (b >> 3);
-            if (cid < n) map[r++] = cid;
+    {   // map[rank in dispatch order] = chunk index: block b = (row r = b >> 3, XCD x = b & 7) reads index x * per + r; the only
+        // blocks without a chunk sit in the last column(s), rows r >= n - x * per
+        const int per = (n + 7) >> 3, r0 = n - 7 * per;
+        if (r0 >= 0) {
+            for (int b = threadIdx.x; b < 8 * per; b += blockDim.x) {
+                const int r = b >> 3, x = b & 7, cid = x * per + r;
+                if (cid < n) map[b - (r > r0 ? r - r0 : 0)] = cid;
+            }
+        } else if (threadIdx.x == 0) {
+            int r = 0;
+            for (int b = 0; b < 8 * per; b++) {
+                const int cid = (b & 7) * per + (b >> 3);
+                if (cid < n) map[r++] = cid;
+            }
         }
     }
     __syncthreads();
-    for (int k = 2; k <= CAP; k <<= 1) {                     // bitonic sort, descending
+    for (int k = 2; k <= cap; k <<= 1) {                     // bitonic sort, descending
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < CAP; i += blockDim.x) {
+            for (int i = threadIdx.x; i < cap; i += blockDim.x) {
                 const int l = i ^ j;
                 if (l > i) {
                     const bool up = (i & k) == 0;

@@ -374,9 +374,8 @@ __device__ __forceinline__ int lane_nnqp_rows(TP A, int ldA, TP T, TP G, TP g0, 
     static_assert(M * (M + 1) / 2 <= kRowsTs, "triangle of a_j a_j' fits its table row");
     constexpr int kTri = M * (M + 1) / 2;
     const double tol = 1e-12, il2 = 1.0 / lam2;
-    // c = A'y - lambda1 is never stored (15 doubles = 30 registers the Cholesky would have to live with): the right-hand side
-    // A_P c_P = (B - lambda2 I) y - lambda1 sum_P a_j comes from the B that is summed anyway, the dual values from
-    // g_j = a_j'(y - w) - lambda1.
+    // c = A'y - lambda1 is never stored (15 doubles = 30 registers the Cholesky would have to live with): c_j is recomputed for
+    // the atoms that change sides (below), the dual values are g_j = a_j'(y - w) - lambda1.
     unsigned P = 0u;
     AMX_RELOAD();
 #pragma unroll
@@ -389,31 +388,39 @@ __device__ __forceinline__ int lane_nnqp_rows(TP A, int ldA, TP T, TP G, TP g0, 
     }
     constexpr int kBackup = 3;               // block exchanges allowed without progress (Kim & Park)
     int ninf = N + 1, backup = 0;
+    // A_P A_P' and the right-hand side A_P c_P are CARRIED from trip to trip: only the atoms that changed sides are added or
+    // subtracted (rank-one terms from the table, a_j c_j with c_j = a_j'y - lambda1 recomputed on the spot).  The branch per atom
+    // is wave-uniform (ballot over the lanes still iterating): in the late trips of a lock-step wavefront few lanes are left and
+    // they exchange one or two atoms each.  (+- accumulation: a handful of updates per voxel, errors of 1e-16 relative.)
+    double Bp[kTri], rp[M];
+#pragma unroll
+    for (int t = 0; t < kTri; t++) Bp[t] = 0.0;
+#pragma unroll
+    for (int i = 0; i < M; i++) rp[i] = 0.0;
+    unsigned flips = P;
     for (int it = 0;; ++it) {
         if (it > 4 * N + 16) return 2;
         double B[kTri], L[kTri], li[M], w[M];
         AMX_RELOAD();
 #pragma unroll
-        for (int t = 0; t < kTri; t++) B[t] = 0.0;
-#pragma unroll
-        for (int i = 0; i < M; i++) w[i] = 0.0;
-#pragma unroll
         for (int j = 0; j < N; j++) {
-            const double mj = ((P >> j) & 1u) ? 1.0 : 0.0;
+            const bool fj = (flips >> j) & 1u;
+            if (__ballot(fj) != 0ull) {
+                const double dj = fj ? (((P >> j) & 1u) ? 1.0 : -1.0) : 0.0;
+                double cj = -lam1;
 #pragma unroll
-            for (int t = 0; t < kTri; t++) B[t] += mj * T[j * kRowsTs + t];
+                for (int i = 0; i < M; i++) cj += A[i * ldA + j] * y[i];
+                cj *= dj;
 #pragma unroll
-            for (int i = 0; i < M; i++) w[i] += mj * A[i * ldA + j];
+                for (int t = 0; t < kTri; t++) Bp[t] += dj * T[j * kRowsTs + t];
+#pragma unroll
+                for (int i = 0; i < M; i++) rp[i] += cj * A[i * ldA + j];
+            }
         }
 #pragma unroll
-        for (int i = 0; i < M; i++) {                      // w = (A_P A_P') y - lambda1 sum_P a_j, then B = lambda2 I + A_P A_P'
-            double acc = -lam1 * w[i];
+        for (int t = 0; t < kTri; t++) B[t] = Bp[t];
 #pragma unroll
-            for (int k = 0; k < M; k++) acc += B[i >= k ? tri<M>(i, k) : tri<M>(k, i)] * y[k];
-            w[i] = acc;
-        }
-#pragma unroll
-        for (int i = 0; i < M; i++) B[tri<M>(i, i)] += lam2;
+        for (int i = 0; i < M; i++) { w[i] = rp[i]; B[tri<M>(i, i)] += lam2; }
 #pragma unroll
         for (int j = 0; j < M; j++) {
             double d = B[tri<M>(j, j)];
@@ -467,7 +474,8 @@ __device__ __forceinline__ int lane_nnqp_rows(TP A, int ldA, TP T, TP G, TP g0, 
         bool block = false;
         if (nbad < ninf) { ninf = nbad; backup = warm ? kBackup : 0; block = warm; }
         else if (backup > 0) { backup--; block = true; }
-        P ^= block ? bad : (1u << (31 - __builtin_clz(bad)));
+        flips = block ? bad : (1u << (31 - __builtin_clz(bad)));
+        P ^= flips;
     }
 }
 
