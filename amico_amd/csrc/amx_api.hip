@@ -733,9 +733,6 @@ static int sandi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
     Plan pl; int rc;
     if ((rc = make_plan(ctx, n_vox, 1, pl))) return rc;
     rec(ctx, 0, s);
-    HIPCHK(ctx, hipMemsetAsync(ctx->misc.p, 0, 64 * sizeof(int), s));
-    const int nb = (int)((n_vox + 255) / 256);
-    hipLaunchKernelGGL(k_plan_linear, dim3(nb), dim3(256), 0, s, (int)n_vox, kChunk, pl.chunks, pl.n_chunks, pl.perm);
     SandiArgs a;
     memset(&a, 0, sizeof a);
     a.c.tiles = lut->tiles; a.c.y = d_y; a.c.y32 = d_y32; a.c.perm = pl.perm; a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks;
@@ -750,8 +747,17 @@ static int sandi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
     }
     a.est = d_estimates; a.rmse = (flags & AMX_F_RMSE) ? d_rmse : nullptr; a.nrmse = (flags & AMX_F_NRMSE) ? d_nrmse : nullptr;
     if ((rc = amx_sandi_prepare(ctx, lut, a, s))) return rc;
+    // the row-space kernel (default protocol) takes the voxels in order and counts straight into the status words: one launch
+    // per fit; the other SANDI kernels walk the (trivial) plan and use the per-call counters
+    const bool rows = a.tables && amx_use_lane_solver(ctx, a.c.n_atoms, a.c.lam2) && !ctx->opt_sandi_atom_space;
+    if (rows) a.n_lin = (int)n_vox;
+    else {
+        HIPCHK(ctx, hipMemsetAsync(ctx->misc.p, 0, 64 * sizeof(int), s));
+        const int nb = (int)((n_vox + 255) / 256);
+        hipLaunchKernelGGL(k_plan_linear, dim3(nb), dim3(256), 0, s, (int)n_vox, kChunk, pl.chunks, pl.n_chunks, pl.perm);
+    }
     rc = amx_launch_sandi(ctx, a, pl, s);
-    hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, s, (const int *)ctx->misc.p, ctx->status_d);
+    if (!rows) hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, s, (const int *)ctx->misc.p, ctx->status_d);
     rec(ctx, 1, s);
     if (!rc) progress_tick(ctx, s, n_vox, n_vox);
     return rc;

@@ -439,7 +439,8 @@ struct SandiArgs {
     const double *norms, *Rs, *d_in, *d_isos;
     int n_rs, n_in, n_iso;
     double *est, *rmse, *nrmse;
-    const double *tables;          // k_sandi_tables (row-space kernel): T | G | g0
+    const double *tables;          // k_sandi_tables (row-space kernel): T | G | g0 | A
+    int n_lin;                     // > 0: no plan, workgroup b takes voxels [256 b, 256 b + 256) of n_lin (row-space kernel: one dictionary, no bucketing)
 };
 
 template <int NR, int NQ, int MAXP>

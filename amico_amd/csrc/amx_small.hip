@@ -549,9 +549,16 @@ constexpr int kSandiTableWords = 15 * kRowsTs + 15 * 6 + 16 + 8 * 16;
 template <int M, int N>
 __global__ void __launch_bounds__(256, AMX_ROWS_OCC) k_sandi_rows(const SandiArgs a)
 {
-    const int cid = xcd_chunk((int)blockIdx.x, *a.c.n_chunks);
-    if (cid < 0) return;
-    const Chunk ck = a.c.chunks[cid];
+    Chunk ck;
+    const bool linear = a.n_lin > 0;           // SANDI has one dictionary: nothing to bucket, the voxels are taken in order
+    if (linear) {
+        ck.start = (int)blockIdx.x * 256; ck.count = a.n_lin - ck.start < 256 ? a.n_lin - ck.start : 256;
+        if (ck.count <= 0) return;
+    } else {
+        const int cid = xcd_chunk((int)blockIdx.x, *a.c.n_chunks);
+        if (cid < 0) return;
+        ck = a.c.chunks[cid];
+    }
     const int n_atoms = a.c.n_atoms, n_rs = a.n_rs, n_in = a.n_in;
     // the dictionary and its tables (4.6 KB, the same for every voxel) are read through the SCALAR cache: every address is
     // wave-uniform, so the loads are s_load_dwordx8/x16 into SGPRs and the fused multiply-adds take them as their scalar
@@ -562,7 +569,7 @@ __global__ void __launch_bounds__(256, AMX_ROWS_OCC) k_sandi_rows(const SandiArg
     CD *T = (CD *)a.tables, *G = T + N * kRowsTs, *g0 = G + N * M, *A = g0 + 16;
     const bool warm = amx_warm_start(a.c.lam2, a.c.flags);
     for (int v = threadIdx.x; v < ck.count; v += blockDim.x) {
-        const int vox = a.c.perm[ck.start + v];
+        const int vox = linear ? ck.start + v : a.c.perm[ck.start + v];
         const double *yv = a.c.y + (size_t)vox * M;
         double y[M], x[N], ysq = 0.0;
         bool ok = true;
@@ -1288,7 +1295,7 @@ int amx_launch_sandi_small(amx_ctx *ctx, SandiArgs &a, const Plan &pl, hipStream
     if (a.c.nS == 6 && n == 15 && amx_warm_start(a.c.lam2, a.c.flags) && !ctx->opt_sandi_atom_space) {
         if (!a.tables) { ctx->err = "amx_launch_sandi_small: dictionary tables missing (amx_sandi_prepare)"; return AMX_E_BADARG; }
         rec(ctx, 2, s);
-        hipLaunchKernelGGL((k_sandi_rows<6, 15>), dim3(((pl.max_chunks + 7) / 8) * 8), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((k_sandi_rows<6, 15>), dim3(a.n_lin > 0 ? (a.n_lin + 255) / 256 : ((pl.max_chunks + 7) / 8) * 8), dim3(256), 0, s, a);
         AMX_TRACE(ctx, s, "row-space SANDI solver");
         rec(ctx, 3, s);
         HIPCHK(ctx, hipGetLastError());
