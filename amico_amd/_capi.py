@@ -21,7 +21,7 @@ SYMBOLS = ['amx_version', 'amx_ctx_create', 'amx_ctx_destroy', 'amx_last_error',
            'amx_noddi_fit_device', 'amx_freewater_fit_device', 'amx_sandi_fit_device', 'amx_sync_status',
            'amx_noddi_fit_device_f32', 'amx_freewater_fit_device_f32', 'amx_sandi_fit_device_f32', 'amx_czb_fit_device_f32',
            'amx_set_debug_x', 'amx_debug_fetch', 'amx_lut_upload_czb', 'amx_czb_fit', 'amx_czb_fit_f32', 'amx_czb_fit_device', 'amx_noddi_fit_f32', 'amx_freewater_fit_f32', 'amx_sandi_fit_f32', 'amx_set_progress',
-           'amx_set_profiling', 'amx_last_kernel_ms', 'amx_last_stats', 'amx_selftest',
+           'amx_set_profiling', 'amx_last_kernel_ms', 'amx_last_stats', 'amx_last_seed_stats', 'amx_selftest',
            'amx_dti_create', 'amx_dti_destroy', 'amx_dti_directions', 'amx_dti_directions_device', 'amx_dti_directions_device_f32', 'amx_prep_gather_device_f32',
            'amx_prep_create', 'amx_prep_destroy', 'amx_prep_gather', 'amx_prep_gather_device',
            'amx_prep_mean_b0', 'amx_prep_mean_b0_device', 'amx_prep_scatter', 'amx_prep_scatter_device',
@@ -101,6 +101,7 @@ def lib():
     L.amx_set_profiling.argtypes = [c_vp, C.c_int]
     L.amx_last_kernel_ms.argtypes = [c_vp, C.c_int, C.POINTER(C.c_float)]
     L.amx_last_stats.argtypes = [c_vp, c_i64p]
+    L.amx_last_seed_stats.argtypes = [c_vp, c_i64p]
     L.amx_selftest.argtypes = [c_vp, c_dp]
     L.amx_dti_create.argtypes = [c_vp, c_dp, C.c_int, C.c_double, C.POINTER(c_vp)]
     L.amx_dti_destroy.argtypes = [c_vp]
@@ -186,6 +187,17 @@ class Context:
         self.check(lib().amx_last_stats(self._h, out))
         return {'rerun_voxels': out[0], 'itercap_voxels': out[1], 'overflow_voxels': out[2],
                 'guard_trips': out[3] >> 32, 'guard_last': out[3] & 0xffffffff}
+
+    def last_seed_stats(self):
+        """how the NODDI voxels since the previous sync were settled (amx_last_seed_stats): certification rates of the three stages"""
+        out = (C.c_int64 * 8)()
+        self.check(lib().amx_last_seed_stats(self._h, out))
+        n = int(out[0])
+        d = {'seeded_voxels': n, 'leftover_stage1': int(out[1]), 'leftover_lasso': int(out[2]), 'leftover_stage3': int(out[3]),
+             'clipped_stage2': int(out[4])}
+        if n > 0:
+            d['certified'] = [1.0 - out[k] / n for k in (1, 2, 3)]
+        return d
 
     def selftest(self):
         out = np.zeros((12, 64))

@@ -124,11 +124,19 @@ __global__ void k_selftest(double *out)
 
 int bad(amx_ctx *ctx, const char *msg) { return amx_bad(ctx, msg); }
 
+// a profiled call starts with no event pair valid: amx_last_kernel_ms of a group this call does not run is an error, not the
+// timing of an earlier call (the dti / prep / lut entry points record slot 4 only and clear it themselves)
+void clear_events(amx_ctx *ctx)
+{
+    if (ctx->profiling) for (int k = 0; k < kEv; k++) ctx->ev_valid[k] = false;
+}
+
 // float32 signals (the image dtype of the reference, core.py:136) -> the float64 rows the solvers read: exact
 __global__ void k_widen(const float *__restrict__ src, double *__restrict__ dst, size_t n)
 {
     const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i0 + 3 < n) {
+    // (16-byte loads only from a 16-byte aligned source: a row slice of a float32 tensor may start at any multiple of 4 bytes)
+    if (i0 + 3 < n && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
         const float4 v = *reinterpret_cast<const float4 *>(src + i0);
         dst[i0] = (double)v.x; dst[i0 + 1] = (double)v.y; dst[i0 + 2] = (double)v.z; dst[i0 + 3] = (double)v.w;
     } else {
@@ -215,7 +223,8 @@ int amx_ctx_create(int device, amx_ctx **out)
         e = getenv("AMX_SEED_STAGES");
         if (e && *e) ctx->opt_seed_stages = atoi(e) & 7;
         e = getenv("AMX_SEED_CHUNK");
-        if (e && atoi(e) >= 64) ctx->opt_seed_chunk = (atoi(e) + 63) & ~63;
+        // (never below kChunk: the left-over passes size their grid by the FIRST plan's chunk count, n / kChunk + ndirs + 1)
+        if (e && atoi(e) >= kChunk) ctx->opt_seed_chunk = (atoi(e) + 63) & ~63;
     }
     reset_status(ctx, nullptr);
     hipStreamSynchronize(nullptr);
@@ -454,6 +463,9 @@ int amx_sync_status(amx_ctx *ctx, void *hip_stream)
     ctx->stats[1] = st[ST_ITCAP];
     ctx->stats[2] = st[ST_OVERFLOW];
     ctx->stats[3] = ((int64_t)st[ST_GUARD] << 32) | (unsigned)st[ST_GUARDVOX];
+    ctx->seed_stats[0] = ctx->seeded_vox; ctx->seeded_vox = 0;
+    for (int k = 0; k < 3; k++) { ctx->seed_stats[1 + k] = st[ST_LEFT + k] + ctx->uncert_vox[k]; ctx->uncert_vox[k] = 0; }
+    ctx->seed_stats[4] = st[ST_CLIP];
     if (amx_debug()) fprintf(stderr, "[amx] dual-vector evaluations per stage: exact %d %d %d  gram %d %d %d  inner iterations %d %d %d\n", st[ST_EXACT], st[ST_EXACT + 1], st[ST_EXACT + 2], st[ST_GRAM], st[ST_GRAM + 1], st[ST_GRAM + 2], st[ST_ITERS], st[ST_ITERS + 1], st[ST_ITERS + 2]);
     if (amx_debug()) fprintf(stderr, "[amx] seeds: stage 1 tried %d certified %d, stage 3 tried %d certified %d; seed solver trips %d lane-trips used %d; stage-1 refusals: malformed %d pivot %d refinement %d x<=0 %d dual %d\n", st[ST_SEED], st[ST_SEED + 1], st[ST_SEED + 2], st[ST_SEED + 3], st[ST_SEED + 4], st[ST_SEED + 5], st[ST_SEED + 7], st[ST_SEED + 8], st[ST_SEED + 9], st[ST_SEED + 10], st[ST_SEED + 11]);
     if (amx_debug()) fprintf(stderr, "[amx] screened certificates: %d exact dot products (NNLS stages), %d (LASSO stage)\n", st[ST_SEED + 22], st[ST_SEED + 23]);
@@ -563,6 +575,13 @@ int amx_last_stats(amx_ctx *ctx, int64_t out[4])
     return AMX_OK;
 }
 
+int amx_last_seed_stats(amx_ctx *ctx, int64_t out[8])
+{
+    if (!ctx || !out) return AMX_E_BADARG;
+    for (int k = 0; k < 8; k++) out[k] = ctx->seed_stats[k];
+    return AMX_OK;
+}
+
 // ------------------------------------------------------------------ NODDI
 static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, const float *d_y32, const double *d_dirs,
                          int64_t n_vox, double lambda1, double lambda2, unsigned flags,
@@ -585,6 +604,7 @@ static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
     if ((rc = make_plan(ctx, n_vox, lut->ndirs, pl, seeds))) return rc;
     if ((rc = ensure(ctx, ctx->xiso, (size_t)n_vox * 2 * sizeof(double)))) return rc;
     if ((rc = ensure(ctx, ctx->supp, (size_t)n_vox * 4 * sizeof(unsigned long long)))) return rc;
+    clear_events(ctx);
     rec(ctx, 0, s);
     if ((rc = enqueue_bucketing(ctx, lut, d_dirs, n_vox, pl, s))) return rc;
     NoddiArgs a;
@@ -605,6 +625,7 @@ static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
     // voxels with an out-of-bounds direction are skipped: give them defined (zero) maps
     HIPCHK(ctx, hipMemsetAsync(d_estimates, 0, (size_t)n_vox * a.n_maps * sizeof(double), s));
     if (seeds) {
+        ctx->seeded_vox += n_vox;
         // y~ = U'y once; the seed solver proposes the stage's support, the stage kernel certifies it (amx_seed.hpp)
         rec(ctx, 10, s);
         const bool gcert = !ctx->opt_no_gcert && lut->nS <= 100 && lut->n_atoms <= 146;
@@ -616,6 +637,7 @@ static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
             rec(ctx, 16, s);
             if ((rc = amx_launch_noddi_seed(ctx, lut, a, pl, s, 1))) return rc;
             rec(ctx, 17, s);
+            if (!gcert) ctx->uncert_vox[0] += n_vox;
             if (gcert) {
                 if ((rc = amx_launch_noddi_gcert(ctx, lut, a, pl, s, 1))) return rc;
                 a.done = (const unsigned char *)ctx->done.p;
@@ -639,6 +661,7 @@ static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
         a.seeds2 = (const unsigned long long *)ctx->seeds2.p;
         a.list_is_pos = 1;
         if (!ctx->opt_no_screen && lut->screen2_S) { a.scr2_S = lut->screen2_S; a.scr2_kappa = lut->screen2_kappa; a.scr2_ytil = (const double *)ctx->ytil2.p; a.scr2_Sg = lut->basis2_S; }
+        if (!gcert2) ctx->uncert_vox[1] += n_vox;
         if (gcert2) {
             const bool wide = !ctx->opt_no_gcert_wide;
             if ((rc = amx_launch_noddi_gcert2(ctx, lut, a, pl, s, wide))) return rc;
@@ -655,6 +678,7 @@ static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
             a.seeds = (const unsigned long long *)ctx->seeds.p;
             rec(ctx, 14, s);
             rc = amx_launch_noddi_seed(ctx, lut, a, pl, s, 3);
+            if (ctx->opt_no_gcert || lut->nS > 100 || lut->n_atoms > 146) ctx->uncert_vox[2] += n_vox;
             if (!rc && !ctx->opt_no_gcert && lut->nS <= 100 && lut->n_atoms <= 146) {
                 rc = amx_launch_noddi_gcert(ctx, lut, a, pl, s, 3);
                 a.done = (const unsigned char *)ctx->done.p;
@@ -690,6 +714,7 @@ static int freewater_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y
     HIPCHK(ctx, hipSetDevice(ctx->device));
     Plan pl; int rc;
     if ((rc = make_plan(ctx, n_vox, lut->ndirs, pl))) return rc;
+    clear_events(ctx);
     rec(ctx, 0, s);
     const bool refill = amx_use_lane_solver(ctx, lut->n_atoms, lambda2) && amx_fw_use_refill(ctx, lut->n_atoms, lut->nS, flags, lambda2);
     if ((rc = enqueue_bucketing(ctx, lut, d_dirs, n_vox, pl, s, refill ? amx_refill_chunk(ctx, n_vox) : kChunk))) return rc;
@@ -732,6 +757,7 @@ static int sandi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
     HIPCHK(ctx, hipSetDevice(ctx->device));
     Plan pl; int rc;
     if ((rc = make_plan(ctx, n_vox, 1, pl))) return rc;
+    clear_events(ctx);
     rec(ctx, 0, s);
     SandiArgs a;
     memset(&a, 0, sizeof a);
@@ -781,6 +807,7 @@ static int czb_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, cons
     HIPCHK(ctx, hipSetDevice(ctx->device));
     Plan pl; int rc;
     if ((rc = make_plan(ctx, n_vox, lut->ndirs, pl))) return rc;
+    clear_events(ctx);
     rec(ctx, 0, s);
     if ((rc = enqueue_bucketing(ctx, lut, d_dirs, n_vox, pl, s))) return rc;
     CzbArgs a;

@@ -35,6 +35,9 @@ struct amx_ctx {
     hipEvent_t ev[kEv];
     bool ev_valid[kEv];
     int64_t stats[4] = {0, 0, 0, 0};
+    int64_t seed_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // amx_last_seed_stats
+    int64_t uncert_vox[3] = {0, 0, 0};   // ... of which a stage ran without its Gram-space certificate (shape gate, AMX_NO_GCERT)
+    int64_t seeded_vox = 0;        // voxels enqueued on the seed -> certificate chain since the last amx_sync_status
     int64_t vox_base = 0;          // index of the first voxel of the batch being enqueued (chunked host entry points)
     double *dbg_x = nullptr;       // AMX_F_DEBUG_X destination (caller-owned device buffer, amx_set_debug_x)
     void (*progress)(int64_t, int64_t, void *) = nullptr;   // amx_set_progress

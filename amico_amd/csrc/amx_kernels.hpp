@@ -19,7 +19,7 @@ struct Chunk { int dir, start, count, pad; };
 constexpr int kSeedKD = 12;      // compressed dimensions of the support-seed problem (amx_seed.hpp)
 constexpr int kScreenLd = 192;   // atoms per row of the float32 screening table [KD][kScreenLd]
 
-enum StatusSlot { ST_ERRVOX = 0, ST_II1 = 1, ST_II2 = 2, ST_OVERFLOW = 3, ST_ITCAP = 4, ST_RERUN = 5, ST_GUARD = 6, ST_GUARDVOX = 7, ST_EXACT = 8, ST_GRAM = 11, ST_ITERS = 14, ST_SEED = 17, ST_WORDS = 96 };
+enum StatusSlot { ST_ERRVOX = 0, ST_II1 = 1, ST_II2 = 2, ST_OVERFLOW = 3, ST_ITCAP = 4, ST_RERUN = 5, ST_GUARD = 6, ST_GUARDVOX = 7, ST_EXACT = 8, ST_GRAM = 11, ST_ITERS = 14, ST_SEED = 17, ST_LEFT = 92, ST_CLIP = 95, ST_WORDS = 96 };   // ST_LEFT + 0..2: voxels the Gram-space certificates of stage 1 / LASSO / stage 3 left to the wavefront-per-voxel kernels; ST_CLIP: voxels whose stage-2 signal was clipped
 
 // ------------------------------------------------------------------ shared pieces
 struct FitCommon {
@@ -672,7 +672,11 @@ __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
         if (cid < 0) return;
         const Chunk ck = a.c.chunks[cid];
         unsigned *ticket = reinterpret_cast<unsigned *>(wm_all + nw_ * 4);     // the 16 spare bytes of fit_lds_bytes
-        if ((STAGE == 1 || STAGE == 3 || STAGE == 4) && a.rlist != nullptr && a.rcount[cid] == 0) return;      // nothing left over in this chunk
+        if ((STAGE == 1 || STAGE == 3 || STAGE == 4) && a.rlist != nullptr) {
+            const int left = a.rcount[cid];
+            if (left == 0) return;                                  // nothing left over in this chunk
+            if (threadIdx.x == 0) atomicAdd(&a.c.status[ST_LEFT + (STAGE == 1 ? 0 : (STAGE == 3 ? 2 : 1))], left);   // (amx_last_seed_stats)
+        }
         if (threadIdx.x == 0) *ticket = (unsigned)nw_;
         stage_noddi_tile<AT>(As, tiles + (size_t)ck.dir * a.c.tile_stride, words, words_pad - words);
         // NNLS stages with seeds: the float32 compressed dictionary of the orientation for the dual-value screening

@@ -159,12 +159,13 @@ class BaseModel(ABC):
                        for k, v in sorted(K.items()) if isinstance(v, np.ndarray))
         sc = self.scheme
         skey = None if sc is None else (int(getattr(sc, 'nS', 0)), tuple(np.asarray(getattr(sc, 'dwi_idx', ())).tolist()))
-        key = (id(K), id(ht), finger, skey, self._lut_extra_key())
+        ctx = get_context()                 # (a dictionary lives in ONE context: reset_context() must not leave a stale upload behind)
+        key = (id(K), id(ht), finger, skey, self._lut_extra_key(), id(ctx))
         cache = getattr(self, '_lut_cache', None)
         if cache is None or cache[0] != key:
             if K.get('model') != self.id:
                 raise ValueError('Response functions were not created with the same model')
-            self._lut_cache = (key, builder(), K, ht)          # K, ht: strong references to the keyed objects
+            self._lut_cache = (key, builder(), K, ht, ctx)     # K, ht, ctx: strong references to the keyed objects
         return self._lut_cache[1]
 
 

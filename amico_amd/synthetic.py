@@ -344,6 +344,60 @@ def noddi_signals(n_vox, kernels, htable, scheme, seed=1, snr=30.0, chunk=65536)
     return y, dirs
 
 
+def noddi_signals_parallel(n_vox, kernels, htable, scheme, seed=1, snr=30.0, block=250_000, threads=None):
+    """noddi_signals for multi-million-voxel batches: blocks of `block` voxels with their own seeds, generated by a thread
+    pool (numpy releases the GIL in the heavy statements), written in place -- 8 M voxels in a few seconds"""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    y = np.empty((n_vox, scheme.nS))
+    dirs = np.empty((n_vox, 3))
+    starts = list(range(0, n_vox, block))
+
+    def one(i):
+        s = starts[i]
+        e = min(n_vox, s + block)
+        y[s:e], dirs[s:e] = noddi_signals(e - s, kernels, htable, scheme, seed=seed * 1000 + i, snr=snr)
+    with ThreadPoolExecutor(threads or min(32, os.cpu_count() or 1)) as ex:
+        list(ex.map(one, range(len(starts))))
+    return y, dirs
+
+
+HARD_KINDS = ('crossing', 'single+iso', 'wrong direction', 'pure noise', 'flat', 'half zeroed', 'CSF dominated', 'background')
+
+
+def noddi_hard_signals(n_vox, kernels, htable, scheme, seed=9):
+    """Signals the dictionary does NOT explain -- what the wiki data sets the reference is verified on contain besides clean white
+    matter (README.md:18-19): two crossing compartments, the fit given the minor fibre's direction, pure noise, flat signals,
+    half of the volumes zeroed, CSF-dominated voxels (f_iso in [0.5, 1]), near-zero background; SNR 5 / 15 / 40 mixed; the first
+    ten voxels all zero.  Returns (y, DIRs, kind) with kind indexing HARD_KINDS.  (models.pyx:902-981 takes the same path whatever
+    the signal; the fast path of the MI355X build must too.)"""
+    rng = np.random.default_rng(seed)
+    wm, iso = kernels['wm'], kernels['iso'].astype(np.float64)
+    n = n_vox
+    d1 = random_unit_vectors(n, rng); d2 = random_unit_vectors(n, rng)
+    l1 = lut_indices(d1, htable); l2 = lut_indices(d2, htable)
+    k1 = rng.integers(0, wm.shape[0], n); k2 = rng.integers(0, wm.shape[0], n)
+    kind = rng.integers(0, len(HARD_KINDS), n)
+    f = rng.dirichlet([1, 1, 1], n)
+    one = kind == 1
+    f[one, 1] = 0.0; f[one, 2] = rng.uniform(0.0, 0.5, int(one.sum())); f[one, 0] = 1.0 - f[one, 2]
+    csf = kind == 6
+    fi = rng.uniform(0.5, 1.0, int(csf.sum()))
+    f[csf, 2] = fi; f[csf, 0] = 1.0 - fi; f[csf, 1] = 0.0
+    y0 = f[:, :1] * wm[k1, l1].astype(np.float64) + f[:, 1:2] * wm[k2, l2].astype(np.float64) + f[:, 2:3] * iso[None, :]
+    sig = 1.0 / rng.choice([5.0, 15.0, 40.0], n)
+    y = np.sqrt((y0 + sig[:, None] * rng.normal(size=y0.shape)) ** 2 + (sig[:, None] * rng.normal(size=y0.shape)) ** 2)
+    y[kind == 3] = np.abs(rng.normal(size=(int((kind == 3).sum()), y.shape[1])))
+    y[kind == 4] = rng.uniform(0.0, 2.0, (int((kind == 4).sum()), 1))
+    y[kind == 5] *= (rng.uniform(size=(int((kind == 5).sum()), y.shape[1])) < 0.5)
+    bg = kind == 7
+    y[bg] = np.abs(rng.normal(scale=0.02, size=(int(bg.sum()), y.shape[1])))
+    y[:10] = 0.0
+    y = np.ascontiguousarray(y.astype(np.float32).astype(np.float64))
+    dirs = np.ascontiguousarray(np.where((kind == 2)[:, None], d2, d1))
+    return y, dirs, kind
+
+
 def freewater_signals(n_vox, kernels, htable, scheme, seed=1, snr=30.0, chunk=65536):
     rng = np.random.default_rng(seed)
     D, CSF = kernels['D'], kernels['CSF'].astype(np.float64)

@@ -497,6 +497,64 @@ def pmc_traffic(stage, n):
         return None
 
 
+def pmc_whole_fit(n):
+    """HBM bytes of ONE whole NODDI fit (all kernel groups of the committed PMC passes), scaled to n voxels"""
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')
+    try:
+        with open(p) as f:
+            t = json.load(f)
+        b = t['stage_bytes_per_launch']
+        return sum(float(b[k]) for k in ('1', '2', '3', '5', '6', '7')) * n / t['voxels_per_launch']
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def noddi_hard_mix(ctx, lut, K, htable, scheme, n, steps, warmup):
+    """the NODDI fit on signals the dictionary does not explain (synthetic.noddi_hard_signals: crossings, wrong direction,
+    CSF-dominated, pure noise, flat, half-zeroed, background; SNR 5 / 15 / 40): rate, certification rates of the three stages, parity
+    on a sample -- the headline's rates are a property of its signal distribution (one atom + iso <= 0.5, SNR 30), this leg says
+    what the same chain does when the seed solvers are wrong more often"""
+    import torch
+    from amico_amd import _capi, synthetic as S
+    from oracle import oracle
+    dev = torch.device('cuda', torch.cuda.current_device())
+    blk = 250_000
+    parts = [S.noddi_hard_signals(min(blk, n - s), K, htable, scheme, seed=900 + s // blk) for s in range(0, n, blk)]
+    y_h = np.concatenate([p[0] for p in parts]); d_h = np.concatenate([p[1] for p in parts])
+    y = torch.from_numpy(y_h).to(dev); d = torch.from_numpy(d_h).to(dev)
+    est = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+    L = _capi.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def fit():
+        ctx.check(L.amx_noddi_fit_device(ctx._h, lut._h, y.data_ptr(), d.data_ptr(), n, 0.5, 1e-3, 0, est.data_ptr(), None, None, None, stream))
+    for _ in range(warmup):
+        fit(); ctx.sync(stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fit(); ctx.sync(stream)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    fit(); ctx.sync(stream)
+    stats, seed = ctx.last_stats(), ctx.last_seed_stats()
+    kms = {}
+    for w, name in ((0, 'all_kernels'), (5, 'stage1_gemm_seed_cert'), (6, 'lasso_gemm_seed_cert'), (7, 'stage3_seed_cert'), (1, 'stage1_leftover'), (2, 'lasso_leftover'), (3, 'stage3_leftover')):
+        try:
+            kms[name] = ctx.last_kernel_ms(w)
+        except Exception:
+            pass
+    pick = np.unique(np.linspace(0, n - 1, min(n, 20000)).astype(np.int64))
+    ref = oracle.noddi_fit(np.ascontiguousarray(y_h[pick]), np.ascontiguousarray(d_h[pick]), K, htable, scheme.dwi_idx, nthreads=physical_cores() or os.cpu_count() or 1)
+    diff = np.abs(est.cpu().numpy()[pick] - ref['estimates']).max(axis=1)
+    out = {'metric': 'voxels/sec, NODDI fit, hard signal mix (inputs resident in HBM)', 'value': n / el, 'unit': 'voxels/s', 'voxels': n,
+           'ms_per_step': 1e3 * el, 'kernel_ms': kms, 'solver_stats': stats, 'seed_chain': seed,
+           'parity': {'sample_voxels': len(pick), 'max_abs_dmap': float(diff.max()), 'frac_within_1e-6': float((diff < 1e-6).mean())},
+           'mix': list(S.HARD_KINDS)}
+    del y, d, est
+    return out
+
+
 def device_barrier(dev, world):
     """both sides of the timed region: drain the device, meet the other ranks, drain again"""
     import torch
@@ -641,6 +699,9 @@ def main():
     elapsed = timed_steps(step, lambda: ctx.sync(stream), args.steps, args.warmup, world, dev, per_step)
     kms /= max(1, args.steps)
     stats = ctx.last_stats()
+    seed_chain = ctx.last_seed_stats()
+    if seed_chain.get('seeded_voxels'):            # (the counters accumulate between two syncs: one step's worth here)
+        seed_chain['certified_by_gram_certificates'] = seed_chain.pop('certified')
 
     if rank == 0:
         value = world * n * args.steps / elapsed
@@ -658,6 +719,7 @@ def main():
         dom_ms = float(kms[stage])
         achieved = BYTES_PER_VOXEL * n / (dom_ms * 1e-3) / 1e9
         traffic = pmc_traffic(stage, n)
+        whole = pmc_whole_fit(n)
         out = {
             'metric': 'voxels/sec (whole node), NODDI fit',
             'value': value, 'unit': 'voxels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -669,6 +731,10 @@ def main():
                        'parallelism': 'voxel shards x%d, one RCCL all_gather of the maps per step' % world},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         # the same two figures for the WHOLE fit: algorithmic bytes of the step over its wall time, and the counter
+                         # traffic of all its kernels (the dominant kernel alone touches ~100 B per voxel: `traffic` above is that)
+                         'frac_end_to_end': BYTES_PER_VOXEL * n / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                         'traffic_whole_fit': whole, 'algorithmic_bytes_whole_fit': BYTES_PER_VOXEL * n,
                          'traffic_source': 'profiles/pmc_traffic.json (rocprofv3 --pmc, bytes per launch)'
                                            if traffic is not None else None,
                          'kernel': names[stage], 'kernel_ms': dom_ms,
@@ -676,7 +742,7 @@ def main():
                          'groups': {str(k): {'kernels': v, 'ms': float(kms[k])} for k, v in groups.items()}, 'all_kernels_ms': float(kms[0]),
                          'note': 'the path is bound by dependent latencies inside the per-voxel active-set solvers, not by HBM (DESIGN.md section 5): see compute_side'},
             'compute_side': pmc_valu(stage, n, dom_ms),
-            'solver_stats': stats,
+            'solver_stats': stats, 'seed_chain': seed_chain,
         }
         if world == 1:
             from oracle import oracle
@@ -721,6 +787,8 @@ def main():
                     del y32
                 except (TypeError, AttributeError, ValueError):
                     pass
+            if not args.no_other_configs:
+                other['noddi_hard_mix'] = noddi_hard_mix(ctx, lut, K, htable, scheme, min(n, 1_000_000), 5, 2)
             if not args.no_cpu_baseline:
                 # bounded CPU legs on the host cores of this box: the oracle -- a port, the reference's
                 # cyspams path cannot be built -- at -O3 -march=native, the reference's chunk-per-thread structure

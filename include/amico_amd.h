@@ -283,6 +283,12 @@ int amx_last_kernel_ms(amx_ctx *ctx, int which, float *out_ms);
 /* solver statistics of the last call: out[0]=voxels re-run with the large active-set
  * variant (stage sum), out[1]=voxels hitting the iteration cap, out[2..3] reserved        */
 int amx_last_stats(amx_ctx *ctx, int64_t out[4]);
+/* NODDI, the seed -> certificate chain (csrc/amx_seed.hpp; no counterpart in the reference, whose every voxel takes one path,
+ * models.pyx:902-981): how the voxels fitted since the previous amx_sync_status were settled.  out[0] = voxels that took the
+ * chain (0: the calls were too small / the dictionary has no bases), out[1..3] = voxels the Gram-space certificates of stage 1 /
+ * the LASSO stage / stage 3 could NOT settle and handed to the wavefront-per-voxel kernels, out[4] = voxels whose stage-2 signal
+ * y2 = max(0, y - x_iso iso) was clipped (models.pyx:924-925), out[5..7] reserved.  Certification rate of stage k = 1 - out[k] / out[0]. */
+int amx_last_seed_stats(amx_ctx *ctx, int64_t out[8]);
 
 /* device self-test of the wavefront primitives (DPP reductions, broadcasts): writes 12 rows of
  * 64 doubles (sum, max, min, bcast lane 37, next-lane, popcount(ballot v>0), int bcast, v, and

@@ -36,6 +36,39 @@ def test_noddi_one_million_voxels_against_the_oracle(htable500):
     assert st['itercap_voxels'] == 0 and st['overflow_voxels'] == 0 and st['guard_trips'] == 0
 
 
+def test_noddi_eight_million_voxels_in_one_call(htable500):
+    """BASELINE config 5's node total (8 M voxels: 6.3 GB of signals, ~23 GB of workspace) fitted by ONE call on one GPU -- the
+    size no 8-GPU node was available for; every 400th voxel against the oracle, no iteration cap, no overflow, and the stage
+    certificates must settle the same share of the voxels as at 1 M (the shard rule itself: tests/test_host_cpu.py)"""
+    import torch
+    from amico_amd import _capi, get_context, synthetic as S
+    from oracle import oracle
+    n = 8_000_000
+    dirs, ht = htable500['dirs'], htable500['htable']
+    sch = S.make_scheme(seed=0)
+    K = S.noddi_kernels(sch, dirs)
+    y, d = S.noddi_signals_parallel(n, K, ht, sch, seed=7)
+    ctx = get_context()
+    lut = _capi.upload_noddi(ctx, K, ht, sch.dwi_idx)
+    dev = torch.device('cuda', 0)
+    yd = torch.from_numpy(y).to(dev); dd = torch.from_numpy(d).to(dev)
+    est = _capi.noddi_fit_device(ctx, lut, yd, dd, 0.5, 1e-3, 3)[0]
+    ctx.sync()
+    st, ss = ctx.last_stats(), ctx.last_seed_stats()
+    print('NODDI 8M:', st, ss)
+    assert st['itercap_voxels'] == 0 and st['overflow_voxels'] == 0 and st['guard_trips'] == 0
+    assert ss['seeded_voxels'] == n and min(ss['certified']) > 0.9
+    pick = np.arange(0, n, 400)
+    ref = oracle.noddi_fit(np.ascontiguousarray(y[pick]), np.ascontiguousarray(d[pick]), K, ht, sch.dwi_idx, nthreads=os.cpu_count() or 1)['estimates']
+    got = est.cpu().numpy()
+    diff = np.abs(got[pick] - ref).max(axis=1)
+    _report('NODDI 8M (every 400th voxel)', diff)
+    assert diff.max() < 1e-4 and (diff > 1e-6).sum() <= 2
+    assert np.isfinite(got).all() and (got[:, 1] > 0).all()         # every voxel was written (ODI of a fitted voxel is positive)
+    del yd, dd, est
+    torch.cuda.empty_cache()
+
+
 def test_freewater_two_million_and_sandi_one_million_voxels_against_the_oracle(htable500):
     import torch
     from amico_amd import _capi, get_context, synthetic as S

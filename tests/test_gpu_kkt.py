@@ -30,18 +30,20 @@ def _by_direction(lut_idx):
     return np.split(order, bounds)
 
 
-def _noddi_certificates(K, sch, ht, y, d, x, lam1, lam2):
-    """max KKT violations of the three NODDI solves, from the device coefficients only"""
+def _noddi_certificates(K, sch, ht, y, d, x, lam1, lam2, exvivo=False):
+    """max KKT violations of the three NODDI solves, from the device coefficients only (exvivo: the dot atom -- a column of
+    ones, models.pyx:843-844 -- sits between the wm atoms and iso)"""
     from amico_amd import synthetic as S
     lut = S.lut_indices(d, ht)
     n_wm = K['wm'].shape[0]
     iso = K['iso'].astype(np.float64)
+    fixed = ([np.ones_like(iso)] if exvivo else []) + [iso]
     dwi = np.asarray(sch.dwi_idx)
     norms = K['norms'][0]
     out = {k: 0.0 for k in ('s1_wP', 's1_wZ', 's2_gP', 's2_gZ', 's3_wP', 's3_wZ', 's3_off_support')}
     neg = 0.0
     for rows in _by_direction(lut):
-        A = np.concatenate([K['wm'][:, lut[rows[0]], :].astype(np.float64), iso[None, :]], axis=0).T      # nS x n_atoms
+        A = np.concatenate([K['wm'][:, lut[rows[0]], :].astype(np.float64)] + [f[None, :] for f in fixed], axis=0).T      # nS x n_atoms
         Y = y[rows]
         x1, x2, x3 = x[rows, 0], x[rows, 1], x[rows, 2]
         neg = min(neg, x1.min(), x2.min(), x3.min())
@@ -52,14 +54,14 @@ def _noddi_certificates(K, sch, ht, y, d, x, lam1, lam2):
         out['s1_wZ'] = max(out['s1_wZ'], W[~P].max(initial=0.0))
         # stage 2: non-negative elastic net on the column-normalised wm atoms, y2 clipped (models.pyx:914-926)
         A2 = A[dwi][:, :n_wm] * norms[None, :]
-        Y2 = np.maximum(Y[:, dwi] - x1[:, -1:] * iso[dwi][None, :], 0.0)
+        Y2 = np.maximum(Y[:, dwi] - x1[:, n_wm:] @ A[dwi][:, n_wm:].T, 0.0)
         xl = x2[:, :n_wm]
         G = (Y2 - xl @ A2.T) @ A2 - lam2 * xl - lam1
         P = xl > 0
         out['s2_gP'] = max(out['s2_gP'], np.abs(G[P]).max(initial=0.0))
         out['s2_gZ'] = max(out['s2_gZ'], G[~P].max(initial=0.0))
         # stage 3: NNLS on the LASSO support + iso (models.pyx:929-942)
-        allowed = np.concatenate([P, np.ones((len(rows), 1), dtype=bool)], axis=1)
+        allowed = np.concatenate([P, np.ones((len(rows), len(fixed)), dtype=bool)], axis=1)
         W = (Y - x3 @ A.T) @ A
         P3 = x3 > 0
         out['s3_off_support'] = max(out['s3_off_support'], np.abs(x3[~allowed]).max(initial=0.0))
@@ -105,6 +107,48 @@ def test_noddi_kkt_certificates_and_supports(htable500, snr, mapping, amx_env):
     assert diff.max() < CAP, (diff.max(), int((diff > 1e-6).sum()))
     assert (diff < 1e-6).mean() >= 0.9999
     assert np.abs(x[:, 0, -1] - ref['x'][:, 0, -1]).max() < 1e-7      # x_iso handed from stage 1 to stage 2
+
+
+@pytest.mark.parametrize('exvivo', [False, True])
+def test_noddi_hard_mix_kkt_and_oracle(htable500, exvivo):
+    """Signals the dictionary does not explain (synthetic.noddi_hard_signals: crossings, wrong direction, CSF-dominated f_iso in
+    [0.5, 1], pure noise, flat, half-zeroed, background, SNR 5 / 15 / 40) through the default path for this size -- the seed ->
+    certificate chain in vivo, the wavefront-per-voxel solvers ex vivo: every voxel's coefficient vectors must satisfy the numpy
+    KKT certificates, and the maps must equal the oracle's.  models.pyx:902-981 takes one path whatever the signal; the
+    certificate thresholds of the fast path were tuned on clean single-atom voxels."""
+    import torch
+    from amico_amd import _capi, get_context, synthetic as S
+    from oracle import oracle
+    dirs, ht = htable500['dirs'], htable500['htable']
+    sch = S.make_scheme(seed=9)
+    K = S.noddi_kernels(sch, dirs)
+    y, d, kind = S.noddi_hard_signals(N_VOX, K, ht, sch, seed=9)
+    ctx = get_context()
+    lut = _capi.upload_noddi(ctx, K, ht, sch.dwi_idx, is_exvivo=exvivo)
+    dev = torch.device('cuda', 0)
+    est, _, _, _, xd = _capi.noddi_fit_device(ctx, lut, torch.from_numpy(y).to(dev), torch.from_numpy(d).to(dev),
+                                              0.5, 1e-3, 4 if exvivo else 3, return_x=True)
+    ctx.sync()
+    st, ss = ctx.last_stats(), ctx.last_seed_stats()
+    print('hard mix', 'ex vivo' if exvivo else 'in vivo', st, ss)
+    assert st['itercap_voxels'] == 0 and st['guard_trips'] == 0 and st['overflow_voxels'] == 0
+    if not exvivo:
+        assert ss['seeded_voxels'] == N_VOX                     # the fast path ran; what it could not certify it handed on
+    x = xd.cpu().numpy()
+    est = est.cpu().numpy()
+    c = _noddi_certificates(K, sch, ht, y, d, x, 0.5, 1e-3, exvivo=exvivo)
+    print(c)
+    assert c['min_x'] >= 0.0 and c['s3_off_support'] == 0.0, c
+    tol = 4e-9                                                  # (signals up to 2.0 and ||y|| up to 20: four times the clean-data bound)
+    assert c['s1_wP'] < tol and c['s3_wP'] < tol and c['s2_gP'] < tol, c
+    assert c['s1_wZ'] < tol and c['s3_wZ'] < tol and c['s2_gZ'] < tol, c
+    ref = oracle.noddi_fit(y, d, K, ht, sch.dwi_idx, is_exvivo=exvivo, nthreads=os.cpu_count() or 1)['estimates']
+    diff = np.abs(est - ref).max(axis=1)
+    bad = np.flatnonzero(diff > 1e-6)
+    print('max %.3e, > 1e-8: %d, > 1e-6: %d, kinds of those %s' % (diff.max(), int((diff > 1e-8).sum()), len(bad), np.bincount(kind[bad], minlength=8).tolist()))
+    assert diff.max() < CAP, (diff.max(), kind[int(diff.argmax())])
+    assert (diff < 1e-6).mean() >= 0.9999
+    assert np.abs(est[:10] - ref[:10]).max() < 1e-12 and np.abs(est[:10, :3] - np.array([0.0, 1.0, 0.0])).max() < 1e-12   # all-zero voxels: NDI 0, ODI 1, FWF 0
 
 
 def test_noddi_fixture_coefficients_per_stage(noddi_fix, htable500):

@@ -67,6 +67,38 @@ def test_sharded_step_and_fit_sharded_under_rccl_world1():
         dist.destroy_process_group()
 
 
+def test_fit_sharded_one_million_voxel_shard_under_rccl():
+    """config 5's per-GPU share: a 1 M-voxel shard handed to fit_sharded(n_total=...) with the process group on RCCL, the maps
+    gathered straight from HBM by the packed all_gather_into_tensor (world 1: the only world a test box has)"""
+    import torch
+    import amico_amd
+    from amico_amd import synthetic as S
+    from amico_amd.parallel import fit_sharded, shard_range
+    from oracle import oracle
+    dist = _nccl_world1(38600 + os.getpid() % 2000)
+    try:
+        dirs = S.fibonacci_hemisphere(500); ht = S.build_htable(dirs)
+        sch = S.make_scheme(seed=0); K = S.noddi_kernels(sch, dirs)
+        n = 1_000_000
+        assert shard_range(8 * n, 3, 8) == (3 * n, 4 * n)               # models.pyx:204-211: rank 3 of 8 owns [3 M, 4 M)
+        y_h, d_h = S.noddi_signals_parallel(n, K, ht, sch, seed=31)
+        m = amico_amd.NODDI(); m.scheme = sch
+
+        class Ev:
+            def get_config(self, key):
+                return False
+        ev = Ev(); ev.y = y_h; ev.DIRs = d_h; ev.KERNELS = K; ev.htable = ht; ev.nthreads = 8
+        out = fit_sharded(m, ev, n_total=n, to_host=False)
+        est = out['estimates']
+        assert est.is_cuda and est.shape == (n, 3)
+        pick = np.arange(0, n, 100)
+        ref = oracle.noddi_fit(np.ascontiguousarray(y_h[pick]), np.ascontiguousarray(d_h[pick]), K, ht, sch.dwi_idx, nthreads=os.cpu_count() or 1)['estimates']
+        diff = np.abs(est.cpu().numpy()[pick] - ref).max(axis=1)
+        assert diff.max() < 1e-4 and (diff > 1e-6).sum() <= 1
+    finally:
+        dist.destroy_process_group()
+
+
 def test_bench_gpus2_starts_its_own_ranks():
     """one visible GPU: the command form of the driver's scaling run must get as far as the ranks and say what is missing"""
     import torch
