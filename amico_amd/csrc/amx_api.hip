@@ -2,6 +2,7 @@
 // Host side only drives HIP: workspace, dictionary upload, kernel launches, status.
 #include "amx_host.hpp"
 #include "amx_prep.hpp"
+#include <algorithm>
 
 using namespace amx;
 
@@ -24,7 +25,7 @@ int reset_status(amx_ctx *ctx, hipStream_t s)
     return AMX_OK;
 }
 
-int make_plan(amx_ctx *ctx, int64_t n, int ndirs, Plan &pl, bool seeds = false)
+int make_plan(amx_ctx *ctx, int64_t n, int ndirs, Plan &pl, bool seeds = false, int table_rows = 0)
 {
     int rc;
     const int max_chunks = (int)(n / kChunk) + ndirs + 1;
@@ -47,8 +48,11 @@ int make_plan(amx_ctx *ctx, int64_t n, int ndirs, Plan &pl, bool seeds = false)
         if ((rc = ensure(ctx, ctx->schunks, (size_t)pl.max_schunks * sizeof(Chunk)))) return rc;
         if ((rc = ensure(ctx, ctx->ytil, (size_t)n * amx::kSeedKD * sizeof(double)))) return rc;
         if ((rc = ensure(ctx, ctx->seeds, (size_t)n * sizeof(unsigned long long)))) return rc;
-        if ((rc = ensure(ctx, ctx->cgemm, ((size_t)n / 64 + ndirs + 1) * 160 * 64 * sizeof(double)))) return rc;
-        if ((rc = ensure(ctx, ctx->cgemm2, ((size_t)n / 64 + ndirs + 1) * 160 * 64 * sizeof(double)))) return rc;
+        // the A'y table of all voxels, and the compact table of the voxels whose stage-2 signal clips (sized for all of them: a
+        // dictionary whose b0 rows are not ones sends every voxel there), the clipped lists / counts / slots of k_s2_prep
+        if ((rc = ensure(ctx, ctx->cgemm, ((size_t)n / 64 + ndirs + 1) * table_rows * 64 * sizeof(double)))) return rc;
+        if ((rc = ensure(ctx, ctx->cgemm2, ((size_t)n / 64 + ndirs + 1) * table_rows * 64 * sizeof(double)))) return rc;
+        if ((rc = ensure(ctx, ctx->clip, ((size_t)2 * n + pl.max_schunks + 64) * sizeof(int)))) return rc;
         if ((rc = ensure(ctx, ctx->done, (size_t)n + 64))) return rc;
         if ((rc = ensure(ctx, ctx->rlist, 2 * amx_rlist_half(pl) * sizeof(int)))) return rc;
         if ((rc = ensure(ctx, ctx->ytil2, (size_t)n * amx::kSeedKD * sizeof(double)))) return rc;
@@ -198,6 +202,8 @@ int amx_ctx_create(int device, amx_ctx **out)
         ctx->opt_no_seed = e && *e && *e != '0';
         e = getenv("AMX_NO_GCERT");
         ctx->opt_no_gcert = e && *e && *e != '0';
+        e = getenv("AMX_S2_EXACT");
+        ctx->opt_s2_exact = e && *e && *e != '0';
         auto on = [](const char *name) { const char *v = getenv(name); return v && *v && *v != '0'; };
         ctx->opt_no_gram = on("AMX_NO_GRAM"); ctx->opt_lasso_qr = on("AMX_LASSO_QR"); ctx->opt_cold_start = on("AMX_COLD_START");
         ctx->opt_host_one_shot = on("AMX_HOST_ONE_SHOT"); ctx->opt_host_one_stream = on("AMX_HOST_ONE_STREAM");
@@ -239,7 +245,7 @@ void amx_ctx_destroy(amx_ctx *ctx)
     hipDeviceSynchronize();
     DevBuf *bufs[] = {&ctx->lutidx, &ctx->perm, &ctx->counts, &ctx->dir_start, &ctx->cursor, &ctx->chunks,
                       &ctx->misc, &ctx->xiso, &ctx->supp, &ctx->ovf, &ctx->cproj, &ctx->hy, &ctx->hdirs, &ctx->hest,
-                      &ctx->hrmse, &ctx->hnrmse, &ctx->hextra, &ctx->hy32, &ctx->wy, &ctx->ytil, &ctx->seeds, &ctx->schunks, &ctx->ytil2, &ctx->seeds2, &ctx->cgemm, &ctx->done, &ctx->rlist, &ctx->cgemm2};
+                      &ctx->hrmse, &ctx->hnrmse, &ctx->hextra, &ctx->hy32, &ctx->wy, &ctx->ytil, &ctx->seeds, &ctx->schunks, &ctx->ytil2, &ctx->seeds2, &ctx->cgemm, &ctx->done, &ctx->rlist, &ctx->cgemm2, &ctx->clip};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     for (DevBuf &b : ctx->alt) if (b.p) hipFree(b.p);
     if (ctx->status_d) hipFree(ctx->status_d);
@@ -255,7 +261,7 @@ void amx_lut_destroy(amx_lut *lut)
 {
     if (!lut) return;
     if (lut->ctx) hipSetDevice(lut->ctx->device);
-    void *ps[] = {lut->screen2_kappa0, lut->screen_kappa0, lut->screen2_S, lut->screen2_kappa, lut->screen_S, lut->screen_kappa, lut->basis_U, lut->basis_S, lut->basis2_U, lut->basis2_S, lut->gram, lut->gram_dwi, lut->tiles, lut->htable, lut->rowdwi, lut->colscale, lut->icvf, lut->kappa,
+    void *ps[] = {lut->u2iso, lut->screen2_kappa0, lut->screen_kappa0, lut->screen2_S, lut->screen2_kappa, lut->screen_S, lut->screen_kappa, lut->basis_U, lut->basis_S, lut->basis2_U, lut->basis2_S, lut->gram, lut->gram_dwi, lut->tiles, lut->htable, lut->rowdwi, lut->colscale, lut->icvf, lut->kappa,
                   lut->norms, lut->Rs, lut->d_in, lut->d_isos, lut->fw_prep, lut->sandi_prep};
     for (void *p : ps) if (p) hipFree(p);
     if (lut->fw_ready) (void)hipEventDestroy(lut->fw_ready);
@@ -312,6 +318,15 @@ int amx_lut_upload_noddi(amx_ctx *ctx, const float *wm, const float *iso, const 
         const int64_t row = single_b0 ? j + 1 : dwi_idx[j];
         if (row < 0 || row >= nS) { amx_lut_destroy(lut); return bad(ctx, "amx_lut_upload_noddi: dwi_idx out of range"); }
         rowdwi[row] = 1;
+    }
+    // Are the rows outside stage 2 (the b0 volumes) exactly 1.0 in every atom, as resample_kernel leaves them (lut.pyx:298, 305)?
+    // Then the stage-2 products of an unclipped voxel derive from the stage-1 table (k_noddi_gemm); otherwise every voxel takes
+    // the exact pass.
+    lut->s2_derive = is_exvivo ? 0 : 1;
+    for (int i = 0; i < nS && lut->s2_derive; i++) {
+        if (rowdwi[i]) { if (!(iso[i] > 1e-30f) || !(iso[i] <= 3.0e38f)) lut->s2_derive = 0; continue; }
+        if (iso[i] != 1.0f) lut->s2_derive = 0;
+        for (size_t kd = 0; kd < (size_t)n_wm * ndirs && lut->s2_derive; kd++) if (wm[kd * nS + i] != 1.0f) lut->s2_derive = 0;
     }
     std::vector<double> colscale(n_atoms, 1.0);
     for (int k = 0; k < n_wm; k++) colscale[k] = dwi_count > 0 ? norms[k] : 1.0;   // rows of norms are identical
@@ -601,7 +616,8 @@ static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
     Plan pl; int rc;
     const bool seeds = lut->basis_S != nullptr && lut->gram != nullptr && !ctx->opt_no_seed &&
                        (ctx->in_host_fit ? ctx->host_total_vox : n_vox) >= ctx->opt_seed_min_voxels;   // (batches of one host call all take the same path: bit-identical to the one-shot call)
-    if ((rc = make_plan(ctx, n_vox, lut->ndirs, pl, seeds))) return rc;
+    const int gemm_ks = seeds ? amx_gemm_ksteps(lut) : 0;                        // 0: no table kernels for this shape (seeds certified on the true residual only)
+    if ((rc = make_plan(ctx, n_vox, lut->ndirs, pl, seeds, gemm_rows(lut->n_atoms)))) return rc;
     if ((rc = ensure(ctx, ctx->xiso, (size_t)n_vox * 2 * sizeof(double)))) return rc;
     if ((rc = ensure(ctx, ctx->supp, (size_t)n_vox * 4 * sizeof(unsigned long long)))) return rc;
     clear_events(ctx);
@@ -628,7 +644,7 @@ static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
         ctx->seeded_vox += n_vox;
         // y~ = U'y once; the seed solver proposes the stage's support, the stage kernel certifies it (amx_seed.hpp)
         rec(ctx, 10, s);
-        const bool gcert = !ctx->opt_no_gcert && lut->nS <= 100 && lut->n_atoms <= 146;
+        const bool gcert = !ctx->opt_no_gcert && gemm_ks > 0;
         if (gcert && (rc = amx_launch_noddi_gemm(ctx, lut, a, pl, s, false))) return rc;
         if (!gcert && (rc = amx_launch_noddi_project(ctx, lut, a, pl, s))) return rc;      // (the GEMM writes y~ as well)
         if (!ctx->opt_no_screen) { a.scr_S = lut->screen_S; a.scr_kappa = lut->screen_kappa; a.scr_ytil = (const double *)ctx->ytil.p; a.scr_Sg = lut->basis_S; }
@@ -652,9 +668,10 @@ static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
     a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks; a.rlist = nullptr; a.rcount = nullptr; a.done = nullptr;
     // the LASSO seeds need x_iso: Gram-space solver only (lambda2 >= 1e-5), with the default dictionary shape
     if (seeds && (ctx->opt_seed_stages & 4) && lut->basis2_S != nullptr && lambda2 >= 1e-5 && lut->nS <= 128 && !ctx->opt_lasso_qr) {
-        const bool gcert2 = !ctx->opt_no_gcert && lut->nS <= 100 && lut->n_atoms <= 146 && lut->n_wm <= 144 && lut->screen2_kappa0 != nullptr;
+        const bool gcert2 = !ctx->opt_no_gcert && gemm_ks > 0 && lut->screen2_kappa0 != nullptr && lut->u2iso != nullptr;
         rec(ctx, 12, s);
-        if (gcert2 && (rc = amx_launch_noddi_gemm(ctx, lut, a, pl, s, true))) return rc;        // c2 = A2'y2, y2~, ||y2||^2
+        // y2~ of every voxel and c2 = A2'y2, ||y2||^2 of the unclipped ones derive from the stage-1 table; the clipped voxels' exactly
+        if (gcert2 && (rc = amx_launch_noddi_s2prep(ctx, lut, a, pl, s))) return rc;
         rec(ctx, 18, s);
         if ((rc = amx_launch_noddi_seed2(ctx, lut, a, pl, s, gcert2))) return rc;
         rec(ctx, 19, s);
@@ -678,8 +695,9 @@ static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
             a.seeds = (const unsigned long long *)ctx->seeds.p;
             rec(ctx, 14, s);
             rc = amx_launch_noddi_seed(ctx, lut, a, pl, s, 3);
-            if (ctx->opt_no_gcert || lut->nS > 100 || lut->n_atoms > 146) ctx->uncert_vox[2] += n_vox;
-            if (!rc && !ctx->opt_no_gcert && lut->nS <= 100 && lut->n_atoms <= 146) {
+            const bool gcert3 = !ctx->opt_no_gcert && gemm_ks > 0;
+            if (!gcert3) ctx->uncert_vox[2] += n_vox;
+            if (!rc && gcert3) {
                 rc = amx_launch_noddi_gcert(ctx, lut, a, pl, s, 3);
                 a.done = (const unsigned char *)ctx->done.p;
                 a.rlist = (const int *)ctx->rlist.p; a.rcount = a.rlist + pl.n;
@@ -955,6 +973,8 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
     const bool two_streams = pipelined && !ctx->opt_host_one_stream;
     hipStream_t s = pipelined ? ctx->hs : nullptr;
     int64_t off = 0, done_before[kBufs] = {0, 0, 0};         // voxels complete once the event of that buffer has fired
+    int64_t reported = 0;                                    // progress is reported once per batch, in order
+    auto report = [&](int64_t v) { if (v > reported) { progress(ctx, v, n_vox); reported = v; } };
     for (int c = 0; off < n_vox; c++) {
         // the first copy is the only one the solver cannot hide: one short batch (131 072 voxels; shorter ones cost more in the
         // ~2.4 ms floor of the seeded kernel chain than their copy saves), then the rest in equal batches of <= kHostBatch voxels
@@ -964,7 +984,7 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
         int b = c % kBufs;
         if (pipelined && c >= kBufs) {
             HIPCHK(ctx, hipEventSynchronize(ctx->hev[b]));           // batch c-3 has released this buffer
-            progress(ctx, done_before[b], n_vox);                    // batches 0 .. c-3 are complete
+            report(done_before[b]);                                  // batches 0 .. c-3 are complete
         }
         if (two_streams) { s = (c & 1) ? ctx->hs2 : ctx->hs; if (c) ctx->swap_work(); }
         // (the uploads below are blocking hipMemcpy calls from pageable memory on the null stream; the consumers run on the
@@ -985,7 +1005,7 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
         // (batches c-1 and c-2 run on different streams: both must have fired before batch c-1's count is reported)
         if (pipelined && c >= 1 && ctx->progress && hipEventQuery(ctx->hev[(c - 1) % kBufs]) == hipSuccess &&
             (c < 2 || hipEventQuery(ctx->hev[(c - 2) % kBufs]) == hipSuccess))
-            progress(ctx, done_before[(c - 1) % kBufs], n_vox);
+            report(done_before[(c - 1) % kBufs]);
         ctx->vox_base = off;
         rc = enqueue(yb, db, cnt, (double *)outs[0].buf->p + (size_t)off * outs[0].cols,
                      outs[1].on ? (double *)outs[1].buf->p + off : nullptr, outs[2].on ? (double *)outs[2].buf->p + off : nullptr,
@@ -996,6 +1016,19 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
         if (pipelined) { HIPCHK(ctx, hipEventRecord(ctx->hev[b], s)); done_before[b] = off; }
     }
     ctx->profiling = was_profiling;
+    if (pipelined && ctx->progress) {
+        // the batches still in flight, in submission order: one callback as each of them completes (the queries above only
+        // catch a batch that finished while the next one was being copied)
+        int64_t order[kBufs]; int idx[kBufs];
+        for (int b = 0; b < kBufs; b++) { order[b] = done_before[b]; idx[b] = b; }
+        for (int i = 0; i < kBufs; i++) for (int j = i + 1; j < kBufs; j++) if (order[j] < order[i]) { std::swap(order[i], order[j]); std::swap(idx[i], idx[j]); }
+        for (int i = 0; i < kBufs; i++) {
+            if (order[i] <= 0 || order[i] >= n_vox) continue;
+            HIPCHK(ctx, hipEventSynchronize(ctx->hev[idx[i]]));
+            if (two_streams && i > 0 && order[i - 1] > 0) HIPCHK(ctx, hipEventSynchronize(ctx->hev[idx[i - 1]]));
+            report(order[i]);
+        }
+    }
     if (two_streams) { HIPCHK(ctx, hipStreamSynchronize(s == ctx->hs ? ctx->hs2 : ctx->hs)); }
     rc = amx_sync_status(ctx, s);
     if (rc) return rc;

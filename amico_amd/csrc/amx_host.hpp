@@ -25,7 +25,7 @@ struct amx_ctx {
     int n_cu = 256;                // compute units of the device (persistent-grid launches)
     std::string err;
     // stream-ordered workspace (grow-only)
-    DevBuf lutidx, perm, counts, dir_start, cursor, chunks, misc, xiso, supp, ovf, cproj, ytil, seeds, schunks, ytil2, seeds2, cgemm, done, rlist, cgemm2;
+    DevBuf lutidx, perm, counts, dir_start, cursor, chunks, misc, xiso, supp, ovf, cproj, ytil, seeds, schunks, ytil2, seeds2, cgemm, done, rlist, cgemm2, clip;
     DevBuf hy, hdirs, hest, hrmse, hnrmse, hextra;   // staging for the host-pointer entry points
     int *status_d = nullptr;       // ST_WORDS ints
     int *status_h = nullptr;       // pinned mirror (+16 words: copy of the misc counters)
@@ -48,11 +48,11 @@ struct amx_ctx {
     hipStream_t hs2 = nullptr;     // between the two, so the tail of one batch's kernels is filled by the next batch's
     hipEvent_t hev[3] = {nullptr, nullptr, nullptr};
     // second workspace set for the batch in flight on the other stream (swap_work exchanges it with the named buffers)
-    DevBuf alt[20];
+    DevBuf alt[21];
     void swap_work()
     {
-        DevBuf *named[20] = {&lutidx, &perm, &counts, &dir_start, &cursor, &chunks, &misc, &xiso, &supp, &ovf, &cproj, &ytil, &seeds, &schunks, &ytil2, &seeds2, &cgemm, &done, &rlist, &cgemm2};
-        for (int i = 0; i < 20; i++) { DevBuf t = *named[i]; *named[i] = alt[i]; alt[i] = t; }
+        DevBuf *named[21] = {&lutidx, &perm, &counts, &dir_start, &cursor, &chunks, &misc, &xiso, &supp, &ovf, &cproj, &ytil, &seeds, &schunks, &ytil2, &seeds2, &cgemm, &done, &rlist, &cgemm2, &clip};
+        for (int i = 0; i < 21; i++) { DevBuf t = *named[i]; *named[i] = alt[i]; alt[i] = t; }
     }
     // switches read ONCE, at amx_ctx_create (environment): diagnosis / A-B only
     // switches below: environment variables read ONCE, at amx_ctx_create (diagnosis / A-B tools; the defaults are the product path)
@@ -75,6 +75,7 @@ struct amx_ctx {
     bool opt_no_gcert_wide = false; // AMX_NO_GCERT_WIDE=1: no second Gram-certificate pass for LASSO supports of 13 .. 16 atoms
     bool opt_no_gcert = false;     // AMX_NO_GCERT=1: every seed is certified by the wavefront-per-voxel kernels (true residual)
     bool opt_no_screen = false;    // AMX_NO_SCREEN=1: certify seeds with the full exact sweep of the dual vector
+    bool opt_s2_exact = false;     // AMX_S2_EXACT=1: every voxel's stage-2 products by the exact pass (k_noddi_gemm<true>), none derived from the stage-1 table
     bool opt_no_seed = false;      // AMX_NO_SEED=1: Lawson-Hanson from the empty set in the NNLS stages (the round-2 path)
     long long opt_seed_min_voxels = 40960; // AMX_SEED_MIN_VOXELS: smaller calls run the wavefront-per-voxel kernels on all voxels (the seeded chain of ~16 kernels has a floor of ~2 ms; measured crossover between 30 000 and 50 000 voxels: 14.6 vs 16.2 and 23.0 vs 19.4 M voxels/s)
     int opt_seed_waves = 0;        // AMX_SEED_WAVES: wavefronts per workgroup of the lane kernels (0 = by the number of chunks, make_plan)
@@ -93,6 +94,8 @@ struct amx_lut {
     double *gram = nullptr, *gram_dwi = nullptr;   // per-orientation Gram matrices (NODDI)
     double *basis_U = nullptr, *basis_S = nullptr; // per-orientation compressed basis and dictionary (amx_seed.hpp), NODDI
     double *screen2_kappa0 = nullptr;
+    double *u2iso = nullptr;       // [ndirs][12] U2'iso (amx_build_basis)
+    int s2_derive = 0;             // b0 rows of every atom are exactly 1.0 and iso > 0 on the stage-2 rows: stage-2 products derive from the stage-1 table
     float *screen2_S = nullptr; double *screen2_kappa = nullptr; // the same for the LASSO stage's dictionary
     double *screen_kappa0 = nullptr;                             // max ||(I - U U') a_j|| per orientation (k_nnls_gcert)
     float *screen_S = nullptr; double *screen_kappa = nullptr;   // float32 S [ndirs][12][192] + kappa [ndirs]: dual-value screening
@@ -204,6 +207,8 @@ int amx_launch_noddi_project(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiA
 int amx_launch_noddi_seed(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, int stage);
 int amx_launch_noddi_gcert(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, int stage);
 int amx_launch_noddi_gemm(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, bool lasso);
+int amx_launch_noddi_s2prep(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s);
+int amx_gemm_ksteps(const amx_lut *lut);   // K-steps of the table kernels for this dictionary (25 / 40), 0 = shape not supported
 int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, bool wide);
 size_t amx_gcert2_leftover_offset(const Plan &pl, bool wide);      // which half of ctx->rlist the LASSO certificate passes end in (amx_seed.hip)
 static inline size_t amx_rlist_half(const Plan &pl) { return (size_t)pl.n + pl.max_schunks + 64; }   // ints per left-over list + counts

@@ -17,6 +17,10 @@ namespace amx {
 
 struct Chunk { int dir, start, count, pad; };
 constexpr int kSeedKD = 12;      // compressed dimensions of the support-seed problem (amx_seed.hpp)
+// rows of a block of the A'y table (k_noddi_gemm, amx_seed.hpp): atoms 0 .. n_atoms - 1, then from aux0 = n_atoms: U'y (12), U2'y (12),
+// sum_b0 y, ||y||^2, sum_b0 y^2, t_min = min_dwi y_i / iso_i; padded to whole 16-row MFMA tiles
+constexpr int kAuxU = 0, kAuxU2 = 12, kAuxB0 = 24, kAuxYY = 25, kAuxYB = 26, kAuxTmin = 27, kAuxN = 28;
+__host__ __device__ constexpr int gemm_rows(int n_atoms) { return ((n_atoms + kAuxN + 15) / 16) * 16; }
 constexpr int kScreenLd = 192;   // atoms per row of the float32 screening table [KD][kScreenLd]
 
 enum StatusSlot { ST_ERRVOX = 0, ST_II1 = 1, ST_II2 = 2, ST_OVERFLOW = 3, ST_ITCAP = 4, ST_RERUN = 5, ST_GUARD = 6, ST_GUARDVOX = 7, ST_EXACT = 8, ST_GRAM = 11, ST_ITERS = 14, ST_SEED = 17, ST_LEFT = 92, ST_CLIP = 95, ST_WORDS = 96 };   // ST_LEFT + 0..2: voxels the Gram-space certificates of stage 1 / LASSO / stage 3 left to the wavefront-per-voxel kernels; ST_CLIP: voxels whose stage-2 signal was clipped

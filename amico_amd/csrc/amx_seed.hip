@@ -32,6 +32,10 @@ int amx_build_basis(amx_ctx *ctx, amx_lut *lut)
         hipLaunchKernelGGL(k_build_basis, dim3(lut->ndirs), dim3(256), lds, nullptr, (const float *)lut->tiles, lut->tile_stride, lut->nS,
                            lut->ldA, lut->n_wm, (const unsigned char *)lut->rowdwi, (const double *)lut->colscale, lut->basis2_U, lut->basis2_S, kSeed2Ld,
                            lut->screen2_S, lut->screen2_kappa, lut->screen2_kappa0);
+        // U2'iso: what x_iso takes out of the projected stage-2 signal (k_s2_prep, k_lasso_gcert)
+        HIPCHK(ctx, hipMalloc((void **)&lut->u2iso, (size_t)lut->ndirs * kSeedKD * sizeof(double) + 64));
+        hipLaunchKernelGGL(k_u2iso, dim3(lut->ndirs), dim3(64), 0, nullptr, (const float *)lut->tiles, lut->tile_stride, lut->nS, lut->ldA,
+                           lut->n_atoms - 1, (const double *)lut->basis2_U, lut->u2iso);
     }
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipDeviceSynchronize());
@@ -85,28 +89,69 @@ static void fill(SeedArgs &sa, const amx_lut *lut, const NoddiArgs &a, const Pla
 #endif
 }
 
-// C = [A | U]'Y of every voxel (k_noddi_gemm): block-wise table in ctx->cgemm; lasso: the stage-2 problem (y2, U2, scaled rows)
+// LDS of k_noddi_gemm for a dictionary shape and K-steps: float32 tiles of atoms only, fp64 tiles for the rest, iso table, column scales
+static size_t gemm_lds(int n_cols, int rows, int ks)
+{
+    const int mtf = n_cols / 16, mt = rows / 16;
+    return (size_t)mtf * ks * 64 * sizeof(float) + ((size_t)(mt - mtf) * ks * 64 + 4 * ks + rows) * sizeof(double);
+}
+
+// can the table kernels take this dictionary?  (K-steps of 4 samples: 25 or 40 per voxel; the scans of the seed solvers and
+// certificates hold 160 atoms; one workgroup's operands must fit a CU's LDS)
+int amx_gemm_ksteps(const amx_lut *lut)
+{
+    if (lut->n_atoms > 160 || lut->n_wm > 144) return 0;
+    const int ks = lut->nS <= 100 ? 25 : (lut->nS <= 160 ? 40 : 0);
+    if (ks == 0 || gemm_lds(lut->n_atoms, gemm_rows(lut->n_atoms), ks) > kLdsPerCU) return 0;
+    return ks;
+}
+
+// C = [A | U | U2 | 1_b0]'Y of every voxel (k_noddi_gemm): block-wise table in ctx->cgemm; lasso: the clipped voxels' stage-2
+// problem (y2, U2, scaled rows), compact, in ctx->cgemm2
 int amx_launch_noddi_gemm(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, const Plan &pl, hipStream_t s, bool lasso)
 {
     GemmArgs ga;
     memset(&ga, 0, sizeof ga);
     ga.y = a.c.y; ga.y32 = a.c.y32; ga.perm = pl.perm; ga.schunks = pl.schunks; ga.n_schunks = pl.n_chunks + 1;
     ga.tiles = (const float *)lut->tiles; ga.tile_stride = lut->tile_stride; ga.ldA = lut->ldA; ga.nS = lut->nS; ga.n_atoms = lut->n_atoms;
-    ga.Ub = lasso ? lut->basis2_U : lut->basis_U; ga.Cb = (double *)(lasso ? ctx->cgemm2.p : ctx->cgemm.p); ga.ytil = (double *)(lasso ? ctx->ytil2.p : ctx->ytil.p);
+    ga.rows = gemm_rows(lut->n_atoms); ga.aux0 = lut->n_atoms;
+    ga.Ub = lasso ? lut->basis2_U : lut->basis_U; ga.U2b = lasso ? nullptr : lut->basis2_U;
+    ga.Cb = (double *)(lasso ? ctx->cgemm2.p : ctx->cgemm.p); ga.ytil = (double *)(lasso ? ctx->ytil2.p : ctx->ytil.p);
     ga.xiso = a.xiso; ga.rowdwi = lut->rowdwi; ga.colscale = lut->colscale; ga.iso_atom = lut->n_atoms - 1; ga.is_exvivo = lut->is_exvivo; ga.n_wm = lut->n_wm;
-    const size_t lds = (size_t)9 * 25 * 64 * sizeof(float) + ((size_t)25 * 64 + 100 + 160) * sizeof(double);
+    if (lasso) { ga.clist = (const int *)ctx->clip.p; ga.ccount = (const int *)ctx->clip.p + 2 * pl.n; }
+    const int ks = amx_gemm_ksteps(lut);
+    const size_t lds = gemm_lds(lasso ? lut->n_wm : lut->n_atoms, ga.rows, ks);
     int rc;
     const dim3 grid(((pl.max_schunks + 7) / 8) * 8);
-    if (lasso) {
-        if ((rc = set_lds(ctx, k_noddi_gemm<true>, lds))) return rc;
-        hipLaunchKernelGGL(k_noddi_gemm<true>, grid, dim3(64 * pl.seed_waves), lds, s, ga);
-    } else {
-        if ((rc = set_lds(ctx, k_noddi_gemm<false>, lds))) return rc;
-        hipLaunchKernelGGL(k_noddi_gemm<false>, grid, dim3(64 * pl.seed_waves), lds, s, ga);
-    }
-    AMX_TRACE(ctx, s, "A'y of every voxel on the matrix cores");
+#define AMX_GEMM_GO(L, K)                                                                          \
+    do {                                                                                           \
+        if ((rc = set_lds(ctx, (k_noddi_gemm<L, K>), lds))) return rc;                             \
+        hipLaunchKernelGGL((k_noddi_gemm<L, K>), grid, dim3(512), lds, s, ga);                     \
+    } while (0)
+    if (ks == 25) { if (lasso) AMX_GEMM_GO(true, 25); else AMX_GEMM_GO(false, 25); }
+    else if (ks == 40) { if (lasso) AMX_GEMM_GO(true, 40); else AMX_GEMM_GO(false, 40); }
+    else return amx_bad(ctx, "k_noddi_gemm: unsupported dictionary shape");
+#undef AMX_GEMM_GO
+    AMX_TRACE(ctx, s, lasso ? "stage-2 products of the clipped voxels on the matrix cores" : "A'y of every voxel on the matrix cores");
     HIPCHK(ctx, hipGetLastError());
     return AMX_OK;
+}
+
+// after stage 1: y2~ of every voxel from the table, the clipped voxels compacted (k_s2_prep), then their exact products
+int amx_launch_noddi_s2prep(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, const Plan &pl, hipStream_t s)
+{
+    S2PrepArgs p;
+    memset(&p, 0, sizeof p);
+    p.perm = pl.perm; p.schunks = pl.schunks; p.n_schunks = pl.n_chunks + 1;
+    p.Cb = (const double *)ctx->cgemm.p; p.rows = gemm_rows(lut->n_atoms); p.aux0 = lut->n_atoms;
+    p.xiso = a.xiso; p.u2iso = lut->u2iso; p.ytil2 = (double *)ctx->ytil2.p;
+    p.clist = (int *)ctx->clip.p; p.cslot = p.clist + pl.n; p.ccount = p.clist + 2 * pl.n;
+    p.status = a.c.status; p.force_all = (!lut->s2_derive || ctx->opt_s2_exact) ? 1 : 0;
+    HIPCHK(ctx, hipMemsetAsync(p.ccount, 0, (size_t)pl.max_schunks * sizeof(int), s));
+    hipLaunchKernelGGL(k_s2_prep, dim3(((pl.max_schunks + 7) / 8) * 8), dim3(256), 0, s, p);
+    AMX_TRACE(ctx, s, "stage-2 signals from the table, clipped voxels compacted");
+    HIPCHK(ctx, hipGetLastError());
+    return amx_launch_noddi_gemm(ctx, lut, a, pl, s, true);
 }
 
 size_t amx_gcert2_leftover_offset(const Plan &pl, bool wide)
@@ -120,7 +165,8 @@ int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a
     Gcert2Args g;
     memset(&g, 0, sizeof g);
     g.perm = pl.perm; g.schunks = pl.schunks; g.n_schunks = pl.n_chunks + 1;
-    g.seeds2 = (const unsigned long long *)ctx->seeds2.p; g.Cb = (const double *)ctx->cgemm2.p;
+    g.seeds2 = (const unsigned long long *)ctx->seeds2.p; g.Cb = (const double *)ctx->cgemm.p; g.Cb2 = (const double *)ctx->cgemm2.p;
+    g.cslot = (const int *)ctx->clip.p + pl.n; g.u2iso = lut->u2iso; g.rows = gemm_rows(lut->n_atoms); g.aux0 = lut->n_atoms;
     g.gram = lut->gram_dwi; g.colscale = lut->colscale; g.ldG = lut->ldG; g.n_atoms = lut->n_atoms; g.n_wm = lut->n_wm;
     g.iso_atom = lut->n_atoms - 1; g.dot_atom = lut->is_exvivo ? lut->n_atoms - 2 : -1;
     g.Sb = lut->basis2_S; g.kappa0 = lut->screen2_kappa0; g.lam1 = a.c.lam1; g.lam2 = a.c.lam2;
@@ -131,7 +177,7 @@ int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a
 #ifdef AMX_STATS
     g.stats = a.c.status + ST_SEED + 36;
 #endif
-    const size_t lds = ((size_t)lut->n_wm * kSeedLd + 2 + ((lut->n_wm + 1) & ~1) + (size_t)9 * (kSeedKD / 4) * 64 + (size_t)4 * 64 * 16) * sizeof(double);
+    const size_t lds = ((size_t)lut->n_wm * kSeedLd + 2 + 2 * ((lut->n_wm + 1) & ~1) + (size_t)9 * (kSeedKD / 4) * 64 + (size_t)4 * 64 * 16) * sizeof(double);
     int rc;
     if ((rc = set_lds(ctx, (k_lasso_gcert<kGcert2Max, false>), lds))) return rc;
     hipLaunchKernelGGL((k_lasso_gcert<kGcert2Max, false>), dim3(((pl.max_schunks + 7) / 8) * 8), dim3(64 * pl.seed_waves), lds, s, g);
@@ -173,6 +219,7 @@ int amx_launch_noddi_gcert(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a,
     memset(&g, 0, sizeof g);
     g.perm = pl.perm; g.schunks = pl.schunks; g.n_schunks = pl.n_chunks + 1;
     g.seeds = (const unsigned long long *)ctx->seeds.p; g.Cb = (const double *)ctx->cgemm.p;
+    g.rows = gemm_rows(lut->n_atoms); g.aux0 = lut->n_atoms;
     g.gram = lut->gram; g.ldG = lut->ldG; g.n_atoms = lut->n_atoms; g.n_wm = lut->n_wm; g.nS = lut->nS;
     g.iso_atom = lut->n_atoms - 1; g.dot_atom = lut->is_exvivo ? lut->n_atoms - 2 : -1; g.n_maps = a.n_maps;
     g.Sb = lut->basis_S; g.kappa0 = lut->screen_kappa0; g.supp = a.supp; g.icvf = lut->icvf; g.kappa = lut->kappa;

@@ -238,7 +238,7 @@ __device__ __forceinline__ double seed_min(double a, double b)
 }
 
 typedef double seed_v4d __attribute__((ext_vector_type(4)));
-template <int KS, int MT>
+template <int KS, int MT, bool PIPE = true>
 __device__ __forceinline__ void seed_scan_mfma(const double *Aop, double *Rb, const double (&r)[4 * KS], int lane, double &best, int &bj)
 {
     constexpr int KDP = 4 * KS + 1;
@@ -267,11 +267,12 @@ __device__ __forceinline__ void seed_scan_mfma(const double *Aop, double *Rb, co
             for (int nt = 0; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], b[nt][ks], acc[nt], 0, 0, 0);
         }
     };
-    seed_v4d cur[4], nxt[4];
-    products(0, cur);
+    seed_v4d cur[4], nxt[PIPE ? 4 : 1];
+    if (PIPE) products(0, cur);
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
-        if (mt + 1 < MT) products(mt + 1, nxt);
+        if (PIPE) { if (mt + 1 < MT) products(mt + 1, reinterpret_cast<seed_v4d (&)[4]>(nxt)); }
+        else products(mt, cur);                       // (two wavefronts per SIMD: the other wavefront fills the matrix pipe's shadow)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int nt = 0; nt < 4; nt++) {
@@ -283,8 +284,10 @@ __device__ __forceinline__ void seed_scan_mfma(const double *Aop, double *Rb, co
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (PIPE) {
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++) cur[nt] = nxt[nt];
+            for (int nt = 0; nt < 4; nt++) cur[nt] = nxt[PIPE ? nt : 0];
+        }
     }
     double mine = ninf;
 #pragma unroll
@@ -497,7 +500,7 @@ __global__ void __launch_bounds__(256, (MS > 6 ? AMX_SEED1_OCC : AMX_SEED3_OCC))
     // for in every trip in which some lane of the wavefront refills (measured: 15 % of the kernel).
     // (stage 3 as well, at one wavefront per SIMD -- which by itself costs it nothing: 1.10 ms either way -- with the admissible-atom
     //  mask of the next voxel prefetched next to its y~)
-    constexpr bool PREF = (MS > 6) || (STAGE == 3 && AMX_SEED3_OCC == 1);
+    constexpr bool PREF = (MS > 6 && AMX_SEED1_OCC == 1) || (STAGE == 3 && AMX_SEED3_OCC == 1);
     double yv[PREF ? KD : 1], ynext[PREF ? KD : 1];
     unsigned long long nallow[(PREF && STAGE == 3) ? 4 : 1];
     int next_pos = -1;
@@ -674,7 +677,7 @@ __global__ void __launch_bounds__(256, (MS > 6 ? AMX_SEED1_OCC : AMX_SEED3_OCC))
             if (STAGE == 1) {
                 if (n_atoms <= 16 * MT) {
 #ifndef SEED_NO_MFMA
-                    seed_scan_mfma<KS, MT>(Aop, Rb, r, lane, best, bj);
+                    seed_scan_mfma<KS, MT, AMX_SEED1_OCC == 1>(Aop, Rb, r, lane, best, bj);
 #else
                     best = r[0] + r[5]; bj = (int)(r[1] * 100.0) & 127;
 #endif
@@ -807,21 +810,30 @@ __global__ void __launch_bounds__(256, (MS > 6 ? AMX_SEED1_OCC : AMX_SEED3_OCC))
 #endif
 }
 
-// ================================================================== C = [A | U]' Y on the fp64 matrix cores
-// The one genuinely GEMM-shaped piece of the NODDI fit: c_j = a_j'y for every atom and voxel, plus the 12
-// projections u_d'y and ||y||^2 -- everything the Gram-space certificates of the NNLS stages (k_nnls_gcert) and the seed
-// solvers need from the signal, so that neither has to touch y (792 bytes per voxel) again.  v_mfma_f64_16x16x4_f64; one
-// workgroup per chunk of the second plan (one orientation), a wavefront takes 16 voxels at a time:
-//   * A' operand: the orientation's dictionary once per workgroup in LDS in operand order, float32 for the atom tiles (the
-//     dictionary IS float32: exact), fp64 for the last tile (iso atom + the basis U);
+// ================================================================== C = [A | U | U2 | 1_b0]' Y on the fp64 matrix cores
+// The one genuinely GEMM-shaped piece of the NODDI fit: c_j = a_j'y for every atom and voxel, the 12 projections
+// u_d'y, ||y||^2 -- everything the Gram-space certificates of the NNLS stages (k_nnls_gcert) and the seed solvers need from the
+// signal -- AND what the LASSO stage needs of it (round 4): the stage-2 problem of models.pyx:914-926 works on
+// y2 = max(0, y_dwi - x_iso iso_dwi), which is NOT linear in y; but for every voxel in which no row clips it is affine, and the
+// b0 rows of every atom are exactly 1.0 (lut.pyx:298, 305: resample_kernel leaves them at the ones it starts from), so
+//     a_j,dwi' y2 = (c_j - sum_b0 y) - x_iso G_dwi[j, iso],   U2' y2 = U2'y - x_iso U2'iso,
+//     ||y2||^2 = (||y||^2 - sum_b0 y^2) - 2 x_iso (c_iso - sum_b0 y) + x_iso^2 G_dwi[iso, iso]
+// follow from ONE pass over y: the table gains the rows U2'y, sum_b0 y, sum_b0 y^2 and t_min = min_dwi y_i / iso_i (the voxel clips
+// iff x_iso > t_min).  k_s2_prep sorts the voxels after stage 1; only the clipped ones (0.07 % of the bench's voxels, 3 % at
+// SNR 10, 16 % of the hard mix) are multiplied again, exactly, by the LASSO instantiation of this kernel over a compact list.
+// v_mfma_f64_16x16x4_f64; one workgroup (8 wavefronts) per chunk of the second plan (one orientation), a wavefront takes 16 voxels
+// at a time:
+//   * A' operand: the orientation's dictionary once per workgroup in LDS in operand order, float32 for the tiles that hold atoms
+//     only (the dictionary IS float32: exact), fp64 for the tiles with the bases and the b0 indicator;
 //   * B operand: loaded from HBM straight in operand order (lane (q, c16): samples q, 4 + q, ... of voxel c16), one group
-//     ahead; every lane keeps its 25 operand values in registers for all 10 atom tiles;
-//   * output in blocks of 64 voxels, atom-major: Cb[block][160][64] -- a D tile stores four 128-byte row pieces.
-// Rows 146 .. 157 of a block hold the projections y~ = U'y, row 158 holds ||y||^2, whatever the number of atoms.
-constexpr int kGemmRows = 160, kGemmU = 146, kGemmYY = 158;     // rows: atoms (n_atoms <= 146) | y~ at 146 .. 157 | ||y||^2 at 158
+//     ahead; every lane keeps its KS operand values in registers for all atom tiles;
+//   * output in blocks of 64 voxels, row-major: Cb[block][rows][64] -- a D tile stores four 128-byte row pieces.
+// Rows: atoms 0 .. n_atoms - 1, then (aux0 = n_atoms) the kAux* rows below, padded to a multiple of 16.
+// (kAux*, gemm_rows: amx_kernels.hpp)
 struct GemmArgs {
     // LASSO variant (k_noddi_gemm<true>): the signal is y2 = max(0, y - x_iso iso (- x_dot)) on the stage-2 rows, 0 elsewhere
-    // (models.pyx:917-925), the basis is U2, and row j of the output is scaled by colscale[j] (column-normalised atoms)
+    // (models.pyx:917-925), the basis is U2, and row j of the output is scaled by colscale[j] (column-normalised atoms); it
+    // runs over the compact lists of k_s2_prep (clist / ccount) and writes a compact table + the exact y2~ of those voxels
     const double *xiso;           // [n_vox][2]
     const unsigned char *rowdwi;  // [nS]
     const double *colscale;       // [n_atoms]
@@ -833,64 +845,86 @@ struct GemmArgs {
     const int *n_schunks;
     const float *tiles;           // [ndirs][nS][ldA]
     int tile_stride, ldA, nS, n_atoms;
-    const double *Ub;             // [ndirs][nS][12]
-    double *Cb;                   // [n_blocks][160][64]
-    double *ytil;                 // [n][12] bucket order (copy of rows n_atoms .. n_atoms + 11), or null
+    int rows, aux0;               // rows of a table block (gemm_rows), first auxiliary row (= n_atoms)
+    const double *Ub;             // [ndirs][nS][12]: U (NNLS) / U2 (LASSO)
+    const double *U2b;            // NNLS: [ndirs][nS][12] U2 as well (rows kAuxU2), or null
+    double *Cb;                   // [n_blocks][rows][64]
+    double *ytil;                 // [n][12] bucket order (copy of rows aux0 + kAuxU ..), or null
+    const int *clist, *ccount;    // LASSO: bucket positions of the chunk's clipped voxels (compact from the chunk's start), their number
 };
 
-template <bool LASSO>
-__global__ void __launch_bounds__(256, 2) k_noddi_gemm(const GemmArgs a)
+__device__ __forceinline__ double rows_allmin(double k)
 {
-    constexpr int MT = 10, KS = 25;                // nS <= 100
-    constexpr int NB = 3;                          // atom tiles in flight together
+    double a, b;
+    AMX_ROW_SWAP(__builtin_amdgcn_permlane16_swap, k, a, b); k = fmin(a, b);
+    AMX_ROW_SWAP(__builtin_amdgcn_permlane32_swap, k, a, b); k = fmin(a, b);
+    return k;
+}
+
+template <bool LASSO, int KS>
+__global__ void __launch_bounds__(512) k_noddi_gemm(const GemmArgs a)
+{
+    constexpr int NB = KS > 25 ? 1 : 3;            // atom tiles in flight together (registers: KS operand values each)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
-    float *A32 = reinterpret_cast<float *>(smem_g);                       // [9][KS][64]
-    double *A64 = reinterpret_cast<double *>(A32 + (MT - 1) * KS * 64);   // [KS][64]: atoms 144 .. 159
-    double *IsoT = A64 + KS * 64;                                         // [4 KS] iso atom by signal row (LASSO)
-    double *ScT = IsoT + 4 * KS;                                          // [160] column scale by output row, 0 beyond n_wm (LASSO)
+    const int nS = a.nS, n_atoms = a.n_atoms, ldA = a.ldA, aux0 = a.aux0;
+    const int MT = a.rows >> 4;
+    const int n_cols = LASSO ? a.n_wm : n_atoms;
+    const int MTf = n_cols >> 4;                                          // tiles of atoms only: float32 operands
+    float *A32 = reinterpret_cast<float *>(smem_g);                       // [MTf][KS][64]
+    double *A64 = reinterpret_cast<double *>(A32 + (size_t)MTf * KS * 64);   // [MT - MTf][KS][64]
+    double *IsoT = A64 + (size_t)(MT - MTf) * KS * 64;                    // [4 KS] LASSO: iso atom by signal row; NNLS: 1 / iso on the stage-2 rows
+    double *ScT = IsoT + 4 * KS;                                          // [rows] column scale by output row, 0 beyond n_wm (LASSO)
     const int cid = xcd_chunk((int)blockIdx.x, *a.n_schunks);
     if (cid < 0) return;
     const Chunk ck = a.schunks[cid];
+    const int count = LASSO ? a.ccount[cid] : ck.count;
+    if (count == 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
     const int q = lane >> 4, c16 = lane & 15;
-    const int nS = a.nS, n_atoms = a.n_atoms, ldA = a.ldA;
     const float *tile = a.tiles + (size_t)ck.dir * a.tile_stride;
     const double *U = a.Ub + (size_t)ck.dir * nS * kSeedKD;
-    for (int e = threadIdx.x; e < (MT - 1) * KS * 64; e += blockDim.x) {
+    const double *U2 = (!LASSO && a.U2b) ? a.U2b + (size_t)ck.dir * nS * kSeedKD : nullptr;
+    for (int e = threadIdx.x; e < MTf * KS * 64; e += blockDim.x) {
         const int l = e & 63, ks = (e >> 6) % KS, mt = (e >> 6) / KS;
         const int atom = 16 * mt + (l & 15), row = 4 * ks + (l >> 4);
-        A32[e] = (row < nS && atom < (LASSO ? a.n_wm : n_atoms)) ? tile[row * ldA + atom] : 0.0f;
+        A32[e] = (row < nS) ? tile[row * ldA + atom] : 0.0f;
     }
-    for (int e = threadIdx.x; e < KS * 64; e += blockDim.x) {
-        const int l = e & 63, ks = e >> 6;
-        const int atom = 16 * (MT - 1) + (l & 15), row = 4 * ks + (l >> 4);
+    for (int e = threadIdx.x; e < (MT - MTf) * KS * 64; e += blockDim.x) {
+        const int l = e & 63, ks = (e >> 6) % KS, mt = MTf + (e >> 6) / KS;
+        const int r = 16 * mt + (l & 15), row = 4 * ks + (l >> 4);
         double v = 0.0;
         if (row < nS) {
-            if (atom < (LASSO ? a.n_wm : n_atoms)) v = (double)tile[row * ldA + atom];
-            else if (atom >= kGemmU && atom < kGemmU + kSeedKD) v = U[row * kSeedKD + (atom - kGemmU)];
+            if (r < n_cols) v = (double)tile[row * ldA + r];
+            else if (r >= aux0 + kAuxU && r < aux0 + kAuxU + kSeedKD) v = U[row * kSeedKD + (r - aux0 - kAuxU)];
+            else if (U2 != nullptr && r >= aux0 + kAuxU2 && r < aux0 + kAuxU2 + kSeedKD) v = U2[row * kSeedKD + (r - aux0 - kAuxU2)];
+            else if (!LASSO && r == aux0 + kAuxB0) v = a.rowdwi[row] ? 0.0 : 1.0;
         }
         A64[e] = v;
     }
-    if (LASSO) {
-        for (int e = threadIdx.x; e < 4 * KS; e += blockDim.x) IsoT[e] = e < nS ? (double)tile[e * ldA + a.iso_atom] : 0.0;
-        for (int e = threadIdx.x; e < kGemmRows; e += blockDim.x) ScT[e] = e < a.n_wm ? a.colscale[e] : 0.0;
+    for (int e = threadIdx.x; e < 4 * KS; e += blockDim.x) {
+        const double iso = e < nS ? (double)tile[e * ldA + a.iso_atom] : 0.0;
+        IsoT[e] = LASSO ? iso : ((e < nS && a.rowdwi[e] && iso > 0.0) ? 1.0 / iso : 0.0);
     }
+    if (LASSO) for (int e = threadIdx.x; e < a.rows; e += blockDim.x) ScT[e] = e < a.n_wm ? a.colscale[e] : 0.0;
     __syncthreads();
-    const int n_groups = (ck.count + 15) >> 4;
+    const int n_groups = (count + 15) >> 4;
     // the signals of a group of 16 voxels straight in operand order: lane (q, c16) reads samples q, 4 + q, 8 + q, ... of voxel c16
-    // (four lanes share every 32-byte sector; all 800 bytes of a row are used by the 25 loads).  The loads of group g + nw are
-    // issued before the products of group g, so they are long done when their turn comes; no LDS staging: the kernel keeps
-    // two workgroups per CU (two wavefronts per SIMD), one computes while the other waits for its stores.
-    unsigned rowmask = 0u;                 // bit ks: sample 4 ks + q is a stage-2 row (LASSO) / exists (NNLS)
+    // (four lanes share every 32-byte sector; all bytes of a row are used by the KS loads).  The loads of group g + nw are
+    // issued before the products of group g, so they are long done when their turn comes; no LDS staging.
+    unsigned long long maskE = 0ull, maskD = 0ull;      // bit ks: sample 4 ks + q exists / is a stage-2 row
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) {
         const int row = 4 * ks + q;
-        if (row < nS && (!LASSO || a.rowdwi[row] != 0)) rowmask |= 1u << ks;
+        if (row < nS) { maskE |= 1ull << ks; if (a.rowdwi[row] != 0) maskD |= 1ull << ks; }
     }
+    const unsigned long long rowmask = LASSO ? maskD : maskE;
     double bn[KS], xi_n = 0.0, xd_n = 0.0;
+    int pos_n = 0;
     auto issue = [&](int g) {
         const int k = 16 * g + c16;
-        const int vox = a.perm[ck.start + (k < ck.count ? k : ck.count - 1)];
+        const int kk = k < count ? k : count - 1;
+        pos_n = LASSO ? a.clist[ck.start + kk] : ck.start + kk;
+        const int vox = a.perm[pos_n];
         if (a.y32 != nullptr) {
             const float *yv = a.y32 + (size_t)vox * nS + q;
 #pragma unroll
@@ -904,8 +938,9 @@ __global__ void __launch_bounds__(256, 2) k_noddi_gemm(const GemmArgs a)
     };
     if (wave < n_groups) issue(wave);
     for (int g = wave; g < n_groups; g += nw) {
-        const bool live = 16 * g + c16 < ck.count;
-        double b[KS], yy = 0.0;
+        const bool live = 16 * g + c16 < count;
+        const int pos = pos_n;
+        double b[KS], yy = 0.0, yb = 0.0, tmin = __builtin_huge_val();
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
             double t = bn[ks];
@@ -913,20 +948,26 @@ __global__ void __launch_bounds__(256, 2) k_noddi_gemm(const GemmArgs a)
                 t = t - xi_n * IsoT[4 * ks + q] - xd_n;
                 t = t < 0.0 ? 0.0 : t;                                   // (NaN stays NaN: comparisons with NaN are false)
             }
-            b[ks] = (live && ((rowmask >> ks) & 1u)) ? t : 0.0;
+            b[ks] = (live && ((rowmask >> ks) & 1ull)) ? t : 0.0;
             yy += b[ks] * b[ks];
+            if (!LASSO) {
+                const bool inD = (maskD >> ks) & 1ull;
+                yb += inD ? 0.0 : b[ks] * b[ks];
+                const double r = b[ks] * IsoT[4 * ks + q];               // y_i / iso_i on the stage-2 rows
+                tmin = (inD && r < tmin) ? r : tmin;
+            }
         }
         yy = rows_allreduce(yy);
+        if (!LASSO) { yb = rows_allreduce(yb); tmin = rows_allmin(tmin); }
         if (g + nw < n_groups) issue(g + nw);
         const int blk = ck.pad + (g >> 2), col = 16 * (g & 3) + c16;
-        double *out = a.Cb + (size_t)blk * kGemmRows * 64 + col;
-#pragma unroll (LASSO ? 1 : 3)
-        for (int mt = 0; mt < MT - 1; mt += NB) {
+        double *out = a.Cb + (size_t)blk * a.rows * 64 + col;
+        for (int mt = 0; mt < MTf; mt += NB) {
             // the operands of NB atom tiles first (all their LDS reads in flight together), then the products back to back
             float af[NB][KS];
 #pragma unroll
             for (int u = 0; u < NB; u++) {
-                if (mt + u < MT - 1) {
+                if (mt + u < MTf) {
 #pragma unroll
                     for (int ks = 0; ks < KS; ks++) af[u][ks] = A32[((mt + u) * KS + ks) * 64 + lane];
                 }
@@ -939,12 +980,12 @@ __global__ void __launch_bounds__(256, 2) k_noddi_gemm(const GemmArgs a)
             for (int ks = 0; ks < KS; ks++) {
 #pragma unroll
                 for (int u = 0; u < NB; u++)
-                    if (mt + u < MT - 1) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)af[u][ks], b[ks], acc[u], 0, 0, 0);
+                    if (mt + u < MTf) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)af[u][ks], b[ks], acc[u], 0, 0, 0);
             }
             if (live) {
 #pragma unroll
                 for (int u = 0; u < NB; u++) {
-                    if (mt + u < MT - 1) {
+                    if (mt + u < MTf) {
 #pragma unroll
                         for (int rr = 0; rr < 4; rr++) {
                             const int row = 16 * (mt + u) + 4 * rr + q;
@@ -954,21 +995,95 @@ __global__ void __launch_bounds__(256, 2) k_noddi_gemm(const GemmArgs a)
                 }
             }
         }
-        {
+        for (int mt = MTf; mt < MT; mt++) {
             seed_v4d acc = (seed_v4d){0.0, 0.0, 0.0, 0.0};
+            const double *Am = A64 + (size_t)(mt - MTf) * KS * 64;
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A64[ks * 64 + lane], b[ks], acc, 0, 0, 0);
+            for (int ks = 0; ks < KS; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Am[ks * 64 + lane], b[ks], acc, 0, 0, 0);
             if (live) {
 #pragma unroll
                 for (int rr = 0; rr < 4; rr++) {
-                    const int row = 16 * (MT - 1) + 4 * rr + q;
-                    out[(size_t)row * 64] = (row == kGemmYY) ? yy : ((LASSO && row < a.n_wm) ? ScT[row] * acc[rr] : acc[rr]);
-                    // the projections once more in voxel-major order for the kernels that walk the 256-voxel chunks
-                    if (a.ytil != nullptr && row >= kGemmU && row < kGemmU + kSeedKD) a.ytil[(size_t)(ck.start + 16 * g + c16) * kSeedKD + (row - kGemmU)] = acc[rr];
+                    const int row = 16 * mt + 4 * rr + q;
+                    double v = (LASSO && row < a.n_wm) ? ScT[row] * acc[rr] : acc[rr];
+                    v = (row == aux0 + kAuxYY) ? yy : v;
+                    if (!LASSO) { v = (row == aux0 + kAuxYB) ? yb : v; v = (row == aux0 + kAuxTmin) ? tmin : v; }
+                    out[(size_t)row * 64] = v;
+                    // the projections once more in voxel-major order for the kernels that take one voxel at a time
+                    if (a.ytil != nullptr && row >= aux0 + kAuxU && row < aux0 + kAuxU + kSeedKD) a.ytil[(size_t)pos * kSeedKD + (row - aux0 - kAuxU)] = acc[rr];
                 }
             }
         }
     }
+}
+
+// ================================================================== after stage 1: which voxels' stage-2 signal clips?
+// One voxel per lane over the blocks of the table: y2~ = U2'y - x_iso U2'iso for every voxel (the LASSO seed solver's input),
+// and the voxels with x_iso > t_min -- at least one row of y - x_iso iso is negative, models.pyx:924-925 clips it -- compacted per
+// chunk for the exact pass of k_noddi_gemm<true>; cslot[pos] = place in that compact list, -1 for the (unclipped) majority.
+struct S2PrepArgs {
+    const int *perm;
+    const Chunk *schunks;
+    const int *n_schunks;
+    const double *Cb;             // table of k_noddi_gemm<false>
+    int rows, aux0;
+    const double *xiso;           // [n_vox][2]
+    const double *u2iso;          // [ndirs][12] U2'iso (amx_build_basis)
+    double *ytil2;                // [n][12] bucket order
+    int *clist, *ccount, *cslot;
+    int *status;
+    int force_all;                // every voxel takes the exact pass (dictionary whose b0 rows are not all ones; AMX_S2_EXACT=1)
+};
+
+__global__ void __launch_bounds__(256) k_s2_prep(const S2PrepArgs a)
+{
+    const int cid = xcd_chunk((int)blockIdx.x, *a.n_schunks);
+    if (cid < 0) return;
+    const Chunk ck = a.schunks[cid];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
+    const double *__restrict__ u2 = a.u2iso + (size_t)ck.dir * kSeedKD;
+    const int n_blocks = (ck.count + 63) >> 6;
+    int nclip = 0;
+    for (int bl = wave; bl < n_blocks; bl += nw) {
+        const int k = 64 * bl + lane;
+        const bool valid = k < ck.count;
+        const int pos = ck.start + (valid ? k : ck.count - 1);
+        const double *Crow = a.Cb + (size_t)(ck.pad + bl) * a.rows * 64 + lane;
+        const double xi = a.xiso[(size_t)a.perm[pos] * 2];
+        const double tmin = Crow[(size_t)(a.aux0 + kAuxTmin) * 64];
+        const bool clipped = valid && (a.force_all != 0 || !(xi <= tmin));       // (NaN: the exact pass carries it on)
+        double yt[kSeedKD];
+#pragma unroll
+        for (int d = 0; d < kSeedKD; d++) yt[d] = Crow[(size_t)(a.aux0 + kAuxU2 + d) * 64] - xi * u2[d];
+        if (valid) {
+            double2 *dst = reinterpret_cast<double2 *>(a.ytil2 + (size_t)pos * kSeedKD);
+#pragma unroll
+            for (int d = 0; d < kSeedKD; d += 2) dst[d >> 1] = make_double2(yt[d], yt[d + 1]);
+        }
+        const unsigned long long cm = __ballot(clipped);
+        int slot = -1;
+        if (cm != 0ull) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&a.ccount[cid], __builtin_popcountll(cm));
+            base = __builtin_amdgcn_readfirstlane(base);
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
+            if (clipped) { slot = base + rank; a.clist[ck.start + slot] = pos; }
+            nclip += __builtin_popcountll(cm);
+        }
+        if (valid) a.cslot[pos] = slot;
+    }
+    if (lane == 0 && nclip > 0) atomicAdd(&a.status[ST_CLIP], nclip);
+}
+
+// U2'iso of every orientation (once per dictionary upload): what x_iso takes out of the projected stage-2 signal
+__global__ void k_u2iso(const float *__restrict__ tiles, int tile_stride, int nS, int ldA, int iso_atom, const double *__restrict__ U2b, double *__restrict__ out)
+{
+    const int d = threadIdx.x;
+    if (d >= kSeedKD) return;
+    const float *tile = tiles + (size_t)blockIdx.x * tile_stride;
+    const double *U2 = U2b + (size_t)blockIdx.x * nS * kSeedKD;
+    double s = 0.0;
+    for (int i = 0; i < nS; i++) s += U2[i * kSeedKD + d] * (double)tile[i * ldA + iso_atom];      // (rows of U2 outside the stage-2 rows are zero)
+    out[(size_t)blockIdx.x * kSeedKD + d] = s;
 }
 
 // Which atoms of which voxel have a compressed dual value above the voxel's threshold?  One fp64 MFMA product for the 64 voxels
@@ -1067,7 +1182,8 @@ struct GcertArgs {
     const Chunk *schunks;
     const int *n_schunks;
     const unsigned long long *seeds;   // [n], bucket order
-    const double *Cb;                  // [n_blocks][160][64]
+    const double *Cb;                  // [n_blocks][rows][64]
+    int rows, aux0;                    // table layout (gemm_rows)
     const double *gram;                // [ndirs][n_atoms][ldG]
     int ldG, n_atoms, n_wm, nS, iso_atom, dot_atom, n_maps;
     const double *Sb;                  // [ndirs][n_atoms][12]
@@ -1119,7 +1235,7 @@ __global__ void __launch_bounds__(256, 2) k_nnls_gcert(const GcertArgs a)
         const int k = 64 * bl + lane;
         const bool valid = k < ck.count;
         const int pos = ck.start + (valid ? k : ck.count - 1);
-        const double *Crow = a.Cb + (size_t)(ck.pad + bl) * kGemmRows * 64 + lane;
+        const double *Crow = a.Cb + (size_t)(ck.pad + bl) * a.rows * 64 + lane;
         const unsigned long long seed = a.seeds[pos];
         const int vox = a.perm[pos];
         SeedLane<MS> V;
@@ -1174,7 +1290,7 @@ __global__ void __launch_bounds__(256, 2) k_nnls_gcert(const GcertArgs a)
             for (int t = 0; t <= s; t++) V.T[stri<MS>(s, t)] = (s < V.np) ? Gd[(size_t)V.idx[s] * a.ldG + V.idx[t]] : 0.0;
             V.c[s] = (s < V.np) ? Crow[(size_t)V.idx[s] * 64] : 0.0;
         }
-        const double yy = Crow[(size_t)kGemmYY * 64];
+        const double yy = Crow[(size_t)(a.aux0 + kAuxYY) * 64];
         double pmax = 0.0, pmin = __builtin_huge_val();
         bool piv = V.factor();
 #pragma unroll
@@ -1199,7 +1315,7 @@ __global__ void __launch_bounds__(256, 2) k_nnls_gcert(const GcertArgs a)
         {
             double rt[KD];
 #pragma unroll
-            for (int d = 0; d < KD; d++) rt[d] = Crow[(size_t)(kGemmU + d) * 64];
+            for (int d = 0; d < KD; d++) rt[d] = Crow[(size_t)(a.aux0 + kAuxU + d) * 64];
 #pragma unroll
             for (int s = 0; s < MS; s++) {
                 const double *col = Sl + V.idx[s] * LD;
@@ -1354,7 +1470,11 @@ struct Gcert2Args {
     const Chunk *schunks;
     const int *n_schunks;
     const unsigned long long *seeds2;  // [n][4], bucket order
-    const double *Cb;                  // [n_blocks][160][64] of k_noddi_gemm<true>
+    const double *Cb;                  // [n_blocks][rows][64] of k_noddi_gemm<false>: c2, y2~, ||y2||^2 of the unclipped voxels derive from it
+    const double *Cb2;                 // compact table of k_noddi_gemm<true>: the clipped voxels, exactly
+    const int *cslot;                  // [n] bucket order: place in the chunk's compact list, -1 = not clipped
+    const double *u2iso;               // [ndirs][12] U2'iso
+    int rows, aux0;
     const double *gram;                // [ndirs][n_atoms][ldG] stage-2 rows
     const double *colscale;            // [n_atoms]
     int ldG, n_atoms, n_wm, iso_atom, dot_atom;
@@ -1384,7 +1504,8 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
     double *Sl = reinterpret_cast<double *>(smem_c2);             // [n_wm][LD]
     const int n_wm = a.n_wm;
     double *scl = Sl + (size_t)n_wm * LD + 2;                      // [n_wm]
-    double *Aop = scl + ((n_wm + 1) & ~1);                         // [MT][KS][64]
+    double *giso = scl + ((n_wm + 1) & ~1);                        // [n_wm] G_dwi[j][iso]: what x_iso takes out of a_j,dwi'y
+    double *Aop = giso + ((n_wm + 1) & ~1);                        // [MT][KS][64]
     double *Rb = Aop + MT * KS * 64 + (threadIdx.x >> 6) * (64 * RBW);
     const int cid = xcd_chunk((int)blockIdx.x, *a.n_schunks);
     if (cid < 0) return;
@@ -1395,7 +1516,7 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
     const double *__restrict__ Sg = a.Sb + (size_t)ck.dir * n_wm * KD;
     const double *__restrict__ Gd = a.gram + (size_t)ck.dir * a.n_atoms * a.ldG;
     for (int e = threadIdx.x; e < n_wm * KD; e += blockDim.x) { const int j = e / KD, d = e - j * KD; Sl[j * LD + d] = Sg[e]; }
-    for (int e = threadIdx.x; e < n_wm; e += blockDim.x) scl[e] = a.colscale[e];
+    for (int e = threadIdx.x; e < n_wm; e += blockDim.x) { scl[e] = a.colscale[e]; giso[e] = Gd[(size_t)e * a.ldG + a.iso_atom]; }
     for (int e = threadIdx.x; e < MT * KS * 64; e += blockDim.x) {
         const int l = e & 63, ks = (e >> 6) % KS, mt = (e >> 6) / KS;
         const int atom = 16 * mt + (l & 15), d = 4 * ks + (l >> 4);
@@ -1403,6 +1524,8 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
     }
     __syncthreads();
     const double kap = a.kappa0[ck.dir], lam1 = a.lam1, lam2 = a.lam2;
+    const double gii = Gd[(size_t)a.iso_atom * a.ldG + a.iso_atom];      // ||iso_dwi||^2
+    const double *__restrict__ u2 = a.u2iso + (size_t)ck.dir * kSeedKD;
 #ifdef AMX_STATS
     long long gph[5] = {0, 0, 0, 0, 0}, gpt = (long long)__builtin_readcyclecounter();
 #endif
@@ -1411,12 +1534,20 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
         const int k = 64 * bl + lane;
         const bool valid = k < n_items;
         const int pos = WIDE ? a.rlist_in[ck.start + (valid ? k : n_items - 1)] : ck.start + (valid ? k : n_items - 1);
-        const int kk = pos - ck.start;                    // the voxel's place in the chunk: GEMM block and column
-        const double *Crow = a.Cb + (size_t)(ck.pad + (kk >> 6)) * kGemmRows * 64 + (kk & 63);
+        // The voxel's column: in the table of stage 1 (place in the chunk) -- then c2_j = s_j (c_j - sum_b0 y - x_iso G_dwi[j, iso]) etc.
+        // (see k_noddi_gemm) -- or, clipped, in the compact table of the exact pass, whose rows ARE c2, y2~, ||y2||^2.  One pointer
+        // per lane, one formula: value = mul_j (load - sub - xq G_dwi[j, iso]) with sub = xq = 0, mul = 1 for the clipped voxels.
+        const int cs = a.cslot[pos];
+        const bool clip = cs >= 0;
+        const int kk = clip ? cs : pos - ck.start;
+        const double *Crow = (clip ? a.Cb2 : a.Cb) + (size_t)(ck.pad + (kk >> 6)) * a.rows * 64 + (kk & 63);
+        const int vox = a.perm[pos];
+        const double xi = a.xiso[(size_t)vox * 2];
+        const double xq = clip ? 0.0 : xi;
+        const double sub = clip ? 0.0 : Crow[(size_t)(a.aux0 + kAuxB0) * 64];
         const unsigned long long *sd = a.seeds2 + (size_t)pos * 4;
         unsigned long long P[3] = {sd[0], sd[1], sd[2]};
         const unsigned long long flag = sd[3];
-        const int vox = a.perm[pos];
         const int cnt = __builtin_popcountll(P[0]) + __builtin_popcountll(P[1]) + __builtin_popcountll(P[2]);
         bool okv = valid && flag == 0ull && cnt <= MS && (!WIDE || cnt > LOW);
         SeedLane<MS> V;
@@ -1458,9 +1589,15 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
 #pragma unroll
             for (int t = 0; t <= s; t++)
                 V.T[stri<MS>(s, t)] = (s < V.np) ? sc[s] * sc[t] * Gd[(size_t)V.idx[s] * a.ldG + V.idx[t]] + ((s == t) ? lam2 : 0.0) : 0.0;
-            V.c[s] = (s < V.np) ? Crow[(size_t)V.idx[s] * 64] - lam1 : 0.0;
+            V.c[s] = (s < V.np) ? (clip ? 1.0 : sc[s]) * (Crow[(size_t)V.idx[s] * 64] - sub - xq * giso[V.idx[s]]) - lam1 : 0.0;
         }
-        const double yy = Crow[(size_t)kGemmYY * 64];
+        double yy = Crow[(size_t)(a.aux0 + kAuxYY) * 64];
+        if (!clip) {
+            // ||y2||^2 = (||y||^2 - sum_b0 y^2) - 2 x_iso (c_iso - sum_b0 y) + x_iso^2 ||iso_dwi||^2
+            const double ciso = Crow[(size_t)a.iso_atom * 64], yb = Crow[(size_t)(a.aux0 + kAuxYB) * 64];
+            yy = (yy - yb) - 2.0 * xi * (ciso - sub) + xi * xi * gii;
+            yy = yy > 0.0 ? yy : (yy <= 0.0 ? 0.0 : yy);                 // (rounding below zero; NaN stays NaN)
+        }
         const bool piv = V.factor();
         double z[MS];
         V.solve(z);
@@ -1478,8 +1615,9 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
         unsigned long long ex[3] = {0ull, 0ull, 0ull};
         {
             double rt[KD];
+            const double *Cu = Crow + (size_t)(a.aux0 + (clip ? kAuxU : kAuxU2)) * 64;
 #pragma unroll
-            for (int d = 0; d < KD; d++) rt[d] = Crow[(size_t)(kGemmU + d) * 64];
+            for (int d = 0; d < KD; d++) rt[d] = Cu[(size_t)d * 64] - xq * u2[d];
 #pragma unroll
             for (int s = 0; s < MS; s++) {
                 const double *col = Sl + V.idx[s] * LD;
@@ -1508,9 +1646,9 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
 #pragma unroll
                 for (int qq = 0; qq < 3; qq++) rem[qq] = (wq == qq) ? (rem[qq] & (rem[qq] - 1ull)) : rem[qq];
                 const bool on = wq >= 0 && t < n_wm;
-                double g = on ? Crow[(size_t)t * 64] - lam1 : -1.0;
-                const double *gt = Gd + (size_t)t * a.ldG;
                 const double st = on ? scl[t] : 0.0;
+                double g = on ? (clip ? 1.0 : st) * (Crow[(size_t)t * 64] - sub - xq * giso[t]) - lam1 : -1.0;
+                const double *gt = Gd + (size_t)t * a.ldG;
 #pragma unroll
                 for (int s = 0; s < MS; s++) { if (s < V.np && on) g -= st * sc[s] * gt[V.idx[s]] * V.x[s]; }
                 if (on && !(g < -1e-10)) viol = true;
@@ -1548,7 +1686,7 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
                 for (int j = 0; j < a.n_atoms; j++) dst[j] = 0.0;
 #pragma unroll
                 for (int s = 0; s < MS; s++) if (s < V.np) dst[V.idx[s]] = V.x[s];
-                dst[a.iso_atom] = a.xiso[(size_t)vox * 2];
+                dst[a.iso_atom] = xi;
                 if (a.dot_atom >= 0) dst[a.dot_atom] = a.xiso[(size_t)vox * 2 + 1];
             }
         }
@@ -1695,15 +1833,17 @@ __global__ void __launch_bounds__(256, AMX_SEED2_OCC) k_lasso_seed(const Seed2Ar
 #endif
     // (one wavefront per SIMD: y~ of the voxel in registers, the next voxel reserved -- and its y~ loading -- one solve ahead, as in
     //  k_nnls_seed<1>)
-    double yv[KD], ynext[KD];
+    constexpr bool PREF2 = AMX_SEED2_OCC == 1;
+    double yv[KD], ynext[PREF2 ? KD : 1];
     int next_pos = -1;
     bool have_next = false;
     for (int guard = 0; guard < (1 << 20); ++guard) {
+        if (PREF2) {
         if (!active && have_next) {
             pos = next_pos; have_next = false;
             bool finite = true;
 #pragma unroll
-            for (int d = 0; d < KD; d++) { yv[d] = ynext[d]; finite = finite && (fabs(yv[d]) <= 1.79769313486231570e308); }
+            for (int d = 0; d < KD; d++) { yv[d] = ynext[PREF2 ? d : 0]; finite = finite && (fabs(yv[d]) <= 1.79769313486231570e308); }
             trips = 0;
             P[0] = 0ull; P[1] = 0ull; P[2] = 0ull;
 #pragma unroll
@@ -1729,13 +1869,48 @@ __global__ void __launch_bounds__(256, AMX_SEED2_OCC) k_lasso_seed(const Seed2Ar
                     next_pos = ck.start + k; have_next = true;
                     const double *yp = a.ytil + (size_t)next_pos * SLD;
 #pragma unroll
-                    for (int d = 0; d < KD; d++) ynext[d] = yp[d];
+                    for (int d = 0; d < KD; d++) ynext[PREF2 ? d : 0] = yp[d];
                 }
             }
         }
         if (__ballot(active) == 0ull) {
             if (!more && __ballot(have_next) == 0ull) break;
             continue;
+        }
+        } else {
+            // two wavefronts per SIMD: no voxel reserved ahead (its 8 values would cost 16 registers for a whole solve) -- the
+            // other wavefront of the SIMD covers the load
+            const unsigned long long freem = __ballot(!active);
+            if (freem != 0ull && more) {
+                const int nfree = __builtin_popcountll(freem);
+                unsigned base = 0u;
+                if (lane == 0) base = atomicAdd(ticket, (unsigned)nfree);
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                if ((int)base + nfree >= ck.count) more = false;
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(freem >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)freem, 0u));
+                const int k = (int)base + rank;
+                if (!active && k < ck.count) {
+                    pos = ck.start + k;
+                    const double *yp = a.ytil + (size_t)pos * SLD;
+                    bool finite = true;
+#pragma unroll
+                    for (int d = 0; d < KD; d++) { yv[d] = yp[d]; finite = finite && (fabs(yv[d]) <= 1.79769313486231570e308); }
+                    trips = 0;
+                    P[0] = 0ull; P[1] = 0ull; P[2] = 0ull;
+#pragma unroll
+                    for (int i = 0; i < KD; i++) {                 // M = lambda2 I
+#pragma unroll
+                        for (int j = 0; j <= i; j++) T[stri<KD>(i, j)] = (i == j) ? sl2 : 0.0;
+                        dinv[i] = isl2; g[i] = 0.0;
+                    }
+                    if (finite) active = true;
+                    else { a.seeds[(size_t)pos * 4 + 3] = ~0ull; }
+                }
+            }
+            if (__ballot(active) == 0ull) {
+                if (!more) break;
+                continue;
+            }
         }
 #ifdef AMX_STATS
         st_trips++; st_used += __builtin_popcountll(__ballot(active));
@@ -1798,11 +1973,12 @@ __global__ void __launch_bounds__(256, AMX_SEED2_OCC) k_lasso_seed(const Seed2Ar
                     for (int nt = 0; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], b[nt][ks], acc[nt], 0, 0, 0);
                 }
             };
-            seed_v4d cur[4], nxt[4];
-            products(0, cur);
+            seed_v4d cur[4], nxt[PREF2 ? 4 : 1];
+            if (PREF2) products(0, cur);
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
-                if (mt + 1 < MT) products(mt + 1, nxt);
+                if (PREF2) { if (mt + 1 < MT) products(mt + 1, reinterpret_cast<seed_v4d (&)[4]>(nxt)); }
+                else products(mt, cur);
                 // passive bits of the voxels 16 nt + c16 for this tile's atoms (row-shifted), read back per tile instead of
                 // living in 24 registers for the whole scan
                 unsigned long long pw[4];
@@ -1826,8 +2002,10 @@ __global__ void __launch_bounds__(256, AMX_SEED2_OCC) k_lasso_seed(const Seed2Ar
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if (PREF2) {
 #pragma unroll
-                for (int nt = 0; nt < 4; nt++) cur[nt] = nxt[nt];
+                    for (int nt = 0; nt < 4; nt++) cur[nt] = nxt[PREF2 ? nt : 0];
+                }
             }
             double mine = ninf;
 #pragma unroll
