@@ -45,6 +45,7 @@ int make_plan(amx_ctx *ctx, int64_t n, int ndirs, Plan &pl, bool seeds = false, 
         // (measured, ndirs = 500: 100 000 / 200 000 / 400 000 / 1 M voxels -> stage-1 group 1.11 / 1.55 / 2.31 / 4.66 ms with two
         //  wavefronts per workgroup against 1.33 / 1.80 / 2.39 / 4.14 ms with four; every other lane kernel is best with four)
         pl.seed1_waves = ctx->opt_seed_waves ? ctx->opt_seed_waves : ((double)n / (double)pl.max_schunks < 640.0 ? 2 : 4);
+        pl.seed_occ2 = (ctx->in_host_fit ? ctx->host_total_vox : n) >= ctx->opt_seed_occ2_from;
         if ((rc = ensure(ctx, ctx->schunks, (size_t)pl.max_schunks * sizeof(Chunk)))) return rc;
         if ((rc = ensure(ctx, ctx->ytil, (size_t)n * amx::kSeedKD * sizeof(double)))) return rc;
         if ((rc = ensure(ctx, ctx->seeds, (size_t)n * sizeof(unsigned long long)))) return rc;
@@ -221,6 +222,8 @@ int amx_ctx_create(int device, amx_ctx **out)
         if (e && *e) { const int v = atoi(e); ctx->opt_seed_waves = (v == 1 || v == 2 || v == 4) ? v : 0; }
         e = getenv("AMX_SEED_MIN_VOXELS");
         if (e && *e) ctx->opt_seed_min_voxels = atoll(e);
+        e = getenv("AMX_SEED_OCC2_FROM");
+        if (e && *e) ctx->opt_seed_occ2_from = atoll(e);
         ctx->opt_no_chunk_order = on("AMX_NO_CHUNK_ORDER");
         e = getenv("AMX_NO_GCERT_WIDE");
         ctx->opt_no_gcert_wide = e && *e && *e != '0';

@@ -78,6 +78,7 @@ struct amx_ctx {
     bool opt_s2_exact = false;     // AMX_S2_EXACT=1: every voxel's stage-2 products by the exact pass (k_noddi_gemm<true>), none derived from the stage-1 table
     bool opt_no_seed = false;      // AMX_NO_SEED=1: Lawson-Hanson from the empty set in the NNLS stages (the round-2 path)
     long long opt_seed_min_voxels = 40960; // AMX_SEED_MIN_VOXELS: smaller calls run the wavefront-per-voxel kernels on all voxels (the seeded chain of ~16 kernels has a floor of ~2 ms; measured crossover between 30 000 and 50 000 voxels: 14.6 vs 16.2 and 23.0 vs 19.4 M voxels/s)
+    long long opt_seed_occ2_from = 400000; // AMX_SEED_OCC2_FROM: calls of at least this many voxels run the two seed solvers at two wavefronts per SIMD (a third more time per trip, twice the wavefronts: wins when the kernel is throughput bound -- 1 M voxels 2.80 -> 2.14 and 1.67 -> 1.28 ms --, loses when the longest voxel's path bounds it: 200 000 voxels 0.93 -> 1.08 ms)
     int opt_seed_waves = 0;        // AMX_SEED_WAVES: wavefronts per workgroup of the lane kernels (0 = by the number of chunks, make_plan)
     int opt_seed_stages = 7;       // AMX_SEED_STAGES: bit 0 = seed stage 1, bit 1 = seed stage 3, bit 2 = seed the LASSO stage
     int opt_seed_chunk = 0;        // AMX_SEED_CHUNK (0 = by the call's size, make_plan): voxels of one orientation per workgroup of the seed solvers (lanes refill from the chunk: the more voxels per lane, the smaller the share of the tail; 1 M voxels: 1024 -> 7.2 ms, 2048 -> 7.3, 4096 -> 5.5 for stage 1)
@@ -182,6 +183,7 @@ struct Plan {
     int max_schunks = 0;
     int seed_chunk = 4096;         // voxels of one orientation per workgroup of the lane kernels (second plan)
     int seed1_waves = 4;           // the same for k_nnls_seed<1> (one wavefront per SIMD: with few voxels per chunk two wavefronts per workgroup keep more lanes busy)
+    bool seed_occ2 = false;        // k_nnls_seed<1> / k_lasso_seed in their two-wavefronts-per-SIMD builds (large calls)
     int seed_waves = 4;            // wavefronts per workgroup of the lane-per-voxel NODDI kernels (one workgroup per chunk of the second plan)
 };
 

@@ -6,8 +6,14 @@ using namespace amx;
 // basis of the dominant column space of every orientation tile (once per dictionary upload)
 int amx_build_basis(amx_ctx *ctx, amx_lut *lut)
 {
-    const size_t lds = ((size_t)lut->nS * lut->ldA + (size_t)kSeedKD * lut->nS + 256) * sizeof(double);
-    if (lds > kLdsPerCU || lut->n_atoms > 160 || lut->n_wm > 144) return AMX_OK;          // no seeds for this shape
+    if (lut->n_atoms > 160 || lut->n_wm > 144) return AMX_OK;          // no seeds for this shape (the scans hold 160 atoms)
+    // deflated columns in LDS when they fit next to Q, else in a global scratch block per workgroup (<= 4096 orientations per launch)
+    const size_t lds_full = ((size_t)lut->nS * lut->ldA + (size_t)kSeedKD * lut->nS + 256) * sizeof(double);
+    const bool in_lds = lds_full <= kLdsPerCU;
+    const size_t lds = in_lds ? lds_full : ((size_t)kSeedKD * lut->nS + 256) * sizeof(double);
+    const int batch = in_lds ? lut->ndirs : (lut->ndirs < 4096 ? lut->ndirs : 4096);
+    double *Rg = nullptr;
+    if (!in_lds) HIPCHK(ctx, hipMalloc((void **)&Rg, (size_t)batch * lut->nS * lut->ldA * sizeof(double) + 64));
     const size_t ub = (size_t)lut->ndirs * lut->nS * kSeedKD * sizeof(double);
     const size_t sb = (size_t)lut->ndirs * lut->n_atoms * kSeedKD * sizeof(double);
     HIPCHK(ctx, hipMalloc((void **)&lut->basis_U, ub + 64));
@@ -18,9 +24,12 @@ int amx_build_basis(amx_ctx *ctx, amx_lut *lut)
     HIPCHK(ctx, hipMalloc((void **)&lut->screen_kappa0, (size_t)lut->ndirs * sizeof(double) + 64));
     int rc;
     if ((rc = set_lds(ctx, k_build_basis, lds))) return rc;
-    hipLaunchKernelGGL(k_build_basis, dim3(lut->ndirs), dim3(256), lds, nullptr, (const float *)lut->tiles, lut->tile_stride, lut->nS,
-                       lut->ldA, lut->n_atoms, (const unsigned char *)nullptr, (const double *)nullptr, lut->basis_U, lut->basis_S, kSeedKD,
-                       lut->screen_S, lut->screen_kappa, lut->screen_kappa0);
+    for (int d0 = 0; d0 < lut->ndirs; d0 += batch) {
+        const int nb = lut->ndirs - d0 < batch ? lut->ndirs - d0 : batch;
+        hipLaunchKernelGGL(k_build_basis, dim3(nb), dim3(256), lds, nullptr, (const float *)lut->tiles, lut->tile_stride, lut->nS,
+                           lut->ldA, lut->n_atoms, (const unsigned char *)nullptr, (const double *)nullptr, lut->basis_U, lut->basis_S, kSeedKD,
+                           lut->screen_S, lut->screen_kappa, lut->screen_kappa0, Rg, d0);
+    }
     // the LASSO stage's dictionary: DWI rows, column-normalised wm atoms (models.pyx:917-921), rank 8
     if (lut->gram_dwi) {
         HIPCHK(ctx, hipMalloc((void **)&lut->basis2_U, (size_t)lut->ndirs * lut->nS * kSeed2Ld * sizeof(double) + 64));
@@ -29,9 +38,12 @@ int amx_build_basis(amx_ctx *ctx, amx_lut *lut)
         HIPCHK(ctx, hipMemset(lut->screen2_S, 0, (size_t)lut->ndirs * kSeedKD * kScreenLd * sizeof(float)));
         HIPCHK(ctx, hipMalloc((void **)&lut->screen2_kappa, (size_t)lut->ndirs * sizeof(double) + 64));
         HIPCHK(ctx, hipMalloc((void **)&lut->screen2_kappa0, (size_t)lut->ndirs * sizeof(double) + 64));
-        hipLaunchKernelGGL(k_build_basis, dim3(lut->ndirs), dim3(256), lds, nullptr, (const float *)lut->tiles, lut->tile_stride, lut->nS,
-                           lut->ldA, lut->n_wm, (const unsigned char *)lut->rowdwi, (const double *)lut->colscale, lut->basis2_U, lut->basis2_S, kSeed2Ld,
-                           lut->screen2_S, lut->screen2_kappa, lut->screen2_kappa0);
+        for (int d0 = 0; d0 < lut->ndirs; d0 += batch) {
+            const int nb = lut->ndirs - d0 < batch ? lut->ndirs - d0 : batch;
+            hipLaunchKernelGGL(k_build_basis, dim3(nb), dim3(256), lds, nullptr, (const float *)lut->tiles, lut->tile_stride, lut->nS,
+                               lut->ldA, lut->n_wm, (const unsigned char *)lut->rowdwi, (const double *)lut->colscale, lut->basis2_U, lut->basis2_S, kSeed2Ld,
+                               lut->screen2_S, lut->screen2_kappa, lut->screen2_kappa0, Rg, d0);
+        }
         // U2'iso: what x_iso takes out of the projected stage-2 signal (k_s2_prep, k_lasso_gcert)
         HIPCHK(ctx, hipMalloc((void **)&lut->u2iso, (size_t)lut->ndirs * kSeedKD * sizeof(double) + 64));
         hipLaunchKernelGGL(k_u2iso, dim3(lut->ndirs), dim3(64), 0, nullptr, (const float *)lut->tiles, lut->tile_stride, lut->nS, lut->ldA,
@@ -39,6 +51,7 @@ int amx_build_basis(amx_ctx *ctx, amx_lut *lut)
     }
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipDeviceSynchronize());
+    if (Rg) HIPCHK(ctx, hipFree(Rg));
     return AMX_OK;
 }
 
@@ -68,8 +81,13 @@ int amx_launch_noddi_seed2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a,
     }
     const size_t lds = ((size_t)lut->n_wm * (kSeed2KD + 1) + 8 + (size_t)9 * (kSeed2KD / 4) * 64 + (size_t)4 * (64 * (kSeed2KD + 1) + 64 * 3)) * sizeof(double);
     int rc;
-    if ((rc = set_lds(ctx, k_lasso_seed, lds))) return rc;
-    hipLaunchKernelGGL(k_lasso_seed, dim3(((pl.max_schunks + 7) / 8) * 8), dim3(64 * pl.seed1_waves), lds, s, sa);
+    if (pl.seed_occ2) {
+        if ((rc = set_lds(ctx, k_lasso_seed<true>, lds))) return rc;
+        hipLaunchKernelGGL(k_lasso_seed<true>, dim3(((pl.max_schunks + 7) / 8) * 8), dim3(64 * pl.seed1_waves), lds, s, sa);
+    } else {
+        if ((rc = set_lds(ctx, k_lasso_seed<false>, lds))) return rc;
+        hipLaunchKernelGGL(k_lasso_seed<false>, dim3(((pl.max_schunks + 7) / 8) * 8), dim3(64 * pl.seed1_waves), lds, s, sa);
+    }
     AMX_TRACE(ctx, s, "LASSO seed solver");
     HIPCHK(ctx, hipGetLastError());
     return AMX_OK;
@@ -265,7 +283,10 @@ int amx_launch_noddi_seed(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, 
                        (stage == 1 ? ((size_t)10 * (kSeedKD / 4) * 64 + (size_t)4 * 64 * (kSeedKD + 1)) * sizeof(double) : 0);
     const dim3 grid(((pl.max_schunks + 7) / 8) * 8);
     int rc;
-    if (stage == 1) {
+    if (stage == 1 && pl.seed_occ2) {
+        if ((rc = set_lds(ctx, (k_nnls_seed<1, 8, true>), lds))) return rc;
+        hipLaunchKernelGGL((k_nnls_seed<1, 8, true>), grid, dim3(64 * pl.seed1_waves), lds, s, sa);
+    } else if (stage == 1) {
         if ((rc = set_lds(ctx, (k_nnls_seed<1, 8>), lds))) return rc;
         hipLaunchKernelGGL((k_nnls_seed<1, 8>), grid, dim3(64 * pl.seed1_waves), lds, s, sa);
     } else {

@@ -48,16 +48,19 @@ __global__ void __launch_bounds__(256) k_build_basis(const float *__restrict__ t
                                                      const unsigned char *__restrict__ rowsel, const double *__restrict__ colscale,
                                                      double *__restrict__ Ub, double *__restrict__ Sb, int KD,
                                                      float *__restrict__ Sf = nullptr, double *__restrict__ kap = nullptr,
-                                                     double *__restrict__ kap0 = nullptr)
+                                                     double *__restrict__ kap0 = nullptr, double *__restrict__ Rg = nullptr, int dir0 = 0)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    double *R = reinterpret_cast<double *>(smem_b);            // [nS][ldA] deflated columns
-    double *Q = R + (size_t)nS * ldA;                          // [KD][nS]
+    // deflated columns [nS][ldA]: in LDS when they fit next to Q (protocols of up to ~128 volumes), else in a global scratch block of
+    // this workgroup (one-off per dictionary upload: the L2 serves it)
+    double *R = Rg != nullptr ? Rg + (size_t)blockIdx.x * nS * ldA : reinterpret_cast<double *>(smem_b);
+    double *Q = Rg != nullptr ? reinterpret_cast<double *>(smem_b) : R + (size_t)nS * ldA;                          // [KD][nS]
     double *red = Q + (size_t)KD * nS;                         // [256]
+    const int dir = (int)blockIdx.x + dir0;
     __shared__ int s_j;
     __shared__ double s_n, s_coef[kSeedKD];
     const int tid = threadIdx.x, nt = blockDim.x;
-    const float *g = tiles + (size_t)blockIdx.x * tile_stride;
+    const float *g = tiles + (size_t)dir * tile_stride;
     for (int e = tid; e < nS * ldA; e += nt) {
         const int i = e / ldA, j = e - i * ldA;
         double v = (j < n_cols && (rowsel == nullptr || rowsel[i])) ? (double)g[e] : 0.0;
@@ -120,13 +123,13 @@ __global__ void __launch_bounds__(256) k_build_basis(const float *__restrict__ t
         __syncthreads();
         red[tid] = an;
         __syncthreads();
-        if (tid == 0) { double m = 0.0; for (int j = 0; j < n_cols && j < nt; j++) m = red[j] > m ? red[j] : m; kap[blockIdx.x] = emax + 2e-6 * sqrt(m); if (kap0) kap0[blockIdx.x] = emax; }
+        if (tid == 0) { double m = 0.0; for (int j = 0; j < n_cols && j < nt; j++) m = red[j] > m ? red[j] : m; kap[dir] = emax + 2e-6 * sqrt(m); if (kap0) kap0[dir] = emax; }
         __syncthreads();
     }
-    double *U = Ub + (size_t)blockIdx.x * nS * KD;
+    double *U = Ub + (size_t)dir * nS * KD;
     for (int e = tid; e < nS * KD; e += nt) { const int i = e / KD, d = e - i * KD; U[e] = Q[d * nS + i]; }
     // S = U'A from the ORIGINAL (scaled, row-selected) columns
-    double *S = Sb + (size_t)blockIdx.x * n_cols * KD;
+    double *S = Sb + (size_t)dir * n_cols * KD;
     for (int e = tid; e < n_cols * KD; e += nt) {
         const int j = e / KD, d = e - j * KD;
         double c = 0.0;
@@ -136,7 +139,7 @@ __global__ void __launch_bounds__(256) k_build_basis(const float *__restrict__ t
         }
         if (colscale != nullptr) c *= colscale[j];
         S[e] = c;
-        if (Sf != nullptr) Sf[(size_t)blockIdx.x * KD * kScreenLd + d * kScreenLd + j] = (float)c;      // [d][atom], zero padded
+        if (Sf != nullptr) Sf[(size_t)dir * KD * kScreenLd + d * kScreenLd + j] = (float)c;      // [d][atom], zero padded
     }
 }
 
@@ -449,8 +452,12 @@ struct SeedLane {
 #ifndef AMX_SEED3_OCC
 #define AMX_SEED3_OCC 1
 #endif
-template <int STAGE, int MS>
-__global__ void __launch_bounds__(256, (MS > 6 ? AMX_SEED1_OCC : AMX_SEED3_OCC)) k_nnls_seed(const SeedArgs a)
+// OCC2 (stage 1, calls of >= ~0.5 M voxels): two wavefronts per SIMD -- no next voxel reserved in registers, no software pipeline
+// in the scan (244 VGPRs, no scratch): a trip is a third longer, but two wavefronts hide each other's dependent chains and the
+// kernel is throughput bound at that size (1 M voxels: 2.80 -> 2.14 ms).  Small calls are bound by the longest single voxel's path:
+// there the one-wavefront build with the shorter trip wins (50 000 voxels: 0.54 against 0.73 ms).
+template <int STAGE, int MS, bool OCC2 = false>
+__global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AMX_SEED3_OCC)) k_nnls_seed(const SeedArgs a)
 {
     constexpr int KD = kSeedKD, LD = kSeedLd;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
@@ -500,7 +507,7 @@ __global__ void __launch_bounds__(256, (MS > 6 ? AMX_SEED1_OCC : AMX_SEED3_OCC))
     // for in every trip in which some lane of the wavefront refills (measured: 15 % of the kernel).
     // (stage 3 as well, at one wavefront per SIMD -- which by itself costs it nothing: 1.10 ms either way -- with the admissible-atom
     //  mask of the next voxel prefetched next to its y~)
-    constexpr bool PREF = (MS > 6 && AMX_SEED1_OCC == 1) || (STAGE == 3 && AMX_SEED3_OCC == 1);
+    constexpr bool PREF = (MS > 6 && !OCC2 && AMX_SEED1_OCC == 1) || (STAGE == 3 && AMX_SEED3_OCC == 1);
     double yv[PREF ? KD : 1], ynext[PREF ? KD : 1];
     unsigned long long nallow[(PREF && STAGE == 3) ? 4 : 1];
     int next_pos = -1;
@@ -677,7 +684,7 @@ __global__ void __launch_bounds__(256, (MS > 6 ? AMX_SEED1_OCC : AMX_SEED3_OCC))
             if (STAGE == 1) {
                 if (n_atoms <= 16 * MT) {
 #ifndef SEED_NO_MFMA
-                    seed_scan_mfma<KS, MT, AMX_SEED1_OCC == 1>(Aop, Rb, r, lane, best, bj);
+                    seed_scan_mfma<KS, MT, (!OCC2 && AMX_SEED1_OCC == 1)>(Aop, Rb, r, lane, best, bj);
 #else
                     best = r[0] + r[5]; bj = (int)(r[1] * 100.0) & 127;
 #endif
@@ -1791,7 +1798,8 @@ __global__ void __launch_bounds__(1024) k_noddi_project2(const Seed2Args a)
 #ifndef AMX_SEED2_OCC
 #define AMX_SEED2_OCC 1
 #endif
-__global__ void __launch_bounds__(256, AMX_SEED2_OCC) k_lasso_seed(const Seed2Args a)
+template <bool OCC2 = false>
+__global__ void __launch_bounds__(256, OCC2 ? 2 : AMX_SEED2_OCC) k_lasso_seed(const Seed2Args a)
 {
     constexpr int KD = kSeed2KD, KS = KD / 4, MT = 9, KDP = KD + 1, NT = KD * (KD + 1) / 2, LD = KD + 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_l[];
@@ -1833,7 +1841,7 @@ __global__ void __launch_bounds__(256, AMX_SEED2_OCC) k_lasso_seed(const Seed2Ar
 #endif
     // (one wavefront per SIMD: y~ of the voxel in registers, the next voxel reserved -- and its y~ loading -- one solve ahead, as in
     //  k_nnls_seed<1>)
-    constexpr bool PREF2 = AMX_SEED2_OCC == 1;
+    constexpr bool PREF2 = !OCC2 && AMX_SEED2_OCC == 1;       // (see k_nnls_seed: 1 M voxels 1.67 -> 1.28 ms at two wavefronts per SIMD)
     double yv[KD], ynext[PREF2 ? KD : 1];
     int next_pos = -1;
     bool have_next = false;
