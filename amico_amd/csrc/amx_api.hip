@@ -670,7 +670,7 @@ static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
     progress_tick(ctx, s, n_vox / 3, n_vox);                       // (three stages: a third of the work each, roughly)
     a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks; a.rlist = nullptr; a.rcount = nullptr; a.done = nullptr;
     // the LASSO seeds need x_iso: Gram-space solver only (lambda2 >= 1e-5), with the default dictionary shape
-    if (seeds && (ctx->opt_seed_stages & 4) && lut->basis2_S != nullptr && lambda2 >= 1e-5 && lut->nS <= 128 && !ctx->opt_lasso_qr) {
+    if (seeds && (ctx->opt_seed_stages & 4) && lut->basis2_S != nullptr && lambda2 >= 1e-5 && (gemm_ks > 0 || lut->nS <= 128) && !ctx->opt_lasso_qr) {
         const bool gcert2 = !ctx->opt_no_gcert && gemm_ks > 0 && lut->screen2_kappa0 != nullptr && lut->u2iso != nullptr;
         rec(ctx, 12, s);
         // y2~ of every voxel and c2 = A2'y2, ||y2||^2 of the unclipped ones derive from the stage-1 table; the clipped voxels' exactly
@@ -822,8 +822,8 @@ static int czb_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, cons
     if ((!d_y && !d_y32) || !d_dirs || !d_estimates) return bad(ctx, "amx_czb_fit: null buffer");
     if (((flags & AMX_F_RMSE) && !d_rmse) || ((flags & AMX_F_NRMSE) && !d_nrmse))
         return bad(ctx, "amx_czb_fit: flag set but output buffer is null");
-    // the Gram-space solver needs the ridge (models.pyx:439 default: 4.0)
-    if (!(lambda2 >= 1e-6) || !(lambda1 >= 0.0)) return bad(ctx, "amx_czb_fit: need lambda1 >= 0 and lambda2 >= 1e-6");
+    // (the Gram-space solver needs a ridge -- models.pyx:439 default: 4.0; lambda2 < 1e-6 runs the thin-QR solver in A-space)
+    if (!(lambda2 >= 0.0) || !(lambda1 >= 0.0)) return bad(ctx, "amx_czb_fit: need lambda1 >= 0 and lambda2 >= 0");
     hipStream_t s = (hipStream_t)hip_stream;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     Plan pl; int rc;

@@ -536,7 +536,9 @@ struct CzbArgs {
     double *est, *rmse, *nrmse;
 };
 
-template <int NR, int NQ, int MAXP>
+// QR = true: the A-space solver (thin QR of the passive columns + the ridge rows) for lambda2 too small to bound cond(A'A + lambda2 I)
+// -- the reference's lasso accepts any lambda2 >= 0 (models.pyx:439, 615)
+template <int NR, int NQ, int MAXP, bool QR = false>
 __device__ __forceinline__ void czb_voxel(const CzbArgs &a, const float *As, double *rs, double *rl, int vox, const double *gdir, int lane,
                                           const double *Lf = nullptr, const double *lf_inv = nullptr)
 {
@@ -560,11 +562,13 @@ __device__ __forceinline__ void czb_voxel(const CzbArgs &a, const float *As, dou
         if (lane == 0 && a.nrmse) a.nrmse[vox] = __builtin_nan("");
     }
     if (ok) {
-    GramSolver<NR, NQ, MAXP, float> S;
+    typename std::conditional<QR, NNSolver<NR, NQ, MAXP, true, float>, GramSolver<NR, NQ, MAXP, float>>::type S;
     // strong ridge, dense optimum: block principal pivoting from the full set; otherwise (or AMX_COLD_START) Lawson-Hanson
     const bool dense = NQ == 1 && n_atoms <= MAXP && a.c.lam2 >= 1e-2 && !(a.c.flags & 0x80000000u);
     int st_;
-    if constexpr (NQ == 1) {
+    if constexpr (QR) {
+        st_ = S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed, a.c.lam1, a.c.lam2, rs, rl, lane);
+    } else if constexpr (NQ == 1) {
         st_ = dense ? S.solve_dense(As, ldA, nS, n_atoms, yr, a.c.lam1, a.c.lam2, rs, rl, lane, gdir, a.ldG, Lf, lf_inv)
                     : S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed, a.c.lam1, a.c.lam2, rs, rl, lane, gdir, a.ldG);
     } else {
@@ -824,6 +828,35 @@ __global__ void __launch_bounds__(NW * 64) k_czb(const CzbArgs a)
             stage_tile<float>(As, tiles + (size_t)a.c.lutidx[vox] * a.c.tile_stride, words, words_pad - words);
             __syncthreads();
             czb_voxel<NR, NQ, MAXP>(a, As, rs, rl, vox, a.gram + (size_t)a.c.lutidx[vox] * a.c.n_atoms * a.ldG, lane);
+        }
+    }
+}
+
+// CylinderZeppelinBall with (nearly) no ridge: the A-space QR solver, tile only (no Gram matrix in LDS)
+template <int NR, int NQ, int MAXP, int NW, bool LIST>
+__global__ void __launch_bounds__(NW * 64) k_czb_qr(const CzbArgs a)
+{
+    AMX_KERNEL_PROLOGUE(float, NR, NQ, NW, solver_lds_words(false, MAXP))
+    (void)wmask;
+    const float *tiles = reinterpret_cast<const float *>(a.c.tiles);
+    if (!LIST) {
+        const int cid = xcd_chunk((int)blockIdx.x, *a.c.n_chunks);
+        if (cid < 0) return;
+        const Chunk ck = a.c.chunks[cid];
+        unsigned *ticket = reinterpret_cast<unsigned *>(wm_all + nw_ * 4);
+        if (threadIdx.x == 0) *ticket = (unsigned)nw_;
+        stage_tile<float>(As, tiles + (size_t)ck.dir * a.c.tile_stride, words, words_pad - words);
+        __syncthreads();
+        for (int k = wave; k < ck.count; k = next_ticket(ticket, lane))
+            czb_voxel<NR, NQ, MAXP, true>(a, As, rs, rl, a.c.perm[ck.start + k], nullptr, lane);
+    } else {
+        const int cnt = *a.c.list_count;
+        for (int it = blockIdx.x; it < cnt; it += gridDim.x) {
+            const int vox = a.c.list[it];
+            __syncthreads();
+            stage_tile<float>(As, tiles + (size_t)a.c.lutidx[vox] * a.c.tile_stride, words, words_pad - words);
+            __syncthreads();
+            czb_voxel<NR, NQ, MAXP, true>(a, As, rs, rl, vox, nullptr, lane);
         }
     }
 }

@@ -14,6 +14,13 @@ static int go(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
 #endif
     constexpr int NW = AMX_S1_NW; // wavefronts per workgroup: as many as the register budget of this stage allows
     const size_t scr = (a.scr_S && a.seeds) ? (size_t)kSeedKD * kScreenLd * sizeof(float) : 0;   // screening table (amx_solver.hpp)
+    // Left-overs of the Gram certificates (seeded chain): few voxels per chunk, and the ones that get here are the hard ones --
+    // room for 12 passive atoms and 12 wavefronts (168 VGPRs, 16 spilled, against 128 / 64 with 8 atoms and 16 wavefronts): nothing
+    // overflows into the one-wavefront re-run kernel any more (it cost 0.16 ms for five voxels per million), 1 M voxels 0.82 -> 0.65 ms
+    if (a.rlist != nullptr && fit_lds_bytes<double>(a.c.nS, a.c.ldA, NR, NQ, 12, 12, false, false) + scr <= kLdsPerCU && !ctx->opt_tile_f32)
+        return launch_pair<12>(ctx, a, pl, s, k_noddi<1, NR, NQ, 12, 12, false, double>, k_noddi<1, NR, NQ, MB, 1, true>,
+                               [&](int nw) { return fit_lds_bytes<double>(a.c.nS, a.c.ldA, NR, NQ, nw, 12, false, false) + scr; },
+                               fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, false), 0, 2);
     // fp64 tile in LDS when it fits next to the per-wavefront blocks (99 x 145: 115 KB + 16 x 2.3 KB of 160 KB): the
     // fp32 -> fp64 conversions of the tile reads are then paid once per chunk.  AMX_TILE_F32=1: the fp32 tile.
     {

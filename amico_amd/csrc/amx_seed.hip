@@ -141,12 +141,14 @@ int amx_launch_noddi_gemm(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, 
     const size_t lds = gemm_lds(lasso ? lut->n_wm : lut->n_atoms, ga.rows, ks);
     int rc;
     const dim3 grid(((pl.max_schunks + 7) / 8) * 8);
-#define AMX_GEMM_GO(L, K)                                                                          \
+#define AMX_GEMM_GO(L, K, ...)                                                                     \
     do {                                                                                           \
-        if ((rc = set_lds(ctx, (k_noddi_gemm<L, K>), lds))) return rc;                             \
-        hipLaunchKernelGGL((k_noddi_gemm<L, K>), grid, dim3(512), lds, s, ga);                     \
+        if ((rc = set_lds(ctx, (k_noddi_gemm<L, K, ##__VA_ARGS__>), lds))) return rc;              \
+        hipLaunchKernelGGL((k_noddi_gemm<L, K, ##__VA_ARGS__>), grid, dim3(512), lds, s, ga);      \
     } while (0)
-    if (ks == 25) { if (lasso) AMX_GEMM_GO(true, 25); else AMX_GEMM_GO(false, 25); }
+    const int mtf = (lasso ? lut->n_wm : lut->n_atoms) / 16;
+    if (ks == 25 && mtf == 9 && !lasso) AMX_GEMM_GO(false, 25, 9);          // the default dictionary: unrolled tile loop
+    else if (ks == 25) { if (lasso) AMX_GEMM_GO(true, 25); else AMX_GEMM_GO(false, 25); }
     else if (ks == 40) { if (lasso) AMX_GEMM_GO(true, 40); else AMX_GEMM_GO(false, 40); }
     else return amx_bad(ctx, "k_noddi_gemm: unsupported dictionary shape");
 #undef AMX_GEMM_GO

@@ -868,7 +868,9 @@ __device__ __forceinline__ double rows_allmin(double k)
     return k;
 }
 
-template <bool LASSO, int KS>
+// MTF > 0: the number of float32 tiles is known at compile time (9 for the 144 + 1 atoms of the default dictionary) and their loop
+// is unrolled -- the LDS reads of the next tiles overlap the products of the current ones; MTF = 0: any dictionary
+template <bool LASSO, int KS, int MTF = 0>
 __global__ void __launch_bounds__(512) k_noddi_gemm(const GemmArgs a)
 {
     constexpr int NB = KS > 25 ? 1 : 3;            // atom tiles in flight together (registers: KS operand values each)
@@ -876,7 +878,7 @@ __global__ void __launch_bounds__(512) k_noddi_gemm(const GemmArgs a)
     const int nS = a.nS, n_atoms = a.n_atoms, ldA = a.ldA, aux0 = a.aux0;
     const int MT = a.rows >> 4;
     const int n_cols = LASSO ? a.n_wm : n_atoms;
-    const int MTf = n_cols >> 4;                                          // tiles of atoms only: float32 operands
+    const int MTf = MTF > 0 ? MTF : (n_cols >> 4);                        // tiles of atoms only: float32 operands
     float *A32 = reinterpret_cast<float *>(smem_g);                       // [MTf][KS][64]
     double *A64 = reinterpret_cast<double *>(A32 + (size_t)MTf * KS * 64);   // [MT - MTf][KS][64]
     double *IsoT = A64 + (size_t)(MT - MTf) * KS * 64;                    // [4 KS] LASSO: iso atom by signal row; NNLS: 1 / iso on the stage-2 rows
@@ -969,6 +971,7 @@ __global__ void __launch_bounds__(512) k_noddi_gemm(const GemmArgs a)
         if (g + nw < n_groups) issue(g + nw);
         const int blk = ck.pad + (g >> 2), col = 16 * (g & 3) + c16;
         double *out = a.Cb + (size_t)blk * a.rows * 64 + col;
+#pragma unroll (MTF > 0 && !LASSO ? 3 : 1)
         for (int mt = 0; mt < MTf; mt += NB) {
             // the operands of NB atom tiles first (all their LDS reads in flight together), then the products back to back
             float af[NB][KS];

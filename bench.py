@@ -555,6 +555,50 @@ def noddi_hard_mix(ctx, lut, K, htable, scheme, n, steps, warmup):
     return out
 
 
+def noddi_other_protocol(ctx, shells, n_b0, n, steps, warmup, headline_rate_per_byte):
+    """the NODDI fit on another acquisition protocol (the reference's loop is shape generic, models.pyx:825-828, 851-861): voxels/s,
+    the share of the headline's rate per byte of signal, certification rates, parity on a sample"""
+    import torch
+    from amico_amd import _capi, synthetic as S
+    from oracle import oracle
+    dev = torch.device('cuda', torch.cuda.current_device())
+    lut_dirs = S.fibonacci_hemisphere(500)
+    htable = S.build_htable(lut_dirs)
+    scheme = S.make_scheme(n_b0, shells, seed=4)
+    K = S.noddi_kernels(scheme, lut_dirs)
+    y_h, d_h = S.noddi_signals_parallel(n, K, htable, scheme, seed=17)
+    lut = _capi.upload_noddi(ctx, K, htable, scheme.dwi_idx, False)
+    y = torch.from_numpy(y_h).to(dev); d = torch.from_numpy(d_h).to(dev)
+    est = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+    L = _capi.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def fit():
+        ctx.check(L.amx_noddi_fit_device(ctx._h, lut._h, y.data_ptr(), d.data_ptr(), n, 0.5, 1e-3, 0, est.data_ptr(), None, None, None, stream))
+    for _ in range(warmup):
+        fit(); ctx.sync(stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fit(); ctx.sync(stream)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    fit(); ctx.sync(stream)
+    stats, seed = ctx.last_stats(), ctx.last_seed_stats()
+    pick = np.unique(np.linspace(0, n - 1, min(n, 10000)).astype(np.int64))
+    ref = oracle.noddi_fit(np.ascontiguousarray(y_h[pick]), np.ascontiguousarray(d_h[pick]), K, htable, scheme.dwi_idx, nthreads=physical_cores() or os.cpu_count() or 1)
+    diff = np.abs(est.cpu().numpy()[pick] - ref['estimates']).max(axis=1)
+    bpv = 8 * scheme.nS + 48
+    out = {'metric': 'voxels/sec, NODDI fit, %d-volume protocol (inputs resident in HBM)' % scheme.nS, 'value': n / el, 'unit': 'voxels/s', 'voxels': n,
+           'ms_per_step': 1e3 * el, 'volumes': int(scheme.nS), 'bytes_per_voxel': bpv,
+           'rate_per_byte_vs_headline': (n / el * bpv) / headline_rate_per_byte,
+           'solver_stats': stats, 'seed_chain': seed,
+           'parity': {'sample_voxels': len(pick), 'max_abs_dmap': float(diff.max()), 'frac_within_1e-6': float((diff < 1e-6).mean())}}
+    del y, d, est, lut
+    torch.cuda.empty_cache()
+    return out
+
+
 def device_barrier(dev, world):
     """both sides of the timed region: drain the device, meet the other ranks, drain again"""
     import torch
@@ -789,6 +833,9 @@ def main():
                     pass
             if not args.no_other_configs:
                 other['noddi_hard_mix'] = noddi_hard_mix(ctx, lut, K, htable, scheme, min(n, 1_000_000), 5, 2)
+                per_byte = value * BYTES_PER_VOXEL
+                other['noddi_105vol'] = noddi_other_protocol(ctx, ((700.0, 50), (2000.0, 50)), 5, min(n, 1_000_000), 5, 2, per_byte)
+                other['noddi_150vol'] = noddi_other_protocol(ctx, ((700.0, 40), (2000.0, 60), (3000.0, 40)), 10, min(n, 1_000_000), 5, 2, per_byte)
             if not args.no_cpu_baseline:
                 # bounded CPU legs on the host cores of this box: the oracle -- a port, the reference's
                 # cyspams path cannot be built -- at -O3 -march=native, the reference's chunk-per-thread structure

@@ -96,9 +96,9 @@ int amx_sandi_fit(amx_ctx *ctx, const amx_lut *lut, const double *y, int64_t n_v
                   double lambda1, double lambda2, unsigned flags,
                   double *out_estimates, double *out_rmse, double *out_nrmse);
 
-/* CylinderZeppelinBall._fit models.pyx:526-652: estimates f64[n_vox][3] = v, a, d (lambda2 >= 1e-6: the default 4.0
- * makes the Gram-space solver the right tool; the model's `isExvivo`, which the reference never defines, is not a
- * parameter here) */
+/* CylinderZeppelinBall._fit models.pyx:526-652: estimates f64[n_vox][3] = v, a, d.  Any lambda2 >= 0 like the reference's
+ * lasso (models.pyx:439, 615): the default 4.0 makes the Gram-space solver the right tool, lambda2 < 1e-6 runs the thin-QR
+ * solver in A-space.  (The model's `isExvivo`, which the reference never defines, is not a parameter here.) */
 int amx_czb_fit(amx_ctx *ctx, const amx_lut *lut, const double *y, const double *dirs, int64_t n_vox,
                 double lambda1, double lambda2, unsigned flags,
                 double *out_estimates, double *out_rmse, double *out_nrmse);

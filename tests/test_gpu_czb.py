@@ -81,3 +81,49 @@ def test_czb_vs_oracle_and_kkt(czb_fix, htable500):
         gp, gz = max(gp, np.abs(G[P]).max(initial=0.0)), max(gz, G[~P].max(initial=0.0))
     assert x[ok].min() >= 0.0 and gp < 1e-9 and gz < 1e-9, (gp, gz)
     assert ctx.last_stats()['itercap_voxels'] == 0 and ctx.last_stats()['overflow_voxels'] == 0
+
+
+@pytest.mark.parametrize('lam2', [0.0, 1e-8])
+def test_czb_without_a_ridge(czb_fix, htable500, lam2):
+    """the reference's lasso accepts any lambda2 >= 0 (models.pyx:439, 615): below 1e-6 the fit runs the thin-QR solver in A-space.
+    Without a ridge `x` need not be unique (26 nearly collinear atoms), A x is: KKT certificate of the device x, and A x against
+    the oracle's."""
+    import os
+    import torch
+    from amico_amd import _capi, get_context, synthetic as S
+    from oracle import oracle
+    f = czb_fix
+    ht, K, ids = htable500['htable'], f['kernels'], f['lut_ids']
+    rng = np.random.default_rng(5)
+    d = S.random_unit_vectors(200000, rng)
+    d = d[np.isin(S.lut_indices(d, ht), ids)][:4000]
+    lut = S.lut_indices(d, ht)
+    n = len(d)
+    n_rs, n_p = K['wmr'].shape[0], K['wmh'].shape[0]
+    w = rng.dirichlet([2.0, 2.0, 1.0], n)
+    y0 = w[:, :1] * K['wmr'][rng.integers(n_rs, size=n), lut].astype(np.float64) + \
+        w[:, 1:2] * K['wmh'][rng.integers(n_p, size=n), lut].astype(np.float64) + w[:, 2:] * K['iso'][0].astype(np.float64)
+    y = np.abs(y0 + rng.normal(scale=1 / 30.0, size=y0.shape) + 1j * rng.normal(scale=1 / 30.0, size=y0.shape))
+    ctx = get_context()
+    L = _capi.upload_czb(ctx, K, f['Rs'], ht)
+    dev = torch.device('cuda', 0)
+    est, _, _, xd = _capi.czb_fit_device(ctx, L, torch.from_numpy(y).to(dev), torch.from_numpy(d).to(dev), 0.0, lam2, return_x=True)
+    ctx.sync()
+    x = xd.cpu().numpy()
+    st = ctx.last_stats()
+    assert st['itercap_voxels'] == 0 and st['overflow_voxels'] == 0 and st['guard_trips'] == 0
+    gp = gz = ax = 0.0
+    for lid in ids:
+        rows = np.flatnonzero(lut == lid)
+        if len(rows) == 0:
+            continue
+        A = np.concatenate([K['wmr'][:, lid], K['wmh'][:, lid], K['iso']], axis=0).astype(np.float64).T
+        G = (y[rows] - x[rows] @ A.T) @ A - lam2 * x[rows]
+        P = x[rows] > 0
+        gp, gz = max(gp, np.abs(G[P]).max(initial=0.0)), max(gz, G[~P].max(initial=0.0))
+        for v in rows[::25]:                                  # lambda1 = 0 and (nearly) no ridge: plain NNLS, A x is unique
+            xr, _, _ = oracle.nnls(A, y[v])
+            ax = max(ax, np.abs(A @ x[v] - A @ xr).max())
+    assert x.min() >= 0.0 and gp < 1e-9 and gz < 1e-9, (gp, gz)
+    assert ax < (1e-8 if lam2 == 0.0 else 1e-6), ax
+    assert np.isfinite(est.cpu().numpy()).all()
