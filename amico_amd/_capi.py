@@ -25,7 +25,8 @@ SYMBOLS = ['amx_version', 'amx_ctx_create', 'amx_ctx_destroy', 'amx_last_error',
            'amx_dti_create', 'amx_dti_destroy', 'amx_dti_directions', 'amx_dti_directions_device', 'amx_dti_directions_device_f32', 'amx_prep_gather_device_f32',
            'amx_prep_create', 'amx_prep_destroy', 'amx_prep_gather', 'amx_prep_gather_device',
            'amx_prep_mean_b0', 'amx_prep_mean_b0_device', 'amx_prep_scatter', 'amx_prep_scatter_device',
-           'amx_lut_resample', 'amx_lut_rotate_resample']
+           'amx_lut_resample', 'amx_lut_rotate_resample',
+           'amx_dict_upload', 'amx_dict_destroy', 'amx_nnls_batched', 'amx_lasso_batched', 'amx_nnls_batched_device', 'amx_lasso_batched_device']
 
 _lib = None
 c_vp, c_dp, c_fp = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float)
@@ -102,6 +103,13 @@ def lib():
     L.amx_last_kernel_ms.argtypes = [c_vp, C.c_int, C.POINTER(C.c_float)]
     L.amx_last_stats.argtypes = [c_vp, c_i64p]
     L.amx_last_seed_stats.argtypes = [c_vp, c_i64p]
+    L.amx_dict_upload.argtypes = [c_vp, c_dp, C.c_int, C.c_int, C.c_int, C.POINTER(c_vp)]
+    L.amx_dict_destroy.argtypes = [c_vp]
+    L.amx_dict_destroy.restype = None
+    L.amx_nnls_batched.argtypes = [c_vp, c_vp, c_i32p, c_dp, C.c_int64, c_dp, c_dp]
+    L.amx_lasso_batched.argtypes = [c_vp, c_vp, c_i32p, c_dp, C.c_int64, C.c_double, C.c_double, c_dp]
+    L.amx_nnls_batched_device.argtypes = [c_vp, c_vp, c_vp, c_vp, C.c_int64, c_vp, c_vp, c_vp]
+    L.amx_lasso_batched_device.argtypes = [c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_double, C.c_double, c_vp, c_vp]
     L.amx_selftest.argtypes = [c_vp, c_dp]
     L.amx_dti_create.argtypes = [c_vp, c_dp, C.c_int, C.c_double, C.POINTER(c_vp)]
     L.amx_dti_destroy.argtypes = [c_vp]
@@ -472,6 +480,63 @@ def sandi_fit_device(ctx, lut, y_t, lambda1, lambda2, rmse=False, nrmse=False, s
     ctx.check(_dev_fn('sandi', y_t)(ctx._h, lut._h, _dptr(y_t), n, float(lambda1), float(lambda2), flags, _dptr(est),
                                          _dptr(r), _dptr(nr), c_vp(stream or 0)))
     return (est, r, nr, xd) if return_x else (est, r, nr)
+
+
+class Dict:
+    """amx_dict: the dictionaries of the batched solver entry points (cyspams.interfaces.nnls / lasso, models.pyx:18, batched).
+    A: [n_dicts, m, n] (or [m, n]) in numpy's own layout -- the column-major m x n slices the C ABI wants are made here."""
+
+    def __init__(self, ctx, A):
+        A = np.asarray(A, dtype=np.float64)
+        if A.ndim == 2:
+            A = A[None]
+        if A.ndim != 3:
+            raise ValueError('dictionary must be [m, n] or [n_dicts, m, n]')
+        self.ctx, (self.n_dicts, self.m, self.n) = ctx, A.shape
+        cm = np.ascontiguousarray(np.transpose(A, (0, 2, 1)))          # [n_dicts][n][m]: column-major m x n per dictionary
+        h = c_vp()
+        ctx.check(lib().amx_dict_upload(ctx._h, _p(cm, c_dp), self.m, self.n, self.n_dicts, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, '_h', None):
+                lib().amx_dict_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def _batched_inputs(dic, y, idx):
+    y = np.ascontiguousarray(np.atleast_2d(y), dtype=np.float64)
+    if y.shape[1] != dic.m:
+        raise ValueError(f'y has {y.shape[1]} samples, the dictionary {dic.m}')
+    if idx is not None:
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        if idx.shape != (y.shape[0],):
+            raise ValueError('dict_idx must have one entry per voxel')
+    elif dic.n_dicts != 1:
+        raise ValueError('dict_idx is required with more than one dictionary')
+    return y, idx
+
+
+def nnls_batched(ctx, dic, y, dict_idx=None, return_rnorm=False):
+    """x_v = argmin_{x >= 0} ||A_d x - y_v||, d = dict_idx[v]: (X [n_vox, n], rnorm [n_vox]) -- models.pyx:911, 940"""
+    y, idx = _batched_inputs(dic, y, dict_idx)
+    x = np.zeros((y.shape[0], dic.n))
+    rn = np.zeros(y.shape[0]) if return_rnorm else None
+    ctx.check(lib().amx_nnls_batched(ctx._h, dic._h, _p(idx, c_i32p) if idx is not None else None, _p(y, c_dp), y.shape[0], _p(x, c_dp),
+                                     _p(rn, c_dp) if rn is not None else None))
+    return (x, rn) if return_rnorm else x
+
+
+def lasso_batched(ctx, dic, y, lambda1, lambda2, dict_idx=None):
+    """x_v = argmin_{x >= 0} 1/2 ||y_v - A_d x||^2 + lambda1 sum(x) + lambda2 / 2 ||x||^2 -- models.pyx:615, 926, 1238, 1569"""
+    y, idx = _batched_inputs(dic, y, dict_idx)
+    x = np.zeros((y.shape[0], dic.n))
+    ctx.check(lib().amx_lasso_batched(ctx._h, dic._h, _p(idx, c_i32p) if idx is not None else None, _p(y, c_dp), y.shape[0],
+                                      float(lambda1), float(lambda2), _p(x, c_dp)))
+    return x
 
 
 def dir_to_lut_idx(ctx, lut, dirs):

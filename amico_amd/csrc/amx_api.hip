@@ -25,7 +25,7 @@ int reset_status(amx_ctx *ctx, hipStream_t s)
     return AMX_OK;
 }
 
-int make_plan(amx_ctx *ctx, int64_t n, int ndirs, Plan &pl, bool seeds = false, int table_rows = 0)
+int make_plan(amx_ctx *ctx, int64_t n, int ndirs, Plan &pl, bool seeds = false, int table_rows = 0, int blocks_chunk = 0)
 {
     int rc;
     const int max_chunks = (int)(n / kChunk) + ndirs + 1;
@@ -45,7 +45,11 @@ int make_plan(amx_ctx *ctx, int64_t n, int ndirs, Plan &pl, bool seeds = false, 
         // (measured, ndirs = 500: 100 000 / 200 000 / 400 000 / 1 M voxels -> stage-1 group 1.11 / 1.55 / 2.31 / 4.66 ms with two
         //  wavefronts per workgroup against 1.33 / 1.80 / 2.39 / 4.14 ms with four; every other lane kernel is best with four)
         pl.seed1_waves = ctx->opt_seed_waves ? ctx->opt_seed_waves : ((double)n / (double)pl.max_schunks < 640.0 ? 2 : 4);
-        pl.seed_occ2 = (ctx->in_host_fit ? ctx->host_total_vox : n) >= ctx->opt_seed_occ2_from;
+        const long long call_vox = ctx->in_host_fit ? ctx->host_total_vox : n;      // (batches of one host call all take the same build)
+        pl.seed_occ2 = call_vox >= ctx->opt_seed_occ2_from;
+        pl.seed2_occ2 = call_vox >= ctx->opt_seed2_occ2_from;
+        pl.seed2_waves = pl.seed1_waves;
+        if (!ctx->opt_seed_waves) { if (pl.seed_occ2) pl.seed1_waves = 4; if (pl.seed2_occ2) pl.seed2_waves = 4; }
         if ((rc = ensure(ctx, ctx->schunks, (size_t)pl.max_schunks * sizeof(Chunk)))) return rc;
         if ((rc = ensure(ctx, ctx->ytil, (size_t)n * amx::kSeedKD * sizeof(double)))) return rc;
         if ((rc = ensure(ctx, ctx->seeds, (size_t)n * sizeof(unsigned long long)))) return rc;
@@ -58,6 +62,14 @@ int make_plan(amx_ctx *ctx, int64_t n, int ndirs, Plan &pl, bool seeds = false, 
         if ((rc = ensure(ctx, ctx->rlist, 2 * amx_rlist_half(pl) * sizeof(int)))) return rc;
         if ((rc = ensure(ctx, ctx->ytil2, (size_t)n * amx::kSeedKD * sizeof(double)))) return rc;
         if ((rc = ensure(ctx, ctx->seeds2, (size_t)n * 4 * sizeof(unsigned long long)))) return rc;
+        pl.schunks = (Chunk *)ctx->schunks.p;
+    }
+    if (!seeds && blocks_chunk > 0) {
+        // second plan only (chunks of whole 64-voxel blocks) + a block-wise table of table_rows rows: CylinderZeppelinBall's fast path
+        pl.seed_chunk = blocks_chunk;
+        pl.max_schunks = (int)(n / blocks_chunk) + ndirs + 1;
+        if ((rc = ensure(ctx, ctx->schunks, (size_t)pl.max_schunks * sizeof(Chunk)))) return rc;
+        if ((rc = ensure(ctx, ctx->cgemm, ((size_t)n / 64 + ndirs + 1) * table_rows * 64 * sizeof(double)))) return rc;
         pl.schunks = (Chunk *)ctx->schunks.p;
     }
     if ((rc = ensure(ctx, ctx->lutidx, n * sizeof(int)))) return rc;
@@ -224,6 +236,8 @@ int amx_ctx_create(int device, amx_ctx **out)
         if (e && *e) ctx->opt_seed_min_voxels = atoll(e);
         e = getenv("AMX_SEED_OCC2_FROM");
         if (e && *e) ctx->opt_seed_occ2_from = atoll(e);
+        e = getenv("AMX_SEED2_OCC2_FROM");
+        if (e && *e) ctx->opt_seed2_occ2_from = atoll(e);
         ctx->opt_no_chunk_order = on("AMX_NO_CHUNK_ORDER");
         e = getenv("AMX_NO_GCERT_WIDE");
         ctx->opt_no_gcert_wide = e && *e && *e != '0';
@@ -265,10 +279,11 @@ void amx_lut_destroy(amx_lut *lut)
     if (!lut) return;
     if (lut->ctx) hipSetDevice(lut->ctx->device);
     void *ps[] = {lut->u2iso, lut->screen2_kappa0, lut->screen_kappa0, lut->screen2_S, lut->screen2_kappa, lut->screen_S, lut->screen_kappa, lut->basis_U, lut->basis_S, lut->basis2_U, lut->basis2_S, lut->gram, lut->gram_dwi, lut->tiles, lut->htable, lut->rowdwi, lut->colscale, lut->icvf, lut->kappa,
-                  lut->norms, lut->Rs, lut->d_in, lut->d_isos, lut->fw_prep, lut->sandi_prep};
+                  lut->norms, lut->Rs, lut->d_in, lut->d_isos, lut->fw_prep, lut->sandi_prep, lut->czb_prep};
     for (void *p : ps) if (p) hipFree(p);
     if (lut->fw_ready) (void)hipEventDestroy(lut->fw_ready);
     if (lut->sandi_ready) (void)hipEventDestroy(lut->sandi_ready);
+    if (lut->czb_ready) (void)hipEventDestroy(lut->czb_ready);
     delete lut;
 }
 
@@ -827,7 +842,10 @@ static int czb_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, cons
     hipStream_t s = (hipStream_t)hip_stream;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     Plan pl; int rc;
-    if ((rc = make_plan(ctx, n_vox, lut->ndirs, pl))) return rc;
+    // the default problem (strong ridge, <= 32 atoms, maps only): complementary form, one voxel per lane (amx_czb.hip)
+    const bool fast = lut->n_atoms <= 32 && lambda2 >= 1e-2 && !(flags & (AMX_F_RMSE | AMX_F_NRMSE)) && !ctx->opt_cold_start &&
+                      !ctx->opt_wave_per_voxel && lut->nS <= 160 && lut->gram != nullptr;
+    if ((rc = make_plan(ctx, n_vox, lut->ndirs, pl, false, 64, fast ? 2048 : 0))) return rc;
     clear_events(ctx);
     rec(ctx, 0, s);
     if ((rc = enqueue_bucketing(ctx, lut, d_dirs, n_vox, pl, s))) return rc;
@@ -844,12 +862,163 @@ static int czb_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, cons
     }
     a.est = d_estimates; a.rmse = (flags & AMX_F_RMSE) ? d_rmse : nullptr; a.nrmse = (flags & AMX_F_NRMSE) ? d_nrmse : nullptr;
     HIPCHK(ctx, hipMemsetAsync(d_estimates, 0, (size_t)n_vox * 3 * sizeof(double), s));
-    rc = amx_launch_czb(ctx, a, pl, s);
+    if (fast) { if (!(rc = amx_czb_prepare(ctx, lut, lambda2, s))) rc = amx_launch_czb_fast(ctx, lut, a, pl, s); }
+    else rc = amx_launch_czb(ctx, a, pl, s);
     hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, s, (const int *)ctx->misc.p, ctx->status_d);
     rec(ctx, 1, s);
     if (!rc) progress_tick(ctx, s, n_vox, n_vox);
     return rc;
 }
+
+}  // extern "C"
+
+#define AMX_H2D(buf, src, bytes)                                                     \
+    if ((rc = ensure(ctx, buf, bytes))) return rc;                                   \
+    HIPCHK(ctx, hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, nullptr));
+
+// ------------------------------------------------------------------ the solvers themselves, batched
+// histogram of the caller's dictionary indices (+ range check: the first bad voxel is reported like a bad direction)
+__global__ void k_idx_hist(const int *__restrict__ idx, int n, int n_dicts, int *__restrict__ lutidx, int *__restrict__ counts, int *__restrict__ status)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    int d = idx ? idx[v] : 0;
+    if (d < 0 || d >= n_dicts) {
+        const int old = atomicMin(&status[ST_ERRVOX], v);
+        if (old > v) { status[ST_II1] = d; status[ST_II2] = n_dicts; }
+        d = -1;
+    } else {
+        atomicAdd(&counts[d], 1);
+    }
+    lutidx[v] = d;
+}
+
+static int batched_dev(amx_ctx *ctx, const amx_dict *dict, const int32_t *d_idx, const double *d_y, int64_t n_vox, double lambda1, double lambda2,
+                       bool ridge, double *d_x, double *d_rnorm, void *hip_stream, const char *who)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!dict || dict->ctx != ctx) return bad(ctx, "amx_*_batched: not a dictionary of this ctx");
+    if (n_vox < 0 || n_vox > INT_MAX / 4) return bad(ctx, "amx_*_batched: bad n_vox");
+    if (n_vox == 0) return AMX_OK;
+    if (!d_y || !d_x) return bad(ctx, "amx_*_batched: null buffer");
+    if (!(lambda1 >= 0.0) || !(lambda2 >= 0.0)) return bad(ctx, "amx_lasso_batched: need lambda1 >= 0 and lambda2 >= 0");
+    if (!d_idx && dict->n_dicts != 1) return bad(ctx, "amx_*_batched: dict_idx may only be NULL for a single dictionary");
+    (void)who;
+    hipStream_t s = (hipStream_t)hip_stream;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Plan pl; int rc;
+    if ((rc = make_plan(ctx, n_vox, dict->n_dicts, pl))) return rc;
+    clear_events(ctx);
+    rec(ctx, 0, s);
+    HIPCHK(ctx, hipMemsetAsync(pl.counts, 0, (size_t)(dict->n_dicts + 1) * sizeof(int), s));
+    HIPCHK(ctx, hipMemsetAsync(ctx->misc.p, 0, 64 * sizeof(int), s));
+    hipLaunchKernelGGL(k_idx_hist, dim3((unsigned)((n_vox + 255) / 256)), dim3(256), 0, s, (const int *)d_idx, (int)n_vox, dict->n_dicts, pl.lutidx, pl.counts, ctx->status_d);
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, pl.counts, dict->n_dicts, kChunk, pl.dir_start, pl.cursor, pl.chunks, pl.n_chunks, 0, (Chunk *)nullptr);
+    const int nb = (int)((n_vox + kPrepSpan - 1) / kPrepSpan);
+    const int use_lds = dict->n_dicts <= 8192 ? 1 : 0;
+    hipLaunchKernelGGL(k_bucket, dim3(nb), dim3(1024), use_lds ? (size_t)2 * dict->n_dicts * sizeof(int) : 0, s, pl.lutidx, (int)n_vox, dict->n_dicts,
+                       pl.dir_start, pl.cursor, pl.perm, use_lds);
+    HIPCHK(ctx, hipGetLastError());
+    BatchedArgs a;
+    memset(&a, 0, sizeof a);
+    a.c.tiles = dict->tiles; a.c.y = d_y; a.c.perm = pl.perm; a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks;
+    a.c.lutidx = pl.lutidx; a.c.status = ctx->status_d; a.c.nS = dict->m; a.c.ldA = dict->ldA; a.c.n_atoms = dict->n;
+    a.c.tile_stride = dict->tile_stride; a.c.lam1 = lambda1; a.c.lam2 = lambda2;
+    a.x = d_x; a.rnorm = d_rnorm;
+    // (voxels with a bad dictionary index are skipped: defined zeros)
+    HIPCHK(ctx, hipMemsetAsync(d_x, 0, (size_t)n_vox * dict->n * sizeof(double), s));
+    rc = amx_launch_batched(ctx, a, pl, s, ridge);
+    hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, s, (const int *)ctx->misc.p, ctx->status_d);
+    rec(ctx, 1, s);
+    return rc;
+}
+
+extern "C" {
+
+int amx_dict_upload(amx_ctx *ctx, const double *A, int m, int n, int n_dicts, amx_dict **out)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!A || !out || m <= 0 || n <= 0 || n_dicts <= 0) return bad(ctx, "amx_dict_upload: bad argument");
+    if (n > 192 || m > 256) return bad(ctx, "amx_dict_upload: unsupported size (n <= 192 atoms, m <= 256 samples)");
+    const int ldA = (n & 1) ? n : n + 1;
+    const int tile_stride = (m * ldA + 3) & ~3;
+    if (fit_lds_bytes<double>(m, ldA, m <= 128 ? 2 : 4, 3, 1, 48, false, true) > (size_t)160 * 1024)
+        return bad(ctx, "amx_dict_upload: an m x n float64 dictionary of this size does not fit the 160 KB LDS of a compute unit");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<double> t((size_t)n_dicts * tile_stride, 0.0);
+    for (int d = 0; d < n_dicts; d++)
+        for (int j = 0; j < n; j++)
+            for (int i = 0; i < m; i++) t[(size_t)d * tile_stride + (size_t)i * ldA + j] = A[((size_t)d * n + j) * m + i];     // column-major in, ld = m
+    amx_dict *h = new amx_dict();
+    h->ctx = ctx; h->m = m; h->n = n; h->ldA = ldA; h->tile_stride = tile_stride; h->n_dicts = n_dicts;
+    int rc;
+    if ((rc = upload(ctx, &h->tiles, t.data(), t.size()))) { delete h; return rc; }
+    *out = h;
+    return AMX_OK;
+}
+
+void amx_dict_destroy(amx_dict *h)
+{
+    if (!h) return;
+    if (h->ctx) hipSetDevice(h->ctx->device);
+    if (h->tiles) hipFree(h->tiles);
+    delete h;
+}
+
+int amx_nnls_batched_device(amx_ctx *ctx, const amx_dict *dict, const int32_t *d_dict_idx, const double *d_y, int64_t n_vox, double *d_x,
+                            double *d_rnorm, void *hip_stream)
+{
+    return batched_dev(ctx, dict, d_dict_idx, d_y, n_vox, 0.0, 0.0, false, d_x, d_rnorm, hip_stream, "amx_nnls_batched");
+}
+
+int amx_lasso_batched_device(amx_ctx *ctx, const amx_dict *dict, const int32_t *d_dict_idx, const double *d_y, int64_t n_vox, double lambda1,
+                             double lambda2, double *d_x, void *hip_stream)
+{
+    return batched_dev(ctx, dict, d_dict_idx, d_y, n_vox, lambda1, lambda2, true, d_x, nullptr, hip_stream, "amx_lasso_batched");
+}
+
+static int batched_host(amx_ctx *ctx, const amx_dict *dict, const int32_t *idx, const double *y, int64_t n_vox, double lambda1, double lambda2, bool ridge,
+                        double *x, double *rnorm)
+{
+    if (!ctx) return AMX_E_BADARG;
+    if (!dict) return bad(ctx, "amx_*_batched: null dictionary");
+    if (n_vox == 0) return AMX_OK;
+    if (n_vox < 0 || !y || !x) return bad(ctx, "amx_*_batched: bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    AMX_H2D(ctx->hy, y, (size_t)n_vox * dict->m * sizeof(double))
+    if (idx) { AMX_H2D(ctx->hdirs, idx, (size_t)n_vox * sizeof(int32_t)) }
+    if ((rc = ensure(ctx, ctx->hest, (size_t)n_vox * dict->n * sizeof(double)))) return rc;
+    if (rnorm && (rc = ensure(ctx, ctx->hrmse, (size_t)n_vox * sizeof(double)))) return rc;
+    if ((rc = batched_dev(ctx, dict, idx ? (const int32_t *)ctx->hdirs.p : nullptr, (const double *)ctx->hy.p, n_vox, lambda1, lambda2, ridge,
+                          (double *)ctx->hest.p, rnorm ? (double *)ctx->hrmse.p : nullptr, nullptr, "amx_*_batched"))) return rc;
+    if ((rc = amx_sync_status(ctx, nullptr))) {
+        if (rc == AMX_E_DIR_OOB) {
+            const int *st = ctx->status_h;
+            char b[256];
+            snprintf(b, sizeof b, "amx_*_batched: dict_idx out of range (%d, dictionaries: %d) [voxel %d]", st[ST_II1], st[ST_II2], st[ST_ERRVOX]);
+            ctx->err = b;
+        }
+        return rc;
+    }
+    HIPCHK(ctx, hipMemcpy(x, ctx->hest.p, (size_t)n_vox * dict->n * sizeof(double), hipMemcpyDeviceToHost));
+    if (rnorm) HIPCHK(ctx, hipMemcpy(rnorm, ctx->hrmse.p, (size_t)n_vox * sizeof(double), hipMemcpyDeviceToHost));
+    return AMX_OK;
+}
+
+int amx_nnls_batched(amx_ctx *ctx, const amx_dict *dict, const int32_t *dict_idx, const double *y, int64_t n_vox, double *x, double *rnorm)
+{
+    return batched_host(ctx, dict, dict_idx, y, n_vox, 0.0, 0.0, false, x, rnorm);
+}
+
+int amx_lasso_batched(amx_ctx *ctx, const amx_dict *dict, const int32_t *dict_idx, const double *y, int64_t n_vox, double lambda1, double lambda2, double *x)
+{
+    return batched_host(ctx, dict, dict_idx, y, n_vox, lambda1, lambda2, true, x, nullptr);
+}
+
+}  // extern "C"
+
+extern "C" {
 
 // ---- public device-pointer entry points: float64 signals, or the float32 the image holds (core.py:136; lossless).  float32 is
 // read in place by the NODDI kernels, by every wavefront-per-voxel kernel and by FreeWater's matrix-core projection; the other
@@ -929,9 +1098,6 @@ int amx_czb_fit_device_f32(amx_ctx *ctx, const amx_lut *lut, const float *d_y, c
 }  // extern "C"
 
 // ------------------------------------------------------------------ host-pointer entry points
-#define AMX_H2D(buf, src, bytes)                                                     \
-    if ((rc = ensure(ctx, buf, bytes))) return rc;                                   \
-    HIPCHK(ctx, hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, nullptr));
 
 // Host buffers in, host buffers out, for all three models and both signal dtypes (float64 = evaluation.y of the
 // reference; float32 = the dtype the image has before core.py:451 casts it -- lossless, half the PCIe bytes).

@@ -78,7 +78,8 @@ struct amx_ctx {
     bool opt_s2_exact = false;     // AMX_S2_EXACT=1: every voxel's stage-2 products by the exact pass (k_noddi_gemm<true>), none derived from the stage-1 table
     bool opt_no_seed = false;      // AMX_NO_SEED=1: Lawson-Hanson from the empty set in the NNLS stages (the round-2 path)
     long long opt_seed_min_voxels = 40960; // AMX_SEED_MIN_VOXELS: smaller calls run the wavefront-per-voxel kernels on all voxels (the seeded chain of ~16 kernels has a floor of ~2 ms; measured crossover between 30 000 and 50 000 voxels: 14.6 vs 16.2 and 23.0 vs 19.4 M voxels/s)
-    long long opt_seed_occ2_from = 400000; // AMX_SEED_OCC2_FROM: calls of at least this many voxels run the two seed solvers at two wavefronts per SIMD (a third more time per trip, twice the wavefronts: wins when the kernel is throughput bound -- 1 M voxels 2.80 -> 2.14 and 1.67 -> 1.28 ms --, loses when the longest voxel's path bounds it: 200 000 voxels 0.93 -> 1.08 ms)
+    long long opt_seed_occ2_from = 250000; // AMX_SEED_OCC2_FROM: calls of at least this many voxels run k_nnls_seed<1> at two wavefronts per SIMD (a third more time per trip, twice the wavefronts: wins when the kernel is throughput bound -- 1 M voxels 2.80 -> 2.14 ms --, loses when the longest voxel's path bounds it: 50 000 voxels 0.54 -> 0.73 ms; with four wavefronts per workgroup the crossover sits between 200 000 and 300 000 voxels)
+    long long opt_seed2_occ2_from = 150000; // AMX_SEED2_OCC2_FROM: the same for k_lasso_seed (200 000 voxels: 0.50 -> 0.42 ms, 1 M: 1.67 -> 1.27 ms)
     int opt_seed_waves = 0;        // AMX_SEED_WAVES: wavefronts per workgroup of the lane kernels (0 = by the number of chunks, make_plan)
     int opt_seed_stages = 7;       // AMX_SEED_STAGES: bit 0 = seed stage 1, bit 1 = seed stage 3, bit 2 = seed the LASSO stage
     int opt_seed_chunk = 0;        // AMX_SEED_CHUNK (0 = by the call's size, make_plan): voxels of one orientation per workgroup of the seed solvers (lanes refill from the chunk: the more voxels per lane, the smaller the share of the tail; 1 M voxels: 1024 -> 7.2 ms, 2048 -> 7.3, 4096 -> 5.5 for stage 1)
@@ -113,10 +114,21 @@ struct amx_lut {
     mutable double fw_lam2 = -1.0;
     mutable int fw_N = 0;
     mutable hipEvent_t fw_ready = nullptr;
+    // CylinderZeppelinBall fast path (amx_czb.hip), per orientation and for one lambda2: M = (A'A + lambda2 I)^-1, M 1, M A'
+    mutable double *czb_prep = nullptr;
+    mutable double czb_lam2 = -1.0;
+    mutable hipEvent_t czb_ready = nullptr;
     // SANDI row-space solver tables (k_sandi_tables) for one (lambda1, lambda2)
     mutable double *sandi_prep = nullptr;
     mutable double sandi_lam1 = -1.0, sandi_lam2 = -1.0;
     mutable hipEvent_t sandi_ready = nullptr;
+};
+
+// dictionaries of the batched solver entry points (amx_nnls_batched / amx_lasso_batched)
+struct amx_dict {
+    amx_ctx *ctx = nullptr;
+    int m = 0, n = 0, ldA = 0, tile_stride = 0, n_dicts = 0;
+    double *tiles = nullptr;       // device f64 [n_dicts][m][ldA] (row-major, odd leading dimension)
 };
 
 // principal-direction estimator of one acquisition scheme (amx_signal.hip)
@@ -183,7 +195,8 @@ struct Plan {
     int max_schunks = 0;
     int seed_chunk = 4096;         // voxels of one orientation per workgroup of the lane kernels (second plan)
     int seed1_waves = 4;           // the same for k_nnls_seed<1> (one wavefront per SIMD: with few voxels per chunk two wavefronts per workgroup keep more lanes busy)
-    bool seed_occ2 = false;        // k_nnls_seed<1> / k_lasso_seed in their two-wavefronts-per-SIMD builds (large calls)
+    bool seed_occ2 = false, seed2_occ2 = false;   // k_nnls_seed<1> / k_lasso_seed in their two-wavefronts-per-SIMD builds (large calls)
+    int seed2_waves = 4;           // wavefronts per workgroup of k_lasso_seed
     int seed_waves = 4;            // wavefronts per workgroup of the lane-per-voxel NODDI kernels (one workgroup per chunk of the second plan)
 };
 
@@ -221,6 +234,9 @@ int amx_launch_noddi_s3(amx_ctx *ctx, amx::NoddiArgs &a, const Plan &pl, hipStre
 int amx_launch_fw(amx_ctx *ctx, amx::FwArgs &a, const Plan &pl, hipStream_t s);
 int amx_launch_sandi(amx_ctx *ctx, amx::SandiArgs &a, const Plan &pl, hipStream_t s);
 int amx_launch_czb(amx_ctx *ctx, amx::CzbArgs &a, const Plan &pl, hipStream_t s);
+int amx_launch_batched(amx_ctx *ctx, amx::BatchedArgs &a, const Plan &pl, hipStream_t s, bool ridge);
+int amx_czb_prepare(amx_ctx *ctx, const amx_lut *lut, double lam2, hipStream_t s);
+int amx_launch_czb_fast(amx_ctx *ctx, const amx_lut *lut, amx::CzbArgs &a, const Plan &pl, hipStream_t s);
 // lane-per-voxel variants for dictionaries of <= 16 atoms (amx_small.hip)
 int amx_launch_fw_small(amx_ctx *ctx, amx::FwArgs &a, const Plan &pl, hipStream_t s);
 int amx_fw_prepare(amx_ctx *ctx, const amx_lut *lut, amx::FwArgs &a, hipStream_t s);

@@ -861,6 +861,85 @@ __global__ void __launch_bounds__(NW * 64) k_czb_qr(const CzbArgs a)
     }
 }
 
+// ------------------------------------------------------------------ the solvers themselves, batched (models.pyx:18: `from cyspams.interfaces
+// cimport nnls, lasso`): one dictionary per voxel chosen by index, the coefficient vector x (and ||A x - y||) out.  RIDGE = false: nnls
+// (lambda1 = lambda2 = 0), true: lasso.  fp64 dictionary tile in LDS, one wavefront per voxel (amx_solver.hpp).
+struct BatchedArgs {
+    FitCommon c;                  // tiles: double [n_dicts][nS][ldA]; lutidx: the dictionary of each voxel
+    double *x;                    // [n_vox][n_atoms]
+    double *rnorm;                // [n_vox] or null
+};
+
+template <int NR, int NQ, int MAXP, bool RIDGE>
+__device__ __forceinline__ void batched_voxel(const BatchedArgs &a, const double *As, double *rs, double *rl, int vox, int lane)
+{
+    const int nS = a.c.nS, ldA = a.c.ldA, n_atoms = a.c.n_atoms;
+    double yr[NR];
+    const bool ok = load_rows<NR>(a.c, vox, nS, lane, yr);
+    bool rowok[NR];
+    double scl[NQ];
+    unsigned long long allowed[NQ];
+#pragma unroll
+    for (int rr = 0; rr < NR; rr++) rowok[rr] = (lane + kWave * rr) < nS;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const int cnt = n_atoms - kWave * q;
+        allowed[q] = cnt >= 64 ? ~0ull : (cnt > 0 ? ((1ull << cnt) - 1ull) : 0ull);
+        scl[q] = 1.0;
+    }
+    double *dst = a.x + (size_t)vox * n_atoms;
+    if (!ok) {                                                // non-finite signal: NaN out, never iterate
+        for (int j = lane; j < n_atoms; j += kWave) dst[j] = __builtin_nan("");
+        if (lane == 0 && a.rnorm) a.rnorm[vox] = __builtin_nan("");
+        return;
+    }
+    NNSolver<NR, NQ, MAXP, RIDGE, double> S;
+    const int st = __builtin_amdgcn_readfirstlane(S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed, RIDGE ? a.c.lam1 : 0.0, RIDGE ? a.c.lam2 : 0.0, rs, rl, lane));
+    if (st == kOverflow) {
+        if (lane == 0) { const int k = atomicAdd(a.c.ovf_count, 1); a.c.ovf_list[k] = vox; }
+        return;
+    }
+    if (st == kIterCap && lane == 0) atomicAdd(&a.c.status[ST_ITCAP], 1);
+    if (st > kIterCap && lane == 0) { atomicAdd(&a.c.status[ST_GUARD], 1); a.c.status[ST_GUARDVOX] = vox * 8 + st; }
+    store_x_dense<NQ>(dst, n_atoms, lane, S.np, S.idx, S.x);
+    if (a.rnorm) {
+        S.residual(yr, RIDGE ? a.c.lam1 : 0.0);
+        double rsq = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) rsq += S.r[rr] * S.r[rr];
+        rsq = wave_sum(rsq);
+        if (lane == 0) a.rnorm[vox] = sqrt(rsq);
+    }
+}
+
+template <int NR, int NQ, int MAXP, int NW, bool RIDGE, bool LIST>
+__global__ void __launch_bounds__(NW * 64) k_batched(const BatchedArgs a)
+{
+    AMX_KERNEL_PROLOGUE(double, NR, NQ, NW, solver_lds_words(false, MAXP, RIDGE))
+    (void)wmask;
+    const double *tiles = reinterpret_cast<const double *>(a.c.tiles);
+    if (!LIST) {
+        const int cid = xcd_chunk((int)blockIdx.x, *a.c.n_chunks);
+        if (cid < 0) return;
+        const Chunk ck = a.c.chunks[cid];
+        unsigned *ticket = reinterpret_cast<unsigned *>(wm_all + nw_ * 4);
+        if (threadIdx.x == 0) *ticket = (unsigned)nw_;
+        stage_tile<double>(As, tiles + (size_t)ck.dir * a.c.tile_stride, words, words_pad - words);
+        __syncthreads();
+        for (int k = wave; k < ck.count; k = next_ticket(ticket, lane))
+            batched_voxel<NR, NQ, MAXP, RIDGE>(a, As, rs, rl, a.c.perm[ck.start + k], lane);
+    } else {
+        const int cnt = *a.c.list_count;
+        for (int it = blockIdx.x; it < cnt; it += gridDim.x) {
+            const int vox = a.c.list[it];
+            __syncthreads();
+            stage_tile<double>(As, tiles + (size_t)a.c.lutidx[vox] * a.c.tile_stride, words, words_pad - words);
+            __syncthreads();
+            batched_voxel<NR, NQ, MAXP, RIDGE>(a, As, rs, rl, vox, lane);
+        }
+    }
+}
+
 template <typename AT>
 static inline size_t fit_lds_bytes(int nS, int ldA, int NR, int NQ, int NW, int MAXP, bool gram = false, bool ridge = true)
 {

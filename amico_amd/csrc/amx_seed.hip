@@ -81,12 +81,12 @@ int amx_launch_noddi_seed2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a,
     }
     const size_t lds = ((size_t)lut->n_wm * (kSeed2KD + 1) + 8 + (size_t)9 * (kSeed2KD / 4) * 64 + (size_t)4 * (64 * (kSeed2KD + 1) + 64 * 3)) * sizeof(double);
     int rc;
-    if (pl.seed_occ2) {
+    if (pl.seed2_occ2) {
         if ((rc = set_lds(ctx, k_lasso_seed<true>, lds))) return rc;
-        hipLaunchKernelGGL(k_lasso_seed<true>, dim3(((pl.max_schunks + 7) / 8) * 8), dim3(64 * pl.seed1_waves), lds, s, sa);
+        hipLaunchKernelGGL(k_lasso_seed<true>, dim3(((pl.max_schunks + 7) / 8) * 8), dim3(64 * pl.seed2_waves), lds, s, sa);
     } else {
         if ((rc = set_lds(ctx, k_lasso_seed<false>, lds))) return rc;
-        hipLaunchKernelGGL(k_lasso_seed<false>, dim3(((pl.max_schunks + 7) / 8) * 8), dim3(64 * pl.seed1_waves), lds, s, sa);
+        hipLaunchKernelGGL(k_lasso_seed<false>, dim3(((pl.max_schunks + 7) / 8) * 8), dim3(64 * pl.seed2_waves), lds, s, sa);
     }
     AMX_TRACE(ctx, s, "LASSO seed solver");
     HIPCHK(ctx, hipGetLastError());

@@ -185,6 +185,37 @@ int amx_set_debug_x(amx_ctx *ctx, double *d_x);
  * dictionary, f64[ndirs][nS][12] / f64[ndirs][n_wm][12] (the seed solver reads the first 8 components) -- into the HOST buffer dst (synchronises the device).              */
 int amx_debug_fetch(amx_ctx *ctx, const amx_lut *lut, int which, void *dst, size_t bytes);
 
+/* ---- the solvers themselves, batched.  What the reference's FFI binds for this path is (models.pyx:18)
+ *     from cyspams.interfaces cimport nnls, lasso
+ *     nnls (&A[0,0], &y[i,0], m, n, &x[0], rnorm)                        models.pyx:911, 940
+ *     lasso(&A[0,0], &y[i,0], m, n, 1, &x[0], lambda1, lambda2)          models.pyx:615, 926, 1238, 1569
+ * one call per voxel, A column-major m x n with leading dimension m (a slice of the LUT), y one signal, x fully written.
+ * A model injected through AMICO_WIP_MODELS (models.pyx:20-26) that writes its own _fit around these two calls reaches the GPU
+ * solvers through the batched forms below: the dictionaries are uploaded once (one per LUT orientation, or a single one), every
+ * voxel names its dictionary by index -- the `lut_idx` the reference computes per voxel (models.pyx:904) -- and all voxels are
+ * solved by one call.
+ *   amx_dict_upload    A f64[n_dicts][n][m]: n_dicts dictionaries, each column-major m x n with leading dimension m
+ *                      (n <= 192 atoms, m <= 256 samples, and m x n doubles must fit the LDS of a compute unit)
+ *   amx_nnls_batched   x_v = argmin_{x >= 0} ||A_d x - y_v||_2,  d = dict_idx[v] (NULL: the single dictionary),
+ *                      Y f64[n_vox][m] -> X f64[n_vox][n] (exact zeros off the support), rnorm f64[n_vox] = ||A x - y||_2 or NULL
+ *   amx_lasso_batched  x_v = argmin_{x >= 0} 1/2 ||y_v - A_d x||^2 + lambda1 sum(x) + lambda2/2 ||x||^2   (SPAMS lasso, mode
+ *                      PENALTY, pos = true: what cyspams.lasso computes for p = 1; any lambda1, lambda2 >= 0)
+ * Lawson-Hanson / its elastic-net form with a thin QR of the passive columns, one wavefront per voxel, strict Kuhn-Tucker stop
+ * (csrc/amx_solver.hpp); a support of more than 48 atoms is beyond it (AMX_E_OVERFLOW -- AMICO's problems end at ~25).  A voxel with a non-finite signal gets NaN; an index outside [0, n_dicts) is reported like a bad
+ * direction (AMX_E_DIR_OOB, the first offending voxel in the message) and its x stays zero.  The *_device forms take device
+ * pointers and a hipStream_t and are asynchronous (amx_sync_status returns the status).                                      */
+typedef struct amx_dict amx_dict;
+int  amx_dict_upload(amx_ctx *ctx, const double *A, int m, int n, int n_dicts, amx_dict **out);
+void amx_dict_destroy(amx_dict *dict);
+int amx_nnls_batched(amx_ctx *ctx, const amx_dict *dict, const int32_t *dict_idx, const double *y, int64_t n_vox,
+                     double *x, double *rnorm);
+int amx_lasso_batched(amx_ctx *ctx, const amx_dict *dict, const int32_t *dict_idx, const double *y, int64_t n_vox,
+                      double lambda1, double lambda2, double *x);
+int amx_nnls_batched_device(amx_ctx *ctx, const amx_dict *dict, const int32_t *d_dict_idx, const double *d_y, int64_t n_vox,
+                            double *d_x, double *d_rnorm, void *hip_stream);
+int amx_lasso_batched_device(amx_ctx *ctx, const amx_dict *dict, const int32_t *d_dict_idx, const double *d_y, int64_t n_vox,
+                             double lambda1, double lambda2, double *d_x, void *hip_stream);
+
 /* ---- next rows of the hot-path table (SURVEY.md section 8 f): the steps either side of model.fit ---- */
 
 /* (f1) principal directions, core.py:431-436 + 456-458:

@@ -1,0 +1,110 @@
+"""The solvers the reference binds -- `from cyspams.interfaces cimport nnls, lasso` (models.pyx:18), called once per voxel as
+nnls(A, y, m, n, x, rnorm) / lasso(A, y, m, n, 1, x, lambda1, lambda2) -- in their batched C-ABI form (amx_nnls_batched,
+amx_lasso_batched): against the oracle's Lawson-Hanson / LARS restatements, scipy's NNLS, and the Kuhn-Tucker conditions of the
+device x itself (the certificate that needs no reference)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _noddi_dictionaries(htable500, n_dirs=12):
+    from amico_amd import synthetic as S
+    sch = S.make_scheme(seed=0)
+    K = S.noddi_kernels(sch, htable500['dirs'])
+    ids = np.arange(0, 500, 500 // n_dirs)[:n_dirs]
+    A = np.stack([np.concatenate([K['wm'][:, d, :].astype(np.float64), K['iso'][None, :].astype(np.float64)], axis=0).T for d in ids])
+    return sch, K, A                                                    # A: [n_dirs, 99, 145]
+
+
+def test_nnls_batched_matches_lawson_hanson(htable500):
+    from scipy.optimize import nnls as scipy_nnls
+    from amico_amd import _capi, get_context
+    from oracle import oracle
+    sch, K, A = _noddi_dictionaries(htable500)
+    rng = np.random.default_rng(3)
+    n = 6000
+    idx = rng.integers(0, A.shape[0], n).astype(np.int32)
+    w = rng.dirichlet(np.ones(3), n)
+    cols = rng.integers(0, A.shape[2], (n, 3))
+    y = np.einsum('vk,vmk->vm', w, np.stack([A[idx, :, cols[:, k]] for k in range(3)], axis=2)) + rng.normal(scale=0.03, size=(n, A.shape[1]))
+    y = np.abs(y)
+    y[7] = 0.0                                                          # all-zero signal: x = 0, rnorm = 0
+    ctx = get_context()
+    dic = _capi.Dict(ctx, A)
+    x, rn = _capi.nnls_batched(ctx, dic, y, idx, return_rnorm=True)
+    assert ctx.last_stats()['itercap_voxels'] == 0 and ctx.last_stats()['overflow_voxels'] == 0
+    assert x.min() >= 0.0 and (x[7] == 0).all() and rn[7] == 0.0
+    wp = wz = 0.0
+    for d in range(A.shape[0]):
+        rows = np.flatnonzero(idx == d)
+        W = (y[rows] - x[rows] @ A[d].T) @ A[d]
+        P = x[rows] > 0
+        wp, wz = max(wp, np.abs(W[P]).max(initial=0.0)), max(wz, W[~P].max(initial=0.0))
+        assert np.abs(np.linalg.norm(y[rows] - x[rows] @ A[d].T, axis=1) - rn[rows]).max() < 1e-12
+    assert wp < 1e-9 and wz < 1e-9, (wp, wz)
+    for v in range(0, n, 40):                                           # the same decisions as Lawson-Hanson: x itself
+        xo, _, _ = oracle.nnls(A[idx[v]], y[v])
+        assert np.abs(x[v] - xo).max() < 1e-7
+        xs, rs = scipy_nnls(A[idx[v]], y[v])
+        assert np.abs(A[idx[v]] @ x[v] - A[idx[v]] @ xs).max() < 1e-8 and abs(rn[v] - rs) < 1e-8
+
+
+@pytest.mark.parametrize('lam1,lam2', [(0.5, 1e-3), (0.3, 5e-3), (0.2, 0.0)])      # (lambda1 = 0 on 144 nearly collinear atoms has a dense optimum: beyond the 48-atom passive set of the wavefront solver -> AMX_E_OVERFLOW, tested below)
+def test_lasso_batched_matches_the_elastic_net(htable500, lam1, lam2):
+    from amico_amd import _capi, get_context
+    from oracle import oracle
+    sch, K, A = _noddi_dictionaries(htable500, 6)
+    dwi = np.asarray(sch.dwi_idx)
+    A2 = A[:, dwi, :144] * K['norms'][0][None, None, :]                 # the stage-2 dictionaries of models.pyx:917-921
+    rng = np.random.default_rng(5)
+    n = 3000
+    idx = rng.integers(0, A2.shape[0], n).astype(np.int32)
+    y = np.abs(A2[idx, :, rng.integers(0, 144, n)] * rng.uniform(0.3, 1.0, (n, 1)) + rng.normal(scale=0.03, size=(n, A2.shape[1])))
+    ctx = get_context()
+    dic = _capi.Dict(ctx, A2)
+    x = _capi.lasso_batched(ctx, dic, y, lam1, lam2, idx)
+    assert ctx.last_stats()['itercap_voxels'] == 0 and ctx.last_stats()['overflow_voxels'] == 0
+    assert x.min() >= 0.0
+    gp = gz = 0.0
+    for d in range(A2.shape[0]):
+        rows = np.flatnonzero(idx == d)
+        G = (y[rows] - x[rows] @ A2[d].T) @ A2[d] - lam2 * x[rows] - lam1
+        P = x[rows] > 0
+        gp, gz = max(gp, np.abs(G[P]).max(initial=0.0)), max(gz, G[~P].max(initial=0.0))
+    assert gp < 1e-9 and gz < 1e-9, (gp, gz)
+    if lam2 > 0:                                                        # strictly convex: x is unique
+        for v in range(0, n, 30):
+            xo = oracle.lasso(A2[idx[v]], y[v], lam1, lam2)[0]
+            assert np.abs(x[v] - xo).max() < 1e-7
+
+
+def test_batched_solvers_single_dictionary_and_errors():
+    from amico_amd import _capi, get_context, synthetic as S
+    from oracle import oracle
+    avg = S.directional_average_scheme(S.make_sandi_scheme())
+    K, Rs, d_in, d_isos = S.sandi_kernels(avg)
+    A = np.asarray(K['signal'], dtype=np.float64)                       # 6 x 15, one dictionary for all voxels
+    y = S.sandi_signals(2000, K, avg, seed=3)
+    ctx = get_context()
+    dic = _capi.Dict(ctx, A)
+    x = _capi.lasso_batched(ctx, dic, y, 0.0, 5e-3)                     # dict_idx = NULL
+    for v in range(0, 2000, 50):
+        assert np.abs(x[v] - oracle.lasso(A, y[v], 0.0, 5e-3)[0]).max() < 1e-8
+    yy = y.copy(); yy[3, 2] = np.nan
+    xn = _capi.nnls_batched(ctx, dic, yy)
+    assert np.isnan(xn[3]).all() and np.isfinite(xn[4]).all()
+    dic2 = _capi.Dict(ctx, np.stack([A, A]))
+    with pytest.raises(ValueError):
+        _capi.nnls_batched(ctx, dic2, y)                                # two dictionaries need an index per voxel
+    bad = np.zeros(2000, dtype=np.int32); bad[11] = 2
+    with pytest.raises(RuntimeError):
+        _capi.nnls_batched(ctx, dic2, y, bad)                           # index out of range: reported with the voxel
+    assert np.abs(_capi.nnls_batched(ctx, dic2, y, np.ones(2000, dtype=np.int32)) - _capi.nnls_batched(ctx, dic, y)).max() == 0.0
+    with pytest.raises(ValueError):
+        _capi.Dict(ctx, np.zeros((300, 10)))                            # m > 256
+    # a dense optimum beyond the solver's passive-set capacity (48 atoms) is an error, never a wrong answer
+    rng = np.random.default_rng(1)
+    Ad = np.abs(rng.normal(size=(60, 100))) + 1.0
+    with pytest.raises(_capi.AmxError):
+        _capi.lasso_batched(ctx, _capi.Dict(ctx, Ad), np.abs(rng.normal(size=(10, 60))) + Ad.sum(axis=1)[None, :], 0.0, 50.0)
