@@ -1,0 +1,19 @@
+#!/bin/bash
+# rocprofv3 evidence of round 3 (seeded NODDI fit): kernel stats + PMC passes of bench.py; bash tools/r04/profile.sh r04a
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+TAG=${1:-r04}
+O=gpurun_out/prof_$TAG
+mkdir -p $O
+B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs"
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/noddi -o noddi -- $B > $O/noddi_bench.log 2>&1
+i=0
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
+           "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_INSTS_SMEM" \
+           "FETCH_SIZE" "WRITE_SIZE" \
+           "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES" \
+           "SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc$i -- $B > $O/pmc$i.log 2>&1
+done
+tail -1 $O/noddi_bench.log | cut -c1-300
