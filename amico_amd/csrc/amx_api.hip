@@ -371,7 +371,9 @@ int amx_lut_upload_noddi(amx_ctx *ctx, const float *wm, const float *iso, const 
             HIPCHK(ctx, hipGetLastError());
             HIPCHK(ctx, hipDeviceSynchronize());
             // compressed basis of every orientation: support seeds of the NNLS stages (amx_seed.hpp)
-            if (!is_exvivo && (rc = amx_build_basis(ctx, lut))) { amx_lut_destroy(lut); return rc; }
+            // (ex-vivo dictionaries too: the dot atom -- a column of ones -- is one more atom; their stage-2 products always take the exact
+            //  pass, s2_derive = 0: y2 = y - x_iso iso - x_dot is not a function of x_iso alone)
+            if ((rc = amx_build_basis(ctx, lut))) { amx_lut_destroy(lut); return rc; }
         }
     }
     *out = lut;

@@ -555,7 +555,7 @@ def noddi_hard_mix(ctx, lut, K, htable, scheme, n, steps, warmup):
     return out
 
 
-def noddi_other_protocol(ctx, shells, n_b0, n, steps, warmup, headline_rate_per_byte):
+def noddi_other_protocol(ctx, shells, n_b0, n, steps, warmup, headline_rate_per_byte, exvivo=False):
     """the NODDI fit on another acquisition protocol (the reference's loop is shape generic, models.pyx:825-828, 851-861): voxels/s,
     the share of the headline's rate per byte of signal, certification rates, parity on a sample"""
     import torch
@@ -567,9 +567,9 @@ def noddi_other_protocol(ctx, shells, n_b0, n, steps, warmup, headline_rate_per_
     scheme = S.make_scheme(n_b0, shells, seed=4)
     K = S.noddi_kernels(scheme, lut_dirs)
     y_h, d_h = S.noddi_signals_parallel(n, K, htable, scheme, seed=17)
-    lut = _capi.upload_noddi(ctx, K, htable, scheme.dwi_idx, False)
+    lut = _capi.upload_noddi(ctx, K, htable, scheme.dwi_idx, exvivo)
     y = torch.from_numpy(y_h).to(dev); d = torch.from_numpy(d_h).to(dev)
-    est = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+    est = torch.zeros((n, 4 if exvivo else 3), dtype=torch.float64, device=dev)
     L = _capi.lib()
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -586,10 +586,11 @@ def noddi_other_protocol(ctx, shells, n_b0, n, steps, warmup, headline_rate_per_
     fit(); ctx.sync(stream)
     stats, seed = ctx.last_stats(), ctx.last_seed_stats()
     pick = np.unique(np.linspace(0, n - 1, min(n, 10000)).astype(np.int64))
-    ref = oracle.noddi_fit(np.ascontiguousarray(y_h[pick]), np.ascontiguousarray(d_h[pick]), K, htable, scheme.dwi_idx, nthreads=physical_cores() or os.cpu_count() or 1)
+    ref = oracle.noddi_fit(np.ascontiguousarray(y_h[pick]), np.ascontiguousarray(d_h[pick]), K, htable, scheme.dwi_idx, is_exvivo=exvivo,
+                           nthreads=physical_cores() or os.cpu_count() or 1)
     diff = np.abs(est.cpu().numpy()[pick] - ref['estimates']).max(axis=1)
     bpv = 8 * scheme.nS + 48
-    out = {'metric': 'voxels/sec, NODDI fit, %d-volume protocol (inputs resident in HBM)' % scheme.nS, 'value': n / el, 'unit': 'voxels/s', 'voxels': n,
+    out = {'metric': 'voxels/sec, NODDI fit, %d-volume protocol%s (inputs resident in HBM)' % (scheme.nS, ', ex-vivo model (dot compartment, 4 maps)' if exvivo else ''), 'value': n / el, 'unit': 'voxels/s', 'voxels': n,
            'ms_per_step': 1e3 * el, 'volumes': int(scheme.nS), 'bytes_per_voxel': bpv,
            'rate_per_byte_vs_headline': (n / el * bpv) / headline_rate_per_byte,
            'solver_stats': stats, 'seed_chain': seed,
@@ -836,6 +837,7 @@ def main():
                 per_byte = value * BYTES_PER_VOXEL
                 other['noddi_105vol'] = noddi_other_protocol(ctx, ((700.0, 50), (2000.0, 50)), 5, min(n, 1_000_000), 5, 2, per_byte)
                 other['noddi_150vol'] = noddi_other_protocol(ctx, ((700.0, 40), (2000.0, 60), (3000.0, 40)), 10, min(n, 1_000_000), 5, 2, per_byte)
+                other['noddi_exvivo'] = noddi_other_protocol(ctx, ((700.0, 30), (2000.0, 60)), 9, min(n, 1_000_000), 5, 2, per_byte, exvivo=True)
             if not args.no_cpu_baseline:
                 # bounded CPU legs on the host cores of this box: the oracle -- a port, the reference's
                 # cyspams path cannot be built -- at -O3 -march=native, the reference's chunk-per-thread structure

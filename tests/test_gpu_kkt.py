@@ -113,7 +113,7 @@ def test_noddi_kkt_certificates_and_supports(htable500, snr, mapping, amx_env):
 def test_noddi_hard_mix_kkt_and_oracle(htable500, exvivo):
     """Signals the dictionary does not explain (synthetic.noddi_hard_signals: crossings, wrong direction, CSF-dominated f_iso in
     [0.5, 1], pure noise, flat, half-zeroed, background, SNR 5 / 15 / 40) through the default path for this size -- the seed ->
-    certificate chain in vivo, the wavefront-per-voxel solvers ex vivo: every voxel's coefficient vectors must satisfy the numpy
+    certificate chain, in vivo and ex vivo (dot atom): every voxel's coefficient vectors must satisfy the numpy
     KKT certificates, and the maps must equal the oracle's.  models.pyx:902-981 takes one path whatever the signal; the
     certificate thresholds of the fast path were tuned on clean single-atom voxels."""
     import torch
@@ -132,8 +132,7 @@ def test_noddi_hard_mix_kkt_and_oracle(htable500, exvivo):
     st, ss = ctx.last_stats(), ctx.last_seed_stats()
     print('hard mix', 'ex vivo' if exvivo else 'in vivo', st, ss)
     assert st['itercap_voxels'] == 0 and st['guard_trips'] == 0 and st['overflow_voxels'] == 0
-    if not exvivo:
-        assert ss['seeded_voxels'] == N_VOX                     # the fast path ran; what it could not certify it handed on
+    assert ss['seeded_voxels'] == N_VOX                         # the fast path ran (ex vivo too); what it could not certify it handed on
     x = xd.cpu().numpy()
     est = est.cpu().numpy()
     c = _noddi_certificates(K, sch, ht, y, d, x, 0.5, 1e-3, exvivo=exvivo)
