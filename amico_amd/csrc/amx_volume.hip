@@ -48,58 +48,16 @@ __global__ __launch_bounds__(64 * kPrepWaves) void k_prep_gather(PrepArgs a)
     float *T = smf + (size_t)wave * per_wave;
     float *O = a.inplace ? T : T + 64 * a.ldt;
     const long long wave_id = (long long)blockIdx.x * kPrepWaves + wave, n_waves = (long long)gridDim.x * kPrepWaves;
-    // Planar images of up to kPrepRegs volumes: the NEXT tile's values are loaded into registers while the current tile's rows are
-    // being stored (round 4) -- a tile is a load phase and a store phase, and with two or three wavefronts per CU (the LDS tile)
-    // nothing else overlaps the two directions: float32 rows out took the same time as float64 rows, i.e. the kernel was bound by
-    // the serial phases, not by bytes.
-    constexpr int kPrepRegs = 128;
-    const bool piped = a.layout != 2 && a.nS <= kPrepRegs;
-    float nxt[kPrepRegs];
-    int r_nxt = -1;
-    unsigned long long live_nxt = 0ull;
-    long long t_nxt = wave_id;
-    auto tile_rank = [&](long long t, int &r, unsigned long long &live, long long &base) {
+    for (long long t = wave_id; t < a.n_tiles; t += n_waves) {
         const long long row = t / a.tiles_per_row;
         const long long x0 = (t - row * a.tiles_per_row) * 64;
         const long long i2 = row / a.d1, i1 = row - i2 * a.d1;
         const long long x = x0 + lane;
-        r = x < a.d0 ? a.rank[(i2 * a.d1 + i1) * a.d0 + x] : -1;
-        live = __ballot(r >= 0);
-        base = x0 * a.s0 + i1 * a.s1 + i2 * a.s2;
-    };
-    auto prefetch = [&]() {
-        // the next tile of this wavefront that has a voxel in the mask: its rank, and its values on the way into registers
-        live_nxt = 0ull; r_nxt = -1;
-        for (; t_nxt < a.n_tiles; t_nxt += n_waves) {
-            long long base;
-            tile_rank(t_nxt, r_nxt, live_nxt, base);
-            if (live_nxt == 0ull) continue;
-            if (r_nxt >= 0) {
-                const float *src = a.img + base + lane * a.s0;
-#pragma unroll
-                for (int v = 0; v < kPrepRegs; v++) nxt[v] = (v < a.nS) ? src[(long long)v * a.sv] : 0.0f;
-            }
-            break;
-        }
-    };
-    if (piped) prefetch();
-    for (long long t = wave_id; t < a.n_tiles; t += n_waves) {
-        int r; unsigned long long live; long long base;
-        float *row_l = T + lane * a.ldt;
-        if (piped) {
-            if (t_nxt >= a.n_tiles) break;
-            t = t_nxt; r = r_nxt; live = live_nxt;
-            if (r >= 0) {
-#pragma unroll
-                for (int v = 0; v < kPrepRegs; v++) if (v < a.nS) row_l[v] = nxt[v];
-            }
-            t_nxt += n_waves;
-            WAVE_SYNC();
-            prefetch();                                   // (not waited for before the next trip's LDS writes)
-            base = 0;
-        } else {
-        tile_rank(t, r, live, base);
+        const int r = x < a.d0 ? a.rank[(i2 * a.d1 + i1) * a.d0 + x] : -1;
+        const unsigned long long live = __ballot(r >= 0);
         if (live == 0ull) continue;
+        const long long base = x0 * a.s0 + i1 * a.s1 + i2 * a.s2;
+        float *row_l = T + lane * a.ldt;
         if (a.layout == 2) {
             // interleaved: lanes run over the volumes of one voxel; sixteen rows in flight
             for (int k = 0; k < 64; k += 16) {
@@ -133,7 +91,6 @@ __global__ __launch_bounds__(64 * kPrepWaves) void k_prep_gather(PrepArgs a)
             for (; v < a.nS; v++) row_l[v] = src[(long long)v * a.sv];
         }
         WAVE_SYNC();
-        }
         float f = 1.0f;
         if (r >= 0) {
             if (a.normalize) {
