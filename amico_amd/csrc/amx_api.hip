@@ -58,6 +58,7 @@ int make_plan(amx_ctx *ctx, int64_t n, int ndirs, Plan &pl, bool seeds = false, 
         if ((rc = ensure(ctx, ctx->cgemm, ((size_t)n / 64 + ndirs + 1) * table_rows * 64 * sizeof(double)))) return rc;
         if ((rc = ensure(ctx, ctx->cgemm2, ((size_t)n / 64 + ndirs + 1) * table_rows * 64 * sizeof(double)))) return rc;
         if ((rc = ensure(ctx, ctx->clip, ((size_t)2 * n + pl.max_schunks + 64) * sizeof(int)))) return rc;
+        if ((rc = ensure(ctx, ctx->feed, (size_t)3 * (pl.max_schunks + 8) * sizeof(int)))) return rc;      // chunk counters of the three seed solvers (SeedFeed)
         if ((rc = ensure(ctx, ctx->done, (size_t)n + 64))) return rc;
         if ((rc = ensure(ctx, ctx->rlist, 2 * amx_rlist_half(pl) * sizeof(int)))) return rc;
         if ((rc = ensure(ctx, ctx->ytil2, (size_t)n * amx::kSeedKD * sizeof(double)))) return rc;
@@ -262,7 +263,7 @@ void amx_ctx_destroy(amx_ctx *ctx)
     hipDeviceSynchronize();
     DevBuf *bufs[] = {&ctx->lutidx, &ctx->perm, &ctx->counts, &ctx->dir_start, &ctx->cursor, &ctx->chunks,
                       &ctx->misc, &ctx->xiso, &ctx->supp, &ctx->ovf, &ctx->cproj, &ctx->hy, &ctx->hdirs, &ctx->hest,
-                      &ctx->hrmse, &ctx->hnrmse, &ctx->hextra, &ctx->hy32, &ctx->wy, &ctx->ytil, &ctx->seeds, &ctx->schunks, &ctx->ytil2, &ctx->seeds2, &ctx->cgemm, &ctx->done, &ctx->rlist, &ctx->cgemm2, &ctx->clip};
+                      &ctx->hrmse, &ctx->hnrmse, &ctx->hextra, &ctx->hy32, &ctx->wy, &ctx->ytil, &ctx->seeds, &ctx->schunks, &ctx->ytil2, &ctx->seeds2, &ctx->cgemm, &ctx->done, &ctx->rlist, &ctx->cgemm2, &ctx->clip, &ctx->feed};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     for (DevBuf &b : ctx->alt) if (b.p) hipFree(b.p);
     if (ctx->status_d) hipFree(ctx->status_d);

@@ -25,7 +25,7 @@ struct amx_ctx {
     int n_cu = 256;                // compute units of the device (persistent-grid launches)
     std::string err;
     // stream-ordered workspace (grow-only)
-    DevBuf lutidx, perm, counts, dir_start, cursor, chunks, misc, xiso, supp, ovf, cproj, ytil, seeds, schunks, ytil2, seeds2, cgemm, done, rlist, cgemm2, clip;
+    DevBuf lutidx, perm, counts, dir_start, cursor, chunks, misc, xiso, supp, ovf, cproj, ytil, seeds, schunks, ytil2, seeds2, cgemm, done, rlist, cgemm2, clip, feed;
     DevBuf hy, hdirs, hest, hrmse, hnrmse, hextra;   // staging for the host-pointer entry points
     int *status_d = nullptr;       // ST_WORDS ints
     int *status_h = nullptr;       // pinned mirror (+16 words: copy of the misc counters)
@@ -48,11 +48,11 @@ struct amx_ctx {
     hipStream_t hs2 = nullptr;     // between the two, so the tail of one batch's kernels is filled by the next batch's
     hipEvent_t hev[3] = {nullptr, nullptr, nullptr};
     // second workspace set for the batch in flight on the other stream (swap_work exchanges it with the named buffers)
-    DevBuf alt[21];
+    DevBuf alt[22];
     void swap_work()
     {
-        DevBuf *named[21] = {&lutidx, &perm, &counts, &dir_start, &cursor, &chunks, &misc, &xiso, &supp, &ovf, &cproj, &ytil, &seeds, &schunks, &ytil2, &seeds2, &cgemm, &done, &rlist, &cgemm2, &clip};
-        for (int i = 0; i < 21; i++) { DevBuf t = *named[i]; *named[i] = alt[i]; alt[i] = t; }
+        DevBuf *named[22] = {&lutidx, &perm, &counts, &dir_start, &cursor, &chunks, &misc, &xiso, &supp, &ovf, &cproj, &ytil, &seeds, &schunks, &ytil2, &seeds2, &cgemm, &done, &rlist, &cgemm2, &clip, &feed};
+        for (int i = 0; i < 22; i++) { DevBuf t = *named[i]; *named[i] = alt[i]; alt[i] = t; }
     }
     // switches read ONCE, at amx_ctx_create (environment): diagnosis / A-B only
     // switches below: environment variables read ONCE, at amx_ctx_create (diagnosis / A-B tools; the defaults are the product path)

@@ -81,6 +81,8 @@ int amx_launch_noddi_seed2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a,
     }
     const size_t lds = ((size_t)lut->n_wm * (kSeed2KD + 1) + 8 + (size_t)9 * (kSeed2KD / 4) * 64 + (size_t)4 * (64 * (kSeed2KD + 1) + 64 * 3)) * sizeof(double);
     int rc;
+    sa.gcount = (int *)ctx->feed.p + (size_t)(pl.max_schunks + 8); sa.n_gcount = pl.max_schunks;       // (second of the three counter sets)
+    HIPCHK(ctx, hipMemsetAsync(sa.gcount, 0, (size_t)(pl.max_schunks + 1) * sizeof(int), s));
     if (pl.seed2_occ2) {
         if ((rc = set_lds(ctx, k_lasso_seed<true>, lds))) return rc;
         hipLaunchKernelGGL(k_lasso_seed<true>, dim3(((pl.max_schunks + 7) / 8) * 8), dim3(64 * pl.seed2_waves), lds, s, sa);
@@ -285,6 +287,8 @@ int amx_launch_noddi_seed(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, 
                        (stage == 1 ? ((size_t)10 * (kSeedKD / 4) * 64 + (size_t)4 * 64 * (kSeedKD + 1)) * sizeof(double) : 0);
     const dim3 grid(((pl.max_schunks + 7) / 8) * 8);
     int rc;
+    sa.gcount = (int *)ctx->feed.p + (stage == 1 ? 0 : 2) * (size_t)(pl.max_schunks + 8); sa.n_gcount = pl.max_schunks;
+    HIPCHK(ctx, hipMemsetAsync(sa.gcount, 0, (size_t)(pl.max_schunks + 1) * sizeof(int), s));
     if (stage == 1 && pl.seed_occ2) {
         if ((rc = set_lds(ctx, (k_nnls_seed<1, 8, true>), lds))) return rc;
         hipLaunchKernelGGL((k_nnls_seed<1, 8, true>), grid, dim3(64 * pl.seed1_waves), lds, s, sa);

@@ -157,6 +157,8 @@ struct SeedArgs {
     unsigned long long *seeds;    // [n_vox], bucket order: up to 8 atom ids, one per byte, 0xff = empty; kNoSeed = none
     const unsigned long long *supp;   // stage 3: [n_vox][4] stage-2 support bit set (voxel order), null for stage 1
     int nS, n_atoms, iso_atom, dot_atom;
+    int *gcount;                  // [max_schunks + 1]: voxels of each chunk handed out so far (zeroed before the launch); last: helpers
+    int n_gcount;
     int *stats;                   // optional counters (AMX_STATS): [0] trips, [1] lane-trips in use, [2] voxels, [3] no-seed voxels
 };
 
@@ -442,6 +444,75 @@ struct SeedLane {
     }
 };
 
+// How the lanes of the seed solvers get their voxels (round 4).  A chunk's voxels are handed out from a GLOBAL counter of the chunk in
+// private blocks per wavefront (64 voxels, 16 near the chunk's end): inside a block a take is register arithmetic, and -- the point --
+// several workgroups can work on ONE chunk.  One workgroup per orientation chunk fills the chip exactly once (~500 chunks on 512
+// slots), so a launch used to last as long as its LARGEST chunk (1.15 x the mean at 1 M voxels, more on real data); now a workgroup
+// whose chunk is exhausted joins the largest chunks that still have voxels (the chunk list is in order of decreasing size), staging
+// that orientation's tables again.  Every decision of a lane still depends on its own voxel only: results are bit-identical.
+struct SeedFeed {
+    int lo, hi;                   // this wavefront's block [lo, hi) of the chunk's voxels (wave-uniform)
+    bool more;                    // the chunk's counter may still have voxels beyond it
+    int left;                     // voxels left in the chunk at the last fetch
+    __device__ __forceinline__ void reset() { lo = 0; hi = 0; more = true; left = 1 << 30; }
+    __device__ __forceinline__ bool pending() const { return more || lo < hi; }
+    // the lanes of `needm` want a voxel: this lane's voxel number within the chunk, or -1 (served next trip, or none left)
+    __device__ __forceinline__ int take(unsigned long long needm, int *gcount, int count, int lane)
+    {
+        int mine = -1;
+        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(needm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)needm, 0u));
+        int served = 0;                         // lanes of needm (in rank order) that have their voxel
+        const int want_n = __builtin_popcountll(needm);
+#pragma unroll 1
+        for (int pass = 0; pass < 2; pass++) {
+            if (lo == hi && more) {
+                // blocks of 64 voxels; near the chunk's end smaller ones, so that the wavefronts (and workgroups) working on it end together
+                const int want = left > 1024 ? 64 : (left > 256 ? 32 : 16);
+                int old = 0;
+                if (lane == 0) old = atomicAdd(gcount, want);
+                old = __builtin_amdgcn_readfirstlane(old);
+                lo = old < count ? old : count;
+                hi = old + want < count ? old + want : count;
+                left = count - hi;
+                if (hi >= count) more = false;
+            }
+            const int have_n = hi - lo, todo = want_n - served;
+            const int give = todo < have_n ? todo : have_n;
+            if (((needm >> lane) & 1ull) && rank >= served && rank < served + give) mine = lo + (rank - served);
+            lo += give; served += give;
+            if (served >= want_n || !more) break;
+        }
+        return mine;
+    }
+};
+
+// the chunk a workgroup works on next: its own first, then -- once that is exhausted -- the largest chunks that still have voxels
+// (steal[0] counts the helpers; the p-th dispatched workgroup's chunk is the p-th largest: k_order_schunks)
+__device__ __forceinline__ int seed_next_chunk(int round, int own, const Chunk *schunks, int n_schunks, const int *gcount, int *steal, int *lds_slot, int min_left)
+{
+    if (round == 0) return own;
+#ifdef AMX_SEED_NO_STEAL
+    return -1;
+#endif
+    if (threadIdx.x == 0) {
+        int pick = -1;
+        for (int tries = 0; tries < 12 && pick < 0; tries++) {
+            const int h = atomicAdd(steal, 1);
+            const int per = (n_schunks + 7) >> 3;
+            if (h >= 8 * per) break;
+            const int cand = xcd_chunk(h, n_schunks);
+            if (cand < 0) continue;
+            const int left = schunks[cand].count - __hip_atomic_load(&gcount[cand], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (left >= min_left) pick = cand;
+        }
+        *lds_slot = pick;
+    }
+    __syncthreads();
+    const int pick = *lds_slot;
+    __syncthreads();
+    return pick;
+}
+
 // STAGE 1: all atoms are candidates; STAGE 3: the atoms of the stage-2 support plus iso (dot)
 // (MS = 8: the compiler needs ~540 registers for this kernel; at two wavefronts per SIMD it spilled 290 of them and the kernel moved
 //  27 GB + 9 GB of scratch per 1 M voxels (rocprofv3 FETCH_SIZE / WRITE_SIZE) -- at one wavefront per SIMD, with the accumulation
@@ -469,10 +540,22 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
     static_assert(KD % 4 == 0, "whole K-steps");
     double *Aop = reinterpret_cast<double *>(ticket + 4);
     double *Rb = Aop + (STAGE == 1 ? MT * KS * 64 : 0) + (threadIdx.x >> 6) * (64 * KDP);
-    const int cid = xcd_chunk((int)blockIdx.x, *a.n_schunks);
-    if (cid < 0) return;
-    const Chunk ck = a.schunks[cid];
+    const int n_sch = *a.n_schunks;
+    const int own = xcd_chunk((int)blockIdx.x, n_sch);
+    if (own < 0) return;
     const int lane = threadIdx.x & 63;
+#ifdef AMX_STATS
+    int st_trips = 0, st_used = 0;
+    long long ph[6] = {0, 0, 0, 0, 0, 0}, pt = (long long)__builtin_readcyclecounter();
+#define SEED_PH(k) do { const long long t__ = (long long)__builtin_readcyclecounter(); ph[k] += t__ - pt; pt = t__; } while (0)
+#else
+#define SEED_PH(k) do { } while (0)
+#endif
+    // the workgroup's own chunk first, then the largest chunks that still have voxels (SeedFeed)
+    for (int round = 0; round < 256; round++) {
+    const int cid = seed_next_chunk(round, own, a.schunks, n_sch, a.gcount, a.gcount + a.n_gcount, reinterpret_cast<int *>(ticket), 32 * (int)(blockDim.x >> 6));
+    if (cid < 0) break;
+    const Chunk ck = a.schunks[cid];
     const double *__restrict__ Sg = a.Sb + (size_t)ck.dir * n_atoms * KD;
     for (int e = threadIdx.x; e < n_atoms * KD; e += blockDim.x) { const int j = e / KD, d = e - j * KD; Sl[j * LD + d] = Sg[e]; }
     if (STAGE == 1) {
@@ -482,7 +565,6 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
             Aop[e] = (atom < n_atoms) ? Sg[(size_t)atom * KD + d] : 0.0;
         }
     }
-    if (threadIdx.x == 0) *ticket = 0u;
     __syncthreads();
     const double tol = 1e-10, inf = __builtin_huge_val();
     constexpr int trip_cap = 64;
@@ -494,14 +576,8 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
     unsigned long long allow[STAGE == 3 ? 4 : 1];
     unsigned long long cand[STAGE == 3 ? 4 : 1];      // stage 3: the voxel's admissible atoms as a byte list (<= 32), made once per voxel
     int ncand = 0;
-    bool more = true;
-#ifdef AMX_STATS
-    int st_trips = 0, st_used = 0;
-    long long ph[6] = {0, 0, 0, 0, 0, 0}, pt = (long long)__builtin_readcyclecounter();
-#define SEED_PH(k) do { const long long t__ = (long long)__builtin_readcyclecounter(); ph[k] += t__ - pt; pt = t__; } while (0)
-#else
-#define SEED_PH(k) do { } while (0)
-#endif
+    SeedFeed feed;
+    feed.reset();
     // Stage 1 (one wavefront per SIMD, registers to spare): the voxel's y~ stays in registers, and a lane RESERVES its next voxel
     // while it works on the current one -- the 12 loads of the next y~ are in flight for a whole solve instead of being waited
     // for in every trip in which some lane of the wavefront refills (measured: 15 % of the kernel).
@@ -531,15 +607,9 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
                 else a.seeds[pos] = kNoSeed;
             }
             const unsigned long long needm = __ballot(!have_next);
-            if (needm != 0ull && more) {
-                const int nneed = __builtin_popcountll(needm);
-                unsigned base = 0u;
-                if (lane == 0) base = atomicAdd(ticket, (unsigned)nneed);
-                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-                if ((int)base + nneed >= ck.count) more = false;
-                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(needm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)needm, 0u));
-                const int k = (int)base + rank;
-                if (!have_next && k < ck.count) {
+            if (needm != 0ull && feed.pending()) {
+                const int k = feed.take(needm, a.gcount + cid, ck.count, lane);
+                if (k >= 0) {
                     next_pos = ck.start + k; have_next = true;
                     const double *yp = a.ytil + (size_t)next_pos * KD;
 #pragma unroll
@@ -554,20 +624,14 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
                 }
             }
             if (__ballot(active) == 0ull) {
-                if (!more && __ballot(have_next) == 0ull) break;
+                if (!feed.pending() && __ballot(have_next) == 0ull) break;
                 continue;
             }
         } else {
         const unsigned long long freem = __ballot(!active);
-        if (freem != 0ull && more) {
-            const int nfree = __builtin_popcountll(freem);
-            unsigned base = 0u;
-            if (lane == 0) base = atomicAdd(ticket, (unsigned)nfree);
-            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-            if ((int)base + nfree >= ck.count) more = false;
-            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(freem >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)freem, 0u));
-            const int k = (int)base + rank;
-            if (!active && k < ck.count) {
+        if (freem != 0ull && feed.pending()) {
+            const int k = feed.take(freem, a.gcount + cid, ck.count, lane);
+            if (k >= 0) {
                 pos = ck.start + k;
                 const double *yp = a.ytil + (size_t)pos * KD;
                 bool finite = true;
@@ -588,7 +652,7 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
             }
         }
         if (__ballot(active) == 0ull) {
-            if (!more) break;
+            if (!feed.pending()) break;
             continue;
         }
         }
@@ -807,6 +871,8 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
             active = false;
         }
         SEED_PH(5);
+    }
+    __syncthreads();                          // every wavefront is through with this chunk's tables
     }
 #ifdef AMX_STATS
     if (a.stats && lane == 0) {
@@ -1738,6 +1804,8 @@ struct Seed2Args {
     unsigned long long *seeds;    // [n_vox][4], bucket order: passive-set bits; word 3 = all ones: no seed
     int nS, n_wm, iso_atom, is_exvivo;
     double lam1, lam2;
+    int *gcount;                  // [max_schunks + 1]: see SeedArgs
+    int n_gcount;
     int *stats;
     double *trace;                // SEED2_TRACE: per-trip records of the voxel at bucket position 0
 };
@@ -1812,11 +1880,19 @@ __global__ void __launch_bounds__(256, OCC2 ? 2 : AMX_SEED2_OCC) k_lasso_seed(co
     double *Aop = reinterpret_cast<double *>(ticket + 4);         // [MT][KS][64] in MFMA operand order
     double *Rb = Aop + MT * KS * 64 + (threadIdx.x >> 6) * (64 * KDP + 64 * 3);
     unsigned long long *Pb = reinterpret_cast<unsigned long long *>(Rb + 64 * KDP);      // [64][3] passive-set bits of the lanes' voxels
-    const int cid = xcd_chunk((int)blockIdx.x, *a.n_schunks);
-    if (cid < 0) return;
-    const Chunk ck = a.schunks[cid];
+    const int n_sch = *a.n_schunks;
+    const int own = xcd_chunk((int)blockIdx.x, n_sch);
+    if (own < 0) return;
     const int lane = threadIdx.x & 63, q = lane >> 4, c16 = lane & 15;
     constexpr int SLD = kSeed2Ld;
+#ifdef AMX_STATS
+    int st_trips = 0, st_used = 0;
+#endif
+    // the workgroup's own chunk first, then the largest chunks that still have voxels (SeedFeed)
+    for (int round = 0; round < 256; round++) {
+    const int cid = seed_next_chunk(round, own, a.schunks, n_sch, a.gcount, a.gcount + a.n_gcount, reinterpret_cast<int *>(ticket), 32 * (int)(blockDim.x >> 6));
+    if (cid < 0) break;
+    const Chunk ck = a.schunks[cid];
     const double *__restrict__ Sg = a.Sb + (size_t)ck.dir * n_wm * SLD;
     for (int e = threadIdx.x; e < n_wm * KD; e += blockDim.x) { const int j = e / KD, d = e - j * KD; Sl[j * LD + d] = Sg[(size_t)j * SLD + d]; }
     for (int e = threadIdx.x; e < MT * KS * 64; e += blockDim.x) {
@@ -1824,7 +1900,6 @@ __global__ void __launch_bounds__(256, OCC2 ? 2 : AMX_SEED2_OCC) k_lasso_seed(co
         const int atom = 16 * mt + (l & 15), d = 4 * ks + (l >> 4);
         Aop[e] = (atom < n_wm) ? Sg[(size_t)atom * SLD + d] : 0.0;
     }
-    if (threadIdx.x == 0) *ticket = 0u;
     __syncthreads();
     const double lam1 = a.lam1, lam2 = a.lam2, tol = 1e-9, inf = __builtin_huge_val();
     const double sl2 = sqrt(lam2), isl2 = 1.0 / sl2;
@@ -1838,10 +1913,8 @@ __global__ void __launch_bounds__(256, OCC2 ? 2 : AMX_SEED2_OCC) k_lasso_seed(co
     for (int e = 0; e < NT; e++) T[e] = 0.0;
 #pragma unroll
     for (int d = 0; d < KD; d++) { dinv[d] = 0.0; g[d] = 0.0; }
-    bool more = true;
-#ifdef AMX_STATS
-    int st_trips = 0, st_used = 0;
-#endif
+    SeedFeed feed;
+    feed.reset();
     // (one wavefront per SIMD: y~ of the voxel in registers, the next voxel reserved -- and its y~ loading -- one solve ahead, as in
     //  k_nnls_seed<1>)
     constexpr bool PREF2 = !OCC2 && AMX_SEED2_OCC == 1;       // (see k_nnls_seed: 1 M voxels 1.67 -> 1.28 ms at two wavefronts per SIMD)
@@ -1868,15 +1941,9 @@ __global__ void __launch_bounds__(256, OCC2 ? 2 : AMX_SEED2_OCC) k_lasso_seed(co
         }
         {
             const unsigned long long needm = __ballot(!have_next);
-            if (needm != 0ull && more) {
-                const int nneed = __builtin_popcountll(needm);
-                unsigned base = 0u;
-                if (lane == 0) base = atomicAdd(ticket, (unsigned)nneed);
-                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-                if ((int)base + nneed >= ck.count) more = false;
-                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(needm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)needm, 0u));
-                const int k = (int)base + rank;
-                if (!have_next && k < ck.count) {
+            if (needm != 0ull && feed.pending()) {
+                const int k = feed.take(needm, a.gcount + cid, ck.count, lane);
+                if (k >= 0) {
                     next_pos = ck.start + k; have_next = true;
                     const double *yp = a.ytil + (size_t)next_pos * SLD;
 #pragma unroll
@@ -1885,22 +1952,16 @@ __global__ void __launch_bounds__(256, OCC2 ? 2 : AMX_SEED2_OCC) k_lasso_seed(co
             }
         }
         if (__ballot(active) == 0ull) {
-            if (!more && __ballot(have_next) == 0ull) break;
+            if (!feed.pending() && __ballot(have_next) == 0ull) break;
             continue;
         }
         } else {
             // two wavefronts per SIMD: no voxel reserved ahead (its 8 values would cost 16 registers for a whole solve) -- the
             // other wavefront of the SIMD covers the load
             const unsigned long long freem = __ballot(!active);
-            if (freem != 0ull && more) {
-                const int nfree = __builtin_popcountll(freem);
-                unsigned base = 0u;
-                if (lane == 0) base = atomicAdd(ticket, (unsigned)nfree);
-                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-                if ((int)base + nfree >= ck.count) more = false;
-                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(freem >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)freem, 0u));
-                const int k = (int)base + rank;
-                if (!active && k < ck.count) {
+            if (freem != 0ull && feed.pending()) {
+                const int k = feed.take(freem, a.gcount + cid, ck.count, lane);
+                if (k >= 0) {
                     pos = ck.start + k;
                     const double *yp = a.ytil + (size_t)pos * SLD;
                     bool finite = true;
@@ -1919,7 +1980,7 @@ __global__ void __launch_bounds__(256, OCC2 ? 2 : AMX_SEED2_OCC) k_lasso_seed(co
                 }
             }
             if (__ballot(active) == 0ull) {
-                if (!more) break;
+                if (!feed.pending()) break;
                 continue;
             }
         }
@@ -2109,6 +2170,8 @@ __global__ void __launch_bounds__(256, OCC2 ? 2 : AMX_SEED2_OCC) k_lasso_seed(co
             sd[0] = P[0]; sd[1] = P[1]; sd[2] = P[2]; sd[3] = noseed ? ~0ull : 0ull;
             active = false;
         }
+    }
+    __syncthreads();                          // every wavefront is through with this chunk's tables
     }
 #ifdef AMX_STATS
     if (a.stats && lane == 0) { atomicAdd(&a.stats[0], st_trips); atomicAdd(&a.stats[1], st_used); }
