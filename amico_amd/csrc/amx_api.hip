@@ -58,12 +58,13 @@ int make_plan(amx_ctx *ctx, int64_t n, int ndirs, Plan &pl, bool seeds = false, 
         if ((rc = ensure(ctx, ctx->cgemm, ((size_t)n / 64 + ndirs + 1) * table_rows * 64 * sizeof(double)))) return rc;
         if ((rc = ensure(ctx, ctx->cgemm2, ((size_t)n / 64 + ndirs + 1) * table_rows * 64 * sizeof(double)))) return rc;
         if ((rc = ensure(ctx, ctx->clip, ((size_t)2 * n + pl.max_schunks + 64) * sizeof(int)))) return rc;
-        if ((rc = ensure(ctx, ctx->feed, (size_t)3 * (pl.max_schunks + 8) * sizeof(int)))) return rc;      // chunk counters of the three seed solvers (SeedFeed)
+        if ((rc = ensure(ctx, ctx->feed, (size_t)kFeedSets * (pl.max_schunks + 8) * sizeof(int)))) return rc;      // chunk counters of the kernels that share their chunks (SeedFeed, BlockFeed)
         if ((rc = ensure(ctx, ctx->done, (size_t)n + 64))) return rc;
         if ((rc = ensure(ctx, ctx->rlist, 2 * amx_rlist_half(pl) * sizeof(int)))) return rc;
         if ((rc = ensure(ctx, ctx->ytil2, (size_t)n * amx::kSeedKD * sizeof(double)))) return rc;
         if ((rc = ensure(ctx, ctx->seeds2, (size_t)n * 4 * sizeof(unsigned long long)))) return rc;
         pl.schunks = (Chunk *)ctx->schunks.p;
+        pl.feed = (int *)ctx->feed.p;
     }
     if (!seeds && blocks_chunk > 0) {
         // second plan only (chunks of whole 64-voxel blocks) + a block-wise table of table_rows rows: CylinderZeppelinBall's fast path
@@ -94,6 +95,7 @@ int enqueue_bucketing(amx_ctx *ctx, const amx_lut *lut, const double *d_dirs, in
 {
     HIPCHK(ctx, hipMemsetAsync(pl.counts, 0, (size_t)(lut->ndirs + 1) * sizeof(int), s));
     HIPCHK(ctx, hipMemsetAsync(ctx->misc.p, 0, 64 * sizeof(int), s));
+    if (pl.feed) HIPCHK(ctx, hipMemsetAsync(pl.feed, 0, (size_t)kFeedSets * (pl.max_schunks + 8) * sizeof(int), s));
     const int nb = (int)((n + kPrepSpan - 1) / kPrepSpan);
     const int use_lds = lut->ndirs <= 8192 ? 1 : 0;          // LDS histograms: 2 * ndirs ints
     hipLaunchKernelGGL(k_dir_to_lut, dim3(nb), dim3(1024), use_lds ? (size_t)lut->ndirs * sizeof(int) : 0, s, d_dirs,

@@ -199,7 +199,10 @@ struct Plan {
     bool seed_occ2 = false, seed2_occ2 = false;   // k_nnls_seed<1> / k_lasso_seed in their two-wavefronts-per-SIMD builds (large calls)
     int seed2_waves = 4;           // wavefronts per workgroup of k_lasso_seed
     int seed_waves = 4;            // wavefronts per workgroup of the lane-per-voxel NODDI kernels (one workgroup per chunk of the second plan)
+    int *feed = nullptr;           // kFeedSets sets of max_schunks + 8 chunk counters, one per kernel that shares its chunks (zeroed with the plan)
+    int *feed_set(int k) const { return feed + (size_t)k * (max_schunks + 8); }
 };
+enum { FEED_SEED1 = 0, FEED_SEED2, FEED_SEED3, FEED_GEMM, FEED_CERT1, FEED_CERT2, FEED_CERT3, kFeedSets };
 
 // AMX_DEBUG=1: synchronise after every launch and trace progress on stderr
 static inline bool amx_debug() { static int d = -1; if (d < 0) { const char *e = getenv("AMX_DEBUG"); d = (e && *e && *e != '0') ? 1 : 0; } return d == 1; }

@@ -81,8 +81,7 @@ int amx_launch_noddi_seed2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a,
     }
     const size_t lds = ((size_t)lut->n_wm * (kSeed2KD + 1) + 8 + (size_t)9 * (kSeed2KD / 4) * 64 + (size_t)4 * (64 * (kSeed2KD + 1) + 64 * 3)) * sizeof(double);
     int rc;
-    sa.gcount = (int *)ctx->feed.p + (size_t)(pl.max_schunks + 8); sa.n_gcount = pl.max_schunks;       // (second of the three counter sets)
-    HIPCHK(ctx, hipMemsetAsync(sa.gcount, 0, (size_t)(pl.max_schunks + 1) * sizeof(int), s));
+    sa.gcount = pl.feed_set(FEED_SEED2); sa.n_gcount = pl.max_schunks;
     if (pl.seed2_occ2) {
         if ((rc = set_lds(ctx, k_lasso_seed<true>, lds))) return rc;
         hipLaunchKernelGGL(k_lasso_seed<true>, dim3(((pl.max_schunks + 7) / 8) * 8), dim3(64 * pl.seed2_waves), lds, s, sa);
@@ -113,7 +112,7 @@ static void fill(SeedArgs &sa, const amx_lut *lut, const NoddiArgs &a, const Pla
 static size_t gemm_lds(int n_cols, int rows, int ks)
 {
     const int mtf = n_cols / 16, mt = rows / 16;
-    return (size_t)mtf * ks * 64 * sizeof(float) + ((size_t)(mt - mtf) * ks * 64 + 4 * ks + rows) * sizeof(double);
+    return (size_t)mtf * ks * 64 * sizeof(float) + ((size_t)(mt - mtf) * ks * 64 + 4 * ks + rows + 2) * sizeof(double);   // (+ the workgroup's next chunk)
 }
 
 // can the table kernels take this dictionary?  (K-steps of 4 samples: 25 or 40 per voxel; the scans of the seed solvers and
@@ -139,6 +138,7 @@ int amx_launch_noddi_gemm(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, 
     ga.Cb = (double *)(lasso ? ctx->cgemm2.p : ctx->cgemm.p); ga.ytil = (double *)(lasso ? ctx->ytil2.p : ctx->ytil.p);
     ga.xiso = a.xiso; ga.rowdwi = lut->rowdwi; ga.colscale = lut->colscale; ga.iso_atom = lut->n_atoms - 1; ga.is_exvivo = lut->is_exvivo; ga.n_wm = lut->n_wm;
     if (lasso) { ga.clist = (const int *)ctx->clip.p; ga.ccount = (const int *)ctx->clip.p + 2 * pl.n; }
+    else { ga.gcount = pl.feed_set(FEED_GEMM); ga.n_gcount = pl.max_schunks; }
     const int ks = amx_gemm_ksteps(lut);
     const size_t lds = gemm_lds(lasso ? lut->n_wm : lut->n_atoms, ga.rows, ks);
     int rc;
@@ -194,6 +194,7 @@ int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a
     g.Sb = lut->basis2_S; g.kappa0 = lut->screen2_kappa0; g.lam1 = a.c.lam1; g.lam2 = a.c.lam2;
     g.supp = a.supp; g.xiso = a.xiso; g.done = (unsigned char *)ctx->done.p;
     g.rlist = (int *)ctx->rlist.p; g.rcount = (int *)ctx->rlist.p + pl.n;
+    g.gcount = pl.feed_set(FEED_CERT2); g.n_gcount = pl.max_schunks;
     HIPCHK(ctx, hipMemsetAsync(g.rcount, 0, (size_t)pl.max_schunks * sizeof(int), s));
     if (a.c.xdbg) g.xdbg = a.c.xdbg;
 #ifdef AMX_STATS
@@ -246,6 +247,7 @@ int amx_launch_noddi_gcert(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a,
     g.iso_atom = lut->n_atoms - 1; g.dot_atom = lut->is_exvivo ? lut->n_atoms - 2 : -1; g.n_maps = a.n_maps;
     g.Sb = lut->basis_S; g.kappa0 = lut->screen_kappa0; g.supp = a.supp; g.icvf = lut->icvf; g.kappa = lut->kappa;
     g.done = (unsigned char *)ctx->done.p; g.rlist = (int *)ctx->rlist.p; g.rcount = (int *)ctx->rlist.p + pl.n;
+    g.gcount = pl.feed_set(stage == 1 ? FEED_CERT1 : FEED_CERT3); g.n_gcount = pl.max_schunks;
     HIPCHK(ctx, hipMemsetAsync(g.rcount, 0, (size_t)pl.max_schunks * sizeof(int), s));
     g.xiso = a.xiso; g.est = a.est; g.rmse = a.rmse; g.nrmse = a.nrmse; g.mod = a.mod;
     if (a.c.xdbg) g.xdbg = a.c.xdbg;
@@ -287,8 +289,7 @@ int amx_launch_noddi_seed(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, 
                        (stage == 1 ? ((size_t)10 * (kSeedKD / 4) * 64 + (size_t)4 * 64 * (kSeedKD + 1)) * sizeof(double) : 0);
     const dim3 grid(((pl.max_schunks + 7) / 8) * 8);
     int rc;
-    sa.gcount = (int *)ctx->feed.p + (stage == 1 ? 0 : 2) * (size_t)(pl.max_schunks + 8); sa.n_gcount = pl.max_schunks;
-    HIPCHK(ctx, hipMemsetAsync(sa.gcount, 0, (size_t)(pl.max_schunks + 1) * sizeof(int), s));
+    sa.gcount = pl.feed_set(stage == 1 ? FEED_SEED1 : FEED_SEED3); sa.n_gcount = pl.max_schunks;
     if (stage == 1 && pl.seed_occ2) {
         if ((rc = set_lds(ctx, (k_nnls_seed<1, 8, true>), lds))) return rc;
         hipLaunchKernelGGL((k_nnls_seed<1, 8, true>), grid, dim3(64 * pl.seed1_waves), lds, s, sa);

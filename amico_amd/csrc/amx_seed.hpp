@@ -513,6 +513,32 @@ __device__ __forceinline__ int seed_next_chunk(int round, int own, const Chunk *
     return pick;
 }
 
+// The kernels that walk a chunk block by block (the certificates: 64 voxels, the A'y GEMM: groups of 16) share their chunks the
+// same way: a wavefront draws blocks from the chunk's global counter -- the ticket of the NEXT block is requested when the current
+// one is handed out, so the atomic's latency hides behind a block's work -- and a workgroup whose chunk is exhausted joins the
+// largest open ones.
+// (chunks come largest first, k_order_schunks: when even the first is too small to share, nobody needs help -- small calls skip
+//  the search.  Not in seed_next_chunk itself: k_nnls_seed<3, 6> ran 0.81 -> 1.15 ms per 1 M voxels with this test compiled in.)
+__device__ __forceinline__ int block_next_chunk(int round, int own, const Chunk *schunks, int n_schunks, const int *gcount, int *steal, int *lds_slot, int min_left)
+{
+    if (round > 0 && schunks[xcd_chunk(0, n_schunks)].count < min_left) return -1;
+    return seed_next_chunk(round, own, schunks, n_schunks, gcount, steal, lds_slot, min_left);
+}
+
+template <int UNIT>
+struct BlockFeed {
+    int raw;                      // lane 0: voxel offset of this wavefront's next block (the atomic's return value, read when needed)
+    __device__ __forceinline__ void start(int *gcount, int lane) { raw = 0; if (lane == 0) raw = atomicAdd(gcount, UNIT); }
+    __device__ __forceinline__ int next(int *gcount, int count, int lane)        // block index within the chunk, or -1
+    {
+        const int cur = __builtin_amdgcn_readfirstlane(raw);
+        if (cur >= count) return -1;
+        raw = 0;
+        if (lane == 0) raw = atomicAdd(gcount, UNIT);
+        return cur / UNIT;
+    }
+};
+
 // STAGE 1: all atoms are candidates; STAGE 3: the atoms of the stage-2 support plus iso (dot)
 // (MS = 8: the compiler needs ~540 registers for this kernel; at two wavefronts per SIMD it spilled 290 of them and the kernel moved
 //  27 GB + 9 GB of scratch per 1 M voxels (rocprofv3 FETCH_SIZE / WRITE_SIZE) -- at one wavefront per SIMD, with the accumulation
@@ -924,6 +950,7 @@ struct GemmArgs {
     double *Cb;                   // [n_blocks][rows][64]
     double *ytil;                 // [n][12] bucket order (copy of rows aux0 + kAuxU ..), or null
     const int *clist, *ccount;    // LASSO: bucket positions of the chunk's clipped voxels (compact from the chunk's start), their number
+    int *gcount; int n_gcount;    // NNLS: chunk counters of this launch (BlockFeed), helpers' counter at [n_gcount]
 };
 
 __device__ __forceinline__ double rows_allmin(double k)
@@ -949,13 +976,26 @@ __global__ void __launch_bounds__(512) k_noddi_gemm(const GemmArgs a)
     double *A64 = reinterpret_cast<double *>(A32 + (size_t)MTf * KS * 64);   // [MT - MTf][KS][64]
     double *IsoT = A64 + (size_t)(MT - MTf) * KS * 64;                    // [4 KS] LASSO: iso atom by signal row; NNLS: 1 / iso on the stage-2 rows
     double *ScT = IsoT + 4 * KS;                                          // [rows] column scale by output row, 0 beyond n_wm (LASSO)
-    const int cid = xcd_chunk((int)blockIdx.x, *a.n_schunks);
-    if (cid < 0) return;
-    const Chunk ck = a.schunks[cid];
-    const int count = LASSO ? a.ccount[cid] : ck.count;
-    if (count == 0) return;
+    const int n_sch = *a.n_schunks;
+    const int own = xcd_chunk((int)blockIdx.x, n_sch);
+    if (own < 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
     const int q = lane >> 4, c16 = lane & 15;
+    unsigned long long maskE = 0ull, maskD = 0ull;      // bit ks: sample 4 ks + q exists / is a stage-2 row
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+        const int row = 4 * ks + q;
+        if (row < nS) { maskE |= 1ull << ks; if (a.rowdwi[row] != 0) maskD |= 1ull << ks; }
+    }
+    const unsigned long long rowmask = LASSO ? maskD : maskE;
+    // every voxel's table: the workgroup's own chunk, then the largest chunks still open, groups of 16 voxels per wavefront (BlockFeed);
+    // the exact stage-2 pass over the (few) clipped voxels: its own chunk's list, groups of 16 dealt round robin
+    for (int round = 0; round < (LASSO ? 1 : 256); round++) {
+    const int cid = LASSO ? own : block_next_chunk(round, own, a.schunks, n_sch, a.gcount, a.gcount + a.n_gcount, reinterpret_cast<int *>(ScT + a.rows), 32 * nw);
+    if (cid < 0) break;
+    const Chunk ck = a.schunks[cid];
+    const int count = LASSO ? a.ccount[cid] : ck.count;
+    if (count == 0) { if (LASSO) return; else continue; }
     const float *tile = a.tiles + (size_t)ck.dir * a.tile_stride;
     const double *U = a.Ub + (size_t)ck.dir * nS * kSeedKD;
     const double *U2 = (!LASSO && a.U2b) ? a.U2b + (size_t)ck.dir * nS * kSeedKD : nullptr;
@@ -986,13 +1026,6 @@ __global__ void __launch_bounds__(512) k_noddi_gemm(const GemmArgs a)
     // the signals of a group of 16 voxels straight in operand order: lane (q, c16) reads samples q, 4 + q, 8 + q, ... of voxel c16
     // (four lanes share every 32-byte sector; all bytes of a row are used by the KS loads).  The loads of group g + nw are
     // issued before the products of group g, so they are long done when their turn comes; no LDS staging.
-    unsigned long long maskE = 0ull, maskD = 0ull;      // bit ks: sample 4 ks + q exists / is a stage-2 row
-#pragma unroll
-    for (int ks = 0; ks < KS; ks++) {
-        const int row = 4 * ks + q;
-        if (row < nS) { maskE |= 1ull << ks; if (a.rowdwi[row] != 0) maskD |= 1ull << ks; }
-    }
-    const unsigned long long rowmask = LASSO ? maskD : maskE;
     double bn[KS], xi_n = 0.0, xd_n = 0.0;
     int pos_n = 0;
     auto issue = [&](int g) {
@@ -1011,8 +1044,15 @@ __global__ void __launch_bounds__(512) k_noddi_gemm(const GemmArgs a)
         }
         if (LASSO) { xi_n = a.xiso[(size_t)vox * 2]; xd_n = a.is_exvivo ? a.xiso[(size_t)vox * 2 + 1] : 0.0; }
     };
-    if (wave < n_groups) issue(wave);
-    for (int g = wave; g < n_groups; g += nw) {
+    BlockFeed<16> bf;
+    auto advance = [&](int g) -> int {                  // the group after g for this wavefront, -1: none
+        if (LASSO) { const int n = g < 0 ? wave : g + nw; return n < n_groups ? n : -1; }
+        return bf.next(a.gcount + cid, count, lane);
+    };
+    if (!LASSO) bf.start(a.gcount + cid, lane);
+    int g = advance(-1);
+    if (g >= 0) issue(g);
+    while (g >= 0) {
         const bool live = 16 * g + c16 < count;
         const int pos = pos_n;
         double b[KS], yy = 0.0, yb = 0.0, tmin = __builtin_huge_val();
@@ -1034,7 +1074,8 @@ __global__ void __launch_bounds__(512) k_noddi_gemm(const GemmArgs a)
         }
         yy = rows_allreduce(yy);
         if (!LASSO) { yb = rows_allreduce(yb); tmin = rows_allmin(tmin); }
-        if (g + nw < n_groups) issue(g + nw);
+        const int g_nxt = advance(g);
+        if (g_nxt >= 0) issue(g_nxt);
         const int blk = ck.pad + (g >> 2), col = 16 * (g & 3) + c16;
         double *out = a.Cb + (size_t)blk * a.rows * 64 + col;
 #pragma unroll (MTF > 0 && !LASSO ? 3 : 1)
@@ -1089,6 +1130,9 @@ __global__ void __launch_bounds__(512) k_noddi_gemm(const GemmArgs a)
                 }
             }
         }
+        g = g_nxt;
+    }
+    __syncthreads();                          // every wavefront is through with this chunk's operands
     }
 }
 
@@ -1267,6 +1311,7 @@ struct GcertArgs {
     const unsigned long long *supp;    // stage 3: [n_vox][4]
     const float *icvf, *kappa;         // stage 3: maps
     unsigned char *done;               // [n], bucket order: 1 = certified here
+    int *gcount; int n_gcount;         // chunk counters of this launch (BlockFeed; zeroed before the fit), helpers' counter at [n_gcount]
     int *rlist, *rcount;               // refused voxels: positions, compact from the chunk's own start; count per chunk
     double *xiso;                      // stage 1 out: [n_vox][2]
     double *est, *rmse, *nrmse, *mod;  // stage 3 out
@@ -1283,11 +1328,21 @@ __global__ void __launch_bounds__(256, 2) k_nnls_gcert(const GcertArgs a)
     const int n_atoms = a.n_atoms;
     double *Aop = Sl + (size_t)n_atoms * LD + 2;                  // [MT][KS][64]
     double *Rb = Aop + MT * KS * 64 + (threadIdx.x >> 6) * (64 * RBW);   // per wavefront [64][16]: r~ | margin | masks
-    const int cid = xcd_chunk((int)blockIdx.x, *a.n_schunks);
-    if (cid < 0) return;
-    const Chunk ck = a.schunks[cid];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
+    const int n_sch = *a.n_schunks;
+    const int own = xcd_chunk((int)blockIdx.x, n_sch);
+    if (own < 0) return;
+    const int lane = threadIdx.x & 63, nw = (int)blockDim.x >> 6;
     const int q = lane >> 4, c16 = lane & 15;
+#ifdef AMX_STATS
+    long long gph[5] = {0, 0, 0, 0, 0}, gpt = (long long)__builtin_readcyclecounter();
+#define GC_PH(k) do { const long long t__ = (long long)__builtin_readcyclecounter(); gph[k] += t__ - gpt; gpt = t__; } while (0)
+#else
+#define GC_PH(k) do { } while (0)
+#endif
+    for (int round = 0; round < 256; round++) {
+    const int cid = block_next_chunk(round, own, a.schunks, n_sch, a.gcount, a.gcount + a.n_gcount, reinterpret_cast<int *>(Sl + (size_t)n_atoms * LD), 64 * nw);
+    if (cid < 0) break;
+    const Chunk ck = a.schunks[cid];
     const double *__restrict__ Sg = a.Sb + (size_t)ck.dir * n_atoms * KD;
     const double *__restrict__ Gd = a.gram + (size_t)ck.dir * n_atoms * a.ldG;
     for (int e = threadIdx.x; e < n_atoms * KD; e += blockDim.x) { const int j = e / KD, d = e - j * KD; Sl[j * LD + d] = Sg[e]; }
@@ -1300,14 +1355,11 @@ __global__ void __launch_bounds__(256, 2) k_nnls_gcert(const GcertArgs a)
     }
     __syncthreads();
     const double kap = a.kappa0[ck.dir];
-#ifdef AMX_STATS
-    long long gph[5] = {0, 0, 0, 0, 0}, gpt = (long long)__builtin_readcyclecounter();
-#define GC_PH(k) do { const long long t__ = (long long)__builtin_readcyclecounter(); gph[k] += t__ - gpt; gpt = t__; } while (0)
-#else
-#define GC_PH(k) do { } while (0)
-#endif
-    const int n_blocks = (ck.count + 63) >> 6;
-    for (int bl = wave; bl < n_blocks; bl += nw) {
+    BlockFeed<64> bf;
+    bf.start(a.gcount + cid, lane);
+    for (;;) {
+        const int bl = bf.next(a.gcount + cid, ck.count, lane);
+        if (bl < 0) break;
         const int k = 64 * bl + lane;
         const bool valid = k < ck.count;
         const int pos = ck.start + (valid ? k : ck.count - 1);
@@ -1516,6 +1568,8 @@ __global__ void __launch_bounds__(256, 2) k_nnls_gcert(const GcertArgs a)
         }
         GC_PH(4);
     }
+    __syncthreads();                          // every wavefront is through with this chunk's tables
+    }
 #ifdef AMX_STATS
     if (a.stats && lane == 0) for (int q5 = 0; q5 < 5; q5++) atomicAdd(&a.stats[(STAGE == 1 ? 36 : 35) + q5], (int)(gph[q5] >> 10));
 #endif
@@ -1560,6 +1614,7 @@ struct Gcert2Args {
     unsigned long long *supp;          // out: [n_vox][4]
     const double *xiso;                // [n_vox][2] (AMX_F_DEBUG_X only)
     unsigned char *done;
+    int *gcount; int n_gcount;         // first pass: chunk counters (BlockFeed), helpers' counter at [n_gcount]
     int *rlist, *rcount;
     const int *rlist_in, *rcount_in;   // WIDE pass: the left-over lists of the first pass
     double *xdbg;
@@ -1583,12 +1638,20 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
     double *giso = scl + ((n_wm + 1) & ~1);                        // [n_wm] G_dwi[j][iso]: what x_iso takes out of a_j,dwi'y
     double *Aop = giso + ((n_wm + 1) & ~1);                        // [MT][KS][64]
     double *Rb = Aop + MT * KS * 64 + (threadIdx.x >> 6) * (64 * RBW);
-    const int cid = xcd_chunk((int)blockIdx.x, *a.n_schunks);
-    if (cid < 0) return;
+    const int n_sch = *a.n_schunks;
+    const int own = xcd_chunk((int)blockIdx.x, n_sch);
+    if (own < 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
+#ifdef AMX_STATS
+    long long gph[5] = {0, 0, 0, 0, 0}, gpt = (long long)__builtin_readcyclecounter();
+#endif
+    // first pass: the workgroup's own chunk, then the largest chunks still open (BlockFeed); the wide pass walks its own chunk's list only
+    for (int round = 0; round < (WIDE ? 1 : 256); round++) {
+    const int cid = WIDE ? own : block_next_chunk(round, own, a.schunks, n_sch, a.gcount, a.gcount + a.n_gcount, reinterpret_cast<int *>(Sl + (size_t)n_wm * LD), 64 * nw);
+    if (cid < 0) break;
     const Chunk ck = a.schunks[cid];
     const int n_items = WIDE ? a.rcount_in[cid] : ck.count;
     if (WIDE && n_items == 0) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
     const double *__restrict__ Sg = a.Sb + (size_t)ck.dir * n_wm * KD;
     const double *__restrict__ Gd = a.gram + (size_t)ck.dir * a.n_atoms * a.ldG;
     for (int e = threadIdx.x; e < n_wm * KD; e += blockDim.x) { const int j = e / KD, d = e - j * KD; Sl[j * LD + d] = Sg[e]; }
@@ -1602,11 +1665,13 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
     const double kap = a.kappa0[ck.dir], lam1 = a.lam1, lam2 = a.lam2;
     const double gii = Gd[(size_t)a.iso_atom * a.ldG + a.iso_atom];      // ||iso_dwi||^2
     const double *__restrict__ u2 = a.u2iso + (size_t)ck.dir * kSeedKD;
-#ifdef AMX_STATS
-    long long gph[5] = {0, 0, 0, 0, 0}, gpt = (long long)__builtin_readcyclecounter();
-#endif
     const int n_blocks = (n_items + 63) >> 6;
-    for (int bl = wave; bl < n_blocks; bl += nw) {
+    BlockFeed<64> bf;
+    if (!WIDE) bf.start(a.gcount + cid, lane);
+    for (int bls = wave; ; bls += nw) {
+        int bl = bls;
+        if (WIDE) { if (bl >= n_blocks) break; }
+        else { bl = bf.next(a.gcount + cid, ck.count, lane); if (bl < 0) break; }
         const int k = 64 * bl + lane;
         const bool valid = k < n_items;
         const int pos = WIDE ? a.rlist_in[ck.start + (valid ? k : n_items - 1)] : ck.start + (valid ? k : n_items - 1);
@@ -1767,6 +1832,8 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
             }
         }
         GC_PH(4);
+    }
+    __syncthreads();                          // every wavefront is through with this chunk's tables
     }
 #ifdef AMX_STATS
     if (!WIDE && a.stats && lane == 0) for (int q5 = 0; q5 < 5; q5++) atomicAdd(&a.stats[34 + q5], (int)(gph[q5] >> 10));
