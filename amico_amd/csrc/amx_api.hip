@@ -244,6 +244,8 @@ int amx_ctx_create(int device, amx_ctx **out)
         ctx->opt_no_chunk_order = on("AMX_NO_CHUNK_ORDER");
         e = getenv("AMX_NO_GCERT_WIDE");
         ctx->opt_no_gcert_wide = e && *e && *e != '0';
+        e = getenv("AMX_RESCUE_FROM");
+        if (e && *e) ctx->opt_rescue_from = atoll(e);
         e = getenv("AMX_NO_SCREEN");
         ctx->opt_no_screen = e && *e && *e != '0';
         e = getenv("AMX_SEED_STAGES");
@@ -511,6 +513,8 @@ int amx_sync_status(amx_ctx *ctx, void *hip_stream)
                              st[ST_SEED + 24], st[ST_SEED + 25], st[ST_SEED + 26], st[ST_SEED + 27], st[ST_SEED + 28], st[ST_SEED + 29], st[ST_SEED + 30], st[ST_SEED + 31], st[ST_SEED + 32], st[ST_SEED + 33], st[ST_SEED + 34], st[ST_SEED + 35]);
     if (amx_debug()) fprintf(stderr, "[amx] Gram certificates LASSO: %d voxels, %d certified (more than 12 atoms %d, x <= 0 %d, dual %d), %d dual values\n",
                              st[ST_SEED + 36], st[ST_SEED + 37], st[ST_SEED + 38], st[ST_SEED + 39], st[ST_SEED + 40], st[ST_SEED + 41]);
+    if (amx_debug()) fprintf(stderr, "[amx] Gram certificates LASSO, second pass: %d voxels, %d certified (more than 18 atoms %d, x <= 0 %d, dual %d), %d dual values\n",
+                             st[ST_SEED + 48], st[ST_SEED + 49], st[ST_SEED + 50], st[ST_SEED + 51], st[ST_SEED + 52], st[ST_SEED + 53]);
     if (amx_debug()) fprintf(stderr, "[amx] LASSO seeds: tried %d certified %d; seed solver trips %d lane-trips used %d\n", st[ST_SEED + 18], st[ST_SEED + 19], st[ST_SEED + 20], st[ST_SEED + 21]);
     if (amx_debug()) fprintf(stderr, "[amx] seed solver kcycles (wave sums / 1024): take %d solve+drop %d residual %d scan %d append %d store %d\n", st[ST_SEED + 12], st[ST_SEED + 13], st[ST_SEED + 14], st[ST_SEED + 15], st[ST_SEED + 16], st[ST_SEED + 17]);
     if (amx_debug()) fprintf(stderr, "[amx] Gram certificate kcycles (decode | gather+factor+solve | screening | exact duals | output): stage 1 %d %d %d %d %d, stage 3 %d %d %d %d %d\n",
@@ -678,9 +682,10 @@ static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
             rec(ctx, 17, s);
             if (!gcert) ctx->uncert_vox[0] += n_vox;
             if (gcert) {
-                if ((rc = amx_launch_noddi_gcert(ctx, lut, a, pl, s, 1))) return rc;
+                size_t off = 0;
+                if ((rc = amx_launch_noddi_gcert(ctx, lut, a, pl, s, 1, &off))) return rc;
                 a.done = (const unsigned char *)ctx->done.p;
-                a.rlist = (const int *)ctx->rlist.p; a.rcount = a.rlist + pl.n;
+                a.rlist = (const int *)ctx->rlist.p + off; a.rcount = a.rlist + pl.n;
                 a.c.chunks = pl.schunks; a.c.n_chunks = pl.n_chunks + 1;      // the stage kernel walks the left-over lists of the second plan
             }
         }
@@ -721,9 +726,10 @@ static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
             const bool gcert3 = !ctx->opt_no_gcert && gemm_ks > 0;
             if (!gcert3) ctx->uncert_vox[2] += n_vox;
             if (!rc && gcert3) {
-                rc = amx_launch_noddi_gcert(ctx, lut, a, pl, s, 3);
+                size_t off = 0;
+                rc = amx_launch_noddi_gcert(ctx, lut, a, pl, s, 3, &off);
                 a.done = (const unsigned char *)ctx->done.p;
-                a.rlist = (const int *)ctx->rlist.p; a.rcount = a.rlist + pl.n;
+                a.rlist = (const int *)ctx->rlist.p + off; a.rcount = a.rlist + pl.n;
                 a.c.chunks = pl.schunks; a.c.n_chunks = pl.n_chunks + 1;
             }
             rec(ctx, 15, s);

@@ -74,6 +74,7 @@ struct amx_ctx {
     int opt_refill_chunk = 0;          // AMX_REFILL_CHUNK: voxels per workgroup of k_freewater_refill (0 = by problem size)
     bool opt_no_chunk_order = false; // AMX_NO_CHUNK_ORDER=1: the chunks of the second plan stay in orientation order (default: longest first)
     bool opt_no_gcert_wide = false; // AMX_NO_GCERT_WIDE=1: no second Gram-certificate pass for LASSO supports of 13 .. 16 atoms
+    int64_t opt_rescue_from = 2000000;   // AMX_RESCUE_FROM=n: calls of n voxels and more run the rescue pass of the NNLS certificates (k_nnls_gcert<., true>)
     bool opt_no_gcert = false;     // AMX_NO_GCERT=1: every seed is certified by the wavefront-per-voxel kernels (true residual)
     bool opt_no_screen = false;    // AMX_NO_SCREEN=1: certify seeds with the full exact sweep of the dual vector
     bool opt_s2_exact = false;     // AMX_S2_EXACT=1: every voxel's stage-2 products by the exact pass (k_noddi_gemm<true>), none derived from the stage-1 table
@@ -224,7 +225,7 @@ static inline void rec(amx_ctx *ctx, int k, hipStream_t s)
 int amx_build_basis(amx_ctx *ctx, amx_lut *lut);
 int amx_launch_noddi_project(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s);
 int amx_launch_noddi_seed(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, int stage);
-int amx_launch_noddi_gcert(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, int stage);
+int amx_launch_noddi_gcert(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, int stage, size_t *list_off);
 int amx_launch_noddi_gemm(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, bool lasso);
 int amx_launch_noddi_s2prep(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s);
 int amx_gemm_ksteps(const amx_lut *lut);   // K-steps of the table kernels for this dictionary (25 / 40), 0 = shape not supported

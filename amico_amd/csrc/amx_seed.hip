@@ -236,8 +236,10 @@ int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a
 }
 
 // Gram-space certificates of the NNLS seeds, one voxel per lane (k_nnls_gcert): done[pos] = 1 for the voxels it settles
-int amx_launch_noddi_gcert(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, const Plan &pl, hipStream_t s, int stage)
+// (+ the rescue pass over its left-over lists; *list_off: where in ctx->rlist the lists for the wavefront-per-voxel kernel are)
+int amx_launch_noddi_gcert(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, const Plan &pl, hipStream_t s, int stage, size_t *list_off)
 {
+    *list_off = 0;
     GcertArgs g;
     memset(&g, 0, sizeof g);
     g.perm = pl.perm; g.schunks = pl.schunks; g.n_schunks = pl.n_chunks + 1;
@@ -266,6 +268,28 @@ int amx_launch_noddi_gcert(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a,
     }
     AMX_TRACE(ctx, s, "Gram-space certificates");
     HIPCHK(ctx, hipGetLastError());
+    if ((int64_t)pl.n >= ctx->opt_rescue_from) {
+        // second pass (large calls: below ~2 M voxels the launch costs more than the wavefront-per-voxel kernel saves -- 1 M voxels
+        // 8.08 -> 8.24 ms with it, 4 M 24.99 -> 24.38): the supports refused for conditioning, corrected with the signal itself;
+        // what is left goes to the second half
+        g.rlist_in = g.rlist; g.rcount_in = g.rcount;
+        g.rlist = (int *)ctx->rlist.p + amx_rlist_half(pl); g.rcount = g.rlist + pl.n;
+        HIPCHK(ctx, hipMemsetAsync(g.rcount, 0, (size_t)pl.max_schunks * sizeof(int), s));
+        g.y = a.c.y; g.y32 = a.c.y32; g.tiles = (const float *)lut->tiles; g.tile_stride = lut->tile_stride; g.ldA = lut->ldA;
+        const size_t tile = (size_t)lut->nS * lut->ldA * sizeof(float);
+        g.tile_in_lds = lds + tile <= kLdsPerCU ? 1 : 0;
+        const size_t lds2 = lds + (g.tile_in_lds ? tile : 0);
+        if (stage == 1) {
+            if ((rc = set_lds(ctx, (k_nnls_gcert<1, true>), lds2))) return rc;
+            hipLaunchKernelGGL((k_nnls_gcert<1, true>), grid, dim3(64 * pl.seed_waves), lds2, s, g);
+        } else {
+            if ((rc = set_lds(ctx, (k_nnls_gcert<3, true>), lds2))) return rc;
+            hipLaunchKernelGGL((k_nnls_gcert<3, true>), grid, dim3(64 * pl.seed_waves), lds2, s, g);
+        }
+        AMX_TRACE(ctx, s, "Gram-space certificates, rescue pass");
+        HIPCHK(ctx, hipGetLastError());
+        *list_off = amx_rlist_half(pl);
+    }
     return AMX_OK;
 }
 

@@ -342,6 +342,24 @@ struct SeedLane {
             z[j] = f * dinv[j];
         }
     }
+    // z = (L L')^-1 b
+    __device__ __forceinline__ void solve_rhs(const double (&b)[MS], double (&z)[MS]) const
+    {
+#pragma unroll
+        for (int j = 0; j < MS; j++) {
+            double f = b[j];
+#pragma unroll
+            for (int m = 0; m < j; m++) f -= T[stri<MS>(j, m)] * z[m];
+            z[j] = f * dinv[j];
+        }
+#pragma unroll
+        for (int j = MS - 1; j >= 0; j--) {
+            double f = z[j];
+#pragma unroll
+            for (int m = j + 1; m < MS; m++) f -= T[stri<MS>(m, j)] * z[m];
+            z[j] = f * dinv[j];
+        }
+    }
     // in-place Cholesky of the matrix held in T (slots >= np are zero); false: a pivot of a live slot is not positive
     __device__ __forceinline__ bool factor()
     {
@@ -1296,7 +1314,18 @@ __device__ __forceinline__ void seed_flags_mfma(const double *Aop, double *Rb, i
 // for the 64 voxels of the wavefront by one fp64 MFMA product (see seed_scan_mfma).  Everything else -- refused seeds,
 // ill-conditioned supports, ambiguous signs, non-finite signals -- is left to the wavefront-per-voxel kernel (k_noddi with
 // the done[] flags: it skips the certified voxels), whose certificate works on the true residual.
+//
+// RESCUE pass (second launch, over the first pass's left-over lists): five in six of the voxels the first pass leaves are refused
+// for conditioning alone (1 M voxels of the bench mix: 40 093 of 47 620 at stage 1, 23 299 of 24 788 at stage 3).  Their support
+// is right; only x_P = G_PP^-1 c_P is not good enough.  The lane corrects it with the signal and the atoms themselves --
+// x <- x + G_PP^-1 A_P'(y - A_P x), the corrected semi-normal equations, factor already in registers, atoms from the orientation's
+// float32 tile in LDS, one pass over the voxel's nS samples per correction -- until the correction is below kRescueStep |x|
+// (tools/lab/csne_lab.py: two or three corrections bring x to within 7e-10 of the 80-bit solution, where the QR solution of the
+// wavefront-per-voxel kernel itself is at 3e-9), and then runs the same tests.  What does not settle in kRescuePasses corrections,
+// has a pivot ratio below kRescuePivot, a coefficient too close to zero to call, or fails a dual test stays on the list.
 constexpr double kGcertPivot1 = 1e-3, kGcertPivot3 = 3e-3;   // stage 1 only hands x_iso to the LASSO stage; stage 3's x becomes the maps
+constexpr double kRescuePivot = 1e-6, kRescueStep = 1e-9, kRescueTiny = 1e-7;
+constexpr int kRescuePasses = 4;
 struct GcertArgs {
     const int *perm;
     const Chunk *schunks;
@@ -1313,14 +1342,17 @@ struct GcertArgs {
     unsigned char *done;               // [n], bucket order: 1 = certified here
     int *gcount; int n_gcount;         // chunk counters of this launch (BlockFeed; zeroed before the fit), helpers' counter at [n_gcount]
     int *rlist, *rcount;               // refused voxels: positions, compact from the chunk's own start; count per chunk
+    const int *rlist_in, *rcount_in;   // RESCUE pass: the left-over lists of the first pass
+    const double *y; const float *y32; // RESCUE pass: the signals [n_vox][nS] (one of the two)
+    const float *tiles; size_t tile_stride; int ldA, tile_in_lds;   // RESCUE pass: the orientations' atoms [nS][ldA]
     double *xiso;                      // stage 1 out: [n_vox][2]
     double *est, *rmse, *nrmse, *mod;  // stage 3 out
     double *xdbg;                      // AMX_F_DEBUG_X: [n_vox][3][n_atoms]
     int *stats;
 };
 
-template <int STAGE>
-__global__ void __launch_bounds__(256, 2) k_nnls_gcert(const GcertArgs a)
+template <int STAGE, bool RESCUE = false>
+__global__ void __launch_bounds__(256, RESCUE ? 1 : 2) k_nnls_gcert(const GcertArgs a)
 {
     constexpr int KD = kSeedKD, KS = KD / 4, MT = 10, MS = 8, LD = kSeedLd, RBW = 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_c[];
@@ -1328,6 +1360,7 @@ __global__ void __launch_bounds__(256, 2) k_nnls_gcert(const GcertArgs a)
     const int n_atoms = a.n_atoms;
     double *Aop = Sl + (size_t)n_atoms * LD + 2;                  // [MT][KS][64]
     double *Rb = Aop + MT * KS * 64 + (threadIdx.x >> 6) * (64 * RBW);   // per wavefront [64][16]: r~ | margin | masks
+    float *Atl = reinterpret_cast<float *>(Aop + MT * KS * 64 + ((int)blockDim.x >> 6) * (64 * RBW));   // RESCUE: the orientation's atoms [nS][ldA]
     const int n_sch = *a.n_schunks;
     const int own = xcd_chunk((int)blockIdx.x, n_sch);
     if (own < 0) return;
@@ -1339,12 +1372,21 @@ __global__ void __launch_bounds__(256, 2) k_nnls_gcert(const GcertArgs a)
 #else
 #define GC_PH(k) do { } while (0)
 #endif
-    for (int round = 0; round < 256; round++) {
-    const int cid = block_next_chunk(round, own, a.schunks, n_sch, a.gcount, a.gcount + a.n_gcount, reinterpret_cast<int *>(Sl + (size_t)n_atoms * LD), 64 * nw);
+    for (int round = 0; round < (RESCUE ? 1 : 256); round++) {
+    const int cid = RESCUE ? own : block_next_chunk(round, own, a.schunks, n_sch, a.gcount, a.gcount + a.n_gcount, reinterpret_cast<int *>(Sl + (size_t)n_atoms * LD), 64 * nw);
     if (cid < 0) break;
     const Chunk ck = a.schunks[cid];
+    const int n_items = RESCUE ? a.rcount_in[cid] : ck.count;
+    if (RESCUE && n_items == 0) return;
     const double *__restrict__ Sg = a.Sb + (size_t)ck.dir * n_atoms * KD;
     const double *__restrict__ Gd = a.gram + (size_t)ck.dir * n_atoms * a.ldG;
+    const float *__restrict__ At = nullptr;    // RESCUE: the atoms in LDS when the tile fits beside the rest, else the L2-resident original
+    if (RESCUE) {
+        At = a.tiles + (size_t)ck.dir * a.tile_stride;
+        if (a.tile_in_lds) {
+            for (int e = threadIdx.x; e < a.nS * a.ldA; e += blockDim.x) Atl[e] = At[e];
+        }
+    }
     for (int e = threadIdx.x; e < n_atoms * KD; e += blockDim.x) { const int j = e / KD, d = e - j * KD; Sl[j * LD + d] = Sg[e]; }
     {
         for (int e = threadIdx.x; e < MT * KS * 64; e += blockDim.x) {
@@ -1356,14 +1398,17 @@ __global__ void __launch_bounds__(256, 2) k_nnls_gcert(const GcertArgs a)
     __syncthreads();
     const double kap = a.kappa0[ck.dir];
     BlockFeed<64> bf;
-    bf.start(a.gcount + cid, lane);
-    for (;;) {
-        const int bl = bf.next(a.gcount + cid, ck.count, lane);
-        if (bl < 0) break;
+    if (!RESCUE) bf.start(a.gcount + cid, lane);
+    for (int bls = (int)(threadIdx.x >> 6); ; bls += nw) {
+        int bl = bls;
+        if (RESCUE) { if (64 * bl >= n_items) break; }
+        else { bl = bf.next(a.gcount + cid, ck.count, lane); if (bl < 0) break; }
         const int k = 64 * bl + lane;
-        const bool valid = k < ck.count;
-        const int pos = ck.start + (valid ? k : ck.count - 1);
-        const double *Crow = a.Cb + (size_t)(ck.pad + bl) * a.rows * 64 + lane;
+        const bool valid = k < n_items;
+        const int kk = valid ? k : n_items - 1;
+        const int pos = RESCUE ? a.rlist_in[ck.start + kk] : ck.start + kk;
+        const int rel = pos - ck.start;                                   // (first pass: rel = 64 bl + lane)
+        const double *Crow = a.Cb + (size_t)(ck.pad + (rel >> 6)) * a.rows * 64 + (rel & 63);
         const unsigned long long seed = a.seeds[pos];
         const int vox = a.perm[pos];
         SeedLane<MS> V;
@@ -1426,7 +1471,8 @@ __global__ void __launch_bounds__(256, 2) k_nnls_gcert(const GcertArgs a)
             const double di = V.T[stri<MS>(s, s)];
             if (s < V.np) { pmax = di > pmax ? di : pmax; pmin = di < pmin ? di : pmin; }
         }
-        if (V.np > 0 && !(pmin > (STAGE == 1 ? kGcertPivot1 : kGcertPivot3) * pmax)) piv = false;
+        const bool ill = V.np > 0 && !(pmin > (STAGE == 1 ? kGcertPivot1 : kGcertPivot3) * pmax);
+        if (!RESCUE && ill) piv = false;
         double z[MS];
         V.solve(z);
         bool feas = true;
@@ -1434,6 +1480,74 @@ __global__ void __launch_bounds__(256, 2) k_nnls_gcert(const GcertArgs a)
 #pragma unroll
         for (int s = 0; s < MS; s++) { V.x[s] = z[s]; if (s < V.np && !(z[s] > 0.0)) feas = false; rho2 -= z[s] * V.c[s]; }
         rho2 = rho2 > 0.0 ? rho2 : 0.0;
+        if constexpr (RESCUE) {
+            // only the supports refused for conditioning come back (the others failed a test that would fail again)
+            bool need = valid && okv && piv && ill && (pmin > kRescuePivot * pmax) && (yy <= 1.79769313486231570e308);
+            bool conv = false;
+            const double *yv = a.y ? a.y + (size_t)vox * a.nS : nullptr;
+            const float *yv32 = a.y32 ? a.y32 + (size_t)vox * a.nS : nullptr;
+            for (int pass = 0; pass < kRescuePasses; pass++) {
+                if (__ballot(need && !conv) == 0ull) break;
+                double rho[MS], rr = 0.0;
+#pragma unroll
+                for (int s = 0; s < MS; s++) rho[s] = 0.0;
+                // rows in batches of RB: a batch's loads (the lane's own samples -- 8 bytes at a stride of one voxel -- and the
+                // atoms' entries) are issued together, the next batch's samples before this batch's arithmetic
+                constexpr int RB = 9;
+                auto rows = [&](const auto *Ap) {
+                    double yb[RB], yn[RB];
+                    auto fetch = [&](int i0, double (&dst)[RB]) {
+#pragma unroll
+                        for (int u = 0; u < RB; u++) {
+                            const int i = i0 + u < a.nS ? i0 + u : a.nS - 1;
+                            dst[u] = yv ? yv[i] : (double)yv32[i];
+                        }
+                    };
+                    fetch(0, yn);
+                    for (int i0 = 0; i0 < a.nS; i0 += RB) {
+#pragma unroll
+                        for (int u = 0; u < RB; u++) yb[u] = yn[u];
+                        float av[RB][MS];
+#pragma unroll
+                        for (int u = 0; u < RB; u++) {
+                            const int i = i0 + u < a.nS ? i0 + u : a.nS - 1;
+#pragma unroll
+                            for (int s = 0; s < MS; s++) av[u][s] = Ap[(size_t)i * a.ldA + V.idx[s]];     // (slots >= np: idx = 0, x = 0)
+                        }
+                        if (i0 + RB < a.nS) fetch(i0 + RB, yn);
+#pragma unroll
+                        for (int u = 0; u < RB; u++) {
+                            double ri = yb[u];
+#pragma unroll
+                            for (int s = 0; s < MS; s++) ri -= (double)av[u][s] * V.x[s];
+                            ri = i0 + u < a.nS ? ri : 0.0;
+#pragma unroll
+                            for (int s = 0; s < MS; s++) rho[s] += (double)av[u][s] * ri;
+                            rr += ri * ri;
+                        }
+                    }
+                };
+                if (a.tile_in_lds) rows(Atl); else rows(At);
+                double dz[MS];
+                V.solve_rhs(rho, dz);
+                double xm = 0.0, dm = 0.0;
+                const bool upd = need && !conv;
+#pragma unroll
+                for (int s = 0; s < MS; s++) {
+                    if (upd && s < V.np) V.x[s] += dz[s];
+                    const double ax = fabs(V.x[s]), ad = fabs(dz[s]);
+                    if (s < V.np) { xm = ax > xm ? ax : xm; dm = ad > dm ? ad : dm; }
+                }
+                if (upd) { rho2 = rr; if (dm <= kRescueStep * xm) conv = true; }      // (||r||^2 of the x before this -- negligible -- correction)
+            }
+            piv = need && conv;
+            feas = true;
+            double xm = 0.0;
+#pragma unroll
+            for (int s = 0; s < MS; s++) xm = (s < V.np && V.x[s] > xm) ? V.x[s] : xm;
+#pragma unroll
+            for (int s = 0; s < MS; s++) if (s < V.np && !(V.x[s] > kRescueTiny * xm)) feas = false;
+        }
         bool good = okv && piv && feas && (yy <= 1.79769313486231570e308);
         GC_PH(1);
         // ---- which atoms need their exact dual value
@@ -1514,7 +1628,7 @@ __global__ void __launch_bounds__(256, 2) k_nnls_gcert(const GcertArgs a)
             }
         }
 #ifdef AMX_STATS
-        if (a.stats) {
+        if (a.stats && !RESCUE) {
             const int nc = __builtin_popcountll(__ballot(cert)), nv = __builtin_popcountll(__ballot(valid));
             const int npv = __builtin_popcountll(__ballot(valid && okv && !piv)), nfe = __builtin_popcountll(__ballot(valid && okv && piv && !feas)), nvi = __builtin_popcountll(__ballot(valid && good && viol));
             if (lane == 0) { atomicAdd(&a.stats[0], nv); atomicAdd(&a.stats[1], nc); atomicAdd(&a.stats[2], npv); atomicAdd(&a.stats[3], nfe); atomicAdd(&a.stats[4], nvi); }
@@ -1571,6 +1685,7 @@ __global__ void __launch_bounds__(256, 2) k_nnls_gcert(const GcertArgs a)
     __syncthreads();                          // every wavefront is through with this chunk's tables
     }
 #ifdef AMX_STATS
+    if (RESCUE) return;
     if (a.stats && lane == 0) for (int q5 = 0; q5 < 5; q5++) atomicAdd(&a.stats[(STAGE == 1 ? 36 : 35) + q5], (int)(gph[q5] >> 10));
 #endif
 }

@@ -109,14 +109,19 @@ def test_noddi_kkt_certificates_and_supports(htable500, snr, mapping, amx_env):
     assert np.abs(x[:, 0, -1] - ref['x'][:, 0, -1]).max() < 1e-7      # x_iso handed from stage 1 to stage 2
 
 
+@pytest.mark.parametrize('rescue', [False, True])
 @pytest.mark.parametrize('exvivo', [False, True])
-def test_noddi_hard_mix_kkt_and_oracle(htable500, exvivo):
+def test_noddi_hard_mix_kkt_and_oracle(htable500, exvivo, rescue, amx_env):
     """Signals the dictionary does not explain (synthetic.noddi_hard_signals: crossings, wrong direction, CSF-dominated f_iso in
     [0.5, 1], pure noise, flat, half-zeroed, background, SNR 5 / 15 / 40) through the default path for this size -- the seed ->
     certificate chain, in vivo and ex vivo (dot atom): every voxel's coefficient vectors must satisfy the numpy
     KKT certificates, and the maps must equal the oracle's.  models.pyx:902-981 takes one path whatever the signal; the
-    certificate thresholds of the fast path were tuned on clean single-atom voxels."""
+    certificate thresholds of the fast path were tuned on clean single-atom voxels.
+    rescue: with the second pass of the NNLS certificates that large calls run (k_nnls_gcert<., true>: ill-conditioned supports
+    corrected with the signal itself instead of going to the wavefront-per-voxel kernel)."""
     import torch
+    if rescue:
+        amx_env(AMX_RESCUE_FROM='0')
     from amico_amd import _capi, get_context, synthetic as S
     from oracle import oracle
     dirs, ht = htable500['dirs'], htable500['htable']

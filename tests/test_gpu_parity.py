@@ -566,10 +566,10 @@ def test_whole_chain_freewater_and_sandi(htable500):
 
 
 @pytest.mark.parametrize('switch', ['AMX_NO_GCERT', 'AMX_NO_GCERT_WIDE', 'AMX_NO_SCREEN', 'AMX_SEED_STAGES=1', 'AMX_SEED_STAGES=6',
-                                    'AMX_SEED_CHUNK=1024', 'AMX_SEED_WAVES=2', 'AMX_NO_CHUNK_ORDER', 'AMX_NO_SEED'])
+                                    'AMX_SEED_CHUNK=1024', 'AMX_SEED_WAVES=2', 'AMX_NO_CHUNK_ORDER', 'AMX_NO_SEED', 'AMX_RESCUE_FROM=0'])
 def test_noddi_diagnosis_switches_keep_the_maps(htable500, switch, amx_env):
     """every A/B switch of the seeded chain (certificates off, second certificate pass off, screening off, seeds for some stages
-    only, other chunk / workgroup sizes, chunks in orientation order, no seeds at all) must end at the same maps: 70 000 voxels, a sample against the oracle and
+    only, other chunk / workgroup sizes, chunks in orientation order, no seeds at all, the rescue pass of large calls) must end at the same maps: 70 000 voxels, a sample against the oracle and
     all of them against the default chain"""
     from amico_amd import _capi, get_context, synthetic as S
     from oracle import oracle
