@@ -564,8 +564,14 @@ struct BlockFeed {
 #ifndef AMX_SEED1_OCC
 #define AMX_SEED1_OCC 1
 #endif
+// (stage 3: PINNED at two wavefronts per SIMD.  Left to itself -- bound 1 -- the compiler landed on either side of 256 registers
+//  with every unrelated edit of this file, and the kernel ran 0.81 or 1.16 ms per 1 M voxels accordingly.  Without the next-voxel
+//  prefetch: 204 VGPRs, 0.79 ms; with it 256 + 4 spilled, 0.82 ms.)
 #ifndef AMX_SEED3_OCC
-#define AMX_SEED3_OCC 1
+#define AMX_SEED3_OCC 2
+#endif
+#ifndef AMX_SEED3_PREF
+#define AMX_SEED3_PREF 0
 #endif
 // OCC2 (stage 1, calls of >= ~0.5 M voxels): two wavefronts per SIMD -- no next voxel reserved in registers, no software pipeline
 // in the scan (244 VGPRs, no scratch): a trip is a third longer, but two wavefronts hide each other's dependent chains and the
@@ -625,9 +631,9 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
     // Stage 1 (one wavefront per SIMD, registers to spare): the voxel's y~ stays in registers, and a lane RESERVES its next voxel
     // while it works on the current one -- the 12 loads of the next y~ are in flight for a whole solve instead of being waited
     // for in every trip in which some lane of the wavefront refills (measured: 15 % of the kernel).
-    // (stage 3 as well, at one wavefront per SIMD -- which by itself costs it nothing: 1.10 ms either way -- with the admissible-atom
-    //  mask of the next voxel prefetched next to its y~)
-    constexpr bool PREF = (MS > 6 && !OCC2 && AMX_SEED1_OCC == 1) || (STAGE == 3 && AMX_SEED3_OCC == 1);
+    // (stage 3 could do the same, AMX_SEED3_PREF=1, with the admissible-atom mask of the next voxel next to its y~: no gain at two
+    //  wavefronts per SIMD, see AMX_SEED3_OCC)
+    constexpr bool PREF = (MS > 6 && !OCC2 && AMX_SEED1_OCC == 1) || (STAGE == 3 && AMX_SEED3_PREF);
     double yv[PREF ? KD : 1], ynext[PREF ? KD : 1];
     unsigned long long nallow[(PREF && STAGE == 3) ? 4 : 1];
     int next_pos = -1;
