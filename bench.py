@@ -481,8 +481,18 @@ def pmc_valu(stage, n, kernel_ms):
     except (OSError, KeyError, ValueError):
         return None
     busy = insts * n * 4.0 / 1024.0 / (kernel_ms * 1e-3 * 2.4e9)
-    return {'bound': 'dependent latency (VALU issue slots mostly idle)', 'valu_wave_insts_per_voxel': insts, 'issue_cycles_filled': busy,
-            'source': 'profiles/pmc_traffic.json (SQ_INSTS_VALU) x live kernel time'}
+    out = {'bound': 'dependent latency (VALU issue slots mostly idle)', 'valu_wave_insts_per_voxel': insts, 'issue_cycles_filled': busy,
+           'source': 'profiles/pmc_traffic.json (SQ_INSTS_VALU) x live kernel time'}
+    # the same kernel against the fp64 matrix cores: its dual scans are 120 v_mfma_f64_16x16x4 per trip of 64 voxels
+    # (SQ_INSTS_VALU_MFMA_MOPS_F64 counts 512 flops each; MI355X: 78.6 TFLOP/s fp64 matrix peak)
+    if stage == 8:
+        try:
+            mops = [v['mfma_f64_mops'] for k, v in t['kernels'].items() if k.startswith('k_nnls_seed<1')][0] / t['voxels_per_launch']
+            tf = mops * n * 512.0 / (kernel_ms * 1e-3) / 1e12
+            out['mfma_f64'] = {'flops_per_voxel': mops * 512.0, 'achieved': tf, 'peak': 78.6, 'unit': 'TFLOP/s', 'frac': tf / 78.6}
+        except (KeyError, IndexError, TypeError):
+            pass
+    return out
 
 
 def pmc_traffic(stage, n):
