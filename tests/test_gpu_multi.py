@@ -136,3 +136,45 @@ def test_noddi_fit_is_bitwise_repeatable():
             continue
         for a, b in zip(ref, cur):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('n,share', [(150_001, 0.9), (64_123, 1.0), (300_000, 0.5)])
+def test_noddi_skewed_orientation_histograms(n, share, amx_env):
+    """Work sharing of the lane kernels (SeedFeed / BlockFeed, csrc/amx_seed.hpp): `share` of the voxels point along THREE
+    directions, so three orientations hold (almost) everything, are cut into many chunks, and the workgroups of the ~500 empty
+    orientations have nothing but other chunks to join; odd voxel counts; the rescue pass forced on.  Every voxel is fitted once
+    -- the maps equal the oracle's on a sample and the wavefront-per-voxel path's (AMX_NO_SEED=1) everywhere -- and twice the same."""
+    import torch
+    sys.path.insert(0, ROOT)
+    from amico_amd import _capi, get_context, synthetic as S
+    from oracle import oracle
+    dirs = S.fibonacci_hemisphere(500); ht = S.build_htable(dirs)
+    sch = S.make_scheme(seed=0); K = S.noddi_kernels(sch, dirs)
+    rng = np.random.default_rng(5)
+    y_h, d_h = S.noddi_signals(n, K, ht, sch, seed=77)
+    # re-point `share` of the voxels (keeping their signals: a wrong direction is just a harder voxel) at three fixed directions
+    three = S.random_unit_vectors(3, rng)
+    sel = rng.uniform(size=n) < share
+    d_h[sel] = three[rng.integers(0, 3, int(sel.sum()))]
+    amx_env(AMX_SEED_MIN_VOXELS='0', AMX_RESCUE_FROM='0')
+    ctx = get_context()
+    lut = _capi.upload_noddi(ctx, K, ht, sch.dwi_idx)
+    y = torch.from_numpy(y_h).cuda(); d = torch.from_numpy(d_h).cuda()
+    out = _capi.noddi_fit_device(ctx, lut, y, d, 0.5, 1e-3, 3, rmse=True)
+    ctx.sync()
+    st, ss = ctx.last_stats(), ctx.last_seed_stats()
+    assert st['itercap_voxels'] == 0 and st['guard_trips'] == 0 and st['overflow_voxels'] == 0
+    assert ss['seeded_voxels'] == n
+    est, rmse = out[0].cpu().numpy(), out[1].cpu().numpy()
+    again = _capi.noddi_fit_device(ctx, lut, y, d, 0.5, 1e-3, 3, rmse=True)
+    ctx.sync()
+    assert torch.equal(out[0], again[0]) and torch.equal(out[1], again[1])
+    pick = np.unique(np.linspace(0, n - 1, 4000).astype(np.int64))
+    ref = oracle.noddi_fit(np.ascontiguousarray(y_h[pick]), np.ascontiguousarray(d_h[pick]), K, ht, sch.dwi_idx, nthreads=os.cpu_count() or 1)
+    assert np.abs(est[pick] - ref['estimates']).max() < 1e-6
+    amx_env(AMX_NO_SEED='1')
+    ctx2 = get_context()
+    lut2 = _capi.upload_noddi(ctx2, K, ht, sch.dwi_idx)
+    cold = _capi.noddi_fit_device(ctx2, lut2, y, d, 0.5, 1e-3, 3, rmse=True)
+    ctx2.sync()
+    assert np.abs(cold[0].cpu().numpy() - est).max() < 1e-7 and np.abs(cold[1].cpu().numpy() - rmse).max() < 1e-7
