@@ -790,6 +790,10 @@ def main():
                          # traffic of all its kernels (the dominant kernel alone touches ~100 B per voxel: `traffic` above is that)
                          'frac_end_to_end': BYTES_PER_VOXEL * n / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                          'traffic_whole_fit': whole, 'algorithmic_bytes_whole_fit': BYTES_PER_VOXEL * n,
+                         # SURVEY 8(d)'s secondary figure: the dense fp64 contractions no two voxels share (A'y of stage 1, A2'y2 of stage 2,
+                         # A x of the residual: 2 * 99 * 145 + 2 * 90 * 144 + 2 * 99 * 145 flop) over the step, against the fp64 peak
+                         'fp64_end_to_end': {'algorithmic_flops_per_voxel': 83340, 'achieved': 83340.0 * n / (elapsed / args.steps) / 1e12,
+                                             'peak': 78.6, 'unit': 'TFLOP/s', 'frac': 83340.0 * n / (elapsed / args.steps) / 1e12 / 78.6},
                          'traffic_source': 'profiles/pmc_traffic.json (rocprofv3 --pmc, bytes per launch)'
                                            if traffic is not None else None,
                          'kernel': names[stage], 'kernel_ms': dom_ms,
