@@ -268,7 +268,10 @@ int amx_launch_noddi_gcert(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a,
     }
     AMX_TRACE(ctx, s, "Gram-space certificates");
     HIPCHK(ctx, hipGetLastError());
-    if ((int64_t)pl.n >= ctx->opt_rescue_from) {
+    // (ex-vivo dictionaries leave 7 % of the voxels instead of 5 and 2.5 % -- the dot atom makes more supports ill-conditioned -- and
+    //  gain from 1 M voxels: 108 -> 112 M voxels/s; deciding on the device from the first pass's count was tried: the launch that only
+    //  hands the lists on costs every other call 1 %)
+    if ((int64_t)pl.n >= (lut->is_exvivo ? ctx->opt_rescue_from / 4 : ctx->opt_rescue_from)) {
         // second pass (large calls: below ~2 M voxels the launch costs more than the wavefront-per-voxel kernel saves -- 1 M voxels
         // 8.08 -> 8.24 ms with it, 4 M 24.99 -> 24.38): the supports refused for conditioning, corrected with the signal itself;
         // what is left goes to the second half
