@@ -242,6 +242,7 @@ int amx_ctx_create(int device, amx_ctx **out)
         e = getenv("AMX_SEED2_OCC2_FROM");
         if (e && *e) ctx->opt_seed2_occ2_from = atoll(e);
         ctx->opt_no_chunk_order = on("AMX_NO_CHUNK_ORDER");
+        ctx->opt_no_hard_first = on("AMX_NO_HARD_FIRST");
         e = getenv("AMX_NO_GCERT_WIDE");
         ctx->opt_no_gcert_wide = e && *e && *e != '0';
         e = getenv("AMX_RESCUE_FROM");
@@ -250,6 +251,12 @@ int amx_ctx_create(int device, amx_ctx **out)
         ctx->opt_no_screen = e && *e && *e != '0';
         e = getenv("AMX_SEED_STAGES");
         if (e && *e) ctx->opt_seed_stages = atoi(e) & 7;
+        e = getenv("AMX_SEED_TRIPCAP");
+        if (e && *e) {
+            int c[3] = {ctx->opt_seed_tripcap[0], ctx->opt_seed_tripcap[1], ctx->opt_seed_tripcap[2]};
+            sscanf(e, "%d,%d,%d", &c[0], &c[1], &c[2]);
+            for (int k = 0; k < 3; k++) ctx->opt_seed_tripcap[k] = c[k] < 4 ? 4 : c[k];
+        }
         e = getenv("AMX_SEED_CHUNK");
         // (never below kChunk: the left-over passes size their grid by the FIRST plan's chunk count, n / kChunk + ndirs + 1)
         if (e && atoi(e) >= kChunk) ctx->opt_seed_chunk = (atoi(e) + 63) & ~63;
@@ -684,7 +691,7 @@ static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
             if (gcert) {
                 size_t off = 0;
                 if ((rc = amx_launch_noddi_gcert(ctx, lut, a, pl, s, 1, &off))) return rc;
-                a.done = (const unsigned char *)ctx->done.p;
+                a.done = ctx->opt_no_hard_first ? nullptr : (const unsigned char *)ctx->done.p;
                 a.rlist = (const int *)ctx->rlist.p + off; a.rcount = a.rlist + pl.n;
                 a.c.chunks = pl.schunks; a.c.n_chunks = pl.n_chunks + 1;      // the stage kernel walks the left-over lists of the second plan
             }
@@ -728,7 +735,7 @@ static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
             if (!rc && gcert3) {
                 size_t off = 0;
                 rc = amx_launch_noddi_gcert(ctx, lut, a, pl, s, 3, &off);
-                a.done = (const unsigned char *)ctx->done.p;
+                a.done = ctx->opt_no_hard_first ? nullptr : (const unsigned char *)ctx->done.p;
                 a.rlist = (const int *)ctx->rlist.p + off; a.rcount = a.rlist + pl.n;
                 a.c.chunks = pl.schunks; a.c.n_chunks = pl.n_chunks + 1;
             }

@@ -80,8 +80,15 @@ struct amx_ctx {
     bool opt_s2_exact = false;     // AMX_S2_EXACT=1: every voxel's stage-2 products by the exact pass (k_noddi_gemm<true>), none derived from the stage-1 table
     bool opt_no_seed = false;      // AMX_NO_SEED=1: Lawson-Hanson from the empty set in the NNLS stages (the round-2 path)
     long long opt_seed_min_voxels = 40960; // AMX_SEED_MIN_VOXELS: smaller calls run the wavefront-per-voxel kernels on all voxels (the seeded chain of ~16 kernels has a floor of ~2 ms; measured crossover between 30 000 and 50 000 voxels: 14.6 vs 16.2 and 23.0 vs 19.4 M voxels/s)
-    long long opt_seed_occ2_from = 250000; // AMX_SEED_OCC2_FROM: calls of at least this many voxels run k_nnls_seed<1> at two wavefronts per SIMD (a third more time per trip, twice the wavefronts: wins when the kernel is throughput bound -- 1 M voxels 2.80 -> 2.14 ms --, loses when the longest voxel's path bounds it: 50 000 voxels 0.54 -> 0.73 ms; with four wavefronts per workgroup the crossover sits between 200 000 and 300 000 voxels)
-    long long opt_seed2_occ2_from = 150000; // AMX_SEED2_OCC2_FROM: the same for k_lasso_seed (200 000 voxels: 0.50 -> 0.42 ms, 1 M: 1.67 -> 1.27 ms)
+    long long opt_seed_occ2_from = 65536; // AMX_SEED_OCC2_FROM: calls of at least this many voxels run k_nnls_seed<1> at two wavefronts per SIMD (a third more time per trip, twice the wavefronts: wins when the kernel is throughput bound -- 1 M voxels 2.80 -> 2.14 ms --, loses when the longest voxel's path bounds it: 50 000 voxels 0.54 -> 0.73 ms; with four wavefronts per workgroup the crossover sits between 200 000 and 300 000 voxels)
+    long long opt_seed2_occ2_from = 65536; // AMX_SEED2_OCC2_FROM: the same for k_lasso_seed (200 000 voxels: 0.50 -> 0.42 ms, 1 M: 1.67 -> 1.27 ms)
+    // AMX_SEED_TRIPCAP=a,b,c: trips after which k_nnls_seed<1> / k_lasso_seed / k_nnls_seed<3> give a voxel up (no seed: it goes
+    // to the left-over kernels).  A lane kernel lasts as long as its slowest voxel, and the slowest are a handful: of 1 M bench
+    // voxels 12 need more than 32 stage-1 trips (mean ~10), yet with the old cap of 64 they held the kernel 0.4 ms longer.
+    // Measured (tools/r04/tripcap2.sh; 50 000 / 200 000 / 1 M voxels, fit in ms): 64,64,64 2.09 / 3.31 / 8.17; 28,24,12 1.74 / 2.94 /
+    // 7.66; below 20 / 18 / 8 the left-over kernels get more voxels than the shorter tails are worth
+    int opt_seed_tripcap[3] = {28, 24, 12};
+    bool opt_no_hard_first = false; // AMX_NO_HARD_FIRST=1: the left-over kernels of the NNLS stages walk their lists in the order the certificates wrote them
     int opt_seed_waves = 0;        // AMX_SEED_WAVES: wavefronts per workgroup of the lane kernels (0 = by the number of chunks, make_plan)
     int opt_seed_stages = 7;       // AMX_SEED_STAGES: bit 0 = seed stage 1, bit 1 = seed stage 3, bit 2 = seed the LASSO stage
     int opt_seed_chunk = 0;        // AMX_SEED_CHUNK (0 = by the call's size, make_plan): voxels of one orientation per workgroup of the seed solvers (lanes refill from the chunk: the more voxels per lane, the smaller the share of the tail; 1 M voxels: 1024 -> 7.2 ms, 2048 -> 7.3, 4096 -> 5.5 for stage 1)
@@ -154,6 +161,11 @@ struct amx_prep {
     int *rank = nullptr;           // device int32[d2][d1][d0]: index in the masked list or -1
     long long *cidx = nullptr;     // device int64[n_vox]: C-order linear index of the masked voxels
     int *gptr = nullptr, *gidx = nullptr, *b0idx = nullptr;
+    // tiles of 64 voxels along the fastest axis that hold at least one masked voxel, made once with the plan: the wavefronts of
+    // k_prep_gather draw from this list through `tile_counter` (zeroed before every launch -- one launch of a plan at a time): an
+    // image is half background, and a strided walk over ALL tiles left some wavefronts with seven full tiles and others with none
+    int *live64 = nullptr, *tile_counter = nullptr;
+    long long n_live64 = 0;
 };
 
 #define HIPCHK(ctx, call)                                                                         \

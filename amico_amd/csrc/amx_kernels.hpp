@@ -685,7 +685,7 @@ __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
             if (left == 0) return;                                  // nothing left over in this chunk
             if (threadIdx.x == 0) atomicAdd(&a.c.status[ST_LEFT + (STAGE == 1 ? 0 : (STAGE == 3 ? 2 : 1))], left);   // (amx_last_seed_stats)
         }
-        if (threadIdx.x == 0) *ticket = (unsigned)nw_;
+        if (threadIdx.x == 0) { ticket[0] = (unsigned)nw_; ticket[1] = (unsigned)nw_; }
         stage_noddi_tile<AT>(As, tiles + (size_t)ck.dir * a.c.tile_stride, words, words_pad - words);
         // NNLS stages with seeds: the float32 compressed dictionary of the orientation for the dual-value screening
         float *Sf = nullptr;
@@ -708,10 +708,21 @@ __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
         // voxels differ 2-3x in solver iterations: the wavefronts draw the next voxel of the chunk from an LDS ticket
         // (next_ticket keeps the control flow wave-uniform: every lane takes part in the atomic)
         if ((STAGE == 1 || STAGE == 3 || STAGE == 4) && a.rlist != nullptr) {
+            // Left-overs of the Gram certificates.  NNLS stages: two walks over the list, the voxels with a wrong or no seed first
+            // (done = 0: Lawson-Hanson, ~140 us), then the ones refused for conditioning alone (done = 2: certified on the true
+            // residual in ~15 us) -- a long voxel drawn last used to keep eleven wavefronts of the workgroup waiting
             const int cnt = a.rcount[cid];
-            for (int k = wave; k < cnt; k = next_ticket(ticket, lane)) {
-                const int pos = a.rlist[ck.start + k];
-                noddi_voxel<STAGE, NR, NQ, MAXP, AT>(a, As, rs, rl, wmask, a.c.perm[pos], ck.dir, lane, pos, Sf);
+            const bool two = (STAGE == 1 || STAGE == 3) && a.done != nullptr;
+            for (int pass = 0; pass < (two ? 2 : 1); pass++) {
+                unsigned *tk = ticket + pass;
+                for (int k = wave; k < cnt; k = next_ticket(tk, lane)) {
+                    const int pos = a.rlist[ck.start + k];
+                    if (two) {
+                        const int flag = __builtin_amdgcn_readfirstlane((int)a.done[pos]);
+                        if ((flag == 2) != (pass == 1)) continue;
+                    }
+                    noddi_voxel<STAGE, NR, NQ, MAXP, AT>(a, As, rs, rl, wmask, a.c.perm[pos], ck.dir, lane, pos, Sf);
+                }
             }
         } else {
             for (int k = wave; k < ck.count; k = next_ticket(ticket, lane)) {

@@ -67,6 +67,7 @@ int amx_launch_noddi_seed2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a,
     sa.ytil = (double *)ctx->ytil2.p; sa.seeds = (unsigned long long *)ctx->seeds2.p;
     sa.nS = lut->nS; sa.n_wm = lut->n_wm; sa.iso_atom = lut->n_atoms - 1; sa.is_exvivo = lut->is_exvivo;
     sa.lam1 = a.c.lam1; sa.lam2 = a.c.lam2;
+    sa.trip_cap = ctx->opt_seed_tripcap[1];
 #ifdef AMX_STATS
     sa.stats = a.c.status + ST_SEED + 20;
 #endif
@@ -103,6 +104,7 @@ static void fill(SeedArgs &sa, const amx_lut *lut, const NoddiArgs &a, const Pla
     sa.ytil = (double *)ctx->ytil.p; sa.seeds = (unsigned long long *)ctx->seeds.p;
     sa.nS = lut->nS; sa.n_atoms = lut->n_atoms; sa.iso_atom = lut->n_atoms - 1;
     sa.dot_atom = lut->is_exvivo ? lut->n_atoms - 2 : -1;
+    sa.trip_cap = ctx->opt_seed_tripcap[0];
 #ifdef AMX_STATS
     sa.stats = a.c.status + ST_SEED + 4;
 #endif
@@ -311,6 +313,7 @@ int amx_launch_noddi_seed(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, 
 {
     SeedArgs sa; fill(sa, lut, a, pl, ctx);
     sa.supp = stage == 3 ? a.supp : nullptr;
+    sa.trip_cap = ctx->opt_seed_tripcap[stage == 1 ? 0 : 2];
     // S for the per-lane gathers + ticket; stage 1 adds S in MFMA operand order (10 x 3 x 64) and a residual block per wavefront
     const size_t lds = (size_t)lut->n_atoms * kSeedLd * sizeof(double) + 64 +
                        (stage == 1 ? ((size_t)10 * (kSeedKD / 4) * 64 + (size_t)4 * 64 * (kSeedKD + 1)) * sizeof(double) : 0);

@@ -160,6 +160,7 @@ struct SeedArgs {
     int *gcount;                  // [max_schunks + 1]: voxels of each chunk handed out so far (zeroed before the launch); last: helpers
     int n_gcount;
     int *stats;                   // optional counters (AMX_STATS): [0] trips, [1] lane-trips in use, [2] voxels, [3] no-seed voxels
+    int trip_cap;                 // a voxel still on its way after this many trips is given up (no seed: left-over list)
 };
 
 template <int NR>
@@ -617,7 +618,7 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
     }
     __syncthreads();
     const double tol = 1e-10, inf = __builtin_huge_val();
-    constexpr int trip_cap = 64;
+    const int trip_cap = a.trip_cap;
 
     bool active = false;
     int pos = 0, trips = 0, last_added = -1, ban0 = -1, ban1 = -1;
@@ -814,6 +815,9 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
                 }
                 // a refused candidate may not come back before another atom has entered: look again without it (rare)
                 if (__ballot(scan && (bj == ban0 || bj == ban1)) != 0ull) {
+#ifdef AMX_STATS
+                    ph[5] += 1024;                  // (diagnosis: the "store" slot counts the trips that take this path)
+#endif
                     best = -inf; bj = -1;
                     for (int j = 0; j < n_atoms; j++) {
                         const double *sp = Sg + (size_t)j * KD;
@@ -920,7 +924,9 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
             a.seeds[pos] = ((unsigned long long)hi << 32) | (unsigned long long)lo;
             active = false;
         }
-        SEED_PH(5);
+#ifdef AMX_STATS
+        pt = (long long)__builtin_readcyclecounter();          // (slot 5 counts the trips that repeat the scan, see above)
+#endif
     }
     __syncthreads();                          // every wavefront is through with this chunk's tables
     }
@@ -1621,7 +1627,11 @@ __global__ void __launch_bounds__(256, RESCUE ? 1 : 2) k_nnls_gcert(const GcertA
         }
         GC_PH(3);
         const bool cert = good && !viol;
-        if (valid) a.done[pos] = cert ? 1 : 0;
+        // done = 2: refused for the conditioning of its Gram block alone -- the support is most likely right, and the left-over kernel's
+        // certificate on the true residual settles it in ~15 us; 0: wrong or no seed, ~140 us of Lawson-Hanson.  The left-over kernel
+        // starts the long ones first (k_noddi)
+        const bool easy = !RESCUE && okv && ill && (pmin > kRescuePivot * pmax);
+        if (valid) a.done[pos] = cert ? 1 : (easy ? 2 : 0);
         {
             // the voxels left to the wavefront-per-voxel kernel, compacted per chunk (that kernel then shares out real work only)
             const unsigned long long rm = __ballot(valid && !cert);
@@ -1996,6 +2006,7 @@ struct Seed2Args {
     int n_gcount;
     int *stats;
     double *trace;                // SEED2_TRACE: per-trip records of the voxel at bucket position 0
+    int trip_cap;                 // see SeedArgs
 };
 
 template <int NR>
@@ -2091,7 +2102,7 @@ __global__ void __launch_bounds__(256, OCC2 ? 2 : AMX_SEED2_OCC) k_lasso_seed(co
     __syncthreads();
     const double lam1 = a.lam1, lam2 = a.lam2, tol = 1e-9, inf = __builtin_huge_val();
     const double sl2 = sqrt(lam2), isl2 = 1.0 / sl2;
-    constexpr int trip_cap = 64;
+    const int trip_cap = a.trip_cap;
 
     bool active = false;
     int pos = 0, trips = 0;
