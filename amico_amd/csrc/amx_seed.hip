@@ -316,7 +316,8 @@ int amx_launch_noddi_seed(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, 
     sa.trip_cap = ctx->opt_seed_tripcap[stage == 1 ? 0 : 2];
     // S for the per-lane gathers + ticket; stage 1 adds S in MFMA operand order (10 x 3 x 64) and a residual block per wavefront
     const size_t lds = (size_t)lut->n_atoms * kSeedLd * sizeof(double) + 64 +
-                       (stage == 1 ? ((size_t)10 * (kSeedKD / 4) * 64 + (size_t)4 * 64 * (kSeedKD + 1)) * sizeof(double) : 0);
+                       (stage == 1 ? ((size_t)10 * (kSeedKD / 4) * 64 + (size_t)4 * 64 * (kSeedKD + 1)) * sizeof(double)
+                                   : (size_t)256 * kSeed3ListRow);                  // stage 3: the lanes' candidate byte lists
     const dim3 grid(((pl.max_schunks + 7) / 8) * 8);
     int rc;
     sa.gcount = pl.feed_set(stage == 1 ? FEED_SEED1 : FEED_SEED3); sa.n_gcount = pl.max_schunks;

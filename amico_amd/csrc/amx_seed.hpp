@@ -25,6 +25,7 @@
 namespace amx {
 
 constexpr int kSeedMax = 8;      // passive-set capacity of the seed solver (= MAXP of the NNLS stage kernels)
+constexpr int kSeed3ListRow = 36;      // bytes per lane of the stage-3 candidate lists in LDS (k_nnls_seed<3>)
 #ifndef SEED3_SCAN_MAX
 #define SEED3_SCAN_MAX 32      // (diagnosis: a smaller value truncates the stage-3 candidate scan)
 #endif
@@ -708,34 +709,37 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
         }
         }
         if (STAGE == 3) {
-            // new voxels: set bits of the candidate mask -> byte list, once per voxel instead of once per trip
+            // new voxels: set bits of the candidate mask -> byte list, once per voxel instead of once per trip.  Some lane is fresh in
+            // nearly every trip, so the WHOLE wavefront walks this loop every trip: the bytes go to the lane's 36-byte row of an LDS
+            // block (one ds_write_b8 per atom; an odd number of words per row: no bank conflicts) instead of being shifted into four
+            // 64-bit registers under selects (~60 instructions per atom -- the conversion was a quarter of this kernel)
             if (__ballot(ncand < 0) != 0ull) {
                 const bool fresh = ncand < 0;
-                unsigned long long rem[4];
+                unsigned char *row = reinterpret_cast<unsigned char *>(ticket + 4) + (size_t)threadIdx.x * kSeed3ListRow;
+                if (fresh) {
 #pragma unroll
-                for (int q = 0; q < 4; q++) rem[q] = fresh ? allow[q] : 0ull;
-                unsigned long long cl[4] = {0ull, 0ull, 0ull, 0ull};
+                    for (int w8 = 0; w8 < 8; w8++) reinterpret_cast<unsigned *>(row)[w8] = 0u;
+                }
                 int nc = 0;
-                for (int it = 0; it < 33; it++) {
-                    int q = -1;
 #pragma unroll
-                    for (int qq = 3; qq >= 0; qq--) q = (rem[qq] != 0ull) ? qq : q;
-                    if (__ballot(q >= 0) == 0ull) break;
-                    unsigned long long word = 0ull;
-#pragma unroll
-                    for (int qq = 0; qq < 4; qq++) word = (q == qq) ? rem[qq] : word;
-                    const unsigned long long j = (q >= 0) ? (unsigned long long)(q * 64 + __builtin_ctzll(word)) : 0ull;
-#pragma unroll
-                    for (int qq = 0; qq < 4; qq++) rem[qq] = (q == qq) ? (rem[qq] & (rem[qq] - 1ull)) : rem[qq];
-                    if (q >= 0 && nc < 32) {
-#pragma unroll
-                        for (int w4 = 0; w4 < 4; w4++) cl[w4] |= ((nc >> 3) == w4) ? (j << (8 * (nc & 7))) : 0ull;
+                for (int q = 0; q < 4; q++) {
+                    unsigned long long rem = fresh ? allow[q] : 0ull;
+                    for (int it = 0; it < 64; it++) {
+                        if (__ballot(rem != 0ull) == 0ull) break;
+                        if (rem != 0ull) {
+                            const int j = q * 64 + __builtin_ctzll(rem);
+                            rem &= rem - 1ull;
+                            if (nc < 32) row[nc] = (unsigned char)j;
+                            nc++;
+                        }
                     }
-                    nc += (q >= 0) ? 1 : 0;
                 }
                 if (fresh) {
 #pragma unroll
-                    for (int w4 = 0; w4 < 4; w4++) cand[STAGE == 3 ? w4 : 0] = cl[w4];
+                    for (int w4 = 0; w4 < 4; w4++) {
+                        const unsigned lo = reinterpret_cast<const unsigned *>(row)[2 * w4], hi = reinterpret_cast<const unsigned *>(row)[2 * w4 + 1];
+                        cand[STAGE == 3 ? w4 : 0] = ((unsigned long long)hi << 32) | (unsigned long long)lo;
+                    }
                     ncand = nc;
                     if (nc > 32 && active) { a.seeds[pos] = kNoSeed; active = false; }      // (never seen: LASSO supports end at 23 atoms)
                 }
