@@ -79,7 +79,7 @@ struct amx_ctx {
     bool opt_no_screen = false;    // AMX_NO_SCREEN=1: certify seeds with the full exact sweep of the dual vector
     bool opt_s2_exact = false;     // AMX_S2_EXACT=1: every voxel's stage-2 products by the exact pass (k_noddi_gemm<true>), none derived from the stage-1 table
     bool opt_no_seed = false;      // AMX_NO_SEED=1: Lawson-Hanson from the empty set in the NNLS stages (the round-2 path)
-    long long opt_seed_min_voxels = 40960; // AMX_SEED_MIN_VOXELS: smaller calls run the wavefront-per-voxel kernels on all voxels (the seeded chain of ~16 kernels has a floor of ~2 ms; measured crossover between 30 000 and 50 000 voxels: 14.6 vs 16.2 and 23.0 vs 19.4 M voxels/s)
+    long long opt_seed_min_voxels = 22528; // AMX_SEED_MIN_VOXELS: smaller calls run the wavefront-per-voxel kernels on all voxels (the seeded chain of ~16 kernels has a floor of ~1.5 ms; measured, tools/r04/round8.sh: 20 000 voxels 1.58 against 1.49 ms, 25 000 voxels 1.60 against 1.78, 40 000 1.70 against 2.34)
     long long opt_seed_occ2_from = 65536; // AMX_SEED_OCC2_FROM: calls of at least this many voxels run k_nnls_seed<1> at two wavefronts per SIMD (a third more time per trip, twice the wavefronts: wins when the kernel is throughput bound -- 1 M voxels 2.80 -> 2.14 ms --, loses when the longest voxel's path bounds it: 50 000 voxels 0.54 -> 0.73 ms; with four wavefronts per workgroup the crossover sits between 200 000 and 300 000 voxels)
     long long opt_seed2_occ2_from = 65536; // AMX_SEED2_OCC2_FROM: the same for k_lasso_seed (200 000 voxels: 0.50 -> 0.42 ms, 1 M: 1.67 -> 1.27 ms)
     // AMX_SEED_TRIPCAP=a,b,c: trips after which k_nnls_seed<1> / k_lasso_seed / k_nnls_seed<3> give a voxel up (no seed: it goes
