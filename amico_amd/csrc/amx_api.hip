@@ -243,6 +243,7 @@ int amx_ctx_create(int device, amx_ctx **out)
         if (e && *e) ctx->opt_seed2_occ2_from = atoll(e);
         ctx->opt_no_chunk_order = on("AMX_NO_CHUNK_ORDER");
         ctx->opt_no_hard_first = on("AMX_NO_HARD_FIRST");
+        ctx->opt_prep_no_direct = on("AMX_PREP_NO_DIRECT");
         e = getenv("AMX_NO_GCERT_WIDE");
         ctx->opt_no_gcert_wide = e && *e && *e != '0';
         e = getenv("AMX_RESCUE_FROM");

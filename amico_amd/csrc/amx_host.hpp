@@ -67,6 +67,7 @@ struct amx_ctx {
     bool opt_fw_proj_valu = false;     // AMX_FW_PROJ_VALU=1: FreeWater projection without the matrix cores
     bool opt_sandi_atom_space = false; // AMX_SANDI_ATOM_SPACE=1: SANDI 6 x 15 by the atom-space lane kernel
     bool opt_prep_scalar = false;      // AMX_PREP_SCALAR=1: the streaming preparation kernel with one voxel per lane (4-byte loads) instead of four
+    bool opt_prep_no_direct = false;   // AMX_PREP_NO_DIRECT=1: k_prep_gather stages the planes through registers (32 loads in flight) instead of global -> LDS loads
     bool opt_prep_tile = false;        // AMX_PREP_TILE=1: signal preparation always through the transposition tile
     bool opt_lut_regs = false;         // AMX_LUT_REGS=1: LUT resampling with register operands
     bool opt_no_refill = false;        // AMX_NO_REFILL=1: FreeWater by k_freewater_lane (one solve per lane and pass)

@@ -11,13 +11,14 @@ namespace amx {
 // the lanes of a wavefront exchange data through LDS: order the accesses, no workgroup barrier needed
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
+constexpr int kDirectLd = 65;              // words per volume row of the direct-load tile (k_prep_gather)
 constexpr int kPrepWaves = 2;               // wavefronts per workgroup, one 64-voxel tile each
 
 struct PrepArgs {
     const float *img; const int *rank; double *y; float *y32; float *mean_b0;     // y32: float32 output instead of y (lossless: the values ARE float32)
     long long d0, d1, d2, s0, s1, s2, sv;
     long long n_tiles, tiles_per_row;
-    int nS, n_out, n_b0, n_gidx, ldt, inplace, layout, normalize;
+    int nS, n_out, n_b0, n_gidx, ldt, inplace, layout, normalize, direct;
     const int *gptr, *gidx, *b0idx;
     float thr;
     const int *live;              // tiles with masked voxels (amx_prep::live64), n_live of them
@@ -45,12 +46,16 @@ __device__ __forceinline__ long long next_live_tile(const PrepArgs &a, int lane)
 //      (core.py:225-227 / 236-252); with identity groups the single multiplication is applied on the way out;
 //  (3) rows are written to y[rank][:] as float64 with negative values clipped (core.py:451-452), coalesced per row.
 // The plan's index lists live in LDS (P): scalar loads from global memory would serialise phase 2.
-template <bool IDENTITY>
+template <bool IDENTITY, bool DIRECT>
 __global__ __launch_bounds__(64 * kPrepWaves) void k_prep_gather(PrepArgs a)
 {
     extern __shared__ float smf[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int per_wave = 64 * a.ldt * (a.inplace ? 1 : 2);
+    // IDENTITY groups on a planar image: the plane runs go global -> LDS directly (no registers in between, so ALL volumes of the
+    // tile are in flight at once instead of 32 at a time) as T[volume][voxel] with a row stride of kDirectLd = 65 words; the other
+    // paths keep T[voxel][volume] (odd stride ldt).  Both are conflict-free for the lane = voxel and the lane = volume accesses.
+    constexpr bool direct = IDENTITY && DIRECT;
+    const int per_wave = IDENTITY ? (direct ? a.nS * kDirectLd : 64 * a.ldt) : 64 * a.ldt * (a.inplace ? 1 : 2);
     int *P = reinterpret_cast<int *>(smf + (size_t)kPrepWaves * per_wave);
     int *Pb0 = P, *Pgp = P + a.n_b0, *Pgi = Pgp + a.n_out + 1;
     for (int i = threadIdx.x; i < a.n_b0; i += blockDim.x) Pb0[i] = a.b0idx[i];
@@ -72,17 +77,30 @@ __global__ __launch_bounds__(64 * kPrepWaves) void k_prep_gather(PrepArgs a)
         const long long base = x0 * a.s0 + i1 * a.s1 + i2 * a.s2;
         float *row_l = T + lane * a.ldt;
         if (a.layout == 2) {
-            // interleaved: lanes run over the volumes of one voxel; sixteen rows in flight
-            for (int k = 0; k < 64; k += 16) {
-                if (!((live >> k) & 0xffffull)) continue;
-                for (int v = lane; v < a.nS; v += 64) {
-                    float tr[16];
-#pragma unroll
-                    for (int u = 0; u < 16; u++) tr[u] = ((live >> (k + u)) & 1ull) ? a.img[base + (k + u) * a.s0 + v] : 0.0f;
-#pragma unroll
-                    for (int u = 0; u < 16; u++) T[(k + u) * a.ldt + v] = tr[u];
+            // interleaved: lanes run over the volumes of one voxel, every live row goes global -> LDS directly (two loads per 99-volume
+            // row, all rows of the tile in flight at once; through registers it was sixteen rows at a time)
+            for (int k = 0; k < 64; k++) {
+                if (!((live >> k) & 1ull)) continue;
+                const float *rowp = a.img + base + k * a.s0;
+                for (int v0 = 0; v0 < a.nS; v0 += 64) {
+                    if (v0 + lane < a.nS)
+                        __builtin_amdgcn_global_load_lds(rowp + v0 + lane, (__attribute__((address_space(3))) void *)(T + k * a.ldt + v0), 4, 0, 0);
                 }
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (direct) {
+            if (r >= 0) {
+                const float *src = a.img + base + lane * a.s0;
+                int v = 0;
+                for (; v + 8 <= a.nS; v += 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        __builtin_amdgcn_global_load_lds(src + (long long)(v + u) * a.sv, (__attribute__((address_space(3))) void *)(T + (v + u) * kDirectLd), 4, 0, 0);
+                }
+                for (; v < a.nS; v++)
+                    __builtin_amdgcn_global_load_lds(src + (long long)v * a.sv, (__attribute__((address_space(3))) void *)(T + v * kDirectLd), 4, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else if (r >= 0) {
             // planar (or generic strides): lanes run over the voxels of one volume; 32 volumes in flight
             const float *src = a.img + base + lane * a.s0;
@@ -108,7 +126,8 @@ __global__ __launch_bounds__(64 * kPrepWaves) void k_prep_gather(PrepArgs a)
         if (r >= 0) {
             if (a.normalize) {
                 float m = 0.0f;
-                for (int i = 0; i < a.n_b0; i++) m = m + row_l[Pb0[i]];
+                if (direct) { for (int i = 0; i < a.n_b0; i++) m = m + T[Pb0[i] * kDirectLd + lane]; }
+                else { for (int i = 0; i < a.n_b0; i++) m = m + row_l[Pb0[i]]; }
                 m = m / (float)a.n_b0;
                 if (a.mean_b0) a.mean_b0[r] = m;
                 f = (m <= a.thr) ? 0.0f : 1.0f / m;                  // norm_factor[idx] = 0, else 1 / mean_b0
@@ -130,6 +149,7 @@ __global__ __launch_bounds__(64 * kPrepWaves) void k_prep_gather(PrepArgs a)
         }
         if (!IDENTITY) WAVE_SYNC();
         const bool scale = IDENTITY && a.normalize;
+        // (four rows per step -- their LDS reads in flight together -- measured slower: 0.254 -> 0.268 ms)
         for (int k = 0; k < 64; k++) {
             if (!((live >> k) & 1ull)) continue;
             const int rk = __builtin_amdgcn_readlane(r, k);
@@ -137,7 +157,7 @@ __global__ __launch_bounds__(64 * kPrepWaves) void k_prep_gather(PrepArgs a)
             double *dst = a.y + (long long)rk * a.n_out;
             float *dst32 = a.y32 + (long long)rk * a.n_out;
             for (int j = lane; j < a.n_out; j += 64) {
-                float val = O[k * a.ldt + j];
+                float val = direct ? T[j * kDirectLd + k] : O[k * a.ldt + j];
                 if (scale) val = val * fk;
                 val = val < 0.0f ? 0.0f : val;
                 if (a.y32) dst32[j] = val;
@@ -465,12 +485,15 @@ static int prep_gather_dev(amx_ctx *ctx, const amx_prep *p, const float *d_img, 
     a.gptr = p->gptr; a.gidx = p->gidx; a.b0idx = p->b0idx; a.thr = b0_threshold;
     a.n_gidx = p->n_gidx;
     const bool identity = p->identity != 0;
-    const size_t lds = ((size_t)kPrepWaves * 64 * a.ldt * (a.inplace ? 1 : 2) + (size_t)p->n_b0 + p->n_out + 1 + p->n_gidx) * sizeof(float);
+    a.direct = (identity && p->layout != 2 && !ctx->opt_prep_no_direct) ? 1 : 0;
+    const size_t per_wave = identity ? (a.direct ? (size_t)a.nS * kDirectLd : (size_t)64 * a.ldt) : (size_t)64 * a.ldt * (a.inplace ? 1 : 2);
+    const size_t lds = ((size_t)kPrepWaves * per_wave + (size_t)p->n_b0 + p->n_out + 1 + p->n_gidx) * sizeof(float);
     if (lds > 160 * 1024) return amx_bad(ctx, "amx_prep_gather: scheme too long for the LDS tile");
     static bool attr_set[64];                                        // per device: the attribute belongs to (function, device)
     if (!attr_set[ctx->device & 63]) {
-        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_prep_gather<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_prep_gather<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_prep_gather<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_prep_gather<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_prep_gather<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[ctx->device & 63] = true;
     }
     const int per_cu = (int)((160 * 1024) / lds) > 8 ? 8 : (int)((160 * 1024) / lds);
@@ -499,8 +522,9 @@ static int prep_gather_dev(amx_ctx *ctx, const amx_prep *p, const float *d_img, 
     }
     HIPCHK(ctx, hipMemsetAsync(p->tile_counter, 0, sizeof(int), s));
     rec(ctx, 8, s);
-    if (identity) hipLaunchKernelGGL(k_prep_gather<true>, dim3((unsigned)grid), dim3(64 * kPrepWaves), lds, s, a);
-    else hipLaunchKernelGGL(k_prep_gather<false>, dim3((unsigned)grid), dim3(64 * kPrepWaves), lds, s, a);
+    if (identity && a.direct) hipLaunchKernelGGL((k_prep_gather<true, true>), dim3((unsigned)grid), dim3(64 * kPrepWaves), lds, s, a);
+    else if (identity) hipLaunchKernelGGL((k_prep_gather<true, false>), dim3((unsigned)grid), dim3(64 * kPrepWaves), lds, s, a);
+    else hipLaunchKernelGGL((k_prep_gather<false, false>), dim3((unsigned)grid), dim3(64 * kPrepWaves), lds, s, a);
     HIPCHK(ctx, hipGetLastError());
     rec(ctx, 9, s);
     return AMX_OK;
