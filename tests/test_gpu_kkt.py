@@ -109,7 +109,7 @@ def test_noddi_kkt_certificates_and_supports(htable500, snr, mapping, amx_env):
     assert np.abs(x[:, 0, -1] - ref['x'][:, 0, -1]).max() < 1e-7      # x_iso handed from stage 1 to stage 2
 
 
-@pytest.mark.parametrize('rescue', [False, True])
+@pytest.mark.parametrize('rescue', [False, True, 'tight trip caps'])
 @pytest.mark.parametrize('exvivo', [False, True])
 def test_noddi_hard_mix_kkt_and_oracle(htable500, exvivo, rescue, amx_env):
     """Signals the dictionary does not explain (synthetic.noddi_hard_signals: crossings, wrong direction, CSF-dominated f_iso in
@@ -118,9 +118,13 @@ def test_noddi_hard_mix_kkt_and_oracle(htable500, exvivo, rescue, amx_env):
     KKT certificates, and the maps must equal the oracle's.  models.pyx:902-981 takes one path whatever the signal; the
     certificate thresholds of the fast path were tuned on clean single-atom voxels.
     rescue: with the second pass of the NNLS certificates that large calls run (k_nnls_gcert<., true>: ill-conditioned supports
-    corrected with the signal itself instead of going to the wavefront-per-voxel kernel)."""
+    corrected with the signal itself instead of going to the wavefront-per-voxel kernel).
+    tight trip caps: the seed solvers give a voxel up after 28 / 24 / 12 trips by default (it goes to the left-over kernels with no
+    seed); with caps of 6 / 5 / 4 a large share of the voxels takes that road -- same certificates, same maps."""
     import torch
-    if rescue:
+    if rescue == 'tight trip caps':
+        amx_env(AMX_SEED_TRIPCAP='6,5,4')
+    elif rescue:
         amx_env(AMX_RESCUE_FROM='0')
     from amico_amd import _capi, get_context, synthetic as S
     from oracle import oracle
@@ -138,6 +142,8 @@ def test_noddi_hard_mix_kkt_and_oracle(htable500, exvivo, rescue, amx_env):
     print('hard mix', 'ex vivo' if exvivo else 'in vivo', st, ss)
     assert st['itercap_voxels'] == 0 and st['guard_trips'] == 0 and st['overflow_voxels'] == 0
     assert ss['seeded_voxels'] == N_VOX                         # the fast path ran (ex vivo too); what it could not certify it handed on
+    if rescue == 'tight trip caps':
+        assert ss['leftover_stage1'] > N_VOX // 20 and ss['leftover_stage3'] > N_VOX // 50, ss
     x = xd.cpu().numpy()
     est = est.cpu().numpy()
     c = _noddi_certificates(K, sch, ht, y, d, x, 0.5, 1e-3, exvivo=exvivo)

@@ -230,6 +230,31 @@ def test_directional_average_bit_exact_including_the_view_aliasing(order):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('order', ['F', 'C'])
+@pytest.mark.parametrize('density', [0.004, 0.5, 1.0])
+def test_prepare_signal_sparse_and_full_masks(order, density):
+    """the gather kernel walks a plan-time list of the tiles that hold masked voxels (amx_prep::live64): a mask with a handful of
+    voxels (most tiles dead, the live ones with a single voxel), a ragged one, and a full one -- extents that are no multiples of the
+    64-voxel tile, both memory orders, float64 and float32 rows -- all bit-exact with the numpy statements of core.py:209-223, 451-452"""
+    from amico_amd import prep
+    sc = S.make_scheme()
+    shape = (131, 7, 9) if order == 'F' else (5, 6, 131)
+    rng = np.random.default_rng(11)
+    img = rng.uniform(0.0, 900.0, shape + (sc.nS,)).astype(np.float32)
+    img[..., sc.b0_idx] += 600.0
+    mask = (rng.uniform(size=shape) < density).astype(np.uint8)
+    mask[-1, -1, -1] = 1                                                 # the very last voxel of the image
+    mask[0, 0, 0] = 1
+    img = np.asarray(img, order=order)
+    ref, mb0 = signal_np.prepare_signal(img, mask, sc.b0_idx, sc.dwi_idx)
+    sp = prep.SignalPreparation(sc, img, mask)
+    for _ in range(2):                                                   # the plan's tile counter is reset by every launch
+        y, m = sp.gather(img)
+        assert y.shape == ref.shape and np.array_equal(y, ref)
+        assert np.array_equal(m, mb0[mask == 1])
+
+
+@pytest.mark.gpu
 def test_prepare_signal_errors_and_edges():
     from amico_amd import prep
     sc = S.make_scheme(n_b0=0, shells=((1000.0, 8),), seed=1)
