@@ -884,6 +884,28 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
                 } else if (V.np >= MS || trips > trip_cap) {
                     done = true; noseed = true;                          // no usable seed
                 } else {
+#ifndef AMX_SEED_ISO_FIRST
+#define AMX_SEED_ISO_FIRST 1
+#endif
+                    if (STAGE == 1 && OCC2 && AMX_SEED_ISO_FIRST) {      // (the one-wavefront build of small calls: 0.279 -> 0.297 ms at 50 000 voxels with it)
+                        // The first atom of a voxel does not enter alone: the isotropic atom, which nearly every optimum holds, takes
+                        // slot 0 in the same trip (unsolved, x = 0 -- if its dual value is positive, as Lawson-Hanson asks of any entering
+                        // atom; should its coefficient come out negative, the next trip's step drops it again).  Two trips fewer per voxel
+                        // (10.4 -> 8.5 on the bench mix, 6.0 -> 4.5 on the hard mix: tools/lab/two_add_lab.py rule 8).
+                        const double *ci = Sl + a.iso_atom * LD;
+                        double si[KD], ciso = 0.0, hii = 0.0;
+                        seed_col<KD>(ci, si);
+#pragma unroll
+                        for (int d = 0; d < KD; d++) { ciso += si[d] * (PREF ? yv[PREF ? d : 0] : yp[d]); hii += si[d] * si[d]; }
+                        const bool pre = V.np == 0 && bj != a.iso_atom && ciso > tol && hii > 0.0;
+                        const double di0 = pre ? inv_sqrt(hii) : 0.0;
+                        V.T[stri<MS>(0, 0)] = pre ? hii * di0 : V.T[stri<MS>(0, 0)];
+                        V.dinv[0] = pre ? di0 : V.dinv[0];
+                        V.idx[0] = pre ? a.iso_atom : V.idx[0];
+                        V.c[0] = pre ? ciso : V.c[0];
+                        V.x[0] = pre ? 0.0 : V.x[0];
+                        V.np += pre ? 1 : 0;
+                    }
                     // append atom bj as slot np: new row of the factor by one forward substitution
                     const double *ct = Sl + bj * LD;
                     double st[KD], cn = 0.0, htt = 0.0;
