@@ -635,6 +635,10 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
         }
     }
     __syncthreads();
+#ifndef AMX_SEED_ISO_FIRST
+#define AMX_SEED_ISO_FIRST 3          // bit 0: stage 1 (two-wavefront build), bit 1: stage 3
+#endif
+    constexpr bool iso_first = (STAGE == 1 && OCC2 && (AMX_SEED_ISO_FIRST & 1)) || (STAGE == 3 && (AMX_SEED_ISO_FIRST & 2));
     const double tol = 1e-10, inf = __builtin_huge_val();
     const int trip_cap = a.trip_cap;
 
@@ -868,10 +872,21 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
 #pragma unroll
                     for (int d = 0; d < KD; d += 2) { w0a += u0[d] * r[d]; w0b += u0[d + 1] * r[d + 1]; w1a += u1[d] * r[d]; w1b += u1[d + 1] * r[d + 1]; }
                     const double w0 = w0a + w0b, w1 = w1a + w1b;
-                    const bool ok0 = scan && (it < ncand) && (j0 != ban0) && (j0 != ban1) && (w0 > best);
+                    // (a voxel's first atom is chosen among the others: the isotropic atom enters with it, see the append below)
+                    const bool ok0 = scan && (it < ncand) && (j0 != ban0) && (j0 != ban1) && (w0 > best) && !(iso_first && V.np == 0 && j0 == a.iso_atom);
                     best = ok0 ? w0 : best; bj = ok0 ? j0 : bj;
-                    const bool ok1 = scan && (it + 1 < ncand) && (j1 != ban0) && (j1 != ban1) && (w1 > best);
+                    const bool ok1 = scan && (it + 1 < ncand) && (j1 != ban0) && (j1 != ban1) && (w1 > best) && !(iso_first && V.np == 0 && j1 == a.iso_atom);
                     best = ok1 ? w1 : best; bj = ok1 ? j1 : bj;
+                }
+                if (iso_first && __ballot(scan && V.np == 0 && !(best > tol)) != 0ull) {
+                    // nothing but the isotropic atom may want in: it is a candidate after all
+                    const double *ci = Sl + a.iso_atom * LD;
+                    double si[KD], wi = 0.0;
+                    seed_col<KD>(ci, si);
+#pragma unroll
+                    for (int d = 0; d < KD; d++) wi += si[d] * r[d];
+                    const bool oki = scan && V.np == 0 && !(best > tol) && wi > best;
+                    best = oki ? wi : best; bj = oki ? a.iso_atom : bj;
                 }
             }
             SEED_PH(3);
@@ -884,10 +899,7 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
                 } else if (V.np >= MS || trips > trip_cap) {
                     done = true; noseed = true;                          // no usable seed
                 } else {
-#ifndef AMX_SEED_ISO_FIRST
-#define AMX_SEED_ISO_FIRST 1
-#endif
-                    if (STAGE == 1 && OCC2 && AMX_SEED_ISO_FIRST) {      // (the one-wavefront build of small calls: 0.279 -> 0.297 ms at 50 000 voxels with it)
+                    if (iso_first) {      // (stage 1: not in the one-wavefront build of small calls -- 0.279 -> 0.297 ms at 50 000 voxels with it)
                         // The first atom of a voxel does not enter alone: the isotropic atom, which nearly every optimum holds, takes
                         // slot 0 in the same trip (unsolved, x = 0 -- if its dual value is positive, as Lawson-Hanson asks of any entering
                         // atom; should its coefficient come out negative, the next trip's step drops it again).  Two trips fewer per voxel
