@@ -62,13 +62,17 @@ def seed(Sk, yt, rule, scale=None):
         if scan:
             r = yt - (Sk[:, idx] @ np.array(x) if idx else 0)
             w = Sk.T @ r
-            if rule >= 4: w = np.where(w > tol, w * scale[min(rule, 4) if rule >= 7 else rule], w)
+            if rule in (9, 10) and idx:
+                Q, _ = np.linalg.qr(Sk[:, idx]); out = Sk - Q @ (Q.T @ Sk); nrm = np.sqrt((out * out).sum(0)); nrm[nrm < 1e-9] = np.inf
+                w = np.where(w > tol, w / nrm, w)
+            elif rule >= 4: w = np.where(w > tol, w * scale[min(rule, 4) if rule >= 7 else rule], w)
             for b in ban:
                 if b >= 0: w[b] = -np.inf
             order = np.argsort(-w)
             bj = int(order[0])
             if not w[bj] > tol or bj in idx: return idx, trips, 'kkt'
             if len(idx) >= MS or trips > cap: return idx, trips, 'noseed'
+            if rule in (10, 11) and not idx and bj != Sk.shape[1] - 1 and (Sk[:, -1] @ yt) > tol: idx.append(Sk.shape[1] - 1); x.append(0.0)
             idx.append(bj); x.append(0.0); last = [bj]
             b2 = int(order[1])
             two = rule == 1 or (rule == 2 and len(idx) <= 2) or rule == 3
@@ -78,7 +82,7 @@ def seed(Sk, yt, rule, scale=None):
         if trips > 2 * cap: return idx, trips, 'noseed'
 
 cache = {}
-res = {r: [] for r in (0, 4, 7, 8)}
+res = {r: [] for r in (0, 4, 11, 9, 10)}
 for v in range(n_vox):
     if lut[v] not in cache:
         A = np.concatenate([wm[:, lut[v], :].astype(np.float64).T, iso[:, None]], axis=1)
