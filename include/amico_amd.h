@@ -263,7 +263,8 @@ int  amx_prep_create(amx_ctx *ctx, const int64_t dims[3], const int64_t strides[
                      int overwrite_in_order, amx_prep **out);
 void amx_prep_destroy(amx_prep *p);
 /* img -> y f64[n_vox][n_out] (+ mean_b0 f32[n_vox] of the masked voxels when normalize != 0 and the pointer is
- * not NULL).  normalize = doNormalizeSignal; b0_threshold = the right-hand side of core.py:217 (0 by default).  */
+ * not NULL).  normalize = doNormalizeSignal; b0_threshold = the right-hand side of core.py:217 (0 by default).
+ * A plan carries the work counter of its gather kernel: ONE gather of a plan in flight at a time (calls on one stream are).  */
 int amx_prep_gather(amx_ctx *ctx, const amx_prep *p, const float *img, int normalize, float b0_threshold,
                     double *out_y, float *out_mean_b0);
 /* (_f32: the prepared signals stay float32 -- every value of core.py:209-268 IS a float32, core.py:451-452 only widen them; the
