@@ -178,3 +178,30 @@ def test_noddi_skewed_orientation_histograms(n, share, amx_env):
     cold = _capi.noddi_fit_device(ctx2, lut2, y, d, 0.5, 1e-3, 3, rmse=True)
     ctx2.sync()
     assert np.abs(cold[0].cpu().numpy() - est).max() < 1e-7 and np.abs(cold[1].cpu().numpy() - rmse).max() < 1e-7
+
+
+def test_order_of_the_left_over_lists_does_not_show_in_the_maps(amx_env):
+    """The NNLS left-over kernels walk their lists twice (voxels with a wrong or no seed first, conditioning-only refusals after:
+    csrc/amx_kernels.hpp k_noddi), and the seed solvers give voxels up after a number of trips.  A voxel's result depends on the voxel
+    alone: the maps are bit-identical with the lists walked in the order they were written (AMX_NO_HARD_FIRST=1), and the maps with
+    trip caps of 64 agree with the default's to solver precision (a given-up voxel is solved by Lawson-Hanson from its signal)."""
+    import torch
+    sys.path.insert(0, ROOT)
+    from amico_amd import _capi, get_context, synthetic as S
+    dirs = S.fibonacci_hemisphere(500); ht = S.build_htable(dirs)
+    sch = S.make_scheme(seed=0); K = S.noddi_kernels(sch, dirs)
+    n = 120_000
+    y_h, d_h = S.noddi_signals(n, K, ht, sch, seed=21, snr=50.0)             # clean data: the most conditioning-only refusals
+    y = torch.from_numpy(y_h).cuda(); d = torch.from_numpy(d_h).cuda()
+    res = {}
+    for name, env in (('default', {}), ('list order', dict(AMX_NO_HARD_FIRST='1')), ('caps 64', dict(AMX_SEED_TRIPCAP='64,64,64'))):
+        amx_env(**{**dict(AMX_NO_HARD_FIRST=None, AMX_SEED_TRIPCAP=None), **env})
+        ctx = get_context()
+        lut = _capi.upload_noddi(ctx, K, ht, sch.dwi_idx)
+        out = _capi.noddi_fit_device(ctx, lut, y, d, 0.5, 1e-3, 3, rmse=True)
+        ctx.sync()
+        ss = ctx.last_seed_stats()
+        assert ss['seeded_voxels'] == n and ss['leftover_stage1'] > n // 50, ss
+        res[name] = (out[0].cpu().numpy(), out[1].cpu().numpy())
+    assert np.array_equal(res['default'][0], res['list order'][0]) and np.array_equal(res['default'][1], res['list order'][1])
+    assert np.abs(res['default'][0] - res['caps 64'][0]).max() < 1e-8
