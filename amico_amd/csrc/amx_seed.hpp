@@ -610,24 +610,6 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
     const Chunk ck = a.schunks[cid];
     const double *__restrict__ Sg = a.Sb + (size_t)ck.dir * n_atoms * KD;
     for (int e = threadIdx.x; e < n_atoms * KD; e += blockDim.x) { const int j = e / KD, d = e - j * KD; Sl[j * LD + d] = Sg[e]; }
-#ifndef AMX_SEED_ISO_FIRST
-#define AMX_SEED_ISO_FIRST 7          // bit 0: stage 1 (two-wavefront build), bit 1: stage 3, bit 2: stage 1 keeps iso out of the MFMA scan
-#endif
-    constexpr bool iso_first = (STAGE == 1 && OCC2 && (AMX_SEED_ISO_FIRST & 1)) || (STAGE == 3 && (AMX_SEED_ISO_FIRST & 2));
-    // Stage 1 (iso_hand): the isotropic atom is NOT in the scan's operand -- its dual value is 12 FMAs with the atom in SCALAR registers
-    // (one orientation per chunk: wave-uniform), so that a voxel's first scan names the best OTHER atom and both enter together even
-    // when iso's own dual value is the largest (emulation: 9.6 -> 8.5 trips per voxel, tools/lab/two_add_lab.py rule 11 -> 8)
-    constexpr bool iso_hand = STAGE == 1 && iso_first && (AMX_SEED_ISO_FIRST & 4);
-    double siso[KD];                       // s_iso (wave-uniform)
-    double niso = 0.0;                     // 1 / ||s_iso||
-    if (iso_hand) {
-        const int dir_u = __builtin_amdgcn_readfirstlane(ck.dir);
-        const double *su = a.Sb + ((size_t)dir_u * n_atoms + a.iso_atom) * KD;
-        double n2 = 0.0;
-#pragma unroll
-        for (int d = 0; d < KD; d++) { siso[d] = su[d]; n2 += siso[d] * siso[d]; }
-        niso = n2 > 0.0 ? inv_sqrt(n2) : 0.0;
-    }
     if (STAGE == 1) {
         // The scan's operand holds the atoms NORMALISED (s_j / ||s_j||): the entering atom is then the one whose direction fits the
         // residual best, not the one with the largest dual value -- Lawson-Hanson may admit any atom with a positive dual value, and
@@ -640,7 +622,7 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
             const int l = e & 63, ks = (e >> 6) % KS, mt = (e >> 6) / KS;
             const int atom = 16 * mt + (l & 15), d = 4 * ks + (l >> 4);
             double v = 0.0;
-            if (atom < n_atoms && !(iso_hand && atom == a.iso_atom)) {
+            if (atom < n_atoms) {
                 v = Sg[(size_t)atom * KD + d];
                 if (AMX_SEED_SCAN_NORM) {
                     double n2 = 0.0;
@@ -653,6 +635,10 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
         }
     }
     __syncthreads();
+#ifndef AMX_SEED_ISO_FIRST
+#define AMX_SEED_ISO_FIRST 3          // bit 0: stage 1 (two-wavefront build), bit 1: stage 3
+#endif
+    constexpr bool iso_first = (STAGE == 1 && OCC2 && (AMX_SEED_ISO_FIRST & 1)) || (STAGE == 3 && (AMX_SEED_ISO_FIRST & 2));
     const double tol = 1e-10, inf = __builtin_huge_val();
     const int trip_cap = a.trip_cap;
 
@@ -852,19 +838,6 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
                         best = ok ? w : best; bj = ok ? j : bj;
                     }
                 }
-                if (iso_hand) {
-                    double wi = 0.0;
-#pragma unroll
-                    for (int d = 0; d < KD; d++) wi = fma(siso[d], r[d], wi);
-                    wi *= niso;
-                    bool iso_p = false;
-#pragma unroll
-                    for (int s = 0; s < MS; s++) iso_p = iso_p || (s < V.np && V.idx[s] == a.iso_atom);
-                    const bool iso_ok = scan && !iso_p && a.iso_atom != ban0 && a.iso_atom != ban1 && wi > tol;
-                    // first trip: iso joins whatever the scan named (append below); alone only if nothing else wants in.  Later: the larger wins
-                    const bool take = iso_ok && (V.np == 0 ? !(best > tol) : (wi > best));
-                    best = take ? wi : best; bj = take ? a.iso_atom : bj;
-                }
                 // a refused candidate may not come back before another atom has entered: look again without it (rare)
                 if (__ballot(scan && (bj == ban0 || bj == ban1)) != 0ull) {
 #ifdef AMX_STATS
@@ -931,17 +904,11 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
                         // slot 0 in the same trip (unsolved, x = 0 -- if its dual value is positive, as Lawson-Hanson asks of any entering
                         // atom; should its coefficient come out negative, the next trip's step drops it again).  Two trips fewer per voxel
                         // (10.4 -> 8.5 on the bench mix, 6.0 -> 4.5 on the hard mix: tools/lab/two_add_lab.py rule 8).
-                        double ciso = 0.0, hii = 0.0;
-                        if (iso_hand) {
+                        const double *ci = Sl + a.iso_atom * LD;
+                        double si[KD], ciso = 0.0, hii = 0.0;
+                        seed_col<KD>(ci, si);
 #pragma unroll
-                            for (int d = 0; d < KD; d++) { ciso = fma(siso[d], (PREF ? yv[PREF ? d : 0] : yp[d]), ciso); hii = fma(siso[d], siso[d], hii); }
-                        } else {
-                            const double *ci = Sl + a.iso_atom * LD;
-                            double si[KD];
-                            seed_col<KD>(ci, si);
-#pragma unroll
-                            for (int d = 0; d < KD; d++) { ciso += si[d] * (PREF ? yv[PREF ? d : 0] : yp[d]); hii += si[d] * si[d]; }
-                        }
+                        for (int d = 0; d < KD; d++) { ciso += si[d] * (PREF ? yv[PREF ? d : 0] : yp[d]); hii += si[d] * si[d]; }
                         const bool pre = V.np == 0 && bj != a.iso_atom && ciso > tol && hii > 0.0;
                         const double di0 = pre ? inv_sqrt(hii) : 0.0;
                         V.T[stri<MS>(0, 0)] = pre ? hii * di0 : V.T[stri<MS>(0, 0)];
