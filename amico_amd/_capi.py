@@ -15,7 +15,7 @@ AMX_OK, AMX_E_BADARG, AMX_E_HIP, AMX_E_DIR_OOB, AMX_E_OVERFLOW, AMX_E_NODEVICE =
 F_RMSE, F_NRMSE, F_MODULATED, F_CORRECTED, F_DEBUG_X = 1, 2, 4, 8, 16
 
 # every symbol include/amico_amd.h declares (tests check that the library exports them all)
-SYMBOLS = ['amx_version', 'amx_ctx_create', 'amx_ctx_destroy', 'amx_last_error',
+SYMBOLS = ['amx_version', 'amx_build_id', 'amx_ctx_create', 'amx_ctx_destroy', 'amx_last_error',
            'amx_lut_upload_noddi', 'amx_lut_upload_freewater', 'amx_lut_upload_sandi', 'amx_lut_destroy',
            'amx_dir_to_lut_idx', 'amx_noddi_fit', 'amx_freewater_fit', 'amx_sandi_fit',
            'amx_noddi_fit_device', 'amx_freewater_fit_device', 'amx_sandi_fit_device', 'amx_sync_status',
@@ -32,6 +32,29 @@ _lib = None
 c_vp, c_dp, c_fp = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float)
 c_i16p, c_i32p, c_i64p = C.POINTER(C.c_int16), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
 PROGRESS_CB = C.CFUNCTYPE(None, C.c_int64, C.c_int64, c_vp)
+
+
+def source_id():
+    """sha256[:16] of the library's sources as they are in the tree now (same recipe as amico_amd/csrc/Makefile)"""
+    import glob
+    import hashlib
+    csrc = os.path.join(_HERE, 'csrc')
+    files = sorted(glob.glob(os.path.join(csrc, '*.hip')) + glob.glob(os.path.join(csrc, '*.hpp')), key=os.path.basename)
+    files.append(os.path.join(_HERE, '..', 'include', 'amico_amd.h'))
+    h = hashlib.sha256()
+    for f in files:
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def build_id():
+    """what the loaded library says it was built from: 'amico_amd <version> csrc <hash>'"""
+    return lib().amx_build_id().decode()
+
+
+def build_is_current():
+    return build_id().split()[-1] == source_id()
 
 
 class AmxError(RuntimeError):
@@ -58,6 +81,7 @@ def lib():
         pass
     L = C.CDLL(LIB_PATH)
     L.amx_version.restype = C.c_int
+    L.amx_build_id.restype = C.c_char_p
     L.amx_ctx_create.argtypes = [C.c_int, C.POINTER(c_vp)]
     L.amx_ctx_destroy.argtypes = [c_vp]
     L.amx_ctx_destroy.restype = None
@@ -134,7 +158,7 @@ def lib():
     L.amx_lut_rotate_resample.argtypes = [c_vp, c_fp, C.c_int, c_fp, C.c_int, C.c_int, C.c_int, c_fp, c_i32p, C.c_int, C.c_int, c_fp]
     for name in SYMBOLS:
         fn = getattr(L, name)
-        if fn.restype is C.c_int and name not in ('amx_version',):
+        if fn.restype is C.c_int and name not in ('amx_version', 'amx_build_id'):
             fn.restype = C.c_int
     _lib = L
     return L

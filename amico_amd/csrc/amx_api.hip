@@ -21,7 +21,7 @@ int upload(amx_ctx *ctx, T **dst, const T *src, size_t n)
 int reset_status(amx_ctx *ctx, hipStream_t s)
 {
     HIPCHK(ctx, hipMemsetAsync(ctx->status_d, 0, ST_WORDS * sizeof(int), s));
-    HIPCHK(ctx, hipMemsetAsync(ctx->status_d + ST_ERRVOX, 0x7f, sizeof(int), s));
+    HIPCHK(ctx, hipMemsetAsync(ctx->status_d + ST_ERRPACK, 0x7f, 2 * sizeof(int), s));
     return AMX_OK;
 }
 
@@ -530,6 +530,16 @@ int amx_sync_status(amx_ctx *ctx, void *hip_stream)
     if (amx_debug()) fprintf(stderr, "[amx] LASSO Gram certificate kcycles (decode | gather+factor+solve | screening | exact duals | output): %d %d %d %d %d\n",
                              st[ST_SEED + 70], st[ST_SEED + 71], st[ST_SEED + 72], st[ST_SEED + 73], st[ST_SEED + 74]);
     if (amx_debug()) fprintf(stderr, "[amx] stage-3 seed solver kcycles: take %d solve+drop %d residual %d scan %d append %d store %d\n", st[ST_SEED + 54], st[ST_SEED + 55], st[ST_SEED + 56], st[ST_SEED + 57], st[ST_SEED + 58], st[ST_SEED + 59]);
+    {
+        // first offending voxel and what it held, as the kernels' one 64-bit atomicMin left them
+        int *sth = ctx->status_h;
+        const unsigned lo = (unsigned)sth[ST_ERRPACK], hi = (unsigned)sth[ST_ERRPACK + 1];
+        sth[ST_ERRVOX] = (int)hi;
+        if (hi != 0x7f7f7f7fu) {
+            if (sth[ST_ERRKIND] == 1) sth[ST_II1] = (int)lo;                                   // (ST_II2 = number of dictionaries, stored by the kernel)
+            else { sth[ST_II1] = (int)(lo >> 16) - 1; sth[ST_II2] = (int)(lo & 0xffffu) - 1; }
+        }
+    }
     if (st[ST_ERRVOX] != 0x7f7f7f7f) {
         char b[256];
         snprintf(b, sizeof b, "\"amico.lut.dir_to_lut_idx\" index out of bounds (%d, %d) [voxel %d]", st[ST_II1], st[ST_II2], st[ST_ERRVOX]);
@@ -903,8 +913,10 @@ __global__ void k_idx_hist(const int *__restrict__ idx, int n, int n_dicts, int 
     if (v >= n) return;
     int d = idx ? idx[v] : 0;
     if (d < 0 || d >= n_dicts) {
-        const int old = atomicMin(&status[ST_ERRVOX], v);
-        if (old > v) { status[ST_II1] = d; status[ST_II2] = n_dicts; }
+        // first bad voxel and ITS index in one 64-bit atomic (two plain stores after an atomicMin on the voxel alone could pair the
+        // smallest voxel with another voxel's index); k_fold_counters unpacks it into ST_ERRVOX / ST_II1
+        atomicMin(reinterpret_cast<unsigned long long *>(status + ST_ERRPACK), ((unsigned long long)(unsigned)v << 32) | (unsigned)d);
+        status[ST_II2] = n_dicts; status[ST_ERRKIND] = 1;      // (the same values from every lane)
         d = -1;
     } else {
         atomicAdd(&counts[d], 1);
@@ -920,7 +932,7 @@ static int batched_dev(amx_ctx *ctx, const amx_dict *dict, const int32_t *d_idx,
     if (n_vox < 0 || n_vox > INT_MAX / 4) return bad(ctx, "amx_*_batched: bad n_vox");
     if (n_vox == 0) return AMX_OK;
     if (!d_y || !d_x) return bad(ctx, "amx_*_batched: null buffer");
-    if (!(lambda1 >= 0.0) || !(lambda2 >= 0.0)) return bad(ctx, "amx_lasso_batched: need lambda1 >= 0 and lambda2 >= 0");
+    if (ridge && (!(lambda1 >= 0.0) || !(lambda2 >= 0.0))) return bad(ctx, "amx_lasso_batched: need lambda1 >= 0 and lambda2 >= 0");
     if (!d_idx && dict->n_dicts != 1) return bad(ctx, "amx_*_batched: dict_idx may only be NULL for a single dictionary");
     (void)who;
     hipStream_t s = (hipStream_t)hip_stream;
@@ -1000,9 +1012,12 @@ static int batched_host(amx_ctx *ctx, const amx_dict *dict, const int32_t *idx, 
                         double *x, double *rnorm)
 {
     if (!ctx) return AMX_E_BADARG;
-    if (!dict) return bad(ctx, "amx_*_batched: null dictionary");
+    const std::string who = ridge ? "amx_lasso_batched" : "amx_nnls_batched";
+    if (!dict || dict->ctx != ctx) return bad(ctx, (who + ": not a dictionary of this ctx").c_str());
     if (n_vox == 0) return AMX_OK;
-    if (n_vox < 0 || !y || !x) return bad(ctx, "amx_*_batched: bad argument");
+    if (n_vox < 0 || n_vox > INT_MAX / 4) return bad(ctx, (who + ": bad n_vox").c_str());      // (before anything is sized from it)
+    if (!y || !x) return bad(ctx, (who + ": null buffer").c_str());
+    if (ridge && (!(lambda1 >= 0.0) || !(lambda2 >= 0.0))) return bad(ctx, "amx_lasso_batched: need lambda1 >= 0 and lambda2 >= 0");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc;
     AMX_H2D(ctx->hy, y, (size_t)n_vox * dict->m * sizeof(double))
@@ -1011,18 +1026,18 @@ static int batched_host(amx_ctx *ctx, const amx_dict *dict, const int32_t *idx, 
     if (rnorm && (rc = ensure(ctx, ctx->hrmse, (size_t)n_vox * sizeof(double)))) return rc;
     if ((rc = batched_dev(ctx, dict, idx ? (const int32_t *)ctx->hdirs.p : nullptr, (const double *)ctx->hy.p, n_vox, lambda1, lambda2, ridge,
                           (double *)ctx->hest.p, rnorm ? (double *)ctx->hrmse.p : nullptr, nullptr, "amx_*_batched"))) return rc;
-    if ((rc = amx_sync_status(ctx, nullptr))) {
-        if (rc == AMX_E_DIR_OOB) {
-            const int *st = ctx->status_h;
-            char b[256];
-            snprintf(b, sizeof b, "amx_*_batched: dict_idx out of range (%d, dictionaries: %d) [voxel %d]", st[ST_II1], st[ST_II2], st[ST_ERRVOX]);
-            ctx->err = b;
-        }
-        return rc;
-    }
+    const int rcs = amx_sync_status(ctx, nullptr);
+    if (rcs == AMX_E_DIR_OOB) {
+        const int *st = ctx->status_h;
+        char b[256];
+        snprintf(b, sizeof b, "%s: dict_idx out of range (%d, dictionaries: %d) [voxel %d]", who.c_str(), st[ST_II1], st[ST_II2], st[ST_ERRVOX]);
+        ctx->err = b;
+    } else if (rcs) return rcs;
+    // (a bad dict_idx: every other voxel is solved, the offending ones hold zeros -- the caller gets those results with the error code,
+    //  as include/amico_amd.h says)
     HIPCHK(ctx, hipMemcpy(x, ctx->hest.p, (size_t)n_vox * dict->n * sizeof(double), hipMemcpyDeviceToHost));
     if (rnorm) HIPCHK(ctx, hipMemcpy(rnorm, ctx->hrmse.p, (size_t)n_vox * sizeof(double), hipMemcpyDeviceToHost));
-    return AMX_OK;
+    return rcs;
 }
 
 int amx_nnls_batched(amx_ctx *ctx, const amx_dict *dict, const int32_t *dict_idx, const double *y, int64_t n_vox, double *x, double *rnorm)

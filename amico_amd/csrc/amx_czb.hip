@@ -200,7 +200,6 @@ __global__ void __launch_bounds__(256, 1) k_czb_lane(const CzbFastArgs a)
     __syncthreads();
     const int n_atoms = a.n_atoms;
     const unsigned valid_atoms = n_atoms >= 32 ? ~0u : ((1u << n_atoms) - 1u);
-    const double tol = 1e-12;
     constexpr int kBackup = 3;
     const int n_blocks = (ck.count + 63) >> 6;
     for (int bl = wave; bl < n_blocks; bl += nw) {
@@ -219,6 +218,15 @@ __global__ void __launch_bounds__(256, 1) k_czb_lane(const CzbFastArgs a)
             if (!(z > 0.0)) Z |= 1u << j;
         }
         Z &= valid_atoms;
+        // the dual tests compare gradients (units of c = A'y - lambda1) with zero: the tolerance follows the voxel's own scale, so that
+        // un-normalised signals (doNormalizeSignal = False: y ~ 1e3) do not flip a near-degenerate atom back and forth on rounding noise
+        double cmax = 1.0;
+        {
+            const double *cz0 = src + (size_t)N * 64;
+#pragma unroll
+            for (int j = 0; j < N; j++) { const double cj = fabs(cz0[(size_t)j * 64]); cmax = (((valid_atoms >> j) & 1u) && cj > cmax) ? cj : cmax; }
+        }
+        const double tol = 1e-12 * cmax;
         bool active = valid && finite, overflow = false;
         int ninf = N + 1, backup = 0, its = 0;
         for (int guard = 0; guard < 6 * N + 32; guard++) {
@@ -305,7 +313,7 @@ __global__ void __launch_bounds__(256, 1) k_czb_lane(const CzbFastArgs a)
                 const int nbad = __builtin_popcount(bad);
                 if (bad == 0u || its > 4 * N + 16) {
                     active = false;
-                    if (bad != 0u) atomicAdd(&a.status[ST_ITCAP], 1);
+                    if (bad != 0u) overflow = true;      // no optimum within the cap: the wavefront-per-voxel solver takes the voxel (overflow list), nothing approximate is emitted
                     // the coefficients, in the lane's column of the LDS block (a clamped or infeasible iterate never reaches the maps negative)
 #pragma unroll
                     for (int j = 0; j < N; j++) xt[j * 64 + lane] = (zform && !((Z >> j) & 1u) && acc[j] > 0.0) ? acc[j] : 0.0;

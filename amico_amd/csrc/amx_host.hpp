@@ -163,9 +163,12 @@ struct amx_prep {
     long long *cidx = nullptr;     // device int64[n_vox]: C-order linear index of the masked voxels
     int *gptr = nullptr, *gidx = nullptr, *b0idx = nullptr;
     // tiles of 64 voxels along the fastest axis that hold at least one masked voxel, made once with the plan: the wavefronts of
-    // k_prep_gather draw from this list through `tile_counter` (zeroed before every launch -- one launch of a plan at a time): an
+    // k_prep_gather draw from this list through a counter of `tile_counter` (a ring: launch k of the plan zeroes and uses entry
+    // k mod kCounterRing on its own stream, so up to kCounterRing gathers of one plan may be in flight together): an
     // image is half background, and a strided walk over ALL tiles left some wavefronts with seven full tiles and others with none
+    static constexpr int kCounterRing = 16;
     int *live64 = nullptr, *tile_counter = nullptr;
+    mutable unsigned launch_seq = 0;
     long long n_live64 = 0;
 };
 

@@ -23,7 +23,7 @@ constexpr int kAuxU = 0, kAuxU2 = 12, kAuxB0 = 24, kAuxYY = 25, kAuxYB = 26, kAu
 __host__ __device__ constexpr int gemm_rows(int n_atoms) { return ((n_atoms + kAuxN + 15) / 16) * 16; }
 constexpr int kScreenLd = 192;   // atoms per row of the float32 screening table [KD][kScreenLd]
 
-enum StatusSlot { ST_ERRVOX = 0, ST_II1 = 1, ST_II2 = 2, ST_OVERFLOW = 3, ST_ITCAP = 4, ST_RERUN = 5, ST_GUARD = 6, ST_GUARDVOX = 7, ST_EXACT = 8, ST_GRAM = 11, ST_ITERS = 14, ST_SEED = 17, ST_LEFT = 92, ST_CLIP = 95, ST_WORDS = 96 };   // ST_LEFT + 0..2: voxels the Gram-space certificates of stage 1 / LASSO / stage 3 left to the wavefront-per-voxel kernels; ST_CLIP: voxels whose stage-2 signal was clipped
+enum StatusSlot { ST_ERRVOX = 0, ST_II1 = 1, ST_II2 = 2, ST_OVERFLOW = 3, ST_ITCAP = 4, ST_RERUN = 5, ST_GUARD = 6, ST_GUARDVOX = 7, ST_EXACT = 8, ST_GRAM = 11, ST_ITERS = 14, ST_SEED = 17, ST_LEFT = 92, ST_CLIP = 95, ST_ERRPACK = 96, ST_ERRKIND = 98, ST_WORDS = 100 };   // ST_LEFT + 0..2: voxels the Gram-space certificates of stage 1 / LASSO / stage 3 left to the wavefront-per-voxel kernels; ST_CLIP: voxels whose stage-2 signal was clipped; ST_ERRPACK (two words, 8-byte aligned): first offending voxel << 32 | what it held, ONE 64-bit atomicMin (amx_sync_status decodes it into ST_ERRVOX / ST_II1 / ST_II2 of the host mirror); ST_ERRKIND: 1 = the payload is a dictionary index of the batched solvers
 
 // ------------------------------------------------------------------ shared pieces
 struct FitCommon {

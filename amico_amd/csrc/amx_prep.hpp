@@ -45,8 +45,10 @@ __global__ __launch_bounds__(1024) void k_dir_to_lut(const double *__restrict__ 
         int idx = dir_to_lut_idx_dev(dirs[3 * (size_t)v], dirs[3 * (size_t)v + 1], dirs[3 * (size_t)v + 2], ht, ii1, ii2);
         if (idx < 0 || idx >= ndirs) {
             idx = -1;
-            const int old = atomicMin(&status[ST_ERRVOX], v + vbase);     // vbase: offset of this batch in the caller's arrays
-            if (old > v + vbase) { status[ST_II1] = ii1; status[ST_II2] = ii2; }
+            // first offending voxel AND its (i1, i2) in one 64-bit atomic -- two plain stores behind an atomicMin on the voxel alone could
+            // pair the smallest voxel with another voxel's indices (vbase: offset of this batch in the caller's arrays; i1, i2 in -1 .. 181)
+            atomicMin(reinterpret_cast<unsigned long long *>(status + ST_ERRPACK),
+                      ((unsigned long long)(unsigned)(v + vbase) << 32) | (unsigned long long)(((unsigned)(ii1 + 1) << 16) | (unsigned)(ii2 + 1)));
         } else if (counts) {
             atomicAdd(use_lds ? &hist[idx] : &counts[idx], 1);
         }

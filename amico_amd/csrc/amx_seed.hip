@@ -273,7 +273,9 @@ int amx_launch_noddi_gcert(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a,
     // (ex-vivo dictionaries leave 7 % of the voxels instead of 5 and 2.5 % -- the dot atom makes more supports ill-conditioned -- and
     //  gain from 1 M voxels: 108 -> 112 M voxels/s; deciding on the device from the first pass's count was tried: the launch that only
     //  hands the lists on costs every other call 1 %)
-    if ((int64_t)pl.n >= (lut->is_exvivo ? ctx->opt_rescue_from / 4 : ctx->opt_rescue_from)) {
+    // (batches of one host-buffer call all take the path the whole call's size asks for, as make_plan does for the seed solvers' builds:
+    //  host and device entry points settle the same voxels with the same arithmetic)
+    if ((ctx->in_host_fit ? ctx->host_total_vox : (int64_t)pl.n) >= (lut->is_exvivo ? ctx->opt_rescue_from / 4 : ctx->opt_rescue_from)) {
         // second pass (large calls: below ~2 M voxels the launch costs more than the wavefront-per-voxel kernel saves -- 1 M voxels
         // 8.08 -> 8.24 ms with it, 4 M 24.99 -> 24.38): the supports refused for conditioning, corrected with the signal itself;
         // what is left goes to the second half

@@ -439,7 +439,7 @@ int amx_prep_create(amx_ctx *ctx, const int64_t dims[3], const int64_t strides[4
     p->n_live64 = (long long)live64.size();
     int rc = dev_copy(ctx, &p->rank, rank_mem.data(), rank_mem.size());
     if (!rc) rc = dev_copy(ctx, &p->live64, live64.data(), live64.size());
-    if (!rc) { const int zero[4] = {0, 0, 0, 0}; rc = dev_copy(ctx, &p->tile_counter, zero, 4); }
+    if (!rc) { const int zero[amx_prep::kCounterRing] = {0}; rc = dev_copy(ctx, &p->tile_counter, zero, amx_prep::kCounterRing); }
     if (!rc) rc = dev_copy(ctx, &p->cidx, cidx.data(), cidx.size());
     if (!rc) rc = dev_copy(ctx, &p->gptr, group_ptr, (size_t)n_out + 1);
     if (!rc) rc = dev_copy(ctx, &p->gidx, group_idx, (size_t)group_ptr[n_out]);
@@ -500,7 +500,10 @@ static int prep_gather_dev(amx_ctx *ctx, const amx_prep *p, const float *d_img, 
     long long grid = 256LL * per_cu;               // what is resident at once: the wavefronts draw their tiles from the live list
     const long long need = (p->n_live64 + kPrepWaves - 1) / kPrepWaves;
     if (grid > need) grid = need;
-    a.live = p->live64; a.n_live = p->n_live64; a.counter = p->tile_counter;
+    // every launch draws its tiles from ITS OWN counter (a ring of kCounterRing, taken in launch order): two gathers of one plan may
+    // be in flight together (two streams, double-buffered images sharing a mask) without sharing or resetting each other's ticket
+    int *const my_counter = p->tile_counter + (p->launch_seq++ % amx_prep::kCounterRing);
+    a.live = p->live64; a.n_live = p->n_live64; a.counter = my_counter;
     if (!identity && !p->hazard && p->layout == 1 && !ctx->opt_prep_tile) {
         // grouped outputs on a planar image: streaming kernel, no transposition tile
         const size_t lds_s = ((size_t)p->n_b0 + p->n_out + 1 + p->n_gidx) * sizeof(int);
@@ -520,7 +523,7 @@ static int prep_gather_dev(amx_ctx *ctx, const amx_prep *p, const float *d_img, 
         rec(ctx, 9, s);
         return AMX_OK;
     }
-    HIPCHK(ctx, hipMemsetAsync(p->tile_counter, 0, sizeof(int), s));
+    HIPCHK(ctx, hipMemsetAsync(my_counter, 0, sizeof(int), s));
     rec(ctx, 8, s);
     if (identity && a.direct) hipLaunchKernelGGL((k_prep_gather<true, true>), dim3((unsigned)grid), dim3(64 * kPrepWaves), lds, s, a);
     else if (identity) hipLaunchKernelGGL((k_prep_gather<true, false>), dim3((unsigned)grid), dim3(64 * kPrepWaves), lds, s, a);

@@ -27,6 +27,17 @@ def reset_context():
     _CTX = None
 
 
+def _digest(a):
+    """content digest of a whole array (xxh3-128 when xxhash is importable, sha1 otherwise)"""
+    b = np.ascontiguousarray(a)
+    try:
+        import xxhash
+        return xxhash.xxh3_128(b.data).hexdigest()
+    except ImportError:
+        import hashlib
+        return hashlib.sha1(b.data).hexdigest()
+
+
 class BaseModel(ABC):
     """models.pyx:75-217"""
 
@@ -149,14 +160,14 @@ class BaseModel(ABC):
 
     # ---- dictionary cache: one upload per (KERNELS, htable) object pair AND model / scheme state that shapes the
     #      device dictionary.  The keyed objects are held (an id() can be recycled once its object is collected), and
-    #      a cheap content fingerprint catches in-place edits of KERNELS.
+    #      a digest of EVERY byte of the arrays catches in-place edits of KERNELS (the reference re-reads KERNELS on every
+    #      fit, models.pyx:840-847; xxh3 of the default NODDI dictionary, 28 MB: 4 ms).
     def _lut_extra_key(self):
         return ()
 
     def _lut(self, evaluation, builder):
         K, ht = evaluation.KERNELS, getattr(evaluation, 'htable', None)
-        finger = tuple((k, getattr(v, 'shape', None), float(np.asarray(v).ravel()[:: max(1, np.asarray(v).size // 64)].sum()))
-                       for k, v in sorted(K.items()) if isinstance(v, np.ndarray))
+        finger = tuple((k, v.shape, str(v.dtype), _digest(v)) for k, v in sorted(K.items()) if isinstance(v, np.ndarray))
         sc = self.scheme
         skey = None if sc is None else (int(getattr(sc, 'nS', 0)), tuple(np.asarray(getattr(sc, 'dwi_idx', ())).tolist()))
         ctx = get_context()                 # (a dictionary lives in ONE context: reset_context() must not leave a stale upload behind)

@@ -45,12 +45,40 @@ def median_rate(fn, n, runs=5):
     return n / float(np.median(ts)), float(np.median(ts))
 
 
+_PMC = {}
+
+
+def pmc_json():
+    """profiles/pmc_traffic.json -- but only when it was measured on THIS build: the summary carries the source hash of the library
+    it profiled (`csrc_hash`, written by tools/r05/summarise.py from amx_build_id); counters of other kernels are not reported as
+    this run's.  Returns (dict or None, note)."""
+    if 'v' not in _PMC:
+        t, note = None, None
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
+                t = json.load(f)
+            from amico_amd import _capi
+            have = _capi.build_id().split()[-1]
+            if t.get('csrc_hash') != have:
+                note = 'profiles/pmc_traffic.json was measured on build %s, this library is %s: counter figures withheld' % (t.get('csrc_hash'), have)
+                t = None
+        except (OSError, ValueError) as e:
+            note = 'profiles/pmc_traffic.json unreadable: %s' % e
+        _PMC['v'] = (t, note)
+    return _PMC['v']
+
+
+def build_record():
+    from amico_amd import _capi
+    return {'build_id': _capi.build_id(), 'source_id': _capi.source_id(), 'library_matches_sources': _capi.build_is_current(),
+            'pmc_summary_note': pmc_json()[1]}
+
+
 def pmc_small(model, key):
     """per-launch counter figure of the lane kernels from the committed profile summary (profiles/pmc_traffic.json)"""
     try:
-        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
-            return json.load(f)['small_models'][model][key]
-    except (OSError, KeyError, ValueError):
+        return pmc_json()[0]['small_models'][model][key]
+    except (KeyError, TypeError):
         return None
 
 
@@ -106,7 +134,7 @@ def small_model(model, n, steps, warmup, cpu=True, host_legs=True):
             ctx.check(L.amx_czb_fit_device(ctx._h, lut._h, y.data_ptr(), d.data_ptr(), n, 0.0, 4.0, 0, est.data_ptr(), None, None, None))
         ref = lambda m: oracle.czb_fit(y_h[:m], d_h[:m], K, Rs_, htable, nthreads=cores)['estimates']
         name = 'CylinderZeppelinBall fit, %d voxels, %d volumes (3 shells), 26 atoms, ndirs=500' % (n, scheme.nS)
-        kernel = 'k_czb<2, 1, 32, 8, false>'
+        kernel = 'k_czb_project<25> + k_czb_lane (projection z0 = M(A\'y - lambda1), c on the fp64 matrix cores, then block principal pivoting, one voxel per lane)'
     else:
         full = S.make_sandi_scheme()
         avg = S.directional_average_scheme(full)
@@ -473,12 +501,10 @@ def _capi_lib():
 def pmc_valu(stage, n, kernel_ms):
     """compute-side reading of the stage kernel: VALU wave-instructions per voxel (committed rocprofv3 PMC pass) and the
     share of the SIMDs' issue cycles they fill at the live kernel time (1024 SIMDs, 2.4 GHz, 4 cycles per wave64 VALU op)"""
-    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')
+    t = pmc_json()[0]
     try:
-        with open(p) as f:
-            t = json.load(f)
         insts = float(t['stage_valu_insts_per_launch'][str(stage)]) / t['voxels_per_launch']
-    except (OSError, KeyError, ValueError):
+    except (KeyError, ValueError, TypeError):
         return None
     busy = insts * n * 4.0 / 1024.0 / (kernel_ms * 1e-3 * 2.4e9)
     out = {'bound': 'dependent latency (VALU issue slots mostly idle)', 'valu_wave_insts_per_voxel': insts, 'issue_cycles_filled': busy,
@@ -498,24 +524,20 @@ def pmc_valu(stage, n, kernel_ms):
 def pmc_traffic(stage, n):
     """HBM bytes per launch of the stage kernel from the committed rocprofv3 PMC passes (profiles/), scaled to
     this run's voxels per launch; None when the profile summary is not there."""
-    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')
+    t = pmc_json()[0]
     try:
-        with open(p) as f:
-            t = json.load(f)
         return float(t['stage_bytes_per_launch'][str(stage)]) * n / t['voxels_per_launch']
-    except (OSError, KeyError, ValueError):
+    except (KeyError, ValueError, TypeError):
         return None
 
 
 def pmc_whole_fit(n):
     """HBM bytes of ONE whole NODDI fit (all kernel groups of the committed PMC passes), scaled to n voxels"""
-    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')
+    t = pmc_json()[0]
     try:
-        with open(p) as f:
-            t = json.load(f)
         b = t['stage_bytes_per_launch']
         return sum(float(b[k]) for k in ('1', '2', '3', '5', '6', '7')) * n / t['voxels_per_launch']
-    except (OSError, KeyError, ValueError):
+    except (KeyError, ValueError, TypeError):
         return None
 
 
@@ -565,7 +587,7 @@ def noddi_hard_mix(ctx, lut, K, htable, scheme, n, steps, warmup):
     return out
 
 
-def noddi_other_protocol(ctx, shells, n_b0, n, steps, warmup, headline_rate_per_byte, exvivo=False):
+def noddi_other_protocol(ctx, shells, n_b0, n, steps, warmup, headline_rate_per_byte, exvivo=False, snr=None):
     """the NODDI fit on another acquisition protocol (the reference's loop is shape generic, models.pyx:825-828, 851-861): voxels/s,
     the share of the headline's rate per byte of signal, certification rates, parity on a sample"""
     import torch
@@ -576,7 +598,7 @@ def noddi_other_protocol(ctx, shells, n_b0, n, steps, warmup, headline_rate_per_
     htable = S.build_htable(lut_dirs)
     scheme = S.make_scheme(n_b0, shells, seed=4)
     K = S.noddi_kernels(scheme, lut_dirs)
-    y_h, d_h = S.noddi_signals_parallel(n, K, htable, scheme, seed=17)
+    y_h, d_h = S.noddi_signals_parallel(n, K, htable, scheme, seed=17, **({} if snr is None else {'snr': snr}))
     lut = _capi.upload_noddi(ctx, K, htable, scheme.dwi_idx, exvivo)
     y = torch.from_numpy(y_h).to(dev); d = torch.from_numpy(d_h).to(dev)
     est = torch.zeros((n, 4 if exvivo else 3), dtype=torch.float64, device=dev)
@@ -600,7 +622,7 @@ def noddi_other_protocol(ctx, shells, n_b0, n, steps, warmup, headline_rate_per_
                            nthreads=physical_cores() or os.cpu_count() or 1)
     diff = np.abs(est.cpu().numpy()[pick] - ref['estimates']).max(axis=1)
     bpv = 8 * scheme.nS + 48
-    out = {'metric': 'voxels/sec, NODDI fit, %d-volume protocol%s (inputs resident in HBM)' % (scheme.nS, ', ex-vivo model (dot compartment, 4 maps)' if exvivo else ''), 'value': n / el, 'unit': 'voxels/s', 'voxels': n,
+    out = {'metric': 'voxels/sec, NODDI fit, %d-volume protocol%s%s (inputs resident in HBM)' % (scheme.nS, ', ex-vivo model (dot compartment, 4 maps)' if exvivo else '', '' if snr is None else ', SNR %g' % snr), 'value': n / el, 'unit': 'voxels/s', 'voxels': n,
            'ms_per_step': 1e3 * el, 'volumes': int(scheme.nS), 'bytes_per_voxel': bpv,
            'rate_per_byte_vs_headline': (n / el * bpv) / headline_rate_per_byte,
            'solver_stats': stats, 'seed_chain': seed,
@@ -650,11 +672,35 @@ def timed_steps(step, step_sync, steps, warmup, world, dev, per_step=None):
             per_step()
     device_barrier(dev, world)
     elapsed = time.perf_counter() - t0
+    per_rank = [elapsed]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        # every rank's own clock next to the MAX (the contract's figure): the first N > 1 run should read like any other
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        every = torch.zeros(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(every, mine)
+        per_rank = [float(v) for v in every.cpu()]
+        elapsed = max(per_rank)
+    timed_steps.per_rank = per_rank
     return elapsed
+
+
+def rank_records(world, rank, dev):
+    """who ran: backend, world size and each rank's device (gathered through the process group when there is one)"""
+    import torch
+    import torch.distributed as dist
+    me = {'rank': rank, 'device': torch.cuda.get_device_name(dev) if dev.type == 'cuda' else 'cpu', 'index': dev.index, 'pid': os.getpid()}
+    if dev.type == 'cuda':
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            me['pci_bus_id'] = '%04x:%02x:%02x' % (getattr(pr, 'pci_domain_id', 0), pr.pci_bus_id, getattr(pr, 'pci_device_id', 0))
+        except Exception:
+            pass
+    recs = [me]
+    if world > 1:
+        recs = [None] * world
+        dist.all_gather_object(recs, me)
+    return {'rccl_ranks': world, 'backend': dist.get_backend() if (world > 1 and dist.is_initialized()) else 'none (single process)',
+            'ranks': recs}
 
 
 def self_launch(n_gpus):
@@ -758,6 +804,7 @@ def main():
     if seed_chain.get('seeded_voxels'):            # (the counters accumulate between two syncs: one step's worth here)
         seed_chain['certified_by_gram_certificates'] = seed_chain.pop('certified')
 
+    who = rank_records(world, rank, dev)
     if rank == 0:
         value = world * n * args.steps / elapsed
         groups = {1: 'k_noddi<1> (stage 1: voxels the Gram certificate left over) + re-run kernel', 2: 'k_noddi<4> (LASSO: left-over voxels) + re-run kernel',
@@ -802,6 +849,8 @@ def main():
                          'note': 'the path is bound by dependent latencies inside the per-voxel active-set solvers, not by HBM (DESIGN.md section 5): see compute_side'},
             'compute_side': pmc_valu(stage, n, dom_ms),
             'solver_stats': stats, 'seed_chain': seed_chain,
+            'multi_gpu': dict(who, elapsed_s_per_rank=getattr(timed_steps, 'per_rank', None), elapsed_s_max=elapsed),
+            'build': build_record(),
         }
         if world == 1:
             from oracle import oracle
@@ -852,6 +901,12 @@ def main():
                 other['noddi_105vol'] = noddi_other_protocol(ctx, ((700.0, 50), (2000.0, 50)), 5, min(n, 1_000_000), 5, 2, per_byte)
                 other['noddi_150vol'] = noddi_other_protocol(ctx, ((700.0, 40), (2000.0, 60), (3000.0, 40)), 10, min(n, 1_000_000), 5, 2, per_byte)
                 other['noddi_exvivo'] = noddi_other_protocol(ctx, ((700.0, 30), (2000.0, 60)), 9, min(n, 1_000_000), 5, 2, per_byte, exvivo=True)
+                # the headline's protocol at other noise levels: the chain's thresholds (trip caps, pivot ratios, switch points) were tuned
+                # at SNR 30 -- correctness does not depend on them, the rate does
+                other['noddi_snr10'] = noddi_other_protocol(ctx, ((700.0, 30), (2000.0, 60)), 9, min(n, 1_000_000), 5, 2, per_byte, snr=10.0)
+                other['noddi_snr50'] = noddi_other_protocol(ctx, ((700.0, 30), (2000.0, 60)), 9, min(n, 1_000_000), 5, 2, per_byte, snr=50.0)
+                # an HCP-style acquisition (18 b0 + 3 x 90 directions = 288 volumes): the most common public NODDI data
+                other['noddi_288vol'] = noddi_other_protocol(ctx, ((1000.0, 90), (2000.0, 90), (3000.0, 90)), 18, min(n, 1_000_000), 5, 2, per_byte)
             if not args.no_cpu_baseline:
                 # bounded CPU legs on the host cores of this box: the oracle -- a port, the reference's
                 # cyspams path cannot be built -- at -O3 -march=native, the reference's chunk-per-thread structure

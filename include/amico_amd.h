@@ -42,6 +42,11 @@ typedef struct amx_ctx amx_ctx;   /* one per process+GPU: stream-ordered workspa
 typedef struct amx_lut amx_lut;   /* device-resident dictionary (KERNELS) of one model          */
 
 int  amx_version(void);
+/* "amico_amd <version> csrc <16 hex digits>": the digits are sha256 of the library's sources (the .hip and .hpp files of amico_amd/csrc and this
+ * header, concatenated in name order) as they were when the library was BUILT -- amico_amd._capi.source_id() takes the same hash of
+ * the sources in the tree, so a stale .so, or a profile summary taken from other kernels (profiles/pmc_traffic.json carries the id
+ * of the build it measured), is detected instead of trusted.  Static storage. */
+const char *amx_build_id(void);
 /* device < 0: current HIP device.  Fails with AMX_E_NODEVICE when no gfx950 GPU is visible. */
 int  amx_ctx_create(int device, amx_ctx **out);
 void amx_ctx_destroy(amx_ctx *ctx);

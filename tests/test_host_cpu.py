@@ -181,16 +181,30 @@ def _worker_presharded(rank, world, port, tmp):
     t = torch.tensor([el], dtype=torch.float64)
     lo = t.clone(); dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     assert float(lo) == el                                       # every rank reports the same (maximum) time
+    assert len(bench.timed_steps.per_rank) == world and max(bench.timed_steps.per_rank) == el    # ... and every rank's own clock beside it
+    who = bench.rank_records(world, rank, torch.device('cpu'))    # the bench line's multi_gpu record (devices gathered through the group)
+    assert who['rccl_ranks'] == world and who['backend'] == 'gloo' and [r['rank'] for r in who['ranks']] == list(range(world))
+    assert len({r['pid'] for r in who['ranks']}) == world        # one process per rank
     np.save(os.path.join(tmp, f'ok{rank}.npy'), np.array([el]))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world', [2, 3, 8])
 def test_presharded_fit_and_bench_step_gloo(tmp_path, world):
     import torch.multiprocessing as mp
     rng = np.random.default_rng(world)
-    np.save(tmp_path / 'full.npy', rng.random((1003, 7)))       # 1003 = 3 * 334 + 1 = 2 * 501 + 1: odd remainders
+    # 1003 = 3 * 334 + 1 = 2 * 501 + 1: odd remainders; world 8 (config 5's real world size): 8 x 4096 voxels + 5 -- the last of
+    # the eight shards is the longer one (models.pyx:204-211) and the packed gather runs at the world size the driver will use
+    np.save(tmp_path / 'full.npy', rng.random((8 * 4096 + 5 if world == 8 else 1003, 7)))
     port = 33500 + (os.getpid() % 2000) + world
     mp.spawn(_worker_presharded, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert os.path.exists(tmp_path / f'ok{r}.npy')
+
+
+def test_build_id_matches_the_sources():
+    """amx_build_id carries the hash of the sources the library was built from; _capi.source_id() takes the same hash of the tree"""
+    from amico_amd import _capi
+    bid = _capi.build_id()
+    assert bid.startswith('amico_amd ') and ' csrc ' in bid and len(bid.split()[-1]) == 16
+    assert _capi.build_is_current(), 'libamico_amd.so is older than its sources: run make -C amico_amd/csrc'
