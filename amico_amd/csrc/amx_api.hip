@@ -308,7 +308,7 @@ static int build_tiles(amx_ctx *ctx, amx_lut *lut, const float *src, size_t src_
     if ((rc = upload(ctx, &d_src, src, src_n))) return rc;
     if ((rc = upload(ctx, &d_fix, fix, fix_n ? fix_n : 1))) return rc;
     if ((rc = upload(ctx, &d_ones, fix_ones.data(), fix_ones.size()))) return rc;
-    const size_t bytes = (size_t)lut->ndirs * lut->tile_stride * sizeof(float) + 64;
+    const size_t bytes = ((size_t)lut->ndirs * lut->tile_stride + kTileSlack) * sizeof(float) + 64;   // (slack: the global-tile kernels' row sweeps read past the last row's end)
     HIPCHK(ctx, hipMalloc(&lut->tiles, bytes));
     HIPCHK(ctx, hipMemset(lut->tiles, 0, bytes));
     hipLaunchKernelGGL(k_build_lut, dim3(2048), dim3(256), 0, nullptr, d_src, d_fix, d_ones, n_lut,
@@ -329,7 +329,8 @@ int amx_lut_upload_noddi(amx_ctx *ctx, const float *wm, const float *iso, const 
         nS <= 0 || dwi_count < 0 || dwi_count > nS)
         return bad(ctx, "amx_lut_upload_noddi: bad argument");
     const int n_atoms = n_wm + 1 + (is_exvivo ? 1 : 0);
-    if (n_atoms > 192 || nS > 256) return bad(ctx, "amx_lut_upload_noddi: unsupported size (n_atoms <= 192, nS <= 256)");
+    // any shape models.pyx:825-861 would run, up to what a wavefront's lanes hold: 8 rows / 4 atoms per lane
+    if (n_atoms > 256 || nS > 512) return bad(ctx, "amx_lut_upload_noddi: unsupported size (n_atoms <= 256, nS <= 512)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     amx_lut *lut = new amx_lut();
     lut->ctx = ctx; lut->model = 1; lut->nS = nS; lut->n_atoms = n_atoms; lut->ndirs = ndirs;
@@ -370,17 +371,19 @@ int amx_lut_upload_noddi(amx_ctx *ctx, const float *wm, const float *iso, const 
     // they let the solver update the dual vector without sweeping the tile (amx_solver.hpp)
     {
         if (!ctx->opt_no_gram) {
-            lut->ldG = 192;
+            lut->ldG = n_atoms <= 192 ? 192 : 256;            // (>= 64 atoms per lane-row of the solvers' column reads)
             const size_t gbytes = (size_t)ndirs * n_atoms * lut->ldG * sizeof(double);
-            const size_t lds = (size_t)nS * lut->ldA * sizeof(float);
+            const size_t lds_tile = (size_t)nS * lut->ldA * sizeof(float);
+            const int in_lds = lds_tile <= 160 * 1024 ? 1 : 0;
+            const size_t lds = in_lds ? lds_tile : 0;
             HIPCHK(ctx, hipMalloc((void **)&lut->gram, gbytes));
             HIPCHK(ctx, hipMalloc((void **)&lut->gram_dwi, gbytes));
             HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_build_gram),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(k_build_gram, dim3(ndirs), dim3(512), lds, nullptr, (const float *)lut->tiles,
-                               lut->tile_stride, nS, lut->ldA, n_atoms, (const unsigned char *)nullptr, lut->ldG, lut->gram);
+                               lut->tile_stride, nS, lut->ldA, n_atoms, (const unsigned char *)nullptr, lut->ldG, lut->gram, in_lds);
             hipLaunchKernelGGL(k_build_gram, dim3(ndirs), dim3(512), lds, nullptr, (const float *)lut->tiles,
-                               lut->tile_stride, nS, lut->ldA, n_atoms, (const unsigned char *)lut->rowdwi, lut->ldG, lut->gram_dwi);
+                               lut->tile_stride, nS, lut->ldA, n_atoms, (const unsigned char *)lut->rowdwi, lut->ldG, lut->gram_dwi, in_lds);
             HIPCHK(ctx, hipGetLastError());
             HIPCHK(ctx, hipDeviceSynchronize());
             // compressed basis of every orientation: support seeds of the NNLS stages (amx_seed.hpp)
@@ -970,13 +973,13 @@ int amx_dict_upload(amx_ctx *ctx, const double *A, int m, int n, int n_dicts, am
 {
     if (!ctx) return AMX_E_BADARG;
     if (!A || !out || m <= 0 || n <= 0 || n_dicts <= 0) return bad(ctx, "amx_dict_upload: bad argument");
-    if (n > 192 || m > 256) return bad(ctx, "amx_dict_upload: unsupported size (n <= 192 atoms, m <= 256 samples)");
+    // (dictionaries that fit a CU's LDS as fp64 are staged there; larger ones -- up to 512 samples x 256 atoms, what a wavefront's lanes
+    //  hold -- are read where they lie: amx_batched.hip)
+    if (n > 256 || m > 512) return bad(ctx, "amx_dict_upload: unsupported size (n <= 256 atoms, m <= 512 samples)");
     const int ldA = (n & 1) ? n : n + 1;
     const int tile_stride = (m * ldA + 3) & ~3;
-    if (fit_lds_bytes<double>(m, ldA, m <= 128 ? 2 : 4, 3, 1, 48, false, true) > (size_t)160 * 1024)
-        return bad(ctx, "amx_dict_upload: an m x n float64 dictionary of this size does not fit the 160 KB LDS of a compute unit");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    std::vector<double> t((size_t)n_dicts * tile_stride, 0.0);
+    std::vector<double> t((size_t)n_dicts * tile_stride + kTileSlack, 0.0);
     for (int d = 0; d < n_dicts; d++)
         for (int j = 0; j < n; j++)
             for (int i = 0; i < m; i++) t[(size_t)d * tile_stride + (size_t)i * ldA + j] = A[((size_t)d * n + j) * m + i];     // column-major in, ld = m

@@ -289,23 +289,7 @@ struct GramSolver {
             double u[NQ], w2[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; q++) { u[q] = 0.0; w2[q] = 0.0; }
-            {
-                const AT *ap = As + lane;
-                int i = 0;
-                for (; i + 1 < nS; i += 2) {
-                    const double r0 = rs[i], r1 = rs[i + 1];
-#pragma unroll
-                    for (int q = 0; q < NQ; q++) {
-                        u[q] += (double)ap[i * ldA + kWave * q] * r0;
-                        w2[q] += (double)ap[(i + 1) * ldA + kWave * q] * r1;
-                    }
-                }
-                if (i < nS) {
-                    const double r0 = rs[i];
-#pragma unroll
-                    for (int q = 0; q < NQ; q++) u[q] += (double)ap[i * ldA + kWave * q] * r0;
-                }
-            }
+            tile_sweep<NQ, AT>(As + lane, ldA, nS, rs, u, w2);
 #pragma unroll
             for (int q = 0; q < NQ; q++) {
                 const double gq = scl[q] * (u[q] + w2[q]) - lam1;
@@ -416,23 +400,7 @@ struct GramSolver {
                 double w2[NQ];
 #pragma unroll
                 for (int q = 0; q < NQ; q++) { u[q] = 0.0; w2[q] = 0.0; }
-                {
-                    const AT *ap = As + lane;
-                    int i = 0;
-                    for (; i + 1 < nS; i += 2) {
-                        const double r0 = rs[i], r1 = rs[i + 1];
-#pragma unroll
-                        for (int q = 0; q < NQ; q++) {
-                            u[q] += (double)ap[i * ldA + kWave * q] * r0;
-                            w2[q] += (double)ap[(i + 1) * ldA + kWave * q] * r1;
-                        }
-                    }
-                    if (i < nS) {
-                        const double r0 = rs[i];
-#pragma unroll
-                        for (int q = 0; q < NQ; q++) u[q] += (double)ap[i * ldA + kWave * q] * r0;
-                    }
-                }
+                tile_sweep<NQ, AT>(As + lane, ldA, nS, rs, u, w2);
 #pragma unroll
                 for (int q = 0; q < NQ; q++) u[q] += w2[q];
                 if (!have_u) {

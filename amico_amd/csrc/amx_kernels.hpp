@@ -654,11 +654,15 @@ __device__ __forceinline__ int next_ticket(unsigned *ticket, int lane)
     return __builtin_amdgcn_readfirstlane((int)old);
 }
 
-#define AMX_KERNEL_PROLOGUE(AT, NRv, NQv, NWv, RLWv)                                                        \
+// GTv (global tile): the dictionary tile is too large for a CU's LDS (an HCP-style protocol: 288 x 145 float32 = 167 KB) -- the
+// solver then reads it where it lies, in HBM / L2 (the chunk's voxels share one orientation, the XCD-aware chunk map keeps it in one
+// L2), and LDS holds the per-wavefront blocks only.  A template switch, not a run-time one: the LDS variants keep their ds_read
+// addressing.  The tiles array carries kTileSlack floats behind its last tile (lanes of atoms >= n_atoms read past a row's end).
+#define AMX_KERNEL_PROLOGUE_GT(AT, NRv, NQv, NWv, RLWv, GTv)                                                \
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                              \
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;                                       \
     const int words = a.c.nS * a.c.ldA;                                                               \
-    const int words_pad = (words + kWave * NQv + 3) & ~3;                                             \
+    const int words_pad = (GTv) ? 0 : ((words + kWave * NQv + 3) & ~3);                               \
     AT *As = reinterpret_cast<AT *>(smem);                                                            \
     double *rs_all = reinterpret_cast<double *>(smem + (((size_t)words_pad * sizeof(AT) + 15) & ~(size_t)15)); \
     double *rs = rs_all + wave * (NRv * kWave);                                                       \
@@ -668,12 +672,16 @@ __device__ __forceinline__ int next_ticket(unsigned *ticket, int lane)
     unsigned long long *wm_all = reinterpret_cast<unsigned long long *>(rl_all + nw_ * (RLWv)); \
     unsigned long long *wmask = wm_all + wave * 4;                                                    \
 
+#define AMX_KERNEL_PROLOGUE(AT, NRv, NQv, NWv, RLWv) AMX_KERNEL_PROLOGUE_GT(AT, NRv, NQv, NWv, RLWv, false)
+constexpr int kTileSlack = 512;      // floats (doubles for fp64 dictionaries) readable behind the last tile of a dictionary: 64 * NQ <= 256 atoms per row sweep
 
-template <int STAGE, int NR, int NQ, int MAXP, int NW, bool LIST, typename AT = float>
+template <int STAGE, int NR, int NQ, int MAXP, int NW, bool LIST, typename AT = float, bool GT = false>
 __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
 {
+    static_assert(!GT || std::is_same<AT, float>::value, "the global tile is the float32 dictionary itself");
+    using ATs = typename std::conditional<GT, gtile<float>, AT>::type;      // what the solver is told about the tile (amx_solver.hpp: tile_sweep)
     constexpr int RLW = solver_lds_words(STAGE == 4, MAXP, STAGE == 2);
-    AMX_KERNEL_PROLOGUE(AT, NR, NQ, NW, RLW)
+    AMX_KERNEL_PROLOGUE_GT(AT, NR, NQ, NW, RLW, GT)
     const float *tiles = reinterpret_cast<const float *>(a.c.tiles);
     if (!LIST) {
         const int cid = xcd_chunk((int)blockIdx.x, *a.c.n_chunks);
@@ -686,7 +694,9 @@ __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
             if (threadIdx.x == 0) atomicAdd(&a.c.status[ST_LEFT + (STAGE == 1 ? 0 : (STAGE == 3 ? 2 : 1))], left);   // (amx_last_seed_stats)
         }
         if (threadIdx.x == 0) { ticket[0] = (unsigned)nw_; ticket[1] = (unsigned)nw_; }
-        stage_noddi_tile<AT>(As, tiles + (size_t)ck.dir * a.c.tile_stride, words, words_pad - words);
+        const AT *At = As;
+        if constexpr (GT) At = reinterpret_cast<const AT *>(tiles + (size_t)ck.dir * a.c.tile_stride);
+        else stage_noddi_tile<AT>(As, tiles + (size_t)ck.dir * a.c.tile_stride, words, words_pad - words);
         // NNLS stages with seeds: the float32 compressed dictionary of the orientation for the dual-value screening
         float *Sf = nullptr;
         if ((STAGE == 1 || STAGE == 3) && a.scr_S != nullptr && a.seeds != nullptr) {
@@ -702,7 +712,7 @@ __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
         __syncthreads();
 #ifdef AMX_STATIC_VOXELS
         for (int k = wave; k < ck.count; k += nw_) {
-            noddi_voxel<STAGE, NR, NQ, MAXP, AT>(a, As, rs, rl, wmask, a.c.perm[ck.start + k], ck.dir, lane);
+            noddi_voxel<STAGE, NR, NQ, MAXP, ATs>(a, reinterpret_cast<const ATs *>(At), rs, rl, wmask, a.c.perm[ck.start + k], ck.dir, lane);
         }
 #else
         // voxels differ 2-3x in solver iterations: the wavefronts draw the next voxel of the chunk from an LDS ticket
@@ -721,12 +731,12 @@ __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
                         const int flag = __builtin_amdgcn_readfirstlane((int)a.done[pos]);
                         if ((flag == 2) != (pass == 1)) continue;
                     }
-                    noddi_voxel<STAGE, NR, NQ, MAXP, AT>(a, As, rs, rl, wmask, a.c.perm[pos], ck.dir, lane, pos, Sf);
+                    noddi_voxel<STAGE, NR, NQ, MAXP, ATs>(a, reinterpret_cast<const ATs *>(At), rs, rl, wmask, a.c.perm[pos], ck.dir, lane, pos, Sf);
                 }
             }
         } else {
             for (int k = wave; k < ck.count; k = next_ticket(ticket, lane)) {
-                noddi_voxel<STAGE, NR, NQ, MAXP, AT>(a, As, rs, rl, wmask, a.c.perm[ck.start + k], ck.dir, lane, ck.start + k, Sf);
+                noddi_voxel<STAGE, NR, NQ, MAXP, ATs>(a, reinterpret_cast<const ATs *>(At), rs, rl, wmask, a.c.perm[ck.start + k], ck.dir, lane, ck.start + k, Sf);
             }
         }
 #endif
@@ -738,10 +748,14 @@ __global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
             const int e = a.c.list[it];
             const int pos = (STAGE == 4 && a.list_is_pos) ? e : -1;
             const int vox = (STAGE == 4 && a.list_is_pos) ? a.c.perm[e] : e;
-            __syncthreads();
-            stage_noddi_tile<AT>(As, tiles + (size_t)a.c.lutidx[vox] * a.c.tile_stride, words, words_pad - words);
-            __syncthreads();
-            noddi_voxel<STAGE, NR, NQ, MAXP, AT>(a, As, rs, rl, wmask, vox, a.c.lutidx[vox], lane, pos);
+            if constexpr (GT) {
+                noddi_voxel<STAGE, NR, NQ, MAXP, ATs>(a, reinterpret_cast<const ATs *>(tiles + (size_t)a.c.lutidx[vox] * a.c.tile_stride), rs, rl, wmask, vox, a.c.lutidx[vox], lane, pos);
+            } else {
+                __syncthreads();
+                stage_noddi_tile<AT>(As, tiles + (size_t)a.c.lutidx[vox] * a.c.tile_stride, words, words_pad - words);
+                __syncthreads();
+                noddi_voxel<STAGE, NR, NQ, MAXP, AT>(a, As, rs, rl, wmask, vox, a.c.lutidx[vox], lane, pos);
+            }
         }
     }
 }
@@ -881,8 +895,8 @@ struct BatchedArgs {
     double *rnorm;                // [n_vox] or null
 };
 
-template <int NR, int NQ, int MAXP, bool RIDGE>
-__device__ __forceinline__ void batched_voxel(const BatchedArgs &a, const double *As, double *rs, double *rl, int vox, int lane)
+template <int NR, int NQ, int MAXP, bool RIDGE, typename AT = double>
+__device__ __forceinline__ void batched_voxel(const BatchedArgs &a, const AT *As, double *rs, double *rl, int vox, int lane)
 {
     const int nS = a.c.nS, ldA = a.c.ldA, n_atoms = a.c.n_atoms;
     double yr[NR];
@@ -904,7 +918,7 @@ __device__ __forceinline__ void batched_voxel(const BatchedArgs &a, const double
         if (lane == 0 && a.rnorm) a.rnorm[vox] = __builtin_nan("");
         return;
     }
-    NNSolver<NR, NQ, MAXP, RIDGE, double> S;
+    NNSolver<NR, NQ, MAXP, RIDGE, AT> S;
     const int st = __builtin_amdgcn_readfirstlane(S.solve(As, ldA, nS, n_atoms, yr, rowok, scl, allowed, RIDGE ? a.c.lam1 : 0.0, RIDGE ? a.c.lam2 : 0.0, rs, rl, lane));
     if (st == kOverflow) {
         if (lane == 0) { const int k = atomicAdd(a.c.ovf_count, 1); a.c.ovf_list[k] = vox; }
@@ -923,10 +937,10 @@ __device__ __forceinline__ void batched_voxel(const BatchedArgs &a, const double
     }
 }
 
-template <int NR, int NQ, int MAXP, int NW, bool RIDGE, bool LIST>
+template <int NR, int NQ, int MAXP, int NW, bool RIDGE, bool LIST, bool GT = false>
 __global__ void __launch_bounds__(NW * 64) k_batched(const BatchedArgs a)
 {
-    AMX_KERNEL_PROLOGUE(double, NR, NQ, NW, solver_lds_words(false, MAXP, RIDGE))
+    AMX_KERNEL_PROLOGUE_GT(double, NR, NQ, NW, solver_lds_words(false, MAXP, RIDGE), GT)
     (void)wmask;
     const double *tiles = reinterpret_cast<const double *>(a.c.tiles);
     if (!LIST) {
@@ -935,26 +949,33 @@ __global__ void __launch_bounds__(NW * 64) k_batched(const BatchedArgs a)
         const Chunk ck = a.c.chunks[cid];
         unsigned *ticket = reinterpret_cast<unsigned *>(wm_all + nw_ * 4);
         if (threadIdx.x == 0) *ticket = (unsigned)nw_;
-        stage_tile<double>(As, tiles + (size_t)ck.dir * a.c.tile_stride, words, words_pad - words);
+        using ATs = typename std::conditional<GT, gtile<double>, double>::type;
+        const double *At = As;
+        if constexpr (GT) At = tiles + (size_t)ck.dir * a.c.tile_stride;
+        else stage_tile<double>(As, tiles + (size_t)ck.dir * a.c.tile_stride, words, words_pad - words);
         __syncthreads();
         for (int k = wave; k < ck.count; k = next_ticket(ticket, lane))
-            batched_voxel<NR, NQ, MAXP, RIDGE>(a, As, rs, rl, a.c.perm[ck.start + k], lane);
+            batched_voxel<NR, NQ, MAXP, RIDGE, ATs>(a, reinterpret_cast<const ATs *>(At), rs, rl, a.c.perm[ck.start + k], lane);
     } else {
         const int cnt = *a.c.list_count;
         for (int it = blockIdx.x; it < cnt; it += gridDim.x) {
             const int vox = a.c.list[it];
-            __syncthreads();
-            stage_tile<double>(As, tiles + (size_t)a.c.lutidx[vox] * a.c.tile_stride, words, words_pad - words);
-            __syncthreads();
-            batched_voxel<NR, NQ, MAXP, RIDGE>(a, As, rs, rl, vox, lane);
+            if constexpr (GT) {
+                batched_voxel<NR, NQ, MAXP, RIDGE, gtile<double>>(a, reinterpret_cast<const gtile<double> *>(tiles + (size_t)a.c.lutidx[vox] * a.c.tile_stride), rs, rl, vox, lane);
+            } else {
+                __syncthreads();
+                stage_tile<double>(As, tiles + (size_t)a.c.lutidx[vox] * a.c.tile_stride, words, words_pad - words);
+                __syncthreads();
+                batched_voxel<NR, NQ, MAXP, RIDGE>(a, As, rs, rl, vox, lane);
+            }
         }
     }
 }
 
 template <typename AT>
-static inline size_t fit_lds_bytes(int nS, int ldA, int NR, int NQ, int NW, int MAXP, bool gram = false, bool ridge = true)
+static inline size_t fit_lds_bytes(int nS, int ldA, int NR, int NQ, int NW, int MAXP, bool gram = false, bool ridge = true, bool global_tile = false)
 {
-    const size_t words_pad = ((size_t)nS * ldA + kWave * NQ + 3) & ~(size_t)3;
+    const size_t words_pad = global_tile ? 0 : (((size_t)nS * ldA + kWave * NQ + 3) & ~(size_t)3);
     size_t b = (words_pad * sizeof(AT) + 15) & ~(size_t)15;
     b += (size_t)NW * NR * kWave * sizeof(double);
     b += (size_t)NW * solver_lds_words(gram, MAXP, ridge) * sizeof(double);

@@ -14,6 +14,17 @@ static int set_lds(amx_ctx *ctx, K kern, size_t bytes)
 // main pass over the orientation chunks + re-run of the voxels whose passive set overflowed
 constexpr size_t kLdsPerCU = 160 * 1024;
 
+// NODDI wavefront-per-voxel kernels: does this shape run the global-tile variants (amx_kernels.hpp: GT)?  The LDS variants hold
+// <= 256 rows (4 per lane), <= 192 atoms (3 per lane) and need the float32 tile + the blocks of at least two wavefronts in LDS
+// (the widest: the LASSO stage's Gram solver with 32 passive atoms; the re-run kernels with 64)
+static inline bool amx_noddi_tile_global(int nS, int ldA, int n_atoms)
+{
+    if (nS > 256 || n_atoms > 192) return true;
+    const int NR = nS <= 128 ? 2 : 4;
+    return amx::fit_lds_bytes<float>(nS, ldA, NR, 3, 2, 32, true) + (size_t)amx::kSeedKD * amx::kScreenLd * sizeof(float) > kLdsPerCU ||
+           amx::fit_lds_bytes<float>(nS, ldA, NR, 3, 1, 64, true) > kLdsPerCU;
+}
+
 // LDSF(nw) -> dynamic LDS bytes of the main kernel with nw wavefronts per workgroup
 template <int NW, typename Args, typename KM, typename KL, typename LDSF>
 static int launch_pair(amx_ctx *ctx, Args &a, const Plan &pl, hipStream_t s, KM km, KL kl, LDSF ldsf,

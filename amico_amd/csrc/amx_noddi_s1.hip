@@ -34,7 +34,20 @@ static int go(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
                        0, 2);
 }
 
+// Any shape the reference's loop takes (models.pyx:825-861: any nS, any n_wm): protocols of more than 256 volumes, dictionaries of more
+// than 192 atoms, and tiles that do not fit a CU's LDS (288 x 145 float32 = 167 KB) run the SAME solver with the tile read where it
+// lies (k_noddi<..., GT = true>: 8 rows and 4 atoms per lane: nS <= 512, n_atoms <= 256), room for 12 passive atoms, 4 wavefronts.
+static int go_global(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
+{
+    constexpr int NR = 8, NQ = 4, MP = 12, MB = 32, NW = 4;
+    const size_t scr = (a.scr_S && a.seeds) ? (size_t)kSeedKD * kScreenLd * sizeof(float) : 0;
+    return launch_pair<NW>(ctx, a, pl, s, k_noddi<1, NR, NQ, MP, NW, false, float, true>, k_noddi<1, NR, NQ, MB, 1, true, float, true>,
+                           [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MP, false, false, true) + scr; },
+                           fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, false, true), 0, 2);
+}
+
 int amx_launch_noddi_s1(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
 {
+    if (amx_noddi_tile_global(a.c.nS, a.c.ldA, a.c.n_atoms)) return go_global(ctx, a, pl, s);
     return a.c.nS <= 128 ? go<2>(ctx, a, pl, s) : go<4>(ctx, a, pl, s);
 }

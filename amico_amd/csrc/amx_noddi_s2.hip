@@ -33,9 +33,28 @@ static int go_gram(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
                        1, 4);
 }
 
+// shapes beyond the LDS variants (see amx_noddi_s1.hip): the tile read where it lies; passive sets of up to 32 atoms in the main
+// pass, 48 in the re-run pass
+static int go_global(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s, bool gram)
+{
+    constexpr int NR = 8, NQ = 4, NW = 4;
+    if (gram) {
+        constexpr int MP = 32, MB = 64;
+        const size_t scr = (a.scr2_S && a.seeds2) ? (size_t)kSeedKD * kScreenLd * sizeof(float) : 0;
+        return launch_pair<NW>(ctx, a, pl, s, k_noddi<4, NR, NQ, MP, NW, false, float, true>, k_noddi<4, NR, NQ, MB, 1, true, float, true>,
+                               [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MP, true, true, true) + scr; },
+                               fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, true, true, true), 1, 4);
+    }
+    constexpr int MP = 20, MB = 32;       // (A-space QR: the factor lives in registers -- 32 x 8 rows per lane is what a wavefront holds)
+    return launch_pair<NW>(ctx, a, pl, s, k_noddi<2, NR, NQ, MP, NW, false, float, true>, k_noddi<2, NR, NQ, MB, 1, true, float, true>,
+                           [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MP, false, true, true); },
+                           fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, true, true), 1, 4);
+}
+
 int amx_launch_noddi_s2(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
 {
     const bool gram = a.gram_dwi != nullptr && a.c.lam2 >= 1e-5 && !ctx->opt_lasso_qr;
+    if (amx_noddi_tile_global(a.c.nS, a.c.ldA, a.c.n_atoms)) return go_global(ctx, a, pl, s, gram);
     if (gram) return a.c.nS <= 128 ? go_gram<2>(ctx, a, pl, s) : go_gram<4>(ctx, a, pl, s);
     return a.c.nS <= 128 ? go_qr<2>(ctx, a, pl, s) : go_qr<4>(ctx, a, pl, s);
 }

@@ -27,7 +27,18 @@ static int go(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
                        2, 6);
 }
 
+// shapes beyond the LDS variants (see amx_noddi_s1.hip): the tile read where it lies
+static int go_global(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
+{
+    constexpr int NR = 8, NQ = 4, MP = 8, MB = 32, NW = 4;
+    const size_t scr = (a.scr_S && a.seeds) ? (size_t)kSeedKD * kScreenLd * sizeof(float) : 0;
+    return launch_pair<NW>(ctx, a, pl, s, k_noddi<3, NR, NQ, MP, NW, false, float, true>, k_noddi<3, NR, NQ, MB, 1, true, float, true>,
+                           [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MP, false, false, true) + scr; },
+                           fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, false, true), 2, 6);
+}
+
 int amx_launch_noddi_s3(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
 {
+    if (amx_noddi_tile_global(a.c.nS, a.c.ldA, a.c.n_atoms)) return go_global(ctx, a, pl, s);
     return a.c.nS <= 128 ? go<2>(ctx, a, pl, s) : go<4>(ctx, a, pl, s);
 }

@@ -193,23 +193,28 @@ __global__ void k_build_lut(const float *__restrict__ src, const float *__restri
 // Gram matrices of the orientation tiles: G[dir][j][k] = sum_{i in rows} A[i][j] A[i][k] in fp64
 // (products of fp32 values are exact in fp64); one workgroup per orientation, tile staged in LDS.
 // rowsel == nullptr: all rows.  Row stride ldG (>= n_atoms, padding stays zero).
+// (in_lds == 0: a tile larger than a CU's LDS is read where it lies -- a one-off per dictionary upload, the L2 serves it)
 __global__ void k_build_gram(const float *__restrict__ tiles, int tile_stride, int nS, int ldA, int n_atoms,
-                             const unsigned char *__restrict__ rowsel, int ldG, double *__restrict__ G)
+                             const unsigned char *__restrict__ rowsel, int ldG, double *__restrict__ G, int in_lds = 1)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
     float *As = reinterpret_cast<float *>(smem_g);
     const float *g = tiles + (size_t)blockIdx.x * tile_stride;
-    for (int k = threadIdx.x; k < nS * ldA; k += blockDim.x) {
-        const int i = k / ldA;
-        As[k] = (rowsel == nullptr || rowsel[i]) ? g[k] : 0.f;
+    if (in_lds) {
+        for (int k = threadIdx.x; k < nS * ldA; k += blockDim.x) {
+            const int i = k / ldA;
+            As[k] = (rowsel == nullptr || rowsel[i]) ? g[k] : 0.f;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     double *out = G + (size_t)blockIdx.x * n_atoms * ldG;
     for (int e = threadIdx.x; e < n_atoms * ldG; e += blockDim.x) {
         const int j = e / ldG, c = e % ldG;
         double acc = 0.0;
-        if (c < n_atoms)
-            for (int i = 0; i < nS; i++) acc += (double)As[i * ldA + j] * (double)As[i * ldA + c];
+        if (c < n_atoms) {
+            if (in_lds) { for (int i = 0; i < nS; i++) acc += (double)As[i * ldA + j] * (double)As[i * ldA + c]; }
+            else { for (int i = 0; i < nS; i++) if (rowsel == nullptr || rowsel[i]) acc += (double)g[i * ldA + j] * (double)g[i * ldA + c]; }
+        }
         out[e] = acc;
     }
 }

@@ -77,7 +77,8 @@ int amx_launch_noddi_seed2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a,
     const dim3 grid(((pl.max_chunks + 7) / 8) * 8);
     if (!have_ytil2) {
         if (lut->nS <= 128) hipLaunchKernelGGL(k_noddi_project2<2>, grid, dim3(1024), 0, s, sa);
-        else hipLaunchKernelGGL(k_noddi_project2<4>, grid, dim3(1024), 0, s, sa);
+        else if (lut->nS <= 256) hipLaunchKernelGGL(k_noddi_project2<4>, grid, dim3(1024), 0, s, sa);
+        else hipLaunchKernelGGL(k_noddi_project2<8>, grid, dim3(512), 0, s, sa);
         AMX_TRACE(ctx, s, "projection of the clipped signals");
     }
     const size_t lds = ((size_t)lut->n_wm * (kSeed2KD + 1) + 8 + (size_t)9 * (kSeed2KD / 4) * 64 + (size_t)4 * (64 * (kSeed2KD + 1) + 64 * 3)) * sizeof(double);
@@ -119,11 +120,15 @@ static size_t gemm_lds(int n_cols, int rows, int ks)
 
 // can the table kernels take this dictionary?  (K-steps of 4 samples: 25 or 40 per voxel; the scans of the seed solvers and
 // certificates hold 160 atoms; one workgroup's operands must fit a CU's LDS)
+// Protocols of more than 160 volumes take several launches, each over a window of <= 160 samples of every voxel (GemmArgs::k0, k1):
+// 288 volumes = 2 windows of 144, 512 = 4 of 128.
+static int gemm_passes(int nS) { return (nS + 159) / 160; }
+static int gemm_window(int nS) { const int np = gemm_passes(nS); return ((nS + np - 1) / np + 3) & ~3; }   // samples per window, a multiple of 4
 int amx_gemm_ksteps(const amx_lut *lut)
 {
-    if (lut->n_atoms > 160 || lut->n_wm > 144) return 0;
-    const int ks = lut->nS <= 100 ? 25 : (lut->nS <= 160 ? 40 : 0);
-    if (ks == 0 || gemm_lds(lut->n_atoms, gemm_rows(lut->n_atoms), ks) > kLdsPerCU) return 0;
+    if (lut->n_atoms > 160 || lut->n_wm > 144 || lut->nS > 512) return 0;
+    const int ks = gemm_window(lut->nS) <= 100 ? 25 : 40;
+    if (gemm_lds(lut->n_atoms, gemm_rows(lut->n_atoms), ks) > kLdsPerCU) return 0;
     return ks;
 }
 
@@ -151,10 +156,18 @@ int amx_launch_noddi_gemm(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, 
         hipLaunchKernelGGL((k_noddi_gemm<L, K, ##__VA_ARGS__>), grid, dim3(512), lds, s, ga);      \
     } while (0)
     const int mtf = (lasso ? lut->n_wm : lut->n_atoms) / 16;
-    if (ks == 25 && mtf == 9 && !lasso) AMX_GEMM_GO(false, 25, 9);          // the default dictionary: unrolled tile loop
-    else if (ks == 25) { if (lasso) AMX_GEMM_GO(true, 25); else AMX_GEMM_GO(false, 25); }
-    else if (ks == 40) { if (lasso) AMX_GEMM_GO(true, 40); else AMX_GEMM_GO(false, 40); }
-    else return amx_bad(ctx, "k_noddi_gemm: unsupported dictionary shape");
+    const int n_pass = gemm_passes(lut->nS), win = gemm_window(lut->nS);
+    for (int p = 0; p < n_pass; p++) {
+        ga.k0 = p * win; ga.k1 = (p + 1) * win < lut->nS ? (p + 1) * win : lut->nS;
+        ga.accumulate = p > 0 ? 1 : 0; ga.last = p == n_pass - 1 ? 1 : 0;
+        // (every window walks all voxels: its launch starts from fresh chunk counters)
+        if (p > 0 && !lasso) HIPCHK(ctx, hipMemsetAsync(ga.gcount, 0, (size_t)(pl.max_schunks + 8) * sizeof(int), s));
+        if (n_pass > 1) { if (lasso) AMX_GEMM_GO(true, 40, 0, true); else AMX_GEMM_GO(false, 40, 0, true); }      // windows: K-steps 40 (gemm_window > 100)
+        else if (ks == 25 && mtf == 9 && !lasso) AMX_GEMM_GO(false, 25, 9);          // the default dictionary: unrolled tile loop
+        else if (ks == 25) { if (lasso) AMX_GEMM_GO(true, 25); else AMX_GEMM_GO(false, 25); }
+        else if (ks == 40) { if (lasso) AMX_GEMM_GO(true, 40); else AMX_GEMM_GO(false, 40); }
+        else return amx_bad(ctx, "k_noddi_gemm: unsupported dictionary shape");
+    }
 #undef AMX_GEMM_GO
     AMX_TRACE(ctx, s, lasso ? "stage-2 products of the clipped voxels on the matrix cores" : "A'y of every voxel on the matrix cores");
     HIPCHK(ctx, hipGetLastError());
@@ -275,7 +288,10 @@ int amx_launch_noddi_gcert(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a,
     //  hands the lists on costs every other call 1 %)
     // (batches of one host-buffer call all take the path the whole call's size asks for, as make_plan does for the seed solvers' builds:
     //  host and device entry points settle the same voxels with the same arithmetic)
-    if ((ctx->in_host_fit ? ctx->host_total_vox : (int64_t)pl.n) >= (lut->is_exvivo ? ctx->opt_rescue_from / 4 : ctx->opt_rescue_from)) {
+    // (shapes whose tile does not fit the LDS -- an HCP-style protocol -- run it at every size: a left-over voxel costs their
+    //  wavefront-per-voxel kernels ten times what it costs the LDS variants, and the lane that corrects a support reads 8 atoms, not the tile)
+    if ((ctx->in_host_fit ? ctx->host_total_vox : (int64_t)pl.n) >= (lut->is_exvivo ? ctx->opt_rescue_from / 4 : ctx->opt_rescue_from) ||
+        amx_noddi_tile_global(lut->nS, lut->ldA, lut->n_atoms)) {
         // second pass (large calls: below ~2 M voxels the launch costs more than the wavefront-per-voxel kernel saves -- 1 M voxels
         // 8.08 -> 8.24 ms with it, 4 M 24.99 -> 24.38): the supports refused for conditioning, corrected with the signal itself;
         // what is left goes to the second half
@@ -305,7 +321,8 @@ int amx_launch_noddi_project(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &
     SeedArgs sa; fill(sa, lut, a, pl, ctx);
     const dim3 grid(((pl.max_chunks + 7) / 8) * 8);
     if (lut->nS <= 128) hipLaunchKernelGGL(k_noddi_project<2>, grid, dim3(1024), 0, s, sa);
-    else hipLaunchKernelGGL(k_noddi_project<4>, grid, dim3(1024), 0, s, sa);
+    else if (lut->nS <= 256) hipLaunchKernelGGL(k_noddi_project<4>, grid, dim3(1024), 0, s, sa);
+    else hipLaunchKernelGGL(k_noddi_project<8>, grid, dim3(512), 0, s, sa);
     AMX_TRACE(ctx, s, "projection onto the orientation bases");
     HIPCHK(ctx, hipGetLastError());
     return AMX_OK;

@@ -1036,6 +1036,10 @@ struct GemmArgs {
     double *ytil;                 // [n][12] bucket order (copy of rows aux0 + kAuxU ..), or null
     const int *clist, *ccount;    // LASSO: bucket positions of the chunk's clipped voxels (compact from the chunk's start), their number
     int *gcount; int n_gcount;    // NNLS: chunk counters of this launch (BlockFeed), helpers' counter at [n_gcount]
+    // K-window of this launch: the samples k0 <= row < k1 of every voxel.  A protocol of more than 160 volumes (an HCP-style one: 288)
+    // takes several passes of <= 160 rows each, every pass with its rows' operands in LDS: the first writes the table, the others add
+    // to it (accumulate = 1); the voxel-major copy of y~ is written by the last (last = 1), which holds the totals
+    int k0, k1, accumulate, last;
 };
 
 __device__ __forceinline__ double rows_allmin(double k)
@@ -1048,7 +1052,9 @@ __device__ __forceinline__ double rows_allmin(double k)
 
 // MTF > 0: the number of float32 tiles is known at compile time (9 for the 144 + 1 atoms of the default dictionary) and their loop
 // is unrolled -- the LDS reads of the next tiles overlap the products of the current ones; MTF = 0: any dictionary
-template <bool LASSO, int KS, int MTF = 0>
+// WIN: this launch covers a window of the samples only (GemmArgs::k0, k1, accumulate, last) -- a template switch, so that the
+// one-pass builds keep their constants (the default dictionary's build sits at 246 registers: four run-time values more spilled 58)
+template <bool LASSO, int KS, int MTF = 0, bool WIN = false>
 __global__ void __launch_bounds__(512) k_noddi_gemm(const GemmArgs a)
 {
     constexpr int NB = KS > 25 ? 1 : 3;            // atom tiles in flight together (registers: KS operand values each)
@@ -1066,11 +1072,12 @@ __global__ void __launch_bounds__(512) k_noddi_gemm(const GemmArgs a)
     if (own < 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
     const int q = lane >> 4, c16 = lane & 15;
-    unsigned long long maskE = 0ull, maskD = 0ull;      // bit ks: sample 4 ks + q exists / is a stage-2 row
+    const int k0 = WIN ? a.k0 : 0, k1 = WIN ? a.k1 : nS;    // this launch's window of samples (GemmArgs)
+    unsigned long long maskE = 0ull, maskD = 0ull;      // bit ks: sample k0 + 4 ks + q exists / is a stage-2 row
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) {
-        const int row = 4 * ks + q;
-        if (row < nS) { maskE |= 1ull << ks; if (a.rowdwi[row] != 0) maskD |= 1ull << ks; }
+        const int row = k0 + 4 * ks + q;
+        if (row < k1) { maskE |= 1ull << ks; if (a.rowdwi[row] != 0) maskD |= 1ull << ks; }
     }
     const unsigned long long rowmask = LASSO ? maskD : maskE;
     // every voxel's table: the workgroup's own chunk, then the largest chunks still open, groups of 16 voxels per wavefront (BlockFeed);
@@ -1086,14 +1093,14 @@ __global__ void __launch_bounds__(512) k_noddi_gemm(const GemmArgs a)
     const double *U2 = (!LASSO && a.U2b) ? a.U2b + (size_t)ck.dir * nS * kSeedKD : nullptr;
     for (int e = threadIdx.x; e < MTf * KS * 64; e += blockDim.x) {
         const int l = e & 63, ks = (e >> 6) % KS, mt = (e >> 6) / KS;
-        const int atom = 16 * mt + (l & 15), row = 4 * ks + (l >> 4);
-        A32[e] = (row < nS) ? tile[row * ldA + atom] : 0.0f;
+        const int atom = 16 * mt + (l & 15), row = k0 + 4 * ks + (l >> 4);
+        A32[e] = (row < k1) ? tile[row * ldA + atom] : 0.0f;
     }
     for (int e = threadIdx.x; e < (MT - MTf) * KS * 64; e += blockDim.x) {
         const int l = e & 63, ks = (e >> 6) % KS, mt = MTf + (e >> 6) / KS;
-        const int r = 16 * mt + (l & 15), row = 4 * ks + (l >> 4);
+        const int r = 16 * mt + (l & 15), row = k0 + 4 * ks + (l >> 4);
         double v = 0.0;
-        if (row < nS) {
+        if (row < k1) {
             if (r < n_cols) v = (double)tile[row * ldA + r];
             else if (r >= aux0 + kAuxU && r < aux0 + kAuxU + kSeedKD) v = U[row * kSeedKD + (r - aux0 - kAuxU)];
             else if (U2 != nullptr && r >= aux0 + kAuxU2 && r < aux0 + kAuxU2 + kSeedKD) v = U2[row * kSeedKD + (r - aux0 - kAuxU2)];
@@ -1102,8 +1109,9 @@ __global__ void __launch_bounds__(512) k_noddi_gemm(const GemmArgs a)
         A64[e] = v;
     }
     for (int e = threadIdx.x; e < 4 * KS; e += blockDim.x) {
-        const double iso = e < nS ? (double)tile[e * ldA + a.iso_atom] : 0.0;
-        IsoT[e] = LASSO ? iso : ((e < nS && a.rowdwi[e] && iso > 0.0) ? 1.0 / iso : 0.0);
+        const int row = k0 + e;
+        const double iso = row < k1 ? (double)tile[row * ldA + a.iso_atom] : 0.0;
+        IsoT[e] = LASSO ? iso : ((row < k1 && a.rowdwi[row] && iso > 0.0) ? 1.0 / iso : 0.0);
     }
     if (LASSO) for (int e = threadIdx.x; e < a.rows; e += blockDim.x) ScT[e] = e < a.n_wm ? a.colscale[e] : 0.0;
     __syncthreads();
@@ -1119,16 +1127,17 @@ __global__ void __launch_bounds__(512) k_noddi_gemm(const GemmArgs a)
         pos_n = LASSO ? a.clist[ck.start + kk] : ck.start + kk;
         const int vox = a.perm[pos_n];
         if (a.y32 != nullptr) {
-            const float *yv = a.y32 + (size_t)vox * nS + q;
+            const float *yv = a.y32 + (size_t)vox * nS + k0 + q;
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) bn[ks] = (4 * ks + q < nS) ? (double)yv[4 * ks] : 0.0;
+            for (int ks = 0; ks < KS; ks++) bn[ks] = (k0 + 4 * ks + q < k1) ? (double)yv[4 * ks] : 0.0;
         } else {
-            const double *yv = a.y + (size_t)vox * nS + q;
+            const double *yv = a.y + (size_t)vox * nS + k0 + q;
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) bn[ks] = (4 * ks + q < nS) ? yv[4 * ks] : 0.0;
+            for (int ks = 0; ks < KS; ks++) bn[ks] = (k0 + 4 * ks + q < k1) ? yv[4 * ks] : 0.0;
         }
         if (LASSO) { xi_n = a.xiso[(size_t)vox * 2]; xd_n = a.is_exvivo ? a.xiso[(size_t)vox * 2 + 1] : 0.0; }
     };
+    const bool accumulate = WIN && a.accumulate != 0, last = !WIN || a.last != 0;
     BlockFeed<16> bf;
     auto advance = [&](int g) -> int {                  // the group after g for this wavefront, -1: none
         if (LASSO) { const int n = g < 0 ? wave : g + nw; return n < n_groups ? n : -1; }
@@ -1191,7 +1200,9 @@ __global__ void __launch_bounds__(512) k_noddi_gemm(const GemmArgs a)
 #pragma unroll
                         for (int rr = 0; rr < 4; rr++) {
                             const int row = 16 * (mt + u) + 4 * rr + q;
-                            out[(size_t)row * 64] = LASSO ? ScT[row] * acc[u][rr] : acc[u][rr];
+                            double v = LASSO ? ScT[row] * acc[u][rr] : acc[u][rr];
+                            if (accumulate) v += out[(size_t)row * 64];            // (the earlier windows' share; uniform branch)
+                            out[(size_t)row * 64] = v;
                         }
                     }
                 }
@@ -1209,9 +1220,13 @@ __global__ void __launch_bounds__(512) k_noddi_gemm(const GemmArgs a)
                     double v = (LASSO && row < a.n_wm) ? ScT[row] * acc[rr] : acc[rr];
                     v = (row == aux0 + kAuxYY) ? yy : v;
                     if (!LASSO) { v = (row == aux0 + kAuxYB) ? yb : v; v = (row == aux0 + kAuxTmin) ? tmin : v; }
+                    if (accumulate) {
+                        const double old = out[(size_t)row * 64];
+                        v = (!LASSO && row == aux0 + kAuxTmin) ? (old < v ? old : v) : v + old;       // sums add up over the windows, t_min is a minimum
+                    }
                     out[(size_t)row * 64] = v;
                     // the projections once more in voxel-major order for the kernels that take one voxel at a time
-                    if (a.ytil != nullptr && row >= aux0 + kAuxU && row < aux0 + kAuxU + kSeedKD) a.ytil[(size_t)pos * kSeedKD + (row - aux0 - kAuxU)] = acc[rr];
+                    if (a.ytil != nullptr && last && row >= aux0 + kAuxU && row < aux0 + kAuxU + kSeedKD) a.ytil[(size_t)pos * kSeedKD + (row - aux0 - kAuxU)] = v;
                 }
             }
         }

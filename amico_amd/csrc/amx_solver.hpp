@@ -175,6 +175,54 @@ __device__ __forceinline__ double from_next_lane(double v)
     return __hiloint2double(from_next_lane(__double2hiint(v)), from_next_lane(__double2loint(v)));
 }
 
+// ------------------------------------------------------------------ the dictionary tile: in LDS, or -- gtile<T> -- where it lies
+// A tile too large for a CU's LDS (an HCP-style protocol: 288 x 145 float32 = 167 KB) is read from HBM / L2 (amx_kernels.hpp: GT).
+// The element TYPE says so: gtile<float> converts like a float, and the one place where it matters -- the row sweep u = A'v, a chain
+// of L2 round trips if it loads two rows at a time as the LDS loop does -- dispatches on it: kSweepBatch rows' loads in flight together.
+template <typename T> struct gtile {
+    T v;
+    __device__ __forceinline__ operator double() const { return (double)v; }
+};
+template <typename AT> struct is_global_tile { static constexpr bool value = false; };
+template <typename T> struct is_global_tile<gtile<T>> { static constexpr bool value = true; };
+constexpr int kSweepBatch = 8;
+
+// u += (even rows), w2 += (odd rows) of A'v for the atoms lane + 64 q; ap = As + lane, v in the per-wave scratch rs
+template <int NQ, typename AT>
+__device__ __forceinline__ void tile_sweep(const AT *ap, int ldA, int nS, const double *rs, double (&u)[NQ], double (&w2)[NQ])
+{
+    int i = 0;
+    if constexpr (is_global_tile<AT>::value) {
+        for (; i + kSweepBatch <= nS; i += kSweepBatch) {
+            AT av[kSweepBatch][NQ];
+#pragma unroll
+            for (int b = 0; b < kSweepBatch; b++) {
+#pragma unroll
+                for (int q = 0; q < NQ; q++) av[b][q] = ap[(i + b) * ldA + kWave * q];
+            }
+#pragma unroll
+            for (int b = 0; b < kSweepBatch; b += 2) {
+                const double r0 = rs[i + b], r1 = rs[i + b + 1];
+#pragma unroll
+                for (int q = 0; q < NQ; q++) { u[q] += (double)av[b][q] * r0; w2[q] += (double)av[b + 1][q] * r1; }
+            }
+        }
+    }
+    for (; i + 1 < nS; i += 2) {
+        const double r0 = rs[i], r1 = rs[i + 1];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            u[q] += (double)ap[i * ldA + kWave * q] * r0;
+            w2[q] += (double)ap[(i + 1) * ldA + kWave * q] * r1;
+        }
+    }
+    if (i < nS) {
+        const double r0 = rs[i];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) u[q] += (double)ap[i * ldA + kWave * q] * r0;
+    }
+}
+
 // ------------------------------------------------------------------ the solver
 // NR   rows per lane   (nS      <= 64*NR)
 // NQ   atoms per lane  (n_atoms <= 64*NQ)
@@ -313,21 +361,7 @@ struct NNSolver {
         double w2[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; q++) { u[q] = 0.0; w2[q] = 0.0; }
-        const AT *ap = As + lane;
-        int i = 0;
-        for (; i + 1 < nS; i += 2) {
-            const double r0 = rs[i], r1 = rs[i + 1];
-#pragma unroll
-            for (int q = 0; q < NQ; q++) {
-                u[q] += (double)ap[i * ldA + kWave * q] * r0;
-                w2[q] += (double)ap[(i + 1) * ldA + kWave * q] * r1;
-            }
-        }
-        if (i < nS) {
-            const double r0 = rs[i];
-#pragma unroll
-            for (int q = 0; q < NQ; q++) u[q] += (double)ap[i * ldA + kWave * q] * r0;
-        }
+        tile_sweep<NQ, AT>(As + lane, ldA, nS, rs, u, w2);
 #pragma unroll
         for (int q = 0; q < NQ; q++) u[q] += w2[q];
     }
@@ -729,23 +763,7 @@ struct NNSolver {
                 double w2[NQ];
 #pragma unroll
                 for (int q = 0; q < NQ; q++) { u[q] = 0.0; w2[q] = 0.0; }
-                {
-                    const AT *ap = As + lane;
-                    int i = 0;
-                    for (; i + 1 < nS; i += 2) {
-                        const double r0 = rs[i], r1 = rs[i + 1];
-#pragma unroll
-                        for (int q = 0; q < NQ; q++) {
-                            u[q] += (double)ap[i * ldA + kWave * q] * r0;
-                            w2[q] += (double)ap[(i + 1) * ldA + kWave * q] * r1;
-                        }
-                    }
-                    if (i < nS) {
-                        const double r0 = rs[i];
-#pragma unroll
-                        for (int q = 0; q < NQ; q++) u[q] += (double)ap[i * ldA + kWave * q] * r0;
-                    }
-                }
+                tile_sweep<NQ, AT>(As + lane, ldA, nS, rs, u, w2);
 #pragma unroll
                 for (int q = 0; q < NQ; q++) u[q] += w2[q];
                 have_u = true; force_exact = false; gram_steps = 0; n_exact++;

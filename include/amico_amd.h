@@ -200,7 +200,7 @@ int amx_debug_fetch(amx_ctx *ctx, const amx_lut *lut, int which, void *dst, size
  * voxel names its dictionary by index -- the `lut_idx` the reference computes per voxel (models.pyx:904) -- and all voxels are
  * solved by one call.
  *   amx_dict_upload    A f64[n_dicts][n][m]: n_dicts dictionaries, each column-major m x n with leading dimension m
- *                      (n <= 192 atoms, m <= 256 samples, and m x n doubles must fit the LDS of a compute unit)
+ *                      (n <= 256 atoms, m <= 512 samples; a dictionary that does not fit a compute unit's LDS as fp64 is read from HBM / L2 instead: slower, same results; supports of up to 48 atoms)
  *   amx_nnls_batched   x_v = argmin_{x >= 0} ||A_d x - y_v||_2,  d = dict_idx[v] (NULL: the single dictionary),
  *                      Y f64[n_vox][m] -> X f64[n_vox][n] (exact zeros off the support), rnorm f64[n_vox] = ||A x - y||_2 or NULL
  *   amx_lasso_batched  x_v = argmin_{x >= 0} 1/2 ||y_v - A_d x||^2 + lambda1 sum(x) + lambda2/2 ||x||^2   (SPAMS lasso, mode

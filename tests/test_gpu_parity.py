@@ -307,6 +307,33 @@ def test_other_protocol_shapes(htable500, seed_path, amx_env):
     diff2 = np.abs(out2['estimates'] - ref2['estimates']).max(axis=1)
     assert (diff2 < TOL).mean() > 0.998, (diff2 > TOL).sum()
     assert diff2.max() < CAP, diff2.max()
+    # (e) an HCP-style acquisition: 18 b0 + 3 x 90 = 288 volumes (the 288 x 145 float32 tile -- 167 KB -- does not fit a CU's LDS: the
+    #     wavefront-per-voxel kernels read it where it lies; the table kernels take the samples in two windows of 144)
+    sch5 = S.make_scheme(18, ((1000.0, 90), (2000.0, 90), (3000.0, 90)), seed=11)
+    K5 = S.noddi_kernels(sch5, dirs)
+    y5, d5 = S.noddi_signals(1500, K5, ht, sch5, seed=6)
+    m5 = NODDI()
+    m5.scheme = sch5
+    out5 = m5.fit(Holder(y5, d5, ht, K5, doComputeRMSE=True))
+    ref5 = oracle.noddi_fit(y5, d5, K5, ht, sch5.dwi_idx, nthreads=8, rmse=True)
+    diff5 = np.abs(out5['estimates'] - ref5['estimates']).max(axis=1)
+    assert (diff5 < TOL).mean() > 0.998, (diff5 > TOL).sum()
+    assert diff5.max() < CAP, diff5.max()
+    assert np.abs(out5['rmse'] - ref5['rmse']).max() < 1e-6
+    # (f) a 13 x 13 grid: 169 + 1 atoms (more than the seed solvers' scans hold: every voxel on the wavefront-per-voxel kernels),
+    #     and 15 x 15 = 225 + 1 (four atoms per lane: the global-tile variants)
+    for ng, nv in ((13, 1200), (15, 600)):
+        vfs6, ods6 = np.linspace(0.1, 0.99, ng), np.linspace(0.03, 0.99, ng)
+        K6 = S.noddi_kernels(sch, dirs, IC_VFs=vfs6, IC_ODs=ods6)
+        y6, d6 = S.noddi_signals(nv, K6, ht, sch, seed=7)
+        m6 = NODDI()
+        m6.set(IC_VFs=vfs6, IC_ODs=ods6)
+        m6.scheme = sch
+        out6 = m6.fit(Holder(y6, d6, ht, K6))
+        ref6 = oracle.noddi_fit(y6, d6, K6, ht, sch.dwi_idx, nthreads=8)
+        diff6 = np.abs(out6['estimates'] - ref6['estimates']).max(axis=1)
+        assert (diff6 < TOL).mean() > 0.995, (ng, (diff6 > TOL).sum())
+        assert diff6.max() < CAP, (ng, diff6.max())
     # (c) FreeWater with 33 volumes
     sch3 = S.make_scheme(1, ((1000.0, 32),), seed=9)
     K3 = S.freewater_kernels(sch3, dirs)

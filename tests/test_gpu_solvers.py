@@ -102,9 +102,45 @@ def test_batched_solvers_single_dictionary_and_errors():
         _capi.nnls_batched(ctx, dic2, y, bad)                           # index out of range: reported with the voxel
     assert np.abs(_capi.nnls_batched(ctx, dic2, y, np.ones(2000, dtype=np.int32)) - _capi.nnls_batched(ctx, dic, y)).max() == 0.0
     with pytest.raises(ValueError):
-        _capi.Dict(ctx, np.zeros((300, 10)))                            # m > 256
+        _capi.Dict(ctx, np.zeros((600, 10)))                            # m > 512: beyond what a wavefront's lanes hold (8 rows each)
+    with pytest.raises(ValueError):
+        _capi.Dict(ctx, np.zeros((100, 300)))                           # n > 256
     # a dense optimum beyond the solver's passive-set capacity (48 atoms) is an error, never a wrong answer
     rng = np.random.default_rng(1)
     Ad = np.abs(rng.normal(size=(60, 100))) + 1.0
     with pytest.raises(_capi.AmxError):
         _capi.lasso_batched(ctx, _capi.Dict(ctx, Ad), np.abs(rng.normal(size=(10, 60))) + Ad.sum(axis=1)[None, :], 0.0, 50.0)
+
+
+@pytest.mark.parametrize('m,n', [(300, 200), (512, 256), (260, 40)])
+def test_batched_solvers_take_large_dictionaries(m, n):
+    """dictionaries beyond a compute unit's LDS (the reference's nnls / lasso take any m x n, models.pyx:18): the tile is read from
+    HBM / L2 instead -- same Kuhn-Tucker points (scipy NNLS, and the elastic net's own conditions computed in numpy)"""
+    from scipy.optimize import nnls as scipy_nnls
+    from amico_amd import _capi, get_context
+    rng = np.random.default_rng(m + n)
+    nd, nv = 3, 400
+    A = np.abs(rng.normal(size=(nd, m, n))) + 0.1 * rng.random((nd, m, n))
+    A /= np.linalg.norm(A, axis=1, keepdims=True)
+    idx = rng.integers(0, nd, nv).astype(np.int32)
+    cols = rng.integers(0, n, (nv, 4))
+    w = rng.dirichlet(np.ones(4), nv)
+    y = np.stack([A[idx[v]][:, cols[v]] @ w[v] for v in range(nv)]) + rng.normal(scale=0.003, size=(nv, m))
+    ctx = get_context()
+    dic = _capi.Dict(ctx, A)
+    x, rn = _capi.nnls_batched(ctx, dic, y, idx, return_rnorm=True)
+    st = ctx.last_stats()
+    assert st['itercap_voxels'] == 0 and st['overflow_voxels'] == 0
+    assert x.min() >= 0.0
+    for v in range(0, nv, 8):
+        xs, rs = scipy_nnls(A[idx[v]], y[v], maxiter=20 * n)
+        assert abs(rn[v] - rs) < 1e-9 and np.abs(A[idx[v]] @ (x[v] - xs)).max() < 1e-8
+        W = A[idx[v]].T @ (y[v] - A[idx[v]] @ x[v])
+        assert np.abs(W[x[v] > 0]).max(initial=0.0) < 1e-9 and W[x[v] == 0].max(initial=0.0) < 1e-9
+    lam1, lam2 = 0.05, 1e-2
+    xl = _capi.lasso_batched(ctx, dic, y, lam1, lam2, idx)
+    st = ctx.last_stats()
+    assert st['itercap_voxels'] == 0 and st['overflow_voxels'] == 0
+    for v in range(0, nv, 8):
+        g = A[idx[v]].T @ (y[v] - A[idx[v]] @ xl[v]) - lam2 * xl[v] - lam1
+        assert np.abs(g[xl[v] > 0]).max(initial=0.0) < 1e-9 and g[xl[v] == 0].max(initial=0.0) < 1e-9
