@@ -58,7 +58,7 @@ int make_plan(amx_ctx *ctx, int64_t n, int ndirs, Plan &pl, bool seeds = false, 
         if ((rc = ensure(ctx, ctx->cgemm, ((size_t)n / 64 + ndirs + 1) * table_rows * 64 * sizeof(double)))) return rc;
         if ((rc = ensure(ctx, ctx->cgemm2, ((size_t)n / 64 + ndirs + 1) * table_rows * 64 * sizeof(double)))) return rc;
         if ((rc = ensure(ctx, ctx->clip, ((size_t)2 * n + pl.max_schunks + 64) * sizeof(int)))) return rc;
-        if ((rc = ensure(ctx, ctx->feed, (size_t)kFeedSets * (pl.max_schunks + 8) * sizeof(int)))) return rc;      // chunk counters of the kernels that share their chunks (SeedFeed, BlockFeed)
+        if ((rc = ensure(ctx, ctx->feed, (size_t)(kFeedSets + kZCounts) * (pl.max_schunks + 8) * sizeof(int)))) return rc;      // chunk counters of the kernels that share their chunks (SeedFeed, BlockFeed) + the list counts of every pass (Plan::zcount)
         if ((rc = ensure(ctx, ctx->done, (size_t)n + 64))) return rc;
         if ((rc = ensure(ctx, ctx->rlist, 2 * amx_rlist_half(pl) * sizeof(int)))) return rc;
         if ((rc = ensure(ctx, ctx->ytil2, (size_t)n * amx::kSeedKD * sizeof(double)))) return rc;
@@ -95,7 +95,7 @@ int enqueue_bucketing(amx_ctx *ctx, const amx_lut *lut, const double *d_dirs, in
 {
     HIPCHK(ctx, hipMemsetAsync(pl.counts, 0, (size_t)(lut->ndirs + 1) * sizeof(int), s));
     HIPCHK(ctx, hipMemsetAsync(ctx->misc.p, 0, 64 * sizeof(int), s));
-    if (pl.feed) HIPCHK(ctx, hipMemsetAsync(pl.feed, 0, (size_t)kFeedSets * (pl.max_schunks + 8) * sizeof(int), s));
+    if (pl.feed) HIPCHK(ctx, hipMemsetAsync(pl.feed, 0, (size_t)(kFeedSets + kZCounts) * (pl.max_schunks + 8) * sizeof(int), s));
     const int nb = (int)((n + kPrepSpan - 1) / kPrepSpan);
     const int use_lds = lut->ndirs <= 8192 ? 1 : 0;          // LDS histograms: 2 * ndirs ints
     hipLaunchKernelGGL(k_dir_to_lut, dim3(nb), dim3(1024), use_lds ? (size_t)lut->ndirs * sizeof(int) : 0, s, d_dirs,
@@ -703,10 +703,10 @@ static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
             rec(ctx, 17, s);
             if (!gcert) ctx->uncert_vox[0] += n_vox;
             if (gcert) {
-                size_t off = 0;
-                if ((rc = amx_launch_noddi_gcert(ctx, lut, a, pl, s, 1, &off))) return rc;
+                size_t off = 0; const int *cnt = nullptr;
+                if ((rc = amx_launch_noddi_gcert(ctx, lut, a, pl, s, 1, &off, &cnt))) return rc;
                 a.done = ctx->opt_no_hard_first ? nullptr : (const unsigned char *)ctx->done.p;
-                a.rlist = (const int *)ctx->rlist.p + off; a.rcount = a.rlist + pl.n;
+                a.rlist = (const int *)ctx->rlist.p + off; a.rcount = cnt;
                 a.c.chunks = pl.schunks; a.c.n_chunks = pl.n_chunks + 1;      // the stage kernel walks the left-over lists of the second plan
             }
         }
@@ -731,7 +731,7 @@ static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
         if (gcert2) {
             const bool wide = !ctx->opt_no_gcert_wide;
             if ((rc = amx_launch_noddi_gcert2(ctx, lut, a, pl, s, wide))) return rc;
-            a.rlist = (const int *)ctx->rlist.p + amx_gcert2_leftover_offset(pl, wide); a.rcount = a.rlist + pl.n;   // (two wide passes end in the first half again)
+            a.rlist = (const int *)ctx->rlist.p + amx_gcert2_leftover_offset(pl, wide); a.rcount = amx_gcert2_leftover_counts(pl, wide);   // (two wide passes end in the first half again)
             a.c.chunks = pl.schunks; a.c.n_chunks = pl.n_chunks + 1;
         }
         rec(ctx, 13, s);
@@ -747,10 +747,10 @@ static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
             const bool gcert3 = !ctx->opt_no_gcert && gemm_ks > 0;
             if (!gcert3) ctx->uncert_vox[2] += n_vox;
             if (!rc && gcert3) {
-                size_t off = 0;
-                rc = amx_launch_noddi_gcert(ctx, lut, a, pl, s, 3, &off);
+                size_t off = 0; const int *cnt = nullptr;
+                rc = amx_launch_noddi_gcert(ctx, lut, a, pl, s, 3, &off, &cnt);
                 a.done = ctx->opt_no_hard_first ? nullptr : (const unsigned char *)ctx->done.p;
-                a.rlist = (const int *)ctx->rlist.p + off; a.rcount = a.rlist + pl.n;
+                a.rlist = (const int *)ctx->rlist.p + off; a.rcount = cnt;
                 a.c.chunks = pl.schunks; a.c.n_chunks = pl.n_chunks + 1;
             }
             rec(ctx, 15, s);

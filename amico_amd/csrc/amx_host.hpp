@@ -218,8 +218,15 @@ struct Plan {
     int seed_waves = 4;            // wavefronts per workgroup of the lane-per-voxel NODDI kernels (one workgroup per chunk of the second plan)
     int *feed = nullptr;           // kFeedSets sets of max_schunks + 8 chunk counters, one per kernel that shares its chunks (zeroed with the plan)
     int *feed_set(int k) const { return feed + (size_t)k * (max_schunks + 8); }
+    // per-chunk counts of the lists the kernels of the chain compact (left-over lists of every certificate pass, clipped lists): one
+    // array per pass, all in the arena behind the feed sets and cleared by the ONE memset that clears those -- each pass used to clear
+    // its own (ten 5 us fill kernels per fit: 3 % of a 50 000-voxel call)
+    int *zcount(int k) const { return feed + (size_t)(kFeedSetsN + k) * (max_schunks + 8); }
+    static constexpr int kFeedSetsN = 7;
 };
 enum { FEED_SEED1 = 0, FEED_SEED2, FEED_SEED3, FEED_GEMM, FEED_CERT1, FEED_CERT2, FEED_CERT3, kFeedSets };
+enum { ZC_CERT1 = 0, ZC_RESC1, ZC_CLIP, ZC_CERT2, ZC_CERT2W, ZC_CERT2W3, ZC_CERT3, ZC_RESC3, kZCounts };
+static_assert(kFeedSets == Plan::kFeedSetsN, "Plan::zcount sits behind the feed sets");
 
 // AMX_DEBUG=1: synchronise after every launch and trace progress on stderr
 static inline bool amx_debug() { static int d = -1; if (d < 0) { const char *e = getenv("AMX_DEBUG"); d = (e && *e && *e != '0') ? 1 : 0; } return d == 1; }
@@ -241,12 +248,13 @@ static inline void rec(amx_ctx *ctx, int k, hipStream_t s)
 int amx_build_basis(amx_ctx *ctx, amx_lut *lut);
 int amx_launch_noddi_project(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s);
 int amx_launch_noddi_seed(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, int stage);
-int amx_launch_noddi_gcert(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, int stage, size_t *list_off);
+int amx_launch_noddi_gcert(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, int stage, size_t *list_off, const int **count_out);
 int amx_launch_noddi_gemm(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, bool lasso);
 int amx_launch_noddi_s2prep(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s);
 int amx_gemm_ksteps(const amx_lut *lut);   // K-steps of the table kernels for this dictionary (25 / 40), 0 = shape not supported
 int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, bool wide);
 size_t amx_gcert2_leftover_offset(const Plan &pl, bool wide);      // which half of ctx->rlist the LASSO certificate passes end in (amx_seed.hip)
+const int *amx_gcert2_leftover_counts(const Plan &pl, bool wide);  // ... and the per-chunk counts of those lists (Plan::zcount)
 static inline size_t amx_rlist_half(const Plan &pl) { return (size_t)pl.n + pl.max_schunks + 64; }   // ints per left-over list + counts
 int amx_launch_noddi_seed2(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, bool have_ytil2);
 int amx_launch_noddi_s1(amx_ctx *ctx, amx::NoddiArgs &a, const Plan &pl, hipStream_t s);

@@ -144,7 +144,7 @@ int amx_launch_noddi_gemm(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, 
     ga.Ub = lasso ? lut->basis2_U : lut->basis_U; ga.U2b = lasso ? nullptr : lut->basis2_U;
     ga.Cb = (double *)(lasso ? ctx->cgemm2.p : ctx->cgemm.p); ga.ytil = (double *)(lasso ? ctx->ytil2.p : ctx->ytil.p);
     ga.xiso = a.xiso; ga.rowdwi = lut->rowdwi; ga.colscale = lut->colscale; ga.iso_atom = lut->n_atoms - 1; ga.is_exvivo = lut->is_exvivo; ga.n_wm = lut->n_wm;
-    if (lasso) { ga.clist = (const int *)ctx->clip.p; ga.ccount = (const int *)ctx->clip.p + 2 * pl.n; }
+    if (lasso) { ga.clist = (const int *)ctx->clip.p; ga.ccount = pl.zcount(ZC_CLIP); }
     else { ga.gcount = pl.feed_set(FEED_GEMM); ga.n_gcount = pl.max_schunks; }
     const int ks = amx_gemm_ksteps(lut);
     const size_t lds = gemm_lds(lasso ? lut->n_wm : lut->n_atoms, ga.rows, ks);
@@ -182,9 +182,8 @@ int amx_launch_noddi_s2prep(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a
     p.perm = pl.perm; p.schunks = pl.schunks; p.n_schunks = pl.n_chunks + 1;
     p.Cb = (const double *)ctx->cgemm.p; p.rows = gemm_rows(lut->n_atoms); p.aux0 = lut->n_atoms;
     p.xiso = a.xiso; p.u2iso = lut->u2iso; p.ytil2 = (double *)ctx->ytil2.p;
-    p.clist = (int *)ctx->clip.p; p.cslot = p.clist + pl.n; p.ccount = p.clist + 2 * pl.n;
+    p.clist = (int *)ctx->clip.p; p.cslot = p.clist + pl.n; p.ccount = pl.zcount(ZC_CLIP);      // (counts: cleared with the plan)
     p.status = a.c.status; p.force_all = (!lut->s2_derive || ctx->opt_s2_exact) ? 1 : 0;
-    HIPCHK(ctx, hipMemsetAsync(p.ccount, 0, (size_t)pl.max_schunks * sizeof(int), s));
     hipLaunchKernelGGL(k_s2_prep, dim3(((pl.max_schunks + 7) / 8) * 8), dim3(256), 0, s, p);
     AMX_TRACE(ctx, s, "stage-2 signals from the table, clipped voxels compacted");
     HIPCHK(ctx, hipGetLastError());
@@ -194,6 +193,10 @@ int amx_launch_noddi_s2prep(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a
 size_t amx_gcert2_leftover_offset(const Plan &pl, bool wide)
 {
     return (wide && !(kGcert2Wide3 > kGcert2Wide)) ? amx_rlist_half(pl) : 0;      // (an even number of passes after the first ends in the first half again)
+}
+const int *amx_gcert2_leftover_counts(const Plan &pl, bool wide)
+{
+    return pl.zcount(!wide ? ZC_CERT2 : (kGcert2Wide3 > kGcert2Wide ? ZC_CERT2W3 : ZC_CERT2W));
 }
 
 // Gram-space certificates of the LASSO seeds (k_lasso_gcert): support bits of the voxels it settles, left-over lists for k_noddi<4>
@@ -208,9 +211,8 @@ int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a
     g.iso_atom = lut->n_atoms - 1; g.dot_atom = lut->is_exvivo ? lut->n_atoms - 2 : -1;
     g.Sb = lut->basis2_S; g.kappa0 = lut->screen2_kappa0; g.lam1 = a.c.lam1; g.lam2 = a.c.lam2;
     g.supp = a.supp; g.xiso = a.xiso; g.done = (unsigned char *)ctx->done.p;
-    g.rlist = (int *)ctx->rlist.p; g.rcount = (int *)ctx->rlist.p + pl.n;
+    g.rlist = (int *)ctx->rlist.p; g.rcount = pl.zcount(ZC_CERT2);
     g.gcount = pl.feed_set(FEED_CERT2); g.n_gcount = pl.max_schunks;
-    HIPCHK(ctx, hipMemsetAsync(g.rcount, 0, (size_t)pl.max_schunks * sizeof(int), s));
     if (a.c.xdbg) g.xdbg = a.c.xdbg;
 #ifdef AMX_STATS
     g.stats = a.c.status + ST_SEED + 36;
@@ -224,8 +226,7 @@ int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a
     if (wide) {
         // second pass: supports of 12 .. 18 atoms from the left-over lists; its own left-overs in the second half of the buffer
         g.rlist_in = g.rlist; g.rcount_in = g.rcount;
-        g.rlist = (int *)ctx->rlist.p + amx_rlist_half(pl); g.rcount = g.rlist + pl.n;
-        HIPCHK(ctx, hipMemsetAsync(g.rcount, 0, (size_t)pl.max_schunks * sizeof(int), s));
+        g.rlist = (int *)ctx->rlist.p + amx_rlist_half(pl); g.rcount = pl.zcount(ZC_CERT2W);
 #ifdef AMX_STATS
         g.stats = a.c.status + ST_SEED + 48;
 #endif
@@ -236,8 +237,7 @@ int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a
         if (kGcert2Wide3 > kGcert2Wide) {
             // third pass: supports beyond the second pass from the second pass's left-overs, back into the first half of the buffer
             g.rlist_in = g.rlist; g.rcount_in = g.rcount;
-            g.rlist = (int *)ctx->rlist.p; g.rcount = g.rlist + pl.n;
-            HIPCHK(ctx, hipMemsetAsync(g.rcount, 0, (size_t)pl.max_schunks * sizeof(int), s));
+            g.rlist = (int *)ctx->rlist.p; g.rcount = pl.zcount(ZC_CERT2W3);
 #ifdef AMX_STATS
             g.stats = nullptr;
 #endif
@@ -252,7 +252,7 @@ int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a
 
 // Gram-space certificates of the NNLS seeds, one voxel per lane (k_nnls_gcert): done[pos] = 1 for the voxels it settles
 // (+ the rescue pass over its left-over lists; *list_off: where in ctx->rlist the lists for the wavefront-per-voxel kernel are)
-int amx_launch_noddi_gcert(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, const Plan &pl, hipStream_t s, int stage, size_t *list_off)
+int amx_launch_noddi_gcert(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, const Plan &pl, hipStream_t s, int stage, size_t *list_off, const int **count_out)
 {
     *list_off = 0;
     GcertArgs g;
@@ -263,9 +263,9 @@ int amx_launch_noddi_gcert(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a,
     g.gram = lut->gram; g.ldG = lut->ldG; g.n_atoms = lut->n_atoms; g.n_wm = lut->n_wm; g.nS = lut->nS;
     g.iso_atom = lut->n_atoms - 1; g.dot_atom = lut->is_exvivo ? lut->n_atoms - 2 : -1; g.n_maps = a.n_maps;
     g.Sb = lut->basis_S; g.kappa0 = lut->screen_kappa0; g.supp = a.supp; g.icvf = lut->icvf; g.kappa = lut->kappa;
-    g.done = (unsigned char *)ctx->done.p; g.rlist = (int *)ctx->rlist.p; g.rcount = (int *)ctx->rlist.p + pl.n;
+    g.done = (unsigned char *)ctx->done.p; g.rlist = (int *)ctx->rlist.p; g.rcount = pl.zcount(stage == 1 ? ZC_CERT1 : ZC_CERT3);
+    *count_out = g.rcount;
     g.gcount = pl.feed_set(stage == 1 ? FEED_CERT1 : FEED_CERT3); g.n_gcount = pl.max_schunks;
-    HIPCHK(ctx, hipMemsetAsync(g.rcount, 0, (size_t)pl.max_schunks * sizeof(int), s));
     g.xiso = a.xiso; g.est = a.est; g.rmse = a.rmse; g.nrmse = a.nrmse; g.mod = a.mod;
     if (a.c.xdbg) g.xdbg = a.c.xdbg;
 #ifdef AMX_STATS
@@ -296,8 +296,8 @@ int amx_launch_noddi_gcert(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a,
         // 8.08 -> 8.24 ms with it, 4 M 24.99 -> 24.38): the supports refused for conditioning, corrected with the signal itself;
         // what is left goes to the second half
         g.rlist_in = g.rlist; g.rcount_in = g.rcount;
-        g.rlist = (int *)ctx->rlist.p + amx_rlist_half(pl); g.rcount = g.rlist + pl.n;
-        HIPCHK(ctx, hipMemsetAsync(g.rcount, 0, (size_t)pl.max_schunks * sizeof(int), s));
+        g.rlist = (int *)ctx->rlist.p + amx_rlist_half(pl); g.rcount = pl.zcount(stage == 1 ? ZC_RESC1 : ZC_RESC3);
+        *count_out = g.rcount;
         g.y = a.c.y; g.y32 = a.c.y32; g.tiles = (const float *)lut->tiles; g.tile_stride = lut->tile_stride; g.ldA = lut->ldA;
         const size_t tile = (size_t)lut->nS * lut->ldA * sizeof(float);
         g.tile_in_lds = lds + tile <= kLdsPerCU ? 1 : 0;

@@ -268,11 +268,19 @@ __global__ __launch_bounds__(256) void k_prep_stream4(PrepArgs a)
         float f[4] = {1.0f, 1.0f, 1.0f, 1.0f};
         if (a.normalize) {
             float mm[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            for (int i = 0; i < a.n_b0; i++) {
-                float v[4];
-                load4((long long)Pb0[i] * a.sv, v);
+            // (batches of eight loads in flight, the tail of a list as a clamped batch: a loop of single loads is a chain of HBM round
+            //  trips -- 6 b0 volumes + 4 left-over volumes in each of 5 shells were 26 of a tile's 64 trips)
+            for (int i0 = 0; i0 < a.n_b0; i0 += 8) {
+                float t4[8][4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) mm[u] = mm[u] + v[u];
+                for (int w = 0; w < 8; w++) load4((long long)Pb0[i0 + w < a.n_b0 ? i0 + w : a.n_b0 - 1] * a.sv, t4[w]);
+#pragma unroll
+                for (int w = 0; w < 8; w++) {
+                    if (i0 + w < a.n_b0) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) mm[u] = mm[u] + t4[w][u];
+                    }
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -295,11 +303,17 @@ __global__ __launch_bounds__(256) void k_prep_stream4(PrepArgs a)
                     for (int u = 0; u < 4; u++) { const float v = scaled(t4[w][u], f[u]); acc[u] = (g + w == g0) ? v : acc[u] + v; }
                 }
             }
-            for (; g < g1; g++) {
-                float t1[4];
-                load4((long long)Pgi[g] * a.sv, t1);
+            if (g < g1) {                               // the list's tail: one clamped batch, same order of the sums
+                float t4[8][4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) { const float v = scaled(t1[u], f[u]); acc[u] = (g == g0) ? v : acc[u] + v; }
+                for (int w = 0; w < 8; w++) load4((long long)Pgi[g + w < g1 ? g + w : g1 - 1] * a.sv, t4[w]);
+#pragma unroll
+                for (int w = 0; w < 8; w++) {
+                    if (g + w < g1) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { const float v = scaled(t4[w][u], f[u]); acc[u] = (g + w == g0) ? v : acc[u] + v; }
+                    }
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {

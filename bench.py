@@ -300,7 +300,7 @@ def signal_preparation(args):
     from oracle import signal_np
     dev = torch.device('cuda', 0)
     scheme = S.make_scheme()
-    shape = (128, 128, 80)
+    shape = tuple(int(v) for v in os.environ.get('PREP_SHAPE', '128,128,80').split(','))      # (PREP_SHAPE=192,192,120: ~1.9 M masked voxels)
     rng = np.random.default_rng(1)
     out = {}
     for order in os.environ.get('PREP_ORDERS', 'F,C').split(','):
@@ -356,7 +356,7 @@ def signal_preparation(args):
     if os.environ.get('PREP_DIRAVG', '1') != '0':
         # SANDI preprocessing: 306 volumes (6 b0 + 5 shells x 60) -> b0 mean + 5 shell means per masked voxel (core.py:229-252)
         full = S.make_sandi_scheme()
-        shp = (128, 128, 40)
+        shp = tuple(int(v) for v in os.environ.get('PREP_DIRAVG_SHAPE', '128,128,40').split(','))
         img = np.asfortranarray(rng.uniform(0.0, 900.0, shp + (full.nS,)).astype(np.float32))
         xx, yy, zz = np.meshgrid(*[np.linspace(-1, 1, s) for s in shp], indexing='ij')
         mask = ((xx * xx + yy * yy + zz * zz) < 0.92).astype(np.uint8)
@@ -384,8 +384,8 @@ def signal_preparation(args):
     print(json.dumps({'metric': 'voxels/sec, signal preparation (mask gather + b0 normalisation + clip)',
                       'value': best['voxels_per_s'], 'unit': 'voxels/s', 'n_gpus': 1, 'steps': args.steps,
                       'warmup': args.warmup, 'dtype': 'f32->f64', 'data': 'synthetic',
-                      'config': {'workload': '128x128x80x99 float32 image, %d masked voxels, Fortran order (nibabel) '
-                                             '[C order alongside]' % best['voxels']},
+                      'config': {'workload': '%s float32 image, %d masked voxels, Fortran order (nibabel) '
+                                             '[C order alongside]' % ('x'.join(str(v) for v in shape + (scheme.nS,)), best['voxels'])},
                       'roofline': {'bound': 'hbm', 'achieved': best['achieved_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                    'frac': best['achieved_GBs'] / HBM_PEAK_GBS, 'traffic': None, 'kernel': 'k_prep_gather',
                                    'kernel_ms': best['kernel_ms'], 'bytes_per_voxel': 12 * scheme.nS + 4},
