@@ -1782,6 +1782,63 @@ __global__ void __launch_bounds__(256, RESCUE ? 1 : 2) k_nnls_gcert(const GcertA
 // dual value of atom t: g_t = c2_t - (S G2 S)_tP x_P - lambda1.  The ridge bounds cond(H), so no pivot guard is needed
 // -- this is the arithmetic GramSolver::certify_seed performs too.  A lane holds the factor of up to 12 passive atoms
 // (87 % of the voxels; the rest, and everything refused, goes to k_noddi<4> through the left-over lists).
+// The passive system of one voxel in as few registers as it takes (round 5): ONE packed triangle -- the factor's off-diagonal entries
+// with the RECIPROCAL pivots on its diagonal --, ONE vector that is the right-hand side going in and the solution coming out, the
+// atoms.  SeedLane (T, dinv, c, x, idx + the caller's z and column scales) asked 18 atoms for ~520 registers of a lane's 512:
+// k_lasso_gcert<18, wide> spilled 129 of them to scratch, the 11-atom pass 33.  x'c of the solution falls out of the forward
+// substitution (x'c = x'Hx = ||L'x||^2 = ||L^-1 c||^2), so c need not survive the solve.
+template <int MS>
+struct LeanLane {
+    static constexpr int NT = MS * (MS + 1) / 2;
+    double T[NT], c[MS];
+    int idx[MS], np;
+    // in-place Cholesky of the matrix in T (slots >= np: zero rows); false: a pivot of a live slot is not positive
+    __device__ __forceinline__ bool factor()
+    {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < MS; j++) {
+            double dj = T[stri<MS>(j, j)];
+            const double hjj = dj;
+#pragma unroll
+            for (int m = 0; m < j; m++) dj -= T[stri<MS>(j, m)] * T[stri<MS>(j, m)];
+            const bool good = dj > 1e-15 * hjj;
+            ok = ok && (j >= np || good);
+            const double di = (j < np && good) ? inv_sqrt(dj) : 0.0;
+            T[stri<MS>(j, j)] = di;
+#pragma unroll
+            for (int i = j + 1; i < MS; i++) {
+                double v = T[stri<MS>(i, j)];
+#pragma unroll
+                for (int m = 0; m < j; m++) v -= T[stri<MS>(i, m)] * T[stri<MS>(j, m)];
+                T[stri<MS>(i, j)] = v * di;
+            }
+        }
+        return ok;
+    }
+    // c <- (L L')^-1 c; returns c_in' x = ||L^-1 c_in||^2
+    __device__ __forceinline__ double solve()
+    {
+        double q = 0.0;
+#pragma unroll
+        for (int j = 0; j < MS; j++) {
+            double f = c[j];
+#pragma unroll
+            for (int m = 0; m < j; m++) f -= T[stri<MS>(j, m)] * c[m];
+            c[j] = f * T[stri<MS>(j, j)];
+            q += c[j] * c[j];
+        }
+#pragma unroll
+        for (int j = MS - 1; j >= 0; j--) {
+            double f = c[j];
+#pragma unroll
+            for (int m = j + 1; m < MS; m++) f -= T[stri<MS>(m, j)] * c[m];
+            c[j] = f * T[stri<MS>(j, j)];
+        }
+        return q;
+    }
+};
+
 #ifndef AMX_GCERT2_MAX
 #define AMX_GCERT2_MAX 11      // (12: 37 spilled registers in the first pass, LASSO group 3.44 ms; 11: none, 3.37 ms; 10: 3.48 ms)
 #endif
@@ -1892,8 +1949,7 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
         const unsigned long long flag = sd[3];
         const int cnt = __builtin_popcountll(P[0]) + __builtin_popcountll(P[1]) + __builtin_popcountll(P[2]);
         bool okv = valid && flag == 0ull && cnt <= MS && (!WIDE || cnt > LOW);
-        SeedLane<MS> V;
-        V.clear();
+        LeanLane<MS> V;
         {
             // slots = set bits in ascending order
             unsigned long long rem[3] = {okv ? P[0] : 0ull, okv ? P[1] : 0ull, okv ? P[2] : 0ull};
@@ -1923,16 +1979,22 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
             cand[w3] = all & ~P[w3];
         }
         GC_PH(0);
-        double sc[MS];
+        // (the column scales are read from LDS where they are needed -- scl[idx] -- instead of living in MS registers through the
+        //  factorisation: the kernel's register peak is T + c + z + idx there)
+        {
+            double sc[MS];
 #pragma unroll
-        for (int s = 0; s < MS; s++) sc[s] = scl[V.idx[s]];
+            for (int s = 0; s < MS; s++) sc[s] = scl[V.idx[s]];
 #pragma unroll
-        for (int s = 0; s < MS; s++) {
+            for (int s = 0; s < MS; s++) {
 #pragma unroll
-            for (int t = 0; t <= s; t++)
-                V.T[stri<MS>(s, t)] = (s < V.np) ? sc[s] * sc[t] * Gd[(size_t)V.idx[s] * a.ldG + V.idx[t]] + ((s == t) ? lam2 : 0.0) : 0.0;
-            V.c[s] = (s < V.np) ? (clip ? 1.0 : sc[s]) * (Crow[(size_t)V.idx[s] * 64] - sub - xq * giso[V.idx[s]]) - lam1 : 0.0;
+                for (int t = 0; t <= s; t++)
+                    V.T[stri<MS>(s, t)] = (s < V.np) ? sc[s] * sc[t] * Gd[(size_t)V.idx[s] * a.ldG + V.idx[t]] + ((s == t) ? lam2 : 0.0) : 0.0;
+                V.c[s] = (s < V.np) ? (clip ? 1.0 : sc[s]) * (Crow[(size_t)V.idx[s] * 64] - sub - xq * giso[V.idx[s]]) - lam1 : 0.0;
+                if (WIDE) __builtin_amdgcn_sched_barrier(0);      // row by row: 171 addresses computed ahead of their loads were 342 registers of their own
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
         double yy = Crow[(size_t)(a.aux0 + kAuxYY) * 64];
         if (!clip) {
             // ||y2||^2 = (||y||^2 - sum_b0 y^2) - 2 x_iso (c_iso - sum_b0 y) + x_iso^2 ||iso_dwi||^2
@@ -1941,15 +2003,15 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
             yy = yy > 0.0 ? yy : (yy <= 0.0 ? 0.0 : yy);                 // (rounding below zero; NaN stays NaN)
         }
         const bool piv = V.factor();
-        double z[MS];
-        V.solve(z);
+        // x = H_PP^-1 (c2_P - lambda1) in place; ||r||^2 = ||y2||^2 - [x'(c2 - lambda1) + 2 lambda1 sum x + lambda2 x'x]
+        // (x'(c2 - lambda1) comes with the forward substitution: LeanLane::solve)
+        double rho2 = yy - V.solve();
         bool feas = true;
-        double rho2 = yy;
 #pragma unroll
         for (int s = 0; s < MS; s++) {
-            V.x[s] = z[s];
-            if (s < V.np && !(z[s] > 0.0)) feas = false;
-            rho2 -= z[s] * (V.c[s] + ((s < V.np) ? lam1 : 0.0)) + lam1 * z[s] + lam2 * z[s] * z[s];
+            const double zs = V.c[s];
+            if (s < V.np && !(zs > 0.0)) feas = false;
+            rho2 -= 2.0 * lam1 * zs + lam2 * zs * zs;
         }
         rho2 = rho2 > 0.0 ? rho2 : 0.0;
         const bool good = okv && piv && feas && (yy <= 1.79769313486231570e308);
@@ -1966,7 +2028,7 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
                 double cv[KD];
                 seed_col<KD>(col, cv);
 #pragma unroll
-                for (int d = 0; d < KD; d++) rt[d] -= V.x[s] * cv[d];
+                for (int d = 0; d < KD; d++) rt[d] -= V.c[s] * cv[d];
             }
             // compressed dual value s2_t'r~ - lambda1 > -kappa ||r||  <=>  s2_t'r~ > lambda1 - kappa ||r||
             seed_flags_mfma<KS, MT>(Aop, Rb, lane, rt, good, good ? lam1 - 1.0625 * kap * sqrt(rho2) - 1e-12 : __builtin_huge_val(), cand, ex);
@@ -1975,6 +2037,9 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
         bool viol = false;
         int n_ex = 0;
         {
+            double xs[MS];                                 // the coefficients with their columns' scales (the factor is dead by now)
+#pragma unroll
+            for (int s = 0; s < MS; s++) xs[s] = scl[V.idx[s]] * V.c[s];
             unsigned long long rem[3] = {good ? ex[0] : 0ull, good ? ex[1] : 0ull, good ? ex[2] : 0ull};
             for (int it = 0; it < 192; it++) {
                 int wq = -1;
@@ -1992,7 +2057,7 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
                 double g = on ? (clip ? 1.0 : st) * (Crow[(size_t)t * 64] - sub - xq * giso[t]) - lam1 : -1.0;
                 const double *gt = Gd + (size_t)t * a.ldG;
 #pragma unroll
-                for (int s = 0; s < MS; s++) { if (s < V.np && on) g -= st * sc[s] * gt[V.idx[s]] * V.x[s]; }
+                for (int s = 0; s < MS; s++) { if (s < V.np && on) g -= st * gt[V.idx[s]] * xs[s]; }
                 if (on && !(g < -1e-10)) viol = true;
                 n_ex += on ? 1 : 0;
             }
@@ -2027,7 +2092,7 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
                 double *dst = a.xdbg + ((size_t)vox * 3 + 1) * a.n_atoms;
                 for (int j = 0; j < a.n_atoms; j++) dst[j] = 0.0;
 #pragma unroll
-                for (int s = 0; s < MS; s++) if (s < V.np) dst[V.idx[s]] = V.x[s];
+                for (int s = 0; s < MS; s++) if (s < V.np) dst[V.idx[s]] = V.c[s];
                 dst[a.iso_atom] = xi;
                 if (a.dot_atom >= 0) dst[a.dot_atom] = a.xiso[(size_t)vox * 2 + 1];
             }
