@@ -225,7 +225,7 @@ int amx_ctx_create(int device, amx_ctx **out)
         ctx->opt_host_one_shot = on("AMX_HOST_ONE_SHOT"); ctx->opt_host_one_stream = on("AMX_HOST_ONE_STREAM");
         ctx->opt_tile_f32 = on("AMX_TILE_F32"); ctx->opt_fw_proj_valu = on("AMX_FW_PROJ_VALU"); ctx->opt_sandi_atom_space = on("AMX_SANDI_ATOM_SPACE");
         ctx->opt_prep_tile = on("AMX_PREP_TILE"); ctx->opt_prep_scalar = on("AMX_PREP_SCALAR"); ctx->opt_lut_regs = on("AMX_LUT_REGS"); ctx->opt_no_refill = on("AMX_NO_REFILL");
-        ctx->opt_wave_per_voxel = on("AMX_WAVE_PER_VOXEL");
+        ctx->opt_wave_per_voxel = on("AMX_WAVE_PER_VOXEL"); ctx->opt_fw_no_fuse = on("AMX_FW_NO_FUSE");
         e = getenv("AMX_REFILL_CHUNK");
         if (e) ctx->opt_refill_chunk = atoi(e);
         e = getenv("AMX_HOST_RAMP");

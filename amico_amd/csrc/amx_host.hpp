@@ -65,6 +65,7 @@ struct amx_ctx {
     long long opt_host_batch = 393216; // AMX_HOST_BATCH: voxels per pipelined batch (>= 131072, multiple of 4)
     bool opt_tile_f32 = false;         // AMX_TILE_F32=1: NNLS stages keep the float32 tile in LDS
     bool opt_fw_proj_valu = false;     // AMX_FW_PROJ_VALU=1: FreeWater projection without the matrix cores
+    bool opt_fw_no_fuse = false;       // AMX_FW_NO_FUSE=1: FreeWater by the projection + solver kernel pair instead of k_freewater_fused
     bool opt_sandi_atom_space = false; // AMX_SANDI_ATOM_SPACE=1: SANDI 6 x 15 by the atom-space lane kernel
     bool opt_prep_scalar = false;      // AMX_PREP_SCALAR=1: the streaming preparation kernel with one voxel per lane (4-byte loads) instead of four
     bool opt_prep_no_direct = false;   // AMX_PREP_NO_DIRECT=1: k_prep_gather stages the planes through registers (32 loads in flight) instead of global -> LDS loads

@@ -1166,6 +1166,437 @@ __global__ void __launch_bounds__(256, 2) k_freewater_refill(const FwArgs a)
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// FreeWater in ONE kernel (round 5): a PRODUCER wavefront and seven CONSUMER wavefronts per CU.
+//
+// k_fw_project_mfma + k_freewater_refill move c = A'y - lambda1 (96 B) and the first passive set (4 B) of every voxel through HBM and
+// run one after the other: 0.32 ms of streaming with idle vector units, then 0.40 ms of fp64 vector work with an idle memory system
+// (per 2 M voxels).  Here wavefront 0 of a workgroup of eight does what the projection kernel did -- signal tiles global -> LDS by
+// direct loads, kFuseAhead tiles in flight behind the one being multiplied, c and z0 = H^-1 c on the fp64 matrix cores -- and leaves
+// each batch of 64 voxels (c, voxel numbers, first passive sets) in a slot of an LDS ring; wavefronts 1 .. 7 are the lanes-that-never-
+// idle solver of k_freewater_refill, drawing their batches from the ring instead of from HBM (ticket = LDS atomic, slot state = one
+// sequence word per slot: 2 t + 1 "batch t is here", 2 t + 2 "batch t has been taken").  c never leaves the chip; the loads of the
+// next signals hide behind the pivoting of the current ones.  The per-voxel arithmetic is that of the two kernels, in the same order.
+// Needs 64 <= nS <= 96 (whole tiles of 16 values dominate, the dictionary operand lives in 24 K-steps of registers): other protocols
+// keep the two-kernel path.
+// Workgroups of FOUR wavefronts, two per CU: one producer + three consumers each.  (One producer for seven consumers -- a workgroup of
+// eight -- was measured first: 0.84 - 0.88 ms per 2 M voxels whatever the number of tiles in flight, against 0.735 for the kernel pair:
+// the producer shares its SIMD with a consumer, both live on the fp64 pipe, and 7 k cycles of matrix instructions per batch at half a
+// SIMD are ~6 us, while seven consumers want a batch every 3.7 us.)
+#ifndef AMX_FUSE_RING
+#define AMX_FUSE_RING 5
+#endif
+constexpr int kFuseRing = AMX_FUSE_RING;   // batches between producer and consumers
+#ifndef AMX_FUSE_AHEAD
+#define AMX_FUSE_AHEAD 2
+#endif
+constexpr int kFuseAhead = AMX_FUSE_AHEAD; // signal tiles in flight behind the one being multiplied (2 x 8 KB per workgroup, 32 KB per CU)
+constexpr int kFuseTiles = kFuseAhead + 1;
+constexpr int kFuseHs = 3;                 // H tables per consumer wavefront (lanes may still work on voxels of the last two orientations)
+constexpr int kFuseSub = 1024;             // voxels per unit of the global queue (one orientation: the operand registers are loaded per unit,
+                                           // and the pipeline of tiles fills once per unit)
+constexpr int kFuseConsumers = 3;
+static_assert(kFuseAhead * 8 <= 63 && kFuseAhead <= 7, "s_waitcnt vmcnt holds six bits");
+
+template <int N> constexpr int fuse_hslot_words() { return 128 * ((N * N + 127) / 128) + 2; }
+template <int N> constexpr int fuse_slot_words() { return 64 * ((N + 1) & ~1) + 64; }       // Cb [64][NP] | Vb int[64] | Pb unsigned[64]
+template <int N> constexpr size_t fuse_lds_bytes(int n_tail)      // n_tail = nS % 16: signal rows beyond the last full tile
+{
+    return ((size_t)kFuseRing * fuse_slot_words<N>() + (size_t)kFuseTiles * 64 * 16 + (size_t)n_tail * 64 +
+            (size_t)kFuseConsumers * kFuseHs * fuse_hslot_words<N>()) * sizeof(double) + (64 + (kFuseSub / 64) * 64) * sizeof(int);
+}
+
+template <int N, bool F32>
+__global__ void __launch_bounds__(64 * (kFuseConsumers + 1), 2) k_freewater_fused(const FwArgs a)
+{
+    static_assert(N <= 16, "one 16-row MFMA tile of atoms");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_u[];
+    constexpr int NP = (N + 1) & ~1;
+    constexpr int R = kFuseRing, TB = kFuseTiles, D = kFuseAhead;
+    constexpr int kSlotW = fuse_slot_words<N>(), kHW = fuse_hslot_words<N>(), kHPieces = (N * N + 127) / 128;
+    constexpr int kTile = 64 * 16;                              // doubles per signal tile (float32 signals use half of it)
+    double *ring = reinterpret_cast<double *>(smem_u);
+    double *tiles = ring + (size_t)R * kSlotW;
+    unsigned *Ttail = reinterpret_cast<unsigned *>(tiles + (size_t)TB * kTile);     // [<= 30 dwords][64 voxels]: rows beyond the last full tile
+    double *Hp = reinterpret_cast<double *>(Ttail) + (size_t)(a.c.nS & 15) * 64;            // (2 dwords x 64 voxels per row)
+    int *ctl = reinterpret_cast<int *>(Hp + (size_t)kFuseConsumers * kFuseHs * kHW);
+    int *seq = ctl, *sdir = ctl + R, *scnt = ctl + 2 * R, *head = ctl + 3 * R, *total = ctl + 3 * R + 1;
+    int *Vu = ctl + 64;                                         // [kFuseSub / 64][64]: voxel numbers of the unit the producer works on
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nS = a.c.nS, n_atoms = a.c.n_atoms, n_perp = a.n_perp;
+    if (threadIdx.x < R) { seq[threadIdx.x] = 2 * ((int)threadIdx.x - R) + 2; sdir[threadIdx.x] = -1; scnt[threadIdx.x] = 0; }
+    if (threadIdx.x == 0) { *head = 0; *total = -1; }
+    __syncthreads();
+    const int n_chunks = *a.c.n_chunks;
+    const int n_units = n_chunks * a.sub_per_chunk;
+    auto lds_load = [](const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto lds_store = [](int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); };
+
+    // Which wavefront produces: the two workgroups of a CU are dispatched half a grid apart (the first 256 fill the chip, the second 256
+    // follow in the same order), and a workgroup's wavefront w runs on SIMD w & 3: wavefront 0 in the first half, wavefront 2 in the
+    // second, so that the two producers of a CU -- matrix instructions on the fp64 pipe, like the consumers' vector work -- sit on
+    // DIFFERENT SIMDs next to one consumer each (both on wavefront 0: a SIMD without any pivoting, 0.589 ms per 2 M voxels)
+#ifndef AMX_FUSE_PW
+#define AMX_FUSE_PW 2
+#endif
+    const int pw = ((int)blockIdx.x >= ((int)gridDim.x >> 1)) ? AMX_FUSE_PW : 0;
+    if (wave == pw) {
+        // ================================================================ producer
+        __builtin_amdgcn_s_setprio(3);
+        const int q = lane >> 4, v16 = lane & 15;
+        const int n_pass = nS >> 4, n_tail = nS - 16 * n_pass;              // full tiles of 16 values, rows beyond them (< 16)
+        const int seg = F32 ? (lane & 3) : (lane & 7), grp = F32 ? (lane >> 2) : (lane >> 3);
+        constexpr int NL = F32 ? 4 : 8;                                     // direct loads per tile
+        int batch_no = 0;                                                   // batches published so far
+        for (;;) {
+            int u = 0;
+            if (lane == 0) u = atomicAdd(a.queue, 1);
+            u = __builtin_amdgcn_readfirstlane(u);
+            if (u >= n_units) break;
+            const Chunk ck = a.c.chunks[u / a.sub_per_chunk];
+            const int k0 = (u % a.sub_per_chunk) * kFuseSub;
+            if (k0 >= ck.count) continue;
+            const int upos = ck.start + k0, ucnt = min(kFuseSub, ck.count - k0);
+            const int nb = (ucnt + 63) >> 6;
+            // the orientation's operands: A' in registers (lane l: A[4 ks + (l >> 4)][l & 15]), H^-1 likewise
+            const double *src = a.prep + (size_t)ck.dir * fw_prep_words<N>(nS);
+            const int KS = (nS + 3) >> 2;
+            double ad[kProjKS], hi[4];
+#pragma unroll
+            for (int ks = 0; ks < kProjKS; ks++) {
+                const int row = 4 * ks + q;
+                ad[ks] = (ks < KS && row < nS && v16 < NP) ? src[row * NP + v16] : 0.0;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                const int k = 4 * ks + q;
+                hi[ks] = (v16 < N && k < N) ? src[(size_t)nS * NP + v16 * NP + k] : 0.0;
+            }
+            // ---- ring slots of the batches of this unit: batch b of the unit is batch (batch_no + b) of the workgroup
+            auto slot_of = [&](int b) { return (batch_no + b) % R; };
+            auto claim = [&](int b) {                                        // wait until the slot's previous batch has been taken
+                const int t = batch_no + b, sl = t % R;
+                for (int spin = 0; spin < (1 << 26); spin++) {
+                    if (lds_load(&seq[sl]) == 2 * (t - R) + 2) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            };
+            auto slot_vb = [&](int b) { return Vu + 64 * b; };          // (the unit's voxel numbers: loaded once, below)
+            auto issue_perm = [&](int b) {                                   // the batch's voxel numbers, global -> LDS
+                const int cnt = min(64, ucnt - 64 * b);
+                const int pl = upos + 64 * b + min(lane, cnt - 1);           // (lanes past the end repeat the last voxel; their results are dropped)
+                __builtin_amdgcn_global_load_lds(a.c.perm + pl, (__attribute__((address_space(3))) void *)slot_vb(b), 4, 0, 0);
+            };
+            const char *yl[8];                                               // this lane's piece of the issue batch's signal rows
+            auto set_yl = [&](int b) {
+                const int *Vb = slot_vb(b);
+#pragma unroll
+                for (int it = 0; it < NL; it++) {
+                    const int vloc = F32 ? it * 16 + grp : it * 8 + grp;
+                    if (F32) yl[it] = reinterpret_cast<const char *>(a.c.y32 + (size_t)Vb[vloc] * nS + 4 * (seg ^ ((vloc >> 2) & 3)));
+                    else yl[it] = reinterpret_cast<const char *>(a.c.y + (size_t)Vb[vloc] * nS + 2 * (seg ^ ((vloc >> 1) & 7)));
+                }
+            };
+            auto issue_tile = [&](int gi) {                                  // tile gi of the unit's stream: batch gi / n_pass, pass gi % n_pass
+                const int b = gi / n_pass, p = gi - b * n_pass;
+                char *dst = reinterpret_cast<char *>(tiles + (size_t)(gi % TB) * kTile);
+#pragma unroll
+                for (int it = 0; it < NL; it++)
+                    __builtin_amdgcn_global_load_lds(yl[it] + (F32 ? 64 : 128) * p, (__attribute__((address_space(3))) void *)(dst + it * 1024), 16, 0, 0);
+                if (p == n_pass - 1 && n_tail > 0) {
+                    // rows beyond the last full tile: one dword column of the 64 voxels per load, Ttail[dword][voxel]
+                    const int *Vb = slot_vb(b);
+                    const int ndw = F32 ? n_tail : 2 * n_tail;
+                    const unsigned *row0 = F32 ? reinterpret_cast<const unsigned *>(a.c.y32 + (size_t)Vb[lane] * nS + 16 * n_pass)
+                                               : reinterpret_cast<const unsigned *>(a.c.y + (size_t)Vb[lane] * nS + 16 * n_pass);
+                    for (int dw = 0; dw < ndw; dw++)
+                        __builtin_amdgcn_global_load_lds(row0 + dw, (__attribute__((address_space(3))) void *)(Ttail + dw * 64), 4, 0, 0);
+                }
+            };
+            // ---- prologue of the unit: every batch's voxel numbers, first tiles
+            for (int b = 0; b < nb; b++) issue_perm(b);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            set_yl(0);
+            const int n_steps = nb * n_pass;
+            for (int gi = 0; gi < D && gi < n_steps; gi++) {
+                if (gi > 0 && gi % n_pass == 0) set_yl(gi / n_pass);        // (more tiles ahead than a batch has: the next batch's rows)
+                issue_tile(gi);
+            }
+            v4d acc[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) acc[mt] = (v4d){0.0, 0.0, 0.0, 0.0};
+            for (int g = 0; g < n_steps; g++) {
+                const int gi = g + D;
+                asm volatile("" ::: "memory");
+                if (gi < n_steps) {
+                    const int bi = gi / n_pass, pi = gi - bi * n_pass;
+                    if (pi == 0) set_yl(bi);                             // a new batch on the issue side
+                    issue_tile(gi);
+                }
+                // tile g has landed when at most the loads of the tiles behind it are outstanding (their extra loads only make the wait longer)
+                {
+                    const int younger = n_steps - 1 - g < D ? n_steps - 1 - g : D;
+#define AMX_FUSE_WAIT(K) case K: if (F32) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * K) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 * K) : "memory"); break;
+                    switch (younger) {
+                        AMX_FUSE_WAIT(7) AMX_FUSE_WAIT(6) AMX_FUSE_WAIT(5) AMX_FUSE_WAIT(4) AMX_FUSE_WAIT(3) AMX_FUSE_WAIT(2) AMX_FUSE_WAIT(1)
+                        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                    }
+#undef AMX_FUSE_WAIT
+                }
+                const int b = g / n_pass, p = g - b * n_pass;
+                const double *tile = tiles + (size_t)(g % TB) * kTile;
+                // the dictionary registers need compile-time indices: the pass number selects its four K-steps
+#pragma unroll
+                for (int pp = 0; pp < kProjKS / 4; pp++) {
+                    if (pp == p) {
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++) {
+                            const int k = 4 * kk + q, s2 = k >> 1, half = k & 1;
+#pragma unroll
+                            for (int mt = 0; mt < 4; mt++) {
+                                const int vloc = mt * 16 + v16;
+                                const double bv = F32 ? (double)reinterpret_cast<const float *>(tile)[vloc * 16 + ((kk ^ ((vloc >> 2) & 3)) << 2) + q]
+                                                      : tile[vloc * 16 + ((s2 ^ ((vloc >> 1) & 7)) << 1) + half];
+                                acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[4 * pp + kk], bv, acc[mt], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+                asm volatile("" ::: "memory");
+                if (p == n_pass - 1) {
+                    // ---- the batch is complete: rows beyond the last full tile (the operand of a row >= nS is zero: a neighbour's value
+                    // in the padding of the K-step must not reach the sum as NaN x 0)
+                    if (n_tail > 0) {
+#pragma unroll
+                        for (int pp = 4; pp <= kProjKS / 4; pp++) {
+                            if (pp == n_pass) {
+#pragma unroll
+                                for (int kk = 0; kk < 4; kk++) {
+                                    if (pp < kProjKS / 4 && 4 * kk < n_tail) {
+                                        const int rt = 4 * kk + q;               // row within the tail
+#pragma unroll
+                                        for (int mt = 0; mt < 4; mt++) {
+                                            const int vloc = mt * 16 + v16;
+                                            double bv = 0.0;
+                                            if (rt < n_tail) {
+                                                if (F32) bv = (double)__builtin_bit_cast(float, Ttail[rt * 64 + vloc]);
+                                                else bv = __hiloint2double((int)Ttail[(2 * rt + 1) * 64 + vloc], (int)Ttail[(2 * rt) * 64 + vloc]);
+                                            }
+                                            acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[(4 * pp + kk) < kProjKS ? 4 * pp + kk : 0], bv, acc[mt], 0, 0, 0);
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    // c = A'y - lambda1; z0 = H^-1 c; passive set after the first block removal -> the batch's ring slot
+                    claim(b);                                                // (the slot's previous batch has been taken: normally long ago)
+                    const int sl = slot_of(b), cnt = min(64, ucnt - 64 * b);
+                    double *Cb = ring + (size_t)sl * kSlotW;
+                    int *Vs = reinterpret_cast<int *>(Cb + 64 * NP);
+                    unsigned *Pb = reinterpret_cast<unsigned *>(Vs + 64);
+                    Vs[lane] = Vu[64 * b + lane];
+#pragma unroll
+                    for (int mt = 0; mt < 4; mt++) {
+                        v4d cf = acc[mt], z = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int r = 0; r < 4; r++) cf[r] = (q + 4 * r < n_atoms) ? cf[r] - a.c.lam1 : 0.0;
+#pragma unroll
+                        for (int ks = 0; ks < 4; ks++) z = __builtin_amdgcn_mfma_f64_16x16x4f64(hi[ks], cf[ks], z, 0, 0, 0);
+                        unsigned m = 0u;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            if (q + 4 * r < n_atoms && z[r] > 0.0) m |= 1u << (q + 4 * r);
+                            if (!(fabs(cf[r]) <= 1.79769313486231570e308)) m |= 0x80000000u;       // non-finite signal
+                        }
+                        m |= __shfl_xor((int)m, 16);
+                        m |= __shfl_xor((int)m, 32);
+                        const int vloc = mt * 16 + v16;
+                        const bool finite = !(m & 0x80000000u);
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            if (q + 4 * r < NP) Cb[vloc * NP + q + 4 * r] = finite ? cf[r] : __builtin_nan("");
+                        if (q == 0) Pb[vloc] = m & 0x7fffffffu;
+                        acc[mt] = (v4d){0.0, 0.0, 0.0, 0.0};
+                    }
+                    if (lane == 0) { sdir[sl] = ck.dir; scnt[sl] = cnt; }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) lds_store(&seq[sl], 2 * (batch_no + b) + 1);
+                }
+            }
+            batch_no += nb;
+        }
+        if (lane == 0) lds_store(total, batch_no);
+        return;
+    }
+
+    // ==================================================================== consumers: the solver of k_freewater_refill
+    const int cw = wave < pw ? wave : wave - 1;
+    double *Hs = Hp + (size_t)cw * kFuseHs * kHW;
+    const double tol = 1e-12;
+    const bool warm0 = amx_warm_start(a.c.lam2, a.c.flags);
+    constexpr int kBackup = 3;
+    bool active = false;
+    int vox = 0, its = 0, ninf = N + 1, backup = 0;
+    unsigned P = 0u;
+    const double *Hl = Hs;
+    double c[N], x[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) { c[j] = 0.0; x[j] = 0.0; }
+    // wave-uniform: the slot being consumed, the one claimed next, the orientations of the H tables
+    int buf_slot = -1, buf_tick = -1, buf_pos = 0, buf_cnt = 0, buf_h = 0;
+    int nxt_slot = -1, nxt_tick = -1, nxt_cnt = 0, nxt_h = 0;
+    int tick = -1;
+    bool fin = false;
+    int hdir[kFuseHs];
+#pragma unroll
+    for (int h = 0; h < kFuseHs; h++) hdir[h] = -1;
+    for (int trip = 0; trip < (1 << 26); ++trip) {
+        // ------------------------------------------------------------ the next batch: ticket, then wait for the producer (without blocking)
+        if (nxt_cnt == 0 && !fin) {
+            if (tick < 0) {
+                int t = 0;
+                if (lane == 0) t = atomicAdd(head, 1);
+                tick = __builtin_amdgcn_readfirstlane(t);
+            }
+            const int sl = tick % R;
+            if (lds_load(&seq[sl]) == 2 * tick + 1) {
+                const int d = __builtin_amdgcn_readfirstlane(sdir[sl]);
+                // an H table for the batch's orientation: one that holds it already, else one no lane works with
+                int hsel = -1;
+#pragma unroll
+                for (int h = 0; h < kFuseHs; h++) if (hsel < 0 && hdir[h] == d) hsel = h;
+                bool need_load = false;
+                if (hsel < 0) {
+#pragma unroll
+                    for (int h = 0; h < kFuseHs; h++) {
+                        const bool busy = __ballot(active && Hl == Hs + h * kHW) != 0ull || (buf_cnt > 0 && buf_h == h);
+                        if (hsel < 0 && !busy) hsel = h;
+                    }
+                    need_load = hsel >= 0;
+                }
+                if (hsel >= 0) {
+                    if (need_load) {
+                        const double *hsrc = a.prep + (size_t)d * fw_prep_words<N>(nS) + (size_t)(nS + N) * NP;
+#pragma unroll
+                        for (int i = 0; i < kHPieces; i++) {
+                            const int hoff = min(i * 128 + lane * 2, (N * N - 1) & ~1);   // (the tail lanes re-read the last piece)
+                            __builtin_amdgcn_global_load_lds(hsrc + hoff, (__attribute__((address_space(3))) void *)(Hs + hsel * kHW + i * 128), 16, 0, 0);
+                        }
+#pragma unroll
+                        for (int h = 0; h < kFuseHs; h++) hdir[h] = (h == hsel) ? d : hdir[h];
+                    }
+                    nxt_slot = sl; nxt_tick = tick; nxt_cnt = __builtin_amdgcn_readfirstlane(scnt[sl]); nxt_h = hsel;
+                    tick = -1;
+                }
+            } else {
+                const int tot = lds_load(total);
+                if (tot >= 0 && tick >= tot) { fin = true; tick = -1; }
+            }
+        }
+        const unsigned long long freem = __ballot(!active);
+        // ------------------------------------------------------------ the buffer ran dry: switch to the batch claimed next
+        if (freem != 0ull && buf_cnt == 0 && nxt_cnt > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (its H table, if one was requested)
+            buf_slot = nxt_slot; buf_tick = nxt_tick; buf_pos = 0; buf_cnt = nxt_cnt; buf_h = nxt_h; nxt_cnt = 0;
+        }
+        // ------------------------------------------------------------ free lanes take the next voxels of the batch
+        if (freem != 0ull && buf_cnt > 0) {
+            const double *Cb = ring + (size_t)buf_slot * kSlotW;
+            const int *Vb = reinterpret_cast<const int *>(Cb + 64 * NP);
+            const unsigned *Pb = reinterpret_cast<const unsigned *>(Vb + 64);
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(freem >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)freem, 0u));
+            const bool take = !active && rank < buf_cnt;
+            const int e = take ? buf_pos + rank : 0;
+            const int nv = Vb[e];
+            const unsigned np0 = Pb[e];
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                const double cj = Cb[e * NP + j];
+                c[j] = take ? cj : c[j];
+            }
+            if (take) { active = true; vox = nv; P = warm0 ? np0 : 0u; its = warm0 ? 1 : 0; ninf = N + 1; backup = 0; Hl = Hs + buf_h * kHW; }
+            const int taken = min(__builtin_popcountll(freem), buf_cnt);
+            buf_pos += taken; buf_cnt -= taken;
+            if (buf_cnt == 0) {
+                // every voxel of the batch is in a lane's registers: the slot goes back to the producer
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) lds_store(&seq[buf_slot], 2 * buf_tick + 2);
+            }
+        }
+        if (__ballot(active) == 0ull) {
+            if (fin && buf_cnt == 0 && nxt_cnt == 0) break;
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+        }
+        // ------------------------------------------------------------ one pivoting step per lane (block principal pivoting: see k_freewater_refill)
+        bool done = false;
+        if (active && !(c[0] == c[0])) done = true;             // non-finite signal: NaN maps, never iterate
+        const bool slv = active && !done;
+        {
+            lane_solve<N>(Hl, c, P, x);
+            AMX_RELOAD();
+            unsigned v1 = 0u, v2 = 0u;
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                double g = c[j];
+#pragma unroll
+                for (int k = 0; k < N; k++) g -= Hl[j * N + k] * x[k];
+                const bool pj = (P >> j) & 1u;
+                if (pj && !(x[j] > 0.0)) v1 |= 1u << j;
+                if (!pj && j < n_atoms && g > tol) v2 |= 1u << j;
+            }
+            if (slv) {
+                const unsigned bad = v1 | v2;
+                const int nbad = __builtin_popcount(bad);
+                if (bad == 0u || its > 4 * N + 16) {
+                    done = true;
+                } else {
+                    bool block = false;
+                    if (nbad < ninf) { ninf = nbad; backup = warm0 ? kBackup : 0; block = warm0; }
+                    else if (backup > 0) { backup--; block = true; }
+                    const unsigned ex = block ? bad : (1u << (31 - __builtin_clz(bad)));
+                    P ^= ex;
+                    its++;
+                }
+            }
+        }
+        // ------------------------------------------------------------ finished voxels: maps (models.pyx:1241-1256)
+        if (__ballot(done) != 0ull) {
+            if (done) {
+                double *e = a.est + (size_t)vox * a.n_maps;
+                if (!(c[0] == c[0])) {
+                    const double nan = __builtin_nan("");
+                    for (int m = 0; m < a.n_maps; m++) e[m] = nan;
+                } else {
+                    if (its > 4 * N + 16) {
+                        atomicAdd(&a.c.status[ST_ITCAP], 1);
+#pragma unroll
+                        for (int j = 0; j < N; j++) x[j] = (x[j] > 0.0) ? x[j] : 0.0;
+                    }
+                    if (a.c.xdbg) {
+#pragma unroll
+                        for (int j = 0; j < N; j++) if (j < n_atoms) a.c.xdbg[(size_t)vox * n_atoms + j] = x[j];
+                    }
+                    double x_sum = 0.0, x_perp = 0.0;
+#pragma unroll
+                    for (int j = 0; j < N; j++) { x_sum += x[j]; if (j < n_perp) x_perp += x[j]; }
+                    x_sum += 1e-16;
+                    const double vv = x_perp / x_sum;
+                    e[0] = vv; e[1] = 1.0 - vv;
+                    if (a.is_mouse) {
+                        double xb = 0.0, xc = 0.0;
+#pragma unroll
+                        for (int j = 0; j < N; j++) { if (j == n_perp) xb = x[j]; if (j == n_perp + 1) xc = x[j]; }
+                        e[2] = xb / x_sum; e[3] = xc / x_sum;
+                    }
+                }
+                active = false;
+            }
+        }
+    }
+}
+
 static size_t refill_lds_bytes(int N, int nw) { return (size_t)nw * (2 * (128 * ((N * N + 127) / 128) + 2) + 2 + 2 * (64 * ((N + 1) & ~1) + 64)) * sizeof(double); }
 static size_t project_lds_bytes(int nS, int N, int nw)
 {
@@ -1191,9 +1622,24 @@ int launch_lane(amx_ctx *ctx, Args &a, const Plan &pl, hipStream_t s, K kern, si
 }  // namespace
 
 typedef void (*FwKernel)(const FwArgs);
-static int launch_refill(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s, FwKernel proj, FwKernel pmfma, FwKernel pmfma32, FwKernel kern, int N)
+static int launch_refill(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s, FwKernel proj, FwKernel pmfma, FwKernel pmfma32, FwKernel kern, int N,
+                         FwKernel fused, FwKernel fused32, size_t fused_lds)
 {
     int rc;
+    // one kernel (k_freewater_fused) when the protocol fits its pipeline: four or more full tiles of 16 values per voxel, dictionary
+    // operand in registers (AMX_FW_NO_FUSE=1: the projection + solver pair, for A/B)
+    if (a.c.nS >= 64 && a.c.nS <= 4 * kProjKS && !ctx->opt_fw_proj_valu && !ctx->opt_fw_no_fuse) {
+        FwKernel k = a.c.y32 != nullptr ? fused32 : fused;
+        if ((rc = set_lds(ctx, k, fused_lds))) return rc;
+        a.queue = pl.n_chunks + 60;                            // (misc word 60: zeroed with the plan counters)
+        a.sub_per_chunk = (amx_refill_chunk(ctx, (long long)pl.n) + kFuseSub - 1) / kFuseSub;
+        rec(ctx, 2, s);
+        hipLaunchKernelGGL(k, dim3(2 * ctx->n_cu), dim3(64 * (kFuseConsumers + 1)), fused_lds, s, a);
+        AMX_TRACE(ctx, s, "FreeWater: projection (producer wavefront) + lane-per-voxel solver (consumers), one kernel");
+        rec(ctx, 3, s);
+        HIPCHK(ctx, hipGetLastError());
+        return AMX_OK;
+    }
     // workspace of the projection: c [ldC][NP], p0 [ldC]
     a.ldC = (int)((pl.n + 63) & ~(size_t)63);
     const size_t cbytes = (size_t)((N + 1) & ~1) * a.ldC * sizeof(double);
@@ -1257,8 +1703,10 @@ int amx_launch_fw_small(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s)
     // compile-time dictionary sizes: the reference's defaults (11 Human, 12 Mouse) exactly, 16 otherwise
     const int n = a.c.n_atoms;
     if (amx_fw_use_refill(ctx, n, a.c.nS, a.c.flags, a.c.lam2)) {
-        if (n <= 11) return launch_refill(ctx, a, pl, s, k_fw_project<11>, k_fw_project_mfma<11, false>, k_fw_project_mfma<11, true>, k_freewater_refill<11>, 11);
-        return launch_refill(ctx, a, pl, s, k_fw_project<12>, k_fw_project_mfma<12, false>, k_fw_project_mfma<12, true>, k_freewater_refill<12>, 12);
+        if (n <= 11) return launch_refill(ctx, a, pl, s, k_fw_project<11>, k_fw_project_mfma<11, false>, k_fw_project_mfma<11, true>, k_freewater_refill<11>, 11,
+                                          k_freewater_fused<11, false>, k_freewater_fused<11, true>, fuse_lds_bytes<11>(a.c.nS & 15));
+        return launch_refill(ctx, a, pl, s, k_fw_project<12>, k_fw_project_mfma<12, false>, k_fw_project_mfma<12, true>, k_freewater_refill<12>, 12,
+                             k_freewater_fused<12, false>, k_freewater_fused<12, true>, fuse_lds_bytes<12>(a.c.nS & 15));
     }
     if (n <= 11) return launch_lane(ctx, a, pl, s, k_freewater_lane<11>, sizeof(float), 11);
     if (n == 12) return launch_lane(ctx, a, pl, s, k_freewater_lane<12>, sizeof(float), 12);

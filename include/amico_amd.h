@@ -58,7 +58,11 @@ const char *amx_last_error(amx_ctx *ctx);
 
 /* NODDI.  KERNELS['wm'] f32[n_wm][ndirs][nS], ['iso'] f32[nS], ['norms'] f64[dwi][n_wm]
  * (rows identical, models.pyx:781-784), ['icvf'],['kappa'] f32[n_wm] (models.pyx:763-789);
- * htable int16[181*181] (lut.pyx:71-91); dwi_idx = scheme.dwi_idx int64[dwi_count].       */
+ * htable int16[181*181] (lut.pyx:71-91); dwi_idx = scheme.dwi_idx int64[dwi_count].
+ * Any shape the reference's loop takes (models.pyx:825-861) up to nS <= 512 volumes and n_wm + 1 (+ 1) <= 256 atoms.  The seeded
+ * chain (seed solvers -> Gram-space certificates) covers every protocol of that range with <= 160 atoms; a dictionary tile that does
+ * not fit a compute unit's LDS (288 volumes x 145 atoms float32 = 167 KB: an HCP-style acquisition) is read from HBM / L2 by the
+ * wavefront-per-voxel kernels instead -- slower for the few per cent of voxels that reach them, same results.                      */
 int amx_lut_upload_noddi(amx_ctx *ctx, const float *wm, const float *iso, const double *norms,
                          const float *icvf, const float *kappa, const int16_t *htable,
                          const int64_t *dwi_idx, int n_wm, int ndirs, int nS, int dwi_count,
