@@ -403,7 +403,7 @@ int amx_lut_upload_freewater(amx_ctx *ctx, const float *D, const float *CSF, con
     if (!D || !CSF || !htable || !out || n_perp <= 0 || n_iso <= 0 || ndirs <= 0 || nS <= 0)
         return bad(ctx, "amx_lut_upload_freewater: bad argument");
     const int n_atoms = n_perp + n_iso;
-    if (n_atoms > 64 || nS > 256) return bad(ctx, "amx_lut_upload_freewater: unsupported size (n_atoms <= 64, nS <= 256)");
+    if (n_atoms > 64 || nS > 512) return bad(ctx, "amx_lut_upload_freewater: unsupported size (n_atoms <= 64, nS <= 512)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     amx_lut *lut = new amx_lut();
     lut->ctx = ctx; lut->model = 2; lut->nS = nS; lut->n_atoms = n_atoms; lut->ndirs = ndirs;
@@ -454,7 +454,7 @@ int amx_lut_upload_czb(amx_ctx *ctx, const float *wmr, const float *wmh, const f
     if (!wmr || !wmh || !iso || !Rs || !htable || !out || n_rs <= 0 || n_perp <= 0 || n_iso <= 0 || ndirs <= 0 || nS <= 0)
         return bad(ctx, "amx_lut_upload_czb: bad argument");
     const int n_atoms = n_rs + n_perp + n_iso;
-    if (n_atoms > 64 || nS > 256) return bad(ctx, "amx_lut_upload_czb: unsupported size (n_atoms <= 64, nS <= 256)");
+    if (n_atoms > 64 || nS > 512) return bad(ctx, "amx_lut_upload_czb: unsupported size (n_atoms <= 64, nS <= 512)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     amx_lut *lut = new amx_lut();
     lut->ctx = ctx; lut->model = 4; lut->nS = nS; lut->n_atoms = n_atoms; lut->ndirs = ndirs;

@@ -14,5 +14,6 @@ static int go(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s)
 int amx_launch_fw(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s)
 {
     if (amx_use_lane_solver(ctx, a.c.n_atoms, a.c.lam2)) return amx_launch_fw_small(ctx, a, pl, s);
-    return a.c.nS <= 128 ? go<2>(ctx, a, pl, s) : go<4>(ctx, a, pl, s);
+    // (8 rows per lane: protocols of up to 512 volumes -- the <= 64-atom tile still fits the LDS)
+    return a.c.nS <= 128 ? go<2>(ctx, a, pl, s) : (a.c.nS <= 256 ? go<4>(ctx, a, pl, s) : go<8>(ctx, a, pl, s));
 }

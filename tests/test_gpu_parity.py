@@ -343,13 +343,18 @@ def test_other_protocol_shapes(htable500, seed_path, amx_env):
     assert np.abs(out3['estimates'] - ref3['estimates']).max() < TOL
     # (d) FreeWater protocol lengths around the tiling of the projection kernel: 16 values per LDS tile (17 = one tile + a
     #     remainder row, 64 = whole tiles only, 81 = five tiles + one), 97 and 130 > 96 volumes (VALU projection / lane kernel)
-    for nd in (16, 63, 80, 96, 129):
+    #     299 + 1 volumes: beyond 256 (8 signal rows per lane in the wavefront-per-voxel kernel, which the second pass forces)
+    for nd in (16, 63, 80, 96, 129, 299):
         schd = S.make_scheme(1, ((1000.0, nd),), seed=nd)
         Kd = S.freewater_kernels(schd, dirs)
         yd, dd = S.freewater_signals(900, Kd, ht, schd, seed=nd + 1)
         outd = FreeWater().fit(Holder(yd, dd, ht, Kd))
         refd = oracle.freewater_fit(yd, dd, Kd, ht, nthreads=8)
         assert np.abs(outd['estimates'] - refd['estimates']).max() < TOL, nd
+        if nd == 299:
+            amx_env(AMX_WAVE_PER_VOXEL='1', **({'AMX_SEED_MIN_VOXELS': '0'} if seed_path == 'seeded' else {}))
+            outw = FreeWater().fit(Holder(yd, dd, ht, Kd))
+            assert np.abs(outw['estimates'] - refd['estimates']).max() < TOL, 'wavefront per voxel, 300 volumes'
 
 
 def test_small_models_both_mappings(fw_fix, sandi_fix, htable500, amx_env):
