@@ -183,19 +183,14 @@ __global__ void __launch_bounds__(512) k_czb_project(const CzbFastArgs a)
     }
 }
 
-// (round 5: TWO wavefronts per SIMD -- the coefficients overwrite the lane's z0 column when its voxel is done (nothing reads z0 after
-//  that), and the column block holds n_atoms rows instead of 32: 13 KB per wavefront instead of 32, two workgroups per CU)
-#ifndef AMX_CZB_OCC
-#define AMX_CZB_OCC 2
-#endif
-__global__ void __launch_bounds__(256, AMX_CZB_OCC) k_czb_lane(const CzbFastArgs a)
+__global__ void __launch_bounds__(256, 1) k_czb_lane(const CzbFastArgs a)
 {
     constexpr int N = kCzbN, ZM = kCzbZ, LD = kCzbLd, NT = ZM * (ZM + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_l[];
     double *Ml = reinterpret_cast<double *>(smem_l);                      // [32][33] M = H^-1
     double *Hl = Ml + N * LD;                                             // [32][33] H
-    double *zt = Hl + N * LD + 2 + (threadIdx.x >> 6) * (a.n_atoms * 64);  // this wavefront's block: z0 [n_atoms][64], later x; a lane touches its own column only
-    double *xt = zt;
+    double *zt = Hl + N * LD + 2 + (threadIdx.x >> 6) * (2 * N * 64);     // this wavefront's block: z0 [32][64] | x [32][64]; a lane touches its own column only
+    double *xt = zt + N * 64;
     const int cid = xcd_chunk((int)blockIdx.x, *a.n_schunks);
     if (cid < 0) return;
     const Chunk ck = a.schunks[cid];
@@ -205,7 +200,6 @@ __global__ void __launch_bounds__(256, AMX_CZB_OCC) k_czb_lane(const CzbFastArgs
     for (int e = threadIdx.x; e < 2 * N * LD; e += blockDim.x) Ml[e] = T[e];
     __syncthreads();
     const int n_atoms = a.n_atoms;
-    const int n_atoms_u = __builtin_amdgcn_readfirstlane(n_atoms);
     const unsigned valid_atoms = n_atoms >= 32 ? ~0u : ((1u << n_atoms) - 1u);
     constexpr int kBackup = 3;
     const int n_blocks = (ck.count + 63) >> 6;
@@ -215,12 +209,12 @@ __global__ void __launch_bounds__(256, AMX_CZB_OCC) k_czb_lane(const CzbFastArgs
         const int vox = a.perm[ck.start + (valid ? k : ck.count - 1)];
         const double *src = a.Zb + (size_t)(ck.pad + bl) * 2 * N * 64 + lane;
 #pragma unroll
-        for (int j = 0; j < N; j++) if (j < n_atoms_u) zt[j * 64 + lane] = src[(size_t)j * 64];
+        for (int j = 0; j < N; j++) zt[j * 64 + lane] = src[(size_t)j * 64];
         unsigned Z = 0u;
         bool finite = true;
 #pragma unroll
         for (int j = 0; j < N; j++) {
-            const double z = (j < n_atoms_u) ? zt[j * 64 + lane] : 0.0;
+            const double z = zt[j * 64 + lane];
             finite = finite && (fabs(z) <= 1.79769313486231570e308);
             if (!(z > 0.0)) Z |= 1u << j;
         }
@@ -294,7 +288,7 @@ __global__ void __launch_bounds__(256, AMX_CZB_OCC) k_czb_lane(const CzbFastArgs
             //   else : base = -c, acc = the gradient H x - c on the clamped atoms, x on P is sol itself
             double acc[N];
 #pragma unroll
-            for (int j = 0; j < N; j++) acc[j] = zform ? ((j < n_atoms_u) ? zt[j * 64 + lane] : 0.0) : -cz[(size_t)j * 64];
+            for (int j = 0; j < N; j++) acc[j] = zform ? zt[j * 64 + lane] : -cz[(size_t)j * 64];
 #pragma unroll
             for (int s = 0; s < ZM; s++) {
                 if (__ballot(s < ns) == 0ull) break;
@@ -323,7 +317,7 @@ __global__ void __launch_bounds__(256, AMX_CZB_OCC) k_czb_lane(const CzbFastArgs
                     if (bad != 0u) overflow = true;      // no optimum within the cap: the wavefront-per-voxel solver takes the voxel (overflow list), nothing approximate is emitted
                     // the coefficients, in the lane's column of the LDS block (a clamped or infeasible iterate never reaches the maps negative)
 #pragma unroll
-                    for (int j = 0; j < N; j++) if (j < n_atoms_u) xt[j * 64 + lane] = (zform && !((Z >> j) & 1u) && acc[j] > 0.0) ? acc[j] : 0.0;
+                    for (int j = 0; j < N; j++) xt[j * 64 + lane] = (zform && !((Z >> j) & 1u) && acc[j] > 0.0) ? acc[j] : 0.0;
                     if (!zform) {
 #pragma unroll
                         for (int s = 0; s < ZM; s++) if (s < ns && sol[s] > 0.0) xt[si[s] * 64 + lane] = sol[s];
@@ -350,7 +344,7 @@ __global__ void __launch_bounds__(256, AMX_CZB_OCC) k_czb_lane(const CzbFastArgs
                 double f1 = 0.0, f2 = 0.0, am = 0.0;
 #pragma unroll
                 for (int j = 0; j < N; j++) {
-                    const double xj = (j < n_atoms_u) ? xt[j * 64 + lane] : 0.0;
+                    const double xj = xt[j * 64 + lane];
                     if (j < a.n_rs) { f1 += xj; am += a.Rs[j] * xj; }
                     else if (j < a.n_rs + a.n_perp) f2 += xj;
                     if (a.xdbg && j < n_atoms) a.xdbg[(size_t)vox * n_atoms + j] = xj;
@@ -408,7 +402,7 @@ int amx_launch_czb_fast(amx_ctx *ctx, const amx_lut *lut, CzbArgs &a, const Plan
         hipLaunchKernelGGL(k_czb_project<40>, grid, dim3(512), lds, s, f);
     }
     AMX_TRACE(ctx, s, "z0 = M A'y on the matrix cores");
-    const size_t lds2 = ((size_t)2 * kCzbN * kCzbLd + 2 + (size_t)4 * lut->n_atoms * 64) * sizeof(double);
+    const size_t lds2 = ((size_t)2 * kCzbN * kCzbLd + 2 + (size_t)4 * 2 * kCzbN * 64) * sizeof(double);
     if ((rc = set_lds(ctx, k_czb_lane, lds2))) return rc;
     hipLaunchKernelGGL(k_czb_lane, grid, dim3(256), lds2, s, f);
     AMX_TRACE(ctx, s, "complementary-form pivoting, one voxel per lane");
@@ -421,7 +415,7 @@ int amx_launch_czb_fast(amx_ctx *ctx, const amx_lut *lut, CzbArgs &a, const Plan
         if (a.c.nS <= 128) {
             if ((rc = set_lds(ctx, (k_czb<2, 1, 64, 1, true>), lds_list))) return rc;
             hipLaunchKernelGGL((k_czb<2, 1, 64, 1, true>), dim3(kListGrid), dim3(64), lds_list, s, b);
-        } else {      // (the fast path holds nS <= 160)
+        } else {
             const size_t l4 = fit_lds_bytes<float>(a.c.nS, a.c.ldA, 4, 1, 1, 64, true);
             if ((rc = set_lds(ctx, (k_czb<4, 1, 64, 1, true>), l4))) return rc;
             hipLaunchKernelGGL((k_czb<4, 1, 64, 1, true>), dim3(kListGrid), dim3(64), l4, s, b);
