@@ -36,6 +36,30 @@ def test_noddi_one_million_voxels_against_the_oracle(htable500):
     assert st['itercap_voxels'] == 0 and st['overflow_voxels'] == 0 and st['guard_trips'] == 0
 
 
+def test_noddi_host_and_device_entry_points_agree_above_the_rescue_threshold(htable500):
+    """2.2 M voxels -- above AMX_RESCUE_FROM (2 M), where the NNLS certificates run their rescue pass: the host-buffer entry point
+    (batches of <= 393 216 voxels, pipelined) must take the path the WHOLE call's size asks for, so that it settles every voxel with
+    the arithmetic of the one-shot device call (the rescue gate looked at the batch's size)"""
+    import torch
+    from amico_amd import _capi, get_context, synthetic as S
+    n = 2_200_000
+    dirs, ht = htable500['dirs'], htable500['htable']
+    sch = S.make_scheme(seed=0)
+    K = S.noddi_kernels(sch, dirs)
+    y, d = S.noddi_signals_parallel(n, K, ht, sch, seed=11)
+    ctx = get_context()
+    lut = _capi.upload_noddi(ctx, K, ht, sch.dwi_idx)
+    dev = torch.device('cuda', 0)
+    yd = torch.from_numpy(y).to(dev); dd = torch.from_numpy(d).to(dev)
+    est_dev = _capi.noddi_fit_device(ctx, lut, yd, dd, 0.5, 1e-3, 3)[0]
+    ctx.sync()
+    got_dev = est_dev.cpu().numpy()
+    del yd, dd, est_dev
+    torch.cuda.empty_cache()
+    got_host = _capi.noddi_fit(ctx, lut, y, d, 0.5, 1e-3, 3)[0]
+    assert np.array_equal(got_host, got_dev), np.abs(got_host - got_dev).max()
+
+
 def test_noddi_eight_million_voxels_in_one_call(htable500):
     """BASELINE config 5's node total (8 M voxels: 6.3 GB of signals, ~23 GB of workspace) fitted by ONE call on one GPU -- the
     size no 8-GPU node was available for; every 400th voxel against the oracle, no iteration cap, no overflow, and the stage

@@ -1,0 +1,4 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_gpu_fullsize.py -m gpu -x -q -k "host_and_device" 2>&1 | tail -5
