@@ -289,6 +289,12 @@ __global__ __launch_bounds__(256) void k_prep_stream4(PrepArgs a)
                 f[u] = (mm[u] <= a.thr) ? 0.0f : 1.0f / mm[u];
             }
         }
+        // (round 5) few outputs per voxel -- the shell means of a direction-averaged acquisition: 6 -- wait in registers and leave as ONE
+        // run of stores per voxel: written one group at a time, 8 bytes per voxel every ~50 volumes, they cost 4.8 x their bytes in HBM
+        // writes (WRITE_SIZE 264 MB against 55 MB for 1.16 M voxels: every store a partial sector of its own)
+        constexpr int kHold = 8;
+        const bool hold = a.n_out <= kHold;
+        float held[kHold][4];
         for (int j = 0; j < a.n_out; j++) {
             const int g0 = Pgp[j], g1 = Pgp[j + 1];
             float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -320,9 +326,26 @@ __global__ __launch_bounds__(256) void k_prep_stream4(PrepArgs a)
                 float v = acc[u];
                 if (g1 - g0 > 1) v = v / (float)(g1 - g0);
                 v = v < 0.0f ? 0.0f : v;
-                if (r[u] >= 0) {
+                if (hold) {
+#pragma unroll
+                    for (int jj = 0; jj < kHold; jj++) held[jj][u] = (jj == j) ? v : held[jj][u];
+                } else if (r[u] >= 0) {
                     if (a.y32) a.y32[(long long)r[u] * a.n_out + j] = v;
                     else a.y[(long long)r[u] * a.n_out + j] = (double)v;
+                }
+            }
+        }
+        if (hold) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (r[u] >= 0) {
+#pragma unroll
+                    for (int jj = 0; jj < kHold; jj++) {
+                        if (jj < a.n_out) {
+                            if (a.y32) a.y32[(long long)r[u] * a.n_out + jj] = held[jj][u];
+                            else a.y[(long long)r[u] * a.n_out + jj] = (double)held[jj][u];
+                        }
+                    }
                 }
             }
         }
