@@ -32,6 +32,68 @@ constexpr int kSeed3ListRow = 36;      // bytes per lane of the stage-3 candidat
 // one column of S for THIS lane from the LDS copy (row stride kSeedLd doubles = 112 bytes: 16-byte aligned rows): 16-byte reads --
 // the per-lane gathers are bound by the NUMBER of LDS instructions (a float32 copy with half the bytes changed nothing, reads of
 // twice the width took 9 % off the stage-3 seed solver)
+// A chunk's tables global -> LDS with UB elements of a thread in flight together.  (As `dst[e] = src[e]` in a plain loop the compiler
+// keeps ONE load per thread in flight -- it may not hoist a load over the guard of its iteration --, so staging a chunk was a chain
+// of 7 + 8 memory round trips: ~13 us per workgroup and chunk, all of it exposed in small calls and in the table GEMM, whose one
+// workgroup per CU multiplies nothing meanwhile.  Here the loads are unconditional at clamped indices and the guards sit on the stores.)
+#ifndef AMX_STAGE_UBN
+#define AMX_STAGE_UBN 2
+#endif
+#ifndef AMX_STAGE_UB
+#define AMX_STAGE_UB 4
+#endif
+template <int KD, int LD, int UB = AMX_STAGE_UB>
+__device__ __forceinline__ void stage_rows(double *Sl, const double *__restrict__ Sg, int n, int src_ld)
+{
+    const int N = n * KD;
+    for (int e0 = threadIdx.x; e0 < N; e0 += UB * (int)blockDim.x) {
+        double v[UB];
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            const int e = e0 + u * (int)blockDim.x, ec = e < N ? e : 0, j = ec / KD, d = ec - j * KD;
+            v[u] = Sg[(size_t)j * src_ld + d];
+        }
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            const int e = e0 + u * (int)blockDim.x, j = e / KD, d = e - j * KD;
+            if (e < N) Sl[j * LD + d] = v[u];
+        }
+    }
+}
+// the same rows in MFMA operand order: Aop[(mt KS + ks) 64 + l] = S[16 mt + (l & 15)][4 ks + (l >> 4)], 0 beyond n rows;
+// NORM: every row scaled to unit length (k_nnls_seed stage 1)
+template <int KS, int MT, bool NORM = false, int UB = AMX_STAGE_UB>
+__device__ __forceinline__ void stage_operand(double *Aop, const double *__restrict__ Sg, int n, int src_ld)
+{
+    constexpr int KD = 4 * KS, N = MT * KS * 64;
+    for (int e0 = threadIdx.x; e0 < N; e0 += UB * (int)blockDim.x) {
+        double v[UB], n2[UB];
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            const int e = e0 + u * (int)blockDim.x, ec = e < N ? e : 0;
+            const int l = ec & 63, ks = (ec >> 6) % KS, mt = (ec >> 6) / KS;
+            const int atom = 16 * mt + (l & 15), d = 4 * ks + (l >> 4);
+            const double *row = Sg + (size_t)(atom < n ? atom : 0) * src_ld;
+            v[u] = row[d];
+            n2[u] = 1.0;
+            if (NORM) {
+                double t2 = 0.0;
+#pragma unroll
+                for (int dd = 0; dd < KD; dd++) { const double t = row[dd]; t2 += t * t; }
+                n2[u] = t2;
+            }
+            v[u] = atom < n ? v[u] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            const int e = e0 + u * (int)blockDim.x;
+            double w = v[u];
+            if (NORM) w = n2[u] > 0.0 ? w * inv_sqrt(n2[u]) : 0.0;
+            if (e < N) Aop[e] = w;
+        }
+    }
+}
+
 template <int KD>
 __device__ __forceinline__ void seed_col(const double *col, double (&cv)[KD])
 {
@@ -609,7 +671,7 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
     if (cid < 0) break;
     const Chunk ck = a.schunks[cid];
     const double *__restrict__ Sg = a.Sb + (size_t)ck.dir * n_atoms * KD;
-    for (int e = threadIdx.x; e < n_atoms * KD; e += blockDim.x) { const int j = e / KD, d = e - j * KD; Sl[j * LD + d] = Sg[e]; }
+    stage_rows<KD, LD>(Sl, Sg, n_atoms, KD);
     if (STAGE == 1) {
         // The scan's operand holds the atoms NORMALISED (s_j / ||s_j||): the entering atom is then the one whose direction fits the
         // residual best, not the one with the largest dual value -- Lawson-Hanson may admit any atom with a positive dual value, and
@@ -618,21 +680,7 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
 #ifndef AMX_SEED_SCAN_NORM
 #define AMX_SEED_SCAN_NORM 1
 #endif
-        for (int e = threadIdx.x; e < MT * KS * 64; e += blockDim.x) {
-            const int l = e & 63, ks = (e >> 6) % KS, mt = (e >> 6) / KS;
-            const int atom = 16 * mt + (l & 15), d = 4 * ks + (l >> 4);
-            double v = 0.0;
-            if (atom < n_atoms) {
-                v = Sg[(size_t)atom * KD + d];
-                if (AMX_SEED_SCAN_NORM) {
-                    double n2 = 0.0;
-#pragma unroll
-                    for (int dd = 0; dd < KD; dd++) { const double t = Sg[(size_t)atom * KD + dd]; n2 += t * t; }
-                    v = n2 > 0.0 ? v * inv_sqrt(n2) : 0.0;
-                }
-            }
-            Aop[e] = v;
-        }
+        stage_operand<KS, MT, AMX_SEED_SCAN_NORM != 0, AMX_STAGE_UBN>(Aop, Sg, n_atoms, KD);
     }
     __syncthreads();
 #ifndef AMX_SEED_ISO_FIRST
@@ -706,10 +754,13 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
             const int k = feed.take(freem, a.gcount + cid, ck.count, lane);
             if (k >= 0) {
                 pos = ck.start + k;
-                const double *yp = a.ytil + (size_t)pos * KD;
-                bool finite = true;
-#pragma unroll
-                for (int d = 0; d < KD; d++) finite = finite && (fabs(yp[d]) <= 1.79769313486231570e308);
+                // (no look at the voxel's y~ here: `finite = finite && |y~_d| <= max` over a pointer compiles to KD loads that each
+                //  wait for the one before -- a chain of 12 memory round trips in nearly every trip of the wavefront, the "taking
+                //  voxels" fifth of this kernel.  A non-finite y~ needs no test of its own: NaN dual values never beat -inf (v_max_f64
+                //  drops them, an index in the mantissa of an infinity is a NaN as well), so the voxel is done in its first trip or at
+                //  the trip cap at the latest, and the certificate refuses it on ||y||^2 whatever seed it got: the wavefront-per-voxel
+                //  kernel writes its NaN maps)
+                const bool finite = true;
                 trips = 0; last_added = -1; ban0 = -1; ban1 = -1;
                 V.clear();
                 if (STAGE == 3) {
@@ -1074,10 +1125,18 @@ __global__ void __launch_bounds__(512) k_noddi_gemm(const GemmArgs a)
     const int q = lane >> 4, c16 = lane & 15;
     const int k0 = WIN ? a.k0 : 0, k1 = WIN ? a.k1 : nS;    // this launch's window of samples (GemmArgs)
     unsigned long long maskE = 0ull, maskD = 0ull;      // bit ks: sample k0 + 4 ks + q exists / is a stage-2 row
+    {
+        // (unconditional loads at clamped rows: as `if (row < k1) ... rowdwi[row]` the KS byte loads each sat in a branch of their own,
+        //  25 memory round trips one after the other before a workgroup's first product)
+        unsigned char dw[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ks++) {
-        const int row = k0 + 4 * ks + q;
-        if (row < k1) { maskE |= 1ull << ks; if (a.rowdwi[row] != 0) maskD |= 1ull << ks; }
+        for (int ks = 0; ks < KS; ks++) { const int row = k0 + 4 * ks + q; dw[ks] = a.rowdwi[row < k1 ? row : k0]; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const int row = k0 + 4 * ks + q;
+            maskE |= (row < k1) ? (1ull << ks) : 0ull;
+            maskD |= (row < k1 && dw[ks] != 0) ? (1ull << ks) : 0ull;
+        }
     }
     const unsigned long long rowmask = LASSO ? maskD : maskE;
     // every voxel's table: the workgroup's own chunk, then the largest chunks still open, groups of 16 voxels per wavefront (BlockFeed);
@@ -1091,22 +1150,51 @@ __global__ void __launch_bounds__(512) k_noddi_gemm(const GemmArgs a)
     const float *tile = a.tiles + (size_t)ck.dir * a.tile_stride;
     const double *U = a.Ub + (size_t)ck.dir * nS * kSeedKD;
     const double *U2 = (!LASSO && a.U2b) ? a.U2b + (size_t)ck.dir * nS * kSeedKD : nullptr;
-    for (int e = threadIdx.x; e < MTf * KS * 64; e += blockDim.x) {
-        const int l = e & 63, ks = (e >> 6) % KS, mt = (e >> 6) / KS;
-        const int atom = 16 * mt + (l & 15), row = k0 + 4 * ks + (l >> 4);
-        A32[e] = (row < k1) ? tile[row * ldA + atom] : 0.0f;
-    }
-    for (int e = threadIdx.x; e < (MT - MTf) * KS * 64; e += blockDim.x) {
-        const int l = e & 63, ks = (e >> 6) % KS, mt = MTf + (e >> 6) / KS;
-        const int r = 16 * mt + (l & 15), row = k0 + 4 * ks + (l >> 4);
-        double v = 0.0;
-        if (row < k1) {
-            if (r < n_cols) v = (double)tile[row * ldA + r];
-            else if (r >= aux0 + kAuxU && r < aux0 + kAuxU + kSeedKD) v = U[row * kSeedKD + (r - aux0 - kAuxU)];
-            else if (U2 != nullptr && r >= aux0 + kAuxU2 && r < aux0 + kAuxU2 + kSeedKD) v = U2[row * kSeedKD + (r - aux0 - kAuxU2)];
-            else if (!LASSO && r == aux0 + kAuxB0) v = a.rowdwi[row] ? 0.0 : 1.0;
+    // The operands of a chunk, SG elements of a thread in flight together (as `A32[e] = tile[..]` in a plain loop every element waited
+    // for the one before: ~28 + 7 memory round trips per chunk during which the CU's one workgroup multiplies nothing)
+    constexpr int SG = 8;
+    for (int e0 = threadIdx.x; e0 < MTf * KS * 64; e0 += SG * blockDim.x) {
+        float v[SG];
+#pragma unroll
+        for (int u = 0; u < SG; u++) {
+            const int e = e0 + u * (int)blockDim.x;
+            const int l = e & 63, ks = (e >> 6) % KS, mt = (e >> 6) / KS;
+            const int atom = 16 * mt + (l & 15), row = k0 + 4 * ks + (l >> 4);
+            const bool in = e < MTf * KS * 64 && row < k1;
+            v[u] = tile[in ? row * ldA + atom : 0];
+            v[u] = in ? v[u] : 0.0f;
         }
-        A64[e] = v;
+#pragma unroll
+        for (int u = 0; u < SG; u++) { const int e = e0 + u * (int)blockDim.x; if (e < MTf * KS * 64) A32[e] = v[u]; }
+    }
+    for (int e0 = threadIdx.x; e0 < (MT - MTf) * KS * 64; e0 += SG * blockDim.x) {
+        // one load per element whatever its kind: 0 atom (float32), 1 basis (fp64), 2 b0 indicator (byte), 3 zero
+        float vf[SG]; double vd[SG]; unsigned char vb[SG]; int kind[SG];
+#pragma unroll
+        for (int u = 0; u < SG; u++) {
+            const int e = e0 + u * (int)blockDim.x;
+            const int l = e & 63, ks = (e >> 6) % KS, mt = MTf + (e >> 6) / KS;
+            const int r = 16 * mt + (l & 15), row = k0 + 4 * ks + (l >> 4);
+            int kd = 3;
+            const double *pd = U;
+            int od = 0, of = 0;
+            if (e < (MT - MTf) * KS * 64 && row < k1) {
+                if (r < n_cols) { kd = 0; of = row * ldA + r; }
+                else if (r >= aux0 + kAuxU && r < aux0 + kAuxU + kSeedKD) { kd = 1; od = row * kSeedKD + (r - aux0 - kAuxU); }
+                else if (U2 != nullptr && r >= aux0 + kAuxU2 && r < aux0 + kAuxU2 + kSeedKD) { kd = 1; pd = U2; od = row * kSeedKD + (r - aux0 - kAuxU2); }
+                else if (!LASSO && r == aux0 + kAuxB0) kd = 2;
+            }
+            kind[u] = kd;
+            vf[u] = tile[of];
+            vd[u] = pd[od];
+            vb[u] = a.rowdwi[kd == 2 ? row : k0];
+        }
+#pragma unroll
+        for (int u = 0; u < SG; u++) {
+            const int e = e0 + u * (int)blockDim.x;
+            const double v = kind[u] == 0 ? (double)vf[u] : (kind[u] == 1 ? vd[u] : (kind[u] == 2 ? (vb[u] ? 0.0 : 1.0) : 0.0));
+            if (e < (MT - MTf) * KS * 64) A64[e] = v;
+        }
     }
     for (int e = threadIdx.x; e < 4 * KS; e += blockDim.x) {
         const int row = k0 + e;
@@ -1469,14 +1557,8 @@ __global__ void __launch_bounds__(256, RESCUE ? 1 : 2) k_nnls_gcert(const GcertA
             for (int e = threadIdx.x; e < a.nS * a.ldA; e += blockDim.x) Atl[e] = At[e];
         }
     }
-    for (int e = threadIdx.x; e < n_atoms * KD; e += blockDim.x) { const int j = e / KD, d = e - j * KD; Sl[j * LD + d] = Sg[e]; }
-    {
-        for (int e = threadIdx.x; e < MT * KS * 64; e += blockDim.x) {
-            const int l = e & 63, ks = (e >> 6) % KS, mt = (e >> 6) / KS;
-            const int atom = 16 * mt + (l & 15), d = 4 * ks + (l >> 4);
-            Aop[e] = (atom < n_atoms) ? Sg[(size_t)atom * KD + d] : 0.0;
-        }
-    }
+    stage_rows<KD, LD>(Sl, Sg, n_atoms, KD);
+    stage_operand<KS, MT>(Aop, Sg, n_atoms, KD);
     __syncthreads();
     const double kap = a.kappa0[ck.dir];
     BlockFeed<64> bf;
@@ -1912,13 +1994,9 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
     if (WIDE && n_items == 0) return;
     const double *__restrict__ Sg = a.Sb + (size_t)ck.dir * n_wm * KD;
     const double *__restrict__ Gd = a.gram + (size_t)ck.dir * a.n_atoms * a.ldG;
-    for (int e = threadIdx.x; e < n_wm * KD; e += blockDim.x) { const int j = e / KD, d = e - j * KD; Sl[j * LD + d] = Sg[e]; }
+    stage_rows<KD, LD>(Sl, Sg, n_wm, KD);
     for (int e = threadIdx.x; e < n_wm; e += blockDim.x) { scl[e] = a.colscale[e]; giso[e] = Gd[(size_t)e * a.ldG + a.iso_atom]; }
-    for (int e = threadIdx.x; e < MT * KS * 64; e += blockDim.x) {
-        const int l = e & 63, ks = (e >> 6) % KS, mt = (e >> 6) / KS;
-        const int atom = 16 * mt + (l & 15), d = 4 * ks + (l >> 4);
-        Aop[e] = (atom < n_wm) ? Sg[(size_t)atom * KD + d] : 0.0;
-    }
+    stage_operand<KS, MT>(Aop, Sg, n_wm, KD);
     __syncthreads();
     const double kap = a.kappa0[ck.dir], lam1 = a.lam1, lam2 = a.lam2;
     const double gii = Gd[(size_t)a.iso_atom * a.ldG + a.iso_atom];      // ||iso_dwi||^2
@@ -1982,16 +2060,28 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
         // (the column scales are read from LDS where they are needed -- scl[idx] -- instead of living in MS registers through the
         //  factorisation: the kernel's register peak is T + c + z + idx there)
         {
-            double sc[MS];
+            // Every entry is loaded whatever the lane's np (slots >= np hold atom 0: a valid address) and lands in the register it
+            // will live in; the selects come afterwards.  As `(s < np) ? .. Gd[..] .. : 0` each load sat in a branch of its own with
+            // a wait behind it: 77 (wide pass: 189) memory round trips one after the other per block of 64 voxels -- the whole
+            // kernel (SQ_WAIT_ANY 76 - 81 % of its wave cycles).
+            const unsigned ldg = (unsigned)a.ldG;
+            unsigned rowo[MS];
 #pragma unroll
-            for (int s = 0; s < MS; s++) sc[s] = scl[V.idx[s]];
+            for (int s = 0; s < MS; s++) rowo[s] = (unsigned)V.idx[s] * ldg;
 #pragma unroll
             for (int s = 0; s < MS; s++) {
 #pragma unroll
-                for (int t = 0; t <= s; t++)
-                    V.T[stri<MS>(s, t)] = (s < V.np) ? sc[s] * sc[t] * Gd[(size_t)V.idx[s] * a.ldG + V.idx[t]] + ((s == t) ? lam2 : 0.0) : 0.0;
-                V.c[s] = (s < V.np) ? (clip ? 1.0 : sc[s]) * (Crow[(size_t)V.idx[s] * 64] - sub - xq * giso[V.idx[s]]) - lam1 : 0.0;
+                for (int t = 0; t <= s; t++) V.T[stri<MS>(s, t)] = Gd[rowo[s] + (unsigned)V.idx[t]];
+                V.c[s] = Crow[(size_t)V.idx[s] * 64];
                 if (WIDE) __builtin_amdgcn_sched_barrier(0);      // row by row: 171 addresses computed ahead of their loads were 342 registers of their own
+            }
+#pragma unroll
+            for (int s = 0; s < MS; s++) {
+                const double ss = scl[V.idx[s]];
+#pragma unroll
+                for (int t = 0; t <= s; t++)
+                    V.T[stri<MS>(s, t)] = (s < V.np) ? ss * scl[V.idx[t]] * V.T[stri<MS>(s, t)] + ((s == t) ? lam2 : 0.0) : 0.0;
+                V.c[s] = (s < V.np) ? (clip ? 1.0 : ss) * (V.c[s] - sub - xq * giso[V.idx[s]]) - lam1 : 0.0;
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -2053,11 +2143,16 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
 #pragma unroll
                 for (int qq = 0; qq < 3; qq++) rem[qq] = (wq == qq) ? (rem[qq] & (rem[qq] - 1ull)) : rem[qq];
                 const bool on = wq >= 0 && t < n_wm;
-                const double st = on ? scl[t] : 0.0;
-                double g = on ? (clip ? 1.0 : st) * (Crow[(size_t)t * 64] - sub - xq * giso[t]) - lam1 : -1.0;
-                const double *gt = Gd + (size_t)t * a.ldG;
+                const int tc = on ? t : 0;                             // (loads at a valid address whatever the lane: all in flight together)
+                const double st = on ? scl[tc] : 0.0;
+                const double ct = Crow[(size_t)tc * 64];
+                const double *gt = Gd + (size_t)tc * a.ldG;
+                double gv[MS];
 #pragma unroll
-                for (int s = 0; s < MS; s++) { if (s < V.np && on) g -= st * gt[V.idx[s]] * xs[s]; }
+                for (int s = 0; s < MS; s++) gv[s] = gt[V.idx[s]];
+                double g = on ? (clip ? 1.0 : st) * (ct - sub - xq * giso[tc]) - lam1 : -1.0;
+#pragma unroll
+                for (int s = 0; s < MS; s++) { const double xv = (s < V.np && on) ? xs[s] : 0.0; g -= st * gv[s] * xv; }    // (the expression the guarded loop had: same contraction, same bits)
                 if (on && !(g < -1e-10)) viol = true;
                 n_ex += on ? 1 : 0;
             }
@@ -2228,12 +2323,8 @@ __global__ void __launch_bounds__(256, OCC2 ? 2 : AMX_SEED2_OCC) k_lasso_seed(co
     if (cid < 0) break;
     const Chunk ck = a.schunks[cid];
     const double *__restrict__ Sg = a.Sb + (size_t)ck.dir * n_wm * SLD;
-    for (int e = threadIdx.x; e < n_wm * KD; e += blockDim.x) { const int j = e / KD, d = e - j * KD; Sl[j * LD + d] = Sg[(size_t)j * SLD + d]; }
-    for (int e = threadIdx.x; e < MT * KS * 64; e += blockDim.x) {
-        const int l = e & 63, ks = (e >> 6) % KS, mt = (e >> 6) / KS;
-        const int atom = 16 * mt + (l & 15), d = 4 * ks + (l >> 4);
-        Aop[e] = (atom < n_wm) ? Sg[(size_t)atom * SLD + d] : 0.0;
-    }
+    stage_rows<KD, LD>(Sl, Sg, n_wm, SLD);
+    stage_operand<KS, MT>(Aop, Sg, n_wm, SLD);
     __syncthreads();
     const double lam1 = a.lam1, lam2 = a.lam2, tol = 1e-9, inf = __builtin_huge_val();
     const double sl2 = sqrt(lam2), isl2 = 1.0 / sl2;
