@@ -136,10 +136,22 @@ __global__ void __launch_bounds__(512) k_czb_project(const CzbFastArgs a)
     const int q = lane >> 4, c16 = lane & 15, nS = a.nS;
     const double *T = a.tables + (size_t)ck.dir * a.table_stride;
     const double *B = T + 2 * kCzbN * kCzbLd + kCzbN;                     // rows 0 .. 31: M A', rows 32 .. 63: A'
-    for (int e = threadIdx.x; e < 4 * KS * 64; e += blockDim.x) {
-        const int l = e & 63, ks = (e >> 6) % KS, mt = (e >> 6) / KS;
-        const int r = 16 * mt + (l & 15), i = 4 * ks + (l >> 4);
-        A64[e] = (i < a.nSp) ? B[(size_t)r * a.nSp + i] : 0.0;
+    {
+        // (four elements of a thread in flight: one guarded load per trip of a plain loop is a memory round trip per element)
+        constexpr int UB = 4, NE = 4 * KS * 64;
+        for (int e0 = threadIdx.x; e0 < NE; e0 += UB * (int)blockDim.x) {
+            double v[UB];
+#pragma unroll
+            for (int u = 0; u < UB; u++) {
+                const int e = e0 + u * (int)blockDim.x, ec = e < NE ? e : 0;
+                const int l = ec & 63, ks = (ec >> 6) % KS, mt = (ec >> 6) / KS;
+                const int r = 16 * mt + (l & 15), i = 4 * ks + (l >> 4);
+                v[u] = B[(size_t)r * a.nSp + (i < a.nSp ? i : 0)];
+                v[u] = (i < a.nSp) ? v[u] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < UB; u++) { const int e = e0 + u * (int)blockDim.x; if (e < NE) A64[e] = v[u]; }
+        }
     }
     if (threadIdx.x < kCzbN) m1[threadIdx.x] = T[2 * kCzbN * kCzbLd + threadIdx.x];
     __syncthreads();
@@ -197,7 +209,16 @@ __global__ void __launch_bounds__(256, 1) k_czb_lane(const CzbFastArgs a)
     if (ck.count == 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
     const double *T = a.tables + (size_t)ck.dir * a.table_stride;
-    for (int e = threadIdx.x; e < 2 * N * LD; e += blockDim.x) Ml[e] = T[e];
+    {
+        constexpr int UB = 4, NE = 2 * N * LD;
+        for (int e0 = threadIdx.x; e0 < NE; e0 += UB * (int)blockDim.x) {
+            double v[UB];
+#pragma unroll
+            for (int u = 0; u < UB; u++) { const int e = e0 + u * (int)blockDim.x; v[u] = T[e < NE ? e : 0]; }
+#pragma unroll
+            for (int u = 0; u < UB; u++) { const int e = e0 + u * (int)blockDim.x; if (e < NE) Ml[e] = v[u]; }
+        }
+    }
     __syncthreads();
     const int n_atoms = a.n_atoms;
     const unsigned valid_atoms = n_atoms >= 32 ? ~0u : ((1u << n_atoms) - 1u);
@@ -221,11 +242,18 @@ __global__ void __launch_bounds__(256, 1) k_czb_lane(const CzbFastArgs a)
         Z &= valid_atoms;
         // the dual tests compare gradients (units of c = A'y - lambda1) with zero: the tolerance follows the voxel's own scale, so that
         // un-normalised signals (doNormalizeSignal = False: y ~ 1e3) do not flip a near-degenerate atom back and forth on rounding noise
+        // c = A'y - lambda1 (rows 32 .. 63 of the block) waits in the lane's column of the x block: x is written when the lane is done
+        // with the voxel, c is read only until then.  (Read from the hand-over block in HBM / L2 inside the pivoting loop, every
+        // one of the 13 + 32 entries of a trip was a guarded load waited for in turn -- 45 memory round trips one after the other in
+        // every trip in which some lane of the wavefront factors its passive set: most of the kernel.)
         double cmax = 1.0;
         {
             const double *cz0 = src + (size_t)N * 64;
+            double cv[N];
 #pragma unroll
-            for (int j = 0; j < N; j++) { const double cj = fabs(cz0[(size_t)j * 64]); cmax = (((valid_atoms >> j) & 1u) && cj > cmax) ? cj : cmax; }
+            for (int j = 0; j < N; j++) cv[j] = cz0[(size_t)j * 64];
+#pragma unroll
+            for (int j = 0; j < N; j++) { xt[j * 64 + lane] = cv[j]; const double cj = fabs(cv[j]); cmax = (((valid_atoms >> j) & 1u) && cj > cmax) ? cj : cmax; }
         }
         const double tol = 1e-12 * cmax;
         bool active = valid && finite, overflow = false;
@@ -246,7 +274,7 @@ __global__ void __launch_bounds__(256, 1) k_czb_lane(const CzbFastArgs a)
                 for (int s = 0; s < ZM; s++) { si[s] = rem ? __builtin_ctz(rem) : 0; rem &= rem - 1u; }
             }
             const double *Src = zform ? Ml : Hl;
-            const double *cz = src + (size_t)N * 64;                     // c = A'y - lambda1: rows 32 .. 63 of the block
+            const double *cz = xt + lane;                                // c = A'y - lambda1, the lane's column (see above)
             double Tt[NT], dinv[ZM], sol[ZM];
 #pragma unroll
             for (int s = 0; s < ZM; s++) {

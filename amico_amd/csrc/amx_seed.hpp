@@ -1759,13 +1759,23 @@ __global__ void __launch_bounds__(256, RESCUE ? 1 : 2) k_nnls_gcert(const GcertA
                     on[u4] = wq >= 0 && t < n_atoms;
                     tt[u4] = on[u4] ? t : 0;
                 }
+                // Loads under the lanes' own masks, used outside the guards.  A scattered 8-byte load costs the CU's address unit about a
+                // cycle per ACTIVE lane, and that unit -- not HBM, not the vector ALUs -- is what these certificates run against
+                // (~190 load instructions x 64 lanes per block of 64 voxels with every lane loading whether it had a flagged atom
+                // or not: 0.3 ms per 1 M voxels at one lane per cycle and CU).  A guard that also holds the USE of its load makes
+                // the compiler wait inside the guard (a round trip per load): hence load inside, arithmetic outside.
                 double uu[UN], gg[UN][MS];
 #pragma unroll
                 for (int u4 = 0; u4 < UN; u4++) {
-                    uu[u4] = Crow[(size_t)tt[u4] * 64];
-                    const double *gt = Gd + (size_t)tt[u4] * a.ldG;
+                    uu[u4] = 0.0;
 #pragma unroll
-                    for (int s = 0; s < MS; s++) gg[u4][s] = gt[V.idx[s]];          // (slots >= np: idx = 0, x = 0)
+                    for (int s = 0; s < MS; s++) gg[u4][s] = 0.0;
+                    if (on[u4]) {
+                        uu[u4] = Crow[(size_t)tt[u4] * 64];
+                        const double *gt = Gd + (size_t)tt[u4] * a.ldG;
+#pragma unroll
+                        for (int s = 0; s < MS; s++) if (s < V.np) gg[u4][s] = gt[V.idx[s]];
+                    }
                 }
 #pragma unroll
                 for (int u4 = 0; u4 < UN; u4++) {
@@ -1821,14 +1831,18 @@ __global__ void __launch_bounds__(256, RESCUE ? 1 : 2) k_nnls_gcert(const GcertA
                 for (int s = 0; s < MS; s++) sum_wm += (s < V.np && V.idx[s] < a.n_wm) ? V.x[s] / sum_atoms : 0.0;
                 sum_wm += 1e-16;
                 double f1 = 0.0, f2 = 0.0, k1 = 0.0;
+                // (the atoms' parameters first, all 2 MS loads in flight: inside the guard below each load was waited for in turn)
+                float icv[MS], kpv[MS];
+#pragma unroll
+                for (int s = 0; s < MS; s++) { const int j = V.idx[s] < a.n_wm ? V.idx[s] : 0; icv[s] = a.icvf[j]; kpv[s] = a.kappa[j]; }
 #pragma unroll
                 for (int s = 0; s < MS; s++) {
                     if (s < V.np && V.idx[s] < a.n_wm) {
-                        const float ic = a.icvf[V.idx[s]];
+                        const float ic = icv[s];
                         const double t = V.x[s] / sum_atoms / sum_wm;
                         f1 += (double)ic * t;
                         f2 += (double)((float)(1.0 - (double)ic)) * t;
-                        k1 += (double)a.kappa[V.idx[s]] * t;
+                        k1 += (double)kpv[s] * t;
                     }
                 }
                 const double ndi = f1 / (f1 + f2 + 1e-16);
@@ -2060,10 +2074,9 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
         // (the column scales are read from LDS where they are needed -- scl[idx] -- instead of living in MS registers through the
         //  factorisation: the kernel's register peak is T + c + z + idx there)
         {
-            // Every entry is loaded whatever the lane's np (slots >= np hold atom 0: a valid address) and lands in the register it
-            // will live in; the selects come afterwards.  As `(s < np) ? .. Gd[..] .. : 0` each load sat in a branch of its own with
-            // a wait behind it: 77 (wide pass: 189) memory round trips one after the other per block of 64 voxels -- the whole
-            // kernel (SQ_WAIT_ANY 76 - 81 % of its wave cycles).
+            // Every entry lands in the register it will live in, under the lane's own mask (s < np), and is USED outside that guard.
+            // As `(s < np) ? sc sc Gd[..] + .. : 0` each load sat in a branch of its own with a wait behind it: 77 (wide pass: 189)
+            // memory round trips one after the other per block of 64 voxels -- the whole kernel (SQ_WAIT_ANY 76 - 81 % of its cycles).
             const unsigned ldg = (unsigned)a.ldG;
             unsigned rowo[MS];
 #pragma unroll
@@ -2071,8 +2084,13 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
 #pragma unroll
             for (int s = 0; s < MS; s++) {
 #pragma unroll
-                for (int t = 0; t <= s; t++) V.T[stri<MS>(s, t)] = Gd[rowo[s] + (unsigned)V.idx[t]];
-                V.c[s] = Crow[(size_t)V.idx[s] * 64];
+                for (int t = 0; t <= s; t++) V.T[stri<MS>(s, t)] = 0.0;
+                V.c[s] = 0.0;
+                if (s < V.np) {                     // (loads under the lane's mask, used outside it: see k_nnls_gcert's exact dual values)
+#pragma unroll
+                    for (int t = 0; t <= s; t++) V.T[stri<MS>(s, t)] = Gd[rowo[s] + (unsigned)V.idx[t]];
+                    V.c[s] = Crow[(size_t)V.idx[s] * 64];
+                }
                 if (WIDE) __builtin_amdgcn_sched_barrier(0);      // row by row: 171 addresses computed ahead of their loads were 342 registers of their own
             }
 #pragma unroll
@@ -2143,13 +2161,17 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
 #pragma unroll
                 for (int qq = 0; qq < 3; qq++) rem[qq] = (wq == qq) ? (rem[qq] & (rem[qq] - 1ull)) : rem[qq];
                 const bool on = wq >= 0 && t < n_wm;
-                const int tc = on ? t : 0;                             // (loads at a valid address whatever the lane: all in flight together)
+                const int tc = on ? t : 0;
                 const double st = on ? scl[tc] : 0.0;
-                const double ct = Crow[(size_t)tc * 64];
-                const double *gt = Gd + (size_t)tc * a.ldG;
-                double gv[MS];
+                double ct = 0.0, gv[MS];                               // (loads under the lane's mask, all in flight together, used outside it)
 #pragma unroll
-                for (int s = 0; s < MS; s++) gv[s] = gt[V.idx[s]];
+                for (int s = 0; s < MS; s++) gv[s] = 0.0;
+                if (on) {
+                    ct = Crow[(size_t)tc * 64];
+                    const double *gt = Gd + (size_t)tc * a.ldG;
+#pragma unroll
+                    for (int s = 0; s < MS; s++) if (s < V.np) gv[s] = gt[V.idx[s]];
+                }
                 double g = on ? (clip ? 1.0 : st) * (ct - sub - xq * giso[tc]) - lam1 : -1.0;
 #pragma unroll
                 for (int s = 0; s < MS; s++) { const double xv = (s < V.np && on) ? xs[s] : 0.0; g -= st * gv[s] * xv; }    // (the expression the guarded loop had: same contraction, same bits)

@@ -568,6 +568,16 @@ __global__ void __launch_bounds__(256, AMX_ROWS_OCC) k_sandi_rows(const SandiArg
     constexpr int ldA = 16;
     CD *T = (CD *)a.tables, *G = T + N * kRowsTs, *g0 = G + N * M, *A = g0 + 16;
     const bool warm = amx_warm_start(a.c.lam2, a.c.flags);
+    // the atoms' norms and model parameters (Rs | d_in | d_isos by atom class) once per workgroup: read in the maps section below
+    // from their four arrays, every value was a load of its own under a wave-uniform guard, waited for before the next one left --
+    // ~45 memory round trips one after the other per wavefront, as long as the solver itself
+    __shared__ double s_par[2][16];
+    if (threadIdx.x < 16) {
+        const int j = threadIdx.x;
+        s_par[0][j] = j < n_atoms ? a.norms[j] : 0.0;
+        s_par[1][j] = j < n_rs ? a.Rs[j] : (j < n_rs + n_in ? a.d_in[j - n_rs] : (j < n_atoms ? a.d_isos[j - n_rs - n_in] : 0.0));
+    }
+    __syncthreads();
     for (int v = threadIdx.x; v < ck.count; v += blockDim.x) {
         const int vox = linear ? ck.start + v : a.c.perm[ck.start + v];
         const double *yv = a.c.y + (size_t)vox * M;
@@ -592,12 +602,13 @@ __global__ void __launch_bounds__(256, AMX_ROWS_OCC) k_sandi_rows(const SandiArg
         double x_sum = 0.0, xsph = 0.0, xstk = 0.0, xiso = 0.0, Rsoma = 0.0, Din = 0.0, De = 0.0;
 #pragma unroll
         for (int j = 0; j < N; j++) {
+            const double nj = s_par[0][j < 16 ? j : 0], pj = s_par[1][j < 16 ? j : 0];
             if (j < n_atoms) {
-                x[j] *= a.norms[j];
+                x[j] *= nj;
                 x_sum += x[j];
-                if (j < n_rs) { xsph += x[j]; Rsoma += a.Rs[j] * x[j]; }
-                else if (j < n_rs + n_in) { xstk += x[j]; Din += a.d_in[j - n_rs] * x[j]; }
-                else { xiso += x[j]; De += a.d_isos[j - n_rs - n_in] * x[j]; }
+                if (j < n_rs) { xsph += x[j]; Rsoma += pj * x[j]; }
+                else if (j < n_rs + n_in) { xstk += x[j]; Din += pj * x[j]; }
+                else { xiso += x[j]; De += pj * x[j]; }
             }
         }
         if (a.c.xdbg) {                                   // the rescaled x (models.pyx:1570-1571)

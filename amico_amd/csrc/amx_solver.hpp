@@ -566,13 +566,22 @@ struct NNSolver {
                 for (int q = 0; q < NQ; q++) ut[q] = 0.0f;
                 const double rho2 = nrm[0];
                 if (!direct) {
-                    double rt = (lane < KDs) ? scr.ytil[lane] : 0.0;
+                    // (every passive atom's row at once: guarded by `m < np` each load sat in a branch of its own and was waited for
+                    //  before the next one left -- np memory round trips in a row)
+                    const int l12 = lane < KDs ? lane : 0;
+                    double rt = scr.ytil[l12];
+                    double sv[MAXP];
+#pragma unroll
+                    for (int m = 0; m < MAXP; m++) {
+                        const int t = m < np ? bcast_i(idx, m) : 0;
+                        sv[m] = scr.Sg[(size_t)t * KDs + l12];
+                    }
+                    rt = (lane < KDs) ? rt : 0.0;
 #pragma unroll
                     for (int m = 0; m < MAXP; m++) {
                         if (m < np) {
-                            const int t = bcast_i(idx, m);
                             const double xs = bcast(x, m);
-                            if (lane < KDs) rt -= scr.Sg[(size_t)t * KDs + lane] * xs;
+                            if (lane < KDs) rt -= sv[m] * xs;
                         }
                     }
 #pragma unroll
