@@ -162,8 +162,11 @@ __global__ void __launch_bounds__(512) k_czb_project(const CzbFastArgs a)
         const int vox = a.perm[ck.start + (k < ck.count ? k : ck.count - 1)];
         if (a.y32 != nullptr) {
             const float *yv = a.y32 + (size_t)vox * nS + q;
+            float bf32[KS];
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) bn[ks] = (4 * ks + q < nS) ? (double)yv[4 * ks] : 0.0;
+            for (int ks = 0; ks < KS; ks++) bf32[ks] = (4 * ks + q < nS) ? yv[4 * ks] : 0.0f;      // (conversion outside the guard: loads in flight)
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) bn[ks] = (double)bf32[ks];
         } else {
             const double *yv = a.y + (size_t)vox * nS + q;
 #pragma unroll

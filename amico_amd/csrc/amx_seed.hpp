@@ -1215,9 +1215,13 @@ __global__ void __launch_bounds__(512) k_noddi_gemm(const GemmArgs a)
         pos_n = LASSO ? a.clist[ck.start + kk] : ck.start + kk;
         const int vox = a.perm[pos_n];
         if (a.y32 != nullptr) {
+            // (the loads under their guards, the conversions outside: converted inside, every load was waited for before the next left)
             const float *yv = a.y32 + (size_t)vox * nS + k0 + q;
+            float bf32[KS];
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) bn[ks] = (k0 + 4 * ks + q < k1) ? (double)yv[4 * ks] : 0.0;
+            for (int ks = 0; ks < KS; ks++) bf32[ks] = (k0 + 4 * ks + q < k1) ? yv[4 * ks] : 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) bn[ks] = (double)bf32[ks];
         } else {
             const double *yv = a.y + (size_t)vox * nS + k0 + q;
 #pragma unroll
@@ -1554,7 +1558,16 @@ __global__ void __launch_bounds__(256, RESCUE ? 1 : 2) k_nnls_gcert(const GcertA
     if (RESCUE) {
         At = a.tiles + (size_t)ck.dir * a.tile_stride;
         if (a.tile_in_lds) {
-            for (int e = threadIdx.x; e < a.nS * a.ldA; e += blockDim.x) Atl[e] = At[e];
+            // (eight elements of a thread in flight: the plain loop kept one -- 56 memory round trips for a 57 KB tile, most of this pass's time)
+            constexpr int UB = 8;
+            const int NE = a.nS * a.ldA;
+            for (int e0 = threadIdx.x; e0 < NE; e0 += UB * (int)blockDim.x) {
+                float v[UB];
+#pragma unroll
+                for (int u = 0; u < UB; u++) { const int e = e0 + u * (int)blockDim.x; v[u] = At[e < NE ? e : 0]; }
+#pragma unroll
+                for (int u = 0; u < UB; u++) { const int e = e0 + u * (int)blockDim.x; if (e < NE) Atl[e] = v[u]; }
+            }
         }
     }
     stage_rows<KD, LD>(Sl, Sg, n_atoms, KD);
@@ -1661,10 +1674,16 @@ __global__ void __launch_bounds__(256, RESCUE ? 1 : 2) k_nnls_gcert(const GcertA
                 auto rows = [&](const auto *Ap) {
                     double yb[RB], yn[RB];
                     auto fetch = [&](int i0, double (&dst)[RB]) {
+                        // (the signal's type is chosen once per batch, not per element: `yv ? yv[i] : yv32[i]` made every load wait for the one before)
+                        if (yv != nullptr) {
 #pragma unroll
-                        for (int u = 0; u < RB; u++) {
-                            const int i = i0 + u < a.nS ? i0 + u : a.nS - 1;
-                            dst[u] = yv ? yv[i] : (double)yv32[i];
+                            for (int u = 0; u < RB; u++) { const int i = i0 + u < a.nS ? i0 + u : a.nS - 1; dst[u] = yv[i]; }
+                        } else {
+                            float t32[RB];
+#pragma unroll
+                            for (int u = 0; u < RB; u++) { const int i = i0 + u < a.nS ? i0 + u : a.nS - 1; t32[u] = yv32[i]; }
+#pragma unroll
+                            for (int u = 0; u < RB; u++) dst[u] = (double)t32[u];
                         }
                     };
                     fetch(0, yn);

@@ -125,12 +125,20 @@ __device__ __forceinline__ void dti_prefetch(double2 (&pre)[kDtiPre], const doub
 // float32 signals (the image's own dtype, core.py:136): two 4-byte loads per pair (a tile starts at any multiple of 4 bytes)
 __device__ __forceinline__ void dti_prefetch(double2 (&pre)[kDtiPre], const float *__restrict__ src, int cnt, int tid)
 {
+    float2 raw[kDtiPre];
+    bool got[kDtiPre];
 #pragma unroll
     for (int i = 0; i < kDtiPre; i++) {
+        // (the loads under their guards, the conversions outside them: converted inside, every load was waited for before the next one left)
         const int e = 2 * (tid + i * kDtiThreads);
-        if (e + 1 < cnt) pre[i] = make_double2((double)src[e], (double)src[e + 1]);
-        else if (e < cnt) pre[i] = make_double2((double)src[e], 1.0);
+        float2 t = make_float2(1.0f, 1.0f);
+        bool any = false;
+        if (e + 1 < cnt) { t = *reinterpret_cast<const float2 *>(src + e); any = true; }
+        else if (e < cnt) { t.x = src[e]; any = true; }
+        raw[i] = t; got[i] = any;
     }
+#pragma unroll
+    for (int i = 0; i < kDtiPre; i++) if (got[i]) pre[i] = make_double2((double)raw[i].x, (double)raw[i].y);
 }
 
 template <typename YT>
