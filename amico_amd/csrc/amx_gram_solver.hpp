@@ -378,6 +378,54 @@ struct GramSolver {
         double u[NQ], uy[NQ];                 // atom space: A'r and A'y (unscaled)
 #pragma unroll
         for (int q = 0; q < NQ; q++) { u[q] = 0.0; uy[q] = 0.0; }
+#ifndef AMX_NO_LASSO_WARM
+        // WARM START from a refused seed (round 5).  The voxels that reach this solver with a seed that was not certified -- a support
+        // wrong in an atom or two, or the passive set the seed solver held when it gave up at its trip cap (flag word set: then the
+        // set is incomplete, not wrong) -- used to start from the EMPTY set: 20 - 30 additions, one factor row and one dual update
+        // each, ~700 us of a wavefront for a thousand voxels per million that made up most of the left-over kernel's time.  Any set P
+        // whose least-squares solution is positive is a state the active-set method may be in, so: the seed's atoms enter (one factor
+        // row each), the atoms whose coefficient comes out non-positive leave (the most negative first) until all are positive, and
+        // the method continues from there on an exactly computed dual vector.  The ridge makes the optimum unique: same support.
+        if (seedmask != nullptr && np == 0) {
+            const int n0 = __builtin_popcountll(seedmask[0]) + __builtin_popcountll(seedmask[1]) + __builtin_popcountll(seedmask[2]);
+            if (n0 > 0 && n0 <= MAXP - 2) {
+                // A'y first (the new slots' right-hand sides need it): the exact sweep at x = 0
+#pragma unroll
+                for (int rr = 0; rr < NR; rr++) { r[rr] = yr[rr]; rs[lane + kWave * rr] = r[rr]; }
+                double w2[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; q++) { u[q] = 0.0; w2[q] = 0.0; }
+                tile_sweep<NQ, AT>(As + lane, ldA, nS, rs, u, w2);
+#pragma unroll
+                for (int q = 0; q < NQ; q++) { u[q] += w2[q]; uy[q] = u[q]; }
+                have_u = true; n_exact++;
+#pragma unroll
+                for (int w3 = 0; w3 < 3; w3++) {
+                    if (w3 >= NQ) break;
+                    for (unsigned long long rem = seedmask[w3] & allowed[w3 < NQ ? w3 : 0]; rem != 0ull; rem &= rem - 1ull) {
+                        const int tl = __builtin_ctzll(rem), t = w3 * 64 + tl;
+                        if (t >= n_atoms) break;
+                        double sct = 0.0, uyt = 0.0;
+#pragma unroll
+                        for (int q = 0; q < NQ; q++)
+                            if (q == w3) { sct = bcast(scl[q], tl); uyt = bcast(uy[q], tl); }
+                        if (append(t, sct, uyt, lam1, lam2, lane, G, ldG) && lane == tl) fl |= 0x100u << w3;
+                    }
+                }
+                for (int guard = 0; guard <= MAXP && np > 0; guard++) {
+                    const double z = solve_passive(lane);
+                    const bool neg = lane < np && !(z > 0.0);
+                    if (ballot64(neg) == 0ull) { x = (lane < np) ? z : 0.0; break; }
+                    const double zmin = wave_min(neg ? z : inf);
+                    const unsigned long long who = ballot64(neg && z == zmin);
+                    remove_slot(who != 0ull ? __builtin_ctzll(who) : __builtin_ctzll(ballot64(neg)), lane, fl);
+                }
+                if (np == 0) x = 0.0;
+                xprev = x;
+                force_exact = true;              // the dual vector of this state comes from the true residual
+            }
+        }
+#endif
 
         for (int outer = 0; status == kSolved; ++outer) {
             if (outer > 2 * itmax) { status = kGuardOuter; break; }

@@ -1019,7 +1019,10 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
         if (active && !done && trips > 2 * trip_cap) { done = true; noseed = true; }
         if (done) {
             unsigned lo = 0xffffffffu, hi = 0xffffffffu;                 // one byte per slot, 0xff = empty
-            if (!noseed) {
+            // (a voxel given up at the trip cap or at MS atoms hands on the support it holds: not a solution of the compressed problem,
+            //  so the certificate will most likely refuse it -- but the left-over kernel lets a refused seed's atoms enter first, and
+            //  these are the voxels with the longest paths from the empty set)
+            if (!noseed || (STAGE == 1 && V.np > 0)) {      // (stage 3: measured, no gain -- its left-over kernel went 0.249 -> 0.265 ms per 1 M voxels)
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
                     if (s < V.np) lo = (lo & ~(0xffu << (8 * s))) | ((unsigned)(V.idx[s] & 0xff) << (8 * s));
