@@ -24,6 +24,7 @@ SYMBOLS = ['amx_version', 'amx_build_id', 'amx_ctx_create', 'amx_ctx_destroy', '
            'amx_set_profiling', 'amx_last_kernel_ms', 'amx_last_stats', 'amx_last_seed_stats', 'amx_selftest',
            'amx_dti_create', 'amx_dti_destroy', 'amx_dti_directions', 'amx_dti_directions_device', 'amx_dti_directions_device_f32', 'amx_prep_gather_device_f32',
            'amx_prep_create', 'amx_prep_destroy', 'amx_prep_gather', 'amx_prep_gather_device',
+           'amx_prep_gather_directions_device', 'amx_prep_gather_directions_device_f32',
            'amx_prep_mean_b0', 'amx_prep_mean_b0_device', 'amx_prep_scatter', 'amx_prep_scatter_device',
            'amx_lut_resample', 'amx_lut_rotate_resample',
            'amx_dict_upload', 'amx_dict_destroy', 'amx_nnls_batched', 'amx_lasso_batched', 'amx_nnls_batched_device', 'amx_lasso_batched_device']
@@ -150,6 +151,9 @@ def lib():
     L.amx_prep_gather_device.argtypes = [c_vp, c_vp, c_vp, C.c_int, C.c_float, c_vp, c_vp, c_vp]
     L.amx_prep_gather_device_f32.argtypes = [c_vp, c_vp, c_vp, C.c_int, C.c_float, c_vp, c_vp, c_vp]
     L.amx_prep_gather_device_f32.restype = C.c_int
+    for f_ in (L.amx_prep_gather_directions_device, L.amx_prep_gather_directions_device_f32):
+        f_.argtypes = [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_float, c_vp, c_vp, c_vp, c_vp]      # ctx, plan, tensor helper, img, normalize, thr, y, mean_b0, dirs, stream
+        f_.restype = C.c_int
     L.amx_prep_mean_b0.argtypes = [c_vp, c_vp, c_fp, c_fp]
     L.amx_prep_mean_b0_device.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp]
     L.amx_prep_scatter.argtypes = [c_vp, c_vp, c_dp, C.c_int, c_fp]

@@ -3,6 +3,7 @@
 // scatter of the per-voxel results back into float32 volumes.  Reference: core.py:209-223 (normalisation),
 // 225-268 (b0 merge, directional average), 451-452 (mask gather + clip), 472-498 (scatter).
 #include "amx_host.hpp"
+#include "amx_tensor.hpp"
 
 using namespace amx;
 
@@ -21,6 +22,7 @@ struct PrepArgs {
     int nS, n_out, n_b0, n_gidx, ldt, inplace, layout, normalize, direct;
     const int *gptr, *gidx, *b0idx;
     float thr;
+    const double *wt; double min_signal; double *dirs;   // DIRS: tensor fit along the way -- pinv(design) f64[n_out][6], clamp, out f64[n_vox][3]
     const int *live;              // tiles with masked voxels (amx_prep::live64), n_live of them
     int *counter;                 // next entry of `live` to hand out (zeroed before the launch)
     long long n_live;
@@ -46,7 +48,10 @@ __device__ __forceinline__ long long next_live_tile(const PrepArgs &a, int lane)
 //      (core.py:225-227 / 236-252); with identity groups the single multiplication is applied on the way out;
 //  (3) rows are written to y[rank][:] as float64 with negative values clipped (core.py:451-452), coalesced per row.
 // The plan's index lists live in LDS (P): scalar loads from global memory would serialise phase 2.
-template <bool IDENTITY, bool DIRECT>
+// DIRS (round 5): the principal direction of the voxel's diffusion tensor (k_dti_dirs' arithmetic: log-linear fit, Jacobi) is taken
+// while the voxel's nS values sit in the tile -- lane = voxel walks them once more --, so the device pipeline reads the image once
+// and y is not read back for the tensor fit.
+template <bool IDENTITY, bool DIRECT, bool DIRS = false>
 __global__ __launch_bounds__(64 * kPrepWaves) void k_prep_gather(PrepArgs a)
 {
     extern __shared__ float smf[];
@@ -149,6 +154,25 @@ __global__ __launch_bounds__(64 * kPrepWaves) void k_prep_gather(PrepArgs a)
         }
         if (!IDENTITY) WAVE_SYNC();
         const bool scale = IDENTITY && a.normalize;
+        if (DIRS && r >= 0) {
+            // y[r][j] as the write-out below makes it (scaled, clipped, float32), log(max(y, min_signal)) contracted with the six rows
+            // of the design's pseudo-inverse (wave-uniform addresses: scalar loads), then the 3 x 3 eigen-problem -- all in this lane
+            using CD = const __attribute__((address_space(4))) double;
+            CD *W = (CD *)a.wt;
+            double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            for (int j = 0; j < a.n_out; j++) {
+                float val = direct ? T[j * kDirectLd + lane] : O[lane * a.ldt + j];
+                if (scale) val = val * f;
+                val = val < 0.0f ? 0.0f : val;
+                const double ly = fast_log(fmax((double)val, a.min_signal));
+#pragma unroll
+                for (int k = 0; k < 6; k++) acc[k] = fma(W[j * 6 + k], ly, acc[k]);
+            }
+            double o[3];
+            principal_direction(acc, o);
+            double *dd = a.dirs + (long long)r * 3;
+            dd[0] = o[0]; dd[1] = o[1]; dd[2] = o[2];
+        }
         // (four rows per step -- their LDS reads in flight together -- measured slower: 0.254 -> 0.268 ms)
         for (int k = 0; k < 64; k++) {
             if (!((live >> k) & 1ull)) continue;
@@ -487,7 +511,7 @@ int amx_prep_create(amx_ctx *ctx, const int64_t dims[3], const int64_t strides[4
 }
 
 static int prep_gather_dev(amx_ctx *ctx, const amx_prep *p, const float *d_img, int normalize, float b0_threshold,
-                           double *d_y, float *d_y32, float *d_mean_b0, void *hip_stream);
+                           double *d_y, float *d_y32, float *d_mean_b0, void *hip_stream, const amx_dti *dti = nullptr, double *d_dirs = nullptr);
 
 int amx_prep_gather_device(amx_ctx *ctx, const amx_prep *p, const float *d_img, int normalize, float b0_threshold,
                            double *d_y, float *d_mean_b0, void *hip_stream)
@@ -501,14 +525,34 @@ int amx_prep_gather_device_f32(amx_ctx *ctx, const amx_prep *p, const float *d_i
     return prep_gather_dev(ctx, p, d_img, normalize, b0_threshold, nullptr, d_y, d_mean_b0, hip_stream);
 }
 
+// the gather with the tensor fit's principal directions taken along (core.py:209-268, 451-452 and 431-436, 456-458 in one pass over
+// the image): what amx_prep_gather_device[_f32] followed by amx_dti_directions_device[_f32] computes
+int amx_prep_gather_directions_device(amx_ctx *ctx, const amx_prep *p, const amx_dti *h, const float *d_img, int normalize,
+                                      float b0_threshold, double *d_y, float *d_mean_b0, double *d_dirs, void *hip_stream)
+{
+    if (!h) return ctx ? amx_bad(ctx, "amx_prep_gather_directions: null tensor helper") : AMX_E_BADARG;
+    return prep_gather_dev(ctx, p, d_img, normalize, b0_threshold, d_y, nullptr, d_mean_b0, hip_stream, h, d_dirs);
+}
+
+int amx_prep_gather_directions_device_f32(amx_ctx *ctx, const amx_prep *p, const amx_dti *h, const float *d_img, int normalize,
+                                          float b0_threshold, float *d_y, float *d_mean_b0, double *d_dirs, void *hip_stream)
+{
+    if (!h) return ctx ? amx_bad(ctx, "amx_prep_gather_directions: null tensor helper") : AMX_E_BADARG;
+    return prep_gather_dev(ctx, p, d_img, normalize, b0_threshold, nullptr, d_y, d_mean_b0, hip_stream, h, d_dirs);
+}
+
 static int prep_gather_dev(amx_ctx *ctx, const amx_prep *p, const float *d_img, int normalize, float b0_threshold,
-                           double *d_y, float *d_y32, float *d_mean_b0, void *hip_stream)
+                           double *d_y, float *d_y32, float *d_mean_b0, void *hip_stream, const amx_dti *dti, double *d_dirs)
 {
     if (!ctx) return AMX_E_BADARG;
     if (!p || p->ctx != ctx) return amx_bad(ctx, "amx_prep_gather: not a plan of this ctx");
     if (normalize && p->n_b0 == 0) return amx_bad(ctx, "amx_prep_gather: no b0 volume to normalize signal with");   // core.py:214-215
     if (p->n_vox == 0) return AMX_OK;
     if (!d_img || (!d_y && !d_y32)) return amx_bad(ctx, "amx_prep_gather: null buffer");
+    if (dti != nullptr) {
+        if (dti->ctx != ctx || !d_dirs) return amx_bad(ctx, "amx_prep_gather_directions: not a tensor helper of this ctx / null buffer");
+        if (dti->nS != p->n_out) return amx_bad(ctx, "amx_prep_gather_directions: the tensor helper's scheme does not match the plan's output volumes");
+    }
     hipStream_t s = (hipStream_t)hip_stream;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     PrepArgs a;
@@ -521,6 +565,7 @@ static int prep_gather_dev(amx_ctx *ctx, const amx_prep *p, const float *d_img, 
     a.layout = p->layout; a.normalize = normalize ? 1 : 0;
     a.gptr = p->gptr; a.gidx = p->gidx; a.b0idx = p->b0idx; a.thr = b0_threshold;
     a.n_gidx = p->n_gidx;
+    if (dti != nullptr) { a.wt = dti->wt; a.min_signal = dti->min_signal; a.dirs = d_dirs; }
     const bool identity = p->identity != 0;
     a.direct = (identity && p->layout != 2 && !ctx->opt_prep_no_direct) ? 1 : 0;
     const size_t per_wave = identity ? (a.direct ? (size_t)a.nS * kDirectLd : (size_t)64 * a.ldt) : (size_t)64 * a.ldt * (a.inplace ? 1 : 2);
@@ -531,6 +576,9 @@ static int prep_gather_dev(amx_ctx *ctx, const amx_prep *p, const float *d_img, 
         HIPCHK(ctx, hipFuncSetAttribute((const void *)k_prep_gather<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(ctx, hipFuncSetAttribute((const void *)k_prep_gather<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(ctx, hipFuncSetAttribute((const void *)k_prep_gather<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_prep_gather<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_prep_gather<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_prep_gather<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[ctx->device & 63] = true;
     }
     const int per_cu = (int)((160 * 1024) / lds) > 8 ? 8 : (int)((160 * 1024) / lds);
@@ -558,11 +606,20 @@ static int prep_gather_dev(amx_ctx *ctx, const amx_prep *p, const float *d_img, 
         }
         HIPCHK(ctx, hipGetLastError());
         rec(ctx, 9, s);
+        // (the streaming kernels hold no tile a tensor fit could ride on: the directions come from the rows they wrote)
+        if (dti != nullptr)
+            return d_y32 ? amx_dti_directions_device_f32(ctx, dti, d_y32, p->n_vox, d_dirs, hip_stream)
+                         : amx_dti_directions_device(ctx, dti, d_y, p->n_vox, d_dirs, hip_stream);
         return AMX_OK;
     }
     HIPCHK(ctx, hipMemsetAsync(my_counter, 0, sizeof(int), s));
     rec(ctx, 8, s);
-    if (identity && a.direct) hipLaunchKernelGGL((k_prep_gather<true, true>), dim3((unsigned)grid), dim3(64 * kPrepWaves), lds, s, a);
+    if (dti != nullptr) {
+        if (identity && a.direct) hipLaunchKernelGGL((k_prep_gather<true, true, true>), dim3((unsigned)grid), dim3(64 * kPrepWaves), lds, s, a);
+        else if (identity) hipLaunchKernelGGL((k_prep_gather<true, false, true>), dim3((unsigned)grid), dim3(64 * kPrepWaves), lds, s, a);
+        else hipLaunchKernelGGL((k_prep_gather<false, false, true>), dim3((unsigned)grid), dim3(64 * kPrepWaves), lds, s, a);
+    }
+    else if (identity && a.direct) hipLaunchKernelGGL((k_prep_gather<true, true>), dim3((unsigned)grid), dim3(64 * kPrepWaves), lds, s, a);
     else if (identity) hipLaunchKernelGGL((k_prep_gather<true, false>), dim3((unsigned)grid), dim3(64 * kPrepWaves), lds, s, a);
     else hipLaunchKernelGGL((k_prep_gather<false, false>), dim3((unsigned)grid), dim3(64 * kPrepWaves), lds, s, a);
     HIPCHK(ctx, hipGetLastError());

@@ -463,7 +463,8 @@ def volume_pipeline(args):
     img = np.asfortranarray((y.reshape(shape + (-1,)) * 900.0).astype(np.float32))     # nibabel hands out Fortran order
     xx, yy, zz = np.meshgrid(*[np.linspace(-1, 1, s) for s in shape], indexing='ij')
     mask = ((xx * xx + yy * yy + zz * zz) < 0.92).astype(np.uint8)
-    pl = pipeline.NoddiVolumePipeline(scheme, img, mask, K, ht)
+    fused = os.environ.get('AMX_PIPELINE_UNFUSED', '0') in ('', '0')        # A/B: gather + tensor fit as two passes (the round-4 chain)
+    pl = pipeline.NoddiVolumePipeline(scheme, img, mask, K, ht, fused=fused)
     flat = np.lib.stride_tricks.as_strided(img, shape=(img.size,), strides=(4,))
     d_img = torch.from_numpy(flat.copy()).to(dev)
     for _ in range(args.warmup):
@@ -487,7 +488,8 @@ def volume_pipeline(args):
     print(json.dumps({'metric': 'voxels/sec, raw image -> map volumes (prepare + tensor directions + NODDI fit + scatter)',
                       'value': n / el, 'unit': 'voxels/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
                       'ms_per_step': 1e3 * el, 'dtype': 'f32 -> f64 -> f32', 'data': 'synthetic',
-                      'config': {'workload': '128x128x80x99 float32 image (Fortran order), %d masked voxels, NODDI' % n},
+                      'config': {'workload': '128x128x80x99 float32 image (Fortran order), %d masked voxels, NODDI' % n,
+                                 'gather_and_tensor_fit': 'one kernel' if fused else 'two passes'},
                       'parity': {'y_bit_exact': exact_y, 'sample_voxels': m, 'frac_within_1e-6': float((diff < 1e-6).mean()),
                                  'median_abs_dmap': float(np.median(diff)),
                                  'note': 'directions differ from LAPACK\'s by ~1e-13: a voxel whose LUT index flips gets another dictionary orientation'}}))

@@ -282,6 +282,14 @@ int amx_prep_gather_device_f32(amx_ctx *ctx, const amx_prep *p, const float *d_i
                                float *d_y, float *d_mean_b0, void *hip_stream);
 int amx_prep_gather_device(amx_ctx *ctx, const amx_prep *p, const float *d_img, int normalize,
                            float b0_threshold, double *d_y, float *d_mean_b0, void *hip_stream);
+/* The gather with the tensor fit taken along (round 5): y AND the principal directions of core.py:431-436, 456-458 in ONE pass over
+ * the image -- lane = voxel contracts log(max(y, min_signal)) with the helper's pseudo-inverse while the voxel's values are in the
+ * gather's LDS tile; what amx_prep_gather_device[_f32] followed by amx_dti_directions_device[_f32] computes (y bit-identical, the
+ * directions to rounding: the sum over the volumes runs in index order here).  h: amx_dti_create for the plan's n_out volumes.     */
+int amx_prep_gather_directions_device(amx_ctx *ctx, const amx_prep *p, const amx_dti *h, const float *d_img, int normalize,
+                                      float b0_threshold, double *d_y, float *d_mean_b0, double *d_dirs, void *hip_stream);
+int amx_prep_gather_directions_device_f32(amx_ctx *ctx, const amx_prep *p, const amx_dti *h, const float *d_img, int normalize,
+                                          float b0_threshold, float *d_y, float *d_mean_b0, double *d_dirs, void *hip_stream);
 /* self.mean_b0s of EVERY voxel (core.py:213), float32 [X][Y][Z] in C order: input of the threshold above */
 int amx_prep_mean_b0(amx_ctx *ctx, const amx_prep *p, const float *img, float *out_mean_b0_volume);
 int amx_prep_mean_b0_device(amx_ctx *ctx, const amx_prep *p, const float *d_img, float *d_mean_b0_volume,

@@ -255,6 +255,49 @@ def test_prepare_signal_sparse_and_full_masks(order, density):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('order', ['F', 'C'])
+@pytest.mark.parametrize('opts', [dict(), dict(do_normalize=False), dict(do_merge_b0=True)])
+@pytest.mark.parametrize('f32', [True, False])
+def test_gather_with_directions_equals_gather_then_tensor_fit(order, opts, f32):
+    """amx_prep_gather_directions_device[_f32] (the tensor fit rides on the gather's LDS tile: one pass over the image) against
+    amx_prep_gather_device + amx_dti_directions_device on the same image: y bit for bit, the directions to rounding (the fused
+    kernel sums the volumes in index order), on both memory orders, with and without normalisation / b0 merge, ragged mask"""
+    import torch
+    from amico_amd import prep, dti, _capi
+    sc = S.make_scheme()
+    img, mask = _volume((70, 9, 5), sc, order, seed=3)
+    sp = prep.SignalPreparation(sc, img, mask, **opts)
+    td = dti.TensorDirections.from_scheme(sc, do_merge_b0=opts.get('do_merge_b0', False), ctx=sp.ctx)
+    L, c = _capi.lib(), sp.ctx
+    dev = torch.device('cuda', 0)
+    flat = np.lib.stride_tricks.as_strided(img, shape=(img.size,), strides=(4,))
+    d_img = torch.from_numpy(flat.copy()).to(dev)
+    n, m = sp.n_vox, sp.n_out
+    ydt = torch.float32 if f32 else torch.float64
+    y_a, y_b = torch.zeros((n, m), dtype=ydt, device=dev), torch.zeros((n, m), dtype=ydt, device=dev)
+    mb_a, mb_b = torch.zeros(n, dtype=torch.float32, device=dev), torch.zeros(n, dtype=torch.float32, device=dev)
+    d_a, d_b = torch.zeros((n, 3), dtype=torch.float64, device=dev), torch.zeros((n, 3), dtype=torch.float64, device=dev)
+    norm = int(sp.do_normalize)
+    gather = L.amx_prep_gather_device_f32 if f32 else L.amx_prep_gather_device
+    fused = L.amx_prep_gather_directions_device_f32 if f32 else L.amx_prep_gather_directions_device
+    c.check(gather(c._h, sp._plan._h, d_img.data_ptr(), norm, 0.0, y_a.data_ptr(), mb_a.data_ptr(), None))
+    td.fit_device(y_a.data_ptr(), n, d_a.data_ptr(), None, f32=f32)
+    c.check(fused(c._h, sp._plan._h, td._dti._h, d_img.data_ptr(), norm, 0.0, y_b.data_ptr(), mb_b.data_ptr(), d_b.data_ptr(), None))
+    c.sync(None)
+    assert torch.equal(y_a, y_b) and torch.equal(mb_a, mb_b)
+    a, b = d_a.cpu().numpy(), d_b.cpu().numpy()
+    assert np.isfinite(b).all() == np.isfinite(a).all()
+    yv = y_a.cpu().numpy().astype(np.float64)
+    flat_row = np.ptp(np.log(np.maximum(yv, 1e-4)), axis=1) == 0.0          # (norm factor 0 -> a constant row: a zero tensor, any direction)
+    ok = np.isfinite(a).all(axis=1) & ~flat_row
+    assert ok.sum() > 0.9 * n and np.abs(a[ok] - b[ok]).max() < 1e-12
+    # a helper for another scheme is refused
+    other = dti.TensorDirections.from_scheme(S.make_scheme(shells=((1000.0, 8),), seed=1), ctx=sp.ctx)
+    with pytest.raises(Exception):
+        c.check(fused(c._h, sp._plan._h, other._dti._h, d_img.data_ptr(), norm, 0.0, y_b.data_ptr(), mb_b.data_ptr(), d_b.data_ptr(), None))
+
+
+@pytest.mark.gpu
 def test_prepare_signal_errors_and_edges():
     from amico_amd import prep
     sc = S.make_scheme(n_b0=0, shells=((1000.0, 8),), seed=1)
