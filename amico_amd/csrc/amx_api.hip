@@ -731,6 +731,7 @@ static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
         if (gcert2) {
             const bool wide = !ctx->opt_no_gcert_wide;
             if ((rc = amx_launch_noddi_gcert2(ctx, lut, a, pl, s, wide))) return rc;
+            a.cand_lists = 1;       // (k_lasso_gcert: the candidate lists of stage 3 wait in seeds2 for the voxels it settled)
             a.rlist = (const int *)ctx->rlist.p + amx_gcert2_leftover_offset(pl, wide); a.rcount = amx_gcert2_leftover_counts(pl, wide);   // (two wide passes end in the first half again)
             a.c.chunks = pl.schunks; a.c.n_chunks = pl.n_chunks + 1;
         }

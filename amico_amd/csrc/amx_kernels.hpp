@@ -150,6 +150,7 @@ struct NoddiArgs {
     int ldG;
     const unsigned long long *seeds;   // support seeds of the NNLS stage being run, bucket order (amx_seed.hpp), or null
     const unsigned long long *seeds2;  // passive-set seeds of the LASSO stage [n_vox][4], bucket order, or null
+    int cand_lists;                    // 1: the LASSO certificates left the stage-3 candidate byte lists in seeds2 for the voxels they settled (done == 1)
     const unsigned char *done;         // NNLS stages: [n_vox] bucket order, 1 = settled by k_nnls_gcert (skipped here), or null
     const int *rlist, *rcount;         // NNLS stages after k_nnls_gcert: the chunk list is the second plan's, chunk c works on the
                                        // rcount[c] bucket positions rlist[chunk start ...] (the voxels the Gram certificate left over)

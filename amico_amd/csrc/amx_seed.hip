@@ -205,7 +205,7 @@ int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a
     Gcert2Args g;
     memset(&g, 0, sizeof g);
     g.perm = pl.perm; g.schunks = pl.schunks; g.n_schunks = pl.n_chunks + 1;
-    g.seeds2 = (const unsigned long long *)ctx->seeds2.p; g.Cb = (const double *)ctx->cgemm.p; g.Cb2 = (const double *)ctx->cgemm2.p;
+    g.seeds2 = (const unsigned long long *)ctx->seeds2.p; g.cand8 = (unsigned long long *)ctx->seeds2.p; g.Cb = (const double *)ctx->cgemm.p; g.Cb2 = (const double *)ctx->cgemm2.p;
     g.cslot = (const int *)ctx->clip.p + pl.n; g.u2iso = lut->u2iso; g.rows = gemm_rows(lut->n_atoms); g.aux0 = lut->n_atoms;
     g.gram = lut->gram_dwi; g.colscale = lut->colscale; g.ldG = lut->ldG; g.n_atoms = lut->n_atoms; g.n_wm = lut->n_wm;
     g.iso_atom = lut->n_atoms - 1; g.dot_atom = lut->is_exvivo ? lut->n_atoms - 2 : -1;
@@ -332,6 +332,7 @@ int amx_launch_noddi_seed(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, 
 {
     SeedArgs sa; fill(sa, lut, a, pl, ctx);
     sa.supp = stage == 3 ? a.supp : nullptr;
+    if (stage == 3 && a.cand_lists && a.seeds2 != nullptr) { sa.cand8 = a.seeds2; sa.cdone = (const unsigned char *)ctx->done.p; }
     sa.trip_cap = ctx->opt_seed_tripcap[stage == 1 ? 0 : 2];
     // S for the per-lane gathers + ticket; stage 1 adds S in MFMA operand order (10 x 3 x 64) and a residual block per wavefront
     const size_t lds = (size_t)lut->n_atoms * kSeedLd * sizeof(double) + 64 +

@@ -218,6 +218,9 @@ struct SeedArgs {
     const double *Ub, *Sb;        // [ndirs][nS][KD], [ndirs][n_atoms][KD]
     double *ytil;                 // [n_vox][KD], bucket order (k_noddi_project), or
     unsigned long long *seeds;    // [n_vox], bucket order: up to 8 atom ids, one per byte, 0xff = empty; kNoSeed = none
+    // stage 3: the candidate byte lists the LASSO certificates left in the seeds2 array (k_lasso_gcert) for the voxels they settled
+    // (cdone[pos] == 1): 24 atom ids in ascending order in words 0 .. 2, their number in the top byte of word 3; null = none
+    const unsigned long long *cand8; const unsigned char *cdone;
     const unsigned long long *supp;   // stage 3: [n_vox][4] stage-2 support bit set (voxel order), null for stage 1
     int nS, n_atoms, iso_atom, dot_atom;
     int *gcount;                  // [max_schunks + 1]: voxels of each chunk handed out so far (zeroed before the launch); last: helpers
@@ -763,16 +766,29 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
                 const bool finite = true;
                 trips = 0; last_added = -1; ban0 = -1; ban1 = -1;
                 V.clear();
+                ncand = -1;                                     // (byte list below)
                 if (STAGE == 3) {
-                    const int vox = a.perm[pos];
+                    // the candidate list as the LASSO certificate left it (a settled voxel: 99.4 % of them), else from the support bits
+                    bool ready = false;
+                    if (a.cand8 != nullptr) {
+                        const unsigned long long *cl = a.cand8 + (size_t)pos * 4;
+                        const unsigned long long c0 = cl[0], c1 = cl[1], c2 = cl[2], c3 = cl[3];
+                        const int flag = (int)a.cdone[pos];
+                        ready = flag == 1;
+                        if (ready) { cand[0] = c0; cand[STAGE == 3 ? 1 : 0] = c1; cand[STAGE == 3 ? 2 : 0] = c2; cand[STAGE == 3 ? 3 : 0] = 0ull; ncand = (int)(c3 >> 56); }
+                    }
+                    if (__ballot(!ready) != 0ull) {
+                        if (!ready) {
+                            const int vox = a.perm[pos];
 #pragma unroll
-                    for (int q = 0; q < 4; q++) allow[q] = a.supp[(size_t)vox * 4 + q];
-                    allow[a.iso_atom >> 6] |= 1ull << (a.iso_atom & 63);
-                    if (a.dot_atom >= 0) allow[a.dot_atom >> 6] |= 1ull << (a.dot_atom & 63);
+                            for (int q = 0; q < 4; q++) allow[q] = a.supp[(size_t)vox * 4 + q];
+                            allow[a.iso_atom >> 6] |= 1ull << (a.iso_atom & 63);
+                            if (a.dot_atom >= 0) allow[a.dot_atom >> 6] |= 1ull << (a.dot_atom & 63);
+                        }
+                    }
                 }
                 if (finite) active = true;
                 else a.seeds[pos] = kNoSeed;
-                ncand = -1;                                     // (byte list below)
             }
         }
         if (__ballot(active) == 0ull) {
@@ -1976,6 +1992,7 @@ struct Gcert2Args {
     const Chunk *schunks;
     const int *n_schunks;
     const unsigned long long *seeds2;  // [n][4], bucket order
+    unsigned long long *cand8;         // = seeds2: a settled voxel's entry is overwritten with stage 3's candidate byte list (see below)
     const double *Cb;                  // [n_blocks][rows][64] of k_noddi_gemm<false>: c2, y2~, ||y2||^2 of the unclipped voxels derive from it
     const double *Cb2;                 // compact table of k_noddi_gemm<true>: the clipped voxels, exactly
     const int *cslot;                  // [n] bucket order: place in the chunk's compact list, -1 = not clipped
@@ -2064,6 +2081,7 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
         const int cnt = __builtin_popcountll(P[0]) + __builtin_popcountll(P[1]) + __builtin_popcountll(P[2]);
         bool okv = valid && flag == 0ull && cnt <= MS && (!WIDE || cnt > LOW);
         LeanLane<MS> V;
+        unsigned long long wl[3] = {0ull, 0ull, 0ull};          // the support's atoms as a byte list (stage 3's candidates: written out below)
         {
             // slots = set bits in ascending order
             unsigned long long rem[3] = {okv ? P[0] : 0ull, okv ? P[1] : 0ull, okv ? P[2] : 0ull};
@@ -2081,6 +2099,7 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
                 for (int qq = 0; qq < 3; qq++) rem[qq] = (wq == qq) ? (rem[qq] & (rem[qq] - 1ull)) : rem[qq];
                 if (wq >= 0 && t >= n_wm) okv = false;
                 V.idx[s] = (wq >= 0 && t < n_wm) ? t : 0;
+                wl[s >> 3] |= (unsigned long long)((wq >= 0 && t < n_wm) ? t : 0) << (8 * (s & 7));
                 n0 += (wq >= 0) ? 1 : 0;
             }
             V.np = okv ? n0 : 0;
@@ -2227,6 +2246,26 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
         if (cert) {
             unsigned long long *sp = a.supp + (size_t)vox * 4;
             sp[0] = P[0]; sp[1] = P[1]; sp[2] = P[2]; sp[3] = 0ull;
+            if (a.cand8 != nullptr) {
+                // What the stage-3 seed solver makes of these bits when it takes the voxel -- the admissible atoms (support, dot, iso) as a
+                // byte list in ascending order -- is in this lane's registers already: it goes where the voxel's seed was (nobody reads
+                // the seed of a settled voxel again).  The seed solver then takes a voxel with ONE 32-byte load by position instead
+                // of position -> voxel -> bits and a bit-by-bit conversion that every lane of the wavefront walked in every trip (a
+                // third of that kernel).
+                static_assert(MS + 2 <= 24, "the list is 24 bytes");
+                const int n_extra = a.dot_atom >= 0 ? 2 : 1;
+                const int e0 = a.dot_atom >= 0 ? a.dot_atom : a.iso_atom, e1 = a.iso_atom;
+                unsigned long long w[4] = {wl[0], wl[1], wl[2], 0ull};        // (the support's atoms were packed while the bits were decoded)
+#pragma unroll
+                for (int s = 1; s < MS + 2; s++) {
+                    const int b = (s == V.np ? e0 : ((s == V.np + 1 && n_extra == 2) ? e1 : 0));
+                    w[s >> 3] |= (unsigned long long)(b & 0xff) << (8 * (s & 7));
+                }
+                if (V.np == 0) w[0] |= (unsigned long long)(e0 & 0xff);
+                w[3] = (unsigned long long)(V.np + n_extra) << 56;
+                unsigned long long *cl = a.cand8 + (size_t)pos * 4;
+                cl[0] = w[0]; cl[1] = w[1]; cl[2] = w[2]; cl[3] = w[3];
+            }
             if (a.xdbg) {
                 double *dst = a.xdbg + ((size_t)vox * 3 + 1) * a.n_atoms;
                 for (int j = 0; j < a.n_atoms; j++) dst[j] = 0.0;
