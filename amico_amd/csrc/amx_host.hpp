@@ -89,7 +89,7 @@ struct amx_ctx {
     // voxels 12 need more than 32 stage-1 trips (mean ~10), yet with the old cap of 64 they held the kernel 0.4 ms longer.
     // Measured (tools/r04/tripcap2.sh; 50 000 / 200 000 / 1 M voxels, fit in ms): 64,64,64 2.09 / 3.31 / 8.17; 28,24,12 1.74 / 2.94 /
     // 7.66; below 20 / 18 / 8 the left-over kernels get more voxels than the shorter tails are worth
-    int opt_seed_tripcap[3] = {24, 24, 10};     // (28, 24, 12 before the normalised entering rule shortened the paths: tools/r04/round17.sh)
+    int opt_seed_tripcap[3] = {20, 20, 10};     // (28, 24, 12 before the normalised entering rule shortened the paths, 24, 24, 10 until the stage-1 solver handed its support on and the LASSO left-over solver started from the seed: profiles/r05b_tripcaps.txt)
     bool opt_no_hard_first = false; // AMX_NO_HARD_FIRST=1: the left-over kernels of the NNLS stages walk their lists in the order the certificates wrote them
     int opt_seed_waves = 0;        // AMX_SEED_WAVES: wavefronts per workgroup of the lane kernels (0 = by the number of chunks, make_plan)
     int opt_seed_stages = 7;       // AMX_SEED_STAGES: bit 0 = seed stage 1, bit 1 = seed stage 3, bit 2 = seed the LASSO stage
