@@ -222,6 +222,7 @@ int amx_ctx_create(int device, amx_ctx **out)
         ctx->opt_s2_exact = e && *e && *e != '0';
         auto on = [](const char *name) { const char *v = getenv(name); return v && *v && *v != '0'; };
         ctx->opt_no_gram = on("AMX_NO_GRAM"); ctx->opt_lasso_qr = on("AMX_LASSO_QR"); ctx->opt_cold_start = on("AMX_COLD_START");
+        { const char *t3 = getenv("AMX_GCERT2_THIRD"); if (t3 && *t3) ctx->opt_gcert2_third = atoi(t3) != 0 ? 1 : 0; }
         ctx->opt_host_one_shot = on("AMX_HOST_ONE_SHOT"); ctx->opt_host_one_stream = on("AMX_HOST_ONE_STREAM");
         ctx->opt_tile_f32 = on("AMX_TILE_F32"); ctx->opt_fw_proj_valu = on("AMX_FW_PROJ_VALU"); ctx->opt_sandi_atom_space = on("AMX_SANDI_ATOM_SPACE");
         ctx->opt_prep_tile = on("AMX_PREP_TILE"); ctx->opt_prep_scalar = on("AMX_PREP_SCALAR"); ctx->opt_lut_regs = on("AMX_LUT_REGS"); ctx->opt_no_refill = on("AMX_NO_REFILL");
@@ -732,7 +733,8 @@ static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
             const bool wide = !ctx->opt_no_gcert_wide;
             if ((rc = amx_launch_noddi_gcert2(ctx, lut, a, pl, s, wide))) return rc;
             a.cand_lists = 1;       // (k_lasso_gcert: the candidate lists of stage 3 wait in seeds2 for the voxels it settled)
-            a.rlist = (const int *)ctx->rlist.p + amx_gcert2_leftover_offset(pl, wide); a.rcount = amx_gcert2_leftover_counts(pl, wide);   // (two wide passes end in the first half again)
+            const bool third = amx_gcert2_third(ctx, lut, wide);
+            a.rlist = (const int *)ctx->rlist.p + amx_gcert2_leftover_offset(pl, wide, third); a.rcount = amx_gcert2_leftover_counts(pl, wide, third);   // (two wide passes end in the first half again)
             a.c.chunks = pl.schunks; a.c.n_chunks = pl.n_chunks + 1;
         }
         rec(ctx, 13, s);

@@ -252,10 +252,17 @@ struct GramSolver {
                 for (int u = 0; u < 4; u++) {
                     const int t = bcast_i(idx, (s0 + u < np) ? s0 + u : np - 1);
                     p[u] = 0.0;
+                    if constexpr (is_global_tile<AT>::value || AMX_TILE_COL_LDS != 0) {
+                        double col[NR];
+                        tile_column<NR, AT>(As, ldA, nS, t, lane, rowok, col);
 #pragma unroll
-                    for (int rr = 0; rr < NR; rr++) {
-                        const int i = lane + kWave * rr;
-                        if (i < nS && rowok[rr]) p[u] += (double)As[i * ldA + t] * yr[rr];
+                        for (int rr = 0; rr < NR; rr++) p[u] += col[rr] * yr[rr];
+                    } else {
+#pragma unroll
+                        for (int rr = 0; rr < NR; rr++) {
+                            const int i = lane + kWave * rr;
+                            if (i < nS && rowok[rr]) p[u] += (double)As[i * ldA + t] * yr[rr];
+                        }
                     }
                 }
                 wave_sum4(p, lane);
@@ -269,10 +276,17 @@ struct GramSolver {
             for (int s = 0; s < np; s++) {
                 const int t = bcast_i(idx, s);
                 const double cx = bcast(sc * x, s);
+                if constexpr (is_global_tile<AT>::value || AMX_TILE_COL_LDS != 0) {
+                    double col[NR];
+                    tile_column<NR, AT>(As, ldA, nS, t, lane, rowok, col);
 #pragma unroll
-                for (int rr = 0; rr < NR; rr++) {
-                    const int i = lane + kWave * rr;
-                    if (i < nS && rowok[rr]) r[rr] -= (double)As[i * ldA + t] * cx;
+                    for (int rr = 0; rr < NR; rr++) r[rr] -= col[rr] * cx;
+                } else {
+#pragma unroll
+                    for (int rr = 0; rr < NR; rr++) {
+                        const int i = lane + kWave * rr;
+                        if (i < nS && rowok[rr]) r[rr] -= (double)As[i * ldA + t] * cx;
+                    }
                 }
             }
         }
@@ -327,10 +341,17 @@ struct GramSolver {
                     const int t = kWave * q + tl;
                     todo &= todo - 1ull;
                     double p = 0.0;
+                    if constexpr (is_global_tile<AT>::value || AMX_TILE_COL_LDS != 0) {
+                        double col[NR];
+                        tile_column<NR, AT>(As, ldA, nS, t, lane, rowok, col);
 #pragma unroll
-                    for (int rr = 0; rr < NR; rr++) {
-                        const int i = lane + kWave * rr;
-                        if (i < nS && rowok[rr]) p += (double)As[i * ldA + t] * r[rr];
+                        for (int rr = 0; rr < NR; rr++) p += col[rr] * r[rr];
+                    } else {
+#pragma unroll
+                        for (int rr = 0; rr < NR; rr++) {
+                            const int i = lane + kWave * rr;
+                            if (i < nS && rowok[rr]) p += (double)As[i * ldA + t] * r[rr];
+                        }
                     }
                     p = wave_sum(p);
                     const double gt = bcast(scl[q], tl) * p - lam1;
@@ -437,10 +458,17 @@ struct GramSolver {
                 for (int sl = 0; sl < np; sl++) {
                     const int a = bcast_i(idx, sl);
                     const double cx = bcast(sc * x, sl);
+                    if constexpr (is_global_tile<AT>::value || AMX_TILE_COL_LDS != 0) {
+                        double col[NR];
+                        tile_column<NR, AT>(As, ldA, nS, a, lane, rowok, col);
 #pragma unroll
-                    for (int rr = 0; rr < NR; rr++) {
-                        const int i = lane + kWave * rr;
-                        if (i < nS && rowok[rr]) r[rr] -= (double)As[i * ldA + a] * cx;
+                        for (int rr = 0; rr < NR; rr++) r[rr] -= col[rr] * cx;
+                    } else {
+#pragma unroll
+                        for (int rr = 0; rr < NR; rr++) {
+                            const int i = lane + kWave * rr;
+                            if (i < nS && rowok[rr]) r[rr] -= (double)As[i * ldA + a] * cx;
+                        }
                     }
                 }
 #pragma unroll

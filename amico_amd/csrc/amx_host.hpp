@@ -75,6 +75,7 @@ struct amx_ctx {
     bool opt_wave_per_voxel = false;   // AMX_WAVE_PER_VOXEL=1: small models by the wavefront-per-voxel kernels
     int opt_refill_chunk = 0;          // AMX_REFILL_CHUNK: voxels per workgroup of k_freewater_refill (0 = by problem size)
     bool opt_no_chunk_order = false; // AMX_NO_CHUNK_ORDER=1: the chunks of the second plan stay in orientation order (default: longest first)
+    int opt_gcert2_third = -1;      // AMX_GCERT2_THIRD=0 / 1: never / always a third LASSO certificate pass (default: where the tile is read from L2)
     bool opt_no_gcert_wide = false; // AMX_NO_GCERT_WIDE=1: no second Gram-certificate pass for LASSO supports of 13 .. 16 atoms
     int64_t opt_rescue_from = 2000000;   // AMX_RESCUE_FROM=n: calls of n voxels and more run the rescue pass of the NNLS certificates (k_nnls_gcert<., true>)
     bool opt_no_gcert = false;     // AMX_NO_GCERT=1: every seed is certified by the wavefront-per-voxel kernels (true residual)
@@ -254,8 +255,9 @@ int amx_launch_noddi_gemm(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs
 int amx_launch_noddi_s2prep(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s);
 int amx_gemm_ksteps(const amx_lut *lut);   // K-steps of the table kernels for this dictionary (25 / 40), 0 = shape not supported
 int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, bool wide);
-size_t amx_gcert2_leftover_offset(const Plan &pl, bool wide);      // which half of ctx->rlist the LASSO certificate passes end in (amx_seed.hip)
-const int *amx_gcert2_leftover_counts(const Plan &pl, bool wide);  // ... and the per-chunk counts of those lists (Plan::zcount)
+bool amx_gcert2_third(const amx_ctx *ctx, const amx_lut *lut, bool wide);   // a third LASSO certificate pass for this dictionary? (amx_seed.hip)
+size_t amx_gcert2_leftover_offset(const Plan &pl, bool wide, bool third);      // which half of ctx->rlist the LASSO certificate passes end in (amx_seed.hip)
+const int *amx_gcert2_leftover_counts(const Plan &pl, bool wide, bool third);  // ... and the per-chunk counts of those lists (Plan::zcount)
 static inline size_t amx_rlist_half(const Plan &pl) { return (size_t)pl.n + pl.max_schunks + 64; }   // ints per left-over list + counts
 int amx_launch_noddi_seed2(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, bool have_ytil2);
 int amx_launch_noddi_s1(amx_ctx *ctx, amx::NoddiArgs &a, const Plan &pl, hipStream_t s);

@@ -190,18 +190,28 @@ int amx_launch_noddi_s2prep(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a
     return amx_launch_noddi_gemm(ctx, lut, a, pl, s, true);
 }
 
-size_t amx_gcert2_leftover_offset(const Plan &pl, bool wide)
+size_t amx_gcert2_leftover_offset(const Plan &pl, bool wide, bool third)
 {
-    return (wide && !(kGcert2Wide3 > kGcert2Wide)) ? amx_rlist_half(pl) : 0;      // (an even number of passes after the first ends in the first half again)
+    return (wide && !third) ? amx_rlist_half(pl) : 0;      // (an even number of passes after the first ends in the first half again)
 }
-const int *amx_gcert2_leftover_counts(const Plan &pl, bool wide)
+const int *amx_gcert2_leftover_counts(const Plan &pl, bool wide, bool third)
 {
-    return pl.zcount(!wide ? ZC_CERT2 : (kGcert2Wide3 > kGcert2Wide ? ZC_CERT2W3 : ZC_CERT2W));
+    return pl.zcount(!wide ? ZC_CERT2 : (third ? ZC_CERT2W3 : ZC_CERT2W));
+}
+// A third pass (supports of 19 .. 24 atoms, the triangle mostly in scratch) pays where a left-over voxel is expensive: shapes whose
+// wavefront-per-voxel kernels read their tile from L2 (a 288-volume protocol leaves 6.8 % of the voxels after two passes: 6.5 of that
+// fit's 24 ms went to k_noddi<4, .., GT>).  At 99 volumes it is a wash (round 3: 10.34 against 10.33 ms).  AMX_GCERT2_THIRD=0 / 1 forces.
+bool amx_gcert2_third(const amx_ctx *ctx, const amx_lut *lut, bool wide)
+{
+    if (!wide || !(kGcert2Wide3 > kGcert2Wide)) return false;
+    if (ctx->opt_gcert2_third >= 0) return ctx->opt_gcert2_third != 0;
+    return amx_noddi_tile_global(lut->nS, lut->ldA, lut->n_atoms);
 }
 
 // Gram-space certificates of the LASSO seeds (k_lasso_gcert): support bits of the voxels it settles, left-over lists for k_noddi<4>
 int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, const Plan &pl, hipStream_t s, bool wide)
 {
+    const bool third = amx_gcert2_third(ctx, lut, wide);
     Gcert2Args g;
     memset(&g, 0, sizeof g);
     g.perm = pl.perm; g.schunks = pl.schunks; g.n_schunks = pl.n_chunks + 1;
@@ -234,7 +244,7 @@ int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a
         hipLaunchKernelGGL((k_lasso_gcert<kGcert2Wide, true>), dim3(((pl.max_schunks + 7) / 8) * 8), dim3(64 * pl.seed_waves), lds, s, g);
         AMX_TRACE(ctx, s, "Gram-space certificates of the LASSO seeds, supports of 12 .. 18 atoms");
         HIPCHK(ctx, hipGetLastError());
-        if (kGcert2Wide3 > kGcert2Wide) {
+        if (third) {
             // third pass: supports beyond the second pass from the second pass's left-overs, back into the first half of the buffer
             g.rlist_in = g.rlist; g.rcount_in = g.rcount;
             g.rlist = (int *)ctx->rlist.p; g.rcount = pl.zcount(ZC_CERT2W3);

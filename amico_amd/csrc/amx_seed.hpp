@@ -219,7 +219,7 @@ struct SeedArgs {
     double *ytil;                 // [n_vox][KD], bucket order (k_noddi_project), or
     unsigned long long *seeds;    // [n_vox], bucket order: up to 8 atom ids, one per byte, 0xff = empty; kNoSeed = none
     // stage 3: the candidate byte lists the LASSO certificates left in the seeds2 array (k_lasso_gcert) for the voxels they settled
-    // (cdone[pos] == 1): 24 atom ids in ascending order in words 0 .. 2, their number in the top byte of word 3; null = none
+    // (cdone[pos] == 1): up to 31 atom ids in ascending order, their number in the top byte of word 3; null = none
     const unsigned long long *cand8; const unsigned char *cdone;
     const unsigned long long *supp;   // stage 3: [n_vox][4] stage-2 support bit set (voxel order), null for stage 1
     int nS, n_atoms, iso_atom, dot_atom;
@@ -775,7 +775,7 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
                         const unsigned long long c0 = cl[0], c1 = cl[1], c2 = cl[2], c3 = cl[3];
                         const int flag = (int)a.cdone[pos];
                         ready = flag == 1;
-                        if (ready) { cand[0] = c0; cand[STAGE == 3 ? 1 : 0] = c1; cand[STAGE == 3 ? 2 : 0] = c2; cand[STAGE == 3 ? 3 : 0] = 0ull; ncand = (int)(c3 >> 56); }
+                        if (ready) { cand[0] = c0; cand[STAGE == 3 ? 1 : 0] = c1; cand[STAGE == 3 ? 2 : 0] = c2; cand[STAGE == 3 ? 3 : 0] = c3 & 0x00ffffffffffffffull; ncand = (int)(c3 >> 56); }
                     }
                     if (__ballot(!ready) != 0ull) {
                         if (!ready) {
@@ -1982,9 +1982,9 @@ constexpr int kGcert2Max = AMX_GCERT2_MAX;
 #endif
 constexpr int kGcert2Wide = AMX_GCERT2_WIDE;   // second pass (k_lasso_gcert<.., true>)
 #ifndef AMX_GCERT2_WIDE3
-#define AMX_GCERT2_WIDE3 18
+#define AMX_GCERT2_WIDE3 24
 #endif
-constexpr int kGcert2Wide3 = AMX_GCERT2_WIDE3; // optional third pass over what the second left (> kGcert2Wide enables it).  Measured, 1 M voxels, fit ms:
+constexpr int kGcert2Wide3 = AMX_GCERT2_WIDE3; // third pass over what the second left: a RUN-TIME choice (amx_launch_noddi_gcert2: shapes whose left-over kernel reads its tile from L2).  Round 3, 99 volumes, 1 M voxels, fit ms:
                                                // 12 / 16: 10.46; 12 / 18: 10.33 (121 spilled registers, but the left-over kernel sees 1.0 % instead of 2.3 %
                                                // of the voxels); 12 / 19: 10.35; 12 / 20: 10.42; 12 / 16 / 18: 10.34; 12 / 16 / 20: 10.42
 struct Gcert2Args {
@@ -2081,7 +2081,7 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
         const int cnt = __builtin_popcountll(P[0]) + __builtin_popcountll(P[1]) + __builtin_popcountll(P[2]);
         bool okv = valid && flag == 0ull && cnt <= MS && (!WIDE || cnt > LOW);
         LeanLane<MS> V;
-        unsigned long long wl[3] = {0ull, 0ull, 0ull};          // the support's atoms as a byte list (stage 3's candidates: written out below)
+        unsigned long long wl[4] = {0ull, 0ull, 0ull, 0ull};    // the support's atoms as a byte list (stage 3's candidates: written out below)
         {
             // slots = set bits in ascending order
             unsigned long long rem[3] = {okv ? P[0] : 0ull, okv ? P[1] : 0ull, okv ? P[2] : 0ull};
@@ -2252,17 +2252,17 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
                 // the seed of a settled voxel again).  The seed solver then takes a voxel with ONE 32-byte load by position instead
                 // of position -> voxel -> bits and a bit-by-bit conversion that every lane of the wavefront walked in every trip (a
                 // third of that kernel).
-                static_assert(MS + 2 <= 24, "the list is 24 bytes");
+                static_assert(MS + 2 <= 31, "the list is 31 bytes and its length");
                 const int n_extra = a.dot_atom >= 0 ? 2 : 1;
                 const int e0 = a.dot_atom >= 0 ? a.dot_atom : a.iso_atom, e1 = a.iso_atom;
-                unsigned long long w[4] = {wl[0], wl[1], wl[2], 0ull};        // (the support's atoms were packed while the bits were decoded)
+                unsigned long long w[4] = {wl[0], wl[1], wl[2], wl[3]};        // (the support's atoms were packed while the bits were decoded)
 #pragma unroll
                 for (int s = 1; s < MS + 2; s++) {
                     const int b = (s == V.np ? e0 : ((s == V.np + 1 && n_extra == 2) ? e1 : 0));
                     w[s >> 3] |= (unsigned long long)(b & 0xff) << (8 * (s & 7));
                 }
                 if (V.np == 0) w[0] |= (unsigned long long)(e0 & 0xff);
-                w[3] = (unsigned long long)(V.np + n_extra) << 56;
+                w[3] = (w[3] & 0x00ffffffffffffffull) | ((unsigned long long)(V.np + n_extra) << 56);
                 unsigned long long *cl = a.cand8 + (size_t)pos * 4;
                 cl[0] = w[0]; cl[1] = w[1]; cl[2] = w[2]; cl[3] = w[3];
             }

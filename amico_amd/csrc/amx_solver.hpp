@@ -223,6 +223,38 @@ __device__ __forceinline__ void tile_sweep(const AT *ap, int ldA, int nS, const 
     }
 }
 
+// The rows lane + 64 rr of column t: the loads under their guards into registers, the conversions OUTSIDE the guards -- all NR loads of
+// the column in flight together; `cond ? (double)As[..] : 0` makes the compiler wait inside every guard (the raw columns of a 12-atom
+// seed: 96 L2 round trips one after the other per left-over voxel of a 288-volume protocol, 24 LDS round trips at 99 volumes).
+// Measured (profiles/r05b_tile_column_ab.txt): nothing at 288 volumes (those kernels wait elsewhere), 0.5 - 1 % of the 99-volume fit
+// with the LDS tiles built the same way (AMX_TILE_COL_LDS=0: the guarded form).
+#ifndef AMX_TILE_COL_LDS
+#define AMX_TILE_COL_LDS 1
+#endif
+template <int NR, typename AT>
+__device__ __forceinline__ void tile_column(const AT *As, int ldA, int nS, int t, int lane, const bool (&rowok)[NR], double (&col)[NR])
+{
+    if constexpr (is_global_tile<AT>::value || AMX_TILE_COL_LDS != 0) {
+        AT raw[NR] = {};
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) {
+            const int i = lane + kWave * rr;
+            if (i < nS && rowok[rr]) raw[rr] = As[i * ldA + t];
+        }
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) {
+            const int i = lane + kWave * rr;
+            col[rr] = (i < nS && rowok[rr]) ? (double)raw[rr] : 0.0;
+        }
+    } else {
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) {
+            const int i = lane + kWave * rr;
+            col[rr] = (i < nS && rowok[rr]) ? (double)As[i * ldA + t] : 0.0;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ the solver
 // NR   rows per lane   (nS      <= 64*NR)
 // NQ   atoms per lane  (n_atoms <= 64*NQ)
@@ -464,11 +496,7 @@ struct NNSolver {
             for (int m = 0; m < MAXP; m++) {
                 if (m < np) {
                     const int t = bcast_i(idx, m);
-#pragma unroll
-                    for (int rr = 0; rr < NR; rr++) {
-                        const int i = lane + kWave * rr;
-                        Q[m][rr] = (i < nS && rowok[rr]) ? (double)As[i * ldA + t] : 0.0;
-                    }
+                    tile_column<NR, AT>(As, ldA, nS, t, lane, rowok, Q[m]);
                 }
             }
             const int li = (lane < MAXP ? lane : MAXP) * LDR;
@@ -613,10 +641,17 @@ struct NNSolver {
                     for (int u = 0; u < 4; u++) {
                         p[u] = 0.0;
                         const int t = t4[u] < 0 ? t4[0] : t4[u];
+                        if constexpr (is_global_tile<AT>::value || AMX_TILE_COL_LDS != 0) {
+                            double col[NR];
+                            tile_column<NR, AT>(As, ldA, nS, t, lane, rowok, col);
 #pragma unroll
-                        for (int rr = 0; rr < NR; rr++) {
-                            const int i = lane + kWave * rr;
-                            if (i < nS && rowok[rr]) p[u] += (double)As[i * ldA + t] * r[rr];
+                            for (int rr = 0; rr < NR; rr++) p[u] += col[rr] * r[rr];
+                        } else {
+#pragma unroll
+                            for (int rr = 0; rr < NR; rr++) {
+                                const int i = lane + kWave * rr;
+                                if (i < nS && rowok[rr]) p[u] += (double)As[i * ldA + t] * r[rr];
+                            }
                         }
                     }
                     if (t4[1] >= 0) wave_sum4(p, lane);
@@ -851,11 +886,15 @@ struct NNSolver {
                 // candidate column (row space) and its ridge rows (slot space)
                 double v[NR];
                 double vsq = 0.0;
+                {
+                    double col[NR];
+                    tile_column<NR, AT>(As, ldA, nS, t, lane, rowok, col);
 #pragma unroll
-                for (int rr = 0; rr < NR; rr++) {
-                    const int i = lane + kWave * rr;
-                    v[rr] = (i < nS && rowok[rr]) ? sct * (double)As[i * ldA + t] : 0.0;
-                    vsq += v[rr] * v[rr];
+                    for (int rr = 0; rr < NR; rr++) {
+                        const int i = lane + kWave * rr;
+                        v[rr] = (i < nS && rowok[rr]) ? sct * col[rr] : 0.0;
+                        vsq += v[rr] * v[rr];
+                    }
                 }
                 double va = (RIDGE && lane == np) ? sqlam2 : 0.0;
                 const int ls = (lane < MAXP ? lane : MAXP - 1) * LDR;   // this lane's ridge row in Ql
