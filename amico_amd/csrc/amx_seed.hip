@@ -68,6 +68,11 @@ int amx_launch_noddi_seed2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a,
     sa.nS = lut->nS; sa.n_wm = lut->n_wm; sa.iso_atom = lut->n_atoms - 1; sa.is_exvivo = lut->is_exvivo;
     sa.lam1 = a.c.lam1; sa.lam2 = a.c.lam2;
     sa.trip_cap = ctx->opt_seed_tripcap[1];
+    // supports of up to 24 atoms are certified lane-per-voxel where the third pass runs: the seed solver goes on to 26 atoms there
+    // (and gets 2 atoms per trip: the trip cap grows with it); elsewhere 20 (the second pass ends at 18)
+    sa.max_atoms = 20;
+    if (ctx->opt_seed2_maxatoms > 0) sa.max_atoms = ctx->opt_seed2_maxatoms;
+    else if (have_ytil2 && amx_gcert2_third(ctx, lut, !ctx->opt_no_gcert_wide)) { sa.max_atoms = 26; sa.trip_cap += 6; }
 #ifdef AMX_STATS
     sa.stats = a.c.status + ST_SEED + 20;
 #endif

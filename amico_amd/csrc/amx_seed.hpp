@@ -2320,6 +2320,7 @@ struct Seed2Args {
     int *stats;
     double *trace;                // SEED2_TRACE: per-trip records of the voxel at bucket position 0
     int trip_cap;                 // see SeedArgs
+    int max_atoms;                // a voxel whose passive set reaches this many atoms and wants more is given up (its set goes on as an incomplete seed)
 };
 
 template <int NR>
@@ -2632,10 +2633,11 @@ __global__ void __launch_bounds__(256, OCC2 ? 2 : AMX_SEED2_OCC) k_lasso_seed(co
         if (active) {
             const int cnt = __builtin_popcountll(P[0]) + __builtin_popcountll(P[1]) + __builtin_popcountll(P[2]);
             const bool add1 = best > tol && bj < n_wm, add2 = best2 > tol && bj2 < n_wm;
-            if (dj >= 0) { jj = dj; sigma = -1.0; if (add1 && cnt < 20) { jj2 = bj; sigma2 = 1.0; } }
-            else if (add1) { jj = bj; sigma = 1.0; if (add2 && cnt < 19) { jj2 = bj2; sigma2 = 1.0; } }
+            const int mx = a.max_atoms;            // (20; 26 where a third certificate pass takes supports of up to 24 atoms)
+            if (dj >= 0) { jj = dj; sigma = -1.0; if (add1 && cnt < mx) { jj2 = bj; sigma2 = 1.0; } }
+            else if (add1) { jj = bj; sigma = 1.0; if (add2 && cnt < mx - 1) { jj2 = bj2; sigma2 = 1.0; } }
             else done = true;
-            if (!done && (trips > trip_cap || (sigma > 0.0 && cnt >= 20))) { done = true; noseed = true; jj = -1; sigma = 0.0; jj2 = -1; sigma2 = 0.0; }
+            if (!done && (trips > trip_cap || (sigma > 0.0 && cnt >= mx))) { done = true; noseed = true; jj = -1; sigma = 0.0; jj2 = -1; sigma2 = 0.0; }
         }
 #pragma unroll 1
         for (int ch = 0; ch < 2; ch++) {
