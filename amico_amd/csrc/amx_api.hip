@@ -223,6 +223,7 @@ int amx_ctx_create(int device, amx_ctx **out)
         auto on = [](const char *name) { const char *v = getenv(name); return v && *v && *v != '0'; };
         ctx->opt_no_gram = on("AMX_NO_GRAM"); ctx->opt_lasso_qr = on("AMX_LASSO_QR"); ctx->opt_cold_start = on("AMX_COLD_START");
         { const char *m2 = getenv("AMX_SEED2_MAXATOMS"); if (m2 && *m2) { const int v = atoi(m2); ctx->opt_seed2_maxatoms = v < 8 ? 8 : (v > 30 ? 30 : v); } }
+        { const char *rp = getenv("AMX_GCERT_REPAIR"); if (rp && *rp) ctx->opt_gcert_repair = atoi(rp) != 0 ? 1 : 0; }
         { const char *t3 = getenv("AMX_GCERT2_THIRD"); if (t3 && *t3) ctx->opt_gcert2_third = atoi(t3) != 0 ? 1 : 0; }
         ctx->opt_host_one_shot = on("AMX_HOST_ONE_SHOT"); ctx->opt_host_one_stream = on("AMX_HOST_ONE_STREAM");
         ctx->opt_tile_f32 = on("AMX_TILE_F32"); ctx->opt_fw_proj_valu = on("AMX_FW_PROJ_VALU"); ctx->opt_sandi_atom_space = on("AMX_SANDI_ATOM_SPACE");

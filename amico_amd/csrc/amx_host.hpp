@@ -76,6 +76,7 @@ struct amx_ctx {
     int opt_refill_chunk = 0;          // AMX_REFILL_CHUNK: voxels per workgroup of k_freewater_refill (0 = by problem size)
     bool opt_no_chunk_order = false; // AMX_NO_CHUNK_ORDER=1: the chunks of the second plan stay in orientation order (default: longest first)
     int opt_seed2_maxatoms = 0;     // AMX_SEED2_MAXATOMS=n: atoms at which the LASSO seed solver gives a voxel up (default 20, 26 with a third certificate pass; <= 30)
+    int opt_gcert_repair = -1;      // AMX_GCERT_REPAIR=0 / 1: never / always the NNLS certificates' second look at a mendable seed (default: where the tile is read from L2)
     int opt_gcert2_third = -1;      // AMX_GCERT2_THIRD=0 / 1: never / always a third LASSO certificate pass (default: where the tile is read from L2)
     bool opt_no_gcert_wide = false; // AMX_NO_GCERT_WIDE=1: no second Gram-certificate pass for LASSO supports of 13 .. 16 atoms
     int64_t opt_rescue_from = 2000000;   // AMX_RESCUE_FROM=n: calls of n voxels and more run the rescue pass of the NNLS certificates (k_nnls_gcert<., true>)

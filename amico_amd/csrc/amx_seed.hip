@@ -289,9 +289,18 @@ int amx_launch_noddi_gcert(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a,
     const size_t lds = ((size_t)lut->n_atoms * kSeedLd + 2 + (size_t)10 * (kSeedKD / 4) * 64 + (size_t)4 * 64 * 16) * sizeof(double);
     const dim3 grid(((pl.max_schunks + 7) / 8) * 8);
     int rc;
-    if (stage == 1) {
+    // a second look at the seeds a lane can mend itself (k_nnls_gcert<.., REPAIR>): where a left-over voxel is expensive and the seeds are
+    // wrong more often -- the shapes whose tile is read from L2 (AMX_GCERT_REPAIR=0 / 1 forces)
+    const bool repair = ctx->opt_gcert_repair >= 0 ? ctx->opt_gcert_repair != 0 : amx_noddi_tile_global(lut->nS, lut->ldA, lut->n_atoms);
+    if (stage == 1 && repair) {
+        if ((rc = set_lds(ctx, (k_nnls_gcert<1, false, true>), lds))) return rc;
+        hipLaunchKernelGGL((k_nnls_gcert<1, false, true>), grid, dim3(64 * pl.seed_waves), lds, s, g);
+    } else if (stage == 1) {
         if ((rc = set_lds(ctx, k_nnls_gcert<1>, lds))) return rc;
         hipLaunchKernelGGL(k_nnls_gcert<1>, grid, dim3(64 * pl.seed_waves), lds, s, g);
+    } else if (repair) {
+        if ((rc = set_lds(ctx, (k_nnls_gcert<3, false, true>), lds))) return rc;
+        hipLaunchKernelGGL((k_nnls_gcert<3, false, true>), grid, dim3(64 * pl.seed_waves), lds, s, g);
     } else {
         if ((rc = set_lds(ctx, k_nnls_gcert<3>, lds))) return rc;
         hipLaunchKernelGGL(k_nnls_gcert<3>, grid, dim3(64 * pl.seed_waves), lds, s, g);

@@ -1544,7 +1544,16 @@ struct GcertArgs {
     int *stats;
 };
 
-template <int STAGE, bool RESCUE = false>
+// REPAIR (round 5; long protocols, where the compressed-space seed is wrong in 4.5 % of the voxels instead of 0.9 %): a lane whose seed
+// fails for ONE reason the lane itself can mend gets a second look in the same block -- a coefficient that came out non-positive: those
+// atoms leave; a positive dual value outside the support: the most violating atom enters -- and the whole certificate (gather, factor,
+// solve, screening, exact dual values) runs once more on the mended support.  tools/lab/repair_lab.py: at 288 volumes one such step
+// settles 2.8 of the 4.5 % (the left-over kernel reads its tile from L2 there: ~300 us per voxel); at 99 volumes 0.08 of 0.87 %, and
+// every third block would pay a second pass for it: off there.
+#ifndef AMX_REPAIR_ROUNDS
+#define AMX_REPAIR_ROUNDS 1
+#endif
+template <int STAGE, bool RESCUE = false, bool REPAIR = false>
 __global__ void __launch_bounds__(256, RESCUE ? 1 : 2) k_nnls_gcert(const GcertArgs a)
 {
     constexpr int KD = kSeedKD, KS = KD / 4, MT = 10, MS = 8, LD = kSeedLd, RBW = 16;
@@ -1625,6 +1634,10 @@ __global__ void __launch_bounds__(256, RESCUE ? 1 : 2) k_nnls_gcert(const GcertA
             }
             V.np = okv ? n0 : 0;
         }
+        static_assert(!(RESCUE && REPAIR), "the rescue pass takes the first pass's lists as they are");
+        bool cert_any = false, easy_any = false, live = true;
+#pragma unroll 1
+        for (int rep = 0; rep < (REPAIR ? AMX_REPAIR_ROUNDS + 1 : 1); rep++) {
         unsigned long long cand[3] = {~0ull, ~0ull, ~0ull};          // admissible atoms outside the seed
         if (STAGE == 3) {
 #pragma unroll
@@ -1774,6 +1787,8 @@ __global__ void __launch_bounds__(256, RESCUE ? 1 : 2) k_nnls_gcert(const GcertA
         // ---- exact (Gram-form) dual values of the flagged atoms: u_t = c_t - G_tP x
         bool viol = false;
         int n_ex = 0;
+        double umax = 0.0;                      // REPAIR: the largest positive exact dual value and its atom
+        int tmax = -1;
         {
             // (UN flagged atoms per step: their 1 + np loads are independent and in flight together -- one atom per step made this loop,
             //  a chain of L2 round trips as long as the wavefront's LONGEST list, 72 % of the kernel)
@@ -1821,30 +1836,21 @@ __global__ void __launch_bounds__(256, RESCUE ? 1 : 2) k_nnls_gcert(const GcertA
 #pragma unroll
                     for (int s = 0; s < MS; s++) u -= gg[u4][s] * V.x[s];
                     if (on[u4] && !(u < -1e-10)) viol = true;             // positive, or too close to zero for the Gram form to call
+                    if (REPAIR && on[u4] && u > umax) { umax = u; tmax = tt[u4]; }
                     n_ex += on[u4] ? 1 : 0;
                 }
             }
         }
         GC_PH(3);
-        const bool cert = good && !viol;
+        const bool cert = live && good && !viol;
         // done = 2: refused for the conditioning of its Gram block alone -- the support is most likely right, and the left-over kernel's
         // certificate on the true residual settles it in ~15 us; 0: wrong or no seed, ~140 us of Lawson-Hanson.  The left-over kernel
         // starts the long ones first (k_noddi)
-        const bool easy = !RESCUE && okv && ill && (pmin > kRescuePivot * pmax);
-        if (valid) a.done[pos] = cert ? 1 : (easy ? 2 : 0);
-        {
-            // the voxels left to the wavefront-per-voxel kernel, compacted per chunk (that kernel then shares out real work only)
-            const unsigned long long rm = __ballot(valid && !cert);
-            if (rm != 0ull) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&a.rcount[cid], __builtin_popcountll(rm));
-                base = __builtin_amdgcn_readfirstlane(base);
-                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(rm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)rm, 0u));
-                if (valid && !cert) a.rlist[ck.start + base + rank] = pos;
-            }
-        }
+        const bool easy = !RESCUE && live && okv && ill && (pmin > kRescuePivot * pmax);
+        cert_any = cert_any || cert;
+        if (rep == 0) easy_any = easy;
 #ifdef AMX_STATS
-        if (a.stats && !RESCUE) {
+        if (a.stats && !RESCUE && rep == 0) {
             const int nc = __builtin_popcountll(__ballot(cert)), nv = __builtin_popcountll(__ballot(valid));
             const int npv = __builtin_popcountll(__ballot(valid && okv && !piv)), nfe = __builtin_popcountll(__ballot(valid && okv && piv && !feas)), nvi = __builtin_popcountll(__ballot(valid && good && viol));
             if (lane == 0) { atomicAdd(&a.stats[0], nv); atomicAdd(&a.stats[1], nc); atomicAdd(&a.stats[2], npv); atomicAdd(&a.stats[3], nfe); atomicAdd(&a.stats[4], nvi); }
@@ -1900,7 +1906,51 @@ __global__ void __launch_bounds__(256, RESCUE ? 1 : 2) k_nnls_gcert(const GcertA
                 for (int s = 0; s < MS; s++) if (s < V.np) dst[V.idx[s]] = V.x[s];
             }
         }
+        if (REPAIR && rep < AMX_REPAIR_ROUNDS) {
+            // who gets a second look: a well-conditioned block with a non-positive coefficient (those atoms leave), or with every
+            // coefficient positive and a positive dual value outside (that atom enters)
+            const bool base = live && valid && okv && !cert && piv && !ill && (yy <= 1.79769313486231570e308) && V.np > 0;
+            const bool drop = base && !feas;
+            const bool add = base && feas && viol && tmax >= 0 && V.np < MS;
+            if (__ballot(drop || add) == 0ull) break;
+            if (drop) {
+                int nidx[MS], nn = 0;
+#pragma unroll
+                for (int d = 0; d < MS; d++) nidx[d] = 0;
+#pragma unroll
+                for (int s2 = 0; s2 < MS; s2++) {
+                    const bool keep = s2 < V.np && V.x[s2] > 0.0;
+#pragma unroll
+                    for (int d = 0; d < MS; d++) nidx[d] = (keep && nn == d) ? V.idx[s2] : nidx[d];
+                    nn += keep ? 1 : 0;
+                }
+#pragma unroll
+                for (int d = 0; d < MS; d++) V.idx[d] = nidx[d];
+                V.np = nn;
+            }
+            if (add) {
+#pragma unroll
+                for (int d = 0; d < MS; d++) V.idx[d] = (d == V.np) ? tmax : V.idx[d];
+                V.np += 1;
+            }
+            live = drop || add;
+            if (!live) V.np = 0;
+            okv = live;
+        }
         GC_PH(4);
+        }                                         // rep
+        if (valid) a.done[pos] = cert_any ? 1 : (easy_any ? 2 : 0);
+        {
+            // the voxels left to the wavefront-per-voxel kernel, compacted per chunk (that kernel then shares out real work only)
+            const unsigned long long rm = __ballot(valid && !cert_any);
+            if (rm != 0ull) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&a.rcount[cid], __builtin_popcountll(rm));
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(rm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)rm, 0u));
+                if (valid && !cert_any) a.rlist[ck.start + base + rank] = pos;
+            }
+        }
     }
     __syncthreads();                          // every wavefront is through with this chunk's tables
     }

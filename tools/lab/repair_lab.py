@@ -6,6 +6,7 @@ import sys, os
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', '..'))
 src = open(os.path.join(os.path.dirname(__file__), 'seed_emu.py')).read().split("cache = {}; out = []")[0]
+src = src.replace("sch = S.make_scheme(seed=0)", "sch = S.make_scheme(18, ((1000.0, 90), (2000.0, 90), (3000.0, 90)), seed=4) if os.environ.get('PROTO') == 'hcp' else S.make_scheme(seed=0)")
 exec(src)
 cache = {}
 hist = {}
