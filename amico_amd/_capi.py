@@ -21,7 +21,7 @@ SYMBOLS = ['amx_version', 'amx_build_id', 'amx_ctx_create', 'amx_ctx_destroy', '
            'amx_noddi_fit_device', 'amx_freewater_fit_device', 'amx_sandi_fit_device', 'amx_sync_status',
            'amx_noddi_fit_device_f32', 'amx_freewater_fit_device_f32', 'amx_sandi_fit_device_f32', 'amx_czb_fit_device_f32',
            'amx_set_debug_x', 'amx_debug_fetch', 'amx_lut_upload_czb', 'amx_czb_fit', 'amx_czb_fit_f32', 'amx_czb_fit_device', 'amx_noddi_fit_f32', 'amx_freewater_fit_f32', 'amx_sandi_fit_f32', 'amx_set_progress',
-           'amx_set_profiling', 'amx_last_kernel_ms', 'amx_last_stats', 'amx_last_seed_stats', 'amx_selftest',
+           'amx_set_profiling', 'amx_last_kernel_ms', 'amx_last_stats', 'amx_last_seed_stats', 'amx_last_host_narrowed', 'amx_selftest',
            'amx_dti_create', 'amx_dti_destroy', 'amx_dti_directions', 'amx_dti_directions_device', 'amx_dti_directions_device_f32', 'amx_prep_gather_device_f32',
            'amx_prep_create', 'amx_prep_destroy', 'amx_prep_gather', 'amx_prep_gather_device',
            'amx_prep_gather_directions_device', 'amx_prep_gather_directions_device_f32',
@@ -128,6 +128,7 @@ def lib():
     L.amx_last_kernel_ms.argtypes = [c_vp, C.c_int, C.POINTER(C.c_float)]
     L.amx_last_stats.argtypes = [c_vp, c_i64p]
     L.amx_last_seed_stats.argtypes = [c_vp, c_i64p]
+    L.amx_last_host_narrowed.argtypes = [c_vp]
     L.amx_dict_upload.argtypes = [c_vp, c_dp, C.c_int, C.c_int, C.c_int, C.POINTER(c_vp)]
     L.amx_dict_destroy.argtypes = [c_vp]
     L.amx_dict_destroy.restype = None
@@ -223,6 +224,10 @@ class Context:
         self.check(lib().amx_last_stats(self._h, out))
         return {'rerun_voxels': out[0], 'itercap_voxels': out[1], 'overflow_voxels': out[2],
                 'guard_trips': out[3] >> 32, 'guard_last': out[3] & 0xffffffff}
+
+    def last_host_narrowed(self):
+        """batches of the last host-buffer call whose float64 signals crossed PCIe as float32, losslessly (amx_last_host_narrowed)"""
+        return int(lib().amx_last_host_narrowed(self._h))
 
     def last_seed_stats(self):
         """how the NODDI voxels since the previous sync were settled (amx_last_seed_stats): certification rates of the three stages"""

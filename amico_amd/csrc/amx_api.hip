@@ -3,6 +3,10 @@
 #include "amx_host.hpp"
 #include "amx_prep.hpp"
 #include <algorithm>
+#include <chrono>
+#include <thread>
+#include <cstdio>
+#include <cstdlib>
 
 using namespace amx;
 
@@ -226,6 +230,10 @@ int amx_ctx_create(int device, amx_ctx **out)
         { const char *rp = getenv("AMX_GCERT_REPAIR"); if (rp && *rp) ctx->opt_gcert_repair = atoi(rp) != 0 ? 1 : 0; }
         { const char *t3 = getenv("AMX_GCERT2_THIRD"); if (t3 && *t3) ctx->opt_gcert2_third = atoi(t3) != 0 ? 1 : 0; }
         ctx->opt_host_one_shot = on("AMX_HOST_ONE_SHOT"); ctx->opt_host_one_stream = on("AMX_HOST_ONE_STREAM");
+        e = getenv("AMX_HOST_NARROW");
+        ctx->opt_host_no_narrow = e && *e == '0';
+        e = getenv("AMX_HOST_THREADS");
+        if (e && atoi(e) >= 1) ctx->opt_host_threads = atoi(e) > 64 ? 64 : atoi(e);
         ctx->opt_tile_f32 = on("AMX_TILE_F32"); ctx->opt_fw_proj_valu = on("AMX_FW_PROJ_VALU"); ctx->opt_sandi_atom_space = on("AMX_SANDI_ATOM_SPACE");
         ctx->opt_prep_tile = on("AMX_PREP_TILE"); ctx->opt_prep_scalar = on("AMX_PREP_SCALAR"); ctx->opt_lut_regs = on("AMX_LUT_REGS"); ctx->opt_no_refill = on("AMX_NO_REFILL");
         ctx->opt_wave_per_voxel = on("AMX_WAVE_PER_VOXEL"); ctx->opt_fw_no_fuse = on("AMX_FW_NO_FUSE");
@@ -285,6 +293,7 @@ void amx_ctx_destroy(amx_ctx *ctx)
     if (ctx->status_h) hipHostFree(ctx->status_h);
     for (int k = 0; k < kEv; k++) (void)hipEventDestroy(ctx->ev[k]);
     if (ctx->hs) { (void)hipStreamDestroy(ctx->hs); (void)hipStreamDestroy(ctx->hs2); for (hipEvent_t e : ctx->hev) (void)hipEventDestroy(e); }
+    delete ctx->stage;             // (joins the host threads of the float32 transport)
     delete ctx;
 }
 
@@ -640,6 +649,8 @@ int amx_last_stats(amx_ctx *ctx, int64_t out[4])
     for (int k = 0; k < 4; k++) out[k] = ctx->stats[k];
     return AMX_OK;
 }
+
+int amx_last_host_narrowed(amx_ctx *ctx) { return ctx ? ctx->host_narrowed : 0; }
 
 int amx_last_seed_stats(amx_ctx *ctx, int64_t out[8])
 {
@@ -1164,8 +1175,22 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
     const bool pipelined = n_vox >= kPipelineFrom && !ctx->opt_host_one_shot;
     constexpr int kBufs = 3;                      // staging buffers: batch c uploads while c-1 and c-2 are being solved
     const int64_t cap = pipelined ? kBufs * kHostBatch : n_vox;
+    // float64 signals that are float32 values (evaluation.y always is: core.py:136, 451) cross the link as float32 (amx_stage.hpp)
+    constexpr size_t kNarrowFrom = 2u << 20;      // elements of a batch from which the host threads are worth waking (16 MB: 0.3 ms of link)
+    bool narrow = false;
+    if (!kF32 && !ctx->opt_host_no_narrow && !ctx->stage_failed && (size_t)n_vox * nS >= kNarrowFrom) {
+        if (!ctx->stage) {
+            const unsigned hw = std::thread::hardware_concurrency();
+            int nt = ctx->opt_host_threads;
+            if (hw >= 2 && nt > (int)(hw / 2)) nt = (int)(hw / 2);
+            ctx->stage = amx_stage::Pool::create(nt < 1 ? 1 : nt);
+            if (!ctx->stage) ctx->stage_failed = true;
+        }
+        narrow = ctx->stage != nullptr;
+    }
+    ctx->host_narrowed = 0;
     if ((rc = ensure(ctx, ctx->hy, (size_t)cap * nS * sizeof(double)))) return rc;
-    if (kF32 && (rc = ensure(ctx, ctx->hy32, (size_t)cap * nS * sizeof(float)))) return rc;
+    if ((kF32 || narrow) && (rc = ensure(ctx, ctx->hy32, (size_t)cap * nS * sizeof(float)))) return rc;
     if (dirs && (rc = ensure(ctx, ctx->hdirs, (size_t)cap * 3 * sizeof(double)))) return rc;
     for (HostOut &o : outs)
         if (o.on && (rc = ensure(ctx, *o.buf, (size_t)n_vox * o.cols * sizeof(double)))) return rc;
@@ -1184,15 +1209,26 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
     const bool two_streams = pipelined && !ctx->opt_host_one_stream;
     hipStream_t s = pipelined ? ctx->hs : nullptr;
     int64_t off = 0, done_before[kBufs] = {0, 0, 0};         // voxels complete once the event of that buffer has fired
+    // AMX_HOST_TRACE=1 (diagnosis): wall-clock timeline of the call on stderr -- per batch the wait for its buffer, its copy, its enqueue
+    static const bool trace = getenv("AMX_HOST_TRACE") != nullptr;
+    auto wall = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tr0 = trace ? wall() : 0.0;
     int64_t reported = 0;                                    // progress is reported once per batch, in order
     auto report = [&](int64_t v) { if (v > reported) { progress(ctx, v, n_vox); reported = v; } };
+    auto batch_cnt = [&](int c, int64_t at) -> int64_t {
+        const int64_t rem = n_vox - at, ramp = ctx->opt_host_ramp;
+        const int64_t parts = (rem + kHostBatch - 1) / kHostBatch;
+        return !pipelined ? n_vox : ((c < 1 && ramp > 0 && rem > 3 * ramp) ? ramp : (rem + parts - 1) / parts);
+    };
+    amx_stage::Narrower nar;
+    nar.pool = ctx->stage; nar.base = reinterpret_cast<const double *>(y); nar.total_el = (size_t)n_vox * nS;
+    struct NarrowScope { amx_stage::Narrower &n; ~NarrowScope() { n.settle(); } } narrow_scope{nar};     // (its threads read the caller's buffer)
     for (int c = 0; off < n_vox; c++) {
         // the first copy is the only one the solver cannot hide: one short batch (131 072 voxels; shorter ones cost more in the
         // ~2.4 ms floor of the seeded kernel chain than their copy saves), then the rest in equal batches of <= kHostBatch voxels
-        const int64_t rem = n_vox - off, ramp = ctx->opt_host_ramp;
-        const int64_t parts = (rem + kHostBatch - 1) / kHostBatch;
-        const int64_t cnt = !pipelined ? n_vox : ((c < 1 && ramp > 0 && rem > 3 * ramp) ? ramp : (rem + parts - 1) / parts);
+        const int64_t cnt = batch_cnt(c, off);
         int b = c % kBufs;
+        const double tr1 = trace ? wall() : 0.0;
         if (pipelined && c >= kBufs) {
             HIPCHK(ctx, hipEventSynchronize(ctx->hev[b]));           // batch c-3 has released this buffer
             report(done_before[b]);                                  // batches 0 .. c-3 are complete
@@ -1203,15 +1239,30 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
         //  has landed in device memory, which holds for pageable host-to-device copies on ROCm)
         double *yb = (double *)ctx->hy.p + (size_t)b * kHostBatch * nS;
         double *db = dirs ? (double *)ctx->hdirs.p + (size_t)b * kHostBatch * 3 : nullptr;
+        const double tr2 = trace ? wall() : 0.0;
         if (kF32) {
             float *y32 = (float *)ctx->hy32.p + (size_t)b * kHostBatch * nS;
             const size_t nel = (size_t)cnt * nS;
             HIPCHK(ctx, hipMemcpy(y32, y + (size_t)off * nS, nel * sizeof(float), hipMemcpyHostToDevice));
             hipLaunchKernelGGL(k_widen, dim3((unsigned)((nel / 4 + 256) / 256)), dim3(256), 0, s, y32, yb, nel);
         } else {
-            HIPCHK(ctx, hipMemcpy(yb, y + (size_t)off * nS, (size_t)cnt * nS * sizeof(double), hipMemcpyHostToDevice));
+            bool sent = false;
+            const size_t nel = (size_t)cnt * nS;
+            if (narrow && nel >= kNarrowFrom) {
+                float *y32 = (float *)ctx->hy32.p + (size_t)b * kHostBatch * nS;
+                const int64_t next_cnt = off + cnt < n_vox ? batch_cnt(c + 1, off + cnt) : 0;
+                const int r = nar.send((size_t)off * nS, nel, y32, (size_t)next_cnt * nS >= kNarrowFrom ? (size_t)next_cnt * nS : 0);
+                if (r < 0) { (void)hipGetLastError(); narrow = false; }        // (a failed send: this batch and the rest go the plain way)
+                else if (r == 0) narrow = false;                                // not float32 values: nothing to gain for the rest of the call either
+                else {
+                    hipLaunchKernelGGL(k_widen, dim3((unsigned)((nel / 4 + 256) / 256)), dim3(256), 0, s, y32, yb, nel);
+                    sent = true; ctx->host_narrowed++;
+                }
+            }
+            if (!sent) HIPCHK(ctx, hipMemcpy(yb, y + (size_t)off * nS, (size_t)cnt * nS * sizeof(double), hipMemcpyHostToDevice));
         }
         if (dirs) HIPCHK(ctx, hipMemcpy(db, dirs + (size_t)off * 3, (size_t)cnt * 3 * sizeof(double), hipMemcpyHostToDevice));
+        const double tr3 = trace ? wall() : 0.0;
         // the copy above took a while: has the previous batch finished meanwhile? (a query, never a wait)
         // (batches c-1 and c-2 run on different streams: both must have fired before batch c-1's count is reported)
         if (pipelined && c >= 1 && ctx->progress && hipEventQuery(ctx->hev[(c - 1) % kBufs]) == hipSuccess &&
@@ -1225,8 +1276,11 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
         if (rc) { ctx->profiling = was_profiling; return rc; }
         off += cnt;
         if (pipelined) { HIPCHK(ctx, hipEventRecord(ctx->hev[b], s)); done_before[b] = off; }
+        if (trace) fprintf(stderr, "amx host trace: batch %d  %lld voxels  at %.2f ms: buffer wait %.2f, copy %.2f (%.1f GB/s), enqueue %.2f\n", c, (long long)cnt,
+                           tr1 - tr0, tr2 - tr1, tr3 - tr2, ((double)cnt * nS * sizeof(T) + (dirs ? cnt * 24.0 : 0.0)) / (tr3 - tr2) * 1e-6, wall() - tr3);
     }
     ctx->profiling = was_profiling;
+    const double tr4 = trace ? wall() : 0.0;
     if (pipelined && ctx->progress) {
         // the batches still in flight, in submission order: one callback as each of them completes (the queries above only
         // catch a batch that finished while the next one was being copied)
@@ -1243,8 +1297,10 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
     if (two_streams) { HIPCHK(ctx, hipStreamSynchronize(s == ctx->hs ? ctx->hs2 : ctx->hs)); }
     rc = amx_sync_status(ctx, s);
     if (rc) return rc;
+    const double tr5 = trace ? wall() : 0.0;
     for (HostOut &o : outs)
         if (o.on) HIPCHK(ctx, hipMemcpy(o.dst, o.buf->p, (size_t)n_vox * o.cols * sizeof(double), hipMemcpyDeviceToHost));
+    if (trace) fprintf(stderr, "amx host trace: last enqueue at %.2f ms, solver tail %.2f, results to the host %.2f, call %.2f ms, %d batches as float32\n", tr4 - tr0, tr5 - tr4, wall() - tr5, wall() - tr0, ctx->host_narrowed);
     progress(ctx, n_vox, n_vox);
     return AMX_OK;
 }

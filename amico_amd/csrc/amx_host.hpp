@@ -2,6 +2,7 @@
 #pragma once
 #include "../../include/amico_amd.h"
 #include "amx_kernels.hpp"
+#include "amx_stage.hpp"
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
@@ -43,7 +44,10 @@ struct amx_ctx {
     void (*progress)(int64_t, int64_t, void *) = nullptr;   // amx_set_progress
     void *progress_user = nullptr;
     DevBuf wy;                     // float64 copy of float32 device signals for the lane kernels that read float64 only (amx_*_fit_device_f32)
-    DevBuf hy32;                   // float32 signals of the *_fit_f32 entry points
+    DevBuf hy32;                   // float32 signals of the *_fit_f32 entry points (and of float64 host signals that are float32 values: amx_stage.hpp)
+    amx_stage::Pool *stage = nullptr;  // host threads + pinned slots of the lossless float64 -> float32 transport (made at the first large float64 host call)
+    bool stage_failed = false;     // the pool could not be made: host signals are copied as they are
+    int host_narrowed = 0;         // batches of the last host-buffer call that travelled as float32 (amx_last_host_narrowed)
     hipStream_t hs = nullptr;      // non-blocking compute streams of the chunked host entry points: batches alternate
     hipStream_t hs2 = nullptr;     // between the two, so the tail of one batch's kernels is filled by the next batch's
     hipEvent_t hev[3] = {nullptr, nullptr, nullptr};
@@ -61,6 +65,8 @@ struct amx_ctx {
     bool opt_cold_start = false;       // AMX_COLD_START=1: FreeWater / SANDI / CZB start from the empty passive set
     bool opt_host_one_shot = false;    // AMX_HOST_ONE_SHOT=1: host-buffer entry points upload everything, then fit
     bool opt_host_one_stream = false;  // AMX_HOST_ONE_STREAM=1: pipelined host path on one stream
+    bool opt_host_no_narrow = false;   // AMX_HOST_NARROW=0: float64 host signals are always copied as they are (amx_stage.hpp)
+    int opt_host_threads = 12;         // AMX_HOST_THREADS: host threads that narrow + send float64 host signals (1 .. 64; at most half the logical CPUs)
     long long opt_host_ramp = 131072;  // AMX_HOST_RAMP: voxels of the first pipelined batch (its copy is the only one nothing hides; 0 = equal batches)
     long long opt_host_batch = 393216; // AMX_HOST_BATCH: voxels per pipelined batch (>= 131072, multiple of 4)
     bool opt_tile_f32 = false;         // AMX_TILE_F32=1: NNLS stages keep the float32 tile in LDS

@@ -338,6 +338,13 @@ int amx_last_stats(amx_ctx *ctx, int64_t out[4]);
  * the LASSO stage / stage 3 could NOT settle and handed to the wavefront-per-voxel kernels, out[4] = voxels whose stage-2 signal
  * y2 = max(0, y - x_iso iso) was clipped (models.pyx:924-925), out[5..7] reserved.  Certification rate of stage k = 1 - out[k] / out[0]. */
 int amx_last_seed_stats(amx_ctx *ctx, int64_t out[8]);
+/* Host-buffer entry points, float64 signals: evaluation.y is the float64 cast of a float32 image (core.py:136, 209-223, 451), so its
+ * values cross PCIe as float32 -- host threads narrow slices into pinned slots and CHECK every element; one value that is not a
+ * float32 (or a NaN) and that batch and the rest of the call are copied as they are (csrc/amx_stage.hpp).  The kernels read the
+ * caller's values bit for bit either way.  Returns the number of batches of the LAST host-buffer call that travelled as float32
+ * (0: small call, not float32 data, AMX_HOST_NARROW=0, or a *_f32 call -- those are float32 already).  No counterpart in the
+ * reference (its fit reads host memory in place, models.pyx:902).                                                              */
+int amx_last_host_narrowed(amx_ctx *ctx);
 
 /* device self-test of the wavefront primitives (DPP reductions, broadcasts): writes 12 rows of
  * 64 doubles (sum, max, min, bcast lane 37, next-lane, popcount(ballot v>0), int bcast, v, and

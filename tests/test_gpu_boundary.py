@@ -53,6 +53,63 @@ def test_float32_upload_is_lossless_and_progress_is_reported(htable500):
     assert np.array_equal(a[0], b[0])
 
 
+def test_float64_host_signals_that_are_float32_values_cross_the_link_as_float32(htable500):
+    """evaluation.y is the float64 cast of a float32 image (core.py:136, 451): the host-buffer call sends such signals as float32
+    (csrc/amx_stage.hpp: host threads narrow into pinned slots and CHECK every element) -- maps bit-identical to the device call on
+    the same values; ONE value that is not a float32, or a NaN, and that batch and the rest of the call are copied as they are"""
+    import torch
+    from amico_amd import _capi, synthetic as S
+    n = 600_000                                             # three pipelined batches
+    ctx, lut, K, ht, sch, _, _ = _noddi(htable500, 8)
+    y, d = S.noddi_signals_parallel(n, K, ht, sch, seed=23)
+    y = y.astype(np.float32).astype(np.float64)
+    dev = torch.device('cuda', 0)
+
+    def device_maps(yy):
+        e = _capi.noddi_fit_device(ctx, lut, torch.from_numpy(yy).to(dev), torch.from_numpy(d[:len(yy)].copy()).to(dev), 0.5, 1e-3, 3)[0]
+        ctx.sync()
+        return e.cpu().numpy()
+
+    ref = device_maps(y)
+    got = _capi.noddi_fit(ctx, lut, y, d, 0.5, 1e-3, 3)[0]
+    batches = ctx.last_host_narrowed()
+    assert batches >= 2, batches
+    assert np.array_equal(got, ref)
+    # one value of the LAST batch is not a float32: the earlier batches still travel narrow, the last one as it is
+    y2 = y.copy()
+    y2[n - 5, 7] = 0.123456789012345
+    assert float(np.float32(y2[n - 5, 7])) != y2[n - 5, 7]
+    got2 = _capi.noddi_fit(ctx, lut, y2, d, 0.5, 1e-3, 3)[0]
+    assert ctx.last_host_narrowed() == batches - 1
+    assert np.array_equal(got2, device_maps(y2))
+    # a NaN in the first batch: nothing travels narrow, the voxel gets NaN maps, every other voxel its own
+    y3 = y.copy()
+    y3[17, 3] = np.nan
+    got3 = _capi.noddi_fit(ctx, lut, y3, d, 0.5, 1e-3, 3)[0]
+    assert ctx.last_host_narrowed() == 0
+    assert np.isnan(got3[17]).all() and np.array_equal(np.delete(got3, 17, axis=0), np.delete(ref, 17, axis=0))
+    # one-shot call (below the pipelining threshold, above the narrowing threshold) and a call too small to wake the threads
+    got4 = _capi.noddi_fit(ctx, lut, y[:100_000], d[:100_000], 0.5, 1e-3, 3)[0]
+    assert ctx.last_host_narrowed() == 1
+    assert np.array_equal(got4, device_maps(y[:100_000].copy()))
+    _capi.noddi_fit(ctx, lut, y[:5_000], d[:5_000], 0.5, 1e-3, 3)
+    assert ctx.last_host_narrowed() == 0
+    # float32 buffers are narrow already
+    _capi.noddi_fit(ctx, lut, y[:100_000].astype(np.float32), d[:100_000], 0.5, 1e-3, 3)
+    assert ctx.last_host_narrowed() == 0
+    # the other models share the transport: FreeWater, 300 000 voxels
+    s1 = S.make_scheme(1, ((1000.0, 64),), seed=3)
+    dirs = htable500['dirs']
+    Kf = S.freewater_kernels(s1, dirs)
+    yf, df = S.freewater_signals(300_000, Kf, ht, s1, seed=5)
+    yf = yf.astype(np.float32).astype(np.float64)
+    lf = _capi.upload_freewater(ctx, Kf, ht)
+    ef = _capi.freewater_fit(ctx, lf, yf, df, 0.0, 1e-3, False)[0]
+    assert ctx.last_host_narrowed() == 1
+    e32 = _capi.freewater_fit(ctx, lf, yf.astype(np.float32), df, 0.0, 1e-3, False)[0]
+    assert np.array_equal(ef, e32)
+
+
 def test_lambda2_zero_is_accepted(htable500):
     """set_solver(lambda2=0) works in the reference (cyspams lasso); here it runs the QR solver in A-space.  Certified by
     the KKT conditions of the device coefficients (the optimum need not be unique without the ridge; A x is)"""
