@@ -1183,7 +1183,19 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
             const unsigned hw = std::thread::hardware_concurrency();
             int nt = ctx->opt_host_threads;
             if (hw >= 2 && nt > (int)(hw / 2)) nt = (int)(hw / 2);
-            ctx->stage = amx_stage::Pool::create(nt < 1 ? 1 : nt);
+            // The threads stay on the NUMA node of the CALLING thread (where the caller's buffer most likely lives: first touch): on the
+            // two-socket box 12.4 - 13.0 ms per 1 M voxels in every process, against 13.3 - 14.1 with the scheduler's choice and 12.7 - 14.0
+            // on the device's node (AMX_HOST_PIN = caller | gpu | 0, diagnosis; profiles/r05c_host_transport.txt)
+            int node = -1;
+            const char *pe = getenv("AMX_HOST_PIN");
+            if (pe && pe[0] == 'g') node = amx_stage::device_node(ctx->device);
+            else if (!pe || pe[0] != '0') {
+                const int cpu = sched_getcpu();
+                cpu_set_t cs;
+                for (int nd = 0; nd < 16 && cpu >= 0; nd++)
+                    if (amx_stage::node_cpus(nd, &cs) && CPU_ISSET(cpu, &cs)) { node = nd; break; }
+            }
+            ctx->stage = amx_stage::Pool::create(nt < 1 ? 1 : nt, node);
             if (!ctx->stage) ctx->stage_failed = true;
         }
         narrow = ctx->stage != nullptr;

@@ -16,14 +16,56 @@
 #include <hip/hip_runtime.h>
 #include <immintrin.h>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
 #include <mutex>
 #include <thread>
 #include <vector>
+#include <cstdio>
+#include <pthread.h>
+#include <sched.h>
 
 namespace amx_stage {
+
+// The CPUs of one NUMA node (Linux sysfs), intersected with the CPUs this process may use.  false: unknown -- leave the threads alone.
+static bool node_cpus(int node, cpu_set_t *out)
+{
+    char path[96];
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *f = fopen(path, "r");
+    if (!f) return false;
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) { fclose(f); return false; }
+    CPU_ZERO(out);
+    int a, b, n = 0;
+    for (;;) {
+        if (fscanf(f, "%d", &a) != 1) break;
+        b = a;
+        int c = fgetc(f);
+        if (c == '-') { if (fscanf(f, "%d", &b) != 1) break; c = fgetc(f); }
+        for (int k = a; k <= b && k < CPU_SETSIZE; k++) if (CPU_ISSET(k, &allowed)) { CPU_SET(k, out); n++; }
+        if (c != ',') break;
+    }
+    fclose(f);
+    return n > 0;
+}
+// NUMA node a HIP device hangs on (-1: unknown / single node)
+static int device_node(int device)
+{
+    char bus[64] = {0}, path[160];
+    if (hipDeviceGetPCIBusId(bus, sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    for (char *p = bus; *p; p++) if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
+}
 
 // true: every element narrowed exactly (a NaN compares unequal -> false)
 __attribute__((target("avx2"))) static bool narrow_avx2(const double *__restrict__ s, float *__restrict__ d, size_t n)
@@ -53,23 +95,28 @@ class Pool {
 public:
     static constexpr size_t kChunkEl = 4u << 20;           // elements per chunk: 32 MB read, 16 MB sent (0.28 ms of link)
     static constexpr size_t kPieceEl = 32u << 10;          // elements a thread takes at a time
-    static Pool *create(int threads)
+    // node >= 0: the threads stay on that NUMA node's CPUs
+    static Pool *create(int threads, int node = -1)
     {
         Pool *p = new Pool();
         p->T_ = threads;
         p->avx2_ = __builtin_cpu_supports("avx2");
+        if (const char *e = getenv("AMX_HOST_SPIN_US")) p->spin_us_ = atoi(e);
         for (float *&q : p->ring_)
             if (hipHostMalloc((void **)&q, kChunkEl * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); q = nullptr; p->release(); delete p; return nullptr; }
         try {
             for (int t = 0; t < threads; t++) p->th_.emplace_back([p] { p->worker(); });
         } catch (...) { delete p; return nullptr; }
+        cpu_set_t cpus;
+        if (node >= 0 && node_cpus(node, &cpus))
+            for (auto &x : p->th_) (void)pthread_setaffinity_np(x.native_handle(), sizeof cpus, &cpus);
         return p;
     }
     ~Pool()
     {
         {
             std::lock_guard<std::mutex> lk(m_);
-            quit_ = true;
+            quit_.store(true);
         }
         cv_go_.notify_all();
         for (auto &x : th_) if (x.joinable()) x.join();
@@ -83,14 +130,24 @@ public:
             std::lock_guard<std::mutex> lk(m_);
             src_ = src; dst_ = dst; n_el_ = n_el;
             next_.store(0); inexact_.store(0);
-            running_ = T_; gen_++;
+            running_.store(T_);
+            gen_.fetch_add(1, std::memory_order_release);
         }
         cv_go_.notify_all();
     }
     bool wait()                                                     // true: every element of the job was a float32
     {
-        std::unique_lock<std::mutex> lk(m_);
-        cv_done_.wait(lk, [&] { return running_ == 0; });
+        // (the calling thread is the critical path: it looks for a short while before it sleeps -- a condition variable's wake-up costs
+        //  30 - 50 us, a chunk's copy lasts 280)
+        const auto t0 = std::chrono::steady_clock::now();
+        while (running_.load(std::memory_order_acquire) != 0) {
+            _mm_pause();
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(2 * spin_us_)) {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_done_.wait(lk, [&] { return running_.load() == 0; });
+                break;
+            }
+        }
         return inexact_.load() == 0;
     }
 
@@ -101,11 +158,16 @@ private:
         uint64_t seen = 0;
         for (;;) {
             const double *src; float *dst; size_t n_el;
+            // jobs of one call follow each other every ~0.3 ms: look for the next one for a while before sleeping (the threads stay
+            // awake through a call and go to sleep a millisecond after its last chunk)
+            const auto t0 = std::chrono::steady_clock::now();
+            while (gen_.load(std::memory_order_acquire) == seen && !quit_.load(std::memory_order_relaxed) &&
+                   std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(spin_us_)) _mm_pause();
             {
                 std::unique_lock<std::mutex> lk(m_);
-                cv_go_.wait(lk, [&] { return quit_ || gen_ != seen; });
-                if (quit_) return;
-                seen = gen_; src = src_; dst = dst_; n_el = n_el_;
+                cv_go_.wait(lk, [&] { return quit_.load() || gen_.load() != seen; });
+                if (quit_.load()) return;
+                seen = gen_.load(); src = src_; dst = dst_; n_el = n_el_;
             }
             for (;;) {
                 if (inexact_.load(std::memory_order_relaxed)) break;
@@ -115,9 +177,9 @@ private:
                 const bool exact = avx2_ ? narrow_avx2(src + o, dst + o, n) : narrow_base(src + o, dst + o, n);
                 if (!exact) { inexact_.store(1); break; }
             }
-            {
+            if (running_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
                 std::lock_guard<std::mutex> lk(m_);
-                if (--running_ == 0) cv_done_.notify_one();
+                cv_done_.notify_one();
             }
         }
     }
@@ -127,13 +189,14 @@ private:
     }
     int T_ = 0;
     bool avx2_ = false;
+    int spin_us_ = 0;              // AMX_HOST_SPIN_US (diagnosis): threads that look for the next job before they sleep lost (profiles/r05c_host_transport.txt)
     std::vector<std::thread> th_;
     float *ring_[2] = {nullptr, nullptr};
     std::mutex m_;
     std::condition_variable cv_go_, cv_done_;
-    uint64_t gen_ = 0;
-    int running_ = 0;
-    bool quit_ = false;
+    std::atomic<uint64_t> gen_{0};
+    std::atomic<int> running_{0};
+    std::atomic<bool> quit_{false};
     const double *src_ = nullptr;
     float *dst_ = nullptr;
     size_t n_el_ = 0;
