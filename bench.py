@@ -881,23 +881,23 @@ def main():
                                                 'value': n / float(np.median(hb)), 'unit': 'voxels/s', 'voxels': n,
                                                 'ms_per_call': 1e3 * float(np.median(hb)),
                                                 'batches_as_float32': ctx.last_host_narrowed(),
-                                                'note': 'float64 signals from pageable host memory, batches pipelined behind the solver; the synthetic signals are '
-                                                        'float64 noise, NOT float32 values, so they cross PCIe as float64 (see noddi_host_buffers_f32_values)'}}
-                # what the reference's evaluation.y is: the float64 cast of a float32 image (core.py:136, 451) -- the library finds that
-                # out element by element and sends float32 (csrc/amx_stage.hpp); same values in, so the maps equal the float32 call's
-                y_f = y_h.astype(np.float32).astype(np.float64)
-                _capi.noddi_fit(ctx, lut, y_f, d_h, 0.5, 1e-3, 3)
+                                                'note': 'float64 signals from pageable host memory, batches pipelined behind the solver.  The signals are what '
+                                                        'evaluation.y of the reference is -- the float64 cast of a float32 image (core.py:136, 451) -- which the '
+                                                        'library finds out element by element and sends as float32 (csrc/amx_stage.hpp): lossless, bit-identical maps'}}
+                # the same call on genuine float64 values (no float32 round trip): nothing can be narrowed, 8 bytes per value cross PCIe
+                y_g = y_h * (1.0 + 2.0 ** -30)
+                _capi.noddi_fit(ctx, lut, y_g, d_h, 0.5, 1e-3, 3)
                 hb = []
                 for _ in range(3):
                     t1 = time.perf_counter()
-                    e_f = _capi.noddi_fit(ctx, lut, y_f, d_h, 0.5, 1e-3, 3)[0]
+                    _capi.noddi_fit(ctx, lut, y_g, d_h, 0.5, 1e-3, 3)
                     hb.append(time.perf_counter() - t1)
-                other['noddi_host_buffers_f32_values'] = {
-                    'metric': 'voxels/sec, NODDI fit, float64 host buffers holding float32 values (evaluation.y of the reference; PCIe inclusive)',
+                other['noddi_host_buffers_f64_values'] = {
+                    'metric': 'voxels/sec, NODDI fit, float64 host buffers holding genuine float64 values (PCIe inclusive)',
                     'value': n / float(np.median(hb)), 'unit': 'voxels/s', 'voxels': n, 'ms_per_call': 1e3 * float(np.median(hb)),
                     'batches_as_float32': ctx.last_host_narrowed(),
-                    'note': 'host threads narrow + check every element, float32 over PCIe, widened on the device: lossless by construction'}
-                del y_f
+                    'note': 'the call is the link (792 MB at 56.4 GB/s) plus the last batch: profiles/r05c_host_transport.txt'}
+                del y_g
                 try:
                     y32 = y_h.astype(np.float32)
                     _capi.noddi_fit(ctx, lut, y32, d_h, 0.5, 1e-3, 3)
@@ -910,7 +910,6 @@ def main():
                                                        'value': n / float(np.median(hb)), 'unit': 'voxels/s', 'voxels': n,
                                                        'ms_per_call': 1e3 * float(np.median(hb)),
                                                        'max_abs_dmap_vs_f64_upload': float(np.abs(e32 - est.cpu().numpy()).max()),
-                                                       'max_abs_dmap_vs_f32_values_in_f64_buffers': float(np.abs(e32 - e_f).max()),
                                                        'note': 'lossless for AMICO (the image is float32, core.py:136): half the PCIe bytes'}
                     del y32
                 except (TypeError, AttributeError, ValueError):
