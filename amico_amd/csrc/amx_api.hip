@@ -1183,13 +1183,15 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
             const unsigned hw = std::thread::hardware_concurrency();
             int nt = ctx->opt_host_threads;
             if (hw >= 2 && nt > (int)(hw / 2)) nt = (int)(hw / 2);
-            // The threads stay on the NUMA node of the CALLING thread (where the caller's buffer most likely lives: first touch): on the
-            // two-socket box 12.4 - 13.0 ms per 1 M voxels in every process, against 13.3 - 14.1 with the scheduler's choice and 12.7 - 14.0
-            // on the device's node (AMX_HOST_PIN = caller | gpu | 0, diagnosis; profiles/r05c_host_transport.txt)
+            // The threads stay on the NUMA node the DEVICE hangs on, one per physical core (amx_stage.hpp): the pinned ring they write lives
+            // there and the copies leave from there; the caller's buffer is read across the socket link if it lives on the other node.
+            // Measured on the two-socket box, host_trace.py and bench.py, two processes each: 12.6 - 12.9 ms per 1 M voxels in all four;
+            // on the calling thread's node 15.5 - 19 ms when that is the far socket (AMX_HOST_PIN = gpu | caller | 0: diagnosis;
+            // profiles/r05c_host_transport.txt, section 8)
             int node = -1;
             const char *pe = getenv("AMX_HOST_PIN");
-            if (pe && pe[0] == 'g') node = amx_stage::device_node(ctx->device);
-            else if (!pe || pe[0] != '0') {
+            if (!pe || pe[0] == 'g') node = amx_stage::device_node(ctx->device);
+            if ((pe && pe[0] == 'c') || ((!pe || pe[0] == 'g') && node < 0)) {
                 const int cpu = sched_getcpu();
                 cpu_set_t cs;
                 for (int nd = 0; nd < 16 && cpu >= 0; nd++)
@@ -1232,9 +1234,24 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
         const int64_t parts = (rem + kHostBatch - 1) / kHostBatch;
         return !pipelined ? n_vox : ((c < 1 && ramp > 0 && rem > 3 * ramp) ? ramp : (rem + parts - 1) / parts);
     };
-    amx_stage::Narrower nar;
-    nar.pool = ctx->stage; nar.base = reinterpret_cast<const double *>(y); nar.total_el = (size_t)n_vox * nS;
-    struct NarrowScope { amx_stage::Narrower &n; ~NarrowScope() { n.settle(); } } narrow_scope{nar};     // (its threads read the caller's buffer)
+    // the call's batches are known up front, and with them the chunks the host threads narrow ahead of the copies (amx_stage.hpp)
+    std::vector<amx_stage::Chunk> chunks;
+    std::vector<int> first_chunk;                  // of batch c
+    if (narrow) {
+        int64_t at = 0;
+        for (int c = 0; at < n_vox; c++) {
+            const int64_t cnt = batch_cnt(c, at);
+            const size_t nel = (size_t)cnt * nS;
+            if (nel < kNarrowFrom) { narrow = false; break; }         // (a batch too small to be worth it: SANDI's six values per voxel)
+            first_chunk.push_back((int)chunks.size());
+            for (size_t o = 0; o < nel; o += amx_stage::Pool::kChunkEl)
+                chunks.push_back({(size_t)at * nS + o, nel - o < amx_stage::Pool::kChunkEl ? nel - o : amx_stage::Pool::kChunkEl});
+            at += cnt;
+        }
+        first_chunk.push_back((int)chunks.size());
+    }
+    struct NarrowScope { amx_stage::Pool *p; ~NarrowScope() { if (p) p->end(); } } narrow_scope{narrow ? ctx->stage : nullptr};   // (its threads read the caller's buffer)
+    if (narrow) ctx->stage->begin(reinterpret_cast<const double *>(y), chunks);
     for (int c = 0; off < n_vox; c++) {
         // the first copy is the only one the solver cannot hide: one short batch (131 072 voxels; shorter ones cost more in the
         // ~2.4 ms floor of the seeded kernel chain than their copy saves), then the rest in equal batches of <= kHostBatch voxels
@@ -1260,15 +1277,23 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
         } else {
             bool sent = false;
             const size_t nel = (size_t)cnt * nS;
-            if (narrow && nel >= kNarrowFrom) {
+            if (narrow) {
                 float *y32 = (float *)ctx->hy32.p + (size_t)b * kHostBatch * nS;
-                const int64_t next_cnt = off + cnt < n_vox ? batch_cnt(c + 1, off + cnt) : 0;
-                const int r = nar.send((size_t)off * nS, nel, y32, (size_t)next_cnt * nS >= kNarrowFrom ? (size_t)next_cnt * nS : 0);
-                if (r < 0) { (void)hipGetLastError(); narrow = false; }        // (a failed send: this batch and the rest go the plain way)
-                else if (r == 0) narrow = false;                                // not float32 values: nothing to gain for the rest of the call either
-                else {
+                const size_t base_el = (size_t)off * nS;
+                sent = true;
+                for (int j = first_chunk[c]; j < first_chunk[c + 1]; j++) {
+                    // not float32 values (nothing to gain for the rest of the call either) or a failed copy: this batch and the rest go the plain way
+                    if (!ctx->stage->ready(j) ||
+                        hipMemcpy(y32 + (chunks[j].off - base_el), ctx->stage->slot(j), chunks[j].n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+                        (void)hipGetLastError();
+                        ctx->stage->end(); narrow = false; sent = false;
+                        break;
+                    }
+                    ctx->stage->consumed(j);
+                }
+                if (sent) {
                     hipLaunchKernelGGL(k_widen, dim3((unsigned)((nel / 4 + 256) / 256)), dim3(256), 0, s, y32, yb, nel);
-                    sent = true; ctx->host_narrowed++;
+                    ctx->host_narrowed++;
                 }
             }
             if (!sent) HIPCHK(ctx, hipMemcpy(yb, y + (size_t)off * nS, (size_t)cnt * nS * sizeof(double), hipMemcpyHostToDevice));

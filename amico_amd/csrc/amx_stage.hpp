@@ -5,9 +5,9 @@
 // float64 copy): every value of y is exactly a float32.  A host-buffer fit of 1 M NODDI voxels is 14.9 ms of PCIe
 // (792 MB at the link's 56.4 GB/s, measured per batch inside the call: AMX_HOST_TRACE=1, profiles/r05c_host_trace.txt) next
 // to 6.5 ms of kernels -- the copy IS the call.  So the copy is halved where that is exact: host threads narrow the caller's
-// buffer chunk by chunk into two pinned buffers, CHECKING every element ((double)(float)v == v; 144 - 260 GB/s of float64 on
-// the box's cores, tools/probes/h2d_probe.hip), the calling thread sends chunk k with the blocking copy it always used while
-// chunk k + 1 is being narrowed, and the device widens the batch again (k_widen, amx_api.hip).  One element that is not a
+// buffer chunk by chunk into a ring of four pinned buffers, CHECKING every element ((double)(float)v == v; 144 - 260 GB/s of
+// float64 on the box's cores, tools/probes/h2d_probe.hip), the calling thread sends chunk k with the blocking copy it always
+// used while the chunks behind it are being narrowed, and the device widens the batch again (k_widen, amx_api.hip).  One element that is not a
 // float32 (or is a NaN: it never compares equal) and the batch -- and every later batch of the call -- is copied as it is.
 // The values the kernels read are the caller's, bit for bit, either way.
 // (Measured and dropped: every host thread sending its own slices on its own stream -- 100 GB/s of float64 alone on the box,
@@ -20,12 +20,14 @@
 #include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
 #include <cstdio>
 #include <pthread.h>
 #include <sched.h>
+#include <unistd.h>
 
 namespace amx_stage {
 
@@ -90,30 +92,63 @@ static bool narrow_base(const double *__restrict__ s, float *__restrict__ d, siz
     return bad == 0u;
 }
 
-// T host threads that narrow one chunk at a time (start / wait: one job in flight)
+// T host threads that narrow ONE CALL's signals, chunk by chunk, into a ring of pinned buffers, ahead of the calling thread's copies.
+// The job is the whole call (its chunks are known up front: the batches of fit_host are), so the threads wake once per call and run
+// until the ring is full (kRing chunks = 1.1 ms of link ahead of the copies) -- a chunk-at-a-time hand-over (one wake-up per chunk,
+// one chunk of slack) left the calling thread waiting for the narrowing whenever the threads sat on the far socket or woke late:
+// 12.5 ms per 1 M voxels in one process, 14 - 16 ms in another (profiles/r05c_host_transport.txt, section 8).
+struct Chunk { size_t off, n; };       // elements of the caller's buffer
+
 class Pool {
 public:
     static constexpr size_t kChunkEl = 4u << 20;           // elements per chunk: 32 MB read, 16 MB sent (0.28 ms of link)
     static constexpr size_t kPieceEl = 32u << 10;          // elements a thread takes at a time
+    static constexpr int kRing = 4;
     // node >= 0: the threads stay on that NUMA node's CPUs
     static Pool *create(int threads, int node = -1)
     {
         Pool *p = new Pool();
         p->T_ = threads;
         p->avx2_ = __builtin_cpu_supports("avx2");
-        if (const char *e = getenv("AMX_HOST_SPIN_US")) p->spin_us_ = atoi(e);
         for (float *&q : p->ring_)
             if (hipHostMalloc((void **)&q, kChunkEl * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); q = nullptr; p->release(); delete p; return nullptr; }
         try {
             for (int t = 0; t < threads; t++) p->th_.emplace_back([p] { p->worker(); });
         } catch (...) { delete p; return nullptr; }
+        // One thread per physical core of the node, spread over it (AMX_HOST_PIN_CORES=0: the node's CPUs as a set, the scheduler
+        // chooses).  Threads that wake together start on the waker's cache domain and are spread by the load balancer over
+        // MILLISECONDS: the first batches of a call were narrowed at a third of the rate of the later ones (section 8 of
+        // profiles/r05c_host_transport.txt).  The cores rotate with the process id: ranks of a multi-GPU job do not pile up.
         cpu_set_t cpus;
-        if (node >= 0 && node_cpus(node, &cpus))
-            for (auto &x : p->th_) (void)pthread_setaffinity_np(x.native_handle(), sizeof cpus, &cpus);
+        if (node >= 0 && node_cpus(node, &cpus)) {
+            std::vector<int> phys;
+            for (int k = 0; k < CPU_SETSIZE; k++) {
+                if (!CPU_ISSET(k, &cpus)) continue;
+                char path[128];
+                snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", k);
+                int first = k;
+                if (FILE *f = fopen(path, "r")) { if (fscanf(f, "%d", &first) != 1) first = k; fclose(f); }
+                if (first == k || !CPU_ISSET(first, &cpus)) phys.push_back(k);
+            }
+            const char *pc = getenv("AMX_HOST_PIN_CORES");
+            const int P = (int)phys.size();
+            if ((!pc || pc[0] != '0') && P >= 2 * threads) {
+                const int stride = P / threads, start = (int)(((unsigned)getpid() * 7u) % (unsigned)P);
+                for (int t = 0; t < threads; t++) {
+                    cpu_set_t one;
+                    CPU_ZERO(&one);
+                    CPU_SET(phys[(start + t * stride) % P], &one);
+                    (void)pthread_setaffinity_np(p->th_[t].native_handle(), sizeof one, &one);
+                }
+            } else {
+                for (auto &x : p->th_) (void)pthread_setaffinity_np(x.native_handle(), sizeof cpus, &cpus);
+            }
+        }
         return p;
     }
     ~Pool()
     {
+        end();
         {
             std::lock_guard<std::mutex> lk(m_);
             quit_.store(true);
@@ -123,64 +158,86 @@ public:
         release();
     }
     int threads() const { return T_; }
-    float *ring(int s) const { return ring_[s]; }
-    void start(const double *src, float *dst, size_t n_el)         // asynchronous; n_el <= kChunkEl
+    float *slot(int c) const { return ring_[c % kRing]; }
+
+    // start narrowing base[chunks[0]], base[chunks[1]], ... (every n <= kChunkEl); the threads read the CALLER's memory until end()
+    void begin(const double *base, const std::vector<Chunk> &chunks)
     {
+        end();
         {
             std::lock_guard<std::mutex> lk(m_);
-            src_ = src; dst_ = dst; n_el_ = n_el;
-            next_.store(0); inexact_.store(0);
-            running_.store(T_);
+            base_ = base; chunks_ = chunks;
+            const int nc = (int)chunks_.size();
+            first_.assign(nc + 1, 0);
+            for (int c = 0; c < nc; c++) first_[c + 1] = first_[c] + (chunks_[c].n + kPieceEl - 1) / kPieceEl;
+            done_.reset(new std::atomic<int>[nc > 0 ? nc : 1]);
+            for (int c = 0; c < nc; c++) done_[c].store(0);
+            next_.store(0); copied_.store(0); inexact_.store(false); abort_.store(false);
+            running_.store(T_); active_ = true;
             gen_.fetch_add(1, std::memory_order_release);
         }
         cv_go_.notify_all();
     }
-    bool wait()                                                     // true: every element of the job was a float32
+    // blocks until chunk c lies in slot(c): true -- false: an element of the call was not a float32 (end() the job, copy the rest plainly)
+    bool ready(int c)
     {
-        // (the calling thread is the critical path: it looks for a short while before it sleeps -- a condition variable's wake-up costs
-        //  30 - 50 us, a chunk's copy lasts 280)
-        const auto t0 = std::chrono::steady_clock::now();
-        while (running_.load(std::memory_order_acquire) != 0) {
-            _mm_pause();
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(2 * spin_us_)) {
-                std::unique_lock<std::mutex> lk(m_);
-                cv_done_.wait(lk, [&] { return running_.load() == 0; });
-                break;
-            }
+        const int want = (int)(first_[c + 1] - first_[c]);
+        for (int spin = 0; done_[c].load(std::memory_order_acquire) < want; spin++) {
+            if (inexact_.load(std::memory_order_relaxed)) return false;
+            nap(spin);
         }
-        return inexact_.load() == 0;
+        return true;
+    }
+    void consumed(int c) { copied_.store(c + 1, std::memory_order_release); }       // slot(c) may be overwritten
+    // stop whatever is left of the job and wait until no thread reads the caller's memory any more
+    void end()
+    {
+        if (!active_) return;
+        abort_.store(true);
+        for (int spin = 0; running_.load(std::memory_order_acquire) != 0; spin++) nap(spin);
+        active_ = false;
     }
 
 private:
     Pool() = default;
+    static void nap(int spin)
+    {
+        if (spin < 64) _mm_pause();
+        else std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
     void worker()
     {
         uint64_t seen = 0;
         for (;;) {
-            const double *src; float *dst; size_t n_el;
-            // jobs of one call follow each other every ~0.3 ms: look for the next one for a while before sleeping (the threads stay
-            // awake through a call and go to sleep a millisecond after its last chunk)
-            const auto t0 = std::chrono::steady_clock::now();
-            while (gen_.load(std::memory_order_acquire) == seen && !quit_.load(std::memory_order_relaxed) &&
-                   std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(spin_us_)) _mm_pause();
             {
                 std::unique_lock<std::mutex> lk(m_);
                 cv_go_.wait(lk, [&] { return quit_.load() || gen_.load() != seen; });
                 if (quit_.load()) return;
-                seen = gen_.load(); src = src_; dst = dst_; n_el = n_el_;
+                seen = gen_.load();
             }
+            const size_t total = first_.back();
+            const int nc = (int)chunks_.size();
+            int c = 0;
             for (;;) {
-                if (inexact_.load(std::memory_order_relaxed)) break;
-                const size_t o = next_.fetch_add(1) * kPieceEl;
-                if (o >= n_el) break;
-                const size_t n = n_el - o < kPieceEl ? n_el - o : kPieceEl;
-                const bool exact = avx2_ ? narrow_avx2(src + o, dst + o, n) : narrow_base(src + o, dst + o, n);
-                if (!exact) { inexact_.store(1); break; }
+                if (inexact_.load(std::memory_order_relaxed) || abort_.load(std::memory_order_relaxed)) break;
+                const size_t p = next_.fetch_add(1);
+                if (p >= total) break;
+                while (c + 1 < nc && p >= first_[c + 1]) c++;
+                bool stop = false;
+                for (int spin = 0; c >= copied_.load(std::memory_order_acquire) + kRing; spin++) {      // the ring is full: the copies decide the pace
+                    if (inexact_.load(std::memory_order_relaxed) || abort_.load(std::memory_order_relaxed)) { stop = true; break; }
+                    nap(spin);
+                }
+                if (stop) break;
+                const size_t o = (p - first_[c]) * kPieceEl;
+                const size_t n = chunks_[c].n - o < kPieceEl ? chunks_[c].n - o : kPieceEl;
+                const double *src = base_ + chunks_[c].off + o;
+                float *dst = ring_[c % kRing] + o;
+                const bool exact = avx2_ ? narrow_avx2(src, dst, n) : narrow_base(src, dst, n);
+                if (!exact) { inexact_.store(true); break; }
+                done_[c].fetch_add(1, std::memory_order_release);
             }
-            if (running_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
-                std::lock_guard<std::mutex> lk(m_);
-                cv_done_.notify_one();
-            }
+            running_.fetch_sub(1, std::memory_order_acq_rel);
         }
     }
     void release()
@@ -189,59 +246,21 @@ private:
     }
     int T_ = 0;
     bool avx2_ = false;
-    int spin_us_ = 0;              // AMX_HOST_SPIN_US (diagnosis): threads that look for the next job before they sleep lost (profiles/r05c_host_transport.txt)
+    bool active_ = false;          // (calling thread only)
     std::vector<std::thread> th_;
-    float *ring_[2] = {nullptr, nullptr};
+    float *ring_[kRing] = {nullptr, nullptr, nullptr, nullptr};
     std::mutex m_;
-    std::condition_variable cv_go_, cv_done_;
+    std::condition_variable cv_go_;
     std::atomic<uint64_t> gen_{0};
     std::atomic<int> running_{0};
     std::atomic<bool> quit_{false};
-    const double *src_ = nullptr;
-    float *dst_ = nullptr;
-    size_t n_el_ = 0;
+    const double *base_ = nullptr;
+    std::vector<Chunk> chunks_;
+    std::vector<size_t> first_;                     // pieces before chunk c
+    std::unique_ptr<std::atomic<int>[]> done_;      // narrowed pieces of chunk c
     std::atomic<size_t> next_{0};
-    std::atomic<int> inexact_{0};
-};
-
-// One host-buffer call's float64 signals, narrowed ahead of the copies: chunk k + 1 (of this batch, or the first one of the NEXT
-// batch -- the caller says how long that one is) is being narrowed while the calling thread copies chunk k.
-struct Narrower {
-    Pool *pool = nullptr;
-    const double *base = nullptr;      // the caller's signals
-    size_t total_el = 0;
-    bool ok = true;                    // false once an element was not a float32: the rest of the call is copied as it is
-    bool pending = false;              // a job is in flight (it reads the CALLER's memory: never return without settle())
-    size_t p_off = 0, p_n = 0; int p_slot = 0, slot = 0;
-
-    void settle() { if (pending) { (void)pool->wait(); pending = false; } }
-    void kick(size_t off, size_t n)
-    {
-        p_off = off; p_n = n; p_slot = slot; slot ^= 1;
-        pool->start(base + off, pool->ring(p_slot), n);
-        pending = true;
-    }
-    // elements [off, off + n) -> dst (device float32).  1: sent, all float32 values -- 0: some element is not (dst holds rubbish,
-    // ok = false) -- -1: a copy failed (hip error pending)
-    int send(size_t off, size_t n, float *dst, size_t next_batch_el)
-    {
-        size_t done = 0;
-        while (done < n) {
-            const size_t len = n - done < Pool::kChunkEl ? n - done : Pool::kChunkEl;
-            if (!(pending && p_off == off + done && p_n == len)) { settle(); kick(off + done, len); }
-            const int s = p_slot;
-            const bool exact = pool->wait();
-            pending = false;
-            if (!exact) { ok = false; return 0; }
-            const size_t n_off = off + done + len;
-            const size_t n_len = done + len < n ? (n - done - len < Pool::kChunkEl ? n - done - len : Pool::kChunkEl)
-                                                : (next_batch_el < Pool::kChunkEl ? next_batch_el : Pool::kChunkEl);
-            if (n_len > 0 && n_off + n_len <= total_el) kick(n_off, n_len);
-            if (hipMemcpy(dst + done, pool->ring(s), len * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { settle(); ok = false; return -1; }
-            done += len;
-        }
-        return 1;
-    }
+    std::atomic<int> copied_{0};                    // chunks whose slots the calling thread has sent
+    std::atomic<bool> inexact_{false}, abort_{false};
 };
 
 }  // namespace amx_stage
