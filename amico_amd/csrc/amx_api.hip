@@ -230,6 +230,8 @@ int amx_ctx_create(int device, amx_ctx **out)
         { const char *rp = getenv("AMX_GCERT_REPAIR"); if (rp && *rp) ctx->opt_gcert_repair = atoi(rp) != 0 ? 1 : 0; }
         { const char *t3 = getenv("AMX_GCERT2_THIRD"); if (t3 && *t3) ctx->opt_gcert2_third = atoi(t3) != 0 ? 1 : 0; }
         ctx->opt_host_one_shot = on("AMX_HOST_ONE_SHOT"); ctx->opt_host_one_stream = on("AMX_HOST_ONE_STREAM");
+        e = getenv("AMX_HOST_PIPELINE_FROM");
+        if (e && atoll(e) >= 262144) ctx->opt_host_pipeline_from = atoll(e);       // (a pipelined call has a first batch of 131 072 voxels and a second one at least as long)
         e = getenv("AMX_HOST_NARROW");
         ctx->opt_host_no_narrow = e && *e == '0';
         e = getenv("AMX_HOST_THREADS");
@@ -1161,7 +1163,6 @@ int amx_czb_fit_device_f32(amx_ctx *ctx, const amx_lut *lut, const float *d_y, c
 // callback (amx_set_progress; models.pyx:28-43, 981 keep a per-thread counter for the same purpose) is called as
 // batches complete.
 // (largest batch; measured on 1 M NODDI voxels: 131072 -> 38.3 ms, 262144 -> 37.2 ms, 393216 -> 36.3 ms per call)
-constexpr int64_t kPipelineFrom = 524288;      // smaller inputs go in one shot
 
 struct HostOut { void *dst; DevBuf *buf; size_t cols; bool on; };
 
@@ -1172,7 +1173,7 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
     int rc;
     const int64_t kHostBatch = ctx->opt_host_batch;
     constexpr bool kF32 = sizeof(T) == 4;
-    const bool pipelined = n_vox >= kPipelineFrom && !ctx->opt_host_one_shot;
+    const bool pipelined = n_vox >= ctx->opt_host_pipeline_from && !ctx->opt_host_one_shot;
     constexpr int kBufs = 3;                      // staging buffers: batch c uploads while c-1 and c-2 are being solved
     const int64_t cap = pipelined ? kBufs * kHostBatch : n_vox;
     // float64 signals that are float32 values (evaluation.y always is: core.py:136, 451) cross the link as float32 (amx_stage.hpp)
