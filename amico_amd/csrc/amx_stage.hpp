@@ -115,10 +115,12 @@ public:
         try {
             for (int t = 0; t < threads; t++) p->th_.emplace_back([p] { p->worker(); });
         } catch (...) { delete p; return nullptr; }
-        // One thread per physical core of the node, spread over it (AMX_HOST_PIN_CORES=0: the node's CPUs as a set, the scheduler
-        // chooses).  Threads that wake together start on the waker's cache domain and are spread by the load balancer over
-        // MILLISECONDS: the first batches of a call were narrowed at a third of the rate of the later ones (section 8 of
-        // profiles/r05c_host_transport.txt).  The cores rotate with the process id: ranks of a multi-GPU job do not pile up.
+        // Every thread gets its own STRIPE of the node's physical cores (P / T of them; AMX_HOST_PIN_CORES=0: all threads share the node's
+        // CPUs as one set, 1: one core per thread -- diagnosis).  Threads that wake together start on the waker's cache domain and are
+        // spread by the load balancer over MILLISECONDS: with the node as one set the first batches of a call were narrowed at a third of
+        // the rate of the later ones.  One core per thread cures that and has a failure of its own: a thread nailed to the core the CALLING
+        // thread happens to run on shares it with that thread's copies -- 28 ms per call instead of 12.6, one process in five.  Within a
+        // stripe the scheduler can step aside (section 10 of profiles/r05c_host_transport.txt).  The stripes rotate with the process id.
         cpu_set_t cpus;
         if (node >= 0 && node_cpus(node, &cpus)) {
             std::vector<int> phys;
@@ -134,11 +136,12 @@ public:
             const int P = (int)phys.size();
             if ((!pc || pc[0] != '0') && P >= 2 * threads) {
                 const int stride = P / threads, start = (int)(((unsigned)getpid() * 7u) % (unsigned)P);
+                const int width = (pc && pc[0] == '1') ? 1 : stride;
                 for (int t = 0; t < threads; t++) {
-                    cpu_set_t one;
-                    CPU_ZERO(&one);
-                    CPU_SET(phys[(start + t * stride) % P], &one);
-                    (void)pthread_setaffinity_np(p->th_[t].native_handle(), sizeof one, &one);
+                    cpu_set_t mine;
+                    CPU_ZERO(&mine);
+                    for (int j = 0; j < width; j++) CPU_SET(phys[(start + t * stride + j) % P], &mine);
+                    (void)pthread_setaffinity_np(p->th_[t].native_handle(), sizeof mine, &mine);
                 }
             } else {
                 for (auto &x : p->th_) (void)pthread_setaffinity_np(x.native_handle(), sizeof cpus, &cpus);

@@ -873,7 +873,7 @@ def main():
                 # reported beside the headline, never as `value`
                 _capi.noddi_fit(ctx, lut, y_h, d_h, 0.5, 1e-3, 3)
                 hb = []
-                for _ in range(3):
+                for _ in range(7):      # (median of seven: one call in ten takes 10 - 15 ms longer on the two-socket box, whatever the transport)
                     t1 = time.perf_counter()
                     _capi.noddi_fit(ctx, lut, y_h, d_h, 0.5, 1e-3, 3)
                     hb.append(time.perf_counter() - t1)
@@ -888,7 +888,7 @@ def main():
                 y_g = y_h * (1.0 + 2.0 ** -30)
                 _capi.noddi_fit(ctx, lut, y_g, d_h, 0.5, 1e-3, 3)
                 hb = []
-                for _ in range(3):
+                for _ in range(7):      # (median of seven: one call in ten takes 10 - 15 ms longer on the two-socket box, whatever the transport)
                     t1 = time.perf_counter()
                     _capi.noddi_fit(ctx, lut, y_g, d_h, 0.5, 1e-3, 3)
                     hb.append(time.perf_counter() - t1)
@@ -902,7 +902,7 @@ def main():
                     y32 = y_h.astype(np.float32)
                     _capi.noddi_fit(ctx, lut, y32, d_h, 0.5, 1e-3, 3)
                     hb = []
-                    for _ in range(3):
+                    for _ in range(7):      # (median of seven: one call in ten takes 10 - 15 ms longer on the two-socket box, whatever the transport)
                         t1 = time.perf_counter()
                         e32 = _capi.noddi_fit(ctx, lut, y32, d_h, 0.5, 1e-3, 3)[0]
                         hb.append(time.perf_counter() - t1)
