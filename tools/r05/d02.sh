@@ -1,0 +1,7 @@
+#!/bin/bash
+# fourth session, call 2: the GPU suite + smoke on the library as rebuilt in the re-created container (same sources, csrc 341af986130c67fb)
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r05d; mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -x -q > $O/gpu_tests.txt 2>&1; grep -n "passed\|failed" $O/gpu_tests.txt
+timeout 900 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
