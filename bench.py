@@ -634,6 +634,36 @@ def noddi_other_protocol(ctx, shells, n_b0, n, steps, warmup, headline_rate_per_
     return out
 
 
+def noddi_model_fit(K, htable, scheme, y_h, d_h, est_ref):
+    """``model.fit(evaluation)`` of the host mirror (amico_amd/models.py = models.pyx:902-981 behind BaseModel.fit): seconds of the
+    first call (dictionary upload + tables) and voxels/s of the later ones; maps against the device-resident fit of the same voxels"""
+    from amico_amd import NODDI
+
+    class Ev:                                   # the fields model.fit reads of an Evaluation (core.py:42-104)
+        def __init__(self):
+            self.y, self.DIRs, self.htable, self.KERNELS, self.nthreads = y_h, d_h, htable, K, 1
+
+        def get_config(self, k):
+            return False
+
+    m = NODDI()
+    m.scheme = scheme
+    ev = Ev()
+    t0 = time.perf_counter()
+    out = m.fit(ev)
+    first = time.perf_counter() - t0
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        out = m.fit(ev)
+        ts.append(time.perf_counter() - t0)
+    n = len(y_h)
+    return {'metric': 'voxels/sec, NODDI().fit(evaluation): host numpy in, result dict out (PCIe inclusive)', 'value': n / float(np.median(ts)),
+            'unit': 'voxels/s', 'voxels': n, 'ms_per_call': 1e3 * float(np.median(ts)), 'first_call_ms': 1e3 * first,
+            'max_abs_dmap_vs_device_fit': float(np.abs(out['estimates'] - est_ref).max()),
+            'note': 'first call = digest of KERNELS + dictionary upload + Gram matrices / bases on the device + the fit; later calls = digest + fit'}
+
+
 def device_barrier(dev, world):
     """both sides of the timed region: drain the device, meet the other ranks, drain again"""
     import torch
@@ -914,6 +944,11 @@ def main():
                     del y32
                 except (TypeError, AttributeError, ValueError):
                     pass
+            if not args.no_other_configs:
+                # the plug-in surface itself: NODDI().fit(evaluation) as core.py:462-467 calls it (host numpy in, the result dict out) on a
+                # FRESH context -- the first call pays the dictionary upload and the device tables built from it (Gram matrices, bases),
+                # the later ones find the dictionary by the digest of KERNELS (BaseModel._lut)
+                other['noddi_model_fit'] = noddi_model_fit(K, htable, scheme, y_h, d_h, est.cpu().numpy())
             if not args.no_other_configs:
                 other['noddi_hard_mix'] = noddi_hard_mix(ctx, lut, K, htable, scheme, min(n, 1_000_000), 5, 2)
                 per_byte = value * BYTES_PER_VOXEL
