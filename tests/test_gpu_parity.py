@@ -92,6 +92,29 @@ def test_noddi_vs_oracle_synthetic(htable500, seed_path, amx_env):
     assert np.median(diff) < 1e-10
 
 
+def test_noddi_kernels_edited_in_place_are_uploaded_again(htable500):
+    """the reference reads KERNELS on every fit (models.pyx:840-847): a model that has cached its device dictionary must notice an
+    in-place edit (same object, shape, dtype) -- the digest is checked behind the fit, a fit on the stale upload is discarded"""
+    from amico_amd import NODDI, synthetic as S
+    dirs, ht = htable500['dirs'], htable500['htable']
+    sch = S.make_scheme(seed=5)
+    K = S.noddi_kernels(sch, dirs)
+    y, d = S.noddi_signals(3000, K, ht, sch, seed=2)
+    m = NODDI()
+    m.scheme = sch
+    ev = Holder(y, d, ht, K)
+    a = m.fit(ev)['estimates']
+    assert np.array_equal(m.fit(ev)['estimates'], a)                      # cached dictionary: the same maps
+    lut0 = m._lut_cache[1]
+    K['iso'] *= np.float32(0.9)                                           # in place
+    b = m.fit(ev)['estimates']
+    assert m._lut_cache[1] is not lut0 and m._lut_pending is False
+    fresh = NODDI()
+    fresh.scheme = sch
+    assert np.array_equal(fresh.fit(Holder(y, d, ht, K))['estimates'], b)
+    assert np.abs(a - b).max() > 1e-3                                     # and the edit matters
+
+
 @pytest.mark.parametrize('n', [1500, 50000])
 def test_noddi_exvivo_and_lambdas(htable500, n):
     """ex-vivo model (dot compartment: 146 atoms, four maps) with other regularisation weights, error maps and modulated maps;

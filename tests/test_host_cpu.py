@@ -208,3 +208,52 @@ def test_build_id_matches_the_sources():
     bid = _capi.build_id()
     assert bid.startswith('amico_amd ') and ' csrc ' in bid and len(bid.split()[-1]) == 16
     assert _capi.build_is_current(), 'libamico_amd.so is older than its sources: run make -C amico_amd/csrc'
+
+
+def test_dictionary_cache_is_checked_behind_the_fit(monkeypatch):
+    """BaseModel._lut / _verified_fit: the digest of KERNELS runs beside the fit; a fit that ran on a stale upload (KERNELS edited in
+    place since) is discarded and run again on the rebuilt dictionary -- the reference re-reads KERNELS on every fit (models.pyx:840-847)"""
+    from amico_amd import models as M
+
+    class Fake(M.BaseModel):
+        def __init__(self):
+            self.id, self.scheme, self.builds, self.fits = 'Fake', None, 0, 0
+
+        def set(self): pass
+        def get_params(self): return {}
+        def set_solver(self): pass
+        def generate(self, *a): pass
+        def resample(self, *a): pass
+
+        def _builder(self, ev):
+            def build():
+                self.builds += 1
+                return float(ev.KERNELS['wm'].sum())
+            return build
+
+        @M._verified_fit
+        def fit(self, ev):
+            lut = self._lut(ev, self._builder(ev))
+            self.fits += 1
+            return {'v': lut}
+
+    monkeypatch.setattr(M, 'get_context', lambda: 'ctx')
+
+    class Ev:
+        pass
+    ev = Ev()
+    ev.KERNELS, ev.htable = {'model': 'Fake', 'wm': np.ones((4, 5), np.float32)}, None
+    m = Fake()
+    assert m.fit(ev) == {'v': 20.0} and (m.builds, m.fits) == (1, 1)
+    assert m.fit(ev) == {'v': 20.0} and (m.builds, m.fits) == (1, 2)          # cached: one fit, no upload
+    ev.KERNELS['wm'][1, 1] = 3.0                                               # edited in place: same object, shape, dtype
+    assert m.fit(ev) == {'v': 22.0} and (m.builds, m.fits) == (2, 4)          # the stale fit was discarded
+    assert m.fit(ev) == {'v': 22.0} and (m.builds, m.fits) == (2, 5)
+    assert m._lut(ev, m._builder(ev)) == 22.0 and m.builds == 2                # outside a fit: checked on the spot
+    ev.KERNELS['wm'][0, 0] = 5.0
+    assert m._lut(ev, m._builder(ev)) == 26.0 and m.builds == 3
+    ev.KERNELS['model'] = 'Other'
+    ev.KERNELS['wm'] = np.ones((4, 6), np.float32)
+    with pytest.raises(ValueError, match='same model'):
+        m.fit(ev)
+    assert m._lut_pending is False                                             # the wrapper leaves no pending check behind
