@@ -229,7 +229,7 @@ int amx_ctx_create(int device, amx_ctx **out)
         { const char *m2 = getenv("AMX_SEED2_MAXATOMS"); if (m2 && *m2) { const int v = atoi(m2); ctx->opt_seed2_maxatoms = v < 8 ? 8 : (v > 30 ? 30 : v); } }
         { const char *rp = getenv("AMX_GCERT_REPAIR"); if (rp && *rp) ctx->opt_gcert_repair = atoi(rp) != 0 ? 1 : 0; }
         { const char *t3 = getenv("AMX_GCERT2_THIRD"); if (t3 && *t3) ctx->opt_gcert2_third = atoi(t3) != 0 ? 1 : 0; }
-        ctx->opt_host_one_shot = on("AMX_HOST_ONE_SHOT"); ctx->opt_host_one_stream = on("AMX_HOST_ONE_STREAM");
+        ctx->opt_host_one_shot = on("AMX_HOST_ONE_SHOT"); ctx->opt_host_one_stream = on("AMX_HOST_ONE_STREAM"); ctx->opt_host_late_results = on("AMX_HOST_LATE_RESULTS");
         e = getenv("AMX_HOST_PIPELINE_FROM");
         if (e && atoll(e) >= 262144) ctx->opt_host_pipeline_from = atoll(e);       // (a pipelined call has a first batch of 131 072 voxels and a second one at least as long)
         e = getenv("AMX_HOST_NARROW");
@@ -1319,7 +1319,20 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
     }
     ctx->profiling = was_profiling;
     const double tr4 = trace ? wall() : 0.0;
-    if (pipelined && ctx->progress) {
+    // The results of the batches that are through go home while the last ones are still being solved (the calling thread has nothing else to
+    // do during the solver's tail): the voxels [0, upto) of every output are final once every batch that ends at or before `upto` has fired
+    // its event -- batches older than the kBufs last ones were waited for when their staging buffer was taken again.
+    int64_t copied = 0;
+    auto results_upto = [&](int64_t upto) -> int {
+        if (upto <= copied) return AMX_OK;
+        for (HostOut &o : outs)
+            if (o.on) HIPCHK(ctx, hipMemcpy((char *)o.dst + (size_t)copied * o.cols * sizeof(double), (const char *)o.buf->p + (size_t)copied * o.cols * sizeof(double),
+                                            (size_t)(upto - copied) * o.cols * sizeof(double), hipMemcpyDeviceToHost));
+        copied = upto;
+        return AMX_OK;
+    };
+    const bool early_results = pipelined && !ctx->opt_host_late_results;
+    if (pipelined && (ctx->progress || early_results)) {
         // the batches still in flight, in submission order: one callback as each of them completes (the queries above only
         // catch a batch that finished while the next one was being copied)
         int64_t order[kBufs]; int idx[kBufs];
@@ -1330,14 +1343,14 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
             HIPCHK(ctx, hipEventSynchronize(ctx->hev[idx[i]]));
             if (two_streams && i > 0 && order[i - 1] > 0) HIPCHK(ctx, hipEventSynchronize(ctx->hev[idx[i - 1]]));
             report(order[i]);
+            if (early_results && (rc = results_upto(order[i]))) return rc;
         }
     }
     if (two_streams) { HIPCHK(ctx, hipStreamSynchronize(s == ctx->hs ? ctx->hs2 : ctx->hs)); }
     rc = amx_sync_status(ctx, s);
     if (rc) return rc;
     const double tr5 = trace ? wall() : 0.0;
-    for (HostOut &o : outs)
-        if (o.on) HIPCHK(ctx, hipMemcpy(o.dst, o.buf->p, (size_t)n_vox * o.cols * sizeof(double), hipMemcpyDeviceToHost));
+    if ((rc = results_upto(n_vox))) return rc;
     if (trace) fprintf(stderr, "amx host trace: last enqueue at %.2f ms, solver tail %.2f, results to the host %.2f, call %.2f ms, %d batches as float32\n", tr4 - tr0, tr5 - tr4, wall() - tr5, wall() - tr0, ctx->host_narrowed);
     progress(ctx, n_vox, n_vox);
     return AMX_OK;

@@ -65,6 +65,7 @@ struct amx_ctx {
     bool opt_cold_start = false;       // AMX_COLD_START=1: FreeWater / SANDI / CZB start from the empty passive set
     bool opt_host_one_shot = false;    // AMX_HOST_ONE_SHOT=1: host-buffer entry points upload everything, then fit
     bool opt_host_one_stream = false;  // AMX_HOST_ONE_STREAM=1: pipelined host path on one stream
+    bool opt_host_late_results = false; // AMX_HOST_LATE_RESULTS=1: the results of a host-buffer call go home in one copy after the last batch (diagnosis)
     long long opt_host_pipeline_from = 393217;   // AMX_HOST_PIPELINE_FROM: host-buffer calls of fewer voxels upload everything, then fit (>= 262144).  From 3 x 131 072 voxels a call has two batches -- the first short -- and the second copy hides behind the first fit: 400 000 voxels 7.63 -> 6.85 ms (float32 signals 6.94 -> 6.08), 500 000 8.66 -> 7.92 (8.30 -> 7.51); was 524 288 while a float64 copy took twice as long (profiles/r05c_host_transport.txt, section 9)
     bool opt_host_no_narrow = false;   // AMX_HOST_NARROW=0: float64 host signals are always copied as they are (amx_stage.hpp)
     int opt_host_threads = 12;         // AMX_HOST_THREADS: host threads that narrow + send float64 host signals (1 .. 64; at most half the logical CPUs)
