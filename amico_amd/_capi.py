@@ -21,7 +21,7 @@ SYMBOLS = ['amx_version', 'amx_build_id', 'amx_ctx_create', 'amx_ctx_destroy', '
            'amx_noddi_fit_device', 'amx_freewater_fit_device', 'amx_sandi_fit_device', 'amx_sync_status',
            'amx_noddi_fit_device_f32', 'amx_freewater_fit_device_f32', 'amx_sandi_fit_device_f32', 'amx_czb_fit_device_f32',
            'amx_set_debug_x', 'amx_debug_fetch', 'amx_lut_upload_czb', 'amx_czb_fit', 'amx_czb_fit_f32', 'amx_czb_fit_device', 'amx_noddi_fit_f32', 'amx_freewater_fit_f32', 'amx_sandi_fit_f32', 'amx_set_progress',
-           'amx_set_profiling', 'amx_last_kernel_ms', 'amx_last_stats', 'amx_last_seed_stats', 'amx_last_host_narrowed', 'amx_selftest',
+           'amx_set_profiling', 'amx_last_kernel_ms', 'amx_last_stats', 'amx_last_seed_stats', 'amx_last_host_narrowed', 'amx_last_path', 'amx_selftest',
            'amx_dti_create', 'amx_dti_destroy', 'amx_dti_directions', 'amx_dti_directions_device', 'amx_dti_directions_device_f32', 'amx_prep_gather_device_f32',
            'amx_prep_create', 'amx_prep_destroy', 'amx_prep_gather', 'amx_prep_gather_device',
            'amx_prep_gather_directions_device', 'amx_prep_gather_directions_device_f32',
@@ -129,6 +129,7 @@ def lib():
     L.amx_last_stats.argtypes = [c_vp, c_i64p]
     L.amx_last_seed_stats.argtypes = [c_vp, c_i64p]
     L.amx_last_host_narrowed.argtypes = [c_vp]
+    L.amx_last_path.argtypes = [c_vp, C.c_char_p, C.c_int]
     L.amx_dict_upload.argtypes = [c_vp, c_dp, C.c_int, C.c_int, C.c_int, C.POINTER(c_vp)]
     L.amx_dict_destroy.argtypes = [c_vp]
     L.amx_dict_destroy.restype = None
@@ -228,6 +229,12 @@ class Context:
     def last_host_narrowed(self):
         """batches of the last host-buffer call whose float64 signals crossed PCIe as float32, losslessly (amx_last_host_narrowed)"""
         return int(lib().amx_last_host_narrowed(self._h))
+
+    def last_path(self):
+        """the kernels the last fit on this context enqueued, in launch order (amx_last_path)"""
+        buf = C.create_string_buffer(2048)
+        self.check(lib().amx_last_path(self._h, buf, 2048))
+        return buf.value.decode()
 
     def last_seed_stats(self):
         """how the NODDI voxels since the previous sync were settled (amx_last_seed_stats): certification rates of the three stages"""

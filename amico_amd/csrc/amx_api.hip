@@ -64,7 +64,7 @@ int make_plan(amx_ctx *ctx, int64_t n, int ndirs, Plan &pl, bool seeds = false, 
         if ((rc = ensure(ctx, ctx->clip, ((size_t)2 * n + pl.max_schunks + 64) * sizeof(int)))) return rc;
         if ((rc = ensure(ctx, ctx->feed, (size_t)(kFeedSets + kZCounts) * (pl.max_schunks + 8) * sizeof(int)))) return rc;      // chunk counters of the kernels that share their chunks (SeedFeed, BlockFeed) + the list counts of every pass (Plan::zcount)
         if ((rc = ensure(ctx, ctx->done, (size_t)n + 64))) return rc;
-        if ((rc = ensure(ctx, ctx->rlist, 2 * amx_rlist_half(pl) * sizeof(int)))) return rc;
+        if ((rc = ensure(ctx, ctx->rlist, 4 * amx_rlist_half(pl) * sizeof(int)))) return rc;      // (two halves per stage's certificate passes; a forked fit's stage 3 takes the third and fourth)
         if ((rc = ensure(ctx, ctx->ytil2, (size_t)n * amx::kSeedKD * sizeof(double)))) return rc;
         if ((rc = ensure(ctx, ctx->seeds2, (size_t)n * 4 * sizeof(unsigned long long)))) return rc;
         pl.schunks = (Chunk *)ctx->schunks.p;
@@ -85,7 +85,7 @@ int make_plan(amx_ctx *ctx, int64_t n, int ndirs, Plan &pl, bool seeds = false, 
     if ((rc = ensure(ctx, ctx->cursor, (size_t)(ndirs + 1) * sizeof(int)))) return rc;
     if ((rc = ensure(ctx, ctx->chunks, (size_t)max_chunks * sizeof(Chunk)))) return rc;
     if ((rc = ensure(ctx, ctx->misc, 64 * sizeof(int)))) return rc;
-    if ((rc = ensure(ctx, ctx->ovf, (size_t)4 * n * sizeof(int)))) return rc;
+    if ((rc = ensure(ctx, ctx->ovf, (size_t)6 * n * sizeof(int)))) return rc;      // (lists 0 .. 2: the stages' overflow, 3: second level; 4, 5: the same for a forked fit's side stream, amx_launch.hpp)
     pl.lutidx = (int *)ctx->lutidx.p; pl.perm = (int *)ctx->perm.p; pl.counts = (int *)ctx->counts.p;
     pl.dir_start = (int *)ctx->dir_start.p; pl.cursor = (int *)ctx->cursor.p;
     pl.chunks = (Chunk *)ctx->chunks.p; pl.n_chunks = (int *)ctx->misc.p;
@@ -124,8 +124,8 @@ int enqueue_bucketing(amx_ctx *ctx, const amx_lut *lut, const double *d_dirs, in
 __global__ void k_fold_counters(const int *misc, int *status)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        atomicAdd(&status[ST_RERUN], misc[4] + misc[5] + misc[6]);      // (two batches may fold concurrently: fit_host)
-        atomicAdd(&status[ST_OVERFLOW], misc[12]);
+        atomicAdd(&status[ST_RERUN], misc[4] + misc[5] + misc[6] + misc[7]);      // (two batches may fold concurrently: fit_host)
+        atomicAdd(&status[ST_OVERFLOW], misc[12] + misc[13]);
     }
 }
 
@@ -271,6 +271,11 @@ int amx_ctx_create(int device, amx_ctx **out)
             sscanf(e, "%d,%d,%d", &c[0], &c[1], &c[2]);
             for (int k = 0; k < 3; k++) ctx->opt_seed_tripcap[k] = c[k] < 4 ? 4 : c[k];
         }
+        e = getenv("AMX_FORK");
+        if (e && *e) ctx->opt_fork = atoi(e) & 3;
+        e = getenv("AMX_FORK_CUS");
+        if (e && *e) ctx->opt_fork_cus = atoi(e) < 0 ? 0 : atoi(e);
+        ctx->opt_fork_prio = on("AMX_FORK_PRIO") ? 1 : 0;
         e = getenv("AMX_SEED_CHUNK");
         // (never below kChunk: the left-over passes size their grid by the FIRST plan's chunk count, n / kChunk + ndirs + 1)
         if (e && atoi(e) >= kChunk) ctx->opt_seed_chunk = (atoi(e) + 63) & ~63;
@@ -295,6 +300,7 @@ void amx_ctx_destroy(amx_ctx *ctx)
     if (ctx->status_h) hipHostFree(ctx->status_h);
     for (int k = 0; k < kEv; k++) (void)hipEventDestroy(ctx->ev[k]);
     if (ctx->hs) { (void)hipStreamDestroy(ctx->hs); (void)hipStreamDestroy(ctx->hs2); for (hipEvent_t e : ctx->hev) (void)hipEventDestroy(e); }
+    for (int w = 0; w < 2; w++) if (ctx->fork_s[w]) { (void)hipStreamDestroy(ctx->fork_s[w]); for (hipEvent_t e : ctx->fork_ev[w]) if (e) (void)hipEventDestroy(e); }
     delete ctx->stage;             // (joins the host threads of the float32 transport)
     delete ctx;
 }
@@ -654,6 +660,13 @@ int amx_last_stats(amx_ctx *ctx, int64_t out[4])
 
 int amx_last_host_narrowed(amx_ctx *ctx) { return ctx ? ctx->host_narrowed : 0; }
 
+int amx_last_path(amx_ctx *ctx, char *buf, int cap)
+{
+    if (!ctx || !buf || cap <= 0) return AMX_E_BADARG;
+    snprintf(buf, (size_t)cap, "%s", ctx->path.c_str());
+    return AMX_OK;
+}
+
 int amx_last_seed_stats(amx_ctx *ctx, int64_t out[8])
 {
     if (!ctx || !out) return AMX_E_BADARG;
@@ -662,11 +675,32 @@ int amx_last_seed_stats(amx_ctx *ctx, int64_t out[8])
 }
 
 // ------------------------------------------------------------------ NODDI
+// side stream + events of a forked fit (AMX_FORK), one set per workspace set (fit_host alternates two: swap_work)
+static int fork_ready(amx_ctx *ctx)
+{
+    const int w = ctx->work_idx;
+    if (ctx->fork_s[w]) return AMX_OK;
+    int lo = 0, hi = 0;
+    if (ctx->opt_fork_prio) (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (ctx->opt_fork_cus > 0) {
+        // n compute units for the side stream, spread evenly over the mask's bits (one bit per CU)
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int total = ctx->n_cu > 256 ? 256 : ctx->n_cu, n = ctx->opt_fork_cus > total ? total : ctx->opt_fork_cus;
+        for (int k = 0; k < n; k++) { const int b = (int)((long long)k * total / n); mask[b >> 5] |= 1u << (b & 31); }
+        HIPCHK(ctx, hipExtStreamCreateWithCUMask(&ctx->fork_s[w], (uint32_t)((total + 31) / 32), mask));
+    } else {
+        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->fork_s[w], hipStreamNonBlocking, ctx->opt_fork_prio ? hi : lo));
+    }
+    for (int k = 0; k < 4; k++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->fork_ev[w][k], hipEventDisableTiming));
+    return AMX_OK;
+}
+
 static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, const float *d_y32, const double *d_dirs,
                          int64_t n_vox, double lambda1, double lambda2, unsigned flags,
                          double *d_estimates, double *d_rmse, double *d_nrmse, double *d_mod,
                          void *hip_stream)
 {
+    if (ctx && !(ctx->in_host_fit && ctx->vox_base > 0)) ctx->path.clear();
     if (!ctx) return AMX_E_BADARG;
     if (!lut || lut->model != 1 || lut->ctx != ctx) return bad(ctx, "amx_noddi_fit: not a NODDI dictionary of this ctx");
     if (n_vox < 0 || n_vox > INT_MAX / 4) return bad(ctx, "amx_noddi_fit: bad n_vox");
@@ -678,6 +712,7 @@ static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
     hipStream_t s = (hipStream_t)hip_stream;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     Plan pl; int rc;
+    bool joined1 = false, fork2 = false;
     const bool seeds = lut->basis_S != nullptr && lut->gram != nullptr && !ctx->opt_no_seed &&
                        (ctx->in_host_fit ? ctx->host_total_vox : n_vox) >= ctx->opt_seed_min_voxels;   // (batches of one host call all take the same path: bit-identical to the one-shot call)
     const int gemm_ks = seeds ? amx_gemm_ksteps(lut) : 0;                        // 0: no table kernels for this shape (seeds certified on the true residual only)
@@ -728,7 +763,21 @@ static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
         }
         rec(ctx, 11, s);
     }
-    if ((rc = amx_launch_noddi_s1(ctx, a, pl, s))) return rc;
+    // AMX_FORK bit 0 (TIMING PROBE, not a fit): the stage-1 left-over kernel on the side stream beside the LASSO seed solver, which reads
+    // the x_iso the previous call left for those voxels; joined before the LASSO certificates
+    const bool fork1 = (ctx->opt_fork & 1) && a.rlist != nullptr;
+    hipStream_t fs = nullptr;
+    if (ctx->opt_fork) { if ((rc = fork_ready(ctx))) return rc; fs = ctx->fork_s[ctx->work_idx]; }
+    hipEvent_t *fev = ctx->fork_ev[ctx->work_idx];
+    if (fork1) {
+        HIPCHK(ctx, hipEventRecord(fev[0], s));
+        HIPCHK(ctx, hipStreamWaitEvent(fs, fev[0], 0));
+        ctx->side_launch = true;
+        rc = amx_launch_noddi_s1(ctx, a, pl, fs);
+        ctx->side_launch = false;
+        if (rc) return rc;
+        HIPCHK(ctx, hipEventRecord(fev[1], fs));
+    } else if ((rc = amx_launch_noddi_s1(ctx, a, pl, s))) return rc;
     progress_tick(ctx, s, n_vox / 3, n_vox);                       // (three stages: a third of the work each, roughly)
     a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks; a.rlist = nullptr; a.rcount = nullptr; a.done = nullptr;
     // the LASSO seeds need x_iso: Gram-space solver only (lambda2 >= 1e-5), with the default dictionary shape
@@ -744,6 +793,7 @@ static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
         a.list_is_pos = 1;
         if (!ctx->opt_no_screen && lut->screen2_S) { a.scr2_S = lut->screen2_S; a.scr2_kappa = lut->screen2_kappa; a.scr2_ytil = (const double *)ctx->ytil2.p; a.scr2_Sg = lut->basis2_S; }
         if (!gcert2) ctx->uncert_vox[1] += n_vox;
+        if (fork1) { HIPCHK(ctx, hipStreamWaitEvent(s, fev[1], 0)); joined1 = true; }
         if (gcert2) {
             const bool wide = !ctx->opt_no_gcert_wide;
             if ((rc = amx_launch_noddi_gcert2(ctx, lut, a, pl, s, wide))) return rc;
@@ -751,10 +801,31 @@ static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
             const bool third = amx_gcert2_third(ctx, lut, wide);
             a.rlist = (const int *)ctx->rlist.p + amx_gcert2_leftover_offset(pl, wide, third); a.rcount = amx_gcert2_leftover_counts(pl, wide, third);   // (two wide passes end in the first half again)
             a.c.chunks = pl.schunks; a.c.n_chunks = pl.n_chunks + 1;
+            // AMX_FORK bit 1: the voxels these certificates left over (0.6 %) do not come back to the lane kernels -- k_noddi<4> and then
+            // k_noddi<3> (no seed: Lawson-Hanson on the support it has just found, plus iso) finish them, a wavefront per voxel, on the side
+            // stream, while k_nnls_seed<3> / k_nnls_gcert<3> work on everybody else (they skip the voxels whose certificate flag is not 1)
+            fork2 = (ctx->opt_fork & 2) && (ctx->opt_seed_stages & 2) && !ctx->opt_no_gcert && gemm_ks > 0;
         }
         rec(ctx, 13, s);
     }
-    if (!(rc = amx_launch_noddi_s2(ctx, a, pl, s))) {
+    if (fork1 && !joined1) HIPCHK(ctx, hipStreamWaitEvent(s, fev[1], 0));
+    if (fork2) {
+        HIPCHK(ctx, hipEventRecord(fev[2], s));
+        HIPCHK(ctx, hipStreamWaitEvent(fs, fev[2], 0));
+        ctx->side_launch = true;
+        NoddiArgs b = a;
+        rc = amx_launch_noddi_s2(ctx, b, pl, fs);
+        if (!rc) {
+            b = a;      // (same left-over lists, same chunks: now stage 3 without seeds)
+            b.seeds = nullptr; b.done = nullptr; b.seeds2 = nullptr; b.cand_lists = 0;
+            rc = amx_launch_noddi_s3(ctx, b, pl, fs);
+        }
+        ctx->side_launch = false;
+        if (rc) return rc;
+        HIPCHK(ctx, hipEventRecord(fev[3], fs));
+        a.fork_l2 = 1;
+    }
+    if (fork2 || !(rc = amx_launch_noddi_s2(ctx, a, pl, s))) {
         progress_tick(ctx, s, 2 * (n_vox / 3), n_vox);
         a.seeds = nullptr; a.done = nullptr; a.rlist = nullptr; a.rcount = nullptr;
         a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks;
@@ -775,6 +846,7 @@ static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
         }
         if (!rc) rc = amx_launch_noddi_s3(ctx, a, pl, s);
     }
+    if (fork2) HIPCHK(ctx, hipStreamWaitEvent(s, fev[3], 0));      // the side stream's voxels are part of this fit
     hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, s, (const int *)ctx->misc.p, ctx->status_d);
     rec(ctx, 1, s);
     if (!rc) progress_tick(ctx, s, n_vox, n_vox);
@@ -787,6 +859,7 @@ static int freewater_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y
                              int is_mouse, unsigned flags, double *d_estimates, double *d_rmse,
                              double *d_nrmse, double *d_ycorr, void *hip_stream)
 {
+    if (ctx && !(ctx->in_host_fit && ctx->vox_base > 0)) ctx->path.clear();
     if (!ctx) return AMX_E_BADARG;
     if (!lut || lut->model != 2 || lut->ctx != ctx) return bad(ctx, "amx_freewater_fit: not a FreeWater dictionary of this ctx");
     if (n_vox < 0 || n_vox > INT_MAX / 4) return bad(ctx, "amx_freewater_fit: bad n_vox");
@@ -831,6 +904,7 @@ static int sandi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
                          double lambda1, double lambda2, unsigned flags, double *d_estimates,
                          double *d_rmse, double *d_nrmse, void *hip_stream)
 {
+    if (ctx && !(ctx->in_host_fit && ctx->vox_base > 0)) ctx->path.clear();
     if (!ctx) return AMX_E_BADARG;
     if (!lut || lut->model != 3 || lut->ctx != ctx) return bad(ctx, "amx_sandi_fit: not a SANDI dictionary of this ctx");
     if (n_vox < 0 || n_vox > INT_MAX / 4) return bad(ctx, "amx_sandi_fit: bad n_vox");
@@ -880,6 +954,7 @@ static int czb_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, cons
                        double lambda1, double lambda2, unsigned flags, double *d_estimates, double *d_rmse,
                        double *d_nrmse, void *hip_stream)
 {
+    if (ctx && !(ctx->in_host_fit && ctx->vox_base > 0)) ctx->path.clear();
     if (!ctx) return AMX_E_BADARG;
     if (!lut || lut->model != 4 || lut->ctx != ctx) return bad(ctx, "amx_czb_fit: not a CylinderZeppelinBall dictionary of this ctx");
     if (n_vox < 0 || n_vox > INT_MAX / 4) return bad(ctx, "amx_czb_fit: bad n_vox");

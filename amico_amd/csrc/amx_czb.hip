@@ -432,10 +432,12 @@ int amx_launch_czb_fast(amx_ctx *ctx, const amx_lut *lut, CzbArgs &a, const Plan
         if ((rc = set_lds(ctx, k_czb_project<40>, lds))) return rc;
         hipLaunchKernelGGL(k_czb_project<40>, grid, dim3(512), lds, s, f);
     }
+    amx_note(ctx, lut->nS <= 100 ? "k_czb_project<25>" : "k_czb_project<40>");
     AMX_TRACE(ctx, s, "z0 = M A'y on the matrix cores");
     const size_t lds2 = ((size_t)2 * kCzbN * kCzbLd + 2 + (size_t)4 * 2 * kCzbN * 64) * sizeof(double);
     if ((rc = set_lds(ctx, k_czb_lane, lds2))) return rc;
     hipLaunchKernelGGL(k_czb_lane, grid, dim3(256), lds2, s, f);
+    amx_note(ctx, "k_czb_lane");
     AMX_TRACE(ctx, s, "complementary-form pivoting, one voxel per lane");
     // voxels with more clamped atoms than a lane holds: the wavefront-per-voxel kernel, one wavefront per workgroup
     {

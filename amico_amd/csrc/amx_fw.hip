@@ -8,7 +8,7 @@ static int go(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s)
     constexpr int NQ = 1, MP = 16, MB = 64;
     constexpr int NW = 8;
     return launch_pair<NW>(ctx, a, pl, s, k_freewater<NR, NQ, MP, NW, false>, k_freewater<NR, NQ, MB, 1, true>,
-                       [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MP); }, fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB), 0, 2);
+                       [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MP); }, fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB), 0, 2, "k_freewater (wavefront per voxel)");
 }
 
 int amx_launch_fw(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s)

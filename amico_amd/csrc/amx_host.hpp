@@ -57,6 +57,7 @@ struct amx_ctx {
     {
         DevBuf *named[22] = {&lutidx, &perm, &counts, &dir_start, &cursor, &chunks, &misc, &xiso, &supp, &ovf, &cproj, &ytil, &seeds, &schunks, &ytil2, &seeds2, &cgemm, &done, &rlist, &cgemm2, &clip, &feed};
         for (int i = 0; i < 22; i++) { DevBuf t = *named[i]; *named[i] = alt[i]; alt[i] = t; }
+        work_idx ^= 1;
     }
     // switches read ONCE, at amx_ctx_create (environment): diagnosis / A-B only
     // switches below: environment variables read ONCE, at amx_ctx_create (diagnosis / A-B tools; the defaults are the product path)
@@ -104,6 +105,17 @@ struct amx_ctx {
     bool opt_no_hard_first = false; // AMX_NO_HARD_FIRST=1: the left-over kernels of the NNLS stages walk their lists in the order the certificates wrote them
     int opt_seed_waves = 0;        // AMX_SEED_WAVES: wavefronts per workgroup of the lane kernels (0 = by the number of chunks, make_plan)
     int opt_seed_stages = 7;       // AMX_SEED_STAGES: bit 0 = seed stage 1, bit 1 = seed stage 3, bit 2 = seed the LASSO stage
+    // AMX_FORK (round 6; bit 0 / bit 1): the left-over kernels of stage 1 / of the LASSO stage run on a SIDE stream beside the next stage's
+    // lane kernels (noddi_fit_dev).  Bit 1 is a correct fit (the forked voxels skip the stage-3 lane kernels and end in k_noddi<3> on the side
+    // stream); bit 0 is a TIMING PROBE only (the stage-2 lane kernels read the x_iso the previous call left for those voxels).
+    int opt_fork = 0;
+    int opt_fork_cus = 0;           // AMX_FORK_CUS=n: the side stream may use n compute units only (hipExtStreamCreateWithCUMask; 0 = no mask)
+    int opt_fork_prio = 0;          // AMX_FORK_PRIO=1: the side stream at the highest priority
+    hipStream_t fork_s[2] = {nullptr, nullptr};          // (one per workspace set: work_idx)
+    hipEvent_t fork_ev[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+    int work_idx = 0;               // which of the two workspace sets the named buffers are (swap_work)
+    bool side_launch = false;       // transient: the launch being enqueued goes to the side stream (launch_pair picks its own overflow lists)
+    std::string path;               // kernels of the last fit enqueued on this ctx, in launch order (amx_last_path)
     int opt_seed_chunk = 0;        // AMX_SEED_CHUNK (0 = by the call's size, make_plan): voxels of one orientation per workgroup of the seed solvers (lanes refill from the chunk: the more voxels per lane, the smaller the share of the tail; 1 M voxels: 1024 -> 7.2 ms, 2048 -> 7.3, 4096 -> 5.5 for stage 1)
 };
 
@@ -195,6 +207,14 @@ struct amx_prep {
             return AMX_E_HIP;                                                                     \
         }                                                                                         \
     } while (0)
+
+// amx_last_path: every launch site names its kernel (the first batch of a host-buffer call only)
+static inline void amx_note(amx_ctx *ctx, const char *kernel)
+{
+    if ((ctx->in_host_fit && ctx->vox_base > 0) || ctx->path.size() > 1500) return;
+    if (!ctx->path.empty()) ctx->path += " -> ";
+    ctx->path += kernel;
+}
 
 static inline int amx_bad(amx_ctx *ctx, const char *msg)
 {

@@ -162,6 +162,7 @@ struct NoddiArgs {
     unsigned long long *supp;     // [n_vox][4]  stage-2 support bit set
     double *est, *rmse, *nrmse, *mod;
     int list_is_pos;              // stage 4: the overflow list holds bucket positions (seeded fit), not voxel numbers
+    int fork_l2;                  // host side only (round 6, AMX_FORK bit 1): the LASSO left-overs are finished on the side stream
 };
 
 // STAGE 1 = NNLS (models.pyx:911), 2 = LASSO by the QR solver, 4 = LASSO by the Gram solver

@@ -28,8 +28,9 @@ static inline bool amx_noddi_tile_global(int nS, int ldA, int n_atoms)
 // LDSF(nw) -> dynamic LDS bytes of the main kernel with nw wavefronts per workgroup
 template <int NW, typename Args, typename KM, typename KL, typename LDSF>
 static int launch_pair(amx_ctx *ctx, Args &a, const Plan &pl, hipStream_t s, KM km, KL kl, LDSF ldsf,
-                       size_t lds_list, int slot, int ev)
+                       size_t lds_list, int slot, int ev, const char *name = "wavefront-per-voxel solver")
 {
+    amx_note(ctx, name);
     int rc;
     int nw = NW;                               // fewer wavefronts per workgroup for long protocols
     while (nw > 1 && ldsf(nw) > kLdsPerCU) nw >>= 1;
@@ -38,8 +39,12 @@ static int launch_pair(amx_ctx *ctx, Args &a, const Plan &pl, hipStream_t s, KM 
         ctx->err = "dictionary tile does not fit the 160 KB LDS of a CU (nS x n_atoms too large)";
         return AMX_E_BADARG;
     }
+    // overflow lists: slot 0 .. 2 = the three stages (counts at misc[4 + slot], lists of n ints each), second level behind them (misc[12], list 3).
+    // A launch on the side stream of a forked fit (ctx->side_launch; round 6) must not share a list with the main stream's kernels that may
+    // run beside it: its stage-3 pass takes slot 3 (misc[7], list 4) and its re-run kernels count into misc[13] (list 5)
+    if (ctx->side_launch && slot == 2) slot = 3;
     a.c.ovf_count = pl.ovf_count + slot;
-    a.c.ovf_list = pl.ovf_list + (size_t)slot * pl.n;
+    a.c.ovf_list = pl.ovf_list + (size_t)(slot < 3 ? slot : 4) * pl.n;
     a.c.list = a.c.ovf_list;
     a.c.list_count = a.c.ovf_count;
     if ((rc = set_lds(ctx, km, lds_main))) return rc;
@@ -48,8 +53,8 @@ static int launch_pair(amx_ctx *ctx, Args &a, const Plan &pl, hipStream_t s, KM 
     hipLaunchKernelGGL(km, dim3(((pl.max_chunks + 7) / 8) * 8), dim3(nw * 64), lds_main, s, a);   // see xcd_chunk()
     AMX_TRACE(ctx, s, "solver main pass");
     Args b = a;
-    b.c.ovf_count = pl.ovf_count + 8;
-    b.c.ovf_list = pl.ovf_list + 3 * pl.n;
+    b.c.ovf_count = pl.ovf_count + (ctx->side_launch ? 9 : 8);
+    b.c.ovf_list = pl.ovf_list + (size_t)(ctx->side_launch ? 5 : 3) * pl.n;
     hipLaunchKernelGGL(kl, dim3(kListGrid), dim3(64), lds_list, s, b);
     AMX_TRACE(ctx, s, "solver re-run pass");
     rec(ctx, ev + 1, s);

@@ -20,18 +20,18 @@ static int go(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
     if (a.rlist != nullptr && fit_lds_bytes<double>(a.c.nS, a.c.ldA, NR, NQ, 12, 12, false, false) + scr <= kLdsPerCU && !ctx->opt_tile_f32)
         return launch_pair<12>(ctx, a, pl, s, k_noddi<1, NR, NQ, 12, 12, false, double>, k_noddi<1, NR, NQ, MB, 1, true>,
                                [&](int nw) { return fit_lds_bytes<double>(a.c.nS, a.c.ldA, NR, NQ, nw, 12, false, false) + scr; },
-                               fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, false), 0, 2);
+                               fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, false), 0, 2, a.rlist ? "k_noddi<1> (left-overs of k_nnls_gcert<1>)" : "k_noddi<1> (all voxels)");
     // fp64 tile in LDS when it fits next to the per-wavefront blocks (99 x 145: 115 KB + 16 x 2.3 KB of 160 KB): the
     // fp32 -> fp64 conversions of the tile reads are then paid once per chunk.  AMX_TILE_F32=1: the fp32 tile.
     {
         if (fit_lds_bytes<double>(a.c.nS, a.c.ldA, NR, NQ, NW, MP, false, false) + scr <= kLdsPerCU && !ctx->opt_tile_f32)
             return launch_pair<NW>(ctx, a, pl, s, k_noddi<1, NR, NQ, MP, NW, false, double>, k_noddi<1, NR, NQ, MB, 1, true>,
                                    [&](int nw) { return fit_lds_bytes<double>(a.c.nS, a.c.ldA, NR, NQ, nw, MP, false, false) + scr; },
-                                   fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, false), 0, 2);
+                                   fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, false), 0, 2, a.rlist ? "k_noddi<1> (left-overs of k_nnls_gcert<1>)" : "k_noddi<1> (all voxels)");
     }
     return launch_pair<NW>(ctx, a, pl, s, k_noddi<1, NR, NQ, MP, NW, false>, k_noddi<1, NR, NQ, MB, 1, true>,
                        [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MP, false, false) + scr; }, fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, false),
-                       0, 2);
+                       0, 2, a.rlist ? "k_noddi<1> (left-overs of k_nnls_gcert<1>)" : "k_noddi<1> (all voxels)");
 }
 
 // Any shape the reference's loop takes (models.pyx:825-861: any nS, any n_wm): protocols of more than 256 volumes, dictionaries of more
@@ -43,7 +43,7 @@ static int go_global(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
     const size_t scr = (a.scr_S && a.seeds) ? (size_t)kSeedKD * kScreenLd * sizeof(float) : 0;
     return launch_pair<NW>(ctx, a, pl, s, k_noddi<1, NR, NQ, MP, NW, false, float, true>, k_noddi<1, NR, NQ, MB, 1, true, float, true>,
                            [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MP, false, false, true) + scr; },
-                           fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, false, true), 0, 2);
+                           fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, false, true), 0, 2, a.rlist ? "k_noddi<1> (left-overs of k_nnls_gcert<1>)" : "k_noddi<1> (all voxels)");
 }
 
 int amx_launch_noddi_s1(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)

@@ -10,7 +10,7 @@ static int go_qr(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
     constexpr int NW = 8;   // wavefronts per workgroup: as many as the register budget of this stage allows
     return launch_pair<NW>(ctx, a, pl, s, k_noddi<2, NR, NQ, MP, NW, false>, k_noddi<2, NR, NQ, MB, 1, true>,
                        [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MP); }, fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB),
-                       1, 4);
+                       1, 4, a.rlist ? "k_noddi<4|2> (left-overs of k_lasso_gcert)" : "k_noddi<4|2> (all voxels)");
 }
 
 // Gram-space variant (amx_gram_solver.hpp): needs the Gram matrices and a ridge that bounds cond(H)
@@ -26,11 +26,11 @@ static int go_gram(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
         constexpr int MPL = 32, NWL = AMX_S2_NW / 2;
         return launch_pair<NWL>(ctx, a, pl, s, k_noddi<4, NR, NQ, MPL, NWL, false>, k_noddi<4, NR, NQ, MB, 1, true>,
                            [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MPL, true) + scr; }, fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, true),
-                           1, 4);
+                           1, 4, a.rlist ? "k_noddi<4|2> (left-overs of k_lasso_gcert)" : "k_noddi<4|2> (all voxels)");
     }
     return launch_pair<NW>(ctx, a, pl, s, k_noddi<4, NR, NQ, MP, NW, false>, k_noddi<4, NR, NQ, MB, 1, true>,
                        [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MP, true) + scr; }, fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, true),
-                       1, 4);
+                       1, 4, a.rlist ? "k_noddi<4|2> (left-overs of k_lasso_gcert)" : "k_noddi<4|2> (all voxels)");
 }
 
 // shapes beyond the LDS variants (see amx_noddi_s1.hip): the tile read where it lies; passive sets of up to 32 atoms in the main
@@ -43,12 +43,12 @@ static int go_global(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s, 
         const size_t scr = (a.scr2_S && a.seeds2) ? (size_t)kSeedKD * kScreenLd * sizeof(float) : 0;
         return launch_pair<NW>(ctx, a, pl, s, k_noddi<4, NR, NQ, MP, NW, false, float, true>, k_noddi<4, NR, NQ, MB, 1, true, float, true>,
                                [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MP, true, true, true) + scr; },
-                               fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, true, true, true), 1, 4);
+                               fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, true, true, true), 1, 4, a.rlist ? "k_noddi<4|2> (left-overs of k_lasso_gcert)" : "k_noddi<4|2> (all voxels)");
     }
     constexpr int MP = 20, MB = 32;       // (A-space QR: the factor lives in registers -- 32 x 8 rows per lane is what a wavefront holds)
     return launch_pair<NW>(ctx, a, pl, s, k_noddi<2, NR, NQ, MP, NW, false, float, true>, k_noddi<2, NR, NQ, MB, 1, true, float, true>,
                            [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MP, false, true, true); },
-                           fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, true, true), 1, 4);
+                           fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, true, true), 1, 4, a.rlist ? "k_noddi<4|2> (left-overs of k_lasso_gcert)" : "k_noddi<4|2> (all voxels)");
 }
 
 int amx_launch_noddi_s2(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)

@@ -20,11 +20,11 @@ static int go(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
         if (fit_lds_bytes<double>(a.c.nS, a.c.ldA, NR, NQ, NW, MP, false, false) + scr <= kLdsPerCU && !ctx->opt_tile_f32)
             return launch_pair<NW>(ctx, a, pl, s, k_noddi<3, NR, NQ, MP, NW, false, double>, k_noddi<3, NR, NQ, MB, 1, true>,
                                    [&](int nw) { return fit_lds_bytes<double>(a.c.nS, a.c.ldA, NR, NQ, nw, MP, false, false) + scr; },
-                                   fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, false), 2, 6);
+                                   fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, false), 2, 6, a.rlist ? "k_noddi<3> (left-overs)" : "k_noddi<3> (all voxels)");
     }
     return launch_pair<NW>(ctx, a, pl, s, k_noddi<3, NR, NQ, MP, NW, false>, k_noddi<3, NR, NQ, MB, 1, true>,
                        [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MP, false, false) + scr; }, fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, false),
-                       2, 6);
+                       2, 6, a.rlist ? "k_noddi<3> (left-overs)" : "k_noddi<3> (all voxels)");
 }
 
 // shapes beyond the LDS variants (see amx_noddi_s1.hip): the tile read where it lies
@@ -34,7 +34,7 @@ static int go_global(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
     const size_t scr = (a.scr_S && a.seeds) ? (size_t)kSeedKD * kScreenLd * sizeof(float) : 0;
     return launch_pair<NW>(ctx, a, pl, s, k_noddi<3, NR, NQ, MP, NW, false, float, true>, k_noddi<3, NR, NQ, MB, 1, true, float, true>,
                            [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MP, false, false, true) + scr; },
-                           fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, false, true), 2, 6);
+                           fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, false, true), 2, 6, a.rlist ? "k_noddi<3> (left-overs)" : "k_noddi<3> (all voxels)");
 }
 
 int amx_launch_noddi_s3(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)

@@ -96,6 +96,7 @@ int amx_launch_noddi_seed2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a,
         if ((rc = set_lds(ctx, k_lasso_seed<false>, lds))) return rc;
         hipLaunchKernelGGL(k_lasso_seed<false>, dim3(((pl.max_schunks + 7) / 8) * 8), dim3(64 * pl.seed2_waves), lds, s, sa);
     }
+    amx_note(ctx, pl.seed2_occ2 ? "k_lasso_seed<occ2>" : "k_lasso_seed");
     AMX_TRACE(ctx, s, "LASSO seed solver");
     HIPCHK(ctx, hipGetLastError());
     return AMX_OK;
@@ -132,7 +133,9 @@ static int gemm_window(int nS) { const int np = gemm_passes(nS); return ((nS + n
 int amx_gemm_ksteps(const amx_lut *lut)
 {
     if (lut->n_atoms > 160 || lut->n_wm > 144 || lut->nS > 512) return 0;
-    const int ks = gemm_window(lut->nS) <= 100 ? 25 : 40;
+    // (every windowed launch is the KS = 40 build, whatever its window: the LDS size and this fit check must be those of the launched template --
+    //  161 .. 200 volumes have windows of 84 .. 100 samples and were sized for 25 K-steps until round 6: operands beyond the allocation)
+    const int ks = (gemm_passes(lut->nS) > 1 || gemm_window(lut->nS) > 100) ? 40 : 25;
     if (gemm_lds(lut->n_atoms, gemm_rows(lut->n_atoms), ks) > kLdsPerCU) return 0;
     return ks;
 }
@@ -167,13 +170,14 @@ int amx_launch_noddi_gemm(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, 
         ga.accumulate = p > 0 ? 1 : 0; ga.last = p == n_pass - 1 ? 1 : 0;
         // (every window walks all voxels: its launch starts from fresh chunk counters)
         if (p > 0 && !lasso) HIPCHK(ctx, hipMemsetAsync(ga.gcount, 0, (size_t)(pl.max_schunks + 8) * sizeof(int), s));
-        if (n_pass > 1) { if (lasso) AMX_GEMM_GO(true, 40, 0, true); else AMX_GEMM_GO(false, 40, 0, true); }      // windows: K-steps 40 (gemm_window > 100)
+        if (n_pass > 1) { if (lasso) AMX_GEMM_GO(true, 40, 0, true); else AMX_GEMM_GO(false, 40, 0, true); }      // windows: always the K-steps 40 build (amx_gemm_ksteps sizes the LDS for it)
         else if (ks == 25 && mtf == 9 && !lasso) AMX_GEMM_GO(false, 25, 9);          // the default dictionary: unrolled tile loop
         else if (ks == 25) { if (lasso) AMX_GEMM_GO(true, 25); else AMX_GEMM_GO(false, 25); }
         else if (ks == 40) { if (lasso) AMX_GEMM_GO(true, 40); else AMX_GEMM_GO(false, 40); }
         else return amx_bad(ctx, "k_noddi_gemm: unsupported dictionary shape");
     }
 #undef AMX_GEMM_GO
+    amx_note(ctx, lasso ? "k_noddi_gemm<lasso> (clipped voxels)" : (n_pass > 1 ? "k_noddi_gemm<windows>" : (ks == 25 && mtf == 9 ? "k_noddi_gemm<false,25,9>" : (ks == 25 ? "k_noddi_gemm<false,25>" : "k_noddi_gemm<false,40>"))));
     AMX_TRACE(ctx, s, lasso ? "stage-2 products of the clipped voxels on the matrix cores" : "A'y of every voxel on the matrix cores");
     HIPCHK(ctx, hipGetLastError());
     return AMX_OK;
@@ -190,6 +194,7 @@ int amx_launch_noddi_s2prep(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a
     p.clist = (int *)ctx->clip.p; p.cslot = p.clist + pl.n; p.ccount = pl.zcount(ZC_CLIP);      // (counts: cleared with the plan)
     p.status = a.c.status; p.force_all = (!lut->s2_derive || ctx->opt_s2_exact) ? 1 : 0;
     hipLaunchKernelGGL(k_s2_prep, dim3(((pl.max_schunks + 7) / 8) * 8), dim3(256), 0, s, p);
+    amx_note(ctx, "k_s2_prep");
     AMX_TRACE(ctx, s, "stage-2 signals from the table, clipped voxels compacted");
     HIPCHK(ctx, hipGetLastError());
     return amx_launch_noddi_gemm(ctx, lut, a, pl, s, true);
@@ -236,6 +241,7 @@ int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a
     int rc;
     if ((rc = set_lds(ctx, (k_lasso_gcert<kGcert2Max, false>), lds))) return rc;
     hipLaunchKernelGGL((k_lasso_gcert<kGcert2Max, false>), dim3(((pl.max_schunks + 7) / 8) * 8), dim3(64 * pl.seed_waves), lds, s, g);
+    amx_note(ctx, "k_lasso_gcert<11>");
     AMX_TRACE(ctx, s, "Gram-space certificates of the LASSO seeds");
     HIPCHK(ctx, hipGetLastError());
     if (wide) {
@@ -247,6 +253,7 @@ int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a
 #endif
         if ((rc = set_lds(ctx, (k_lasso_gcert<kGcert2Wide, true>), lds))) return rc;
         hipLaunchKernelGGL((k_lasso_gcert<kGcert2Wide, true>), dim3(((pl.max_schunks + 7) / 8) * 8), dim3(64 * pl.seed_waves), lds, s, g);
+        amx_note(ctx, "k_lasso_gcert<18,wide>");
         AMX_TRACE(ctx, s, "Gram-space certificates of the LASSO seeds, supports of 12 .. 18 atoms");
         HIPCHK(ctx, hipGetLastError());
         if (third) {
@@ -258,6 +265,7 @@ int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a
 #endif
             if ((rc = set_lds(ctx, (k_lasso_gcert<kGcert2Wide3, true, kGcert2Wide>), lds))) return rc;
             hipLaunchKernelGGL((k_lasso_gcert<kGcert2Wide3, true, kGcert2Wide>), dim3(((pl.max_schunks + 7) / 8) * 8), dim3(64 * pl.seed_waves), lds, s, g);
+            amx_note(ctx, "k_lasso_gcert<24,wide,18>");
             AMX_TRACE(ctx, s, "Gram-space certificates of the LASSO seeds, supports beyond the second pass");
             HIPCHK(ctx, hipGetLastError());
         }
@@ -278,7 +286,12 @@ int amx_launch_noddi_gcert(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a,
     g.gram = lut->gram; g.ldG = lut->ldG; g.n_atoms = lut->n_atoms; g.n_wm = lut->n_wm; g.nS = lut->nS;
     g.iso_atom = lut->n_atoms - 1; g.dot_atom = lut->is_exvivo ? lut->n_atoms - 2 : -1; g.n_maps = a.n_maps;
     g.Sb = lut->basis_S; g.kappa0 = lut->screen_kappa0; g.supp = a.supp; g.icvf = lut->icvf; g.kappa = lut->kappa;
-    g.done = (unsigned char *)ctx->done.p; g.rlist = (int *)ctx->rlist.p; g.rcount = pl.zcount(stage == 1 ? ZC_CERT1 : ZC_CERT3);
+    // (forked fit, stage 3: the LASSO stage's left-over lists -- either half of the buffer -- are still being read on the side stream:
+    //  this stage's lists go behind them)
+    const size_t lbase = (stage == 3 && a.fork_l2) ? 2 * amx_rlist_half(pl) : 0;
+    g.fork_skip = (stage == 3 && a.fork_l2) ? 1 : 0;
+    g.done = (unsigned char *)ctx->done.p; g.rlist = (int *)ctx->rlist.p + lbase; g.rcount = pl.zcount(stage == 1 ? ZC_CERT1 : ZC_CERT3);
+    *list_off = lbase;
     *count_out = g.rcount;
     g.gcount = pl.feed_set(stage == 1 ? FEED_CERT1 : FEED_CERT3); g.n_gcount = pl.max_schunks;
     g.xiso = a.xiso; g.est = a.est; g.rmse = a.rmse; g.nrmse = a.nrmse; g.mod = a.mod;
@@ -305,6 +318,7 @@ int amx_launch_noddi_gcert(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a,
         if ((rc = set_lds(ctx, k_nnls_gcert<3>, lds))) return rc;
         hipLaunchKernelGGL(k_nnls_gcert<3>, grid, dim3(64 * pl.seed_waves), lds, s, g);
     }
+    amx_note(ctx, stage == 1 ? (repair ? "k_nnls_gcert<1,repair>" : "k_nnls_gcert<1>") : (repair ? "k_nnls_gcert<3,repair>" : "k_nnls_gcert<3>"));
     AMX_TRACE(ctx, s, "Gram-space certificates");
     HIPCHK(ctx, hipGetLastError());
     // (ex-vivo dictionaries leave 7 % of the voxels instead of 5 and 2.5 % -- the dot atom makes more supports ill-conditioned -- and
@@ -320,7 +334,7 @@ int amx_launch_noddi_gcert(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a,
         // 8.08 -> 8.24 ms with it, 4 M 24.99 -> 24.38): the supports refused for conditioning, corrected with the signal itself;
         // what is left goes to the second half
         g.rlist_in = g.rlist; g.rcount_in = g.rcount;
-        g.rlist = (int *)ctx->rlist.p + amx_rlist_half(pl); g.rcount = pl.zcount(stage == 1 ? ZC_RESC1 : ZC_RESC3);
+        g.rlist = (int *)ctx->rlist.p + lbase + amx_rlist_half(pl); g.rcount = pl.zcount(stage == 1 ? ZC_RESC1 : ZC_RESC3);
         *count_out = g.rcount;
         g.y = a.c.y; g.y32 = a.c.y32; g.tiles = (const float *)lut->tiles; g.tile_stride = lut->tile_stride; g.ldA = lut->ldA;
         const size_t tile = (size_t)lut->nS * lut->ldA * sizeof(float);
@@ -333,9 +347,10 @@ int amx_launch_noddi_gcert(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a,
             if ((rc = set_lds(ctx, (k_nnls_gcert<3, true>), lds2))) return rc;
             hipLaunchKernelGGL((k_nnls_gcert<3, true>), grid, dim3(64 * pl.seed_waves), lds2, s, g);
         }
+        amx_note(ctx, stage == 1 ? "k_nnls_gcert<1,rescue>" : "k_nnls_gcert<3,rescue>");
         AMX_TRACE(ctx, s, "Gram-space certificates, rescue pass");
         HIPCHK(ctx, hipGetLastError());
-        *list_off = amx_rlist_half(pl);
+        *list_off = lbase + amx_rlist_half(pl);
     }
     return AMX_OK;
 }
@@ -356,7 +371,7 @@ int amx_launch_noddi_seed(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, 
 {
     SeedArgs sa; fill(sa, lut, a, pl, ctx);
     sa.supp = stage == 3 ? a.supp : nullptr;
-    if (stage == 3 && a.cand_lists && a.seeds2 != nullptr) { sa.cand8 = a.seeds2; sa.cdone = (const unsigned char *)ctx->done.p; }
+    if (stage == 3 && a.cand_lists && a.seeds2 != nullptr) { sa.cand8 = a.seeds2; sa.cdone = (const unsigned char *)ctx->done.p; sa.fork_skip = a.fork_l2; }
     sa.trip_cap = ctx->opt_seed_tripcap[stage == 1 ? 0 : 2];
     // S for the per-lane gathers + ticket; stage 1 adds S in MFMA operand order (10 x 3 x 64) and a residual block per wavefront
     const size_t lds = (size_t)lut->n_atoms * kSeedLd * sizeof(double) + 64 +
@@ -375,6 +390,7 @@ int amx_launch_noddi_seed(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a, 
         if ((rc = set_lds(ctx, (k_nnls_seed<3, 6>), lds))) return rc;
         hipLaunchKernelGGL((k_nnls_seed<3, 6>), grid, dim3(64 * pl.seed_waves), lds, s, sa);
     }
+    amx_note(ctx, stage == 1 ? (pl.seed_occ2 ? "k_nnls_seed<1,8,occ2>" : "k_nnls_seed<1,8>") : "k_nnls_seed<3,6>");
     AMX_TRACE(ctx, s, "seed solver");
     HIPCHK(ctx, hipGetLastError());
     return AMX_OK;

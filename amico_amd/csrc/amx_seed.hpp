@@ -103,6 +103,9 @@ __device__ __forceinline__ void seed_col(const double *col, double (&cv)[KD])
 }
 constexpr int kSeedLd = 14;      // LDS row stride of S (odd: per-lane column gathers spread over the banks)
 constexpr unsigned long long kNoSeed = kSeedNone;
+// round 6 (AMX_FORK bit 1): a voxel the LASSO certificates left over is finished on a SIDE stream (k_noddi<4> -> k_noddi<3>, a wavefront per
+// voxel) while the stage-3 lane kernels run: k_nnls_seed<3> marks it so, k_nnls_gcert<3> neither certifies it nor lists it
+constexpr unsigned long long kSeedForked = 0xfffffffffffffffdull;
 
 // ------------------------------------------------------------------ basis of one orientation
 // One workgroup per orientation.  tile: float [nS][ldA]; rowsel (optional): rows of the sub-problem (others zero);
@@ -227,6 +230,7 @@ struct SeedArgs {
     int n_gcount;
     int *stats;                   // optional counters (AMX_STATS): [0] trips, [1] lane-trips in use, [2] voxels, [3] no-seed voxels
     int trip_cap;                 // a voxel still on its way after this many trips is given up (no seed: left-over list)
+    int fork_skip;                // stage 3: 1 = the voxels the LASSO certificates did not settle (cdone != 1) are finished elsewhere (kSeedForked)
 };
 
 template <int NR>
@@ -763,7 +767,7 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
                 //  drops them, an index in the mantissa of an infinity is a NaN as well), so the voxel is done in its first trip or at
                 //  the trip cap at the latest, and the certificate refuses it on ||y||^2 whatever seed it got: the wavefront-per-voxel
                 //  kernel writes its NaN maps)
-                const bool finite = true;
+                bool finite = true;                             // (stage 3, forked fit: false for the voxels finished on the side stream)
                 trips = 0; last_added = -1; ban0 = -1; ban1 = -1;
                 V.clear();
                 ncand = -1;                                     // (byte list below)
@@ -777,7 +781,8 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
                         ready = flag == 1;
                         if (ready) { cand[0] = c0; cand[STAGE == 3 ? 1 : 0] = c1; cand[STAGE == 3 ? 2 : 0] = c2; cand[STAGE == 3 ? 3 : 0] = c3 & 0x00ffffffffffffffull; ncand = (int)(c3 >> 56); }
                     }
-                    if (__ballot(!ready) != 0ull) {
+                    if (a.fork_skip && !ready) { finite = false; ncand = 0; }
+                    else if (__ballot(!ready) != 0ull) {
                         if (!ready) {
                             const int vox = a.perm[pos];
 #pragma unroll
@@ -788,7 +793,7 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
                     }
                 }
                 if (finite) active = true;
-                else a.seeds[pos] = kNoSeed;
+                else a.seeds[pos] = (STAGE == 3 && a.fork_skip) ? kSeedForked : kNoSeed;
             }
         }
         if (__ballot(active) == 0ull) {
@@ -886,6 +891,10 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
                 for (int d = 0; d < KD; d++) r[d] -= V.x[s] * cv[d];
             }
             SEED_PH(2);
+            // the explicit guard for non-finite signals (round 6): r = y~ - S x with finite x, so r[0] is finite iff y~[0] is, and
+            // y~[0] = u_0'y sums EVERY sample of the voxel (NaN x 0 and Inf x 0 are NaN): one compare on a value that is in a register anyway
+            // -- the lane mask lives in scalar registers -- instead of the chain of 12 loads that the take used to wait for
+            const bool rfin = fabs(r[0]) <= 1.79769313486231570e308;
             double best = -inf;
             int bj = -1;
             if (STAGE == 1) {
@@ -961,7 +970,9 @@ __global__ void __launch_bounds__(256, (MS > 6 ? (OCC2 ? 2 : AMX_SEED1_OCC) : AM
                 bool inp = false;
 #pragma unroll
                 for (int s = 0; s < MS; s++) inp = inp || (s < V.np && V.idx[s] == bj);
-                if (!(best > tol) || bj < 0 || inp) {
+                if (!rfin) {
+                    done = true; noseed = true; V.np = 0;                // non-finite signal: no seed, the wavefront-per-voxel kernel writes the NaN maps
+                } else if (!(best > tol) || bj < 0 || inp) {
                     done = true;                                         // KKT point of the compressed problem
                 } else if (V.np >= MS || trips > trip_cap) {
                     done = true; noseed = true;                          // no usable seed
@@ -1542,6 +1553,7 @@ struct GcertArgs {
     double *est, *rmse, *nrmse, *mod;  // stage 3 out
     double *xdbg;                      // AMX_F_DEBUG_X: [n_vox][3][n_atoms]
     int *stats;
+    int fork_skip;                     // stage 3: 1 = voxels marked kSeedForked are neither certified nor listed (finished on the side stream)
 };
 
 // REPAIR (round 5; long protocols, where the compressed-space seed is wrong in 4.5 % of the voxels instead of 0.9 %): a lane whose seed
@@ -1609,12 +1621,13 @@ __global__ void __launch_bounds__(256, RESCUE ? 1 : 2) k_nnls_gcert(const GcertA
         if (RESCUE) { if (64 * bl >= n_items) break; }
         else { bl = bf.next(a.gcount + cid, ck.count, lane); if (bl < 0) break; }
         const int k = 64 * bl + lane;
-        const bool valid = k < n_items;
-        const int kk = valid ? k : n_items - 1;
+        const bool valid0 = k < n_items;
+        const int kk = valid0 ? k : n_items - 1;
         const int pos = RESCUE ? a.rlist_in[ck.start + kk] : ck.start + kk;
         const int rel = pos - ck.start;                                   // (first pass: rel = 64 bl + lane)
         const double *Crow = a.Cb + (size_t)(ck.pad + (rel >> 6)) * a.rows * 64 + (rel & 63);
         const unsigned long long seed = a.seeds[pos];
+        const bool valid = valid0 && !(STAGE == 3 && a.fork_skip && seed == kSeedForked);
         const int vox = a.perm[pos];
         SeedLane<MS> V;
         V.clear();

@@ -1624,6 +1624,7 @@ int launch_lane(amx_ctx *ctx, Args &a, const Plan &pl, hipStream_t s, K kern, si
     if ((rc = set_lds(ctx, kern, lds))) return rc;
     rec(ctx, 2, s);
     hipLaunchKernelGGL(kern, dim3(((pl.max_chunks + 7) / 8) * 8), dim3(256), lds, s, a);
+    amx_note(ctx, "lane-per-voxel solver (k_freewater_lane / k_sandi_lane)");
     AMX_TRACE(ctx, s, "lane-per-voxel solver");
     rec(ctx, 3, s);
     HIPCHK(ctx, hipGetLastError());
@@ -1646,6 +1647,7 @@ static int launch_refill(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s,
         a.sub_per_chunk = (amx_refill_chunk(ctx, (long long)pl.n) + kFuseSub - 1) / kFuseSub;
         rec(ctx, 2, s);
         hipLaunchKernelGGL(k, dim3(2 * ctx->n_cu), dim3(64 * (kFuseConsumers + 1)), fused_lds, s, a);
+        amx_note(ctx, N == 11 ? "k_freewater_fused<11>" : "k_freewater_fused<12>");
         AMX_TRACE(ctx, s, "FreeWater: projection (producer wavefront) + lane-per-voxel solver (consumers), one kernel");
         rec(ctx, 3, s);
         HIPCHK(ctx, hipGetLastError());
@@ -1668,8 +1670,10 @@ static int launch_refill(amx_ctx *ctx, FwArgs &a, const Plan &pl, hipStream_t s,
     if (mfma && a.c.y32 != nullptr) hipLaunchKernelGGL(pmfma32, grid, dim3(256), lds_p, s, a);
     else if (mfma) hipLaunchKernelGGL(pmfma, grid, dim3(256), lds_p, s, a);
     else hipLaunchKernelGGL(proj, grid, dim3(256), lds_p, s, a);
+    amx_note(ctx, mfma ? "k_fw_project_mfma" : "k_fw_project");
     AMX_TRACE(ctx, s, "A'y of every voxel");
     hipLaunchKernelGGL(kern, dim3(2 * ctx->n_cu), dim3(256), lds, s, a);
+    amx_note(ctx, "k_freewater_refill");
     AMX_TRACE(ctx, s, "lane-per-voxel solver with refill");
     rec(ctx, 3, s);
     HIPCHK(ctx, hipGetLastError());
@@ -1755,6 +1759,7 @@ int amx_launch_sandi_small(amx_ctx *ctx, SandiArgs &a, const Plan &pl, hipStream
         if (!a.tables) { ctx->err = "amx_launch_sandi_small: dictionary tables missing (amx_sandi_prepare)"; return AMX_E_BADARG; }
         rec(ctx, 2, s);
         hipLaunchKernelGGL((k_sandi_rows<6, 15>), dim3(a.n_lin > 0 ? (a.n_lin + 255) / 256 : ((pl.max_chunks + 7) / 8) * 8), dim3(256), 0, s, a);
+        amx_note(ctx, "k_sandi_rows<6,15>");
         AMX_TRACE(ctx, s, "row-space SANDI solver");
         rec(ctx, 3, s);
         HIPCHK(ctx, hipGetLastError());

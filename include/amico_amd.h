@@ -346,6 +346,11 @@ int amx_last_seed_stats(amx_ctx *ctx, int64_t out[8]);
  * reference (its fit reads host memory in place, models.pyx:902).                                                              */
 int amx_last_host_narrowed(amx_ctx *ctx);
 
+/* The kernels the LAST *_fit / *_fit_device call on this ctx enqueued, in launch order, as text ("k_noddi_gemm<false,25,9> -> k_nnls_seed<1,8,occ2>
+ * -> ..."; the first batch of a host-buffer call): which of the library's paths a dictionary shape / call size / solver parameters took.
+ * bench.py labels its roofline kernel from it instead of from a literal.  No counterpart in the reference (one path, models.pyx:902-981). */
+int amx_last_path(amx_ctx *ctx, char *buf, int cap);
+
 /* device self-test of the wavefront primitives (DPP reductions, broadcasts): writes 12 rows of
  * 64 doubles (sum, max, min, bcast lane 37, next-lane, popcount(ballot v>0), int bcast, v, and
  * the four batched sums of wave_sum4) */

@@ -330,6 +330,27 @@ def test_other_protocol_shapes(htable500, seed_path, amx_env):
     diff2 = np.abs(out2['estimates'] - ref2['estimates']).max(axis=1)
     assert (diff2 < TOL).mean() > 0.998, (diff2 > TOL).sum()
     assert diff2.max() < CAP, diff2.max()
+    # (b2) 181 volumes = two windows of 92 samples in the table GEMM (161 .. 200 volumes: windows of <= 100 samples run the K-steps 40
+    #      build; its LDS was sized for 25 K-steps before round 6 -- ADVICE r05, high)
+    sch2b = S.make_scheme(1, ((700.0, 60), (2000.0, 60), (3000.0, 60)), seed=12)
+    K2b = S.noddi_kernels(sch2b, dirs)
+    y2b, d2b = S.noddi_signals(1500, K2b, ht, sch2b, seed=9)
+    m2b = NODDI()
+    m2b.scheme = sch2b
+    out2b = m2b.fit(Holder(y2b, d2b, ht, K2b))
+    ref2b = oracle.noddi_fit(y2b, d2b, K2b, ht, sch2b.dwi_idx, nthreads=8)
+    diff2b = np.abs(out2b['estimates'] - ref2b['estimates']).max(axis=1)
+    y2n = y2b.copy()
+    y2n[3, 0] = np.nan; y2n[700, 180] = np.inf
+    out2n = m2b.fit(Holder(y2n, d2b, ht, K2b))
+    assert np.isnan(out2n['estimates'][[3, 700]]).all() and np.isfinite(np.delete(out2n['estimates'], [3, 700], axis=0)).all()
+    assert (diff2b < TOL).mean() > 0.998, (diff2b > TOL).sum()
+    assert diff2b.max() < CAP, diff2b.max()
+    if seed_path == 'seeded':
+        # the certificates must have settled most voxels from the table (a wrong table = mass refusals, not wrong maps)
+        from amico_amd.models import get_context
+        st = get_context().last_seed_stats()
+        assert st['seeded_voxels'] == 1500 and st['leftover_stage1'] < 0.25 * 1500 and st['leftover_stage3'] < 0.25 * 1500, st
     # (e) an HCP-style acquisition: 18 b0 + 3 x 90 = 288 volumes (the 288 x 145 float32 tile -- 167 KB -- does not fit a CU's LDS: the
     #     wavefront-per-voxel kernels read it where it lies; the table kernels take the samples in two windows of 144)
     sch5 = S.make_scheme(18, ((1000.0, 90), (2000.0, 90), (3000.0, 90)), seed=11)
@@ -340,6 +361,13 @@ def test_other_protocol_shapes(htable500, seed_path, amx_env):
     out5 = m5.fit(Holder(y5, d5, ht, K5, doComputeRMSE=True))
     ref5 = oracle.noddi_fit(y5, d5, K5, ht, sch5.dwi_idx, nthreads=8, rmse=True)
     diff5 = np.abs(out5['estimates'] - ref5['estimates']).max(axis=1)
+    # non-finite signals on this path too (the seed solver's explicit guard): NaN maps for those voxels, every other voxel untouched
+    y5n = y5.copy()
+    y5n[7, 200] = np.nan; y5n[911, 3] = np.inf; y5n[1499, 287] = -np.inf
+    out5n = m5.fit(Holder(y5n, d5, ht, K5))
+    bad5 = np.zeros(1500, bool); bad5[[7, 911, 1499]] = True
+    assert np.isnan(out5n['estimates'][bad5]).all()
+    assert np.array_equal(out5n['estimates'][~bad5], out5['estimates'][~bad5])
     assert (diff5 < TOL).mean() > 0.998, (diff5 > TOL).sum()
     assert diff5.max() < CAP, diff5.max()
     assert np.abs(out5['rmse'] - ref5['rmse']).max() < 1e-6
