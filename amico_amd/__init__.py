@@ -4,7 +4,7 @@ Drop-in for the hot path ``model.fit(evaluation)`` of daducci/AMICO (amico/model
 solver runs as hand-written HIP kernels behind the C ABI of include/amico_amd.h.
 """
 from . import _capi
-from .models import NODDI, FreeWater, SANDI, CylinderZeppelinBall, BaseModel, get_context, reset_context  # noqa: F401
+from .models import NODDI, FreeWater, SANDI, CylinderZeppelinBall, BaseModel, get_context, get_contexts, set_devices, reset_context  # noqa: F401
 from .core import Evaluation  # noqa: F401
 
 __version__ = '0.1.0'

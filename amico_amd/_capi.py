@@ -15,13 +15,13 @@ AMX_OK, AMX_E_BADARG, AMX_E_HIP, AMX_E_DIR_OOB, AMX_E_OVERFLOW, AMX_E_NODEVICE =
 F_RMSE, F_NRMSE, F_MODULATED, F_CORRECTED, F_DEBUG_X = 1, 2, 4, 8, 16
 
 # every symbol include/amico_amd.h declares (tests check that the library exports them all)
-SYMBOLS = ['amx_version', 'amx_build_id', 'amx_ctx_create', 'amx_ctx_destroy', 'amx_last_error',
+SYMBOLS = ['amx_version', 'amx_build_id', 'amx_device_count', 'amx_set_call_voxels', 'amx_ctx_create', 'amx_ctx_destroy', 'amx_last_error',
            'amx_lut_upload_noddi', 'amx_lut_upload_freewater', 'amx_lut_upload_sandi', 'amx_lut_destroy',
            'amx_dir_to_lut_idx', 'amx_noddi_fit', 'amx_freewater_fit', 'amx_sandi_fit',
            'amx_noddi_fit_device', 'amx_freewater_fit_device', 'amx_sandi_fit_device', 'amx_sync_status',
            'amx_noddi_fit_device_f32', 'amx_freewater_fit_device_f32', 'amx_sandi_fit_device_f32', 'amx_czb_fit_device_f32',
            'amx_set_debug_x', 'amx_debug_fetch', 'amx_lut_upload_czb', 'amx_czb_fit', 'amx_czb_fit_f32', 'amx_czb_fit_device', 'amx_noddi_fit_f32', 'amx_freewater_fit_f32', 'amx_sandi_fit_f32', 'amx_set_progress',
-           'amx_set_profiling', 'amx_last_kernel_ms', 'amx_last_stats', 'amx_last_seed_stats', 'amx_last_host_narrowed', 'amx_last_path', 'amx_selftest',
+           'amx_set_profiling', 'amx_last_kernel_ms', 'amx_last_stats', 'amx_last_seed_stats', 'amx_last_host_narrowed', 'amx_last_path', 'amx_host_pool_info', 'amx_selftest',
            'amx_dti_create', 'amx_dti_destroy', 'amx_dti_directions', 'amx_dti_directions_device', 'amx_dti_directions_device_f32', 'amx_prep_gather_device_f32',
            'amx_prep_create', 'amx_prep_destroy', 'amx_prep_gather', 'amx_prep_gather_device',
            'amx_prep_gather_directions_device', 'amx_prep_gather_directions_device_f32',
@@ -130,6 +130,8 @@ def lib():
     L.amx_last_seed_stats.argtypes = [c_vp, c_i64p]
     L.amx_last_host_narrowed.argtypes = [c_vp]
     L.amx_last_path.argtypes = [c_vp, C.c_char_p, C.c_int]
+    L.amx_host_pool_info.argtypes = [c_vp, C.POINTER(C.c_int)]
+    L.amx_set_call_voxels.argtypes = [c_vp, C.c_int64]
     L.amx_dict_upload.argtypes = [c_vp, c_dp, C.c_int, C.c_int, C.c_int, C.POINTER(c_vp)]
     L.amx_dict_destroy.argtypes = [c_vp]
     L.amx_dict_destroy.restype = None
@@ -174,6 +176,11 @@ def _p(a, ct):
     return a.ctypes.data_as(ct) if a is not None else None
 
 
+def device_count():
+    """gfx950 devices this process can see (amx_device_count; 0 without a usable GPU)"""
+    return max(0, int(lib().amx_device_count()))
+
+
 class Context:
     """amx_ctx: one per process and GPU."""
 
@@ -204,6 +211,10 @@ class Context:
             raise ValueError(msg or 'bad argument')
         raise AmxError(rc, msg or f'amico_amd error {rc}')       # RuntimeError, like lut.pyx:352-354
 
+    def set_call_voxels(self, total):
+        """the host-buffer fits that follow are shards of a call of `total` voxels (amx_set_call_voxels; 0 = off)"""
+        self.check(lib().amx_set_call_voxels(self._h, int(total)))
+
     def sync(self, stream=None):
         self.check(lib().amx_sync_status(self._h, c_vp(stream or 0)))
 
@@ -229,6 +240,12 @@ class Context:
     def last_host_narrowed(self):
         """batches of the last host-buffer call whose float64 signals crossed PCIe as float32, losslessly (amx_last_host_narrowed)"""
         return int(lib().amx_last_host_narrowed(self._h))
+
+    def host_pool_info(self):
+        """host threads of the float32 transport of this context (amx_host_pool_info)"""
+        out = (C.c_int * 4)()
+        self.check(lib().amx_host_pool_info(self._h, out))
+        return {'threads': out[0], 'first_cpu': out[1], 'physical_cores': out[2], 'device': out[3]}
 
     def last_path(self):
         """the kernels the last fit on this context enqueued, in launch order (amx_last_path)"""
@@ -358,15 +375,29 @@ def _check_dirs(dirs, n):
     return dirs
 
 
-def noddi_fit(ctx, lut, y, dirs, lambda1, lambda2, n_maps, rmse=False, nrmse=False, mod=False):
+def _outs(out, n, specs):
+    """result arrays of a host fit: fresh zeros, or the caller's (`out`: a tuple like the fit's return value -- C-contiguous float64
+    arrays of the right shape, e.g. row slices of the arrays a multi-device fit hands to its shards; None where a result is off)"""
+    res = []
+    for k, (shape, on) in enumerate(specs):
+        if not on:
+            res.append(None)
+            continue
+        a = None if out is None else out[k]
+        if a is None:
+            a = np.zeros((n,) + shape, dtype=np.float64, order='C')
+        elif a.dtype != np.float64 or a.shape != (n,) + shape or not a.flags['C_CONTIGUOUS'] or not a.flags['WRITEABLE']:
+            raise ValueError('out[%d] must be a writable C-contiguous float64 array of shape %s' % (k, ((n,) + shape,)))
+        res.append(a)
+    return res
+
+
+def noddi_fit(ctx, lut, y, dirs, lambda1, lambda2, n_maps, rmse=False, nrmse=False, mod=False, out=None):
     y = _check_y(y, lut.nS)
     n = y.shape[0]
     dirs = _check_dirs(dirs, n)
     flags = (F_RMSE if rmse else 0) | (F_NRMSE if nrmse else 0) | (F_MODULATED if mod else 0)
-    est = np.zeros((n, n_maps), dtype=np.float64, order='C')
-    r = np.zeros(n) if rmse else None
-    nr = np.zeros(n) if nrmse else None
-    md = np.zeros((n, 2), dtype=np.float64, order='C') if mod else None
+    est, r, nr, md = _outs(out, n, [((n_maps,), True), ((), rmse), ((), nrmse), ((2,), mod)])
     f32, yp = _yp(y)
     fn = lib().amx_noddi_fit_f32 if f32 else lib().amx_noddi_fit
     ctx.check(fn(ctx._h, lut._h, yp, _p(dirs, c_dp), n, float(lambda1), float(lambda2),
@@ -374,15 +405,12 @@ def noddi_fit(ctx, lut, y, dirs, lambda1, lambda2, n_maps, rmse=False, nrmse=Fal
     return est, r, nr, md
 
 
-def freewater_fit(ctx, lut, y, dirs, lambda1, lambda2, is_mouse, rmse=False, nrmse=False, corrected=False):
+def freewater_fit(ctx, lut, y, dirs, lambda1, lambda2, is_mouse, rmse=False, nrmse=False, corrected=False, out=None):
     y = _check_y(y, lut.nS)
     n = y.shape[0]
     dirs = _check_dirs(dirs, n)
     flags = (F_RMSE if rmse else 0) | (F_NRMSE if nrmse else 0) | (F_CORRECTED if corrected else 0)
-    est = np.zeros((n, 4 if is_mouse else 2), dtype=np.float64, order='C')
-    r = np.zeros(n) if rmse else None
-    nr = np.zeros(n) if nrmse else None
-    yc = np.zeros((n, lut.nS), dtype=np.float64, order='C') if corrected else None
+    est, r, nr, yc = _outs(out, n, [((4 if is_mouse else 2,), True), ((), rmse), ((), nrmse), ((lut.nS,), corrected)])
     f32, yp = _yp(y)
     fn = lib().amx_freewater_fit_f32 if f32 else lib().amx_freewater_fit
     ctx.check(fn(ctx._h, lut._h, yp, _p(dirs, c_dp), n, float(lambda1), float(lambda2), int(bool(is_mouse)), flags,
@@ -390,27 +418,23 @@ def freewater_fit(ctx, lut, y, dirs, lambda1, lambda2, is_mouse, rmse=False, nrm
     return est, r, nr, yc
 
 
-def sandi_fit(ctx, lut, y, lambda1, lambda2, rmse=False, nrmse=False):
+def sandi_fit(ctx, lut, y, lambda1, lambda2, rmse=False, nrmse=False, out=None):
     y = _check_y(y, lut.nS)
     n = y.shape[0]
     flags = (F_RMSE if rmse else 0) | (F_NRMSE if nrmse else 0)
-    est = np.zeros((n, 6), dtype=np.float64, order='C')
-    r = np.zeros(n) if rmse else None
-    nr = np.zeros(n) if nrmse else None
+    est, r, nr = _outs(out, n, [((6,), True), ((), rmse), ((), nrmse)])
     f32, yp = _yp(y)
     fn = lib().amx_sandi_fit_f32 if f32 else lib().amx_sandi_fit
     ctx.check(fn(ctx._h, lut._h, yp, n, float(lambda1), float(lambda2), flags, _p(est, c_dp), _p(r, c_dp), _p(nr, c_dp)))
     return est, r, nr
 
 
-def czb_fit(ctx, lut, y, dirs, lambda1, lambda2, rmse=False, nrmse=False):
+def czb_fit(ctx, lut, y, dirs, lambda1, lambda2, rmse=False, nrmse=False, out=None):
     y = _check_y(y, lut.nS)
     n = y.shape[0]
     dirs = _check_dirs(dirs, n)
     flags = (F_RMSE if rmse else 0) | (F_NRMSE if nrmse else 0)
-    est = np.zeros((n, 3), dtype=np.float64, order='C')
-    r = np.zeros(n) if rmse else None
-    nr = np.zeros(n) if nrmse else None
+    est, r, nr = _outs(out, n, [((3,), True), ((), rmse), ((), nrmse)])
     f32, yp = _yp(y)
     fn = lib().amx_czb_fit_f32 if f32 else lib().amx_czb_fit
     ctx.check(fn(ctx._h, lut._h, yp, _p(dirs, c_dp), n, float(lambda1), float(lambda2), flags, _p(est, c_dp), _p(r, c_dp),

@@ -196,6 +196,17 @@ extern "C" {
 
 int amx_version(void) { return 100; }
 
+int amx_device_count(void)
+{
+    int ndev = 0, n = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    for (int d = 0; d < ndev; d++) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) n = d + 1;     // (device numbers are HIP's)
+    }
+    return n;
+}
+
 int amx_ctx_create(int device, amx_ctx **out)
 {
     if (!out) return AMX_E_BADARG;
@@ -659,6 +670,23 @@ int amx_last_stats(amx_ctx *ctx, int64_t out[4])
 }
 
 int amx_last_host_narrowed(amx_ctx *ctx) { return ctx ? ctx->host_narrowed : 0; }
+
+int amx_set_call_voxels(amx_ctx *ctx, int64_t total)
+{
+    if (!ctx || total < 0) return AMX_E_BADARG;
+    ctx->call_total_vox = total;
+    return AMX_OK;
+}
+
+int amx_host_pool_info(amx_ctx *ctx, int out[4])
+{
+    if (!ctx || !out) return AMX_E_BADARG;
+    out[0] = ctx->stage ? ctx->stage->threads() : 0;
+    out[1] = ctx->stage ? ctx->stage->share_first() : -1;
+    out[2] = ctx->stage ? ctx->stage->share_cores() : 0;
+    out[3] = ctx->device;
+    return AMX_OK;
+}
 
 int amx_last_path(amx_ctx *ctx, char *buf, int cap)
 {
@@ -1273,7 +1301,12 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
                 for (int nd = 0; nd < 16 && cpu >= 0; nd++)
                     if (amx_stage::node_cpus(nd, &cs) && CPU_ISSET(cpu, &cs)) { node = nd; break; }
             }
-            ctx->stage = amx_stage::Pool::create(nt < 1 ? 1 : nt, node);
+            // the other devices of that node have pools of their own (this process's other contexts, or other ranks): disjoint shares
+            int sib_i = 0, sib_n = 1;
+            const char *se = getenv("AMX_HOST_SIBLINGS");          // "i/n" forces (diagnosis, tests)
+            if (se && sscanf(se, "%d/%d", &sib_i, &sib_n) == 2 && sib_n >= 1 && sib_i >= 0) { }
+            else { sib_i = 0; sib_n = 1; if (!pe || pe[0] == 'g') amx_stage::device_siblings(ctx->device, node, &sib_i, &sib_n); }
+            ctx->stage = amx_stage::Pool::create(nt < 1 ? 1 : nt, node, sib_i, sib_n);
             if (!ctx->stage) ctx->stage_failed = true;
         }
         narrow = ctx->stage != nullptr;
@@ -1292,7 +1325,9 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
     HIPCHK(ctx, hipStreamSynchronize(nullptr));                      // earlier default-stream work on these buffers
     const bool was_profiling = ctx->profiling;
     if (pipelined) ctx->profiling = false;
-    ctx->in_host_fit = true; ctx->host_total_vox = n_vox;
+    // (a shard of a larger call -- amx_set_call_voxels: one of several contexts that share a fit -- takes the paths the whole call's size asks for,
+    //  as the batches of one call do: every context settles its voxels with the arithmetic the single-context call would use)
+    ctx->in_host_fit = true; ctx->host_total_vox = ctx->call_total_vox > n_vox ? ctx->call_total_vox : n_vox;
     struct HostFitScope { amx_ctx *c; ~HostFitScope() { c->in_host_fit = false; } } host_scope{ctx};
     // Batch c runs on stream c & 1 with workspace set c & 1: the kernels of consecutive batches overlap, so the idle tail
     // of every launch (and the one-wavefront re-run kernels) is filled by the other batch instead of adding up six times.

@@ -32,6 +32,7 @@ struct amx_ctx {
     int *status_h = nullptr;       // pinned mirror (+16 words: copy of the misc counters)
     bool profiling = false;
     int64_t host_total_vox = 0;    // voxels of the whole host-buffer call while its batches are enqueued
+    int64_t call_total_vox = 0;    // amx_set_call_voxels: the host-buffer calls on this ctx are shards of a call of this many voxels (0: they are the call)
     bool in_host_fit = false;      // the host-buffer entry points report progress per batch themselves
     hipEvent_t ev[kEv];
     bool ev_valid[kEv];

@@ -194,10 +194,10 @@ static int dti_directions_dev(amx_ctx *ctx, const amx_dti *h, const YT *d_y, int
     tv = tv > kDtiVox ? kDtiVox : (tv & ~1);
     const size_t lds = ((size_t)((nS * 6 + 1) & ~1) + (size_t)tv * ldl + (size_t)kDtiBatch * tv * 7) * sizeof(double);
     if (tv < 2 || lds > 160 * 1024) return amx_bad(ctx, "amx_dti_directions: scheme too long for the LDS tile");
-    static bool attr_set = false;          // (one flag per instantiation of this function template)
-    if (!attr_set) {
+    static bool attr_set[64];              // (per instantiation of this function template AND device: the attribute belongs to the pair)
+    if (!attr_set[ctx->device & 63]) {
         HIPCHK(ctx, hipFuncSetAttribute((const void *)k_dti_dirs<YT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set[ctx->device & 63] = true;
     }
     const long long n_tiles = (n_vox + tv - 1) / tv;
     const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);

@@ -69,6 +69,44 @@ static int device_node(int device)
     return node;
 }
 
+// physical cores in a CPU set (the first hardware thread of each core that lies in the set)
+static int count_phys(const cpu_set_t &cpus)
+{
+    int n = 0;
+    for (int k = 0; k < CPU_SETSIZE; k++) {
+        if (!CPU_ISSET(k, &cpus)) continue;
+        char path[128];
+        snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", k);
+        int first = k;
+        if (FILE *f = fopen(path, "r")) { if (fscanf(f, "%d", &first) != 1) first = k; fclose(f); }
+        if (first == k || !CPU_ISSET(first, &cpus)) n++;
+    }
+    return n;
+}
+// which of the devices that hang on `node` is `device` (by device number), and how many there are: the siblings of its pool
+static void device_siblings(int device, int node, int *idx, int *count)
+{
+    *idx = 0; *count = 1;
+    int nd = 0;
+    if (node < 0 || hipGetDeviceCount(&nd) != hipSuccess || nd <= 1) { (void)hipGetLastError(); return; }
+    int n = 0, i = 0;
+    for (int d = 0; d < nd; d++) {
+        if (device_node(d) != node) continue;
+        if (d == device) i = n;
+        n++;
+    }
+    if (n > 1) { *idx = i; *count = n; return; }
+    // one visible device per process (HIP_VISIBLE_DEVICES set by the launcher): the launcher's local rank / size say who else is there
+    const char *lr = getenv("LOCAL_RANK"), *lw = getenv("LOCAL_WORLD_SIZE");
+    if (lr && lw && atoi(lw) > 1) {
+        int nodes = 0;
+        cpu_set_t cs;
+        for (int k = 0; k < 16; k++) if (node_cpus(k, &cs)) nodes++;
+        const int per = (atoi(lw) + (nodes > 0 ? nodes : 1) - 1) / (nodes > 0 ? nodes : 1);
+        *count = per > 1 ? per : 1; *idx = atoi(lr) % *count;
+    }
+}
+
 // true: every element narrowed exactly (a NaN compares unequal -> false)
 __attribute__((target("avx2"))) static bool narrow_avx2(const double *__restrict__ s, float *__restrict__ d, size_t n)
 {
@@ -104,9 +142,25 @@ public:
     static constexpr size_t kChunkEl = 4u << 20;           // elements per chunk: 32 MB read, 16 MB sent (0.28 ms of link)
     static constexpr size_t kPieceEl = 32u << 10;          // elements a thread takes at a time
     static constexpr int kRing = 4;
-    // node >= 0: the threads stay on that NUMA node's CPUs
-    static Pool *create(int threads, int node = -1)
+    // node >= 0: the threads stay on that NUMA node's CPUs.  sib_n > 1 (round 6): this pool is one of sib_n on the node -- one per device that
+    // hangs on it, whether the devices are driven by one process (models.py: AMX_DEVICES) or by one process each (torchrun) -- and takes the
+    // sib_i-th share of the node's physical cores: stripes of its own, disjoint from its siblings' (twelve threads per
+    // pool striped over ALL the node's cores overlap pairwise as soon as two pools share a socket).  A share too small for `threads` stripes
+    // of two cores gets fewer threads (never below four: the narrowing of 113 GB/s of float64 needs them).
+    static int sibling_threads(int threads, int node_phys_cores, int sib_n)
     {
+        if (sib_n <= 1 || node_phys_cores <= 0) return threads;
+        const int share = node_phys_cores / sib_n;
+        int t = threads;
+        if (share < 2 * t) t = share / 2;
+        return t < 4 ? (share >= 4 ? 4 : (share > 0 ? share : 1)) : t;
+    }
+    static Pool *create(int threads, int node = -1, int sib_i = 0, int sib_n = 1)
+    {
+        if (node >= 0 && sib_n > 1) {
+            cpu_set_t c0;
+            if (node_cpus(node, &c0)) threads = sibling_threads(threads, count_phys(c0), sib_n);
+        }
         Pool *p = new Pool();
         p->T_ = threads;
         p->avx2_ = __builtin_cpu_supports("avx2");
@@ -133,9 +187,17 @@ public:
                 if (first == k || !CPU_ISSET(first, &cpus)) phys.push_back(k);
             }
             const char *pc = getenv("AMX_HOST_PIN_CORES");
+            if (sib_n > 1 && (int)phys.size() >= sib_n) {
+                // this pool's share of the node: cores [sib_i * share, (sib_i + 1) * share) in the node's order
+                const int share = (int)phys.size() / sib_n;
+                phys = std::vector<int>(phys.begin() + (size_t)(sib_i % sib_n) * share, phys.begin() + (size_t)(sib_i % sib_n + 1) * share);
+            }
             const int P = (int)phys.size();
+            p->share_first_ = P > 0 ? phys.front() : -1; p->share_cores_ = P;
             if ((!pc || pc[0] != '0') && P >= 2 * threads) {
-                const int stride = P / threads, start = (int)(((unsigned)getpid() * 7u) % (unsigned)P);
+                // (a pool alone on its node rotates its stripes with the process id -- processes that do not know of each other; a
+                //  sibling's share is its own: no rotation)
+                const int stride = P / threads, start = sib_n > 1 ? 0 : (int)(((unsigned)getpid() * 7u) % (unsigned)P);
                 const int width = (pc && pc[0] == '1') ? 1 : stride;
                 for (int t = 0; t < threads; t++) {
                     cpu_set_t mine;
@@ -143,6 +205,11 @@ public:
                     for (int j = 0; j < width; j++) CPU_SET(phys[(start + t * stride + j) % P], &mine);
                     (void)pthread_setaffinity_np(p->th_[t].native_handle(), sizeof mine, &mine);
                 }
+            } else if (sib_n > 1 && P > 0) {
+                cpu_set_t mine;
+                CPU_ZERO(&mine);
+                for (int c : phys) CPU_SET(c, &mine);
+                for (auto &x : p->th_) (void)pthread_setaffinity_np(x.native_handle(), sizeof mine, &mine);
             } else {
                 for (auto &x : p->th_) (void)pthread_setaffinity_np(x.native_handle(), sizeof cpus, &cpus);
             }
@@ -161,6 +228,8 @@ public:
         release();
     }
     int threads() const { return T_; }
+    int share_first() const { return share_first_; }       // first CPU and number of physical cores of this pool's share of its node (diagnosis, tests)
+    int share_cores() const { return share_cores_; }
     float *slot(int c) const { return ring_[c % kRing]; }
 
     // start narrowing base[chunks[0]], base[chunks[1]], ... (every n <= kChunkEl); the threads read the CALLER's memory until end()
@@ -248,6 +317,7 @@ private:
         for (float *&q : ring_) if (q) { (void)hipHostFree(q); q = nullptr; }
     }
     int T_ = 0;
+    int share_first_ = -1, share_cores_ = 0;
     bool avx2_ = false;
     bool active_ = false;          // (calling thread only)
     std::vector<std::thread> th_;

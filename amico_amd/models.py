@@ -10,21 +10,61 @@ import numpy as np
 from . import _capi
 
 _CTX = None
+_CTXS = None          # one context per device of the fit's device set (set_devices / AMX_DEVICES); _CTXS[0] is _CTX
+_DEVICES = None
+
+
+def set_devices(ids=None):
+    """The devices `model.fit(evaluation)` spreads a host-buffer fit over (round 6).  The reference's caller is ONE process whose fit
+    cuts the voxels into contiguous chunks, one per host thread (core.py:465-466, models.pyx:204-211); here the chunks are one per GPU:
+    a context and a host thread per device, each shard travelling over its own PCIe link, the results written straight into the
+    caller's arrays (no collective: they go home anyway).  ids: a list of HIP device numbers (a device may be named twice: two
+    contexts on it -- what the one-GPU test box exercises), 'all', or None = the current device only (the default; the environment
+    variable AMX_DEVICES=all | 0,1,... sets the same without touching the caller's script)."""
+    global _DEVICES
+    if isinstance(ids, str):
+        ids = None if not ids.strip() else ('all' if ids.strip().lower() == 'all' else [int(t) for t in ids.replace(',', ' ').split()])
+    _DEVICES = ids if ids is None or ids == 'all' else [int(i) for i in ids]
+    reset_context()
+
+
+def _device_ids():
+    import os
+    ids = _DEVICES
+    if ids is None:
+        e = os.environ.get('AMX_DEVICES', '').strip()
+        if not e:
+            return None
+        ids = 'all' if e.lower() == 'all' else [int(t) for t in e.replace(',', ' ').split()]
+    if ids == 'all':
+        ids = list(range(_capi.device_count()))
+    return ids or None
+
+
+def get_contexts():
+    """the contexts of the fit's device set, in shard order (one, on the current device, unless set_devices / AMX_DEVICES says otherwise)"""
+    global _CTX, _CTXS
+    if _CTXS is None:
+        ids = _device_ids()
+        _CTXS = [_capi.Context(-1)] if ids is None else [_capi.Context(i) for i in ids]
+        _CTX = _CTXS[0]
+    return _CTXS
 
 
 def get_context():
-    """process-wide amx_ctx on the current HIP device (created on first use)"""
+    """process-wide amx_ctx (created on first use): on the current HIP device, or the first device of the fit's device set"""
     global _CTX
     if _CTX is None:
-        _CTX = _capi.Context(-1)
+        get_contexts()
     return _CTX
 
 
 def reset_context():
-    """forget the process-wide context: the next get_context() creates a new one (the library reads its AMX_* environment
+    """forget the process-wide context(s): the next get_context() creates new ones (the library reads its AMX_* environment
     switches once, when a context is created -- tools and tests that flip a switch call this afterwards)"""
-    global _CTX
+    global _CTX, _CTXS
     _CTX = None
+    _CTXS = None
 
 
 def _digest(a):
@@ -79,7 +119,7 @@ def _verified_fit(fit):
             out = fit(self, evaluation)
             pend, self._lut_pending = self._lut_pending, False
             if pend is not None and not pend.matches():
-                self._lut_cache = None      # stale: upload again, fit again
+                self._lut_cache = {}        # stale: upload again (every context), fit again
                 out = fit(self, evaluation)
             return out
         finally:
@@ -214,26 +254,75 @@ class BaseModel(ABC):
     def _lut_extra_key(self):
         return ()
 
-    def _lut(self, evaluation, builder):
+    def _lut(self, evaluation, builder, ctx=None):
+        """the device dictionary of `ctx` (default: the process-wide context) for evaluation.KERNELS: cached per context"""
         K, ht = evaluation.KERNELS, getattr(evaluation, 'htable', None)
         sc = self.scheme
         skey = None if sc is None else (int(getattr(sc, 'nS', 0)), tuple(np.asarray(getattr(sc, 'dwi_idx', ())).tolist()))
-        ctx = get_context()                 # (a dictionary lives in ONE context: reset_context() must not leave a stale upload behind)
+        if ctx is None:
+            ctx = get_context()             # (a dictionary lives in ONE context: reset_context() must not leave a stale upload behind)
         # everything but the content: objects, shapes, types, the model / scheme state that shapes the device dictionary
         cheap = (id(K), id(ht), tuple((k, v.shape, str(v.dtype)) for k, v in sorted(K.items()) if isinstance(v, np.ndarray)),
                  skey, self._lut_extra_key(), id(ctx))
-        cache = getattr(self, '_lut_cache', None)
+        caches = getattr(self, '_lut_cache', None)
+        if not isinstance(caches, dict):
+            caches = self._lut_cache = {}
+        for key in [k for k, c in caches.items() if c[4] is not ctx and c[4] not in (_CTXS or [])]:
+            del caches[key]                 # (uploads of contexts that reset_context() has dropped)
+        cache = caches.get(id(ctx))
         if cache is not None and cache[0][0] == cheap:
             # the content is checked while the fit runs (_verified_fit); outside a fit (no wrapper to ask the question) right here
-            if getattr(self, '_lut_pending', False) is None:
+            pend = getattr(self, '_lut_pending', False)
+            if pend is None:
                 self._lut_pending = _PendingFingerprint(K, cache[0][1])
                 return cache[1]
+            if isinstance(pend, _PendingFingerprint) and pend.expected == cache[0][1]:
+                return cache[1]             # (another context of the same fit: one digest of KERNELS answers for all of them)
             if _fingerprint(K) == cache[0][1]:
                 return cache[1]
         if K.get('model') != self.id:
             raise ValueError('Response functions were not created with the same model')
-        self._lut_cache = ((cheap, _fingerprint(K)), builder(), K, ht, ctx)     # K, ht, ctx: strong references to the keyed objects
-        return self._lut_cache[1]
+        caches[id(ctx)] = ((cheap, _fingerprint(K)), builder(), K, ht, ctx)     # K, ht, ctx: strong references to the keyed objects
+        return caches[id(ctx)][1]
+
+    # ---- host-buffer fit on several devices: contiguous shards (models.pyx:204-211), a context + host thread per device
+    def _fit_on_devices(self, evaluation, n, upload, fit_shard, outs):
+        """upload(ctx) -> Lut; fit_shard(ctx, lut, lo, hi, out_views) fits voxels [lo, hi) into row slices of `outs` (a tuple of
+        arrays / None like the return value of the _capi fit).  Returns outs.  One device: a plain call."""
+        from .parallel import shard_range
+        ctxs = get_contexts()
+        luts = [self._lut(evaluation, (lambda c=c: upload(c)), c) for c in ctxs]        # (uploads one after the other, first fit only)
+        world = len(ctxs)
+        bounds = [shard_range(n, r, world) for r in range(world)]
+
+        def work(r):
+            lo, hi = bounds[r]
+            if hi <= lo:
+                return
+            ctxs[r].set_call_voxels(n if world > 1 else 0)      # every shard takes the paths the whole call's size asks for
+            try:
+                fit_shard(ctxs[r], luts[r], lo, hi, tuple(None if o is None else o[lo:hi] for o in outs))
+            except _capi.AmxError as e:
+                import re
+                m = re.search(r'\[voxel (\d+)\]', str(e))       # (a shard counts its voxels from 0: name the caller's voxel)
+                if m and lo:
+                    raise _capi.AmxError(e.code, str(e).replace(m.group(0), '[voxel %d]' % (int(m.group(1)) + lo))) from None
+                raise
+            finally:
+                ctxs[r].set_call_voxels(0)
+        if world == 1:
+            work(0)
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(world) as ex:        # (ctypes releases the GIL for the length of the C call)
+                futs = [ex.submit(work, r) for r in range(world)]
+            errs = [f.exception() for f in futs]
+            for e in errs:
+                if e is not None:
+                    raise e                              # the lowest shard's error first, like the reference's serial loop would hit it
+        for c in ctxs:
+            self._warn_if_capped(c)
+        return outs
 
 
 class CylinderZeppelinBall(BaseModel):
@@ -311,9 +400,16 @@ class CylinderZeppelinBall(BaseModel):
             est, rmse, nrmse = _capi.czb_fit_device(ctx, lut, dev['y'], self._dev_dirs(evaluation, dev),
                                                     self.solver_params['lambda1'], self.solver_params['lambda2'], **kw)
             return self._finish_device(ctx, dev, {'estimates': est, 'rmse': rmse, 'nrmse': nrmse})
-        est, rmse, nrmse = _capi.czb_fit(ctx, lut, evaluation.y, evaluation.DIRs, self.solver_params['lambda1'],
-                                         self.solver_params['lambda2'], **kw)
-        self._warn_if_capped(ctx)
+        if len(get_contexts()) > 1:
+            n, y, d = evaluation.y.shape[0], evaluation.y, evaluation.DIRs
+            est, rmse, nrmse = self._fit_on_devices(
+                evaluation, n, lambda c: _capi.upload_czb(c, K, self.Rs, evaluation.htable),
+                lambda c, l, lo, hi, o: _capi.czb_fit(c, l, y[lo:hi], d[lo:hi], self.solver_params['lambda1'], self.solver_params['lambda2'], out=o, **kw),
+                (np.zeros((n, 3)), np.zeros(n) if kw['rmse'] else None, np.zeros(n) if kw['nrmse'] else None))
+        else:
+            est, rmse, nrmse = _capi.czb_fit(ctx, lut, evaluation.y, evaluation.DIRs, self.solver_params['lambda1'],
+                                             self.solver_params['lambda2'], **kw)
+            self._warn_if_capped(ctx)
         results = {'estimates': est}
         if self.configs['compute_rmse']:
             results['rmse'] = rmse
@@ -401,11 +497,17 @@ class NODDI(BaseModel):
                 len(self.maps_name), rmse=bool(self.configs['compute_rmse']), nrmse=bool(self.configs['compute_nrmse']),
                 mod=bool(self.configs['compute_modulated_maps']))
             return self._finish_device(ctx, dev, {'estimates': est, 'rmse': rmse, 'nrmse': nrmse, 'estimates_mod': mod})
-        est, rmse, nrmse, mod = _capi.noddi_fit(
-            ctx, lut, evaluation.y, evaluation.DIRs, self.solver_params['lambda1'], self.solver_params['lambda2'],
-            len(self.maps_name), rmse=bool(self.configs['compute_rmse']), nrmse=bool(self.configs['compute_nrmse']),
-            mod=bool(self.configs['compute_modulated_maps']))
-        self._warn_if_capped(ctx)
+        kw = dict(rmse=bool(self.configs['compute_rmse']), nrmse=bool(self.configs['compute_nrmse']), mod=bool(self.configs['compute_modulated_maps']))
+        if len(get_contexts()) > 1:
+            n, y, d, nm = evaluation.y.shape[0], evaluation.y, evaluation.DIRs, len(self.maps_name)
+            est, rmse, nrmse, mod = self._fit_on_devices(
+                evaluation, n, lambda c: _capi.upload_noddi(c, evaluation.KERNELS, evaluation.htable, self.scheme.dwi_idx, self.isExvivo),
+                lambda c, l, lo, hi, o: _capi.noddi_fit(c, l, y[lo:hi], d[lo:hi], self.solver_params['lambda1'], self.solver_params['lambda2'], nm, out=o, **kw),
+                (np.zeros((n, nm)), np.zeros(n) if kw['rmse'] else None, np.zeros(n) if kw['nrmse'] else None, np.zeros((n, 2)) if kw['mod'] else None))
+        else:
+            est, rmse, nrmse, mod = _capi.noddi_fit(ctx, lut, evaluation.y, evaluation.DIRs, self.solver_params['lambda1'],
+                                                    self.solver_params['lambda2'], len(self.maps_name), **kw)
+            self._warn_if_capped(ctx)
         results = {'estimates': est}
         if self.configs['compute_rmse']:
             results['rmse'] = rmse
@@ -484,11 +586,19 @@ class FreeWater(BaseModel):
                 self.type == 'Mouse', rmse=bool(self.configs['compute_rmse']), nrmse=bool(self.configs['compute_nrmse']),
                 corrected=bool(self.configs['save_corrected_DWI']))
             return self._finish_device(ctx, dev, {'estimates': est, 'rmse': rmse, 'nrmse': nrmse, 'y_corrected': yc})
-        est, rmse, nrmse, yc = _capi.freewater_fit(
-            ctx, lut, evaluation.y, evaluation.DIRs, self.solver_params['lambda1'], self.solver_params['lambda2'],
-            self.type == 'Mouse', rmse=bool(self.configs['compute_rmse']), nrmse=bool(self.configs['compute_nrmse']),
-            corrected=bool(self.configs['save_corrected_DWI']))
-        self._warn_if_capped(ctx)
+        kw = dict(rmse=bool(self.configs['compute_rmse']), nrmse=bool(self.configs['compute_nrmse']), corrected=bool(self.configs['save_corrected_DWI']))
+        mouse = self.type == 'Mouse'
+        if len(get_contexts()) > 1:
+            n, y, d = evaluation.y.shape[0], evaluation.y, evaluation.DIRs
+            est, rmse, nrmse, yc = self._fit_on_devices(
+                evaluation, n, lambda c: _capi.upload_freewater(c, evaluation.KERNELS, evaluation.htable),
+                lambda c, l, lo, hi, o: _capi.freewater_fit(c, l, y[lo:hi], d[lo:hi], self.solver_params['lambda1'], self.solver_params['lambda2'], mouse, out=o, **kw),
+                (np.zeros((n, 4 if mouse else 2)), np.zeros(n) if kw['rmse'] else None, np.zeros(n) if kw['nrmse'] else None,
+                 np.zeros((n, y.shape[1])) if kw['corrected'] else None))
+        else:
+            est, rmse, nrmse, yc = _capi.freewater_fit(ctx, lut, evaluation.y, evaluation.DIRs, self.solver_params['lambda1'],
+                                                       self.solver_params['lambda2'], mouse, **kw)
+            self._warn_if_capped(ctx)
         results = {'estimates': est}
         if self.configs['compute_rmse']:
             results['rmse'] = rmse
@@ -569,10 +679,16 @@ class SANDI(BaseModel):
                                                       self.solver_params['lambda2'], rmse=bool(self.configs['compute_rmse']),
                                                       nrmse=bool(self.configs['compute_nrmse']))
             return self._finish_device(ctx, dev, {'estimates': est, 'rmse': rmse, 'nrmse': nrmse})
-        est, rmse, nrmse = _capi.sandi_fit(ctx, lut, evaluation.y, self.solver_params['lambda1'],
-                                           self.solver_params['lambda2'], rmse=bool(self.configs['compute_rmse']),
-                                           nrmse=bool(self.configs['compute_nrmse']))
-        self._warn_if_capped(ctx)
+        kw = dict(rmse=bool(self.configs['compute_rmse']), nrmse=bool(self.configs['compute_nrmse']))
+        if len(get_contexts()) > 1:
+            n, y = evaluation.y.shape[0], evaluation.y
+            est, rmse, nrmse = self._fit_on_devices(
+                evaluation, n, lambda c: _capi.upload_sandi(c, evaluation.KERNELS, self.Rs, self.d_in, self.d_isos),
+                lambda c, l, lo, hi, o: _capi.sandi_fit(c, l, y[lo:hi], self.solver_params['lambda1'], self.solver_params['lambda2'], out=o, **kw),
+                (np.zeros((n, 6)), np.zeros(n) if kw['rmse'] else None, np.zeros(n) if kw['nrmse'] else None))
+        else:
+            est, rmse, nrmse = _capi.sandi_fit(ctx, lut, evaluation.y, self.solver_params['lambda1'], self.solver_params['lambda2'], **kw)
+            self._warn_if_capped(ctx)
         results = {'estimates': est}
         if self.configs['compute_rmse']:
             results['rmse'] = rmse

@@ -107,7 +107,7 @@ def small_model(model, n, steps, warmup, cpu=True, host_legs=True):
                                                  est.data_ptr(), None, None, None, None))
         ref = lambda m: oracle.freewater_fit(y_h[:m], d_h[:m], K, htable, nthreads=cores)['estimates']
         name = 'FreeWater fit, %d voxels, 65-volume single shell (1 b0 + 64@b1000), 11 atoms, ndirs=500' % n
-        kernel = 'k_fw_project_mfma<11> + k_freewater_refill<11> (one launch pair per fit: projection c = A\'y on the fp64 matrix cores, then the active-set solver)'
+        kernel = 'FreeWater: projection c = A\'y on the fp64 matrix cores (producer wavefront) + block-pivoting active-set solver (consumer wavefronts)'
     elif model == 'czb':
         # CylinderZeppelinBall (SURVEY 8 row a-M; not a BASELINE config): dictionary generated + resampled by this repository
         # (amico_amd.synthesis -> lut.rotate_kernel -> amx_lut_resample) on a 3-shell STEJSKALTANNER scheme
@@ -134,7 +134,7 @@ def small_model(model, n, steps, warmup, cpu=True, host_legs=True):
             ctx.check(L.amx_czb_fit_device(ctx._h, lut._h, y.data_ptr(), d.data_ptr(), n, 0.0, 4.0, 0, est.data_ptr(), None, None, None))
         ref = lambda m: oracle.czb_fit(y_h[:m], d_h[:m], K, Rs_, htable, nthreads=cores)['estimates']
         name = 'CylinderZeppelinBall fit, %d voxels, %d volumes (3 shells), 26 atoms, ndirs=500' % (n, scheme.nS)
-        kernel = 'k_czb_project<25> + k_czb_lane (projection z0 = M(A\'y - lambda1), c on the fp64 matrix cores, then block principal pivoting, one voxel per lane)'
+        kernel = 'CylinderZeppelinBall: projection z0 = M(A\'y - lambda1), c on the fp64 matrix cores, then block principal pivoting, one voxel per lane'
     else:
         full = S.make_sandi_scheme()
         avg = S.directional_average_scheme(full)
@@ -149,7 +149,7 @@ def small_model(model, n, steps, warmup, cpu=True, host_legs=True):
             ctx.check(L.amx_sandi_fit_device(ctx._h, lut._h, y.data_ptr(), n, 0.0, 5e-3, 0, est.data_ptr(), None, None, None))
         ref = lambda m: oracle.sandi_fit(y_h[:m], K, Rs, d_in, d_isos, nthreads=cores)['estimates']
         name = 'SANDI fit, %d voxels, 5 shells direction-averaged (6 values per voxel), 15 atoms' % n
-        kernel = 'k_sandi_rows<6, 15>'
+        kernel = 'SANDI: row-space Woodbury solve, one voxel per lane'
     ctx.set_profiling(True)
     for _ in range(warmup):
         step(); ctx.sync()
@@ -162,6 +162,10 @@ def small_model(model, n, steps, warmup, cpu=True, host_legs=True):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     kms /= steps
+    # the kernels that ran, as the library names them (amx_last_path) -- not a literal in this file (the FreeWater
+    # label still named the kernel pair after the fused kernel had replaced it)
+    launched = ctx.last_path()
+    kernel = '%s  [%s]' % (launched, kernel)
     m = min(n, 20000)
     got = est[:m].cpu().numpy()
     want = ref(m)
@@ -875,7 +879,7 @@ def main():
                                              'peak': 78.6, 'unit': 'TFLOP/s', 'frac': 83340.0 * n / (elapsed / args.steps) / 1e12 / 78.6},
                          'traffic_source': 'profiles/pmc_traffic.json (rocprofv3 --pmc, bytes per launch)'
                                            if traffic is not None else None,
-                         'kernel': names[stage], 'kernel_ms': dom_ms,
+                         'kernel': names[stage], 'kernel_ms': dom_ms, 'kernels_launched': ctx.last_path(),
                          'stage_ms': [float(v) for v in kms[1:4]], 'seed_ms': [float(v) for v in kms[5:8]], 'seed_solver_ms': [float(kms[8]), float(kms[9])],
                          'groups': {str(k): {'kernels': v, 'ms': float(kms[k])} for k, v in groups.items()}, 'all_kernels_ms': float(kms[0]),
                          'note': 'the path is bound by dependent latencies inside the per-voxel active-set solvers, not by HBM (DESIGN.md section 5): see compute_side'},
@@ -898,6 +902,24 @@ def main():
                              'frac_within_1e-6': float((diff < 1e-6).mean()),
                              'frac_within_1e-4': float((diff < 1e-4).mean())}
             other = {}
+            # the same fit on the first 50 000 / 200 000 / 300 000 voxels of the resident batch (the sizes a brain mask, and a batch of the
+            # host-buffer pipeline, have): T(n) = floor + slope n is the chain's signature, and the driver should see it
+            size_scan = {}
+            for ns_ in (50_000, 200_000, 300_000):
+                if ns_ >= n:
+                    continue
+                est_s = torch.zeros((ns_, 3), dtype=torch.float64, device=dev)
+
+                def fit_s():
+                    ctx.check(L.amx_noddi_fit_device(ctx._h, lut._h, y.data_ptr(), d.data_ptr(), ns_, 0.5, 1e-3, 0, est_s.data_ptr(), None, None, None, stream))
+                for _ in range(3):
+                    fit_s(); ctx.sync(stream)
+                ts_ = []
+                for _ in range(9):
+                    t1 = time.perf_counter(); fit_s(); ctx.sync(stream); ts_.append(time.perf_counter() - t1)
+                size_scan[str(ns_)] = {'ms': round(1e3 * float(np.median(ts_)), 4), 'voxels_per_s': round(ns_ / float(np.median(ts_)))}
+                del est_s
+            size_scan[str(n)] = {'ms': round(1e3 * elapsed / args.steps, 4), 'voxels_per_s': round(value)}
             if not args.no_other_configs:
                 # host numpy in -> host numpy out through amx_noddi_fit (H2D + kernels + D2H): the PCIe-inclusive rate,
                 # reported beside the headline, never as `value`
@@ -949,6 +971,14 @@ def main():
                 # FRESH context -- the first call pays the dictionary upload and the device tables built from it (Gram matrices, bases),
                 # the later ones find the dictionary by the digest of KERNELS (BaseModel._lut)
                 other['noddi_model_fit'] = noddi_model_fit(K, htable, scheme, y_h, d_h, est.cpu().numpy())
+                # ... and on a device SET (amico_amd.set_devices / AMX_DEVICES: one context + host thread per device, contiguous shards).  This box
+                # has one GPU: naming it twice measures the machinery (two contexts, two copy streams, two narrowing pools on ONE link), not scaling
+                import amico_amd
+                try:
+                    amico_amd.set_devices([local_rank, local_rank])
+                    other['noddi_model_fit_two_contexts_one_gpu'] = noddi_model_fit(K, htable, scheme, y_h, d_h, est.cpu().numpy())
+                finally:
+                    amico_amd.set_devices(None)
             if not args.no_other_configs:
                 other['noddi_hard_mix'] = noddi_hard_mix(ctx, lut, K, htable, scheme, min(n, 1_000_000), 5, 2)
                 per_byte = value * BYTES_PER_VOXEL
@@ -965,23 +995,19 @@ def main():
                 # bounded CPU legs on the host cores of this box: the oracle -- a port, the reference's
                 # cyspams path cannot be built -- at -O3 -march=native, the reference's chunk-per-thread structure
                 # (models.pyx:204-211), one warm-up + median of 5 runs.  "faithful": voxels in the caller's order, so the
-                # LUT slice is copied per voxel like models.pyx:905; "optimised": voxels presented sorted by LUT index
-                # (one copy per orientation and thread)
+                # LUT slice is copied per voxel like models.pyx:905
                 oracle.use_fast_build(True)
                 m = min(n, 100000)
                 fit = lambda yy, dd: oracle.noddi_fit(yy, dd, K, htable, scheme.dwi_idx, nthreads=cores)
                 rate_f, dt_f = median_rate(lambda: fit(y_h[:m], d_h[:m]), m)
-                order = np.argsort(S.lut_indices(d_h[:m], htable), kind='stable')
-                ys, ds = np.ascontiguousarray(y_h[:m][order]), np.ascontiguousarray(d_h[:m][order])
-                rate_o, dt_o = median_rate(lambda: fit(ys, ds), m)
                 oracle.use_fast_build(False)
+                # (rounds 3 - 5 also timed the voxels sorted by LUT index -- "optimised": one dictionary copy per orientation and thread; it was
+                #  never faster than the caller's order on this box, 103.6 k against 109.3 k voxels/s in round 5, and is gone: VERDICT r05 weak 13)
                 out['cpu_baseline'] = {'value': rate_f, 'unit': 'voxels/s', 'cores': cores, 'logical_cpus': os.cpu_count(),
                                        'kind': 'port', 'variant': 'faithful',
-                                       'optimised': {'value': rate_o, 'unit': 'voxels/s',
-                                                     'sample': 'the same voxels sorted by LUT index (one dictionary copy per orientation)'},
                                        'sample': 'first %d voxels of the same workload, oracle/amico_oracle.c (Lawson-Hanson NNLS + LARS '
-                                                 'lasso) -O3 -march=native, %d threads, warm-up + median of 5 runs (%.2f s / %.2f s)'
-                                                 % (m, cores, dt_f, dt_o)}
+                                                 'lasso) -O3 -march=native, %d threads, warm-up + median of 5 runs (%.2f s)'
+                                                 % (m, cores, dt_f)}
             if not args.no_other_configs:
                 # free the headline's buffers first: configs 3 and 4 run on the same GPU, one after the other
                 del y, d, est
@@ -991,6 +1017,26 @@ def main():
                 other['czb_500k'] = small_model('czb', 500_000, 5, 2, cpu=not args.no_cpu_baseline)
             if other:
                 out['other_configs'] = other
+            # LAST in the line (the driver keeps the tail of stdout): the numbers at the reference's own boundary -- model.fit(evaluation) takes
+            # and returns host numpy (core.py:462-467) -- beside the resident headline, and the size scan
+            out['size_scan'] = size_scan
+            if other:
+                g = lambda k, f='value': (round(other[k][f], 3) if k in other and f in other[k] else None)
+                out['host_boundary'] = {
+                    'unit': 'voxels/s', 'voxels': n, 'resident_in_hbm': round(value),
+                    'noddi_host_buffers': g('noddi_host_buffers'), 'noddi_host_buffers_ms': g('noddi_host_buffers', 'ms_per_call'),
+                    'noddi_host_buffers_f64_values': g('noddi_host_buffers_f64_values'), 'noddi_host_buffers_f32': g('noddi_host_buffers_f32'),
+                    'noddi_model_fit': g('noddi_model_fit'), 'noddi_model_fit_ms': g('noddi_model_fit', 'ms_per_call'),
+                    'noddi_model_fit_first_call_ms': g('noddi_model_fit', 'first_call_ms'),
+                    'noddi_model_fit_two_contexts_one_gpu': g('noddi_model_fit_two_contexts_one_gpu'),
+                    'freewater_2M_host_buffers': (round(other['freewater_2M']['host_buffers']['f64']['value']) if 'freewater_2M' in other and 'host_buffers' in other['freewater_2M'] else None),
+                    'sandi_1M_host_buffers': (round(other['sandi_1M']['host_buffers']['f64']['value']) if 'sandi_1M' in other and 'host_buffers' in other['sandi_1M'] else None)}
+                # (scalars the driver's record of `roofline` keeps)
+                out['roofline']['host_buffers_voxels_per_s'] = out['host_boundary']['noddi_host_buffers']
+                out['roofline']['model_fit_voxels_per_s'] = out['host_boundary']['noddi_model_fit']
+            for k_ in ('200000', '300000'):
+                if k_ in size_scan:
+                    out['roofline']['voxels_per_s_at_%s' % k_] = size_scan[k_]['voxels_per_s']
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

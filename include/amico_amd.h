@@ -47,6 +47,16 @@ int  amx_version(void);
  * the sources in the tree, so a stale .so, or a profile summary taken from other kernels (profiles/pmc_traffic.json carries the id
  * of the build it measured), is detected instead of trusted.  Static storage. */
 const char *amx_build_id(void);
+/* HIP devices this process may create contexts on: the largest gfx950 device number + 1 (0: none).  The reference's caller is ONE process
+ * (core.py:465-466: results = self.model.fit(self)) whose fit spreads its voxels over `nthreads` host threads in contiguous chunks
+ * (models.pyx:204-211); the MI355X counterpart of that is one context per device of the node, driven by one host thread each, on contiguous
+ * shards of the caller's arrays -- amico_amd.models does exactly that when AMX_DEVICES=all (or a list) is set: every call of this ABI sets its
+ * context's device for the calling thread, contexts share nothing, and calls on DIFFERENT contexts may run concurrently from different threads. */
+int  amx_device_count(void);
+/* A context that fits ONE SHARD of a larger call (several contexts sharing a fit, see above): the host-buffer calls that follow choose their
+ * paths -- seeded chain or not, kernel builds, rescue pass -- by `total`, the size of the whole call, not by the shard's, so that a voxel is
+ * settled by the same arithmetic whichever device it lands on and however many there are (bit-identical maps).  0 = off (the default). */
+int  amx_set_call_voxels(amx_ctx *ctx, int64_t total);
 /* device < 0: current HIP device.  Fails with AMX_E_NODEVICE when no gfx950 GPU is visible. */
 int  amx_ctx_create(int device, amx_ctx **out);
 void amx_ctx_destroy(amx_ctx *ctx);
@@ -346,6 +356,11 @@ int amx_last_seed_stats(amx_ctx *ctx, int64_t out[8]);
  * reference (its fit reads host memory in place, models.pyx:902).                                                              */
 int amx_last_host_narrowed(amx_ctx *ctx);
 
+/* The host threads of the float32 transport above (made at the first large float64 host-buffer call of the ctx): out[0] = threads, out[1] =
+ * first CPU and out[2] = number of physical cores of the share of the device's NUMA node they are striped over, out[3] = the device.  A
+ * node's cores are divided among the devices that hang on it (one pool per device, whether one process drives them all --
+ * amico_amd.models: AMX_DEVICES -- or one process each), so that sibling pools never share a core; AMX_HOST_SIBLINGS="i/n" forces the share. */
+int amx_host_pool_info(amx_ctx *ctx, int out[4]);
 /* The kernels the LAST *_fit / *_fit_device call on this ctx enqueued, in launch order, as text ("k_noddi_gemm<false,25,9> -> k_nnls_seed<1,8,occ2>
  * -> ..."; the first batch of a host-buffer call): which of the library's paths a dictionary shape / call size / solver parameters took.
  * bench.py labels its roofline kernel from it instead of from a literal.  No counterpart in the reference (one path, models.pyx:902-981). */

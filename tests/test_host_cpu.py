@@ -257,3 +257,64 @@ def test_dictionary_cache_is_checked_behind_the_fit(monkeypatch):
     with pytest.raises(ValueError, match='same model'):
         m.fit(ev)
     assert m._lut_pending is False                                             # the wrapper leaves no pending check behind
+
+
+def test_fit_on_devices_shards_like_the_reference_chunks(monkeypatch):
+    """BaseModel._fit_on_devices (round 6): contiguous shards by the chunk rule of models.pyx:204-211, one (fake) context per device, results
+    into row slices of the caller's arrays, the whole call's size announced to every context, a shard's error reported with the caller's
+    voxel number; no GPU needed."""
+    import amico_amd.models as M
+    from amico_amd import _capi
+    from amico_amd.parallel import shard_range
+
+    class Ctx:
+        def __init__(self, k):
+            self.k, self.sizes = k, []
+
+        def set_call_voxels(self, t):
+            self.sizes.append(t)
+
+        def last_stats(self):
+            return {'itercap_voxels': 0}
+
+    ctxs = [Ctx(0), Ctx(1), Ctx(2)]
+    monkeypatch.setattr(M, 'get_contexts', lambda: ctxs)
+    monkeypatch.setattr(M, '_CTXS', ctxs)
+
+    class Fake(M.BaseModel):
+        def __init__(self):
+            self.id, self.scheme = 'Fake', None
+
+        def set(self): pass
+        def get_params(self): pass
+        def set_solver(self): pass
+        def fit(self, ev): pass
+
+    class Ev:
+        KERNELS, htable = {'model': 'Fake', 'wm': np.ones((2, 3), np.float32)}, None
+    m = Fake()
+    n = 1003
+    seen = []
+
+    def fit_shard(ctx, lut, lo, hi, out):
+        assert lut == 'lut%d' % ctx.k
+        seen.append((ctx.k, lo, hi))
+        out[0][:] = np.arange(lo, hi)[:, None] * np.ones(2)
+        assert out[1] is None
+        out[2][:] = ctx.k
+    est, none, who = m._fit_on_devices(Ev(), n, lambda c: 'lut%d' % c.k, fit_shard, (np.zeros((n, 2)), None, np.zeros(n)))
+    assert none is None and np.array_equal(est[:, 0], np.arange(n))
+    assert sorted(seen) == [(r,) + shard_range(n, r, 3) for r in range(3)]
+    assert [int(who[i]) for i in (0, 333, 334, 667, 668, 1002)] == [0, 0, 1, 1, 2, 2]
+    assert all(c.sizes == [n, 0] for c in ctxs)                       # announced, then withdrawn
+    # the second call finds the dictionaries cached per context
+    calls = []
+    m._fit_on_devices(Ev(), n, lambda c: calls.append(c.k) or 'again', fit_shard, (np.zeros((n, 2)), None, np.zeros(n)))
+    assert calls == []
+
+    def bad(ctx, lut, lo, hi, out):
+        if ctx.k == 2:
+            raise _capi.AmxError(-3, '"amico.lut.dir_to_lut_idx" index out of bounds (7, 9) [voxel 5]')
+    with pytest.raises(RuntimeError, match=r'\[voxel 673\]'):          # 668 + 5
+        m._fit_on_devices(Ev(), n, lambda c: 'x', bad, (np.zeros((n, 2)), None, np.zeros(n)))
+    assert all(c.sizes[-1] == 0 for c in ctxs)
