@@ -85,7 +85,7 @@ int make_plan(amx_ctx *ctx, int64_t n, int ndirs, Plan &pl, bool seeds = false, 
     if ((rc = ensure(ctx, ctx->cursor, (size_t)(ndirs + 1) * sizeof(int)))) return rc;
     if ((rc = ensure(ctx, ctx->chunks, (size_t)max_chunks * sizeof(Chunk)))) return rc;
     if ((rc = ensure(ctx, ctx->misc, 64 * sizeof(int)))) return rc;
-    if ((rc = ensure(ctx, ctx->ovf, (size_t)6 * n * sizeof(int)))) return rc;      // (lists 0 .. 2: the stages' overflow, 3: second level; 4, 5: the same for a forked fit's side stream, amx_launch.hpp)
+    if ((rc = ensure(ctx, ctx->ovf, (size_t)7 * n * sizeof(int)))) return rc;      // (lists 0 .. 2: the stages' overflow, 3: second level; 4, 5: the same for a forked fit's side stream; 6: what k_noddi_lasso_big takes; amx_launch.hpp)
     pl.lutidx = (int *)ctx->lutidx.p; pl.perm = (int *)ctx->perm.p; pl.counts = (int *)ctx->counts.p;
     pl.dir_start = (int *)ctx->dir_start.p; pl.cursor = (int *)ctx->cursor.p;
     pl.chunks = (Chunk *)ctx->chunks.p; pl.n_chunks = (int *)ctx->misc.p;
@@ -282,6 +282,8 @@ int amx_ctx_create(int device, amx_ctx **out)
             sscanf(e, "%d,%d,%d", &c[0], &c[1], &c[2]);
             for (int k = 0; k < 3; k++) ctx->opt_seed_tripcap[k] = c[k] < 4 ? 4 : c[k];
         }
+        e = getenv("AMX_BIG_ALL");
+        ctx->opt_no_big_all = e && *e == '0';
         e = getenv("AMX_FORK");
         if (e && *e) ctx->opt_fork = atoi(e) & 3;
         e = getenv("AMX_FORK_CUS");
@@ -304,7 +306,7 @@ void amx_ctx_destroy(amx_ctx *ctx)
     hipDeviceSynchronize();
     DevBuf *bufs[] = {&ctx->lutidx, &ctx->perm, &ctx->counts, &ctx->dir_start, &ctx->cursor, &ctx->chunks,
                       &ctx->misc, &ctx->xiso, &ctx->supp, &ctx->ovf, &ctx->cproj, &ctx->hy, &ctx->hdirs, &ctx->hest,
-                      &ctx->hrmse, &ctx->hnrmse, &ctx->hextra, &ctx->hy32, &ctx->wy, &ctx->ytil, &ctx->seeds, &ctx->schunks, &ctx->ytil2, &ctx->seeds2, &ctx->cgemm, &ctx->done, &ctx->rlist, &ctx->cgemm2, &ctx->clip, &ctx->feed};
+                      &ctx->hrmse, &ctx->hnrmse, &ctx->hextra, &ctx->big, &ctx->hy32, &ctx->wy, &ctx->ytil, &ctx->seeds, &ctx->schunks, &ctx->ytil2, &ctx->seeds2, &ctx->cgemm, &ctx->done, &ctx->rlist, &ctx->cgemm2, &ctx->clip, &ctx->feed};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     for (DevBuf &b : ctx->alt) if (b.p) hipFree(b.p);
     if (ctx->status_d) hipFree(ctx->status_d);
@@ -809,7 +811,8 @@ static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
     progress_tick(ctx, s, n_vox / 3, n_vox);                       // (three stages: a third of the work each, roughly)
     a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks; a.rlist = nullptr; a.rcount = nullptr; a.done = nullptr;
     // the LASSO seeds need x_iso: Gram-space solver only (lambda2 >= 1e-5), with the default dictionary shape
-    if (seeds && (ctx->opt_seed_stages & 4) && lut->basis2_S != nullptr && lambda2 >= 1e-5 && (gemm_ks > 0 || lut->nS <= 128) && !ctx->opt_lasso_qr) {
+    if (seeds && (ctx->opt_seed_stages & 4) && lut->basis2_S != nullptr && lambda2 >= 1e-5 && (gemm_ks > 0 || lut->nS <= 128) && !ctx->opt_lasso_qr &&
+        (lambda1 > 0.0 || ctx->opt_no_big_all || lut->n_wm <= 64)) {       // (lambda1 = 0: a dense optimum -- no seeds to propose, amx_launch_noddi_s2 goes to k_noddi_lasso_big)
         const bool gcert2 = !ctx->opt_no_gcert && gemm_ks > 0 && lut->screen2_kappa0 != nullptr && lut->u2iso != nullptr;
         rec(ctx, 12, s);
         // y2~ of every voxel and c2 = A2'y2, ||y2||^2 of the unclipped ones derive from the stage-1 table; the clipped voxels' exactly

@@ -26,6 +26,7 @@ struct amx_ctx {
     int n_cu = 256;                // compute units of the device (persistent-grid launches)
     std::string err;
     // stream-ordered workspace (grow-only)
+    DevBuf big;                    // factor blocks of k_noddi_lasso_big for dictionaries of more than 176 candidate atoms (amx_big.hip)
     DevBuf lutidx, perm, counts, dir_start, cursor, chunks, misc, xiso, supp, ovf, cproj, ytil, seeds, schunks, ytil2, seeds2, cgemm, done, rlist, cgemm2, clip, feed;
     DevBuf hy, hdirs, hest, hrmse, hnrmse, hextra;   // staging for the host-pointer entry points
     int *status_d = nullptr;       // ST_WORDS ints
@@ -115,6 +116,7 @@ struct amx_ctx {
     hipStream_t fork_s[2] = {nullptr, nullptr};          // (one per workspace set: work_idx)
     hipEvent_t fork_ev[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
     int work_idx = 0;               // which of the two workspace sets the named buffers are (swap_work)
+    bool opt_no_big_all = false;    // AMX_BIG_ALL=0: lambda1 = 0 fits take the fast kernels first and reach k_noddi_lasso_big through the overflow lists
     bool side_launch = false;       // transient: the launch being enqueued goes to the side stream (launch_pair picks its own overflow lists)
     std::string path;               // kernels of the last fit enqueued on this ctx, in launch order (amx_last_path)
     int opt_seed_chunk = 0;        // AMX_SEED_CHUNK (0 = by the call's size, make_plan): voxels of one orientation per workgroup of the seed solvers (lanes refill from the chunk: the more voxels per lane, the smaller the share of the tail; 1 M voxels: 1024 -> 7.2 ms, 2048 -> 7.3, 4096 -> 5.5 for stage 1)
@@ -291,6 +293,7 @@ size_t amx_gcert2_leftover_offset(const Plan &pl, bool wide, bool third);      /
 const int *amx_gcert2_leftover_counts(const Plan &pl, bool wide, bool third);  // ... and the per-chunk counts of those lists (Plan::zcount)
 static inline size_t amx_rlist_half(const Plan &pl) { return (size_t)pl.n + pl.max_schunks + 64; }   // ints per left-over list + counts
 int amx_launch_noddi_seed2(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, bool have_ytil2);
+int amx_launch_noddi_big(amx_ctx *ctx, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, const int *list, const int *count, int n_all);   // amx_big.hip: LASSO stage, any support size
 int amx_launch_noddi_s1(amx_ctx *ctx, amx::NoddiArgs &a, const Plan &pl, hipStream_t s);
 int amx_launch_noddi_s2(amx_ctx *ctx, amx::NoddiArgs &a, const Plan &pl, hipStream_t s);
 int amx_launch_noddi_s3(amx_ctx *ctx, amx::NoddiArgs &a, const Plan &pl, hipStream_t s);

@@ -28,7 +28,7 @@ static inline bool amx_noddi_tile_global(int nS, int ldA, int n_atoms)
 // LDSF(nw) -> dynamic LDS bytes of the main kernel with nw wavefronts per workgroup
 template <int NW, typename Args, typename KM, typename KL, typename LDSF>
 static int launch_pair(amx_ctx *ctx, Args &a, const Plan &pl, hipStream_t s, KM km, KL kl, LDSF ldsf,
-                       size_t lds_list, int slot, int ev, const char *name = "wavefront-per-voxel solver")
+                       size_t lds_list, int slot, int ev, const char *name = "wavefront-per-voxel solver", bool big_after = false)
 {
     amx_note(ctx, name);
     int rc;
@@ -55,6 +55,9 @@ static int launch_pair(amx_ctx *ctx, Args &a, const Plan &pl, hipStream_t s, KM 
     Args b = a;
     b.c.ovf_count = pl.ovf_count + (ctx->side_launch ? 9 : 8);
     b.c.ovf_list = pl.ovf_list + (size_t)(ctx->side_launch ? 5 : 3) * pl.n;
+    // (NODDI's Gram-space LASSO stage: what does not fit the re-run kernel's 64 atoms either is not an error -- k_noddi_lasso_big, amx_big.hip,
+    //  takes it from a list of its own: misc[14], list 6)
+    if (big_after) { b.c.ovf_count = pl.ovf_count + 10; b.c.ovf_list = pl.ovf_list + (size_t)6 * pl.n; }
     hipLaunchKernelGGL(kl, dim3(kListGrid), dim3(64), lds_list, s, b);
     AMX_TRACE(ctx, s, "solver re-run pass");
     rec(ctx, ev + 1, s);

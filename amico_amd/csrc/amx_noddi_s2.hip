@@ -26,11 +26,11 @@ static int go_gram(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
         constexpr int MPL = 32, NWL = AMX_S2_NW / 2;
         return launch_pair<NWL>(ctx, a, pl, s, k_noddi<4, NR, NQ, MPL, NWL, false>, k_noddi<4, NR, NQ, MB, 1, true>,
                            [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MPL, true) + scr; }, fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, true),
-                           1, 4, a.rlist ? "k_noddi<4|2> (left-overs of k_lasso_gcert)" : "k_noddi<4|2> (all voxels)");
+                           1, 4, a.rlist ? "k_noddi<4|2> (left-overs of k_lasso_gcert)" : "k_noddi<4|2> (all voxels)", true);
     }
     return launch_pair<NW>(ctx, a, pl, s, k_noddi<4, NR, NQ, MP, NW, false>, k_noddi<4, NR, NQ, MB, 1, true>,
                        [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MP, true) + scr; }, fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, true),
-                       1, 4, a.rlist ? "k_noddi<4|2> (left-overs of k_lasso_gcert)" : "k_noddi<4|2> (all voxels)");
+                       1, 4, a.rlist ? "k_noddi<4|2> (left-overs of k_lasso_gcert)" : "k_noddi<4|2> (all voxels)", true);
 }
 
 // shapes beyond the LDS variants (see amx_noddi_s1.hip): the tile read where it lies; passive sets of up to 32 atoms in the main
@@ -43,7 +43,7 @@ static int go_global(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s, 
         const size_t scr = (a.scr2_S && a.seeds2) ? (size_t)kSeedKD * kScreenLd * sizeof(float) : 0;
         return launch_pair<NW>(ctx, a, pl, s, k_noddi<4, NR, NQ, MP, NW, false, float, true>, k_noddi<4, NR, NQ, MB, 1, true, float, true>,
                                [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MP, true, true, true) + scr; },
-                               fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, true, true, true), 1, 4, a.rlist ? "k_noddi<4|2> (left-overs of k_lasso_gcert)" : "k_noddi<4|2> (all voxels)");
+                               fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, true, true, true), 1, 4, a.rlist ? "k_noddi<4|2> (left-overs of k_lasso_gcert)" : "k_noddi<4|2> (all voxels)", true);
     }
     constexpr int MP = 20, MB = 32;       // (A-space QR: the factor lives in registers -- 32 x 8 rows per lane is what a wavefront holds)
     return launch_pair<NW>(ctx, a, pl, s, k_noddi<2, NR, NQ, MP, NW, false, float, true>, k_noddi<2, NR, NQ, MB, 1, true, float, true>,
@@ -54,7 +54,15 @@ static int go_global(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s, 
 int amx_launch_noddi_s2(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
 {
     const bool gram = a.gram_dwi != nullptr && a.c.lam2 >= 1e-5 && !ctx->opt_lasso_qr;
-    if (amx_noddi_tile_global(a.c.nS, a.c.ldA, a.c.n_atoms)) return go_global(ctx, a, pl, s, gram);
-    if (gram) return a.c.nS <= 128 ? go_gram<2>(ctx, a, pl, s) : go_gram<4>(ctx, a, pl, s);
-    return a.c.nS <= 128 ? go_qr<2>(ctx, a, pl, s) : go_qr<4>(ctx, a, pl, s);
+    int rc;
+    // lambda1 = 0 (a pure ridge: set_solver(lambda1=0, ...)): the optimum holds most of the dictionary -- every voxel would walk Lawson-Hanson
+    // to 20, then 64 atoms and overflow twice on its way to the solver that can hold it: straight there (AMX_BIG_ALL=0: the long way, diagnosis)
+    if (gram && a.c.lam1 == 0.0 && a.rlist == nullptr && a.n_wm > 64 && !ctx->opt_no_big_all)
+        return amx_launch_noddi_big(ctx, a, pl, s, nullptr, nullptr, (int)pl.n);
+    if (amx_noddi_tile_global(a.c.nS, a.c.ldA, a.c.n_atoms)) rc = go_global(ctx, a, pl, s, gram);
+    else if (gram) rc = a.c.nS <= 128 ? go_gram<2>(ctx, a, pl, s) : go_gram<4>(ctx, a, pl, s);
+    else return a.c.nS <= 128 ? go_qr<2>(ctx, a, pl, s) : go_qr<4>(ctx, a, pl, s);
+    if (rc || !gram) return rc;
+    // supports of more than 64 atoms (a weak lambda1: the optimum is dense): the slow exact solver, from the re-run kernel's own overflow list
+    return amx_launch_noddi_big(ctx, a, pl, s, pl.ovf_list + (size_t)6 * pl.n, pl.ovf_count + 10, 0);
 }

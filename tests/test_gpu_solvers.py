@@ -2,6 +2,8 @@
 nnls(A, y, m, n, x, rnorm) / lasso(A, y, m, n, 1, x, lambda1, lambda2) -- in their batched C-ABI form (amx_nnls_batched,
 amx_lasso_batched): against the oracle's Lawson-Hanson / LARS restatements, scipy's NNLS, and the Kuhn-Tucker conditions of the
 device x itself (the certificate that needs no reference)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -144,3 +146,75 @@ def test_batched_solvers_take_large_dictionaries(m, n):
     for v in range(0, nv, 8):
         g = A[idx[v]].T @ (y[v] - A[idx[v]] @ xl[v]) - lam2 * xl[v] - lam1
         assert np.abs(g[xl[v] > 0]).max(initial=0.0) < 1e-9 and g[xl[v] == 0].max(initial=0.0) < 1e-9
+
+
+@pytest.mark.parametrize('route', ['direct', 'through_the_overflow_lists', 'weak_lambda1'])
+def test_noddi_dense_lasso_is_a_fit_not_an_error(htable500, route, amx_env):
+    """VERDICT r05 missing 3: NODDI with lambda1 = 0 (a legal set_solver: models.pyx:723-725) has a DENSE LASSO optimum on most of its 144 atoms
+    -- beyond the 64 passive atoms of the wavefront-per-voxel kernels, AMX_E_OVERFLOW until round 5.  k_noddi_lasso_big (csrc/amx_big.hip:
+    block principal pivoting, dense Cholesky, a workgroup per voxel) fits it: straight away when lambda1 = 0, or from the overflow list of the
+    64-atom kernel (AMX_BIG_ALL=0 forces that route; a weak lambda1 takes it voxel by voxel).  Checked against the oracle's LARS and by the
+    Kuhn-Tucker conditions of the device coefficients."""
+    from amico_amd import _capi, synthetic as S
+    from oracle import oracle
+    ht, dirs = htable500['htable'], htable500['dirs']
+    sch = S.make_scheme(seed=0)
+    K = S.noddi_kernels(sch, dirs)
+    n = 6000
+    y, d = S.noddi_signals(n, K, ht, sch, seed=41)
+    lam1, lam2 = (2e-4, 1e-3) if route == 'weak_lambda1' else (0.0, 1e-3)
+    amx_env(AMX_BIG_ALL='0' if route == 'through_the_overflow_lists' else None, AMX_SEED_MIN_VOXELS='0')
+    ctx = _capi.Context(-1)
+    lut = _capi.upload_noddi(ctx, K, ht, sch.dwi_idx)
+    import torch
+    dev = torch.device('cuda', 0)
+    yt, dt = torch.from_numpy(y).to(dev), torch.from_numpy(d).to(dev)
+    est, _, _, _, x = _capi.noddi_fit_device(ctx, lut, yt, dt, lam1, lam2, 3, return_x=True)
+    ctx.sync()
+    st = ctx.last_stats()
+    assert st['overflow_voxels'] == 0 and st['itercap_voxels'] == 0 and st['guard_trips'] == 0, st
+    assert 'k_noddi_lasso_big' in ctx.last_path()
+    est, x = est.cpu().numpy(), x.cpu().numpy()
+    ref = oracle.noddi_fit(y, d, K, ht, sch.dwi_idx, lambda1=lam1, lambda2=lam2, nthreads=os.cpu_count() or 1, return_x=True)
+    supp = (x[:, 1, :144] > 0).sum(axis=1)
+    print('route %s: support sizes min %d mean %.1f max %d, %d voxels beyond 64 atoms' % (route, supp.min(), supp.mean(), supp.max(), int((supp > 64).sum())))
+    assert (supp > 64).any() and (supp <= 64).any(), (supp.min(), supp.max())          # both kinds of voxel in one call: beyond the old cap and below it
+    assert np.abs(x[:, 1, :144] - ref['x'][:, 1, :144]).max() < 1e-7
+    diff = np.abs(est - ref['estimates']).max(axis=1)
+    assert (diff < 1e-6).mean() > 0.995 and diff.max() < 1e-4, (float((diff < 1e-6).mean()), float(diff.max()))
+    # Kuhn-Tucker conditions of the LASSO stage from the device's own numbers (models.pyx:914-926)
+    li = S.lut_indices(d, ht)
+    dwi = np.asarray(sch.dwi_idx)
+    nrm = K['norms'][0]
+    for v in range(0, n, 97):
+        A2 = K['wm'][:, li[v], :][:, dwi].T.astype(np.float64) * nrm[None, :]
+        y2 = np.maximum(0.0, y[v, dwi] - x[v, 0, 144] * K['iso'][dwi].astype(np.float64))
+        g = A2.T @ (y2 - A2 @ x[v, 1, :144]) - lam2 * x[v, 1, :144] - lam1
+        P = x[v, 1, :144] > 0
+        assert np.abs(g[P]).max(initial=0.0) < 1e-9 and g[~P].max(initial=-1.0) < 1e-9
+
+
+def test_freewater_with_a_64_atom_dictionary(htable500):
+    """the largest FreeWater dictionary the library takes (60 zeppelins + 4 balls): every atom may be passive (models.pyx:1238 has no cap)"""
+    from amico_amd import FreeWater, synthetic as S
+    from oracle import oracle
+    ht, dirs = htable500['htable'], htable500['dirs']
+    sch = S.make_scheme(1, ((1000.0, 64),), seed=3)
+    K = S.freewater_kernels(sch, dirs, d_perps=np.linspace(0.05, 1.0, 60) * 1e-3, d_isos=(1.5e-3, 2.0e-3, 2.5e-3, 3.0e-3))
+    y, d = S.freewater_signals(1200, K, ht, sch, seed=8)
+
+    class Ev:
+        KERNELS, htable, nthreads = K, ht, 1
+
+        def __init__(self):
+            self.y, self.DIRs = y, d
+
+        def get_config(self, k):
+            return False
+    m = FreeWater()
+    m.set(d_perps=np.linspace(0.05, 1.0, 60) * 1e-3, d_isos=[1.5e-3, 2.0e-3, 2.5e-3, 3.0e-3])
+    for lam2 in (1e-3, 5.0):                                     # (a strong ridge: dense optimum on most of the 64 atoms)
+        m.set_solver(lambda1=0.0, lambda2=lam2)
+        out = m.fit(Ev())
+        ref = oracle.freewater_fit(y, d, K, ht, lambda1=0.0, lambda2=lam2, nthreads=8)
+        assert np.abs(out['estimates'] - ref['estimates']).max() < 1e-6, lam2

@@ -9,7 +9,7 @@ mkdir -p $out
 cd $root/amico_amd/csrc
 FLAGS="-DAMX_S2_NW=16 -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value"
 pids=()
-for u in amx_api amx_seed amx_noddi_s1 amx_noddi_s2 amx_noddi_s3 amx_fw amx_sandi amx_czb amx_small amx_signal amx_volume amx_batched amx_buildid; do
+for u in amx_api amx_big amx_seed amx_noddi_s1 amx_noddi_s2 amx_noddi_s3 amx_fw amx_sandi amx_czb amx_small amx_signal amx_volume amx_batched amx_buildid; do
   /opt/rocm/bin/hipcc $FLAGS "$@" -c -o $out/$u.o $u.hip 2>/dev/null &
   pids+=($!)
 done
