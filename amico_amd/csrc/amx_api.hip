@@ -282,6 +282,12 @@ int amx_ctx_create(int device, amx_ctx **out)
             sscanf(e, "%d,%d,%d", &c[0], &c[1], &c[2]);
             for (int k = 0; k < 3; k++) ctx->opt_seed_tripcap[k] = c[k] < 4 ? 4 : c[k];
         }
+        e = getenv("AMX_LEFT_SMALL");
+        if (e && *e) {
+            long long c[3] = {ctx->opt_left_small[0], ctx->opt_left_small[1], ctx->opt_left_small[2]};
+            sscanf(e, "%lld,%lld,%lld", &c[0], &c[1], &c[2]);
+            for (int k = 0; k < 3; k++) ctx->opt_left_small[k] = c[k] < 0 ? 0 : c[k];
+        }
         e = getenv("AMX_BIG_ALL");
         ctx->opt_no_big_all = e && *e == '0';
         e = getenv("AMX_FORK");

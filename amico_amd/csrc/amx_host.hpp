@@ -116,6 +116,13 @@ struct amx_ctx {
     hipStream_t fork_s[2] = {nullptr, nullptr};          // (one per workspace set: work_idx)
     hipEvent_t fork_ev[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
     int work_idx = 0;               // which of the two workspace sets the named buffers are (swap_work)
+    // AMX_LEFT_SMALL=a,b,c: calls of fewer voxels run the left-over kernels of stage 1 / LASSO / stage 3 in their small-call builds (float32 tile, 4
+    // wavefronts, two workgroups per CU: amx_noddi_s1.hip).  Measured (tools/r06/a05.sh; 50 000 / 100 000 / 200 000 / 300 000 / 500 000 / 1 M voxels, fit
+    // in ms, round-5 builds 1.441 / 1.817 / 2.386 / 2.885 / 4.000 / 6.421): stage 1 alone 1.421 / 1.793 / 2.394 / 2.921 / 4.072 / 6.591; stage 3 alone
+    // 1.415 / 1.797 / 2.371 / 2.849 / 3.989 / 6.506 (its 12-wavefront build spills 117 registers, this one none); the LASSO stage's (two wavefronts,
+    // no screening table) loses at every size (1.460 / 1.905 / 2.511 / ...): off.  The gain is ~20 us per kernel, not the ~100 the "one round of
+    // workgroups instead of two" arithmetic promised: a left-over kernel lasts as long as its longest voxel's Lawson-Hanson, whatever the rounds.
+    long long opt_left_small[3] = {150000, 0, 600000};
     bool opt_no_big_all = false;    // AMX_BIG_ALL=0: lambda1 = 0 fits take the fast kernels first and reach k_noddi_lasso_big through the overflow lists
     bool side_launch = false;       // transient: the launch being enqueued goes to the side stream (launch_pair picks its own overflow lists)
     std::string path;               // kernels of the last fit enqueued on this ctx, in launch order (amx_last_path)

@@ -677,8 +677,10 @@ __device__ __forceinline__ int next_ticket(unsigned *ticket, int lane)
 #define AMX_KERNEL_PROLOGUE(AT, NRv, NQv, NWv, RLWv) AMX_KERNEL_PROLOGUE_GT(AT, NRv, NQv, NWv, RLWv, false)
 constexpr int kTileSlack = 512;      // floats (doubles for fp64 dictionaries) readable behind the last tile of a dictionary: 64 * NQ <= 256 atoms per row sweep
 
+// (NW <= 4 with the tile in LDS: the small-call builds of the left-over kernels (round 6) -- float32 tile, few wavefronts, at most 80 KB of LDS and
+//  256 registers, so that TWO workgroups share a CU and the ~500 workgroups of a call -- a chunk is an orientation -- run in ONE round)
 template <int STAGE, int NR, int NQ, int MAXP, int NW, bool LIST, typename AT = float, bool GT = false>
-__global__ void __launch_bounds__(NW * 64) k_noddi(const NoddiArgs a)
+__global__ void __launch_bounds__(NW * 64, (NW <= 4 && !LIST && !GT) ? 2 : 1) k_noddi(const NoddiArgs a)
 {
     static_assert(!GT || std::is_same<AT, float>::value, "the global tile is the float32 dictionary itself");
     using ATs = typename std::conditional<GT, gtile<float>, AT>::type;      // what the solver is told about the tile (amx_solver.hpp: tile_sweep)

@@ -17,6 +17,16 @@ static int go(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
     // Left-overs of the Gram certificates (seeded chain): few voxels per chunk, and the ones that get here are the hard ones --
     // room for 12 passive atoms and 12 wavefronts (168 VGPRs, 16 spilled, against 128 / 64 with 8 atoms and 16 wavefronts): nothing
     // overflows into the one-wavefront re-run kernel any more (it cost 0.16 ms for five voxels per million), 1 M voxels 0.82 -> 0.65 ms
+    // SMALL calls (round 6): a chunk is an orientation, so even a 50 000-voxel call launches ~500 workgroups here, each with a handful of
+    // left-over voxels; the build above holds a whole CU's LDS (154 KB: the fp64 tile) -- 500 workgroups on 256 CUs are TWO rounds, each as long
+    // as one hard voxel's Lawson-Hanson (~140 us).  With the float32 tile and 4 wavefronts a workgroup takes 77 KB: two per CU, one round.
+    // Same arithmetic (the tile's values are widened when read instead of when staged): bit-identical maps.  AMX_LEFT_SMALL=a,b,c: call sizes
+    // (voxels) below which stage 1 / LASSO / stage 3 take their small builds.
+    if (a.rlist != nullptr && (long long)pl.n < ctx->opt_left_small[0] &&
+        2 * (fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 4, 12, false, false) + scr) <= kLdsPerCU)
+        return launch_pair<4>(ctx, a, pl, s, k_noddi<1, NR, NQ, 12, 4, false, float>, k_noddi<1, NR, NQ, MB, 1, true>,
+                               [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, 12, false, false) + scr; },
+                               fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, false), 0, 2, "k_noddi<1> (left-overs of k_nnls_gcert<1>; small-call build: two workgroups per CU)");
     if (a.rlist != nullptr && fit_lds_bytes<double>(a.c.nS, a.c.ldA, NR, NQ, 12, 12, false, false) + scr <= kLdsPerCU && !ctx->opt_tile_f32)
         return launch_pair<12>(ctx, a, pl, s, k_noddi<1, NR, NQ, 12, 12, false, double>, k_noddi<1, NR, NQ, MB, 1, true>,
                                [&](int nw) { return fit_lds_bytes<double>(a.c.nS, a.c.ldA, NR, NQ, nw, 12, false, false) + scr; },

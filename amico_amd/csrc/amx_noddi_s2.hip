@@ -24,6 +24,16 @@ static int go_gram(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
         // left-over lists of the Gram certificates: few voxels, mostly seeds of more than 16 atoms -- half the wavefronts with
         // room for 32 atoms each, so that practically nothing is left for the (slow, one wavefront per voxel) re-run kernel
         constexpr int MPL = 32, NWL = AMX_S2_NW / 2;
+        // small calls: two workgroups per CU (amx_noddi_s1.hip) -- two wavefronts with room for 32 atoms each and no screening table (the
+        // certificate of a seed then takes the exact sweep of the dual vector: same decisions, 9 KB of LDS less): 78 KB
+        if ((long long)pl.n < ctx->opt_left_small[1] && 2 * fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 2, MPL, true) <= kLdsPerCU) {
+            NoddiArgs b = a;
+            b.scr2_S = nullptr;
+            const int rc = launch_pair<2>(ctx, b, pl, s, k_noddi<4, NR, NQ, MPL, 2, false>, k_noddi<4, NR, NQ, MB, 1, true>,
+                                          [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MPL, true); }, fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, true),
+                                          1, 4, "k_noddi<4> (left-overs of k_lasso_gcert; small-call build: two workgroups per CU)", true);
+            return rc;
+        }
         return launch_pair<NWL>(ctx, a, pl, s, k_noddi<4, NR, NQ, MPL, NWL, false>, k_noddi<4, NR, NQ, MB, 1, true>,
                            [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MPL, true) + scr; }, fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, true),
                            1, 4, a.rlist ? "k_noddi<4|2> (left-overs of k_lasso_gcert)" : "k_noddi<4|2> (all voxels)", true);

@@ -14,6 +14,12 @@ static int go(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
 #endif
     constexpr int NW = AMX_S3_NW; // wavefronts per workgroup: as many as the register budget of this stage allows
     const size_t scr = (a.scr_S && a.seeds) ? (size_t)kSeedKD * kScreenLd * sizeof(float) : 0;   // screening table (amx_solver.hpp)
+    // small calls: two workgroups per CU (amx_noddi_s1.hip)
+    if (a.rlist != nullptr && (long long)pl.n < ctx->opt_left_small[2] &&
+        2 * (fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 4, MP, false, false) + scr) <= kLdsPerCU)
+        return launch_pair<4>(ctx, a, pl, s, k_noddi<3, NR, NQ, MP, 4, false, float>, k_noddi<3, NR, NQ, MB, 1, true>,
+                               [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MP, false, false) + scr; },
+                               fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, false), 2, 6, "k_noddi<3> (left-overs; small-call build: two workgroups per CU)");
     // fp64 tile in LDS when it fits next to the per-wavefront blocks (99 x 145: 115 KB + 16 x 2.3 KB of 160 KB): the
     // fp32 -> fp64 conversions of the tile reads are then paid once per chunk.  AMX_TILE_F32=1: the fp32 tile.
     {

@@ -2139,14 +2139,16 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
         const double xq = clip ? 0.0 : xi;
         const double sub = clip ? 0.0 : Crow[(size_t)(a.aux0 + kAuxB0) * 64];
         const unsigned long long *sd = a.seeds2 + (size_t)pos * 4;
-        unsigned long long P[3] = {sd[0], sd[1], sd[2]};
         const unsigned long long flag = sd[3];
-        const int cnt = __builtin_popcountll(P[0]) + __builtin_popcountll(P[1]) + __builtin_popcountll(P[2]);
-        bool okv = valid && flag == 0ull && cnt <= MS && (!WIDE || cnt > LOW);
+        int cnt;
+        bool okv;
         LeanLane<MS> V;
         unsigned long long wl[4] = {0ull, 0ull, 0ull, 0ull};    // the support's atoms as a byte list (stage 3's candidates: written out below)
         {
             // slots = set bits in ascending order
+            const unsigned long long P[3] = {sd[0], sd[1], sd[2]};
+            cnt = __builtin_popcountll(P[0]) + __builtin_popcountll(P[1]) + __builtin_popcountll(P[2]);
+            okv = valid && flag == 0ull && cnt <= MS && (!WIDE || cnt > LOW);
             unsigned long long rem[3] = {okv ? P[0] : 0ull, okv ? P[1] : 0ull, okv ? P[2] : 0ull};
             int n0 = 0;
 #pragma unroll
@@ -2166,13 +2168,6 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
                 n0 += (wq >= 0) ? 1 : 0;
             }
             V.np = okv ? n0 : 0;
-        }
-        unsigned long long cand[3];
-#pragma unroll
-        for (int w3 = 0; w3 < 3; w3++) {
-            const int c = n_wm - 64 * w3;
-            const unsigned long long all = c >= 64 ? ~0ull : (c > 0 ? ((1ull << c) - 1ull) : 0ull);
-            cand[w3] = all & ~P[w3];
         }
         GC_PH(0);
         // (the column scales are read from LDS where they are needed -- scl[idx] -- instead of living in MS registers through the
@@ -2229,6 +2224,17 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
         const bool good = okv && piv && feas && (yy <= 1.79769313486231570e308);
         GC_PH(1);
         unsigned long long ex[3] = {0ull, 0ull, 0ull};
+        // (the support bits are read AGAIN here -- 24 bytes the L2 still holds -- instead of living in six registers through the factorisation,
+        //  and the candidates are made from them only now: twelve registers less at the kernel's peak -- first pass 42 -> 30 spilled registers.
+        //  Round 6 also tried the lane's atom table as packed bytes, 18 registers less on paper: the compiler spilled MORE, 145 -> 172)
+        const unsigned long long Pq[3] = {sd[0], sd[1], sd[2]};
+        unsigned long long cand[3];
+#pragma unroll
+        for (int w3 = 0; w3 < 3; w3++) {
+            const int c = n_wm - 64 * w3;
+            const unsigned long long all = c >= 64 ? ~0ull : (c > 0 ? ((1ull << c) - 1ull) : 0ull);
+            cand[w3] = all & ~Pq[w3];
+        }
         {
             double rt[KD];
             const double *Cu = Crow + (size_t)(a.aux0 + (clip ? kAuxU : kAuxU2)) * 64;
@@ -2308,7 +2314,7 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
 #endif
         if (cert) {
             unsigned long long *sp = a.supp + (size_t)vox * 4;
-            sp[0] = P[0]; sp[1] = P[1]; sp[2] = P[2]; sp[3] = 0ull;
+            sp[0] = Pq[0]; sp[1] = Pq[1]; sp[2] = Pq[2]; sp[3] = 0ull;
             if (a.cand8 != nullptr) {
                 // What the stage-3 seed solver makes of these bits when it takes the voxel -- the admissible atoms (support, dot, iso) as a
                 // byte list in ascending order -- is in this lane's registers already: it goes where the voxel's seed was (nobody reads
