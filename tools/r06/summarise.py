@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""gpurun_out/prof_<tag>/ (tools/r04/profile.sh) -> profiles/<tag>_kernel_stats_noddi_1M.txt, profiles/<tag>_pmc.txt and
+"""gpurun_out/prof_<tag>/ (tools/r06/profile.sh) -> profiles/<tag>_kernel_stats_noddi_1M.txt, profiles/<tag>_pmc.txt and
 profiles/pmc_traffic.json (per HIP-event group of bench.py: HBM bytes = 2 * FETCH_SIZE + WRITE_SIZE, VALU wave-instructions).
-usage: python tools/r04/summarise.py r04a"""
+usage: python tools/r06/summarise.py r06a
+Round 6: the exact DRAM byte counters of gfx950 (TCC_EA0_RDREQ_DRAM_32B / TCC_EA0_WRREQ_WRITE_DRAM_32B, 32-byte units) ride along; they agree with
+2 x FETCH_SIZE + WRITE_SIZE on every access pattern of profiles/r06_counter_calibration.txt, and the summary says so per kernel."""
 import collections, csv, glob, json, os, subprocess, sys
 tag = sys.argv[1]
 O = 'gpurun_out/prof_%s' % tag
@@ -38,6 +40,9 @@ groups = {'1': ['k_noddi<1,'], '2': ['k_noddi<4,', 'k_noddi<2,'], '3': ['k_noddi
 tr, valu, per_kernel = {}, {}, {}
 for k, c in acc.items():
     per_kernel[k] = {'bytes': int(2 * mean(c['FETCH_SIZE']) * 1024 + mean(c['WRITE_SIZE']) * 1024), 'valu_insts': mean(c['SQ_INSTS_VALU']),
+                     'bytes_read_dram_32B_counter': int(32 * mean(c['TCC_EA0_RDREQ_DRAM_32B_sum'])) if c.get('TCC_EA0_RDREQ_DRAM_32B_sum') else None,
+                     'bytes_written_dram_32B_counter': int(32 * mean(c['TCC_EA0_WRREQ_WRITE_DRAM_32B_sum'])) if c.get('TCC_EA0_WRREQ_WRITE_DRAM_32B_sum') else None,
+                     'l2_hit_rate': (mean(c['TCC_HIT_sum']) / (mean(c['TCC_HIT_sum']) + mean(c['TCC_MISS_sum']))) if c.get('TCC_HIT_sum') and (mean(c['TCC_HIT_sum']) + mean(c['TCC_MISS_sum'])) > 0 else None,
                      'valu_busy': mean(c['SQ_ACTIVE_INST_VALU']) / mean(c['SQ_WAVE_CYCLES']) if mean(c['SQ_WAVE_CYCLES']) else None,
                      'wait_any': mean(c['SQ_WAIT_ANY']) / mean(c['SQ_WAVE_CYCLES']) if mean(c['SQ_WAVE_CYCLES']) else None,
                      'mfma_f64_mops': mean(c['SQ_INSTS_VALU_MFMA_MOPS_F64'])}
@@ -54,9 +59,16 @@ from amico_amd import _capi
 # the identity of the kernels that were measured: bench.py reports these counter figures only next to a library built from the same sources
 t['csrc_hash'] = _capi.source_id()
 t.update({'_source': 'profiles/%s_pmc.txt (rocprofv3 --pmc, separate passes, NODDI 1 M voxels, mean per launch); git %s' % (tag, g('rev-parse', '--short', 'HEAD')),
-          '_correction': 'bytes = 2 * FETCH_SIZE[KiB] * 1024 (gfx950 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md HBM section) + WRITE_SIZE[KiB] * 1024 (calibrated round 4: a 1 GiB fill counts 1 048 580 KiB of WRITE_SIZE, a 1 GiB copy 524 302 KiB of FETCH_SIZE -- profiles/r04a_counter_calibration.txt)',
+          '_correction': 'bytes = 2 * FETCH_SIZE[KiB] * 1024 + WRITE_SIZE[KiB] * 1024.  CALIBRATED IN ROUND 6 ON EVERY ACCESS CLASS OF THIS LIBRARY (profiles/r06_counter_calibration.txt, tools/probes/counter_probe.hip, 2 GiB buffers, every byte touched once): '
+                         'wide 16-B and 8-B coalesced reads, one 8-B read per 64-B sector, one per 128-B line, one per 512 B, the certificates\' row gathers of a 176 x 512 B table block, global_load_lds dword / dwordx4 -- '
+                         'in ALL of them every DRAM read request is 128 bytes (TCC_EA0_RDREQ_128B = TCC_EA0_RDREQ), FETCH_SIZE tallies it at 64, and the exact counter TCC_EA0_RDREQ_DRAM_32B x 32 equals 2 x FETCH_SIZE to four digits: '
+                         'a lone 8-byte gather moves a 128-byte line (16 x its useful bytes).  WRITE_SIZE is exact: 64-B requests for full sectors, 32-B requests for partial ones (an 8-byte scattered store costs 32 bytes).  '
+                         'per kernel: bytes_read_dram_32B_counter / bytes_written_dram_32B_counter = the exact counters of the same build, beside `bytes`',
           '_groups': 'keys = which of amx_last_kernel_ms: 1-3 stage kernels (incl. their re-run kernels), 5-7 GEMM + seed solver + Gram certificate ahead of stage 1 / 2 / 3, 8 / 9 = k_nnls_seed<1> / k_lasso_seed alone (already contained in 5 / 6)',
           'voxels_per_launch': 1000000, 'stage_bytes_per_launch': tr, 'stage_valu_insts_per_launch': valu, 'kernels': per_kernel})
+exact = sum((v.get('bytes_read_dram_32B_counter') or 0) + (v.get('bytes_written_dram_32B_counter') or 0) for v in per_kernel.values())
+t['bytes_whole_fit_exact_dram_counters'] = exact or None
 json.dump(t, open('profiles/pmc_traffic.json', 'w'), indent=2)
+print('exact DRAM counters, all kernels of a fit: %.3f GB' % (exact / 1e9))
 print('bytes per fit %.3f GB' % (sum(v for k, v in tr.items() if k not in ('8', '9')) / 1e9), {k: round(v / 1e9, 3) for k, v in tr.items()})
 print('VALU wave-instructions per voxel', {k: round(v / 1e6) for k, v in valu.items()})

@@ -40,7 +40,7 @@ for key, name, cmd in (('fw', 'freewater_2M', '--model freewater --voxels 200000
 out = [head_stamp().rstrip(), '# rocprofv3 --kernel-trace --pmc <set> --output-format csv -- python bench.py --model {freewater --voxels 2000000 | sandi --voxels 1000000 | czb --voxels 500000 | lut} '
        '--steps 2 --warmup 1; separate passes (never combined with other trace domains); mean per launch',
        '# FETCH_SIZE / WRITE_SIZE in KiB (FETCH_SIZE under-reports wide coalesced reads 2x on gfx950); SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* in quad-cycles']
-for m, pats in (('freewater', ['k_freewater', 'k_fw_project']), ('sandi', ['k_sandi']), ('czb', ['k_czb']), ('lut', ['k_lut_resample'])):
+for m, pats in (('freewater', ['k_freewater', 'k_fw_project']), ('sandi', ['k_sandi']), ('czb', ['k_czb']), ('lut', ['k_lut_resample']), ('prep', ['k_prep_', 'k_mean_b0', 'k_scatter', 'k_dti_dirs'])):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for fn in glob.glob('%s/pmc_%s_*/*/*_counter_collection.csv' % (O, m)):
         for r in csv.DictReader(open(fn)):
@@ -58,11 +58,13 @@ small = {}
 for m, pats, n in (('freewater', ('k_fw_project', 'k_freewater'), 2000000), ('sandi', ('k_sandi',), 1000000), ('czb', ('k_czb',), 500000)):
     # a fit may be several kernels (FreeWater: projection + solver): per-launch means per kernel, summed over the kernels
     per = collections.defaultdict(lambda: collections.defaultdict(list))
+    names = set()                                       # the kernels that RAN (the summary listed its search prefixes)
     for fn in glob.glob('%s/pmc_%s_*/*/*_counter_collection.csv' % (O, m)):
         for r in csv.DictReader(open(fn)):
             for pat in pats:
                 if pat in r['Kernel_Name']:
                     per[pat][r['Counter_Name']].append(float(r['Counter_Value']))
+                    names.add(r['Kernel_Name'].replace('void ', '').replace('amx::', '').split('(')[0])
     mean = lambda v: sum(v) / len(v)
     tot = collections.defaultdict(float)
     for pat in per:
@@ -70,7 +72,8 @@ for m, pats, n in (('freewater', ('k_fw_project', 'k_freewater'), 2000000), ('sa
             tot[c] += mean(v)
     if 'FETCH_SIZE' in tot and 'WRITE_SIZE' in tot:
         small[m] = {'voxels_per_launch': n, 'bytes_per_voxel_measured': (2 * tot['FETCH_SIZE'] + tot['WRITE_SIZE']) * 1024 / n,
-                    'valu_insts_per_voxel': tot['SQ_INSTS_VALU'] / n, 'kernels': sorted(per),
+                    'valu_insts_per_voxel': tot['SQ_INSTS_VALU'] / n, 'kernels': sorted(names),
+                    'bytes_per_voxel_exact_dram_counters': (32 * (tot.get('TCC_EA0_RDREQ_DRAM_32B_sum', 0) + tot.get('TCC_EA0_WRREQ_WRITE_DRAM_32B_sum', 0)) / n) if 'TCC_EA0_RDREQ_DRAM_32B_sum' in tot else None,
                     'mfma_busy_quad_cycles': tot.get('SQ_VALU_MFMA_BUSY_CYCLES'), 'mfma_f64_mops': tot.get('SQ_INSTS_VALU_MFMA_MOPS_F64'),
                     '_source': 'profiles/%s_pmc_small.txt; bytes = 2 * FETCH_SIZE + WRITE_SIZE (KiB), see _correction' % tag}
 try:
