@@ -271,7 +271,9 @@ int amx_ctx_create(int device, amx_ctx **out)
         e = getenv("AMX_NO_GCERT_WIDE");
         ctx->opt_no_gcert_wide = e && *e && *e != '0';
         e = getenv("AMX_RESCUE_FROM");
-        if (e && *e) ctx->opt_rescue_from = atoll(e);
+        if (e && *e) { ctx->opt_rescue_from = atoll(e); ctx->opt_rescue_from_set = true; }
+        e = getenv("AMX_GCERT2_THIRD_MIN");
+        if (e && *e) ctx->opt_gcert2_third_min = atoi(e) < 0 ? 0 : atoi(e);
         e = getenv("AMX_NO_SCREEN");
         ctx->opt_no_screen = e && *e && *e != '0';
         e = getenv("AMX_SEED_STAGES");
@@ -393,6 +395,7 @@ int amx_lut_upload_noddi(amx_ctx *ctx, const float *wm, const float *iso, const 
     // Are the rows outside stage 2 (the b0 volumes) exactly 1.0 in every atom, as resample_kernel leaves them (lut.pyx:298, 305)?
     // Then the stage-2 products of an unclipped voxel derive from the stage-1 table (k_noddi_gemm); otherwise every voxel takes
     // the exact pass.
+    lut->n_dwi = dwi_count;
     lut->s2_derive = is_exvivo ? 0 : 1;
     for (int i = 0; i < nS && lut->s2_derive; i++) {
         if (rowdwi[i]) { if (!(iso[i] > 1e-30f) || !(iso[i] <= 3.0e38f)) lut->s2_derive = 0; continue; }
@@ -749,6 +752,7 @@ static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
     HIPCHK(ctx, hipSetDevice(ctx->device));
     Plan pl; int rc;
     bool joined1 = false, fork2 = false;
+    ctx->call_vox = ctx->in_host_fit ? ctx->host_total_vox : n_vox;
     const bool seeds = lut->basis_S != nullptr && lut->gram != nullptr && !ctx->opt_no_seed &&
                        (ctx->in_host_fit ? ctx->host_total_vox : n_vox) >= ctx->opt_seed_min_voxels;   // (batches of one host call all take the same path: bit-identical to the one-shot call)
     const int gemm_ks = seeds ? amx_gemm_ksteps(lut) : 0;                        // 0: no table kernels for this shape (seeds certified on the true residual only)

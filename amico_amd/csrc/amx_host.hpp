@@ -33,6 +33,7 @@ struct amx_ctx {
     int *status_h = nullptr;       // pinned mirror (+16 words: copy of the misc counters)
     bool profiling = false;
     int64_t host_total_vox = 0;    // voxels of the whole host-buffer call while its batches are enqueued
+    int64_t call_vox = 0;          // voxels of the call being enqueued (the whole host-buffer call for its batches): size-dependent path choices made below noddi_fit_dev
     int64_t call_total_vox = 0;    // amx_set_call_voxels: the host-buffer calls on this ctx are shards of a call of this many voxels (0: they are the call)
     bool in_host_fit = false;      // the host-buffer entry points report progress per batch themselves
     hipEvent_t ev[kEv];
@@ -88,6 +89,8 @@ struct amx_ctx {
     bool opt_no_chunk_order = false; // AMX_NO_CHUNK_ORDER=1: the chunks of the second plan stay in orientation order (default: longest first)
     int opt_seed2_maxatoms = 0;     // AMX_SEED2_MAXATOMS=n: atoms at which the LASSO seed solver gives a voxel up (default 20, 26 with a third certificate pass; <= 30)
     int opt_gcert_repair = -1;      // AMX_GCERT_REPAIR=0 / 1: never / always the NNLS certificates' second look at a mendable seed (default: where the tile is read from L2)
+    int opt_gcert2_third_min = 48;  // AMX_GCERT2_THIRD_MIN: list entries a chunk must hold for the third LASSO certificate pass to work on it (tiles in LDS; 0 with global tiles)
+    bool opt_rescue_from_set = false;   // AMX_RESCUE_FROM given: the caller's threshold alone decides
     int opt_gcert2_third = -1;      // AMX_GCERT2_THIRD=0 / 1: never / always a third LASSO certificate pass (default: where the tile is read from L2)
     bool opt_no_gcert_wide = false; // AMX_NO_GCERT_WIDE=1: no second Gram-certificate pass for LASSO supports of 13 .. 16 atoms
     int64_t opt_rescue_from = 2000000;   // AMX_RESCUE_FROM=n: calls of n voxels and more run the rescue pass of the NNLS certificates (k_nnls_gcert<., true>)
@@ -134,6 +137,7 @@ struct amx_lut {
     int model = 0;                 // 1 NODDI, 2 FreeWater, 3 SANDI, 4 CylinderZeppelinBall
     int nS = 0, ldA = 0, n_atoms = 0, ndirs = 0, tile_stride = 0;
     int n_wm = 0, is_exvivo = 0;   // NODDI
+    int n_dwi = 0;                 // NODDI: rows of the stage-2 problem (scheme.dwi_idx; the single-b0 rule may add one)
     int n_perp = 0, n_iso = 0;     // FreeWater
     int n_rs = 0, n_in = 0, n_isos = 0;   // SANDI
     void *tiles = nullptr;
@@ -267,7 +271,7 @@ struct Plan {
     static constexpr int kFeedSetsN = 7;
 };
 enum { FEED_SEED1 = 0, FEED_SEED2, FEED_SEED3, FEED_GEMM, FEED_CERT1, FEED_CERT2, FEED_CERT3, kFeedSets };
-enum { ZC_CERT1 = 0, ZC_RESC1, ZC_CLIP, ZC_CERT2, ZC_CERT2W, ZC_CERT2W3, ZC_CERT3, ZC_RESC3, kZCounts };
+enum { ZC_CERT1 = 0, ZC_RESC1, ZC_CLIP, ZC_CERT2, ZC_CERT2W, ZC_CERT2W3, ZC_CERT3, ZC_RESC3, ZC_CERT2Q, kZCounts };   // ZC_CERT2Q: per chunk, what the second LASSO certificate pass leaves that a third could settle
 static_assert(kFeedSets == Plan::kFeedSetsN, "Plan::zcount sits behind the feed sets");
 
 // AMX_DEBUG=1: synchronise after every launch and trace progress on stderr
@@ -295,7 +299,8 @@ int amx_launch_noddi_gemm(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs
 int amx_launch_noddi_s2prep(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s);
 int amx_gemm_ksteps(const amx_lut *lut);   // K-steps of the table kernels for this dictionary (25 / 40), 0 = shape not supported
 int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const amx::NoddiArgs &a, const Plan &pl, hipStream_t s, bool wide);
-bool amx_gcert2_third(const amx_ctx *ctx, const amx_lut *lut, bool wide);   // a third LASSO certificate pass for this dictionary? (amx_seed.hip)
+bool amx_gcert2_third(const amx_ctx *ctx, const amx_lut *lut, bool wide);
+int amx_gcert2_third_min_items(const amx_ctx *ctx, const amx_lut *lut);   // list entries a chunk must hold for that pass to work on it   // a third LASSO certificate pass for this dictionary? (amx_seed.hip)
 size_t amx_gcert2_leftover_offset(const Plan &pl, bool wide, bool third);      // which half of ctx->rlist the LASSO certificate passes end in (amx_seed.hip)
 const int *amx_gcert2_leftover_counts(const Plan &pl, bool wide, bool third);  // ... and the per-chunk counts of those lists (Plan::zcount)
 static inline size_t amx_rlist_half(const Plan &pl) { return (size_t)pl.n + pl.max_schunks + 64; }   // ints per left-over list + counts

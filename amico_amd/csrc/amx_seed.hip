@@ -211,11 +211,24 @@ const int *amx_gcert2_leftover_counts(const Plan &pl, bool wide, bool third)
 // A third pass (supports of 19 .. 24 atoms, the triangle mostly in scratch) pays where a left-over voxel is expensive: shapes whose
 // wavefront-per-voxel kernels read their tile from L2 (a 288-volume protocol leaves 6.8 % of the voxels after two passes: 6.5 of that
 // fit's 24 ms went to k_noddi<4, .., GT>).  At 99 volumes it is a wash (round 3: 10.34 against 10.33 ms).  AMX_GCERT2_THIRD=0 / 1 forces.
+// Round 6: the pass is launched for EVERY shape and decides per chunk (Gcert2Args::min_items): a chunk that still holds a block's worth of
+// such supports is worth its tables, one that holds a dozen is handed on as it is.  AMX_GCERT2_THIRD=0: never (the round-5 default for tiles in
+// LDS), 1: every chunk whatever it holds (the round-5 behaviour for global tiles, still their default).
+// lambda1 is fixed while ||A2'y2|| grows with the number of stage-2 rows: beyond the default protocol's 90 the LASSO supports are denser (105
+// volumes = 100 rows: 41 000 of 1 M voxels beyond 18 atoms, against 6 300) -- there the pass runs too, and decides per chunk.
 bool amx_gcert2_third(const amx_ctx *ctx, const amx_lut *lut, bool wide)
 {
     if (!wide || !(kGcert2Wide3 > kGcert2Wide)) return false;
     if (ctx->opt_gcert2_third >= 0) return ctx->opt_gcert2_third != 0;
-    return amx_noddi_tile_global(lut->nS, lut->ldA, lut->n_atoms);
+    // (... from 600 000 voxels: the pass's kernel holds its 24 x 24 triangle mostly in scratch -- 2.6 KB per lane, beyond what the runtime keeps
+    //  allocated per queue: every launch pays ~0.25 ms for its scratch, whatever its chunks then decide; 105 volumes, 300 000 voxels 3.83 -> 3.99 ms
+    //  with it, 1 M voxels 8.58 -> 8.0 - 8.3)
+    return amx_noddi_tile_global(lut->nS, lut->ldA, lut->n_atoms) || (lut->n_dwi > 95 && ctx->call_vox >= 600000);
+}
+int amx_gcert2_third_min_items(const amx_ctx *ctx, const amx_lut *lut)
+{
+    if (ctx->opt_gcert2_third == 1 || amx_noddi_tile_global(lut->nS, lut->ldA, lut->n_atoms)) return 0;
+    return ctx->opt_gcert2_third_min;
 }
 
 // Gram-space certificates of the LASSO seeds (k_lasso_gcert): support bits of the voxels it settles, left-over lists for k_noddi<4>
@@ -248,6 +261,7 @@ int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a
         // second pass: supports of 12 .. 18 atoms from the left-over lists; its own left-overs in the second half of the buffer
         g.rlist_in = g.rlist; g.rcount_in = g.rcount;
         g.rlist = (int *)ctx->rlist.p + amx_rlist_half(pl); g.rcount = pl.zcount(ZC_CERT2W);
+        if (third) { g.qcount = pl.zcount(ZC_CERT2Q); g.q_hi = kGcert2Wide3; }
 #ifdef AMX_STATS
         g.stats = a.c.status + ST_SEED + 48;
 #endif
@@ -260,6 +274,8 @@ int amx_launch_noddi_gcert2(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a
             // third pass: supports beyond the second pass from the second pass's left-overs, back into the first half of the buffer
             g.rlist_in = g.rlist; g.rcount_in = g.rcount;
             g.rlist = (int *)ctx->rlist.p; g.rcount = pl.zcount(ZC_CERT2W3);
+            g.min_items = amx_gcert2_third_min_items(ctx, lut);
+            g.qcount_in = g.min_items > 0 ? pl.zcount(ZC_CERT2Q) : nullptr; g.qcount = nullptr;
 #ifdef AMX_STATS
             g.stats = nullptr;
 #endif
@@ -328,7 +344,11 @@ int amx_launch_noddi_gcert(amx_ctx *ctx, const amx_lut *lut, const NoddiArgs &a,
     //  host and device entry points settle the same voxels with the same arithmetic)
     // (shapes whose tile does not fit the LDS -- an HCP-style protocol -- run it at every size: a left-over voxel costs their
     //  wavefront-per-voxel kernels ten times what it costs the LDS variants, and the lane that corrects a support reads 8 atoms, not the tile)
+    // (round 6: ... and protocols of more than 128 volumes, whose wavefront-per-voxel kernels hold four signal rows per lane -- a left-over voxel
+    //  costs them 37 ns against 14 at 99 volumes: 150 volumes, 1 M voxels 11.23 -> 10.65 ms with the pass, stage-3 left-overs 38 219 -> 6 429;
+    //  at 99 - 105 volumes it still loses below 2 M voxels, SNR 50 included: profiles/r06_protocols_ab.txt)
     if ((ctx->in_host_fit ? ctx->host_total_vox : (int64_t)pl.n) >= (lut->is_exvivo ? ctx->opt_rescue_from / 4 : ctx->opt_rescue_from) ||
+        (lut->nS > 128 && ctx->opt_rescue_from > 0 && !ctx->opt_rescue_from_set) ||
         amx_noddi_tile_global(lut->nS, lut->ldA, lut->n_atoms)) {
         // second pass (large calls: below ~2 M voxels the launch costs more than the wavefront-per-voxel kernel saves -- 1 M voxels
         // 8.08 -> 8.24 ms with it, 4 M 24.99 -> 24.38): the supports refused for conditioning, corrected with the signal itself;

@@ -2075,6 +2075,10 @@ struct Gcert2Args {
     const int *rlist_in, *rcount_in;   // WIDE pass: the left-over lists of the first pass
     double *xdbg;
     int *stats;
+    int min_items;                     // third pass: a chunk with fewer CANDIDATES (below) is handed on as it is (round 6: the pass decides per chunk)
+    int *qcount;                       // second pass, out: per chunk, the voxels it leaves whose complete seed holds MS + 1 .. q_hi atoms (what a third pass could settle)
+    const int *qcount_in;              // third pass, in: that count
+    int q_hi;
 };
 
 // WIDE = false: every voxel of the chunk, supports of up to 11 atoms, two wavefronts per SIMD.  WIDE = true: second pass over the
@@ -2108,6 +2112,15 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
     const Chunk ck = a.schunks[cid];
     const int n_items = WIDE ? a.rcount_in[cid] : ck.count;
     if (WIDE && n_items == 0) return;
+    if (WIDE && a.qcount_in != nullptr && a.qcount_in[cid] < a.min_items) {
+        // not worth this chunk's tables and a 256-register wavefront's time: the list goes on to the next consumer unchanged.  The third pass
+        // pays where a chunk still holds a block's worth of supports it can hold, 19 .. 24 atoms (counted by the second pass) -- a 105-volume
+        // protocol: 80 per chunk of a 1 M-voxel call, 8.58 -> 8.0 ms -- and costs 0.3 - 0.4 ms where it does not: a dozen per chunk on the
+        // default protocol, and at 150 volumes, where most of what is left holds MORE than 24 atoms (profiles/r06_protocols_ab.txt)
+        for (int e = threadIdx.x; e < n_items; e += blockDim.x) a.rlist[ck.start + e] = a.rlist_in[ck.start + e];
+        if (threadIdx.x == 0) atomicAdd(&a.rcount[cid], n_items);
+        return;
+    }
     const double *__restrict__ Sg = a.Sb + (size_t)ck.dir * n_wm * KD;
     const double *__restrict__ Gd = a.gram + (size_t)ck.dir * a.n_atoms * a.ldG;
     stage_rows<KD, LD>(Sl, Sg, n_wm, KD);
@@ -2292,6 +2305,10 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : AMX_GCERT2_OCC) k_lasso_gcert(
         GC_PH(3);
         const bool cert = good && !viol;
         if (valid) a.done[pos] = cert ? 1 : 0;
+        if (WIDE && a.qcount != nullptr) {
+            const unsigned long long qm = __ballot(valid && !cert && flag == 0ull && cnt > MS && cnt <= a.q_hi);
+            if (qm != 0ull && lane == 0) atomicAdd(&a.qcount[cid], __builtin_popcountll(qm));
+        }
         {
             const unsigned long long rm = __ballot(valid && !cert);
             if (rm != 0ull) {
