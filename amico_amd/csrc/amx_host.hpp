@@ -89,7 +89,7 @@ struct amx_ctx {
     bool opt_no_chunk_order = false; // AMX_NO_CHUNK_ORDER=1: the chunks of the second plan stay in orientation order (default: longest first)
     int opt_seed2_maxatoms = 0;     // AMX_SEED2_MAXATOMS=n: atoms at which the LASSO seed solver gives a voxel up (default 20, 26 with a third certificate pass; <= 30)
     int opt_gcert_repair = -1;      // AMX_GCERT_REPAIR=0 / 1: never / always the NNLS certificates' second look at a mendable seed (default: where the tile is read from L2)
-    int opt_gcert2_third_min = 48;  // AMX_GCERT2_THIRD_MIN: list entries a chunk must hold for the third LASSO certificate pass to work on it (tiles in LDS; 0 with global tiles)
+    int opt_gcert2_third_min = 16;  // AMX_GCERT2_THIRD_MIN: list entries a chunk must hold for the third LASSO certificate pass to work on it (tiles in LDS; 0 with global tiles)
     bool opt_rescue_from_set = false;   // AMX_RESCUE_FROM given: the caller's threshold alone decides
     int opt_gcert2_third = -1;      // AMX_GCERT2_THIRD=0 / 1: never / always a third LASSO certificate pass (default: where the tile is read from L2)
     bool opt_no_gcert_wide = false; // AMX_NO_GCERT_WIDE=1: no second Gram-certificate pass for LASSO supports of 13 .. 16 atoms

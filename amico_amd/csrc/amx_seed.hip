@@ -220,9 +220,9 @@ bool amx_gcert2_third(const amx_ctx *ctx, const amx_lut *lut, bool wide)
 {
     if (!wide || !(kGcert2Wide3 > kGcert2Wide)) return false;
     if (ctx->opt_gcert2_third >= 0) return ctx->opt_gcert2_third != 0;
-    // (... from 600 000 voxels: the pass's kernel holds its 24 x 24 triangle mostly in scratch -- 2.6 KB per lane, beyond what the runtime keeps
-    //  allocated per queue: every launch pays ~0.25 ms for its scratch, whatever its chunks then decide; 105 volumes, 300 000 voxels 3.83 -> 3.99 ms
-    //  with it, 1 M voxels 8.58 -> 8.0 - 8.3)
+    // (... from 600 000 voxels: the pass's kernel holds its 24 x 24 triangle mostly in scratch (2.6 KB per lane) and a block costs it ~0.4 ms whatever
+    //  the call's size -- 105 volumes, tools/r06/a12.sh: 300 000 voxels 3.58 ms without, 3.70 with it (0.50 ms of certificates to save 0.38 of
+    //  left-over kernel); 1 M voxels 8.59 -> 8.01 (0.72 to save 1.27))
     return amx_noddi_tile_global(lut->nS, lut->ldA, lut->n_atoms) || (lut->n_dwi > 95 && ctx->call_vox >= 600000);
 }
 int amx_gcert2_third_min_items(const amx_ctx *ctx, const amx_lut *lut)
