@@ -320,6 +320,7 @@ void amx_ctx_destroy(amx_ctx *ctx)
     if (ctx->status_d) hipFree(ctx->status_d);
     if (ctx->status_h) hipHostFree(ctx->status_h);
     for (int k = 0; k < kEv; k++) (void)hipEventDestroy(ctx->ev[k]);
+    if (ctx->up_ev) (void)hipEventDestroy(ctx->up_ev);
     if (ctx->hs) { (void)hipStreamDestroy(ctx->hs); (void)hipStreamDestroy(ctx->hs2); for (hipEvent_t e : ctx->hev) (void)hipEventDestroy(e); }
     for (int w = 0; w < 2; w++) if (ctx->fork_s[w]) { (void)hipStreamDestroy(ctx->fork_s[w]); for (hipEvent_t e : ctx->fork_ev[w]) if (e) (void)hipEventDestroy(e); }
     delete ctx->stage;             // (joins the host threads of the float32 transport)
@@ -1330,6 +1331,7 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
     if (dirs && (rc = ensure(ctx, ctx->hdirs, (size_t)cap * 3 * sizeof(double)))) return rc;
     for (HostOut &o : outs)
         if (o.on && (rc = ensure(ctx, *o.buf, (size_t)n_vox * o.cols * sizeof(double)))) return rc;
+    if (!ctx->up_ev) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->up_ev, hipEventDisableTiming));
     if (!ctx->hs) {
         HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->hs, hipStreamNonBlocking));
         HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->hs2, hipStreamNonBlocking));
@@ -1387,9 +1389,10 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
             report(done_before[b]);                                  // batches 0 .. c-3 are complete
         }
         if (two_streams) { s = (c & 1) ? ctx->hs2 : ctx->hs; if (c) ctx->swap_work(); }
-        // (the uploads below are blocking hipMemcpy calls from pageable memory on the null stream; the consumers run on the
-        //  non-blocking streams hs / hs2 without an event in between: this relies on hipMemcpy returning only after the data
-        //  has landed in device memory, which holds for pageable host-to-device copies on ROCm)
+        // (the uploads below are blocking hipMemcpy calls on the null stream -- from the caller's pageable memory, or from the pinned slots of the
+        //  float32 transport -- and the consumers run on the non-blocking streams hs / hs2: hipMemcpy returns when the data has landed for pageable
+        //  sources; for the pinned ones that is the runtime's behaviour, not its contract, so the batch's stream WAITS for an event recorded behind
+        //  the batch's last copy (round 6, ADVICE r05: two API calls, ~3 us per batch))
         double *yb = (double *)ctx->hy.p + (size_t)b * kHostBatch * nS;
         double *db = dirs ? (double *)ctx->hdirs.p + (size_t)b * kHostBatch * 3 : nullptr;
         const double tr2 = trace ? wall() : 0.0;
@@ -1423,6 +1426,7 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
             if (!sent) HIPCHK(ctx, hipMemcpy(yb, y + (size_t)off * nS, (size_t)cnt * nS * sizeof(double), hipMemcpyHostToDevice));
         }
         if (dirs) HIPCHK(ctx, hipMemcpy(db, dirs + (size_t)off * 3, (size_t)cnt * 3 * sizeof(double), hipMemcpyHostToDevice));
+        if (ctx->up_ev) { HIPCHK(ctx, hipEventRecord(ctx->up_ev, nullptr)); HIPCHK(ctx, hipStreamWaitEvent(s, ctx->up_ev, 0)); }
         const double tr3 = trace ? wall() : 0.0;
         // the copy above took a while: has the previous batch finished meanwhile? (a query, never a wait)
         // (batches c-1 and c-2 run on different streams: both must have fired before batch c-1's count is reported)

@@ -54,6 +54,7 @@ struct amx_ctx {
     hipStream_t hs = nullptr;      // non-blocking compute streams of the chunked host entry points: batches alternate
     hipStream_t hs2 = nullptr;     // between the two, so the tail of one batch's kernels is filled by the next batch's
     hipEvent_t hev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t up_ev = nullptr;    // recorded on the null stream behind a batch's uploads; the batch's compute stream waits for it
     // second workspace set for the batch in flight on the other stream (swap_work exchanges it with the named buffers)
     DevBuf alt[22];
     void swap_work()

@@ -109,14 +109,24 @@ def _verified_fit(fit):
     """``fit`` with the dictionary cache checked BEHIND the solver: the reference re-reads KERNELS on every fit (models.pyx:840-847), here
     the device dictionary is reused when every byte of KERNELS is what was uploaded -- a 1.2 ms digest of 28 MB per call that need not
     sit in front of a 12.6 ms fit.  A fit that ran on a stale dictionary (KERNELS edited in place since the upload) is discarded and
-    run again on the rebuilt one, so the caller never sees it."""
+    run again on the rebuilt one, so the caller never sees its result -- but a progress callback registered on the context does see
+    the discarded fit's ticks too (the fit runs twice in that case), and an exception of the stale fit is only believed once the
+    digest has confirmed the dictionary (otherwise: upload again, fit again)."""
     import functools
 
     @functools.wraps(fit)
     def wrapper(self, evaluation):
         self._lut_pending = None            # None: inside a verified fit, nothing started yet (False / absent: outside)
         try:
-            out = fit(self, evaluation)
+            try:
+                out = fit(self, evaluation)
+            except Exception:
+                # a fit on a STALE dictionary may also fail (shapes still match, values do not): ask the digest before believing the error
+                pend, self._lut_pending = self._lut_pending, False
+                if isinstance(pend, _PendingFingerprint) and not pend.matches():
+                    self._lut_cache = {}
+                    return fit(self, evaluation)
+                raise
             pend, self._lut_pending = self._lut_pending, False
             if pend is not None and not pend.matches():
                 self._lut_cache = {}        # stale: upload again (every context), fit again

@@ -98,7 +98,10 @@ int amx_dir_to_lut_idx(amx_ctx *ctx, const amx_lut *lut, const double *dirs, int
                        int32_t *out_idx);
 
 /* ---- model.fit hot loops, HOST buffers in / out (H2D + kernels + D2H, blocking; the copies of large
- * inputs overlap with the solver, in batches).
+ * inputs overlap with the solver, in batches -- and the maps of finished batches go home while later batches are still being solved: when a
+ * call returns an error (AMX_E_DIR_OOB from a later batch, a HIP error) the output arrays may already hold the results of the batches before it.
+ * The reference raises before it returns anything (models.pyx:904 inside the loop that fills `estimates`, which is then lost with the
+ * exception); the Python mirror does the same: its wrappers raise and the arrays are unreachable.
  * y f64[n_vox][nS] (evaluation.y, core.py:451-452), dirs f64[n_vox][3] (evaluation.DIRs).
  * lambda1 >= 0, lambda2 >= 0 like cyspams' lasso (lambda2 = 0 runs the QR solver in A-space).  */
 
