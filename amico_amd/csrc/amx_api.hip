@@ -576,6 +576,7 @@ int amx_sync_status(amx_ctx *ctx, void *hip_stream)
     if (amx_debug()) fprintf(stderr, "[amx] LASSO Gram certificate kcycles (decode | gather+factor+solve | screening | exact duals | output): %d %d %d %d %d\n",
                              st[ST_SEED + 70], st[ST_SEED + 71], st[ST_SEED + 72], st[ST_SEED + 73], st[ST_SEED + 74]);
     if (amx_debug()) fprintf(stderr, "[amx] stage-3 seed solver kcycles: take %d solve+drop %d residual %d scan %d append %d store %d\n", st[ST_SEED + 54], st[ST_SEED + 55], st[ST_SEED + 56], st[ST_SEED + 57], st[ST_SEED + 58], st[ST_SEED + 59]);
+    if (amx_debug() && st[ST_GRAM + 1] > 0) fprintf(stderr, "[amx] k_noddi_lasso_big: %d voxels, %.1f pivoting steps per voxel\n", st[ST_GRAM + 1], (double)st[ST_ITERS + 1] / st[ST_GRAM + 1]);
     {
         // first offending voxel and what it held, as the kernels' one 64-bit atomicMin left them
         int *sth = ctx->status_h;

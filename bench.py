@@ -989,6 +989,24 @@ def main():
                 # at SNR 30 -- correctness does not depend on them, the rate does
                 other['noddi_snr10'] = noddi_other_protocol(ctx, ((700.0, 30), (2000.0, 60)), 9, min(n, 1_000_000), 5, 2, per_byte, snr=10.0)
                 other['noddi_snr50'] = noddi_other_protocol(ctx, ((700.0, 30), (2000.0, 60)), 9, min(n, 1_000_000), 5, 2, per_byte, snr=50.0)
+                # lambda1 = 0 (a pure ridge: a legal set_solver): dense LASSO optima, beyond the 64 atoms the fast kernels hold -- AMX_E_OVERFLOW until
+                # round 5, now k_noddi_lasso_big (csrc/amx_big.hip: block principal pivoting, a workgroup per voxel): slow, exact
+                try:
+                    nb_ = min(n, 100_000)
+                    estb = torch.zeros((nb_, 3), dtype=torch.float64, device=dev)
+
+                    def fit_b():
+                        ctx.check(L.amx_noddi_fit_device(ctx._h, lut._h, y.data_ptr(), d.data_ptr(), nb_, 0.0, 1e-3, 0, estb.data_ptr(), None, None, None, stream))
+                    fit_b(); ctx.sync(stream)
+                    t1 = time.perf_counter(); fit_b(); ctx.sync(stream); tb_ = time.perf_counter() - t1
+                    pk_ = np.arange(0, nb_, max(1, nb_ // 2000))
+                    refb = oracle.noddi_fit(np.ascontiguousarray(y_h[pk_]), np.ascontiguousarray(d_h[pk_]), K, htable, scheme.dwi_idx, lambda1=0.0, lambda2=1e-3, nthreads=cores)
+                    other['noddi_lambda1_0'] = {'metric': 'voxels/sec, NODDI fit with lambda1 = 0 (dense LASSO optimum: k_noddi_lasso_big for every voxel)', 'value': nb_ / tb_, 'unit': 'voxels/s',
+                                                'voxels': nb_, 'ms_per_step': 1e3 * tb_, 'kernels_launched': ctx.last_path(), 'solver_stats': ctx.last_stats(),
+                                                'parity': {'sample_voxels': int(len(pk_)), 'max_abs_dmap': float(np.abs(estb.cpu().numpy()[pk_] - refb['estimates']).max())}}
+                    del estb
+                except Exception as e:                                  # (an extra leg must not cost the line)
+                    other['noddi_lambda1_0'] = {'error': repr(e)}
                 # an HCP-style acquisition (18 b0 + 3 x 90 directions = 288 volumes): the most common public NODDI data
                 other['noddi_288vol'] = noddi_other_protocol(ctx, ((1000.0, 90), (2000.0, 90), (3000.0, 90)), 18, min(n, 1_000_000), 5, 2, per_byte)
             if not args.no_cpu_baseline:
