@@ -290,6 +290,8 @@ int amx_ctx_create(int device, amx_ctx **out)
             sscanf(e, "%lld,%lld,%lld", &c[0], &c[1], &c[2]);
             for (int k = 0; k < 3; k++) ctx->opt_left_small[k] = c[k] < 0 ? 0 : c[k];
         }
+        e = getenv("AMX_LEFT_NR4_NW8");
+        ctx->opt_no_nr4_nw8 = e && *e == '0';
         e = getenv("AMX_BIG_ALL");
         ctx->opt_no_big_all = e && *e == '0';
         e = getenv("AMX_FORK");

@@ -127,6 +127,7 @@ struct amx_ctx {
     // no screening table) loses at every size (1.460 / 1.905 / 2.511 / ...): off.  The gain is ~20 us per kernel, not the ~100 the "one round of
     // workgroups instead of two" arithmetic promised: a left-over kernel lasts as long as its longest voxel's Lawson-Hanson, whatever the rounds.
     long long opt_left_small[3] = {150000, 0, 600000};
+    bool opt_no_nr4_nw8 = false;    // AMX_LEFT_NR4_NW8=0: protocols of 129 .. 256 volumes run their left-over lists on the round-5 builds (12 / 16 wavefronts, spilling)
     bool opt_no_big_all = false;    // AMX_BIG_ALL=0: lambda1 = 0 fits take the fast kernels first and reach k_noddi_lasso_big through the overflow lists
     bool side_launch = false;       // transient: the launch being enqueued goes to the side stream (launch_pair picks its own overflow lists)
     std::string path;               // kernels of the last fit enqueued on this ctx, in launch order (amx_last_path)

@@ -27,6 +27,16 @@ static int go(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
         return launch_pair<4>(ctx, a, pl, s, k_noddi<1, NR, NQ, 12, 4, false, float>, k_noddi<1, NR, NQ, MB, 1, true>,
                                [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, 12, false, false) + scr; },
                                fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, false), 0, 2, "k_noddi<1> (left-overs of k_nnls_gcert<1>; small-call build: two workgroups per CU)");
+    // Protocols of 129 .. 256 volumes (four signal rows per lane; the fp64 tile of 150 x 145 does not fit the LDS): the left-over lists used to
+    // fall through to the 16-wavefront build below -- 128 registers, 203 of them spilled.  Eight wavefronts (two per SIMD, 256 registers: no
+    // spills) on the float32 tile (round 6; AMX_LEFT_NR4_NW8=0: the old build)
+    if constexpr (NR == 4) {
+        if (a.rlist != nullptr && !ctx->opt_no_nr4_nw8 && fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 8, 12, false, false) + scr <= kLdsPerCU &&
+            !(fit_lds_bytes<double>(a.c.nS, a.c.ldA, NR, NQ, 12, 12, false, false) + scr <= kLdsPerCU))
+            return launch_pair<8>(ctx, a, pl, s, k_noddi<1, NR, NQ, 12, 8, false, float>, k_noddi<1, NR, NQ, MB, 1, true>,
+                                   [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, 12, false, false) + scr; },
+                                   fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, false), 0, 2, "k_noddi<1> (left-overs of k_nnls_gcert<1>; 8 wavefronts, float32 tile)");
+    }
     if (a.rlist != nullptr && fit_lds_bytes<double>(a.c.nS, a.c.ldA, NR, NQ, 12, 12, false, false) + scr <= kLdsPerCU && !ctx->opt_tile_f32)
         return launch_pair<12>(ctx, a, pl, s, k_noddi<1, NR, NQ, 12, 12, false, double>, k_noddi<1, NR, NQ, MB, 1, true>,
                                [&](int nw) { return fit_lds_bytes<double>(a.c.nS, a.c.ldA, NR, NQ, nw, 12, false, false) + scr; },

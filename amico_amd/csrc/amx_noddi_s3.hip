@@ -20,6 +20,14 @@ static int go(amx_ctx *ctx, NoddiArgs &a, const Plan &pl, hipStream_t s)
         return launch_pair<4>(ctx, a, pl, s, k_noddi<3, NR, NQ, MP, 4, false, float>, k_noddi<3, NR, NQ, MB, 1, true>,
                                [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MP, false, false) + scr; },
                                fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, false), 2, 6, "k_noddi<3> (left-overs; small-call build: two workgroups per CU)");
+    // protocols of 129 .. 256 volumes: eight wavefronts on the float32 tile instead of twelve with 697 spilled registers (amx_noddi_s1.hip)
+    if constexpr (NR == 4) {
+        if (a.rlist != nullptr && !ctx->opt_no_nr4_nw8 && fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 8, MP, false, false) + scr <= kLdsPerCU &&
+            !(fit_lds_bytes<double>(a.c.nS, a.c.ldA, NR, NQ, NW, MP, false, false) + scr <= kLdsPerCU))
+            return launch_pair<8>(ctx, a, pl, s, k_noddi<3, NR, NQ, MP, 8, false, float>, k_noddi<3, NR, NQ, MB, 1, true>,
+                                   [&](int nw) { return fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, nw, MP, false, false) + scr; },
+                                   fit_lds_bytes<float>(a.c.nS, a.c.ldA, NR, NQ, 1, MB, false, false), 2, 6, "k_noddi<3> (left-overs; 8 wavefronts, float32 tile)");
+    }
     // fp64 tile in LDS when it fits next to the per-wavefront blocks (99 x 145: 115 KB + 16 x 2.3 KB of 160 KB): the
     // fp32 -> fp64 conversions of the tile reads are then paid once per chunk.  AMX_TILE_F32=1: the fp32 tile.
     {

@@ -223,7 +223,9 @@ bool amx_gcert2_third(const amx_ctx *ctx, const amx_lut *lut, bool wide)
     // (... from 600 000 voxels: the pass's kernel holds its 24 x 24 triangle mostly in scratch (2.6 KB per lane) and a block costs it ~0.4 ms whatever
     //  the call's size -- 105 volumes, tools/r06/a12.sh: 300 000 voxels 3.58 ms without, 3.70 with it (0.50 ms of certificates to save 0.38 of
     //  left-over kernel); 1 M voxels 8.59 -> 8.01 (0.72 to save 1.27))
-    return amx_noddi_tile_global(lut->nS, lut->ldA, lut->n_atoms) || (lut->n_dwi > 95 && ctx->call_vox >= 600000);
+    // (... and up to 128 volumes: at 150 the pass costs 0.5 ms of certificates to save 0.13 of left-over kernel -- most of what is left there holds
+    //  more than 24 atoms, or fails for other reasons)
+    return amx_noddi_tile_global(lut->nS, lut->ldA, lut->n_atoms) || (lut->n_dwi > 95 && lut->nS <= 128 && ctx->call_vox >= 600000);
 }
 int amx_gcert2_third_min_items(const amx_ctx *ctx, const amx_lut *lut)
 {
