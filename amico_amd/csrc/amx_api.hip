@@ -189,6 +189,51 @@ void progress_tick(amx_ctx *ctx, hipStream_t s, int64_t done, int64_t total)
     if (hipLaunchHostFunc(s, progress_host_fn, t) != hipSuccess) { (void)hipGetLastError(); delete t; }
 }
 
+// The host threads + pinned ring of the float32 transport (amx_stage.hpp).  The threads stay on the NUMA node the DEVICE hangs on, one stripe of
+// physical cores each: the pinned ring they write lives there and the copies leave from there; the caller's buffer is read across the socket
+// link if it lives on the other node.  Measured on the two-socket box, host_trace.py and bench.py, two processes each: 12.6 - 12.9 ms per 1 M
+// voxels in all four; on the calling thread's node 15.5 - 19 ms when that is the far socket (AMX_HOST_PIN = gpu | caller | 0: diagnosis;
+// profiles/r05c_host_transport.txt, section 8)
+amx_stage::Pool *make_stage_pool(amx_ctx *ctx)
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    int nt = ctx->opt_host_threads;
+    if (hw >= 2 && nt > (int)(hw / 2)) nt = (int)(hw / 2);
+    int node = -1;
+    const char *pe = getenv("AMX_HOST_PIN");
+    if (!pe || pe[0] == 'g') node = amx_stage::device_node(ctx->device);
+    if ((pe && pe[0] == 'c') || ((!pe || pe[0] == 'g') && node < 0)) {
+        const int cpu = sched_getcpu();
+        cpu_set_t cs;
+        for (int nd = 0; nd < 16 && cpu >= 0; nd++)
+            if (amx_stage::node_cpus(nd, &cs) && CPU_ISSET(cpu, &cs)) { node = nd; break; }
+    }
+    // the other devices of that node have pools of their own (this process's other contexts, or other ranks): disjoint shares
+    int sib_i = 0, sib_n = 1;
+    const char *se = getenv("AMX_HOST_SIBLINGS");          // "i/n" forces (diagnosis, tests)
+    if (se && sscanf(se, "%d/%d", &sib_i, &sib_n) == 2 && sib_n >= 1 && sib_i >= 0) { }
+    else { sib_i = 0; sib_n = 1; if (!pe || pe[0] == 'g') amx_stage::device_siblings(ctx->device, node, &sib_i, &sib_n); }
+    return amx_stage::Pool::create(nt < 1 ? 1 : nt, node, sib_i, sib_n);
+}
+
+// Round 6: the pool is made WHILE the dictionary is uploaded.  Pinning its 64 MB ring and starting its threads takes ~15 ms, and it used to
+// happen inside the first host-buffer fit of a process -- the one fit a subject gets (core.py:465-466: one model.fit per Evaluation) --
+// behind 10 ms of dictionary tables built on the GPU and a digest of KERNELS on the host: a helper thread makes the pool beside those, the
+// first fit adopts it (NODDI().fit(evaluation), first call of a process, 1 M voxels: 41.6 ms -> see profiles/r06_first_call.txt).
+void prefetch_stage_pool(amx_ctx *ctx)
+{
+    if (ctx->stage || ctx->stage_failed || ctx->stage_bg_started || ctx->opt_host_no_narrow) return;
+    const char *pe = getenv("AMX_HOST_PIN"), *pf = getenv("AMX_HOST_PREFETCH");
+    if ((pe && pe[0] == 'c') || (pf && pf[0] == '0')) return;          // (the caller's node is the CALLING thread's: made where it is needed)
+    ctx->stage_bg_started = true;
+    try {
+        ctx->stage_thread = std::thread([ctx] {
+            if (hipSetDevice(ctx->device) != hipSuccess) { (void)hipGetLastError(); return; }
+            ctx->stage_bg = make_stage_pool(ctx);
+        });
+    } catch (...) { ctx->stage_bg_started = false; }
+}
+
 }  // namespace
 
 // =================================================================== C ABI
@@ -243,6 +288,8 @@ int amx_ctx_create(int device, amx_ctx **out)
         ctx->opt_host_one_shot = on("AMX_HOST_ONE_SHOT"); ctx->opt_host_one_stream = on("AMX_HOST_ONE_STREAM"); ctx->opt_host_late_results = on("AMX_HOST_LATE_RESULTS");
         e = getenv("AMX_HOST_PIPELINE_FROM");
         if (e && atoll(e) >= 262144) ctx->opt_host_pipeline_from = atoll(e);       // (a pipelined call has a first batch of 131 072 voxels and a second one at least as long)
+        e = getenv("AMX_HOST_NATIVE32");
+        ctx->opt_host_no_native32 = e && *e == '0';
         e = getenv("AMX_HOST_NARROW");
         ctx->opt_host_no_narrow = e && *e == '0';
         e = getenv("AMX_HOST_THREADS");
@@ -324,6 +371,8 @@ void amx_ctx_destroy(amx_ctx *ctx)
     for (int k = 0; k < kEv; k++) (void)hipEventDestroy(ctx->ev[k]);
     if (ctx->up_ev) (void)hipEventDestroy(ctx->up_ev);
     if (ctx->hs) { (void)hipStreamDestroy(ctx->hs); (void)hipStreamDestroy(ctx->hs2); for (hipEvent_t e : ctx->hev) (void)hipEventDestroy(e); }
+    if (ctx->stage_thread.joinable()) ctx->stage_thread.join();
+    delete ctx->stage_bg;
     for (int w = 0; w < 2; w++) if (ctx->fork_s[w]) { (void)hipStreamDestroy(ctx->fork_s[w]); for (hipEvent_t e : ctx->fork_ev[w]) if (e) (void)hipEventDestroy(e); }
     delete ctx->stage;             // (joins the host threads of the float32 transport)
     delete ctx;
@@ -376,6 +425,7 @@ int amx_lut_upload_noddi(amx_ctx *ctx, const float *wm, const float *iso, const 
     // any shape models.pyx:825-861 would run, up to what a wavefront's lanes hold: 8 rows / 4 atoms per lane
     if (n_atoms > 256 || nS > 512) return bad(ctx, "amx_lut_upload_noddi: unsupported size (n_atoms <= 256, nS <= 512)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    prefetch_stage_pool(ctx);            // (the host threads of the float32 transport are made beside this upload)
     amx_lut *lut = new amx_lut();
     lut->ctx = ctx; lut->model = 1; lut->nS = nS; lut->n_atoms = n_atoms; lut->ndirs = ndirs;
     lut->n_wm = n_wm; lut->is_exvivo = is_exvivo;
@@ -450,6 +500,7 @@ int amx_lut_upload_freewater(amx_ctx *ctx, const float *D, const float *CSF, con
     const int n_atoms = n_perp + n_iso;
     if (n_atoms > 64 || nS > 512) return bad(ctx, "amx_lut_upload_freewater: unsupported size (n_atoms <= 64, nS <= 512)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    prefetch_stage_pool(ctx);            // (the host threads of the float32 transport are made beside this upload)
     amx_lut *lut = new amx_lut();
     lut->ctx = ctx; lut->model = 2; lut->nS = nS; lut->n_atoms = n_atoms; lut->ndirs = ndirs;
     lut->n_perp = n_perp; lut->n_iso = n_iso;
@@ -474,6 +525,7 @@ int amx_lut_upload_sandi(amx_ctx *ctx, const double *signal, const double *norms
     const int n_atoms = n_rs + n_in + n_iso;
     if (n_atoms <= 0 || n_atoms > 64 || nS > 128) return bad(ctx, "amx_lut_upload_sandi: unsupported size (n_atoms <= 64, nS <= 128)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    prefetch_stage_pool(ctx);            // (the host threads of the float32 transport are made beside this upload)
     amx_lut *lut = new amx_lut();
     lut->ctx = ctx; lut->model = 3; lut->nS = nS; lut->n_atoms = n_atoms; lut->ndirs = 1;
     lut->n_rs = n_rs; lut->n_in = n_in; lut->n_isos = n_iso;
@@ -501,6 +553,7 @@ int amx_lut_upload_czb(amx_ctx *ctx, const float *wmr, const float *wmh, const f
     const int n_atoms = n_rs + n_perp + n_iso;
     if (n_atoms > 64 || nS > 512) return bad(ctx, "amx_lut_upload_czb: unsupported size (n_atoms <= 64, nS <= 512)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    prefetch_stage_pool(ctx);            // (the host threads of the float32 transport are made beside this upload)
     amx_lut *lut = new amx_lut();
     lut->ctx = ctx; lut->model = 4; lut->nS = nS; lut->n_atoms = n_atoms; lut->ndirs = ndirs;
     lut->n_rs = n_rs; lut->n_perp = n_perp; lut->n_iso = n_iso;
@@ -1301,35 +1354,17 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
     bool narrow = false;
     if (!kF32 && !ctx->opt_host_no_narrow && !ctx->stage_failed && (size_t)n_vox * nS >= kNarrowFrom) {
         if (!ctx->stage) {
-            const unsigned hw = std::thread::hardware_concurrency();
-            int nt = ctx->opt_host_threads;
-            if (hw >= 2 && nt > (int)(hw / 2)) nt = (int)(hw / 2);
-            // The threads stay on the NUMA node the DEVICE hangs on, one per physical core (amx_stage.hpp): the pinned ring they write lives
-            // there and the copies leave from there; the caller's buffer is read across the socket link if it lives on the other node.
-            // Measured on the two-socket box, host_trace.py and bench.py, two processes each: 12.6 - 12.9 ms per 1 M voxels in all four;
-            // on the calling thread's node 15.5 - 19 ms when that is the far socket (AMX_HOST_PIN = gpu | caller | 0: diagnosis;
-            // profiles/r05c_host_transport.txt, section 8)
-            int node = -1;
-            const char *pe = getenv("AMX_HOST_PIN");
-            if (!pe || pe[0] == 'g') node = amx_stage::device_node(ctx->device);
-            if ((pe && pe[0] == 'c') || ((!pe || pe[0] == 'g') && node < 0)) {
-                const int cpu = sched_getcpu();
-                cpu_set_t cs;
-                for (int nd = 0; nd < 16 && cpu >= 0; nd++)
-                    if (amx_stage::node_cpus(nd, &cs) && CPU_ISSET(cpu, &cs)) { node = nd; break; }
-            }
-            // the other devices of that node have pools of their own (this process's other contexts, or other ranks): disjoint shares
-            int sib_i = 0, sib_n = 1;
-            const char *se = getenv("AMX_HOST_SIBLINGS");          // "i/n" forces (diagnosis, tests)
-            if (se && sscanf(se, "%d/%d", &sib_i, &sib_n) == 2 && sib_n >= 1 && sib_i >= 0) { }
-            else { sib_i = 0; sib_n = 1; if (!pe || pe[0] == 'g') amx_stage::device_siblings(ctx->device, node, &sib_i, &sib_n); }
-            ctx->stage = amx_stage::Pool::create(nt < 1 ? 1 : nt, node, sib_i, sib_n);
+            if (ctx->stage_thread.joinable()) { ctx->stage_thread.join(); ctx->stage = ctx->stage_bg; ctx->stage_bg = nullptr; }      // made beside the dictionary upload
+            if (!ctx->stage) ctx->stage = make_stage_pool(ctx);
             if (!ctx->stage) ctx->stage_failed = true;
         }
         narrow = ctx->stage != nullptr;
     }
     ctx->host_narrowed = 0;
-    if ((rc = ensure(ctx, ctx->hy, (size_t)cap * nS * sizeof(double)))) return rc;
+    // (a model whose kernels read float32 signals in place -- NODDI: ctx->host_native32 -- needs the float64 staging buffer only for a batch that
+    //  could not travel as float32: made when that happens.  934 MB less to allocate in a process's first call, no k_widen pass per batch)
+    const bool native32 = ctx->host_native32 && !ctx->opt_host_no_native32;
+    if (!(native32 && (kF32 || narrow)) && (rc = ensure(ctx, ctx->hy, (size_t)cap * nS * sizeof(double)))) return rc;
     if ((kF32 || narrow) && (rc = ensure(ctx, ctx->hy32, (size_t)cap * nS * sizeof(float)))) return rc;
     if (dirs && (rc = ensure(ctx, ctx->hdirs, (size_t)cap * 3 * sizeof(double)))) return rc;
     for (HostOut &o : outs)
@@ -1396,14 +1431,16 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
         //  float32 transport -- and the consumers run on the non-blocking streams hs / hs2: hipMemcpy returns when the data has landed for pageable
         //  sources; for the pinned ones that is the runtime's behaviour, not its contract, so the batch's stream WAITS for an event recorded behind
         //  the batch's last copy (round 6, ADVICE r05: two API calls, ~3 us per batch))
-        double *yb = (double *)ctx->hy.p + (size_t)b * kHostBatch * nS;
+        double *yb = ctx->hy.p ? (double *)ctx->hy.p + (size_t)b * kHostBatch * nS : nullptr;
         double *db = dirs ? (double *)ctx->hdirs.p + (size_t)b * kHostBatch * 3 : nullptr;
         const double tr2 = trace ? wall() : 0.0;
+        ctx->host_y32 = nullptr;
         if (kF32) {
             float *y32 = (float *)ctx->hy32.p + (size_t)b * kHostBatch * nS;
             const size_t nel = (size_t)cnt * nS;
             HIPCHK(ctx, hipMemcpy(y32, y + (size_t)off * nS, nel * sizeof(float), hipMemcpyHostToDevice));
-            hipLaunchKernelGGL(k_widen, dim3((unsigned)((nel / 4 + 256) / 256)), dim3(256), 0, s, y32, yb, nel);
+            if (native32) ctx->host_y32 = y32;
+            else hipLaunchKernelGGL(k_widen, dim3((unsigned)((nel / 4 + 256) / 256)), dim3(256), 0, s, y32, yb, nel);
         } else {
             bool sent = false;
             const size_t nel = (size_t)cnt * nS;
@@ -1422,11 +1459,18 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
                     ctx->stage->consumed(j);
                 }
                 if (sent) {
-                    hipLaunchKernelGGL(k_widen, dim3((unsigned)((nel / 4 + 256) / 256)), dim3(256), 0, s, y32, yb, nel);
+                    if (native32) ctx->host_y32 = y32;
+                    else hipLaunchKernelGGL(k_widen, dim3((unsigned)((nel / 4 + 256) / 256)), dim3(256), 0, s, y32, yb, nel);
                     ctx->host_narrowed++;
                 }
             }
-            if (!sent) HIPCHK(ctx, hipMemcpy(yb, y + (size_t)off * nS, (size_t)cnt * nS * sizeof(double), hipMemcpyHostToDevice));
+            if (!sent) {
+                if (!yb) {      // (the float64 staging buffer of a native-float32 call: needed after all)
+                    if ((rc = ensure(ctx, ctx->hy, (size_t)cap * nS * sizeof(double)))) { ctx->profiling = was_profiling; return rc; }
+                    yb = (double *)ctx->hy.p + (size_t)b * kHostBatch * nS;
+                }
+                HIPCHK(ctx, hipMemcpy(yb, y + (size_t)off * nS, (size_t)cnt * nS * sizeof(double), hipMemcpyHostToDevice));
+            }
         }
         if (dirs) HIPCHK(ctx, hipMemcpy(db, dirs + (size_t)off * 3, (size_t)cnt * 3 * sizeof(double), hipMemcpyHostToDevice));
         if (ctx->up_ev) { HIPCHK(ctx, hipEventRecord(ctx->up_ev, nullptr)); HIPCHK(ctx, hipStreamWaitEvent(s, ctx->up_ev, 0)); }
@@ -1440,7 +1484,7 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
         rc = enqueue(yb, db, cnt, (double *)outs[0].buf->p + (size_t)off * outs[0].cols,
                      outs[1].on ? (double *)outs[1].buf->p + off : nullptr, outs[2].on ? (double *)outs[2].buf->p + off : nullptr,
                      outs[3].on ? (double *)outs[3].buf->p + (size_t)off * outs[3].cols : nullptr, s);
-        ctx->vox_base = 0;
+        ctx->vox_base = 0; ctx->host_y32 = nullptr;
         if (rc) { ctx->profiling = was_profiling; return rc; }
         off += cnt;
         if (pipelined) { HIPCHK(ctx, hipEventRecord(ctx->hev[b], s)); done_before[b] = off; }
@@ -1500,8 +1544,13 @@ static int noddi_fit_any(amx_ctx *ctx, const amx_lut *lut, const T *y, const dou
     HostOut outs[4] = {{out_estimates, &ctx->hest, (size_t)(3 + (lut->is_exvivo ? 1 : 0)), true},
                        {out_rmse, &ctx->hrmse, 1, (flags & AMX_F_RMSE) != 0}, {out_nrmse, &ctx->hnrmse, 1, (flags & AMX_F_NRMSE) != 0},
                        {out_mod, &ctx->hextra, 2, (flags & AMX_F_MODULATED) != 0}};
+    // (every NODDI kernel reads float32 signals in place -- the table GEMM, the wavefront-per-voxel kernels' load_rows, the rescue pass --: a batch
+    //  that crossed the link as float32 is fitted as float32, no widened copy; bit-identical maps: amx_noddi_fit_device_f32)
+    ctx->host_native32 = true;
+    struct Native32Scope { amx_ctx *c; ~Native32Scope() { c->host_native32 = false; c->host_y32 = nullptr; } } n32{ctx};
     return fit_host<T>(ctx, y, dirs, n_vox, lut->nS, outs,
                        [&](double *yb, double *db, int64_t cnt, double *e, double *r, double *nr, double *x, hipStream_t s) {
+                           if (ctx->host_y32) return amx_noddi_fit_device_f32(ctx, lut, ctx->host_y32, db, cnt, lambda1, lambda2, flags, e, r, nr, x, s);
                            return amx_noddi_fit_device(ctx, lut, yb, db, cnt, lambda1, lambda2, flags, e, r, nr, x, s);
                        });
 }

@@ -49,6 +49,12 @@ struct amx_ctx {
     DevBuf wy;                     // float64 copy of float32 device signals for the lane kernels that read float64 only (amx_*_fit_device_f32)
     DevBuf hy32;                   // float32 signals of the *_fit_f32 entry points (and of float64 host signals that are float32 values: amx_stage.hpp)
     amx_stage::Pool *stage = nullptr;  // host threads + pinned slots of the lossless float64 -> float32 transport (made at the first large float64 host call)
+    std::thread stage_thread;      // makes the pool beside the dictionary upload (prefetch_stage_pool); joined by the first host-buffer fit that needs it
+    amx_stage::Pool *stage_bg = nullptr;
+    bool stage_bg_started = false;
+    bool host_native32 = false;    // set by a model's host entry point whose kernels read float32 signals in place (fit_host then skips k_widen)
+    const float *host_y32 = nullptr;   // the current batch's float32 signals in HBM (fit_host -> the model's enqueue), or null: float64 in the staging buffer
+    bool opt_host_no_native32 = false; // AMX_HOST_NATIVE32=0: float32 batches are widened on the device first (the round-5 behaviour)
     bool stage_failed = false;     // the pool could not be made: host signals are copied as they are
     int host_narrowed = 0;         // batches of the last host-buffer call that travelled as float32 (amx_last_host_narrowed)
     hipStream_t hs = nullptr;      // non-blocking compute streams of the chunked host entry points: batches alternate
