@@ -1465,7 +1465,7 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
                 }
             }
             if (!sent) {
-                if (!yb) {      // (the float64 staging buffer of a native-float32 call: needed after all)
+                if (native32) {      // (the float64 staging buffer of a native-float32 call: needed after all -- and an earlier, smaller call's may be too small)
                     if ((rc = ensure(ctx, ctx->hy, (size_t)cap * nS * sizeof(double)))) { ctx->profiling = was_profiling; return rc; }
                     yb = (double *)ctx->hy.p + (size_t)b * kHostBatch * nS;
                 }

@@ -164,8 +164,18 @@ public:
         Pool *p = new Pool();
         p->T_ = threads;
         p->avx2_ = __builtin_cpu_supports("avx2");
+        // the pinned ring is allocated (and its pages placed) by a thread that sits on the DEVICE's node for the length of the allocation: the
+        // narrowing threads write it from there and the copies leave from there -- whoever makes the pool (the calling thread of a first fit, or,
+        // round 6, a helper thread beside the dictionary upload) may be running on the other socket
+        cpu_set_t before, on_node;
+        const bool moved = node >= 0 && node_cpus(node, &on_node) && pthread_getaffinity_np(pthread_self(), sizeof before, &before) == 0 &&
+                           pthread_setaffinity_np(pthread_self(), sizeof on_node, &on_node) == 0;
+        bool ring_ok = true;
         for (float *&q : p->ring_)
-            if (hipHostMalloc((void **)&q, kChunkEl * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); q = nullptr; p->release(); delete p; return nullptr; }
+            if (hipHostMalloc((void **)&q, kChunkEl * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); q = nullptr; ring_ok = false; break; }
+        if (ring_ok) for (float *q : p->ring_) for (size_t e = 0; e < kChunkEl; e += 1024) q[e] = 0.0f;       // (first touch, should the runtime leave it to us)
+        if (moved) (void)pthread_setaffinity_np(pthread_self(), sizeof before, &before);
+        if (!ring_ok) { p->release(); delete p; return nullptr; }
         try {
             for (int t = 0; t < threads; t++) p->th_.emplace_back([p] { p->worker(); });
         } catch (...) { delete p; return nullptr; }

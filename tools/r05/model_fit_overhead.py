@@ -20,7 +20,7 @@ class Ev:
 
 m = NODDI(); m.scheme = sch; ev = Ev()
 m.fit(ev)
-ctx = get_context(); lut = m._lut_cache[1]
+ctx = get_context(); lut = next(iter(m._lut_cache.values()))[1]
 _capi.noddi_fit(ctx, lut, y, d, 0.5, 1e-3, 3)
 a, b, c = [], [], []
 for _ in range(9):
