@@ -906,7 +906,7 @@ def main():
             # host-buffer pipeline, have): T(n) = floor + slope n is the chain's signature, and the driver should see it
             size_scan = {}
             for ns_ in (50_000, 200_000, 300_000):
-                if ns_ >= n:
+                if ns_ >= n or args.no_other_configs:          # (profiling runs want the headline's launches only: per-kernel means are taken over ALL launches)
                     continue
                 est_s = torch.zeros((ns_, 3), dtype=torch.float64, device=dev)
 

@@ -13,6 +13,7 @@
 //   k_read_row8      8 B per lane, lane l reads row r_l of a 176 x 512 B block     (the certificates' reads of the A'y table: k_nnls_gcert,
 //                    at column l: sectors 512 B apart, rows scattered               k_lasso_gcert -- Crow[idx * 64], one row per lane)
 //   k_read_line8     8 B per lane, ONE per 128-byte line (the other sector of the line is never read); k_read_row512: one per 512 B
+//   k_read_planes    96 concurrent streams of 256-byte runs per wavefront, planes 22 MB apart (the mask gather's reads of a planar image)
 //   k_read_lds4/16   global -> LDS direct loads (global_load_lds dword / dwordx4), coalesced                     (k_prep_gather, k_freewater_fused)
 //   k_write_wide16   16 B per lane coalesced stores;  k_write_sector8: 8 B per lane, one per 64-byte sector      (WRITE_SIZE)
 #include <hip/hip_runtime.h>
@@ -53,6 +54,23 @@ __global__ void __launch_bounds__(256) k_read_row512(const double *__restrict__ 
     double acc = 0.0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += (size_t)gridDim.x * blockDim.x) acc += p[i * 64 + (i & 63)];
     if (acc == 1.2345e300) *sink = 1;
+}
+// the mask gather's read pattern (k_prep_gather on a planar image): a wavefront reads ONE 256-byte run from each of NV planes that lie `plane`
+// bytes apart (a tile of 64 voxels x NV volumes), all NV loads in flight together -- NV concurrent streams per wavefront, every request in another
+// DRAM row.  Every byte of the buffer is read once, in full lines.
+template <int NV>
+__global__ void __launch_bounds__(256) k_read_planes(const float *__restrict__ p, size_t plane_el, size_t tiles, unsigned *sink)
+{
+    const int lane = threadIdx.x & 63;
+    float acc = 0.f;
+    for (size_t t = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < tiles; t += (size_t)gridDim.x * 4) {
+        float v[NV];
+#pragma unroll
+        for (int k = 0; k < NV; k++) v[k] = p[(size_t)k * plane_el + t * 64 + lane];
+#pragma unroll
+        for (int k = 0; k < NV; k++) acc += v[k];
+    }
+    if (acc == 1.2345e30f) *sink = 1;
 }
 // the certificates' pattern: blocks of ROWS x 64 doubles (one block = 64 voxels of the A'y table, one 512-byte row per atom); a lane reads
 // the entries of ITS voxel's atoms, i.e. 8 bytes of a row that the lanes beside it do not read -- sectors 512 B apart, 8 useful bytes of 64.
@@ -130,6 +148,11 @@ int main(int argc, char **argv)
     timed("k_read_row8", (double)n_blocks * ROWS * 64, (double)n_blocks * ROWS * 512, [&] { hipLaunchKernelGGL(k_read_row8<ROWS>, grid, blk, 0, nullptr, (const double *)buf, n_blocks, sink); });
     timed("k_read_line8", (double)bytes / 16, (double)bytes / 2, [&] { hipLaunchKernelGGL(k_read_line8, grid, blk, 0, nullptr, (const double *)buf, bytes / 128, sink); });
     timed("k_read_row512", (double)bytes / 64, (double)bytes / 8, [&] { hipLaunchKernelGGL(k_read_row512, grid, blk, 0, nullptr, (const double *)buf, bytes / 512, sink); });
+    {
+        constexpr int NV = 96;
+        const size_t plane_el = bytes / 4 / NV, tiles = plane_el / 64;
+        timed("k_read_planes<96>", (double)(tiles * 64 * NV * 4), (double)(tiles * 64 * NV * 4), [&] { hipLaunchKernelGGL(k_read_planes<NV>, grid, blk, 0, nullptr, (const float *)buf, plane_el, tiles, sink); });
+    }
     timed("k_read_lds<4>", (double)bytes, (double)bytes, [&] { hipLaunchKernelGGL(k_read_lds<4>, grid, blk, 0, nullptr, (const unsigned *)buf, bytes / 4, sink); });
     timed("k_read_lds<16>", (double)bytes, (double)bytes, [&] { hipLaunchKernelGGL(k_read_lds<16>, grid, blk, 0, nullptr, (const unsigned *)buf, bytes / 4, sink); });
     timed("k_write_wide16", (double)bytes, (double)bytes, [&] { hipLaunchKernelGGL(k_write_wide16, grid, blk, 0, nullptr, (uint4 *)buf, bytes / 16); });

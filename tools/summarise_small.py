@@ -64,7 +64,7 @@ for m, pats, n in (('freewater', ('k_fw_project', 'k_freewater'), 2000000), ('sa
             for pat in pats:
                 if pat in r['Kernel_Name']:
                     per[pat][r['Counter_Name']].append(float(r['Counter_Value']))
-                    names.add(r['Kernel_Name'].replace('void ', '').replace('amx::', '').split('(')[0])
+                    names.add(r['Kernel_Name'].replace('void ', '').replace('(anonymous namespace)::', '').replace('amx::', '').split('(')[0])
     mean = lambda v: sum(v) / len(v)
     tot = collections.defaultdict(float)
     for pat in per:
