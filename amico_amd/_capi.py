@@ -396,6 +396,8 @@ def noddi_fit(ctx, lut, y, dirs, lambda1, lambda2, n_maps, rmse=False, nrmse=Fal
     y = _check_y(y, lut.nS)
     n = y.shape[0]
     dirs = _check_dirs(dirs, n)
+    if lut.n_maps is not None and n_maps != lut.n_maps:      # (the library writes what the DICTIONARY says: a short buffer would be overrun)
+        raise ValueError(f'the dictionary writes {lut.n_maps} maps per voxel, the model expects {n_maps} (isExvivo changed?)')
     flags = (F_RMSE if rmse else 0) | (F_NRMSE if nrmse else 0) | (F_MODULATED if mod else 0)
     est, r, nr, md = _outs(out, n, [((n_maps,), True), ((), rmse), ((), nrmse), ((2,), mod)])
     f32, yp = _yp(y)

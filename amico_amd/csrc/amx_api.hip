@@ -95,25 +95,24 @@ int make_plan(amx_ctx *ctx, int64_t n, int ndirs, Plan &pl, bool seeds = false, 
     return AMX_OK;
 }
 
-int enqueue_bucketing(amx_ctx *ctx, const amx_lut *lut, const double *d_dirs, int64_t n, Plan &pl, hipStream_t s, int chunk = kChunk)
+int enqueue_bucketing(amx_ctx *ctx, const amx_lut *lut, const double *d_dirs, int64_t n, Plan &pl, hipStream_t s, int chunk = kChunk,
+                      double *zero_rows = nullptr, int zero_cols = 0)
 {
-    HIPCHK(ctx, hipMemsetAsync(pl.counts, 0, (size_t)(lut->ndirs + 1) * sizeof(int), s));
-    HIPCHK(ctx, hipMemsetAsync(ctx->misc.p, 0, 64 * sizeof(int), s));
-    if (pl.feed) HIPCHK(ctx, hipMemsetAsync(pl.feed, 0, (size_t)(kFeedSets + kZCounts) * (pl.max_schunks + 8) * sizeof(int), s));
-    const int nb = (int)((n + kPrepSpan - 1) / kPrepSpan);
+    // (four launches: the counters cleared in one, the chunk order in k_plan's tail; they were three memsets and five kernels --
+    //  ~11 us a node in a small call, profiles/r06_launch_nodes.txt)
+    const int n_feed = pl.feed ? (kFeedSets + kZCounts) * (pl.max_schunks + 8) : 0;
+    hipLaunchKernelGGL(k_clear3, dim3(n_feed > 4096 ? 8 : 1), dim3(1024), 0, s, pl.counts, lut->ndirs + 1, (int *)ctx->misc.p, 64, pl.feed, n_feed);
+    const int span = prep_span(n);
+    const int nb = (int)((n + span - 1) / span);
     const int use_lds = lut->ndirs <= 8192 ? 1 : 0;          // LDS histograms: 2 * ndirs ints
     hipLaunchKernelGGL(k_dir_to_lut, dim3(nb), dim3(1024), use_lds ? (size_t)lut->ndirs * sizeof(int) : 0, s, d_dirs,
-                       (int)n, lut->htable, lut->ndirs, pl.lutidx, pl.counts, ctx->status_d, use_lds, (int)ctx->vox_base);
+                       (int)n, lut->htable, lut->ndirs, pl.lutidx, pl.counts, ctx->status_d, use_lds, (int)ctx->vox_base, span, zero_rows, zero_cols);
     AMX_TRACE(ctx, s, "k_dir_to_lut");
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, pl.counts, lut->ndirs, chunk, pl.dir_start,
-                       pl.cursor, pl.chunks, pl.n_chunks, pl.schunks ? pl.seed_chunk : 0, pl.schunks);
+                       pl.cursor, pl.chunks, pl.n_chunks, pl.schunks ? pl.seed_chunk : 0, pl.schunks, (pl.schunks && !ctx->opt_no_chunk_order) ? 1 : 0);
     AMX_TRACE(ctx, s, "k_plan");
-    if (pl.schunks && !ctx->opt_no_chunk_order) {
-        hipLaunchKernelGGL(k_order_schunks, dim3(1), dim3(1024), 0, s, pl.schunks, pl.n_chunks);
-        AMX_TRACE(ctx, s, "k_order_schunks");
-    }
     hipLaunchKernelGGL(k_bucket, dim3(nb), dim3(1024), use_lds ? (size_t)2 * lut->ndirs * sizeof(int) : 0, s, pl.lutidx,
-                       (int)n, lut->ndirs, pl.dir_start, pl.cursor, pl.perm, use_lds);
+                       (int)n, lut->ndirs, pl.dir_start, pl.cursor, pl.perm, use_lds, span);
     AMX_TRACE(ctx, s, "k_bucket");
     HIPCHK(ctx, hipGetLastError());
     return AMX_OK;
@@ -268,7 +267,7 @@ int amx_ctx_create(int device, amx_ctx **out)
     ctx->device = device;
     ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipMalloc((void **)&ctx->status_d, ST_WORDS * sizeof(int)) != hipSuccess ||
-        hipHostMalloc((void **)&ctx->status_h, (ST_WORDS + 16) * sizeof(int)) != hipSuccess) {
+        hipHostMalloc((void **)&ctx->status_h, (ST_WORDS + 16) * sizeof(int), hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {   // (k_status_home writes it from the device)
         delete ctx;
         return AMX_E_HIP;
     }
@@ -582,18 +581,31 @@ int amx_lut_upload_czb(amx_ctx *ctx, const float *wmr, const float *wmh, const f
     return AMX_OK;
 }
 
+// status words home (the pinned mirror, written from the device) and cleared for the next call: one launch where a copy and two
+// memsets were three nodes of the stream (~11 us each at the end of every call)
+__global__ void k_status_home(int *__restrict__ st, int *__restrict__ home)
+{
+    const int i = threadIdx.x;
+    if (i < ST_WORDS) {
+        home[i] = st[i];
+        st[i] = (i == ST_ERRPACK || i == ST_ERRPACK + 1) ? 0x7f7f7f7f : 0;
+    }
+    __threadfence_system();
+}
+
 int amx_sync_status(amx_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return AMX_E_BADARG;
     hipStream_t s = (hipStream_t)hip_stream;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->status_h, ctx->status_d, ST_WORDS * sizeof(int), hipMemcpyDeviceToHost, s));
+    static_assert(ST_WORDS <= 128, "k_status_home: one thread per status word");
+    hipLaunchKernelGGL(k_status_home, dim3(1), dim3(128), 0, s, ctx->status_d, ctx->status_h);
 #ifdef AMX_PHASES
     unsigned long long ph_[16];
     if (ctx->misc.p) HIPCHK(ctx, hipMemcpyAsync(ph_, (int *)ctx->misc.p + 16, sizeof ph_, hipMemcpyDeviceToHost, s));
 #endif
-    int rc = reset_status(ctx, s);
-    if (rc) return rc;
+    int rc = AMX_OK;
+    HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(s));
 #ifdef AMX_PHASES
     if (ctx->misc.p) {
@@ -818,7 +830,9 @@ static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
     if ((rc = ensure(ctx, ctx->supp, (size_t)n_vox * 4 * sizeof(unsigned long long)))) return rc;
     clear_events(ctx);
     rec(ctx, 0, s);
-    if ((rc = enqueue_bucketing(ctx, lut, d_dirs, n_vox, pl, s))) return rc;
+    // (voxels with an out-of-bounds direction are skipped: k_dir_to_lut gives them defined (zero) maps; every other voxel's maps are
+    //  written by the kernel that settles its stage 3 -- tests/test_gpu_parity.py::test_noddi_fit_writes_every_voxel)
+    if ((rc = enqueue_bucketing(ctx, lut, d_dirs, n_vox, pl, s, kChunk, d_estimates, 3 + (lut->is_exvivo ? 1 : 0)))) return rc;
     NoddiArgs a;
     memset(&a, 0, sizeof a);
     a.c.tiles = lut->tiles; a.c.y = d_y; a.c.y32 = d_y32; a.c.perm = pl.perm; a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks;
@@ -834,8 +848,6 @@ static int noddi_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, co
     a.xiso = (double *)ctx->xiso.p; a.supp = (unsigned long long *)ctx->supp.p;
     a.est = d_estimates; a.rmse = (flags & AMX_F_RMSE) ? d_rmse : nullptr;
     a.nrmse = (flags & AMX_F_NRMSE) ? d_nrmse : nullptr; a.mod = (flags & AMX_F_MODULATED) ? d_mod : nullptr;
-    // voxels with an out-of-bounds direction are skipped: give them defined (zero) maps
-    HIPCHK(ctx, hipMemsetAsync(d_estimates, 0, (size_t)n_vox * a.n_maps * sizeof(double), s));
     if (seeds) {
         ctx->seeded_vox += n_vox;
         // y~ = U'y once; the seed solver proposes the stage's support, the stage kernel certifies it (amx_seed.hpp)
@@ -974,7 +986,8 @@ static int freewater_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y
     clear_events(ctx);
     rec(ctx, 0, s);
     const bool refill = amx_use_lane_solver(ctx, lut->n_atoms, lambda2) && amx_fw_use_refill(ctx, lut->n_atoms, lut->nS, flags, lambda2);
-    if ((rc = enqueue_bucketing(ctx, lut, d_dirs, n_vox, pl, s, refill ? amx_refill_chunk(ctx, n_vox) : kChunk))) return rc;
+    // (no memset of the maps: skipped voxels are zeroed by k_dir_to_lut, every other voxel is written -- test_freewater_fit_writes_every_voxel)
+    if ((rc = enqueue_bucketing(ctx, lut, d_dirs, n_vox, pl, s, refill ? amx_refill_chunk(ctx, n_vox) : kChunk, d_estimates, is_mouse ? 4 : 2))) return rc;
     FwArgs a;
     memset(&a, 0, sizeof a);
     a.c.tiles = lut->tiles; a.c.y = d_y; a.c.y32 = d_y32; a.c.perm = pl.perm; a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks;
@@ -988,7 +1001,6 @@ static int freewater_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y
     }
     a.est = d_estimates; a.rmse = (flags & AMX_F_RMSE) ? d_rmse : nullptr;
     a.nrmse = (flags & AMX_F_NRMSE) ? d_nrmse : nullptr; a.ycorr = (flags & AMX_F_CORRECTED) ? d_ycorr : nullptr;
-    HIPCHK(ctx, hipMemsetAsync(d_estimates, 0, (size_t)n_vox * a.n_maps * sizeof(double), s));
     if (refill && (rc = amx_fw_prepare(ctx, lut, a, s))) return rc;
     rc = amx_launch_fw(ctx, a, pl, s);
     hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, s, (const int *)ctx->misc.p, ctx->status_d);
@@ -1138,11 +1150,11 @@ static int batched_dev(amx_ctx *ctx, const amx_dict *dict, const int32_t *d_idx,
     HIPCHK(ctx, hipMemsetAsync(pl.counts, 0, (size_t)(dict->n_dicts + 1) * sizeof(int), s));
     HIPCHK(ctx, hipMemsetAsync(ctx->misc.p, 0, 64 * sizeof(int), s));
     hipLaunchKernelGGL(k_idx_hist, dim3((unsigned)((n_vox + 255) / 256)), dim3(256), 0, s, (const int *)d_idx, (int)n_vox, dict->n_dicts, pl.lutidx, pl.counts, ctx->status_d);
-    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, pl.counts, dict->n_dicts, kChunk, pl.dir_start, pl.cursor, pl.chunks, pl.n_chunks, 0, (Chunk *)nullptr);
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, pl.counts, dict->n_dicts, kChunk, pl.dir_start, pl.cursor, pl.chunks, pl.n_chunks, 0, (Chunk *)nullptr, 0);
     const int nb = (int)((n_vox + kPrepSpan - 1) / kPrepSpan);
     const int use_lds = dict->n_dicts <= 8192 ? 1 : 0;
     hipLaunchKernelGGL(k_bucket, dim3(nb), dim3(1024), use_lds ? (size_t)2 * dict->n_dicts * sizeof(int) : 0, s, pl.lutidx, (int)n_vox, dict->n_dicts,
-                       pl.dir_start, pl.cursor, pl.perm, use_lds);
+                       pl.dir_start, pl.cursor, pl.perm, use_lds, kPrepSpan);
     HIPCHK(ctx, hipGetLastError());
     BatchedArgs a;
     memset(&a, 0, sizeof a);
@@ -1678,7 +1690,7 @@ int amx_dir_to_lut_idx(amx_ctx *ctx, const amx_lut *lut, const double *dirs, int
     if ((rc = ensure(ctx, ctx->lutidx, (size_t)n * sizeof(int)))) return rc;
     hipLaunchKernelGGL(k_dir_to_lut, dim3((unsigned)((n + kPrepSpan - 1) / kPrepSpan)), dim3(1024), 0, nullptr,
                        (const double *)ctx->hdirs.p, (int)n, lut->htable, lut->ndirs, (int *)ctx->lutidx.p, (int *)nullptr,
-                       ctx->status_d, 0, 0);
+                       ctx->status_d, 0, 0, kPrepSpan, (double *)nullptr, 0);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(out_idx, ctx->lutidx.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, nullptr));
     return amx_sync_status(ctx, nullptr);

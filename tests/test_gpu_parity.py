@@ -139,6 +139,18 @@ def test_noddi_exvivo_and_lambdas(htable500, n):
     assert np.abs(out['rmse'] - ref['rmse']).max() < 1e-6 and np.abs(out['nrmse'] - ref['nrmse']).max() < 1e-6
     tf = 1 - out['estimates'][:, 2]
     assert np.allclose(out['estimates_mod'], out['estimates'][:, :2] * tf[:, None], atol=1e-12)
+    if n == 1500:
+        # the library writes as many maps as the DICTIONARY holds: a caller that asks the low-level wrappers for three of an ex-vivo
+        # dictionary's four is told so (the buffer would be overrun), host and device entry points alike
+        import torch
+        from amico_amd import _capi, get_context
+        ctx = get_context()
+        lut = _capi.upload_noddi(ctx, K, ht, sch.dwi_idx, True)
+        with pytest.raises(ValueError, match='maps per voxel'):
+            _capi.noddi_fit(ctx, lut, y, d, 0.2, 5e-3, 3)
+        with pytest.raises(ValueError, match='maps per voxel'):
+            _capi.noddi_fit_device(ctx, lut, torch.from_numpy(y).cuda(), torch.from_numpy(d).cuda(), 0.2, 5e-3, 3)
+        lut.close()
 
 
 def test_freewater_golden_and_oracle(fw_fix, htable500):
@@ -675,3 +687,88 @@ def test_noddi_diagnosis_switches_keep_the_maps(htable500, switch, amx_env):
     m = 3000
     ref = oracle.noddi_fit(y[:m], d[:m], K, ht, sch.dwi_idx, nthreads=8)['estimates']
     assert np.abs(got[0][:m] - ref).max() < TOL
+
+
+@pytest.mark.parametrize('n,exvivo', [(3000, False), (120_000, False), (700_000, False), (60_000, True)])
+def test_noddi_fit_writes_every_voxel(htable500, n, exvivo):
+    """The fit does not clear its output buffer (round 6: one memset node less per call): every voxel's maps are WRITTEN by the kernel
+    that settles its third stage, and the voxels the call skips -- direction out of bounds, reported as the error -- are zeroed by
+    k_dir_to_lut.  Output buffers full of a sentinel, then full of zeros: the same bits, no sentinel left; hard signal mix (all-zero,
+    flat, half-zeroed, noise voxels), NaN / Inf signals, every path (wavefront-per-voxel only, seeded chain, its large-call builds)."""
+    import torch
+    from amico_amd import _capi, get_context, synthetic as S
+    ctx = get_context()
+    ht = htable500['htable']
+    sch = S.make_scheme(seed=3)
+    K = S.noddi_kernels(sch, htable500['dirs'])
+    y_h, d_h, _ = S.noddi_hard_signals(n, K, ht, sch, seed=31)
+    y_h[11] = np.nan; y_h[12, 3] = np.inf; y_h[n - 1] = np.nan
+    bad = [17, n // 2, n - 2]
+    d_h[bad] = np.nan
+    lut = _capi.upload_noddi(ctx, K, ht, sch.dwi_idx, exvivo)
+    y = torch.from_numpy(y_h).cuda(); d = torch.from_numpy(d_h).cuda()
+    nm = 4 if exvivo else 3
+    L = _capi.lib()
+    outs = []
+    for fill in (-7.25, 0.0):
+        est = torch.full((n, nm), fill, dtype=torch.float64, device='cuda')
+        rm = torch.full((n,), fill, dtype=torch.float64, device='cuda')
+        rc = L.amx_noddi_fit_device(ctx._h, lut._h, y.data_ptr(), d.data_ptr(), n, 0.5, 1e-3, _capi.F_RMSE, est.data_ptr(), rm.data_ptr(), None, None, None)
+        assert rc == 0
+        with pytest.raises(RuntimeError, match=r'index out of bounds.*\[voxel 17\]'):
+            ctx.sync()
+        outs.append((est.cpu().numpy(), rm.cpu().numpy()))
+    (e1, r1), (e0, r0) = outs
+    assert not (e1 == -7.25).any()
+    assert np.array_equal(e1, e0, equal_nan=True)
+    assert (e1[bad] == 0.0).all()
+    ok = np.ones(n, bool); ok[bad] = False
+    assert np.array_equal(r1[ok], r0[ok], equal_nan=True) and not (r1[ok] == -7.25).any()
+    assert np.isnan(e1[11]).all() and np.isnan(e1[n - 1]).all()
+    lut.close()
+
+
+@pytest.mark.parametrize('n,mouse,flags', [(3000, False, 0), (200_000, False, 0), (200_000, True, 3), (50_000, False, 8)])
+def test_freewater_fit_writes_every_voxel(htable500, n, mouse, flags):
+    """as test_noddi_fit_writes_every_voxel, for the FreeWater fit (fused kernel, error maps / corrected signal variants, Mouse): no
+    memset of the maps, skipped voxels zeroed by k_dir_to_lut, everything else written by the solver"""
+    import torch
+    from amico_amd import FreeWater, _capi, get_context, synthetic as S
+    ctx = get_context()
+    ht = htable500['htable']
+    sch = S.make_scheme(1, ((1000.0, 64),), seed=5)
+    m = FreeWater()
+    if mouse:
+        m.set(type='Mouse')
+    K = S.freewater_kernels(sch, htable500['dirs'], d_perps=m.d_perps, d_isos=m.d_isos)
+    y_h, d_h = S.freewater_signals(n, K, ht, sch, seed=6, snr=8.0)
+    y_h[:10] = 0.0; y_h[11] = np.nan; y_h[12, 3] = np.inf; y_h[n - 1] = np.nan
+    y_h[20:40] = np.abs(np.random.default_rng(1).normal(size=(20, y_h.shape[1])))
+    bad = [17, n // 2, n - 2]
+    d_h[bad] = np.nan
+    lut = _capi.upload_freewater(ctx, K, ht)
+    y = torch.from_numpy(y_h).cuda(); d = torch.from_numpy(d_h).cuda()
+    nm = 4 if mouse else 2
+    L = _capi.lib()
+    outs = []
+    for fill in (-7.25, 0.0):
+        est = torch.full((n, nm), fill, dtype=torch.float64, device='cuda')
+        rm = torch.full((n,), fill, dtype=torch.float64, device='cuda')
+        nr = torch.full((n,), fill, dtype=torch.float64, device='cuda')
+        yc = torch.full((n, y_h.shape[1]), fill, dtype=torch.float64, device='cuda')
+        rc = L.amx_freewater_fit_device(ctx._h, lut._h, y.data_ptr(), d.data_ptr(), n, 0.0, 1e-3, int(mouse), flags,
+                                        est.data_ptr(), rm.data_ptr(), nr.data_ptr(), yc.data_ptr(), None)
+        assert rc == 0
+        with pytest.raises(RuntimeError, match=r'index out of bounds.*\[voxel 17\]'):
+            ctx.sync()
+        outs.append((est.cpu().numpy(), rm.cpu().numpy(), nr.cpu().numpy(), yc.cpu().numpy()))
+    a, b = outs
+    ok = np.ones(n, bool); ok[bad] = False
+    assert not (a[0] == -7.25).any() and np.array_equal(a[0], b[0], equal_nan=True) and (a[0][bad] == 0.0).all()
+    if flags & 1:
+        assert np.array_equal(a[1][ok], b[1][ok], equal_nan=True) and not (a[1][ok] == -7.25).any()
+    if flags & 2:
+        assert np.array_equal(a[2][ok], b[2][ok], equal_nan=True) and not (a[2][ok] == -7.25).any()
+    if flags & 8:
+        assert np.array_equal(a[3][ok], b[3][ok], equal_nan=True) and not (a[3][ok] == -7.25).any()
+    lut.close()

@@ -36,7 +36,7 @@ def main():
         for k in kv:
             del os.environ[k]
         lut = _capi.upload_noddi(ctx, K, ht, sch.dwi_idx, False)
-        ctx.set_profiling(True)
+        ctx.set_profiling(os.environ.get('AB_PROFILING', '1') != '0')
         stream = torch.cuda.current_stream().cuda_stream
         for n in sizes:
             est = torch.zeros((n, 3), dtype=torch.float64, device=dev)
