@@ -223,8 +223,10 @@ class Context:
         self._progress_cb = PROGRESS_CB(lambda done, total, _u: fn(int(done), int(total))) if fn else PROGRESS_CB()
         self.check(lib().amx_set_progress(self._h, self._progress_cb, None))
 
-    def set_profiling(self, on=True):
-        self.check(lib().amx_set_profiling(self._h, int(bool(on))))
+    def set_profiling(self, on=True, only=None):
+        """HIP events around the kernel groups of every fit (amx_last_kernel_ms); only=w: the pair of group w alone (each event is a packet
+        of the stream: the full set costs a NODDI fit ~70 us)"""
+        self.check(lib().amx_set_profiling(self._h, (2 + int(only)) if (on and only is not None) else int(bool(on))))
 
     def last_kernel_ms(self, which=0):
         ms = C.c_float()

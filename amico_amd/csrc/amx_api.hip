@@ -727,7 +727,7 @@ int amx_selftest(amx_ctx *ctx, double *out512)
 int amx_set_profiling(amx_ctx *ctx, int enable)
 {
     if (!ctx) return AMX_E_BADARG;
-    ctx->profiling = enable != 0;
+    ctx->profiling = (enable >= 0 && enable <= 11) ? enable : 1;
     for (int k = 0; k < kEv; k++) ctx->ev_valid[k] = false;
     return AMX_OK;
 }
@@ -1388,8 +1388,8 @@ static int fit_host(amx_ctx *ctx, const T *y, const double *dirs, int64_t n_vox,
         for (hipEvent_t &e : ctx->hev) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     HIPCHK(ctx, hipStreamSynchronize(nullptr));                      // earlier default-stream work on these buffers
-    const bool was_profiling = ctx->profiling;
-    if (pipelined) ctx->profiling = false;
+    const int was_profiling = ctx->profiling;
+    if (pipelined) ctx->profiling = 0;
     // (a shard of a larger call -- amx_set_call_voxels: one of several contexts that share a fit -- takes the paths the whole call's size asks for,
     //  as the batches of one call do: every context settles its voxels with the arithmetic the single-context call would use)
     ctx->in_host_fit = true; ctx->host_total_vox = ctx->call_total_vox > n_vox ? ctx->call_total_vox : n_vox;

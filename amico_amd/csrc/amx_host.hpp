@@ -31,7 +31,7 @@ struct amx_ctx {
     DevBuf hy, hdirs, hest, hrmse, hnrmse, hextra;   // staging for the host-pointer entry points
     int *status_d = nullptr;       // ST_WORDS ints
     int *status_h = nullptr;       // pinned mirror (+16 words: copy of the misc counters)
-    bool profiling = false;
+    int profiling = 0;             // 0 off, 1 every event pair of a call, 2 + w: pair w only (amx_set_profiling)
     int64_t host_total_vox = 0;    // voxels of the whole host-buffer call while its batches are enqueued
     int64_t call_vox = 0;          // voxels of the call being enqueued (the whole host-buffer call for its batches): size-dependent path choices made below noddi_fit_dev
     int64_t call_total_vox = 0;    // amx_set_call_voxels: the host-buffer calls on this ctx are shards of a call of this many voxels (0: they are the call)
@@ -295,7 +295,8 @@ static inline bool amx_debug() { static int d = -1; if (d < 0) { const char *e =
 
 static inline void rec(amx_ctx *ctx, int k, hipStream_t s)
 {
-    if (ctx->profiling) { (void)hipEventRecord(ctx->ev[k], s); ctx->ev_valid[k] = true; }
+    // (an event in the stream is a packet of its own: ~5 us of a call's time each -- twenty of them 70 us of a 1.3 ms fit)
+    if (ctx->profiling == 1 || (ctx->profiling >= 2 && (k < 2 ? 0 : k / 2) == ctx->profiling - 2)) { (void)hipEventRecord(ctx->ev[k], s); ctx->ev_valid[k] = true; }
 }
 
 // defined in the per-model launch units (amx_noddi.hip, amx_fw.hip, amx_sandi.hip)

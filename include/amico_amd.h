@@ -339,7 +339,8 @@ int amx_lut_rotate_resample(amx_ctx *ctx, const float *zonal, int n_atoms, const
  * FreeWater/SANDI: 1 = the single solver kernel), 4 = the last amx_dti_directions_device / amx_prep_gather_device kernel,
  * 5..7 = NODDI kernels ahead of stage 1 / 2 / 3 (A'y on the matrix cores + seed solver + Gram-space certificate,
  * csrc/amx_seed.hpp; an error if seeds are off), 8 = k_nnls_seed<1> alone, 9 = k_lasso_seed alone.
- * Requires amx_set_profiling(1). */
+ * Requires amx_set_profiling(1) -- or amx_set_profiling(2 + which): only that pair of events is recorded (every recorded event is a
+ * packet of the stream, ~5 us of the call: the full set costs a NODDI fit ~70 us, which is why profiling is off by default). */
 int amx_set_profiling(amx_ctx *ctx, int enable);
 int amx_last_kernel_ms(amx_ctx *ctx, int which, float *out_ms);
 /* solver statistics of the last call: out[0]=voxels re-run with the large active-set
