@@ -1083,7 +1083,7 @@ static int czb_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, cons
     if ((rc = make_plan(ctx, n_vox, lut->ndirs, pl, false, 64, fast ? 2048 : 0))) return rc;
     clear_events(ctx);
     rec(ctx, 0, s);
-    if ((rc = enqueue_bucketing(ctx, lut, d_dirs, n_vox, pl, s))) return rc;
+    if ((rc = enqueue_bucketing(ctx, lut, d_dirs, n_vox, pl, s, kChunk, d_estimates, 3))) return rc;      // (no memset of the maps: tests/test_gpu_czb.py::test_czb_fit_writes_every_voxel)
     CzbArgs a;
     memset(&a, 0, sizeof a);
     a.c.tiles = lut->tiles; a.c.y = d_y; a.c.y32 = d_y32; a.c.perm = pl.perm; a.c.chunks = pl.chunks; a.c.n_chunks = pl.n_chunks;
@@ -1096,7 +1096,6 @@ static int czb_fit_dev(amx_ctx *ctx, const amx_lut *lut, const double *d_y, cons
         a.c.xdbg = ctx->dbg_x + (size_t)ctx->vox_base * lut->n_atoms;
     }
     a.est = d_estimates; a.rmse = (flags & AMX_F_RMSE) ? d_rmse : nullptr; a.nrmse = (flags & AMX_F_NRMSE) ? d_nrmse : nullptr;
-    HIPCHK(ctx, hipMemsetAsync(d_estimates, 0, (size_t)n_vox * 3 * sizeof(double), s));
     if (fast) { if (!(rc = amx_czb_prepare(ctx, lut, lambda2, s))) rc = amx_launch_czb_fast(ctx, lut, a, pl, s); }
     else rc = amx_launch_czb(ctx, a, pl, s);
     hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, s, (const int *)ctx->misc.p, ctx->status_d);

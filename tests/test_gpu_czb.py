@@ -127,3 +127,43 @@ def test_czb_without_a_ridge(czb_fix, htable500, lam2):
     assert x.min() >= 0.0 and gp < 1e-9 and gz < 1e-9, (gp, gz)
     assert ax < (1e-8 if lam2 == 0.0 else 1e-4), ax            # (a ridge of 1e-8 against singular values of ~1e-4: A x moves by ~1e-6)
     assert np.isfinite(est.cpu().numpy()).all()
+
+
+@pytest.mark.parametrize('lam2', [4.0, 1e-8])
+def test_czb_fit_writes_every_voxel(czb_fix, htable500, lam2):
+    """as test_noddi_fit_writes_every_voxel: the maps are not cleared before the fit (skipped voxels zeroed by k_dir_to_lut, every
+    other voxel written by the solver) -- default ridge (lane solver) and the thin-QR route"""
+    import torch
+    from amico_amd import _capi, get_context, synthetic as S
+    f = czb_fix
+    ht, K, ids = htable500['htable'], f['kernels'], f['lut_ids']
+    rng = np.random.default_rng(5)
+    d = S.random_unit_vectors(600000, rng)
+    d = d[np.isin(S.lut_indices(d, ht), ids)][:30000]
+    lut = S.lut_indices(d, ht)
+    n = len(d)
+    w = rng.dirichlet([2.0, 2.0, 1.0], n)
+    y = w[:, :1] * K['wmr'][rng.integers(K['wmr'].shape[0], size=n), lut].astype(np.float64) + \
+        w[:, 1:2] * K['wmh'][rng.integers(K['wmh'].shape[0], size=n), lut].astype(np.float64) + w[:, 2:] * K['iso'][0].astype(np.float64)
+    y = np.abs(y + rng.normal(scale=0.1, size=y.shape))
+    y[:10] = 0.0; y[11] = np.nan; y[12, 3] = np.inf; y[n - 1] = np.nan
+    y[20:60] = np.abs(rng.normal(size=(40, y.shape[1])))
+    bad = [17, n // 2, n - 2]
+    d[bad] = np.nan
+    ctx = get_context()
+    L = _capi.upload_czb(ctx, K, f['Rs'], ht)
+    yt, dt = torch.from_numpy(y).cuda(), torch.from_numpy(d).cuda()
+    lib = _capi.lib()
+    outs = []
+    for fill in (-7.25, 0.0):
+        est = torch.full((n, 3), fill, dtype=torch.float64, device='cuda')
+        rm = torch.full((n,), fill, dtype=torch.float64, device='cuda')
+        assert lib.amx_czb_fit_device(ctx._h, L._h, yt.data_ptr(), dt.data_ptr(), n, 0.0, lam2, _capi.F_RMSE, est.data_ptr(), rm.data_ptr(), None, None) == 0
+        with pytest.raises(RuntimeError, match=r'index out of bounds.*\[voxel 17\]'):
+            ctx.sync()
+        outs.append((est.cpu().numpy(), rm.cpu().numpy()))
+    (e1, r1), (e0, r0) = outs
+    ok = np.ones(n, bool); ok[bad] = False
+    assert not (e1 == -7.25).any() and np.array_equal(e1, e0, equal_nan=True) and (e1[bad] == 0.0).all()
+    assert np.array_equal(r1[ok], r0[ok], equal_nan=True) and not (r1[ok] == -7.25).any()
+    L.close()
