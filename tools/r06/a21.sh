@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs tools/r06/table_vm.patch applied: the tree keeps the row-major table; variants/tabrm = the same sources with -DAMX_TAB_VM=0)
 # the A'y table with voxel-major atom tiles against the row-major one (variants/tabrm): parity, fit times, per-kernel times, DRAM counters
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (AMX_DBG_GRAM0 is part of tools/r06/table_vm.patch, not of the tree)
 # experiment: how much of the NNLS certificates' time and DRAM traffic is the per-orientation Gram matrix missing the L2?  (AMX_DBG_GRAM0=1: all chunks read matrix 0)
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT

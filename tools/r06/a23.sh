@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs tools/r06/gcert_nw8.patch applied and `bash tools/build_variant.sh gc8 -DAMX_GCERT_NW=8`)
 # NNLS certificates with 8 wavefronts per workgroup, one workgroup per CU (variants/gc8: -DAMX_GCERT_NW=8): half as many orientations'
 # Gram matrices live per XCD -- do the G_PP gathers hit the L2 then?
 cd /tmp && export TMPDIR=/tmp

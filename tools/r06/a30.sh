@@ -1,4 +1,5 @@
 #!/bin/bash
+# (AMX_RESCUE_TILE_GLOBAL was a three-line knob for this run only -- `g.tile_in_lds = fits && !knob` in amx_launch_noddi_gcert --, not kept: profiles/r06_protocols_ab.txt)
 # the rescue pass without the tile staged in LDS (atoms of a support from the L2-resident tile): does it pay below 2 M voxels then?
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
