@@ -772,3 +772,37 @@ def test_freewater_fit_writes_every_voxel(htable500, n, mouse, flags):
     if flags & 8:
         assert np.array_equal(a[3][ok], b[3][ok], equal_nan=True) and not (a[3][ok] == -7.25).any()
     lut.close()
+
+
+def test_profiling_levels_record_only_what_is_asked(htable500):
+    """amx_set_profiling: 0 = no events in the stream (the default: every event is a packet of its own), 1 = every pair of the fit,
+    2 + w = pair w alone -- amx_last_kernel_ms of a pair that was not recorded is an error, not an old call's time"""
+    import torch
+    from amico_amd import _capi, get_context, synthetic as S
+    ctx = get_context()
+    ht = htable500['htable']
+    sch = S.make_scheme(seed=2)
+    K = S.noddi_kernels(sch, htable500['dirs'])
+    y_h, d_h = S.noddi_signals(60_000, K, ht, sch, seed=4)
+    lut = _capi.upload_noddi(ctx, K, ht, sch.dwi_idx)
+    y = torch.from_numpy(y_h).cuda(); d = torch.from_numpy(d_h).cuda()
+    try:
+        ctx.set_profiling(True)
+        ref = _capi.noddi_fit_device(ctx, lut, y, d, 0.5, 1e-3, 3)[0].clone(); ctx.sync()
+        all_ms, seed_ms = ctx.last_kernel_ms(0), ctx.last_kernel_ms(8)
+        assert 0.0 < seed_ms < all_ms
+        ctx.set_profiling(True, only=8)
+        est = _capi.noddi_fit_device(ctx, lut, y, d, 0.5, 1e-3, 3)[0]; ctx.sync()
+        assert torch.equal(est, ref)
+        assert 0.5 * seed_ms < ctx.last_kernel_ms(8) < 2.0 * seed_ms
+        for w in (0, 1, 5, 9):
+            with pytest.raises(ValueError, match='no profiled call'):
+                ctx.last_kernel_ms(w)
+        ctx.set_profiling(False)
+        est = _capi.noddi_fit_device(ctx, lut, y, d, 0.5, 1e-3, 3)[0]; ctx.sync()
+        assert torch.equal(est, ref)
+        with pytest.raises(ValueError, match='no profiled call'):
+            ctx.last_kernel_ms(8)
+    finally:
+        ctx.set_profiling(False)
+        lut.close()
