@@ -806,3 +806,29 @@ def test_profiling_levels_record_only_what_is_asked(htable500):
     finally:
         ctx.set_profiling(False)
         lut.close()
+
+
+@pytest.mark.parametrize('n', [500, 40_000])
+def test_noddi_fit_with_no_valid_direction_at_all(htable500, n):
+    """every direction out of bounds: no orientation has a voxel, no chunk exists -- the call reports voxel 0 and leaves zero maps (both the
+    wavefront-per-voxel path and the seeded chain walk an empty plan)"""
+    import torch
+    from amico_amd import _capi, get_context, synthetic as S
+    ctx = get_context()
+    ht = htable500['htable']
+    sch = S.make_scheme(seed=3)
+    K = S.noddi_kernels(sch, htable500['dirs'])
+    y_h, d_h = S.noddi_signals(n, K, ht, sch, seed=8)
+    d_h[:] = np.nan
+    lut = _capi.upload_noddi(ctx, K, ht, sch.dwi_idx)
+    y = torch.from_numpy(y_h).cuda(); d = torch.from_numpy(d_h).cuda()
+    est = torch.full((n, 3), -7.25, dtype=torch.float64, device='cuda')
+    assert _capi.lib().amx_noddi_fit_device(ctx._h, lut._h, y.data_ptr(), d.data_ptr(), n, 0.5, 1e-3, 0, est.data_ptr(), None, None, None, None) == 0
+    with pytest.raises(RuntimeError, match=r'index out of bounds.*\[voxel 0\]'):
+        ctx.sync()
+    assert (est == 0.0).all()
+    # ... and the context fits the next call as if nothing had happened
+    d_ok = torch.from_numpy(S.noddi_signals(n, K, ht, sch, seed=8)[1]).cuda()
+    out = _capi.noddi_fit_device(ctx, lut, y, d_ok, 0.5, 1e-3, 3)[0]; ctx.sync()
+    assert torch.isfinite(out).all()
+    lut.close()
